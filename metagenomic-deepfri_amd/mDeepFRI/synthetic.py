@@ -1,0 +1,93 @@
+"""Seeded synthetic inputs for the hot path (SURVEY.md section 8d / BASELINE.md section 3).
+
+Sequences are uniform over the 20 standard amino acids (the alphabet of reference
+benchmark/time_benchmark_cpu.py:44-46), C-alpha traces are 3.8 A random walks rounded to 3 decimals
+(PDB precision), alignments are the query mutated with random indels, weights are Glorot-uniform with
+the topology of the shipped models (`GraphConv_gcd_512-512-512_fcd_1024`, reference
+mDeepFRI/__init__.py:73,78).  There is no network for real structures or checkpoints.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+AA20 = "ACDEFGHIKLMNPQRSTVWY"
+# number of GO terms of the v1.0 MERGED heads; always read T from the weights in real use
+GO_TERMS = {"mf": 489, "bp": 1943, "cc": 320, "ec": 538}
+
+
+def random_sequence(rng: np.random.Generator, length: int) -> str:
+    idx = rng.integers(0, len(AA20), size=length)
+    return "".join(AA20[i] for i in idx)
+
+
+def random_walk_coords(rng: np.random.Generator, length: int, step: float = 3.8) -> np.ndarray:
+    """(L,3) float32 C-alpha trace: unit directions * 3.8 A, cumulative sum, rounded to 3 decimals."""
+    v = rng.standard_normal((length, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True) + 1e-12
+    xyz = np.cumsum(v * step, axis=0)
+    return np.round(xyz, 3).astype(np.float32)
+
+
+def mutate_alignment(rng: np.random.Generator, query: str, indel_rate: float = 0.05):
+    """Return (gapped_query, gapped_target, target_length) for a query aligned to a synthetic target.
+
+    Each query residue is, with probability `indel_rate`, an insertion (target gap '-'); before each
+    query residue, with probability `indel_rate`, the target has an extra residue (query gap '-').
+    """
+    q_cols, t_cols = [], []
+    lt = 0
+    for ch in query:
+        if rng.random() < indel_rate:  # extra target residue: gap in the query
+            q_cols.append("-")
+            t_cols.append(AA20[rng.integers(0, 20)])
+            lt += 1
+        if rng.random() < indel_rate:  # query insertion: gap in the target
+            q_cols.append(ch)
+            t_cols.append("-")
+        else:
+            q_cols.append(ch)
+            t_cols.append(ch)
+            lt += 1
+    return "".join(q_cols), "".join(t_cols), lt
+
+
+def glorot_uniform(rng: np.random.Generator, fan_in: int, fan_out: int) -> np.ndarray:
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=(fan_in, fan_out)).astype(np.float32)
+
+
+def glorot_gcn_weights(seed: int = 0, n_terms: int = 489, embed: int = 1024, gc_dims=(512, 512, 512),
+                       fc_dim: int = 1024, fc_gain: float = 0.1) -> dict:
+    """Random-init DeepFRI GCN weights (fp32).  Keys are the ones mDeepFRI.weights reads and writes.
+
+    `fc_gain` scales the Glorot draw of W_fc: the sum-pooled features grow linearly with the protein
+    length, and with untrained unit-gain weights the pair-softmax saturates to exactly 0/1 beyond
+    L~256, which would make an absolute 1e-4 score check vacuous.  0.1 keeps |logit| ~ 2-8 for
+    L = 256-1024, the regime trained heads operate in."""
+    rng = np.random.default_rng(seed)
+    w = {"W_aa": glorot_uniform(rng, 26, embed)}
+    prev = embed
+    for k, c in enumerate(gc_dims, start=1):
+        w[f"W_gc{k}"] = glorot_uniform(rng, prev, c)
+        prev = c
+    w["W_fc"] = (glorot_uniform(rng, int(sum(gc_dims)), fc_dim) * np.float32(fc_gain)).astype(np.float32)
+    w["b_fc"] = rng.uniform(-0.05, 0.05, size=(fc_dim,)).astype(np.float32)
+    w["W_out"] = glorot_uniform(rng, fc_dim, 2 * n_terms)
+    w["b_out"] = rng.uniform(-0.05, 0.05, size=(2 * n_terms,)).astype(np.float32)
+    return w
+
+
+def synthetic_proteins(seed: int, count: int, length, indel_rate: float = 0.0):
+    """List of dicts {id, seq, coords, q_aln, t_aln}.  `length` is an int or a (lo, hi) inclusive range."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(count):
+        L = int(length) if np.isscalar(length) else int(rng.integers(length[0], length[1] + 1))
+        seq = random_sequence(rng, L)
+        if indel_rate > 0:
+            q_aln, t_aln, lt = mutate_alignment(rng, seq, indel_rate)
+        else:
+            q_aln, t_aln, lt = seq, seq, L
+        coords = random_walk_coords(rng, lt)
+        out.append({"id": f"syn{seed}_{i}", "seq": seq, "coords": coords, "q_aln": q_aln, "t_aln": t_aln})
+    return out

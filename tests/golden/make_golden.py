@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference kernels (oracle/_ref, built from
+/root/reference/mDeepFRI/contact_map_utils.pyx by oracle/build_ref.py).
+
+Run in the dev container only:   python oracle/build_ref.py && python tests/golden/make_golden.py
+The fixtures are data (inputs + expected outputs); no reference source is stored.
+
+cmap_golden.npz    -- a1/a3 (+ chained a2/a4) cases: reference KATs, the three align cases whose
+                      expectation in the reference's test file differs from what the .pyx returns
+                      (the .pyx output is the oracle), edge cases, randomised
+                      chains.  Small cases store full arrays; L>=512 store inputs + sha256 of outputs.
+gcn_golden.npz     -- regression anchors for the GCN forward.  *Parity unpinned*: produced by
+                      oracle/gcn_oracle.py in float64 (see its header), NOT by the reference's ONNX path,
+                      which cannot run here (no onnxruntime, no .onnx files).
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "metagenomic-deepfri_amd"))
+
+import build_ref  # noqa: E402
+import gcn_oracle  # noqa: E402
+from mDeepFRI import synthetic  # noqa: E402
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def ref_chain(ref, coords, q, t, thr, gen):
+    """bio_utils.py:348-385 with calculate_contact_map(mode='sparse') (bio_utils.py:196-227), using the
+    compiled reference kernels for both native calls."""
+    D = ref.pairwise_sqeuclidean(coords)
+    cm = (D < thr**2).astype(np.int32)
+    sparse = np.argwhere(cm == 1).astype(np.int32)
+    out = ref.align_contact_map(q, t, sparse, gen)
+    return D, cm, sparse, out
+
+
+def main():
+    ref = build_ref.load()
+    if ref is None:
+        build_ref.build()
+        ref = build_ref.load()
+    assert ref is not None, "reference build unavailable"
+
+    g = {}
+    names = []
+
+    def add_align(name, q, t, pairs, gen):
+        pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+        out = ref.align_contact_map(q, t, pairs, gen)
+        g[f"align/{name}/q"] = np.frombuffer(q.encode(), dtype=np.uint8)
+        g[f"align/{name}/t"] = np.frombuffer(t.encode(), dtype=np.uint8)
+        g[f"align/{name}/pairs"] = pairs
+        g[f"align/{name}/gen"] = np.int32(gen)
+        g[f"align/{name}/out"] = out
+        names.append(f"align/{name}")
+
+    # --- reference KAT: mDeepFRI/tests/test_contact_map_utils.py:15-25
+    np.random.seed(42)
+    X = np.random.rand(3, 3).astype(np.float32)
+    g["pairwise/kat_seed42/X"] = X
+    g["pairwise/kat_seed42/D"] = ref.pairwise_sqeuclidean(X)
+    g["pairwise/kat_seed42/D_testfile"] = np.array(
+        [[0, 1.01354558, 0.12442072], [1.01354558, 0, 0.99467713], [0.12442072, 0.99467713, 0]], dtype=np.float32)
+    # --- collinear KAT: mDeepFRI/tests/test_conctact_map.py:36-41
+    Xc = np.array([[0, 0, 0], [5, 0, 0], [10, 0, 0]], dtype=np.float32)
+    g["pairwise/collinear/X"] = Xc
+    g["pairwise/collinear/D"] = ref.pairwise_sqeuclidean(Xc)
+    g["pairwise/collinear/cmap6"] = (g["pairwise/collinear/D"] < 6.0**2).astype(np.int32)
+    # generic m (not only 3 columns) and degenerate sizes
+    rng = np.random.default_rng(7)
+    for n, m in [(0, 3), (1, 3), (2, 1), (5, 7), (65, 3), (33, 16)]:
+        Xg = (rng.standard_normal((n, m)) * 10).astype(np.float32)
+        g[f"pairwise/gen_{n}x{m}/X"] = Xg
+        g[f"pairwise/gen_{n}x{m}/D"] = ref.pairwise_sqeuclidean(Xg)
+
+    # --- align cases of mDeepFRI/tests/test_contact_map_utils.py:28-110 (actual .pyx output) ...
+    add_align("identity_onedir", "AB", "AB", [[0, 1]], 2)
+    add_align("gap_in_query_onedir", "A-C", "ABC", [[0, 1], [1, 2], [0, 2]], 2)
+    add_align("gap_in_target_onedir", "ABC", "A-C", [[0, 1]], 1)
+    # ... and the same with symmetrised target contacts (the pipeline's argwhere style) -> test-file expectations
+    add_align("identity_sym", "AB", "AB", [[0, 1], [1, 0]], 2)
+    add_align("gap_in_query_sym", "A-C", "ABC", [[0, 1], [1, 0], [1, 2], [2, 1], [0, 2], [2, 0]], 2)
+    add_align("gap_in_target_sym", "ABC", "A-C", [[0, 1], [1, 0]], 1)
+    N = 100
+    add_align("stress100", "A" * N, "A" * N, [[i, i + 1] for i in range(N - 1)], 2)
+    # --- edge cases (SURVEY.md section 8c iii)
+    add_align("empty_contacts", "ACDE", "ACDE", np.zeros((0, 2), np.int32), 2)
+    add_align("out_of_range_dropped", "ACD", "ACD", [[0, 5], [7, 1], [-1, 2], [2, -3], [1, 2]], 2)
+    add_align("all_query_gaps", "---", "ACD", [[0, 1], [1, 2]], 2)
+    add_align("all_target_gaps", "ACD", "---", [[0, 1]], 2)
+    add_align("double_gap_column", "A--C", "A-BC", [[0, 1], [1, 2], [0, 2], [2, 0]], 2)
+    add_align("empty_alignment", "", "", np.zeros((0, 2), np.int32), 2)
+    for gen in (0, 1, 2, 5):
+        add_align(f"gen{gen}_ends", "MKVLAAGIC", "-KV--AG--", [[0, 1], [1, 0], [0, 3], [3, 0], [2, 3], [3, 2]], gen)
+    add_align("query_longer", "ACDEFGHIK", "AC--FG-IK", [[0, 1], [1, 2], [2, 3], [3, 4], [4, 5], [0, 5], [5, 0]], 2)
+    add_align("query_shorter", "AC--FG-IK", "ACDEFGHIK", [[i, j] for i in range(9) for j in range(9) if abs(i - j) <= 2], 2)
+    add_align("target_longer_than_map", "ACD", "ACD", [[0, 2], [2, 0], [3, 1], [1, 3]], 2)
+
+    # --- randomised chains: coords -> D -> cmap -> sparse -> aligned (bio_utils.py:348-385)
+    chain = []
+    for L in (1, 2, 63, 64, 65, 256, 512, 1024):
+        for rate in (0.0, 0.05, 0.2):
+            rng = np.random.default_rng(1000 + L * 7 + int(rate * 100))
+            seq = synthetic.random_sequence(rng, L)
+            q, t, lt = synthetic.mutate_alignment(rng, seq, rate) if rate > 0 else (seq, seq, L)
+            coords = synthetic.random_walk_coords(rng, max(lt, 0)).reshape(-1, 3)
+            for gen in ((2,) if L > 65 else (0, 2)):
+                D, cm, sparse, out = ref_chain(ref, coords, q, t, 6.0, gen)
+                name = f"chain/L{L}_r{int(rate*100)}_g{gen}"
+                g[f"{name}/coords"] = coords
+                g[f"{name}/q"] = np.frombuffer(q.encode(), dtype=np.uint8)
+                g[f"{name}/t"] = np.frombuffer(t.encode(), dtype=np.uint8)
+                g[f"{name}/gen"] = np.int32(gen)
+                g[f"{name}/nnz_target"] = np.int64(sparse.shape[0])
+                g[f"{name}/nnz_out"] = np.int64(out.sum())
+                g[f"{name}/sha_D"] = np.frombuffer(sha(D).encode(), dtype=np.uint8)
+                g[f"{name}/sha_sparse"] = np.frombuffer(sha(sparse).encode(), dtype=np.uint8)
+                g[f"{name}/sha_out"] = np.frombuffer(sha(out).encode(), dtype=np.uint8)
+                if L <= 65:
+                    g[f"{name}/D"] = D
+                    g[f"{name}/sparse"] = sparse
+                    g[f"{name}/out"] = out
+                elif L <= 256:
+                    g[f"{name}/out_bits"] = np.packbits(out.astype(np.uint8), axis=1)
+                chain.append(name)
+    g["index/align"] = np.array(names)
+    g["index/chain"] = np.array(chain)
+    np.savez_compressed(os.path.join(HERE, "cmap_golden.npz"), **g)
+    print("cmap_golden.npz:", len(g), "arrays,", os.path.getsize(os.path.join(HERE, "cmap_golden.npz")), "bytes")
+
+    # --- GCN regression anchors (float64 oracle; parity unpinned, see header)
+    gg = {}
+    cases = []
+    for mode, wseed in (("mf", 0), ("cc", 2)):
+        T = synthetic.GO_TERMS[mode]
+        w = synthetic.glorot_gcn_weights(seed=wseed, n_terms=T)
+        for L, style in ((37, "pipeline"), (128, "pipeline"), (200, "dense01"), (256, "pipeline")):
+            rng = np.random.default_rng(5000 + L)
+            seq = synthetic.random_sequence(rng, L)
+            if style == "pipeline":
+                coords = synthetic.random_walk_coords(rng, L)
+                cm = ref_chain(ref, coords, seq, seq, 6.0, 2)[3]
+            else:  # the reference's own recipe, weight_convert/random_100_protein_prediction.ipynb cell 1
+                cm = rng.integers(0, 2, size=(L, L)).astype(np.int32)
+            y64 = gcn_oracle.gcn_forward(w, seq, cm, dtype=np.float64)
+            name = f"gcn/{mode}_L{L}_{style}"
+            gg[f"{name}/seq"] = np.frombuffer(seq.encode(), dtype=np.uint8)
+            gg[f"{name}/cmap_bits"] = np.packbits(cm.astype(np.uint8), axis=1)
+            gg[f"{name}/wseed"] = np.int32(wseed)
+            gg[f"{name}/n_terms"] = np.int32(T)
+            gg[f"{name}/y64"] = y64
+            cases.append(name)
+    gg["index/gcn"] = np.array(cases)
+    np.savez_compressed(os.path.join(HERE, "gcn_golden.npz"), **gg)
+    print("gcn_golden.npz:", len(gg), "arrays,", os.path.getsize(os.path.join(HERE, "gcn_golden.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()
