@@ -1,0 +1,208 @@
+/*
+ * mdfri.h -- C ABI of libmdfri_hip.so: the MI355X (gfx950) implementation of Metagenomic-DeepFRI's
+ * per-protein inference hot path (contact-map build/align + DeepFRI GCN forward).
+ *
+ * This is the drop-in boundary.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference repository bioinf-mcb/Metagenomic-DeepFRI, v1.1.10).  The reference
+ * binds native code through Cython `cpdef` functions; INTEGRATION.md shows the `cdef extern` stub a
+ * maintainer adds to contact_map_utils.pyx / predict.pyx to call these symbols instead.
+ *
+ * Conventions
+ *   - plain C types only: pointers + sizes, no torch / numpy types.
+ *   - return value: 0 = success, negative = MDF_E* code; mdf_last_error() gives a thread-local message.
+ *   - the caller allocates every output; nothing is retained past return (async entry points: until the
+ *     stream is synchronised).
+ *   - "host" entry points take host pointers and do H2D / kernel / D2H on the current device
+ *     (they are the per-call API of the reference, which hands NumPy arrays across);
+ *     "dev" entry points take device pointers and a hipStream_t (passed as void*), enqueue work and
+ *     return without synchronising: they are the batched counterpart the reference lacks.
+ *   - there is NO CPU fallback: without a GPU every compute entry point fails with MDF_ENODEVICE.
+ */
+#ifndef MDFRI_H
+#define MDFRI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDF_OK 0
+#define MDF_EINVAL (-1)     /* bad argument (NULL pointer, negative size, unsupported dimension)  */
+#define MDF_ENODEVICE (-2)  /* no HIP device / HIP runtime error                                   */
+#define MDF_ENOMEM (-3)     /* allocation failed                                                   */
+#define MDF_EBADCHAR (-4)   /* residue letter outside the 26-letter alphabet (see mdf_seq2onehot)  */
+#define MDF_ECAPACITY (-5)  /* caller-provided capacity too small (sparse outputs, CSR, workspace) */
+#define MDF_EIO (-6)        /* model file unreadable / malformed                                   */
+
+const char *mdf_last_error(void);
+const char *mdf_version(void);
+/* Number of visible HIP devices (0 without a GPU; never fails). */
+int mdf_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-call API, host buffers.  Replaces the Cython functions one for one.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* mDeepFRI/contact_map_utils.pyx:17-37  pairwise_sqeuclidean(float[:, ::1] X, int threads=1)
+ * X: (n,m) C-contiguous f32.  D: (n,n) f32, D[i][j] = sum_k (X[i][k]-X[j][k])^2 accumulated in f32 in
+ * ascending k with separately rounded multiply and add (the reference build has no FMA contraction);
+ * diagonal exactly 0.  Bit-exact with the reference.  `threads` is accepted and ignored. */
+int mdf_pairwise_sqeuclidean_f32(const float *X, int64_t n, int64_t m, float *D, int threads);
+
+/* mDeepFRI/contact_map.py:64-75  DistanceMap.calculate_contacts  /  mDeepFRI/bio_utils.py:220
+ * out[e] = (D[e] < thr) ? 1 : 0 for `count` elements; thr is the already squared threshold as f32
+ * (NumPy>=2 compares an f32 array with a Python float in f32). */
+int mdf_threshold_lt_i32(const float *D, int64_t count, float thr, int32_t *out);
+
+/* mDeepFRI/contact_map.py:88-95  ContactMap.sparsify  /  mDeepFRI/bio_utils.py:222-223
+ * np.argwhere(cmap == 1).astype(int32): row-major sorted (N,2) index pairs of an (n,n) int32 matrix.
+ * Writes at most `capacity` pairs and stores N in *n_pairs; returns MDF_ECAPACITY if N > capacity
+ * (call again with a larger buffer; *n_pairs is valid). */
+int mdf_argwhere_eq1_i32(const int32_t *cmap, int64_t n, int32_t *pairs, int64_t capacity, int64_t *n_pairs);
+
+/* mDeepFRI/bio_utils.py:196-227  calculate_contact_map(coordinates, threshold, "sqeuclidean", mode)
+ * coords (n,3) f32 -> fused on device: distances (never materialised on the host), strict `< threshold^2`.
+ * Exactly one of cmap (n*n int32, mode="matrix") or pairs (mode="sparse", as mdf_argwhere_eq1_i32) is non-NULL. */
+int mdf_calculate_contact_map(const float *coords, int64_t n, double threshold, int32_t *cmap,
+                              int32_t *pairs, int64_t capacity, int64_t *n_pairs);
+
+/* Query length of an alignment = number of non-gap ('-') bytes of q (mDeepFRI/contact_map_utils.pyx:64-80:
+ * final query_idx).  Host-side shape helper so that the caller can size `out`. */
+int mdf_align_len(const char *q_aln, const char *t_aln, int64_t La, int64_t *Lq);
+
+/* mDeepFRI/contact_map_utils.pyx:44-117  align_contact_map(query_alignment, target_alignment,
+ *     sparse_target_contact_map, generated_contacts=2, threads=1)
+ * q_aln/t_aln: La ASCII bytes each; pairs: (N,2) int32 target contacts (any order, may be one-directional,
+ * out-of-range entries are dropped as in the reference); out: (Lq,Lq) int32.  Bit-exact with the reference. */
+int mdf_align_contact_map(const char *q_aln, const char *t_aln, int64_t La, const int32_t *pairs, int64_t N,
+                          int generated_contacts, int32_t *out, int threads);
+
+/* mDeepFRI/bio_utils.py:348-385  build_align_contact_map(alignment, threshold=6, generated_contacts=2)
+ * Fused coords (Lt,3) + alignment -> (Lq,Lq) int32 without the (Lt,Lt) distance matrix or the pair list. */
+int mdf_build_align_contact_map(const float *coords, int64_t Lt, const char *q_aln, const char *t_aln,
+                                int64_t La, double threshold, int generated_contacts, int32_t *out);
+
+/* mDeepFRI/predict.pyx:17-48  seq2onehot(str seq)
+ * out: (L,26) f32 one-hot in the alphabet order "-DGULNTKHYWCPVSOIEFXQABZRM" (predict.pyx:26).
+ * On an invalid byte returns MDF_EBADCHAR and stores its index in *bad_idx (the binding raises
+ * ValueError(f"Invalid character in sequence: {seq[bad_idx]}") as predict.pyx:45-46 does). */
+int mdf_seq2onehot(const char *seq, int64_t L, float *out, int64_t *bad_idx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Model (replaces the onnxruntime.InferenceSession held by mDeepFRI/predict.pyx:50-73 Predictor)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct mdf_model mdf_model;
+
+/* DeepFRI GCN weights, host pointers, fp32, row-major, Keras orientation (in_features x out_features).
+ * Topology: AA_embedding Dense(26->embed, no bias) + relu; n_gc GraphConv layers (no bias, elu);
+ * sum pooling of the concatenated GraphConv outputs; Dense(sum(gc_dims)->fc_dim, relu);
+ * FuncPredictor Dense(fc_dim->2*n_terms) + softmax over pairs (see oracle/gcn_oracle.py). */
+typedef struct {
+    int32_t embed;        /* 1024 in the shipped models */
+    int32_t n_gc;         /* number of GraphConv layers, 1..3 */
+    int32_t gc_dims[3];   /* 512,512,512 */
+    int32_t fc_dim;       /* 1024 */
+    int32_t n_terms;      /* T: GO terms / EC numbers of this head */
+    const float *W_aa;    /* (26, embed) */
+    const float *W_gc[3]; /* (embed, gc0), (gc0, gc1), (gc1, gc2) */
+    const float *W_fc;    /* (sum gc_dims, fc_dim) */
+    const float *b_fc;    /* (fc_dim) */
+    const float *W_out;   /* (fc_dim, 2*n_terms) */
+    const float *b_out;   /* (2*n_terms) */
+} mdf_gcn_weights;
+
+/* Upload weights to `device` and pre-pack them (transposed GEMM operands, folded embedding table). */
+int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out);
+/* Load a `.mdfw` container (format: metagenomic-deepfri_amd/mDeepFRI/weights.py). */
+int mdf_model_load(const char *path, int device, mdf_model **out);
+void mdf_model_free(mdf_model *m);
+int mdf_model_num_terms(const mdf_model *m);
+int mdf_model_feature_dim(const mdf_model *m); /* sum(gc_dims): width of the pooled feature vector */
+int mdf_model_device(const mdf_model *m);
+
+/* mDeepFRI/predict.pyx:75-102  Predictor.forward_pass(seqres, cmap)  -- GCN branch, one protein, host buffers.
+ * seq: L ASCII residues; cmap: (L,L) C-contiguous, dtype by cmap_dtype (MDF_DT_*), cast to f32 as predict.pyx:88.
+ * scores: (T) f32 = softmax(...)[:, 0] as predict.pyx:100.  On a bad residue: MDF_EBADCHAR + *bad_idx. */
+#define MDF_DT_I32 0
+#define MDF_DT_F32 1
+#define MDF_DT_I64 2
+#define MDF_DT_F64 3
+#define MDF_DT_U8 4
+int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *cmap, int cmap_dtype,
+                         float *scores, int64_t *bad_idx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched device API (the counterpart of pipeline.py:476-481 Pool.map(build_align_contact_map) and
+ * pipeline.py:292-319 _run_prediction_loop, for B proteins at once).
+ *
+ * Residue-row layout: protein p owns rows [row_off[p], row_off[p]+Lq[p]) of every per-residue array;
+ * row_off[p] is a multiple of 32 and row_off[B] (= R, total rows) a multiple of 128; rows between
+ * Lq[p] and the next protein are padding (kept zero).  Use mdf_layout_rows() to build row_off.
+ * All descriptor arrays are int32 on the device.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Host helper: row_off[0..B] from Lq[0..B-1] as specified above.  Returns R (total rows) or a negative code. */
+int64_t mdf_layout_rows(const int32_t *Lq, int32_t B, int32_t *row_off);
+
+/* Residue letters -> alphabet index per row (the sparse form of seq2onehot, predict.pyx:17-48).
+ * seqs: packed query sequences, protein p at bytes [seq_off[p], seq_off[p]+Lq[p]); seq_idx: (R) uint8, 255 on
+ * padding rows.  *bad (device int32[2], zero-initialised by the caller) receives {protein+1, position} of the
+ * first invalid byte seen (any one of them if several). */
+int mdf_seq_encode_dev(const char *seqs, const int32_t *seq_off, const int32_t *Lq, const int32_t *row_off,
+                       int32_t B, int64_t R, uint8_t *seq_idx, int32_t *bad, void *stream);
+
+/* Fused contact-map stage for B proteins: C-alpha coords + gapped alignments -> normalised adjacency in CSR,
+ * i.e. bio_utils.py:348-385 (a1+a2+a3) followed by GraphConv's normalisation
+ *     A' = A - diag(A) + I,  d = 1/(1e-6 + sqrt(rowsum A')),  val[i][j] = (d[i]*A'[i][j])*d[j]
+ * coords: packed (sum Lt,3) f32, protein p at residues [coord_off[p], coord_off[p+1]);
+ * q_aln/t_aln: packed alignment bytes, protein p at [aln_off[p], aln_off[p+1]).
+ * Outputs: rowptr (R+1) int32, colidx/val (nnz_cap) with colidx as GLOBAL row numbers.
+ * status: device int32[4], zero-initialised by the caller: [0] != 0 -> CSR overflow (needed nnz in [1]).
+ * workspace: mdf_cmap_workspace_bytes(B, R) bytes of device scratch. */
+size_t mdf_cmap_workspace_bytes(int32_t B, int64_t R);
+int mdf_cmap_csr_dev(const float *coords, const int32_t *coord_off, const char *q_aln, const char *t_aln,
+                     const int32_t *aln_off, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                     double threshold, int generated_contacts, int32_t *rowptr, int32_t *colidx, float *val,
+                     int64_t nnz_cap, int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same stage, reference output format: out[p] = (Lq[p],Lq[p]) int32 at element offset out_off[p] (int64, device).
+ * The batched build_align_contact_map; bit-exact with the reference per protein. */
+int mdf_cmap_dense_dev(const float *coords, const int32_t *coord_off, const char *q_aln, const char *t_aln,
+                       const int32_t *aln_off, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                       double threshold, int generated_contacts, int32_t *out, const int64_t *out_off,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+/* Dense contact maps (what forward_pass receives, predict.pyx:82-90) -> the same normalised CSR.
+ * cmaps: protein p is an (Lq[p],Lq[p]) matrix of cmap_dtype at element offset cmap_off[p] (int64, device). */
+int mdf_dense_to_csr_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_off, const int32_t *Lq,
+                         const int32_t *row_off, int32_t B, int64_t R, int32_t *rowptr, int32_t *colidx,
+                         float *val, int64_t nnz_cap, int32_t *status, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/* GraphConv stack + sum pooling for the rows of a batch:  pooled[p] = sum_rows concat(H1,H2,H3)  (B, feature_dim).
+ * workspace: mdf_gcn_workspace_bytes(model, R) bytes. */
+size_t mdf_gcn_workspace_bytes(const mdf_model *m, int64_t R);
+int mdf_gcn_embed_pool_dev(mdf_model *m, const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx,
+                           const float *val, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                           float *pooled, void *workspace, size_t workspace_bytes, void *stream);
+
+/* GO head for B pooled vectors: relu(g W_fc + b_fc) W_out + b_out -> pair softmax -> channel 0 (predict.pyx:100).
+ * scores: (B, T) f32.  logits (optional, may be NULL): (B, 2T) pre-softmax, for tolerance studies.
+ * workspace: mdf_head_workspace_bytes(model, B). */
+size_t mdf_head_workspace_bytes(const mdf_model *m, int32_t B);
+int mdf_gcn_head_dev(mdf_model *m, const float *pooled, int32_t B, float *scores, float *logits,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* Timing hook for bench.py: when enabled, the library brackets every launch of the named kernel class with
+ * hipEvents on the stream it is launched on and accumulates count and milliseconds (read after a sync).
+ * kernel: "ax" (A.X aggregation), "gemm" (H.W fp32 MFMA), "cmap" (fused contact map), "head". */
+int mdf_timing_enable(int on);
+int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms);
+int mdf_timing_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDFRI_H */

@@ -1,0 +1,963 @@
+// cmap.hip -- contact-map stage of the hot path on gfx950: pairwise squared distances, thresholding,
+// argwhere, alignment projection, and the fused batched coords+alignment -> {CSR | dense int32} kernels.
+//
+// Reference semantics (bit-exact, checked against oracle/cmap_oracle.c and tests/golden):
+//   mDeepFRI/contact_map_utils.pyx:17-37   pairwise_sqeuclidean
+//   mDeepFRI/contact_map_utils.pyx:44-117  align_contact_map
+//   mDeepFRI/bio_utils.py:196-227,348-385  calculate_contact_map / build_align_contact_map
+//
+// All of this is HBM/latency-bound integer and compare work: no LDS tiling tricks, no MFMA.  What matters
+// is coalesced row stores (the (L,L) int32 API output is the dominant byte stream), wave-level ballots
+// instead of atomics, and never materialising the (Lt,Lt) distance matrix in the fused path.
+//
+// Floating point: distances must reproduce the reference's x86-64 build, which has no FMA contraction
+// (setup.py:241-242: -O3, no -march).  This file is compiled with -ffp-contract=off and additionally
+// pins the pragma below; tests check the emitted bit patterns.
+#include <algorithm>
+
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace mdf {
+
+constexpr int GAP = 45;  // '-'
+
+// ------------------------------------------------------------------------------------------------------------------
+// a1: pairwise_sqeuclidean.  64x64 output tiles, 256 threads: thread (tx, ty) owns column tx and rows ty, ty+4, ...
+// ------------------------------------------------------------------------------------------------------------------
+template <bool M3>
+__global__ __launch_bounds__(256) void k_pairwise_sqeuclidean(const float *__restrict__ X, int64_t n, int64_t m,
+                                                              float *__restrict__ D)
+{
+    const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const int64_t i0 = (int64_t)blockIdx.y * 64;
+    if (j >= n) return;
+    if (M3) {
+        const float xj = X[j * 3 + 0], yj = X[j * 3 + 1], zj = X[j * 3 + 2];
+        for (int r = threadIdx.y; r < 64; r += 4) {
+            const int64_t i = i0 + r;
+            if (i >= n) break;
+            // reference order: d = 0; d = d + dx*dx; d = d + dy*dy; d = d + dz*dz  (0 + x == x exactly)
+            const float dx = X[i * 3 + 0] - xj, dy = X[i * 3 + 1] - yj, dz = X[i * 3 + 2] - zj;
+            float d = dx * dx;
+            d = d + dy * dy;
+            d = d + dz * dz;
+            D[i * n + j] = (i == j) ? 0.0f : d;  // the reference never computes the diagonal (stays 0 even for NaN rows)
+        }
+    } else {
+        for (int r = threadIdx.y; r < 64; r += 4) {
+            const int64_t i = i0 + r;
+            if (i >= n) break;
+            float d = 0.0f;
+            for (int64_t k = 0; k < m; ++k) {
+                const float diff = X[i * m + k] - X[j * m + k];
+                d = d + diff * diff;
+            }
+            D[i * n + j] = (i == j) ? 0.0f : d;
+        }
+    }
+}
+
+__global__ void k_threshold_lt(const float *__restrict__ D, int64_t count, float thr, int32_t *__restrict__ out)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = D[e] < thr ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// argwhere over an (n,n) predicate, row-major: one wave per row; count pass, block scan, fill pass.
+// ------------------------------------------------------------------------------------------------------------------
+struct PredDenseEq1 {
+    const int32_t *cmap;
+    int64_t n;
+    __device__ bool operator()(int64_t i, int64_t j) const { return cmap[i * n + j] == 1; }
+};
+struct PredCoordsLt {
+    const float *xyz;  // (n,3)
+    float thr2;
+    __device__ bool operator()(int64_t i, int64_t j) const
+    {
+        if (i == j) return 0.0f < thr2;  // diagonal of the reference matrix is an untouched 0
+        const float dx = xyz[i * 3 + 0] - xyz[j * 3 + 0], dy = xyz[i * 3 + 1] - xyz[j * 3 + 1],
+                    dz = xyz[i * 3 + 2] - xyz[j * 3 + 2];
+        float d = dx * dx;
+        d = d + dy * dy;
+        d = d + dz * dz;
+        return d < thr2;
+    }
+};
+
+template <typename Pred, bool FILL>
+__global__ __launch_bounds__(256) void k_argwhere_rows(Pred pred, int64_t n, int32_t *__restrict__ counts,
+                                                       const int64_t *__restrict__ row_base, int32_t *__restrict__ pairs,
+                                                       int64_t capacity, int32_t *__restrict__ cmap_out)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    int64_t pos = FILL ? row_base[i] : 0;
+    int cnt = 0;
+    for (int64_t j0 = 0; j0 < n; j0 += 64) {
+        const int64_t j = j0 + lane;
+        const bool hit = (j < n) && pred(i, j);
+        const unsigned long long mask = __ballot(hit);
+        if (FILL) {
+            if (cmap_out && j < n) cmap_out[i * n + j] = hit ? 1 : 0;
+            if (pairs && hit) {
+                const int before = __popcll(mask & ((1ull << lane) - 1ull));
+                const int64_t p = pos + before;
+                if (p < capacity) {
+                    pairs[2 * p] = (int32_t)i;
+                    pairs[2 * p + 1] = (int32_t)j;
+                }
+            }
+            pos += __popcll(mask);
+        } else {
+            cnt += __popcll(mask);
+        }
+    }
+    if (!FILL && lane == 0) counts[i] = cnt;
+}
+
+// Exclusive scan of int32 counts into int64 bases with one 1024-thread block; total -> base[n].
+__global__ __launch_bounds__(1024) void k_scan_i32_to_i64(const int32_t *__restrict__ counts, int64_t n,
+                                                          int64_t *__restrict__ base)
+{
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry_s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < n; c0 += 1024) {
+        const int64_t idx = c0 + threadIdx.x;
+        const int64_t v = idx < n ? counts[idx] : 0;
+        int64_t inc = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        int64_t woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const int64_t carry = carry_s;
+        if (idx < n) base[idx] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) base[n] = carry_s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Alignment walk (pyx:64-80) as a parallel scan: one block per protein.
+//   q2t[row_off[p]+q] = target index aligned to query residue q, or -1 when q is an insertion (target gap);
+//   t2q (optional, per-call API)  = the reference's target_to_query_map;  nm_out = its length.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_aln, const char *__restrict__ t_aln,
+                                                    const int32_t *__restrict__ aln_off, const int32_t *__restrict__ row_off,
+                                                    int32_t *__restrict__ q2t, int32_t *__restrict__ t2q,
+                                                    int32_t *__restrict__ nm_out, int32_t *__restrict__ lq_out)
+{
+    const int p = blockIdx.x;
+    const int a0 = aln_off[p], La = aln_off[p + 1] - a0;
+    const char *q = q_aln + a0, *t = t_aln + a0;
+    const int tid = threadIdx.x;
+    const int seg = (La + 255) / 256;
+    const int c_begin = min(tid * seg, La), c_end = min(c_begin + seg, La);
+    int nq = 0, nt = 0;  // query residues / map pushes in my segment
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool qgap = q[c] == GAP, tgap = t[c] == GAP;
+        nq += !qgap;
+        nt += qgap || !tgap;
+    }
+    // block exclusive scan of (nq, nt) packed in one 64-bit word
+    __shared__ unsigned long long wsum[4];
+    unsigned long long v = ((unsigned long long)(unsigned)nq << 32) | (unsigned)nt, inc = v;
+    const int lane = tid & 63, wid = tid >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long u = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += u;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    unsigned long long woff = 0, total = 0;
+    for (int w = 0; w < 4; ++w) {
+        if (w < wid) woff += wsum[w];
+        total += wsum[w];
+    }
+    const unsigned long long ex = woff + inc - v;
+    int qi = (int)(ex >> 32), ti = (int)(ex & 0xffffffffu);
+    int32_t *q2t_p = q2t + row_off[p];
+    int32_t *t2q_p = t2q ? t2q + a0 : nullptr;
+    for (int c = c_begin; c < c_end; ++c) {
+        const bool qgap = q[c] == GAP, tgap = t[c] == GAP;
+        if (qgap) {
+            if (t2q_p) t2q_p[ti] = -1;
+            ++ti;
+        } else if (tgap) {
+            q2t_p[qi] = -1;
+            ++qi;
+        } else {
+            if (t2q_p) t2q_p[ti] = qi;
+            q2t_p[qi] = ti;
+            ++qi;
+            ++ti;
+        }
+    }
+    if (tid == 0) {
+        if (nm_out) nm_out[p] = (int)(total & 0xffffffffu);
+        if (lq_out) lq_out[p] = (int)(total >> 32);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused contact rows.  One block per 32-row group (a group never straddles proteins: row_off is 32-aligned);
+// each of the 4 waves owns 8 consecutive rows.  Lane l of a wave owns column j0+l of the current 64-column
+// chunk and keeps that column's target coordinates in registers while the wave's 8 rows stream past as
+// wave-uniform scalars.
+//   bit(i,j) = (i==j) | synthetic(i,j) | (q2t[i]>=0 & q2t[j]>=0 & both < Lt & dist2(coords[q2t[i]],coords[q2t[j]]) < thr2)
+//   synthetic(i,j) = 0<|i-j|<=gen & (q2t[i]<0 | q2t[j]<0)            (pyx:70-76,91-97, both directions)
+// The contact term is symmetric for coords-derived pairs (argwhere yields (i,j) and (j,i)), so the one-directional
+// write of pyx:115 reproduces exactly this.
+// ------------------------------------------------------------------------------------------------------------------
+enum CmapMode { CM_COUNT = 0, CM_FILL_CSR = 1, CM_DENSE = 2 };
+
+__device__ __forceinline__ int find_protein(const int32_t *__restrict__ row_off, int B, int row)
+{
+    int lo = 0, hi = B;  // largest p with row_off[p] <= row
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (row_off[mid] <= row) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coords, const int32_t *__restrict__ coord_off,
+                                                   const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off,
+                                                   int B, const int32_t *__restrict__ q2t, float thr2, int gen,
+                                                   int32_t *__restrict__ counts,        // COUNT: out (R); FILL: in
+                                                   int32_t *__restrict__ group_sum,     // COUNT: out (R/32)
+                                                   const int32_t *__restrict__ group_base,  // FILL: in (R/32)
+                                                   int32_t *__restrict__ rowptr, int32_t *__restrict__ colidx,
+                                                   float *__restrict__ val, int64_t nnz_cap,
+                                                   int32_t *__restrict__ dense_out, const int64_t *__restrict__ dense_off)
+{
+    const int g = blockIdx.x;
+    const int row0 = g * 32;
+    const int p = find_protein(row_off, B, row0);
+    const int r0 = row_off[p];
+    const int Lq = Lq_arr[p];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int i_first = row0 - r0 + wid * 8;  // first local row of this wave
+    __shared__ int s_cnt[32];
+
+    if (MODE == CM_COUNT && i_first >= Lq) {
+        // padding rows: zero neighbours
+        if (lane < 8) {
+            counts[row0 + wid * 8 + lane] = 0;
+            s_cnt[wid * 8 + lane] = 0;
+        }
+    }
+    const int Lt = coord_off[p + 1] - coord_off[p];
+    const float *xyz = coords + (int64_t)coord_off[p] * 3;
+    const int32_t *q2t_p = q2t + r0;
+
+    // per-row uniforms
+    int ti[8];
+    float xi[8], yi[8], zi[8];
+    int cnt[8];
+    int pos[8];
+    float di[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = i_first + r;
+        int t = -2;  // -2: row is padding
+        float x = 0.f, y = 0.f, z = 0.f;
+        if (i < Lq) {
+            t = q2t_p[i];
+            if (t >= Lt) t = -3;  // aligned to a target residue without coordinates: never in contact
+            if (t >= 0) {
+                x = xyz[t * 3 + 0];
+                y = xyz[t * 3 + 1];
+                z = xyz[t * 3 + 2];
+            }
+        }
+        ti[r] = t; xi[r] = x; yi[r] = y; zi[r] = z;
+        cnt[r] = 0;
+        pos[r] = 0;
+        di[r] = 0.f;
+    }
+    if (MODE == CM_FILL_CSR) {
+        // row starts inside the group: exclusive prefix of the group's row counts (wave-uniform scalars)
+        int run = group_base[g];
+        for (int r = 0; r < wid * 8; ++r) run += counts[row0 + r];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = counts[row0 + wid * 8 + k];
+            pos[k] = run;
+            di[k] = 1.0f / (1e-6f + sqrtf((float)c));
+            if (lane == 0) rowptr[row0 + wid * 8 + k] = run;
+            run += c;
+        }
+    }
+    int32_t *dense_p = nullptr;
+    if (MODE == CM_DENSE) dense_p = dense_out + dense_off[p];
+
+    if (i_first < Lq) {
+        for (int j0 = 0; j0 < Lq; j0 += 64) {
+            const int j = j0 + lane;
+            int tj = -2;
+            float xj = 0.f, yj = 0.f, zj = 0.f, dj = 0.f;
+            if (j < Lq) {
+                tj = q2t_p[j];
+                if (tj >= Lt) tj = -3;
+                if (tj >= 0) {
+                    xj = xyz[tj * 3 + 0];
+                    yj = xyz[tj * 3 + 1];
+                    zj = xyz[tj * 3 + 2];
+                }
+                if (MODE == CM_FILL_CSR) dj = 1.0f / (1e-6f + sqrtf((float)counts[r0 + j]));
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = i_first + r;
+                if (i >= Lq) continue;  // wave-uniform
+                bool bit = false;
+                if (j < Lq) {
+                    const int dist = i > j ? i - j : j - i;
+                    bit = (dist == 0) || (dist <= gen && (ti[r] == -1 || tj == -1));
+                    if (!bit && ti[r] >= 0 && tj >= 0) {
+                        const float dx = xi[r] - xj, dy = yi[r] - yj, dz = zi[r] - zj;
+                        float d = dx * dx;
+                        d = d + dy * dy;
+                        d = d + dz * dz;
+                        // ti == tj only on the diagonal (the map is injective), handled above
+                        bit = d < thr2;
+                    }
+                }
+                if (MODE == CM_DENSE) {
+                    if (j < Lq) dense_p[(int64_t)i * Lq + j] = bit ? 1 : 0;
+                } else {
+                    const unsigned long long mask = __ballot(bit);
+                    if (MODE == CM_COUNT) {
+                        cnt[r] += __popcll(mask);
+                    } else {
+                        if (bit) {
+                            const int64_t w = (int64_t)pos[r] + __popcll(mask & ((1ull << lane) - 1ull));
+                            if (w < nnz_cap) {
+                                colidx[w] = r0 + j;
+                                val[w] = (di[r] * 1.0f) * dj;
+                            }
+                        }
+                        pos[r] += __popcll(mask);
+                    }
+                }
+            }
+        }
+        if (MODE == CM_COUNT && lane == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int i = i_first + r;
+                const int c = i < Lq ? cnt[r] : 0;
+                counts[row0 + wid * 8 + r] = c;
+                s_cnt[wid * 8 + r] = c;
+            }
+        }
+    }
+    if (MODE == CM_COUNT) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int s = 0;
+            for (int r = 0; r < 32; ++r) s += s_cnt[r];
+            group_sum[g] = s;
+        }
+    }
+}
+
+// Exclusive scan of the per-group nnz (int32) with one 1024-thread block; writes rowptr[R] = total and the
+// overflow status.
+__global__ __launch_bounds__(1024) void k_scan_groups(const int32_t *__restrict__ group_sum, int G,
+                                                      int32_t *__restrict__ group_base, int32_t *__restrict__ rowptr_end,
+                                                      int64_t nnz_cap, int32_t *__restrict__ status)
+{
+    __shared__ long long wsum[16];
+    __shared__ long long carry_s;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < G; c0 += 1024) {
+        const int idx = c0 + threadIdx.x;
+        const long long v = idx < G ? group_sum[idx] : 0;
+        long long inc = v;
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long t = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += t;
+        }
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        long long woff = 0;
+        for (int w = 0; w < wid; ++w) woff += wsum[w];
+        const long long carry = carry_s;
+        if (idx < G) group_base[idx] = (int32_t)(carry + woff + inc - v);
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const long long total = carry_s;
+        *rowptr_end = (int32_t)(total < 0x7fffffffLL ? total : 0x7fffffffLL);
+        if (total > nnz_cap || total >= 0x7fffffffLL) {
+            status[0] = 1;
+            status[1] = (int32_t)(total < 0x7fffffffLL ? total : 0x7fffffffLL);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Dense (L,L) contact maps handed to forward_pass -> normalised CSR (general values, possibly non-symmetric).
+// One wave per row.  A'(i,j) = (i==j) ? 1 : A(i,j);  rowsum in f32.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float load_as_f32(const void *base, int64_t idx)
+{
+    return (float)static_cast<const T *>(base)[idx];
+}
+__device__ __forceinline__ float load_cmap(const void *base, int dtype, int64_t idx)
+{
+    switch (dtype) {
+    case MDF_DT_I32: return load_as_f32<int32_t>(base, idx);
+    case MDF_DT_F32: return load_as_f32<float>(base, idx);
+    case MDF_DT_I64: return load_as_f32<long long>(base, idx);
+    case MDF_DT_F64: return load_as_f32<double>(base, idx);
+    default: return load_as_f32<uint8_t>(base, idx);
+    }
+}
+__device__ __forceinline__ int64_t dtype_size(int dtype)
+{
+    return dtype == MDF_DT_U8 ? 1 : (dtype == MDF_DT_I64 || dtype == MDF_DT_F64) ? 8 : 4;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_dense_rows(const void *__restrict__ cmaps, int dtype,
+                                                    const int64_t *__restrict__ cmap_off, const int32_t *__restrict__ Lq_arr,
+                                                    const int32_t *__restrict__ row_off, int B, int32_t *__restrict__ counts,
+                                                    float *__restrict__ rowsum, int32_t *__restrict__ group_sum,
+                                                    const int32_t *__restrict__ group_base, int32_t *__restrict__ rowptr,
+                                                    int32_t *__restrict__ colidx, float *__restrict__ val, int64_t nnz_cap)
+{
+    // block = 32-row group, wave = 8 rows (sequentially)
+    const int g = blockIdx.x, row0 = g * 32;
+    const int p = find_protein(row_off, B, row0);
+    const int r0 = row_off[p], Lq = Lq_arr[p];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const char *A = static_cast<const char *>(cmaps) + cmap_off[p] * dtype_size(dtype);
+    __shared__ int s_cnt[32];
+    int run = 0;
+    if (FILL) run = group_base[g];
+    for (int r = 0; r < 32; ++r) {
+        const int row = row0 + r, i = row - r0;
+        const bool mine = (r >> 3) == wid;
+        if (FILL) {
+            const int c = counts[row];
+            if (wid == 0 && lane == 0) rowptr[row] = run;
+            if (mine && i < Lq) {
+                const float di = 1.0f / (1e-6f + sqrtf(rowsum[row]));
+                int pos = run;
+                for (int j0 = 0; j0 < Lq; j0 += 64) {
+                    const int j = j0 + lane;
+                    float v = 0.f;
+                    if (j < Lq) v = (i == j) ? 1.0f : load_cmap(A, dtype, (int64_t)i * Lq + j);
+                    const bool nz = v != 0.0f;
+                    const unsigned long long mask = __ballot(nz);
+                    if (nz) {
+                        const int64_t w = (int64_t)pos + __popcll(mask & ((1ull << lane) - 1ull));
+                        if (w < nnz_cap) {
+                            const float dj = 1.0f / (1e-6f + sqrtf(rowsum[r0 + j]));
+                            colidx[w] = r0 + j;
+                            val[w] = (di * v) * dj;
+                        }
+                    }
+                    pos += __popcll(mask);
+                }
+            }
+            run += c;
+        } else if (mine) {
+            int c = 0;
+            float s = 0.f;
+            if (i < Lq) {
+                for (int j0 = 0; j0 < Lq; j0 += 64) {
+                    const int j = j0 + lane;
+                    float v = 0.f;
+                    if (j < Lq) v = (i == j) ? 1.0f : load_cmap(A, dtype, (int64_t)i * Lq + j);
+                    s += v;
+                    c += __popcll(__ballot(v != 0.0f));
+                }
+                for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+            }
+            if (lane == 0) {
+                counts[row] = c;
+                rowsum[row] = s;
+                s_cnt[r] = c;
+            }
+        }
+    }
+    if (!FILL) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int s = 0;
+            for (int r = 0; r < 32; ++r) s += s_cnt[r];
+            group_sum[g] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Per-call align_contact_map with an arbitrary pair list: init (zeros + diagonal + synthetic) then scatter.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void k_align_init(const int32_t *__restrict__ q2t, int Lq, int gen, int32_t *__restrict__ out)
+{
+    const int64_t total = (int64_t)Lq * Lq;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / Lq), j = (int)(e % Lq);
+        const int dist = i > j ? i - j : j - i;
+        out[e] = (dist == 0 || (dist <= gen && (q2t[i] == -1 || q2t[j] == -1))) ? 1 : 0;
+    }
+}
+
+__global__ void k_align_scatter(const int32_t *__restrict__ pairs, int64_t N, const int32_t *__restrict__ t2q,
+                                const int32_t *__restrict__ nm_ptr, int Lq, int32_t *__restrict__ out)
+{
+    const unsigned nm = (unsigned)nm_ptr[0];
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < N; r += (int64_t)gridDim.x * blockDim.x) {
+        const int ti = pairs[2 * r], tj = pairs[2 * r + 1];
+        if ((unsigned)ti < nm && (unsigned)tj < nm) {  // unsigned compare: negatives dropped (pyx:110)
+            const int a = t2q[ti], b = t2q[tj];
+            if (a != -1 && b != -1) out[(int64_t)a * Lq + b] = 1;  // benign race: every writer stores 1 (pyx:115)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// seq2onehot (predict.pyx:17-48): dense one-hot rows for the API, index form for the GCN.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int aa_code(unsigned char c)
+{
+    // alphabet "-DGULNTKHYWCPVSOIEFXQABZRM" (predict.pyx:26), index = position
+    switch (c) {
+    case '-': return 0;  case 'D': return 1;  case 'G': return 2;  case 'U': return 3;  case 'L': return 4;
+    case 'N': return 5;  case 'T': return 6;  case 'K': return 7;  case 'H': return 8;  case 'Y': return 9;
+    case 'W': return 10; case 'C': return 11; case 'P': return 12; case 'V': return 13; case 'S': return 14;
+    case 'O': return 15; case 'I': return 16; case 'E': return 17; case 'F': return 18; case 'X': return 19;
+    case 'Q': return 20; case 'A': return 21; case 'B': return 22; case 'Z': return 23; case 'R': return 24;
+    case 'M': return 25;
+    default: return -1;
+    }
+}
+
+__global__ void k_seq2onehot(const char *__restrict__ seq, int64_t L, float *__restrict__ out, int32_t *__restrict__ bad)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < L * 26; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / 26;
+        const int a = (int)(e % 26);
+        const int c = aa_code((unsigned char)seq[i]);
+        out[e] = (c == a) ? 1.0f : 0.0f;
+        if (a == 0 && c < 0) atomicMin(bad, (int32_t)min(i, (int64_t)0x7ffffffe));
+    }
+}
+
+__global__ void k_seq_encode(const char *__restrict__ seqs, const int32_t *__restrict__ seq_off,
+                             const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off, int B,
+                             uint8_t *__restrict__ seq_idx, int32_t *__restrict__ bad)
+{
+    const int p = blockIdx.x;
+    const int r0 = row_off[p], r1 = row_off[p + 1], Lq = Lq_arr[p];
+    const char *s = seqs + seq_off[p];
+    for (int i = threadIdx.x; i < r1 - r0; i += blockDim.x) {
+        int c = 255;
+        if (i < Lq) {
+            c = aa_code((unsigned char)s[i]);
+            if (c < 0) {
+                bad[0] = p + 1;
+                bad[1] = i;
+                c = 255;
+            }
+        }
+        seq_idx[r0 + i] = (uint8_t)c;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host-side helpers
+// ------------------------------------------------------------------------------------------------------------------
+static inline float thr2_f32(double threshold) { return (float)(threshold * threshold); }
+
+struct CmapWs {
+    int32_t *q2t, *counts, *group_sum, *group_base;
+    float *rowsum;
+};
+static size_t cmap_ws_bytes(int32_t B, int64_t R)
+{
+    (void)B;
+    const size_t G = (size_t)(R / 32 + 1);
+    return 256 * 6 + (size_t)R * 4 * 3 + G * 4 * 2 + 4096;
+}
+static bool carve_cmap_ws(void *ws, size_t bytes, int64_t R, CmapWs &o)
+{
+    Carver c(ws, bytes);
+    const size_t G = (size_t)(R / 32 + 1);
+    o.q2t = c.take<int32_t>(R);
+    o.counts = c.take<int32_t>(R);
+    o.rowsum = c.take<float>(R);
+    o.group_sum = c.take<int32_t>(G);
+    o.group_base = c.take<int32_t>(G);
+    return c.ok();
+}
+
+static int check_layout(int32_t B, int64_t R)
+{
+    MDF_REQUIRE(B > 0, "batch must hold at least one protein (B=%d)", B);
+    MDF_REQUIRE(R > 0 && R % 128 == 0 && R < 0x7fffffff, "total rows R=%lld must be a positive multiple of 128", (long long)R);
+    return MDF_OK;
+}
+
+// shared tail of the two argwhere front-ends: counts -> scan -> fill -> copy back
+template <typename Pred>
+static int argwhere_run(Pred pred, int64_t n, char *ws, int32_t *pairs, int64_t capacity, int64_t *n_pairs,
+                        int32_t *cmap_host)
+{
+    // ws layout: counts (n i32) | base ((n+1) i64) | pairs_dev (cap*2 i32) | cmap_dev (n*n i32, optional)
+    int32_t *d_counts = reinterpret_cast<int32_t *>(ws);
+    int64_t *d_base = reinterpret_cast<int64_t *>(ws + align_up((size_t)n * 4, 256));
+    char *after = reinterpret_cast<char *>(d_base) + align_up((size_t)(n + 1) * 8, 256);
+    int32_t *d_pairs = reinterpret_cast<int32_t *>(after);
+    int32_t *d_cmap = cmap_host ? reinterpret_cast<int32_t *>(after + align_up((size_t)capacity * 8, 256)) : nullptr;
+    const dim3 grid((unsigned)((n + 3) / 4)), block(256);
+    hipLaunchKernelGGL((k_argwhere_rows<Pred, false>), grid, block, 0, 0, pred, n, d_counts, (const int64_t *)nullptr,
+                       (int32_t *)nullptr, (int64_t)0, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_scan_i32_to_i64, dim3(1), dim3(1024), 0, 0, d_counts, n, d_base);
+    hipLaunchKernelGGL((k_argwhere_rows<Pred, true>), grid, block, 0, 0, pred, n, d_counts, (const int64_t *)d_base,
+                       pairs ? d_pairs : (int32_t *)nullptr, capacity, d_cmap);
+    MDF_HIP(hipGetLastError());
+    int64_t total = 0;
+    MDF_HIP(hipMemcpy(&total, d_base + n, 8, hipMemcpyDeviceToHost));
+    if (n_pairs) *n_pairs = total;
+    if (cmap_host) MDF_HIP(hipMemcpy(cmap_host, d_cmap, (size_t)n * n * 4, hipMemcpyDeviceToHost));
+    if (pairs) {
+        const int64_t ncopy = std::min(total, capacity);
+        if (ncopy > 0) MDF_HIP(hipMemcpy(pairs, d_pairs, (size_t)ncopy * 8, hipMemcpyDeviceToHost));
+        if (total > capacity)
+            return fail(MDF_ECAPACITY, "argwhere: %lld pairs exceed the capacity of %lld", (long long)total,
+                        (long long)capacity);
+    }
+    return MDF_OK;
+}
+
+}  // namespace mdf
+
+using namespace mdf;
+
+extern "C" {
+
+int mdf_pairwise_sqeuclidean_f32(const float *X, int64_t n, int64_t m, float *D, int threads)
+{
+    (void)threads;
+    MDF_REQUIRE(n >= 0 && m >= 0, "pairwise_sqeuclidean: negative shape (%lld,%lld)", (long long)n, (long long)m);
+    MDF_REQUIRE((X || n * m == 0) && (D || n == 0), "pairwise_sqeuclidean: NULL buffer");
+    if (int rc = require_device()) return rc;
+    if (n == 0) return MDF_OK;
+    const size_t xb = (size_t)n * m * sizeof(float), db = (size_t)n * n * sizeof(float);
+    Scratch &s = scratch(0);
+    if (int rc = s.reserve(align_up(xb, 256) + db + 256)) return rc;
+    float *dX = static_cast<float *>(s.ptr);
+    float *dD = reinterpret_cast<float *>(static_cast<char *>(s.ptr) + align_up(xb + 4, 256));
+    if (xb) MDF_HIP(hipMemcpy(dX, X, xb, hipMemcpyHostToDevice));
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)((n + 63) / 64)), block(64, 4);
+    if (m == 3)
+        hipLaunchKernelGGL(k_pairwise_sqeuclidean<true>, grid, block, 0, 0, dX, n, m, dD);
+    else
+        hipLaunchKernelGGL(k_pairwise_sqeuclidean<false>, grid, block, 0, 0, dX, n, m, dD);
+    MDF_HIP(hipGetLastError());
+    MDF_HIP(hipMemcpy(D, dD, db, hipMemcpyDeviceToHost));
+    return MDF_OK;
+}
+
+int mdf_threshold_lt_i32(const float *D, int64_t count, float thr, int32_t *out)
+{
+    MDF_REQUIRE(count >= 0 && ((D && out) || count == 0), "threshold_lt: bad arguments");
+    if (int rc = require_device()) return rc;
+    if (count == 0) return MDF_OK;
+    const size_t b = (size_t)count * 4;
+    Scratch &s = scratch(0);
+    if (int rc = s.reserve(2 * align_up(b, 256))) return rc;
+    float *dD = static_cast<float *>(s.ptr);
+    int32_t *dO = reinterpret_cast<int32_t *>(static_cast<char *>(s.ptr) + align_up(b, 256));
+    MDF_HIP(hipMemcpy(dD, D, b, hipMemcpyHostToDevice));
+    const int blocks = (int)std::min<int64_t>((count + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_threshold_lt, dim3(blocks), dim3(256), 0, 0, dD, count, thr, dO);
+    MDF_HIP(hipGetLastError());
+    MDF_HIP(hipMemcpy(out, dO, b, hipMemcpyDeviceToHost));
+    return MDF_OK;
+}
+
+int mdf_argwhere_eq1_i32(const int32_t *cmap, int64_t n, int32_t *pairs, int64_t capacity, int64_t *n_pairs)
+{
+    MDF_REQUIRE(n >= 0 && capacity >= 0 && (cmap || n == 0) && (pairs || capacity == 0), "argwhere: bad arguments");
+    if (int rc = require_device()) return rc;
+    if (n_pairs) *n_pairs = 0;
+    if (n == 0) return MDF_OK;
+    const size_t cb = (size_t)n * n * 4;
+    const size_t wsb = align_up((size_t)n * 4, 256) + align_up((size_t)(n + 1) * 8, 256) + align_up((size_t)capacity * 8, 256) + 256;
+    Scratch &s = scratch(0);
+    if (int rc = s.reserve(align_up(cb, 256) + wsb)) return rc;
+    int32_t *d_in = static_cast<int32_t *>(s.ptr);
+    MDF_HIP(hipMemcpy(d_in, cmap, cb, hipMemcpyHostToDevice));
+    PredDenseEq1 pred{d_in, n};
+    return argwhere_run(pred, n, static_cast<char *>(s.ptr) + align_up(cb, 256), pairs, capacity, n_pairs, nullptr);
+}
+
+int mdf_calculate_contact_map(const float *coords, int64_t n, double threshold, int32_t *cmap, int32_t *pairs,
+                              int64_t capacity, int64_t *n_pairs)
+{
+    MDF_REQUIRE(n >= 0 && (coords || n == 0), "calculate_contact_map: bad coords");
+    MDF_REQUIRE((cmap != nullptr) != (pairs != nullptr) || n == 0, "calculate_contact_map: pass exactly one of cmap / pairs");
+    if (int rc = require_device()) return rc;
+    if (n_pairs) *n_pairs = 0;
+    if (n == 0) return MDF_OK;
+    if (!pairs) capacity = 0;
+    const size_t xb = align_up((size_t)n * 12, 256);
+    const size_t wsb = align_up((size_t)n * 4, 256) + align_up((size_t)(n + 1) * 8, 256) + align_up((size_t)capacity * 8, 256) +
+                       (cmap ? (size_t)n * n * 4 : 0) + 256;
+    Scratch &s = scratch(0);
+    if (int rc = s.reserve(xb + wsb)) return rc;
+    float *d_xyz = static_cast<float *>(s.ptr);
+    MDF_HIP(hipMemcpy(d_xyz, coords, (size_t)n * 12, hipMemcpyHostToDevice));
+    PredCoordsLt pred{d_xyz, thr2_f32(threshold)};
+    return argwhere_run(pred, n, static_cast<char *>(s.ptr) + xb, pairs, capacity, n_pairs, cmap);
+}
+
+int mdf_align_len(const char *q_aln, const char *t_aln, int64_t La, int64_t *Lq)
+{
+    (void)t_aln;
+    MDF_REQUIRE(La >= 0 && (q_aln || La == 0) && Lq, "align_len: bad arguments");
+    int64_t c = 0;
+    for (int64_t i = 0; i < La; ++i) c += q_aln[i] != GAP;
+    *Lq = c;
+    return MDF_OK;
+}
+
+int64_t mdf_layout_rows(const int32_t *Lq, int32_t B, int32_t *row_off)
+{
+    if (B < 0 || (B > 0 && (!Lq || !row_off))) return fail(MDF_EINVAL, "layout_rows: bad arguments");
+    int64_t r = 0;
+    for (int32_t p = 0; p < B; ++p) {
+        if (Lq[p] < 0) return fail(MDF_EINVAL, "layout_rows: negative length at %d", p);
+        row_off[p] = (int32_t)r;
+        r += ((int64_t)Lq[p] + 31) / 32 * 32;
+        if (r >= 0x7fffff00LL) return fail(MDF_EINVAL, "layout_rows: batch exceeds 2^31 rows");
+    }
+    r = (r + 127) / 128 * 128;
+    if (r == 0) r = 128;
+    if (row_off) row_off[B] = (int32_t)r;
+    return r;
+}
+
+// single-protein descriptors used by the per-call entry points
+struct OneProtein {
+    int32_t coord_off[2], aln_off[2], Lq[1], row_off[2];
+    int64_t dense_off[1];
+};
+
+int mdf_align_contact_map(const char *q_aln, const char *t_aln, int64_t La, const int32_t *pairs, int64_t N,
+                          int generated_contacts, int32_t *out, int threads)
+{
+    (void)threads;
+    MDF_REQUIRE(La >= 0 && N >= 0 && (La == 0 || (q_aln && t_aln)) && (N == 0 || pairs), "align_contact_map: bad arguments");
+    MDF_REQUIRE(La < 0x7fffffff, "align_contact_map: alignment too long");
+    if (int rc = require_device()) return rc;
+    int64_t Lq = 0;
+    mdf_align_len(q_aln, t_aln, La, &Lq);
+    if (Lq == 0) return MDF_OK;  // (0,0) output
+    MDF_REQUIRE(out, "align_contact_map: out is NULL");
+    const int64_t R = (Lq + 127) / 128 * 128;
+    // scratch: q | t | q2t (R) | t2q (La) | nm | pairs | out
+    const size_t o_q = 0, o_t = align_up((size_t)La, 256), o_q2t = o_t + align_up((size_t)La, 256),
+                 o_t2q = o_q2t + align_up((size_t)R * 4, 256), o_meta = o_t2q + align_up((size_t)La * 4 + 4, 256),
+                 o_pairs = o_meta + 256, o_out = o_pairs + align_up((size_t)N * 8 + 8, 256),
+                 total = o_out + (size_t)Lq * Lq * 4;
+    Scratch &s = scratch(0);
+    if (int rc = s.reserve(total)) return rc;
+    char *b = static_cast<char *>(s.ptr);
+    MDF_HIP(hipMemcpy(b + o_q, q_aln, (size_t)La, hipMemcpyHostToDevice));
+    MDF_HIP(hipMemcpy(b + o_t, t_aln, (size_t)La, hipMemcpyHostToDevice));
+    if (N) MDF_HIP(hipMemcpy(b + o_pairs, pairs, (size_t)N * 8, hipMemcpyHostToDevice));
+    int32_t meta[8] = {0, (int32_t)La, 0, (int32_t)R, 0, 0, 0, 0};  // aln_off[2], row_off[2], nm, lq
+    MDF_HIP(hipMemcpy(b + o_meta, meta, sizeof(meta), hipMemcpyHostToDevice));
+    int32_t *d_meta = reinterpret_cast<int32_t *>(b + o_meta);
+    int32_t *d_q2t = reinterpret_cast<int32_t *>(b + o_q2t), *d_t2q = reinterpret_cast<int32_t *>(b + o_t2q);
+    int32_t *d_out = reinterpret_cast<int32_t *>(b + o_out);
+    hipLaunchKernelGGL(k_align_scan, dim3(1), dim3(256), 0, 0, b + o_q, b + o_t, d_meta, d_meta + 2, d_q2t, d_t2q,
+                       d_meta + 4, d_meta + 5);
+    const int64_t elems = Lq * Lq;
+    hipLaunchKernelGGL(k_align_init, dim3((unsigned)std::min<int64_t>((elems + 255) / 256, 8192)), dim3(256), 0, 0, d_q2t,
+                       (int)Lq, generated_contacts, d_out);
+    if (N)
+        hipLaunchKernelGGL(k_align_scatter, dim3((unsigned)std::min<int64_t>((N + 255) / 256, 4096)), dim3(256), 0, 0,
+                           reinterpret_cast<const int32_t *>(b + o_pairs), N, d_t2q, d_meta + 4, (int)Lq, d_out);
+    MDF_HIP(hipGetLastError());
+    MDF_HIP(hipMemcpy(out, d_out, (size_t)elems * 4, hipMemcpyDeviceToHost));
+    return MDF_OK;
+}
+
+size_t mdf_cmap_workspace_bytes(int32_t B, int64_t R) { return cmap_ws_bytes(B, R); }
+
+int mdf_cmap_csr_dev(const float *coords, const int32_t *coord_off, const char *q_aln, const char *t_aln,
+                     const int32_t *aln_off, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                     double threshold, int generated_contacts, int32_t *rowptr, int32_t *colidx, float *val,
+                     int64_t nnz_cap, int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_layout(B, R)) return rc;
+    MDF_REQUIRE(coords && coord_off && q_aln && t_aln && aln_off && Lq && row_off && rowptr && colidx && val && status && workspace,
+                "cmap_csr_dev: NULL argument");
+    MDF_REQUIRE(nnz_cap > 0 && nnz_cap < 0x7fffffff, "cmap_csr_dev: nnz_cap out of range");
+    CmapWs w;
+    if (!carve_cmap_ws(workspace, workspace_bytes, R, w))
+        return fail(MDF_ECAPACITY, "cmap_csr_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, cmap_ws_bytes(B, R));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int G = (int)(R / 32);
+    const float t2 = thr2_f32(threshold);
+    ScopedTiming tm(TK_CMAP, st);
+    hipLaunchKernelGGL(k_align_scan, dim3(B), dim3(256), 0, st, q_aln, t_aln, aln_off, row_off, w.q2t, (int32_t *)nullptr,
+                       (int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_cmap_rows<CM_COUNT>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t, t2,
+                       generated_contacts, w.counts, w.group_sum, (const int32_t *)nullptr, (int32_t *)nullptr,
+                       (int32_t *)nullptr, (float *)nullptr, (int64_t)0, (int32_t *)nullptr, (const int64_t *)nullptr);
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
+    hipLaunchKernelGGL(k_cmap_rows<CM_FILL_CSR>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t, t2,
+                       generated_contacts, w.counts, (int32_t *)nullptr, (const int32_t *)w.group_base, rowptr, colidx, val,
+                       nnz_cap, (int32_t *)nullptr, (const int64_t *)nullptr);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+int mdf_cmap_dense_dev(const float *coords, const int32_t *coord_off, const char *q_aln, const char *t_aln,
+                       const int32_t *aln_off, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                       double threshold, int generated_contacts, int32_t *out, const int64_t *out_off, void *workspace,
+                       size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_layout(B, R)) return rc;
+    MDF_REQUIRE(coords && coord_off && q_aln && t_aln && aln_off && Lq && row_off && out && out_off && workspace,
+                "cmap_dense_dev: NULL argument");
+    CmapWs w;
+    if (!carve_cmap_ws(workspace, workspace_bytes, R, w))
+        return fail(MDF_ECAPACITY, "cmap_dense_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, cmap_ws_bytes(B, R));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int G = (int)(R / 32);
+    ScopedTiming tm(TK_CMAP, st);
+    hipLaunchKernelGGL(k_align_scan, dim3(B), dim3(256), 0, st, q_aln, t_aln, aln_off, row_off, w.q2t, (int32_t *)nullptr,
+                       (int32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(k_cmap_rows<CM_DENSE>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t,
+                       thr2_f32(threshold), generated_contacts, (int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr,
+                       (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr, (int64_t)0, out, out_off);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+int mdf_build_align_contact_map(const float *coords, int64_t Lt, const char *q_aln, const char *t_aln, int64_t La,
+                                double threshold, int generated_contacts, int32_t *out)
+{
+    MDF_REQUIRE(Lt >= 0 && La >= 0 && (Lt == 0 || coords) && (La == 0 || (q_aln && t_aln)), "build_align_contact_map: bad arguments");
+    MDF_REQUIRE(La < 0x7fffffff && Lt < 0x7fffffff / 3, "build_align_contact_map: input too long");
+    if (int rc = require_device()) return rc;
+    int64_t Lq = 0;
+    mdf_align_len(q_aln, t_aln, La, &Lq);
+    if (Lq == 0) return MDF_OK;
+    MDF_REQUIRE(out, "build_align_contact_map: out is NULL");
+    OneProtein d;
+    d.coord_off[0] = 0; d.coord_off[1] = (int32_t)Lt;
+    d.aln_off[0] = 0; d.aln_off[1] = (int32_t)La;
+    d.Lq[0] = (int32_t)Lq;
+    const int64_t R = mdf_layout_rows(d.Lq, 1, d.row_off);
+    d.dense_off[0] = 0;
+    const size_t wsb = cmap_ws_bytes(1, R);
+    const size_t o_desc = 0, o_xyz = 256, o_q = o_xyz + align_up((size_t)Lt * 12 + 4, 256), o_t = o_q + align_up((size_t)La, 256),
+                 o_ws = o_t + align_up((size_t)La, 256), o_out = o_ws + align_up(wsb, 256), total = o_out + (size_t)Lq * Lq * 4;
+    Scratch &s = scratch(0);
+    if (int rc = s.reserve(total)) return rc;
+    char *b = static_cast<char *>(s.ptr);
+    MDF_HIP(hipMemcpy(b + o_desc, &d, sizeof(d), hipMemcpyHostToDevice));
+    if (Lt) MDF_HIP(hipMemcpy(b + o_xyz, coords, (size_t)Lt * 12, hipMemcpyHostToDevice));
+    MDF_HIP(hipMemcpy(b + o_q, q_aln, (size_t)La, hipMemcpyHostToDevice));
+    MDF_HIP(hipMemcpy(b + o_t, t_aln, (size_t)La, hipMemcpyHostToDevice));
+    const OneProtein *dd = reinterpret_cast<const OneProtein *>(b + o_desc);
+    if (int rc = mdf_cmap_dense_dev(reinterpret_cast<const float *>(b + o_xyz), dd->coord_off, b + o_q, b + o_t, dd->aln_off, dd->Lq,
+                                    dd->row_off, 1, R, threshold, generated_contacts, reinterpret_cast<int32_t *>(b + o_out),
+                                    dd->dense_off, b + o_ws, wsb, nullptr))
+        return rc;
+    MDF_HIP(hipMemcpy(out, b + o_out, (size_t)Lq * Lq * 4, hipMemcpyDeviceToHost));
+    return MDF_OK;
+}
+
+int mdf_dense_to_csr_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_off, const int32_t *Lq,
+                         const int32_t *row_off, int32_t B, int64_t R, int32_t *rowptr, int32_t *colidx, float *val,
+                         int64_t nnz_cap, int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_layout(B, R)) return rc;
+    MDF_REQUIRE(cmaps && cmap_off && Lq && row_off && rowptr && colidx && val && status && workspace, "dense_to_csr_dev: NULL argument");
+    MDF_REQUIRE(cmap_dtype >= MDF_DT_I32 && cmap_dtype <= MDF_DT_U8, "dense_to_csr_dev: unknown dtype %d", cmap_dtype);
+    MDF_REQUIRE(nnz_cap > 0 && nnz_cap < 0x7fffffff, "dense_to_csr_dev: nnz_cap out of range");
+    CmapWs w;
+    if (!carve_cmap_ws(workspace, workspace_bytes, R, w))
+        return fail(MDF_ECAPACITY, "dense_to_csr_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, cmap_ws_bytes(B, R));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int G = (int)(R / 32);
+    hipLaunchKernelGGL(k_dense_rows<false>, dim3(G), dim3(256), 0, st, cmaps, cmap_dtype, cmap_off, Lq, row_off, B, w.counts,
+                       w.rowsum, w.group_sum, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr,
+                       (int64_t)0);
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
+    hipLaunchKernelGGL(k_dense_rows<true>, dim3(G), dim3(256), 0, st, cmaps, cmap_dtype, cmap_off, Lq, row_off, B, w.counts,
+                       w.rowsum, (int32_t *)nullptr, (const int32_t *)w.group_base, rowptr, colidx, val, nnz_cap);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+int mdf_seq2onehot(const char *seq, int64_t L, float *out, int64_t *bad_idx)
+{
+    MDF_REQUIRE(L >= 0 && (L == 0 || (seq && out)), "seq2onehot: bad arguments");
+    if (bad_idx) *bad_idx = -1;
+    if (int rc = require_device()) return rc;
+    if (L == 0) return MDF_OK;
+    const size_t ob = (size_t)L * 26 * 4;
+    Scratch &s = scratch(0);
+    if (int rc = s.reserve(align_up((size_t)L, 256) + 256 + ob)) return rc;
+    char *b = static_cast<char *>(s.ptr);
+    int32_t *d_bad = reinterpret_cast<int32_t *>(b + align_up((size_t)L, 256));
+    float *d_out = reinterpret_cast<float *>(b + align_up((size_t)L, 256) + 256);
+    int32_t init = 0x7fffffff;
+    MDF_HIP(hipMemcpy(b, seq, (size_t)L, hipMemcpyHostToDevice));
+    MDF_HIP(hipMemcpy(d_bad, &init, 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_seq2onehot, dim3((unsigned)std::min<int64_t>((L * 26 + 255) / 256, 4096)), dim3(256), 0, 0, b, L, d_out, d_bad);
+    MDF_HIP(hipGetLastError());
+    int32_t bad = 0;
+    MDF_HIP(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+    if (bad != 0x7fffffff) {
+        if (bad_idx) *bad_idx = bad;
+        return fail(MDF_EBADCHAR, "Invalid character in sequence at index %d", bad);
+    }
+    MDF_HIP(hipMemcpy(out, d_out, ob, hipMemcpyDeviceToHost));
+    return MDF_OK;
+}
+
+int mdf_seq_encode_dev(const char *seqs, const int32_t *seq_off, const int32_t *Lq, const int32_t *row_off, int32_t B,
+                       int64_t R, uint8_t *seq_idx, int32_t *bad, void *stream)
+{
+    if (int rc = check_layout(B, R)) return rc;
+    MDF_REQUIRE(seqs && seq_off && Lq && row_off && seq_idx && bad, "seq_encode_dev: NULL argument");
+    hipLaunchKernelGGL(k_seq_encode, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), seqs, seq_off, Lq, row_off, B, seq_idx, bad);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+}  // extern "C"

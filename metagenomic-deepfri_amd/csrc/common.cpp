@@ -1,0 +1,178 @@
+// common.cpp -- error reporting, device probe, launch timing and scratch buffers for libmdfri_hip.so
+#include "common.h"
+
+namespace mdf {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(MDF_ENODEVICE,
+                    "no HIP device visible (hipGetDeviceCount: %s, count=%d); libmdfri_hip has no CPU fallback",
+                    hipGetErrorString(e), n);
+    }
+    return MDF_OK;
+}
+
+// ---- timing -------------------------------------------------------------------------------------------------------
+struct TimingState {
+    std::mutex mu;
+    bool on = false;
+    struct Pair {
+        hipEvent_t a, b;
+    };
+    std::vector<Pair> pairs[TK_COUNT];      // recorded, not yet folded
+    std::vector<Pair> free_list;            // reusable events
+    int64_t launches[TK_COUNT] = {0, 0, 0, 0};
+    double ms[TK_COUNT] = {0, 0, 0, 0};
+    Pair open[TK_COUNT];
+    bool is_open[TK_COUNT] = {false, false, false, false};
+};
+static TimingState g_t;
+
+bool timing_on() { return g_t.on; }
+
+void timing_begin(TimedKernel k, hipStream_t stream)
+{
+    if (!g_t.on) return;
+    std::lock_guard<std::mutex> lk(g_t.mu);
+    TimingState::Pair p;
+    if (!g_t.free_list.empty()) {
+        p = g_t.free_list.back();
+        g_t.free_list.pop_back();
+    } else {
+        if (hipEventCreate(&p.a) != hipSuccess || hipEventCreate(&p.b) != hipSuccess) return;
+    }
+    (void)hipEventRecord(p.a, stream);
+    g_t.open[k] = p;
+    g_t.is_open[k] = true;
+}
+
+void timing_end(TimedKernel k, hipStream_t stream)
+{
+    if (!g_t.on) return;
+    std::lock_guard<std::mutex> lk(g_t.mu);
+    if (!g_t.is_open[k]) return;
+    (void)hipEventRecord(g_t.open[k].b, stream);
+    g_t.pairs[k].push_back(g_t.open[k]);
+    g_t.is_open[k] = false;
+}
+
+static void fold_locked()
+{
+    for (int k = 0; k < TK_COUNT; ++k) {
+        for (auto &p : g_t.pairs[k]) {
+            (void)hipEventSynchronize(p.b);
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+                g_t.ms[k] += ms;
+                g_t.launches[k] += 1;
+            }
+            g_t.free_list.push_back(p);
+        }
+        g_t.pairs[k].clear();
+    }
+}
+
+}  // namespace mdf
+
+using namespace mdf;
+
+extern "C" {
+
+const char *mdf_last_error(void) { return g_err; }
+const char *mdf_version(void) { return "mdfri-hip 0.1.0 (gfx950)"; }
+
+int mdf_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int mdf_timing_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_t.mu);
+    g_t.on = on != 0;
+    return MDF_OK;
+}
+
+int mdf_timing_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_t.mu);
+    fold_locked();
+    for (int k = 0; k < TK_COUNT; ++k) {
+        g_t.launches[k] = 0;
+        g_t.ms[k] = 0;
+    }
+    return MDF_OK;
+}
+
+int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms)
+{
+    if (!kernel) return fail(MDF_EINVAL, "mdf_timing_read: kernel is NULL");
+    int k = -1;
+    if (!strcmp(kernel, "ax")) k = TK_AX;
+    else if (!strcmp(kernel, "gemm")) k = TK_GEMM;
+    else if (!strcmp(kernel, "cmap")) k = TK_CMAP;
+    else if (!strcmp(kernel, "head")) k = TK_HEAD;
+    if (k < 0) return fail(MDF_EINVAL, "mdf_timing_read: unknown kernel class '%s'", kernel);
+    std::lock_guard<std::mutex> lk(g_t.mu);
+    fold_locked();
+    if (launches) *launches = g_t.launches[k];
+    if (total_ms) *total_ms = g_t.ms[k];
+    return MDF_OK;
+}
+
+}  // extern "C"
+
+namespace mdf {
+
+int Scratch::reserve(size_t need)
+{
+    int dev = 0;
+    MDF_HIP(hipGetDevice(&dev));
+    if (ptr && dev == device && bytes >= need) return MDF_OK;
+    if (ptr) {
+        (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    size_t want = align_up(need + need / 4 + 4096, 4096);
+    MDF_HIP(hipMalloc(&ptr, want));
+    bytes = want;
+    device = dev;
+    return MDF_OK;
+}
+
+Scratch &scratch(int slot)
+{
+    static thread_local Scratch s[8];
+    return s[slot & 7];
+}
+
+}  // namespace mdf

@@ -1,0 +1,80 @@
+// common.h -- shared host-side plumbing for libmdfri_hip.so (error reporting, launch timing, scratch).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mdfri.h"
+
+namespace mdf {
+
+// ---- thread-local error message -------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define MDF_HIP(expr)                                                                                    \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            const int c_ = (e_ == hipErrorOutOfMemory) ? MDF_ENOMEM : MDF_ENODEVICE;                     \
+            return ::mdf::fail(c_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,     \
+                               __LINE__);                                                                \
+        }                                                                                                \
+    } while (0)
+
+#define MDF_REQUIRE(cond, ...)                                   \
+    do {                                                         \
+        if (!(cond)) return ::mdf::fail(MDF_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+// Fails with MDF_ENODEVICE unless at least one HIP device is visible.  No CPU fallback exists.
+int require_device();
+
+// ---- launch timing (mdf_timing_*) -----------------------------------------------------------------------------
+enum TimedKernel { TK_AX = 0, TK_GEMM = 1, TK_CMAP = 2, TK_HEAD = 3, TK_COUNT = 4 };
+bool timing_on();
+// Record an event pair around a launch on `stream`; no-ops when timing is disabled.
+void timing_begin(TimedKernel k, hipStream_t stream);
+void timing_end(TimedKernel k, hipStream_t stream);
+
+struct ScopedTiming {
+    TimedKernel k;
+    hipStream_t s;
+    ScopedTiming(TimedKernel k_, hipStream_t s_) : k(k_), s(s_) { timing_begin(k, s); }
+    ~ScopedTiming() { timing_end(k, s); }
+};
+
+// ---- per-thread device scratch for the host (per-call) entry points ---------------------------------------------
+// Grows monotonically, reused across calls; freed at thread exit is not attempted (process lifetime).
+struct Scratch {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    int device = -1;
+    int reserve(size_t need);  // returns MDF_OK or error
+};
+Scratch &scratch(int slot);  // a few independent slots per thread
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Bump allocator over a caller-provided workspace.
+struct Carver {
+    char *base;
+    size_t cap, off = 0;
+    Carver(void *p, size_t n) : base(static_cast<char *>(p)), cap(n) {}
+    template <typename T>
+    T *take(size_t count) {
+        off = align_up(off, 256);
+        T *r = reinterpret_cast<T *>(base + off);
+        off += count * sizeof(T);
+        return r;
+    }
+    bool ok() const { return off <= cap; }
+};
+
+}  // namespace mdf

@@ -1,0 +1,677 @@
+// gcn.hip -- DeepFRI GCN forward on gfx950 (replaces the onnxruntime session of mDeepFRI/predict.pyx:50-102).
+//
+// Per batch of proteins laid out as residue rows (see mdfri.h "Residue-row layout"):
+//   layer 1   H1 = elu( Ahat . relu(onehot W_aa) . W1 )   -- folded: relu(onehot W_aa) W1 is a 26-row table T1
+//                                                            (one-hot rows select table rows), so layer 1 is a sparse
+//                                                            aggregation of T1 rows: H1[i] = elu(sum_j val_ij T1[seq_j])
+//   layer k   H_k = elu( (Ahat . H_{k-1}) . W_k )          -- k_aggregate (A.X, HBM-bound) then k_gemm (fp32 MFMA)
+//   pooling   g   = sum_rows concat(H1,H2,H3)              -- per-32-row partial sums written by the producing kernel
+//                                                            (deterministic, no atomics), folded by k_pool_reduce
+//   head      y   = softmax2( relu(g W_fc + b_fc) W_out + b_out )[:,0]   -- the same fp32 MFMA GEMM, other epilogues
+//
+// Arithmetic is fp32 throughout (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains); the reference tolerance is 1e-4
+// absolute on the scores (north_star), checked against oracle/gcn_oracle.py.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "common.h"
+
+struct mdf_model {
+    int device = 0;
+    int embed = 0, n_gc = 0, gc[3] = {0, 0, 0}, fc = 0, T = 0, feat = 0;
+    int n_out_pad = 0;            // 2T rounded up to the GEMM's BN
+    float *T1 = nullptr;          // (26, gc0)      relu(W_aa) @ W_gc1, computed in double on the host
+    float *Wt[3] = {nullptr, nullptr, nullptr};  // k>=1: (gc_k, gc_{k-1}) = W_gc{k+1}^T  ([N][K], K contiguous)
+    float *Wfc_t = nullptr;       // (fc, feat)
+    float *bfc = nullptr;         // (fc)
+    float *Wout_t = nullptr;      // (n_out_pad, fc), rows >= 2T zero
+    float *bout = nullptr;        // (n_out_pad)
+    // session scratch of mdf_gcn_forward_host (grown on demand)
+    void *host_ws = nullptr;
+    size_t host_ws_bytes = 0;
+};
+
+namespace mdf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;  // LDS row stride 36 floats: conflict-free ds_read_b128
+constexpr int GEMM_LDS_BYTES = 2 /*buffers*/ * 2 /*A,B*/ * BM * LDT * 4;
+
+enum Epilogue { EPI_ELU_POOL_STORE = 0, EPI_ELU_POOL = 1, EPI_BIAS_RELU = 2, EPI_BIAS_SOFTMAX2 = 3 };
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expf(x) - 1.0f; }
+
+// XCD-aware tile order: block b runs on XCD b%8 (observed placement; used for L2 affinity only).  The NT column
+// tiles of one 128-row tile are issued back to back on the same XCD so that the A rows are fetched into that
+// XCD's L2 once; row tile t lives on XCD t%8 in every kernel of the layer chain.
+__device__ __forceinline__ void tile_of_block(int b, int NT, int &mt, int &nt)
+{
+    const int x = b & 7, q = b >> 3;
+    nt = q % NT;
+    mt = (q / NT) * 8 + x;
+}
+
+// C[M,N] = epilogue(A[M,K] . Bt[N,K]^T).  A rows >= M read as zero.  N % 128 == 0, K % 32 == 0 (host-checked).
+// 256 threads = 4 waves in a 2x2 grid; each wave owns a 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator
+// VGPRs).  Operands are staged global -> VGPR -> LDS (double-buffered, one barrier per k-tile): while the MFMAs of
+// k-tile t run, the loads of k-tile t+1 are in flight.  Fragment reads are ds_read_b128: lane l takes row (l&31)
+// and 4 consecutive k at (l>>5)*4, so the two k-slots of one 32x32x2 MFMA are k and k+4 -- any pairing is valid as
+// long as A and B agree.
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb,
+                                                     int M, int N, int K, float *__restrict__ C, int ldc,
+                                                     const float *__restrict__ bias, float *__restrict__ pool_partial,
+                                                     float *__restrict__ logits, int n_real)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                   // [2][BM][LDT]
+    float *Bs = smem + 2 * BM * LDT;    // [2][BN][LDT]
+
+    int mt, nt;
+    tile_of_block(blockIdx.x, N / BN, mt, nt);
+    const int m0 = mt * BM, n0 = nt * BN;
+    if (m0 >= M) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // staging assignment: float4 index f = tid + 256*i, row = f/8, col4 = f%8
+    const int srow = tid >> 3, scol = (tid & 7) * 4;
+    float4 ra[4], rb[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 32 * i;
+            const int gm = m0 + r;
+            ra[i] = gm < M ? *reinterpret_cast<const float4 *>(A + (size_t)gm * lda + k0 + scol) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rb[i] = *reinterpret_cast<const float4 *>(Bt + (size_t)(n0 + r) * ldb + k0 + scol);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 32 * i;
+            *reinterpret_cast<float4 *>(As + (buf * BM + r) * LDT + scol) = ra[i];
+            *reinterpret_cast<float4 *>(Bs + (buf * BN + r) * LDT + scol) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int nk = K / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        const float *Ab = As + (cur * BM + wm * 64 + frow) * LDT + fk;
+        const float *Bb = Bs + (cur * BN + wn * 64 + frow) * LDT + fk;
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(Ab + kg * 8);
+            const float4 a1 = *reinterpret_cast<const float4 *>(Ab + 32 * LDT + kg * 8);
+            const float4 b0 = *reinterpret_cast<const float4 *>(Bb + kg * 8);
+            const float4 b1 = *reinterpret_cast<const float4 *>(Bb + 32 * LDT + kg * 8);
+#define MDF_MFMA4(c)                                                                          \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b0.c, acc[0][0], 0, 0, 0);          \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b1.c, acc[0][1], 0, 0, 0);          \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b0.c, acc[1][0], 0, 0, 0);          \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b1.c, acc[1][1], 0, 0, 0);
+            MDF_MFMA4(x) MDF_MFMA4(y) MDF_MFMA4(z) MDF_MFMA4(w)
+#undef MDF_MFMA4
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: lane l, register r -> col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+    const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int rbase = m0 + wm * 64 + tm * 32;
+            const int col = n0 + wn * 64 + tn * 32 + lcol;
+            if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL) {
+                float s = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+                    const float v = elu1(acc[tm][tn][r]);
+                    s += v;
+                    if (EPI == EPI_ELU_POOL_STORE) C[(size_t)row * ldc + col] = v;
+                }
+                s += __shfl_xor(s, 32, 64);
+                if (lane < 32) pool_partial[(size_t)(rbase >> 5) * N + col] = s;
+            } else if (EPI == EPI_BIAS_RELU) {
+                const float bv = bias[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+                    if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[tm][tn][r] + bv, 0.0f);
+                }
+            } else {  // EPI_BIAS_SOFTMAX2: columns (2t, 2t+1) are the two channels of term t; keep channel 0
+                const float bv = bias[col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+                    const float z = acc[tm][tn][r] + bv;
+                    const float zo = __shfl_xor(z, 1, 64);
+                    if (row < M && col < n_real) {
+                        if (logits) logits[(size_t)row * n_real + col] = z;
+                        if ((col & 1) == 0) {
+                            const float mx = fmaxf(z, zo);
+                            const float e0 = expf(z - mx), e1 = expf(zo - mx);
+                            C[(size_t)row * ldc + (col >> 1)] = e0 / (e0 + e1);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- A.X aggregation: out[i,:] = sum_e val[e] * H[colidx[e],:]  over the CSR row i.  One wave per row, lane l owns
+// channels [4l,4l+4) of every 256-channel slab (float4 loads/stores: 1 KiB per wave instruction).  Row index, CSR
+// bounds, column indices and values are wave-uniform -> scalar loads.  Row tiles follow the GEMM's XCD placement.
+template <int C>
+__global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, const int32_t *__restrict__ rowptr,
+                                                   const int32_t *__restrict__ colidx, const float *__restrict__ val,
+                                                   float *__restrict__ out, int R)
+{
+    constexpr int NV = C / 256;
+    const int b = blockIdx.x, x = b & 7, q = b >> 3;
+    const int mt = (q >> 5) * 8 + x;                       // 128-row tile
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = mt * 128 + (q & 31) * 4 + wid;
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    float4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = e0;
+    for (; e + 4 <= e1; e += 4) {
+        int c[4];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c[u] = colidx[e + u];
+            w[u] = val[e + u];
+        }
+        float4 h[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                h[u][v] = *reinterpret_cast<const float4 *>(H + (size_t)c[u] * C + v * 256 + lane * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                acc[v].x = fmaf(w[u], h[u][v].x, acc[v].x);
+                acc[v].y = fmaf(w[u], h[u][v].y, acc[v].y);
+                acc[v].z = fmaf(w[u], h[u][v].z, acc[v].z);
+                acc[v].w = fmaf(w[u], h[u][v].w, acc[v].w);
+            }
+    }
+    for (; e < e1; ++e) {
+        const int c = colidx[e];
+        const float w = val[e];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 h = *reinterpret_cast<const float4 *>(H + (size_t)c * C + v * 256 + lane * 4);
+            acc[v].x = fmaf(w, h.x, acc[v].x);
+            acc[v].y = fmaf(w, h.y, acc[v].y);
+            acc[v].z = fmaf(w, h.z, acc[v].z);
+            acc[v].w = fmaf(w, h.w, acc[v].w);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(out + (size_t)row * C + v * 256 + lane * 4) = acc[v];
+}
+
+// ---- layer 1: H1[i,:] = elu(sum_e val[e] * T1[seq[colidx[e]],:]) with the 26 x C table in LDS; one block per
+// 32-row group (wave = 8 consecutive rows), which also emits the group's pooled partial sums.
+template <int C>
+__global__ __launch_bounds__(256) void k_layer1(const float *__restrict__ T1, const uint8_t *__restrict__ seq_idx,
+                                                const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
+                                                const float *__restrict__ val, float *__restrict__ H1,
+                                                float *__restrict__ pool_partial, int R)
+{
+    constexpr int NV = C / 256;
+    __shared__ __attribute__((aligned(16))) float tab[26 * C];
+    __shared__ __attribute__((aligned(16))) float red[4 * C];
+    for (int i = threadIdx.x; i < 26 * C / 4; i += 256)
+        reinterpret_cast<float4 *>(tab)[i] = reinterpret_cast<const float4 *>(T1)[i];
+    __syncthreads();
+    const int b = blockIdx.x, x = b & 7, q = b >> 3;
+    const int g = ((q >> 2) * 8 + x) * 4 + (q & 3);  // 32-row group, same XCD placement as the 128-row tiles
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float4 ps[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ps[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g * 32 < R) {
+        for (int r = 0; r < 8; ++r) {
+            const int row = g * 32 + wid * 8 + r;
+            const int e0 = rowptr[row], e1 = rowptr[row + 1];
+            float4 acc[NV];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = e0; e < e1; ++e) {
+                const int a = min((int)seq_idx[colidx[e]], 25);
+                const float w = val[e];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const float4 t = *reinterpret_cast<const float4 *>(tab + a * C + v * 256 + lane * 4);
+                    acc[v].x = fmaf(w, t.x, acc[v].x);
+                    acc[v].y = fmaf(w, t.y, acc[v].y);
+                    acc[v].z = fmaf(w, t.z, acc[v].z);
+                    acc[v].w = fmaf(w, t.w, acc[v].w);
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float4 h;
+                h.x = elu1(acc[v].x); h.y = elu1(acc[v].y); h.z = elu1(acc[v].z); h.w = elu1(acc[v].w);
+                *reinterpret_cast<float4 *>(H1 + (size_t)row * C + v * 256 + lane * 4) = h;
+                ps[v].x += h.x; ps[v].y += h.y; ps[v].z += h.z; ps[v].w += h.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(red + wid * C + v * 256 + lane * 4) = ps[v];
+    __syncthreads();
+    if (g * 32 < R) {
+        for (int c = threadIdx.x; c < C; c += 256)
+            pool_partial[(size_t)g * C + c] = ((red[c] + red[C + c]) + red[2 * C + c]) + red[3 * C + c];
+    }
+}
+
+// pooled[p, off + c] = sum over the 32-row groups of protein p of partial[g, c]
+__global__ void k_pool_reduce(const float *__restrict__ partial, int C, const int32_t *__restrict__ row_off,
+                              float *__restrict__ pooled, int feat, int off)
+{
+    const int p = blockIdx.x;
+    const int g0 = row_off[p] >> 5, g1 = row_off[p + 1] >> 5;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.0f;
+        for (int g = g0; g < g1; ++g) s += partial[(size_t)g * C + c];
+        pooled[(size_t)p * feat + off + c] = s;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+static int set_gemm_attr_once()
+{
+    static bool done = false;
+    if (done) return MDF_OK;
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_ELU_POOL_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_ELU_POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_BIAS_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_BIAS_SOFTMAX2>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    done = true;
+    return MDF_OK;
+}
+
+template <int EPI>
+static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M, int N, int K, float *C, int ldc,
+                       const float *bias, float *pool_partial, float *logits, int n_real, hipStream_t st)
+{
+    MDF_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d", M, N, K);
+    if (int rc = set_gemm_attr_once()) return rc;
+    const int MT = (M + BM - 1) / BM, NT = N / BN;
+    const int blocks = 8 * NT * ((MT + 7) / 8);
+    hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3(blocks), dim3(256), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
+                       pool_partial, logits, n_real);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+static int upload(float **dst, const float *src, size_t count)
+{
+    MDF_HIP(hipMalloc(reinterpret_cast<void **>(dst), std::max<size_t>(count, 1) * sizeof(float)));
+    if (count) MDF_HIP(hipMemcpy(*dst, src, count * sizeof(float), hipMemcpyHostToDevice));
+    return MDF_OK;
+}
+
+static std::vector<float> transpose(const float *W, int rows, int cols, int pad_cols_to)
+{
+    // (rows, cols) -> (pad_cols_to, rows), zero rows for the padding
+    std::vector<float> t((size_t)pad_cols_to * rows, 0.0f);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = W[(size_t)r * cols + c];
+    return t;
+}
+
+struct GcnWs {
+    float *Ha, *Hb, *AH, *partial[3];
+};
+static size_t gcn_ws_bytes(const mdf_model *m, int64_t R)
+{
+    int cmax = 0;
+    size_t part = 0;
+    for (int k = 0; k < m->n_gc; ++k) {
+        cmax = std::max(cmax, m->gc[k]);
+        part += align_up((size_t)(R / 32) * m->gc[k] * 4, 256);
+    }
+    return 3 * align_up((size_t)R * cmax * 4, 256) + part + 4096;
+}
+
+}  // namespace mdf
+
+using namespace mdf;
+
+extern "C" {
+
+int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
+{
+    MDF_REQUIRE(w && out, "model_create: NULL argument");
+    MDF_REQUIRE(w->n_gc >= 1 && w->n_gc <= 3, "model_create: n_gc=%d not in 1..3", w->n_gc);
+    MDF_REQUIRE(w->embed > 0 && w->fc_dim > 0 && w->n_terms > 0, "model_create: bad dimensions");
+    MDF_REQUIRE(w->fc_dim % BN == 0, "model_create: fc_dim=%d must be a multiple of %d", w->fc_dim, BN);
+    int feat = 0;
+    for (int k = 0; k < w->n_gc; ++k) {
+        MDF_REQUIRE(w->gc_dims[k] == 256 || w->gc_dims[k] == 512 || w->gc_dims[k] == 1024,
+                    "model_create: GraphConv width %d unsupported (256, 512 or 1024)", w->gc_dims[k]);
+        MDF_REQUIRE(w->W_gc[k], "model_create: W_gc[%d] is NULL", k);
+        feat += w->gc_dims[k];
+    }
+    MDF_REQUIRE(w->W_aa && w->W_fc && w->b_fc && w->W_out && w->b_out, "model_create: NULL weight pointer");
+    if (int rc = require_device()) return rc;
+    MDF_HIP(hipSetDevice(device));
+    mdf_model *m = new mdf_model();
+    m->device = device;
+    m->embed = w->embed;
+    m->n_gc = w->n_gc;
+    for (int k = 0; k < 3; ++k) m->gc[k] = k < w->n_gc ? w->gc_dims[k] : 0;
+    m->fc = w->fc_dim;
+    m->T = w->n_terms;
+    m->feat = feat;
+    m->n_out_pad = (2 * w->n_terms + BN - 1) / BN * BN;
+    int rc = MDF_OK;
+    {
+        // T1 = relu(W_aa) @ W_gc1 in double, rounded once to f32
+        const int E = w->embed, C0 = w->gc_dims[0];
+        std::vector<double> acc((size_t)26 * C0, 0.0);
+        for (int a = 0; a < 26; ++a)
+            for (int e = 0; e < E; ++e) {
+                const double x = w->W_aa[(size_t)a * E + e];
+                if (x <= 0.0) continue;
+                const float *wr = w->W_gc[0] + (size_t)e * C0;
+                double *ar = acc.data() + (size_t)a * C0;
+                for (int c = 0; c < C0; ++c) ar[c] += x * (double)wr[c];
+            }
+        std::vector<float> t1(acc.size());
+        for (size_t i = 0; i < acc.size(); ++i) t1[i] = (float)acc[i];
+        rc = upload(&m->T1, t1.data(), t1.size());
+    }
+    for (int k = 1; k < w->n_gc && rc == MDF_OK; ++k) {
+        auto t = transpose(w->W_gc[k], w->gc_dims[k - 1], w->gc_dims[k], w->gc_dims[k]);
+        rc = upload(&m->Wt[k], t.data(), t.size());
+    }
+    if (rc == MDF_OK) {
+        auto t = transpose(w->W_fc, feat, w->fc_dim, w->fc_dim);
+        rc = upload(&m->Wfc_t, t.data(), t.size());
+    }
+    if (rc == MDF_OK) rc = upload(&m->bfc, w->b_fc, (size_t)w->fc_dim);
+    if (rc == MDF_OK) {
+        auto t = transpose(w->W_out, w->fc_dim, 2 * w->n_terms, m->n_out_pad);
+        rc = upload(&m->Wout_t, t.data(), t.size());
+    }
+    if (rc == MDF_OK) {
+        std::vector<float> b((size_t)m->n_out_pad, 0.0f);
+        std::copy(w->b_out, w->b_out + 2 * w->n_terms, b.begin());
+        rc = upload(&m->bout, b.data(), b.size());
+    }
+    if (rc != MDF_OK) {
+        mdf_model_free(m);
+        return rc;
+    }
+    *out = m;
+    return MDF_OK;
+}
+
+void mdf_model_free(mdf_model *m)
+{
+    if (!m) return;
+    (void)hipFree(m->T1);
+    for (int k = 0; k < 3; ++k) (void)hipFree(m->Wt[k]);
+    (void)hipFree(m->Wfc_t);
+    (void)hipFree(m->bfc);
+    (void)hipFree(m->Wout_t);
+    (void)hipFree(m->bout);
+    (void)hipFree(m->host_ws);
+    delete m;
+}
+
+int mdf_model_num_terms(const mdf_model *m) { return m ? m->T : fail(MDF_EINVAL, "model is NULL"); }
+int mdf_model_feature_dim(const mdf_model *m) { return m ? m->feat : fail(MDF_EINVAL, "model is NULL"); }
+int mdf_model_device(const mdf_model *m) { return m ? m->device : fail(MDF_EINVAL, "model is NULL"); }
+
+/* .mdfw container: "MDFW0001" | u32 n | n x { char name[32]; u32 ndim; u64 dims[4]; u64 offset } | raw f32 data */
+int mdf_model_load(const char *path, int device, mdf_model **out)
+{
+    MDF_REQUIRE(path && out, "model_load: NULL argument");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(MDF_EIO, "model_load: cannot open '%s'", path);
+    std::vector<char> buf;
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    if (sz < 12) {
+        fclose(f);
+        return fail(MDF_EIO, "model_load: '%s' is too short", path);
+    }
+    buf.resize((size_t)sz);
+    const size_t got = fread(buf.data(), 1, (size_t)sz, f);
+    fclose(f);
+    if (got != (size_t)sz || memcmp(buf.data(), "MDFW0001", 8) != 0)
+        return fail(MDF_EIO, "model_load: '%s' is not an MDFW0001 container", path);
+    uint32_t n = 0;
+    memcpy(&n, buf.data() + 8, 4);
+    struct Entry {
+        char name[32];
+        uint32_t ndim;
+        uint64_t dims[4], offset;
+    };
+    const size_t esz = 32 + 4 + 8 * 5;
+    if (12 + (size_t)n * esz > (size_t)sz) return fail(MDF_EIO, "model_load: truncated directory in '%s'", path);
+    auto find = [&](const char *name, Entry &e) -> bool {
+        for (uint32_t i = 0; i < n; ++i) {
+            const char *p = buf.data() + 12 + (size_t)i * esz;
+            if (strncmp(p, name, 32) == 0) {
+                memcpy(e.name, p, 32);
+                memcpy(&e.ndim, p + 32, 4);
+                memcpy(e.dims, p + 36, 32);
+                memcpy(&e.offset, p + 68, 8);
+                uint64_t cnt = 1;
+                for (uint32_t d = 0; d < e.ndim && d < 4; ++d) cnt *= e.dims[d];
+                return e.ndim >= 1 && e.ndim <= 4 && e.offset + cnt * 4 <= (uint64_t)sz;
+            }
+        }
+        return false;
+    };
+    mdf_gcn_weights w;
+    memset(&w, 0, sizeof(w));
+    Entry e;
+    if (!find("W_aa", e) || e.ndim != 2 || e.dims[0] != 26) return fail(MDF_EIO, "model_load: W_aa missing or not (26,E)");
+    w.embed = (int32_t)e.dims[1];
+    w.W_aa = reinterpret_cast<const float *>(buf.data() + e.offset);
+    int prev = w.embed;
+    for (int k = 0; k < 3; ++k) {
+        char nm[16];
+        snprintf(nm, sizeof(nm), "W_gc%d", k + 1);
+        if (!find(nm, e)) break;
+        if (e.ndim != 2 || (int)e.dims[0] != prev) return fail(MDF_EIO, "model_load: %s has the wrong shape", nm);
+        w.gc_dims[k] = (int32_t)e.dims[1];
+        w.W_gc[k] = reinterpret_cast<const float *>(buf.data() + e.offset);
+        prev = w.gc_dims[k];
+        w.n_gc = k + 1;
+    }
+    int feat = 0;
+    for (int k = 0; k < w.n_gc; ++k) feat += w.gc_dims[k];
+    if (!find("W_fc", e) || e.ndim != 2 || (int)e.dims[0] != feat) return fail(MDF_EIO, "model_load: W_fc missing or wrong shape");
+    w.fc_dim = (int32_t)e.dims[1];
+    w.W_fc = reinterpret_cast<const float *>(buf.data() + e.offset);
+    if (!find("b_fc", e) || (int)e.dims[0] != w.fc_dim) return fail(MDF_EIO, "model_load: b_fc missing or wrong shape");
+    w.b_fc = reinterpret_cast<const float *>(buf.data() + e.offset);
+    if (!find("W_out", e) || e.ndim != 2 || (int)e.dims[0] != w.fc_dim || e.dims[1] % 2) return fail(MDF_EIO, "model_load: W_out missing or wrong shape");
+    w.n_terms = (int32_t)(e.dims[1] / 2);
+    w.W_out = reinterpret_cast<const float *>(buf.data() + e.offset);
+    if (!find("b_out", e) || (int)e.dims[0] != 2 * w.n_terms) return fail(MDF_EIO, "model_load: b_out missing or wrong shape");
+    w.b_out = reinterpret_cast<const float *>(buf.data() + e.offset);
+    return mdf_model_create(&w, device, out);
+}
+
+size_t mdf_gcn_workspace_bytes(const mdf_model *m, int64_t R) { return m ? gcn_ws_bytes(m, R) : 0; }
+
+int mdf_gcn_embed_pool_dev(mdf_model *m, const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx,
+                           const float *val, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                           float *pooled, void *workspace, size_t workspace_bytes, void *stream)
+{
+    (void)Lq;
+    MDF_REQUIRE(m && seq_idx && rowptr && colidx && val && row_off && pooled && workspace, "gcn_embed_pool_dev: NULL argument");
+    MDF_REQUIRE(B > 0 && R > 0 && R % 128 == 0 && R < 0x7fffffff, "gcn_embed_pool_dev: bad layout (B=%d, R=%lld)", B, (long long)R);
+    if (workspace_bytes < gcn_ws_bytes(m, R))
+        return fail(MDF_ECAPACITY, "gcn_embed_pool_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, gcn_ws_bytes(m, R));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver cv(workspace, workspace_bytes);
+    int cmax = 0;
+    for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
+    float *Ha = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax);
+    float *partial[3] = {nullptr, nullptr, nullptr};
+    for (int k = 0; k < m->n_gc; ++k) partial[k] = cv.take<float>((size_t)(R / 32) * m->gc[k]);
+    const int Ri = (int)R, MT = Ri / 128;
+    const int tiles8 = (MT + 7) / 8;
+
+    // layer 1 (folded embedding)
+    {
+        const int blocks = 8 * 4 * tiles8;
+        const int C0 = m->gc[0];
+#define MDF_L1(CC) hipLaunchKernelGGL(k_layer1<CC>, dim3(blocks), dim3(256), 0, st, m->T1, seq_idx, rowptr, colidx, val, Ha, partial[0], Ri)
+        if (C0 == 256) MDF_L1(256); else if (C0 == 512) MDF_L1(512); else return fail(MDF_EINVAL, "layer 1 width %d unsupported (256 or 512)", C0);
+#undef MDF_L1
+    }
+    float *Hin = Ha, *Hout = Hb;
+    for (int k = 1; k < m->n_gc; ++k) {
+        const int Cin = m->gc[k - 1], Cout = m->gc[k];
+        {
+            ScopedTiming tm(TK_AX, st);
+            const int blocks = 8 * 32 * tiles8;
+#define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, Ri)
+            if (Cin == 256) MDF_AX(256); else if (Cin == 512) MDF_AX(512); else MDF_AX(1024);
+#undef MDF_AX
+        }
+        {
+            ScopedTiming tm(TK_GEMM, st);
+            const bool last = k == m->n_gc - 1;
+            int rc;
+            if (last)
+                rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial[k], nullptr, Cout, st);
+            else
+                rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial[k], nullptr, Cout, st);
+            if (rc) return rc;
+        }
+        std::swap(Hin, Hout);
+    }
+    int off = 0;
+    for (int k = 0; k < m->n_gc; ++k) {
+        hipLaunchKernelGGL(k_pool_reduce, dim3(B), dim3(256), 0, st, partial[k], m->gc[k], row_off, pooled, m->feat, off);
+        off += m->gc[k];
+    }
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+size_t mdf_head_workspace_bytes(const mdf_model *m, int32_t B) { return m ? align_up((size_t)std::max(B, 1) * m->fc * 4, 256) + 256 : 0; }
+
+int mdf_gcn_head_dev(mdf_model *m, const float *pooled, int32_t B, float *scores, float *logits, void *workspace,
+                     size_t workspace_bytes, void *stream)
+{
+    MDF_REQUIRE(m && pooled && scores && workspace && B > 0, "gcn_head_dev: bad argument");
+    if (workspace_bytes < mdf_head_workspace_bytes(m, B)) return fail(MDF_ECAPACITY, "gcn_head_dev: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *f = static_cast<float *>(workspace);
+    ScopedTiming tm(TK_HEAD, st);
+    if (int rc = launch_gemm<EPI_BIAS_RELU>(pooled, m->feat, m->Wfc_t, m->feat, B, m->fc, m->feat, f, m->fc, m->bfc, nullptr, nullptr, m->fc, st)) return rc;
+    if (int rc = launch_gemm<EPI_BIAS_SOFTMAX2>(f, m->fc, m->Wout_t, m->fc, B, m->n_out_pad, m->fc, scores, m->T, m->bout, nullptr, logits, 2 * m->T, st)) return rc;
+    return MDF_OK;
+}
+
+int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *cmap, int cmap_dtype, float *scores,
+                         int64_t *bad_idx)
+{
+    MDF_REQUIRE(m && seq && cmap && scores && L > 0, "gcn_forward_host: bad argument (empty sequences are not supported)");
+    MDF_REQUIRE(L < 46000, "gcn_forward_host: L=%lld too long", (long long)L);
+    MDF_REQUIRE(cmap_dtype >= MDF_DT_I32 && cmap_dtype <= MDF_DT_U8, "gcn_forward_host: unknown cmap dtype %d", cmap_dtype);
+    if (bad_idx) *bad_idx = -1;
+    if (int rc = require_device()) return rc;
+    MDF_HIP(hipSetDevice(m->device));
+    const int64_t es = cmap_dtype == MDF_DT_U8 ? 1 : (cmap_dtype == MDF_DT_I64 || cmap_dtype == MDF_DT_F64) ? 8 : 4;
+    int32_t Lq[1] = {(int32_t)L}, row_off[2];
+    const int64_t R = mdf_layout_rows(Lq, 1, row_off);
+    const int64_t nnz_cap = std::min<int64_t>(L * L, 0x7ffffff0);
+    const size_t cws = mdf_cmap_workspace_bytes(1, R), gws = gcn_ws_bytes(m, R), hws = mdf_head_workspace_bytes(m, 1);
+    // layout of the session scratch
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    const size_t o_desc = take(256), o_seq = take((size_t)L), o_idx = take((size_t)R), o_cm = take((size_t)L * L * es),
+                 o_rp = take((size_t)(R + 1) * 4), o_ci = take((size_t)nnz_cap * 4), o_va = take((size_t)nnz_cap * 4),
+                 o_cws = take(cws), o_gws = take(gws), o_hws = take(hws), o_pool = take((size_t)m->feat * 4),
+                 o_sc = take((size_t)m->T * 4);
+    if (m->host_ws_bytes < o) {
+        (void)hipFree(m->host_ws);
+        m->host_ws = nullptr;
+        m->host_ws_bytes = 0;
+        MDF_HIP(hipMalloc(&m->host_ws, o));
+        m->host_ws_bytes = o;
+    }
+    char *b = static_cast<char *>(m->host_ws);
+    struct Desc {
+        int32_t Lq[2], row_off[2], seq_off[2], bad[2], status[4];
+        int64_t cmap_off[1];
+    } d;
+    memset(&d, 0, sizeof(d));
+    d.Lq[0] = (int32_t)L;
+    d.row_off[0] = row_off[0];
+    d.row_off[1] = row_off[1];
+    MDF_HIP(hipMemcpyAsync(b + o_desc, &d, sizeof(d), hipMemcpyHostToDevice, nullptr));
+    MDF_HIP(hipMemcpyAsync(b + o_seq, seq, (size_t)L, hipMemcpyHostToDevice, nullptr));
+    MDF_HIP(hipMemcpyAsync(b + o_cm, cmap, (size_t)L * L * es, hipMemcpyHostToDevice, nullptr));
+    Desc *dd = reinterpret_cast<Desc *>(b + o_desc);
+    uint8_t *d_idx = reinterpret_cast<uint8_t *>(b + o_idx);
+    int32_t *d_rp = reinterpret_cast<int32_t *>(b + o_rp), *d_ci = reinterpret_cast<int32_t *>(b + o_ci);
+    float *d_va = reinterpret_cast<float *>(b + o_va), *d_pool = reinterpret_cast<float *>(b + o_pool),
+          *d_sc = reinterpret_cast<float *>(b + o_sc);
+    if (int rc = mdf_seq_encode_dev(b + o_seq, dd->seq_off, dd->Lq, dd->row_off, 1, R, d_idx, dd->bad, nullptr)) return rc;
+    if (int rc = mdf_dense_to_csr_dev(b + o_cm, cmap_dtype, dd->cmap_off, dd->Lq, dd->row_off, 1, R, d_rp, d_ci, d_va, nnz_cap,
+                                      dd->status, b + o_cws, cws, nullptr))
+        return rc;
+    if (int rc = mdf_gcn_embed_pool_dev(m, d_idx, d_rp, d_ci, d_va, dd->Lq, dd->row_off, 1, R, d_pool, b + o_gws, gws, nullptr)) return rc;
+    if (int rc = mdf_gcn_head_dev(m, d_pool, 1, d_sc, nullptr, b + o_hws, hws, nullptr)) return rc;
+    Desc back;
+    MDF_HIP(hipMemcpy(&back, b + o_desc, sizeof(back), hipMemcpyDeviceToHost));
+    if (back.bad[0] != 0) {
+        if (bad_idx) *bad_idx = back.bad[1];
+        return fail(MDF_EBADCHAR, "Invalid character in sequence at index %d", back.bad[1]);
+    }
+    if (back.status[0] != 0) return fail(MDF_ECAPACITY, "gcn_forward_host: CSR overflow (%d entries)", back.status[1]);
+    MDF_HIP(hipMemcpy(scores, d_sc, (size_t)m->T * 4, hipMemcpyDeviceToHost));
+    return MDF_OK;
+}
+
+}  // extern "C"

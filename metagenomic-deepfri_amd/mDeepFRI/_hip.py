@@ -1,0 +1,129 @@
+"""ctypes binding of libmdfri_hip.so (C ABI: include/mdfri.h).
+
+The library is the product: there is no CPU fallback.  Importing this module never touches the GPU;
+the first compute call does.  If the shared library has not been built the import of any mDeepFRI
+compute module fails loudly with the build command.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_void_p
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("MDFRI_HIP_LIB", os.path.join(os.path.dirname(_PKG_DIR), "lib", "libmdfri_hip.so"))
+
+MDF_OK, MDF_EINVAL, MDF_ENODEVICE, MDF_ENOMEM, MDF_EBADCHAR, MDF_ECAPACITY, MDF_EIO = 0, -1, -2, -3, -4, -5, -6
+DT_I32, DT_F32, DT_I64, DT_F64, DT_U8 = 0, 1, 2, 3, 4
+
+
+class MdfriError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libmdfri_hip error {code}: {message}")
+        self.code = code
+
+
+class CapacityError(MdfriError):
+    pass
+
+
+class GcnWeights(ctypes.Structure):
+    _fields_ = [
+        ("embed", c_int32), ("n_gc", c_int32), ("gc_dims", c_int32 * 3), ("fc_dim", c_int32), ("n_terms", c_int32),
+        ("W_aa", POINTER(c_float)), ("W_gc", POINTER(c_float) * 3), ("W_fc", POINTER(c_float)),
+        ("b_fc", POINTER(c_float)), ("W_out", POINTER(c_float)), ("b_out", POINTER(c_float)),
+    ]
+
+
+_f32p, _i32p, _i64p, _u8p = POINTER(c_float), POINTER(c_int32), POINTER(c_int64), POINTER(c_uint8)
+
+# name -> (restype, argtypes); every symbol include/mdfri.h declares
+SIGNATURES = {
+    "mdf_last_error": (c_char_p, []),
+    "mdf_version": (c_char_p, []),
+    "mdf_device_count": (c_int, []),
+    "mdf_pairwise_sqeuclidean_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int]),
+    "mdf_threshold_lt_i32": (c_int, [c_void_p, c_int64, c_float, c_void_p]),
+    "mdf_argwhere_eq1_i32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, _i64p]),
+    "mdf_calculate_contact_map": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int64, _i64p]),
+    "mdf_align_len": (c_int, [c_char_p, c_char_p, c_int64, _i64p]),
+    "mdf_align_contact_map": (c_int, [c_char_p, c_char_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_int]),
+    "mdf_build_align_contact_map": (c_int, [c_void_p, c_int64, c_char_p, c_char_p, c_int64, c_double, c_int, c_void_p]),
+    "mdf_seq2onehot": (c_int, [c_char_p, c_int64, c_void_p, _i64p]),
+    "mdf_model_create": (c_int, [POINTER(GcnWeights), c_int, POINTER(c_void_p)]),
+    "mdf_model_load": (c_int, [c_char_p, c_int, POINTER(c_void_p)]),
+    "mdf_model_free": (None, [c_void_p]),
+    "mdf_model_num_terms": (c_int, [c_void_p]),
+    "mdf_model_feature_dim": (c_int, [c_void_p]),
+    "mdf_model_device": (c_int, [c_void_p]),
+    "mdf_gcn_forward_host": (c_int, [c_void_p, c_char_p, c_int64, c_void_p, c_int, c_void_p, _i64p]),
+    "mdf_layout_rows": (c_int64, [c_void_p, c_int32, c_void_p]),
+    "mdf_seq_encode_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mdf_cmap_workspace_bytes": (c_size_t, [c_int32, c_int64]),
+    "mdf_cmap_csr_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
+                                 c_double, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_cmap_dense_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
+                                   c_double, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_dense_to_csr_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p,
+                                     c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_gcn_workspace_bytes": (c_size_t, [c_void_p, c_int64]),
+    "mdf_gcn_embed_pool_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_head_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
+    "mdf_gcn_head_dev": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_timing_enable": (c_int, [c_int]),
+    "mdf_timing_read": (c_int, [c_char_p, _i64p, POINTER(c_double)]),
+    "mdf_timing_reset": (c_int, []),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load libmdfri_hip.so; raise ImportError with the build recipe when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP extension has not been built and mDeepFRI (MI355X) has no CPU "
+                f"fallback.  Build it with `make -C {os.path.join(os.path.dirname(_PKG_DIR), 'csrc')}` "
+                f"(or `python -c 'import __graft_entry__ as g; g.build()'` from the repository root).")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return lib().mdf_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc == MDF_OK:
+        return
+    msg = last_error()
+    if rc == MDF_EINVAL or rc == MDF_EBADCHAR:
+        raise ValueError(msg)
+    if rc == MDF_ENOMEM:
+        raise MemoryError(msg)
+    if rc == MDF_ECAPACITY:
+        raise CapacityError(rc, msg)
+    if rc == MDF_EIO:
+        raise OSError(msg)
+    raise MdfriError(rc, msg)
+
+
+def ptr(a):
+    """Raw address of a NumPy array or a torch tensor (None -> NULL)."""
+    if a is None:
+        return None
+    if hasattr(a, "data_ptr"):
+        return c_void_p(a.data_ptr())
+    return c_void_p(a.ctypes.data)
+
+
+def device_count() -> int:
+    return int(lib().mdf_device_count())

@@ -1,0 +1,385 @@
+"""Batched counterparts of the reference's per-protein loops, built on the device entry points of mdfri.h.
+
+reference                                               here
+---------                                               ----
+pipeline.py:476-481  Pool.map(build_align_contact_map)  build_align_contact_maps()      (dense int32 maps out)
+pipeline.py:292-319  _run_prediction_loop               HotPathEngine.forward_*() + prediction_rows()
+
+`HotPathEngine.forward_alignments` is the fused path: C-alpha coordinates + gapped alignments + sequences go in,
+GO scores come out; the (L,L) maps never exist, the adjacency goes from the contact kernel to the GraphConv kernels
+as CSR in HBM.  PyTorch is used only to own device memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _hip
+
+
+def _torch():
+    import torch
+    return torch
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host-side packing
+# ---------------------------------------------------------------------------------------------------------------------
+def _offsets(lengths) -> np.ndarray:
+    off = np.zeros(len(lengths) + 1, dtype=np.int64)
+    np.cumsum(np.asarray(lengths, dtype=np.int64), out=off[1:])
+    if off[-1] >= 2**31 - 1:
+        raise ValueError("batch too large for int32 offsets; split it")
+    return off.astype(np.int32)
+
+
+@dataclass
+class Chunk:
+    p0: int
+    p1: int
+    rows: int              # R of this chunk (multiple of 128)
+    row_off_pos: int       # start of this chunk's row_off (p1-p0+1 entries) in PackedProteins.chunk_row_off
+
+
+@dataclass
+class PackedProteins:
+    """Proteins packed into flat arrays (host).  Coordinates / alignments are optional (dense-map path)."""
+    seqs: list
+    Lq: np.ndarray
+    seq_bytes: np.ndarray
+    seq_off: np.ndarray
+    coords: np.ndarray | None = None
+    coord_off: np.ndarray | None = None
+    q_aln: np.ndarray | None = None
+    t_aln: np.ndarray | None = None
+    aln_off: np.ndarray | None = None
+    chunks: list = field(default_factory=list)
+    chunk_row_off: np.ndarray | None = None
+
+    @property
+    def B(self) -> int:
+        return len(self.seqs)
+
+    @classmethod
+    def pack(cls, seqs, coords=None, q_alns=None, t_alns=None, max_rows: int = 32768):
+        seqs = list(seqs)
+        if not seqs:
+            raise ValueError("empty batch")
+        enc = [s.encode("ascii") for s in seqs]
+        Lq = np.array([len(b) for b in enc], dtype=np.int32)
+        if (Lq <= 0).any():
+            raise ValueError("empty sequence in batch")
+        pk = cls(seqs=seqs, Lq=Lq, seq_bytes=np.frombuffer(b"".join(enc), dtype=np.uint8).copy(), seq_off=_offsets(Lq))
+        if coords is not None:
+            if q_alns is None or t_alns is None or not (len(coords) == len(q_alns) == len(t_alns) == len(seqs)):
+                raise ValueError("coords, q_alns and t_alns must all be given, one per sequence")
+            cs = []
+            for c in coords:
+                c = np.asarray(c)
+                if c.dtype != np.float32 or c.ndim != 2 or c.shape[1] != 3:
+                    raise ValueError("coordinates must be float32 (Lt,3)")
+                cs.append(np.ascontiguousarray(c))
+            pk.coords = np.concatenate(cs, axis=0) if cs else np.zeros((0, 3), np.float32)
+            if pk.coords.shape[0] == 0:
+                pk.coords = np.zeros((1, 3), np.float32)
+            pk.coord_off = _offsets([c.shape[0] for c in cs])
+            qb = [q.encode("ascii") for q in q_alns]
+            tb = [t.encode("ascii") for t in t_alns]
+            for i, (q, t, s) in enumerate(zip(qb, tb, enc)):
+                if len(q) != len(t):
+                    raise ValueError(f"protein {i}: gapped query and target differ in length")
+                if len(q) - q.count(b"-") != len(s):
+                    raise ValueError(f"protein {i}: gapped query does not spell a sequence of length {len(s)}")
+            pk.q_aln = np.frombuffer(b"".join(qb), dtype=np.uint8).copy()
+            pk.t_aln = np.frombuffer(b"".join(tb), dtype=np.uint8).copy()
+            pk.aln_off = _offsets([len(q) for q in qb])
+        pk._plan(max_rows)
+        return pk
+
+    def _plan(self, max_rows: int):
+        L = _hip.lib()
+        self.chunks, offs = [], []
+        p0, B = 0, self.B
+        pad = (self.Lq.astype(np.int64) + 31) // 32 * 32
+        while p0 < B:
+            p1, rows = p0, 0
+            while p1 < B and (p1 == p0 or rows + pad[p1] <= max_rows):
+                rows += pad[p1]
+                p1 += 1
+            ro = np.zeros(p1 - p0 + 1, dtype=np.int32)
+            lq = np.ascontiguousarray(self.Lq[p0:p1])
+            R = L.mdf_layout_rows(_hip.ptr(lq), p1 - p0, _hip.ptr(ro))
+            if R < 0:
+                _hip.check(int(R))
+            self.chunks.append(Chunk(p0, p1, int(R), sum(len(o) for o in offs)))
+            offs.append(ro)
+            p0 = p1
+        self.chunk_row_off = np.concatenate(offs)
+
+    @property
+    def max_chunk_rows(self) -> int:
+        return max(c.rows for c in self.chunks)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device engine
+# ---------------------------------------------------------------------------------------------------------------------
+def _p(t, elem_offset: int = 0):
+    return ctypes.c_void_p(t.data_ptr() + elem_offset * t.element_size())
+
+
+class DeviceBatch:
+    """PackedProteins uploaded to one GPU (torch tensors)."""
+
+    def __init__(self, packed: PackedProteins, device):
+        torch = _torch()
+        self.packed = packed
+        self.device = device
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device, non_blocking=False)  # noqa: E731
+        self.Lq = up(packed.Lq)
+        self.seq_bytes = up(packed.seq_bytes)
+        self.seq_off = up(packed.seq_off)
+        self.chunk_row_off = up(packed.chunk_row_off)
+        self.coords = self.coord_off = self.q_aln = self.t_aln = self.aln_off = None
+        if packed.coords is not None:
+            self.coords, self.coord_off = up(packed.coords), up(packed.coord_off)
+            self.q_aln, self.t_aln, self.aln_off = up(packed.q_aln), up(packed.t_aln), up(packed.aln_off)
+        n = len(packed.chunks)
+        self.status = torch.zeros((n, 4), dtype=torch.int32, device=device)
+        self.bad = torch.zeros((n, 2), dtype=torch.int32, device=device)
+
+    @property
+    def B(self):
+        return self.packed.B
+
+
+class HotPathEngine:
+    """contact map + GCN forward for batches of proteins on one GPU, for one or several GO heads
+    (`predictors`: {mode: mDeepFRI.predict.Predictor}; all heads share the contact-map stage)."""
+
+    def __init__(self, predictors: dict, device: int = 0, max_rows: int = 32768, nnz_per_row: int = 40,
+                 threshold: float = 6.0, generated_contacts: int = 2):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("HotPathEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.L = _hip.lib()
+        self.predictors = dict(predictors)
+        self.device = torch.device(f"cuda:{device}")
+        self.max_rows = int(max_rows)
+        self.nnz_per_row = int(nnz_per_row)
+        self.threshold = float(threshold)
+        self.generated_contacts = int(generated_contacts)
+        self._rows_alloc = 0
+        self._bufs = {}
+
+    # -- memory ------------------------------------------------------------------------------------------------------
+    def _ensure(self, rows: int, n_proteins: int):
+        torch = _torch()
+        if rows > self._rows_alloc:
+            dev = self.device
+            cap = rows * self.nnz_per_row
+            gws = max(self.L.mdf_gcn_workspace_bytes(p.session.handle, rows) for p in self.predictors.values())
+            self._bufs = {
+                "rowptr": torch.empty(rows + 1, dtype=torch.int32, device=dev),
+                "colidx": torch.empty(cap, dtype=torch.int32, device=dev),
+                "val": torch.empty(cap, dtype=torch.float32, device=dev),
+                "seq_idx": torch.empty(rows, dtype=torch.uint8, device=dev),
+                "cws": torch.empty(self.L.mdf_cmap_workspace_bytes(1 << 20, rows), dtype=torch.uint8, device=dev),
+                "gws": torch.empty(gws, dtype=torch.uint8, device=dev),
+            }
+            self._rows_alloc, self._nnz_cap = rows, cap
+        hws = max(self.L.mdf_head_workspace_bytes(p.session.handle, n_proteins) for p in self.predictors.values())
+        if self._bufs.get("hws") is None or self._bufs["hws"].numel() < hws:
+            self._bufs["hws"] = torch.empty(hws, dtype=torch.uint8, device=self.device)
+
+    def upload(self, packed: PackedProteins) -> DeviceBatch:
+        return DeviceBatch(packed, self.device)
+
+    def _stream(self):
+        return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
+
+    # -- stages ------------------------------------------------------------------------------------------------------
+    def _gcn_chunk(self, db: DeviceBatch, ch: Chunk, pooled: dict, st):
+        b, Bc = self._bufs, ch.p1 - ch.p0
+        for mode, pred in self.predictors.items():
+            feat = pred.session.topology["feature_dim"]
+            _hip.check(self.L.mdf_gcn_embed_pool_dev(
+                pred.session.handle, _p(b["seq_idx"]), _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]), _p(db.Lq, ch.p0),
+                _p(db.chunk_row_off, ch.row_off_pos), Bc, ch.rows, _p(pooled[mode], ch.p0 * feat), _p(b["gws"]),
+                b["gws"].numel(), st))
+
+    def _heads(self, db: DeviceBatch, pooled: dict, want_logits: bool, st):
+        torch = _torch()
+        scores, logits = {}, {}
+        for mode, pred in self.predictors.items():
+            T = pred.n_terms
+            scores[mode] = torch.empty((db.B, T), dtype=torch.float32, device=self.device)
+            lg = torch.empty((db.B, 2 * T), dtype=torch.float32, device=self.device) if want_logits else None
+            _hip.check(self.L.mdf_gcn_head_dev(pred.session.handle, _p(pooled[mode]), db.B, _p(scores[mode]),
+                                               _p(lg) if lg is not None else None, _p(self._bufs["hws"]),
+                                               self._bufs["hws"].numel(), st))
+            if want_logits:
+                logits[mode] = lg
+        return (scores, logits) if want_logits else scores
+
+    def _alloc_pooled(self, db):
+        torch = _torch()
+        return {m: torch.empty((db.B, p.session.topology["feature_dim"]), dtype=torch.float32, device=self.device)
+                for m, p in self.predictors.items()}
+
+    def forward_alignments(self, db: DeviceBatch, want_logits: bool = False):
+        """Fused path: coords + alignments + sequences -> {mode: (B,T) float32 scores on the device}.  Asynchronous
+        on the current stream; call `check(db)` (one sync) before trusting the result."""
+        if db.coords is None:
+            raise ValueError("batch was packed without coordinates/alignments")
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            self._ensure(db.packed.max_chunk_rows, db.B)
+            b, st = self._bufs, self._stream()
+            pooled = self._alloc_pooled(db)
+            for ci, ch in enumerate(db.packed.chunks):
+                Bc = ch.p1 - ch.p0
+                ro = _p(db.chunk_row_off, ch.row_off_pos)
+                _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
+                                                     _p(b["seq_idx"]), _p(db.bad, ci * 2), st))
+                _hip.check(self.L.mdf_cmap_csr_dev(
+                    _p(db.coords), _p(db.coord_off, ch.p0), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off, ch.p0), _p(db.Lq, ch.p0), ro,
+                    Bc, ch.rows, self.threshold, self.generated_contacts, _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]),
+                    self._nnz_cap, _p(db.status, ci * 4), _p(b["cws"]), b["cws"].numel(), st))
+                self._gcn_chunk(db, ch, pooled, st)
+            return self._heads(db, pooled, want_logits, st)
+
+    def forward_dense(self, db: DeviceBatch, cmaps, want_logits: bool = False):
+        """Reference-format path: one dense (L,L) contact map per protein (what build_align_contact_map returns,
+        int32) -> scores.  Maps are uploaded chunk by chunk."""
+        torch = _torch()
+        if len(cmaps) != db.B:
+            raise ValueError("one contact map per protein expected")
+        with torch.cuda.device(self.device):
+            self._ensure(db.packed.max_chunk_rows, db.B)
+            b, st = self._bufs, self._stream()
+            pooled = self._alloc_pooled(db)
+            for ci, ch in enumerate(db.packed.chunks):
+                Bc = ch.p1 - ch.p0
+                ro = _p(db.chunk_row_off, ch.row_off_pos)
+                flat, offs = [], [0]
+                for p in range(ch.p0, ch.p1):
+                    A = np.asarray(cmaps[p])
+                    Lp = int(db.packed.Lq[p])
+                    if A.shape != (Lp, Lp):
+                        raise ValueError(f"protein {p}: cmap shape {A.shape} != ({Lp},{Lp})")
+                    flat.append(np.ascontiguousarray(A, dtype=np.float32 if A.dtype.kind == "f" else np.int32).reshape(-1))
+                    offs.append(offs[-1] + Lp * Lp)
+                kinds = {a.dtype for a in flat}
+                if len(kinds) > 1:
+                    flat = [a.astype(np.float32) for a in flat]
+                host = np.concatenate(flat)
+                d_maps = torch.from_numpy(host).to(self.device)
+                d_off = torch.from_numpy(np.asarray(offs[:-1], dtype=np.int64)).to(self.device)
+                nnz_needed = int(sum(int(np.count_nonzero(a)) for a in flat)) + ch.rows
+                if nnz_needed > self._nnz_cap:
+                    self._bufs["colidx"] = torch.empty(nnz_needed, dtype=torch.int32, device=self.device)
+                    self._bufs["val"] = torch.empty(nnz_needed, dtype=torch.float32, device=self.device)
+                    self._nnz_cap = nnz_needed
+                _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
+                                                     _p(b["seq_idx"]), _p(db.bad, ci * 2), st))
+                dt = _hip.DT_F32 if host.dtype == np.float32 else _hip.DT_I32
+                _hip.check(self.L.mdf_dense_to_csr_dev(_p(d_maps), dt, _p(d_off), _p(db.Lq, ch.p0), ro, Bc, ch.rows, _p(b["rowptr"]),
+                                                       _p(b["colidx"]), _p(b["val"]), self._nnz_cap, _p(db.status, ci * 4),
+                                                       _p(b["cws"]), b["cws"].numel(), st))
+                self._gcn_chunk(db, ch, pooled, st)
+                torch.cuda.current_stream(self.device).synchronize()  # d_maps / d_off are freed on loop exit
+            return self._heads(db, pooled, want_logits, st)
+
+    def check(self, db: DeviceBatch):
+        """Synchronise and raise what the asynchronous stages flagged (invalid residue, CSR overflow)."""
+        torch = _torch()
+        torch.cuda.current_stream(self.device).synchronize()
+        bad = db.bad.cpu().numpy()
+        for ci, ch in enumerate(db.packed.chunks):
+            if bad[ci, 0] != 0:
+                p = ch.p0 + int(bad[ci, 0]) - 1
+                c = db.packed.seqs[p][int(bad[ci, 1])]
+                raise ValueError(f"Invalid character in sequence: {c}")
+        st = db.status.cpu().numpy()
+        if (st[:, 0] != 0).any():
+            need = int(st[:, 1].max())
+            raise _hip.CapacityError(_hip.MDF_ECAPACITY,
+                                     f"CSR capacity {self._nnz_cap} too small (a chunk needs {need}); raise nnz_per_row")
+
+    def run_alignments(self, packed: PackedProteins) -> dict:
+        """Convenience: upload, run the fused path, validate, return {mode: np.ndarray (B,T)}.  On a CSR overflow the
+        capacity is raised once and the batch re-run."""
+        db = self.upload(packed)
+        out = self.forward_alignments(db)
+        try:
+            self.check(db)
+        except _hip.CapacityError:
+            need = int(db.status.cpu().numpy()[:, 1].max())
+            self.nnz_per_row = need // max(packed.max_chunk_rows, 1) + 8
+            self._rows_alloc = 0
+            db = self.upload(packed)
+            out = self.forward_alignments(db)
+            self.check(db)
+        return {m: t.cpu().numpy() for m, t in out.items()}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# batched build_align_contact_map (reference output format)
+# ---------------------------------------------------------------------------------------------------------------------
+def build_align_contact_maps(alignments, threshold: float = 6, generated_contacts: int = 2, device: int = 0,
+                             max_rows: int = 32768):
+    """Batched counterpart of `Pool(threads).map(build_align_contact_map, alignments)` (reference pipeline.py:476-481).
+    Returns [(alignment, int32 (Lq,Lq) | None), ...] in input order, None (with a warning) where coords is None."""
+    import logging
+    torch = _torch()
+    logger = logging.getLogger("mDeepFRI.bio_utils")
+    alignments = list(alignments)
+    results = [None] * len(alignments)
+    live = []
+    for i, a in enumerate(alignments):
+        if a.coords is None:
+            logger.warning(f"No coordinates found for {a.target_name}.")
+            results[i] = (a, None)
+        else:
+            live.append(i)
+    if not live:
+        return results
+    L = _hip.lib()
+    dev = torch.device(f"cuda:{device}")
+    seqs = [alignments[i].gapped_sequence.replace("-", "") for i in live]
+    nonempty = [k for k, s in enumerate(seqs) if len(s) > 0]
+    for k, s in enumerate(seqs):
+        if len(s) == 0:
+            results[live[k]] = (alignments[live[k]], np.zeros((0, 0), dtype=np.int32))
+    if not nonempty:
+        return results
+    live = [live[k] for k in nonempty]
+    seqs = [seqs[k] for k in nonempty]
+    pk = PackedProteins.pack(seqs, [alignments[i].coords for i in live], [alignments[i].gapped_sequence for i in live],
+                             [alignments[i].gapped_target for i in live], max_rows=max_rows)
+    with torch.cuda.device(dev):
+        db = DeviceBatch(pk, dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        cws = torch.empty(L.mdf_cmap_workspace_bytes(pk.B, pk.max_chunk_rows), dtype=torch.uint8, device=dev)
+        for ch in pk.chunks:
+            sizes = pk.Lq[ch.p0:ch.p1].astype(np.int64)**2
+            offs = np.zeros(len(sizes), dtype=np.int64)
+            np.cumsum(sizes[:-1], out=offs[1:])
+            out = torch.empty(int(sizes.sum()), dtype=torch.int32, device=dev)
+            d_off = torch.from_numpy(offs).to(dev)
+            _hip.check(L.mdf_cmap_dense_dev(_p(db.coords), _p(db.coord_off, ch.p0), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off, ch.p0),
+                                            _p(db.Lq, ch.p0), _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows,
+                                            float(threshold), int(generated_contacts), _p(out), _p(d_off), _p(cws), cws.numel(), st))
+            host = out.cpu().numpy()
+            for k, p in enumerate(range(ch.p0, ch.p1)):
+                Lp = int(pk.Lq[p])
+                results[live[p]] = (alignments[live[p]], host[offs[k]:offs[k] + Lp * Lp].reshape(Lp, Lp).copy())
+    return results
+
+
+def prediction_rows(query_ids, scores: np.ndarray, net_type: str = "gcn"):
+    """Rows exactly as reference pipeline.py:318 writes them: [query_id, net_type] + pred_vector.tolist()."""
+    return [[qid, net_type] + np.asarray(row, dtype=np.float32).tolist() for qid, row in zip(query_ids, scores)]

@@ -1,0 +1,138 @@
+"""Drop-in for the reference's Cython module mDeepFRI/predict.pyx: `seq2onehot` and `Predictor`, with the ONNX
+Runtime session replaced by hand-written HIP kernels (libmdfri_hip.so).  No onnxruntime import."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+from . import _hip, weights as _weights
+
+__all__ = ["seq2onehot", "Predictor"]
+
+_DTYPES = {np.dtype(np.int32): _hip.DT_I32, np.dtype(np.float32): _hip.DT_F32, np.dtype(np.int64): _hip.DT_I64,
+           np.dtype(np.float64): _hip.DT_F64, np.dtype(np.uint8): _hip.DT_U8}
+
+
+def seq2onehot(seq: str) -> np.ndarray:
+    """reference predict.pyx:17-48: float32 (L,26) one-hot in the order "-DGULNTKHYWCPVSOIEFXQABZRM";
+    ValueError(f"Invalid character in sequence: {c}") for any other byte; "" -> (0,26)."""
+    if not isinstance(seq, str):
+        raise TypeError(f"Argument 'seq' has incorrect type (expected str, got {type(seq).__name__})")
+    b = seq.encode("ascii")
+    out = np.zeros((len(b), 26), dtype=np.float32)
+    if len(b) == 0:
+        return out
+    bad = _hip.c_int64(-1)
+    rc = _hip.lib().mdf_seq2onehot(b, len(b), _hip.ptr(out), bad)
+    if rc == _hip.MDF_EBADCHAR:
+        raise ValueError(f"Invalid character in sequence: {seq[bad.value]}")
+    _hip.check(rc)
+    return out
+
+
+class _Session:
+    """Owns the mdf_model handle (the role onnxruntime.InferenceSession plays in predict.pyx:63-73)."""
+
+    class _Input:
+        def __init__(self, name):
+            self.name = name
+
+    def __init__(self, handle, topology):
+        self.handle = handle
+        self.topology = topology
+
+    def get_inputs(self):
+        return [self._Input("cmap"), self._Input("seq")]
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                _hip.lib().mdf_model_free(h)
+            except Exception:
+                pass
+
+
+def create_model_handle(weights: dict, device: int = 0):
+    """weights dict (see mDeepFRI.weights) -> (mdf_model* as c_void_p, topology)."""
+    topo = _weights.validate(weights)
+    w = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weights.items()}
+    s = _hip.GcnWeights()
+    s.embed, s.n_gc, s.fc_dim, s.n_terms = topo["embed"], len(topo["gc_dims"]), topo["fc_dim"], topo["n_terms"]
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))  # noqa: E731
+    for k, c in enumerate(topo["gc_dims"]):
+        s.gc_dims[k] = c
+        s.W_gc[k] = fp(w[f"W_gc{k + 1}"])
+    s.W_aa, s.W_fc, s.b_fc, s.W_out, s.b_out = fp(w["W_aa"]), fp(w["W_fc"]), fp(w["b_fc"]), fp(w["W_out"]), fp(w["b_out"])
+    handle = ctypes.c_void_p()
+    _hip.check(_hip.lib().mdf_model_create(ctypes.byref(s), int(device), ctypes.byref(handle)))
+    return handle, topo
+
+
+class Predictor(object):
+    """reference predict.pyx:50-102.  Public attributes as there: model_path, threads, session, input_names.
+
+    `model_path` is the path the pipeline hands over (reference pipeline.py:584); see
+    mDeepFRI.weights.resolve_model_path for the containers accepted.  `threads` is kept for signature
+    compatibility (the reference forwards it to ORT's CPU thread pools; there are none here).
+    Extra keyword `device`: HIP device ordinal (default: $MDFRI_DEVICE or 0).  `weights=` builds a predictor from
+    an in-memory weight dict (used with synthetic weights)."""
+
+    def __init__(self, model_path: str, threads: int = 1, device: int | None = None, weights: dict | None = None):
+        self.model_path = model_path
+        self.threads = threads
+        self.device = int(os.environ.get("MDFRI_DEVICE", "0")) if device is None else int(device)
+        self._weights = weights
+        self.session = None
+        self.input_names = []
+        self._load_model()
+
+    def _load_model(self):
+        L = _hip.lib()
+        if self._weights is not None:
+            handle, _ = create_model_handle(self._weights, self.device)
+        else:
+            path = _weights.resolve_model_path(self.model_path)
+            if path.endswith(".mdfw"):  # native container: read by the library itself
+                handle = ctypes.c_void_p()
+                _hip.check(L.mdf_model_load(path.encode(), self.device, ctypes.byref(handle)))
+            else:
+                handle, _ = create_model_handle(_weights.load_weights(path), self.device)
+        topo = {"n_terms": int(L.mdf_model_num_terms(handle)), "feature_dim": int(L.mdf_model_feature_dim(handle))}
+        self.session = _Session(handle, topo)
+        self.input_names = [node.name for node in self.session.get_inputs()]
+        self._weights = None
+
+    @property
+    def n_terms(self) -> int:
+        return self.session.topology["n_terms"]
+
+    def forward_pass(self, seqres: str, cmap=None) -> np.ndarray:
+        """reference predict.pyx:75-102, GCN branch: float32 (T,) = softmax(...)[:, :, 0].reshape(-1)."""
+        if cmap is None:
+            raise NotImplementedError(
+                "sequence-only (CNN) models are outside this build's hot path (SURVEY.md section 8f row 2); "
+                "pass the contact map")
+        if not isinstance(seqres, str):
+            raise TypeError("seqres must be str")
+        b = seqres.encode("ascii")
+        L = len(b)
+        A = np.asarray(cmap)
+        if A.ndim != 2 or A.shape != (L, L):
+            raise ValueError(f"cmap has shape {A.shape}, expected ({L}, {L}) for a sequence of length {L}")
+        if L == 0:
+            raise ValueError("empty sequence")
+        if A.dtype == np.bool_:
+            A = A.view(np.uint8)
+        if A.dtype not in _DTYPES:
+            A = A.astype(np.float32)  # predict.pyx:88 casts to float32 anyway
+        A = np.ascontiguousarray(A)
+        scores = np.empty((self.n_terms,), dtype=np.float32)
+        bad = _hip.c_int64(-1)
+        rc = _hip.lib().mdf_gcn_forward_host(self.session.handle, b, L, _hip.ptr(A), _DTYPES[A.dtype], _hip.ptr(scores), bad)
+        if rc == _hip.MDF_EBADCHAR:
+            raise ValueError(f"Invalid character in sequence: {seqres[bad.value]}")
+        _hip.check(rc)
+        return scores

@@ -1,0 +1,70 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, proteins dealt to ranks by cost, no communication
+while computing, ONE gather of the (n_local, T) score blocks to rank 0 at the end (RCCL over xGMI when the
+backend is "nccl"; "gloo" on CPU for tests).  The reference has no distributed path at all (SURVEY.md section 2,
+"Parallelism census"); every protein is independent through contact map + GCN, weights are replicated.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def protein_cost(length: int) -> int:
+    """Work of one protein ~ its padded residue rows (the H.W GEMMs dominate and are linear in rows)."""
+    return (int(length) + 31) // 32 * 32
+
+
+def partition_by_cost(lengths, world_size: int):
+    """Greedy longest-processing-time assignment.  Returns `world_size` index lists (each sorted by length, as the
+    reference sorts its work list, pipeline.py:529-533).  Deterministic."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    loads = [0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        shards[r].append(i)
+        loads[r] += protein_cost(lengths[i])
+    for s in shards:
+        s.sort(key=lambda i: (int(lengths[i]), i))
+    return shards
+
+
+def gather_scores(local_scores, local_index, total: int, dst: int = 0, group=None):
+    """Gather per-rank score blocks to `dst` and restore the original protein order.
+
+    local_scores: torch tensor (n_local, T) on this rank's device (CUDA for nccl, CPU for gloo);
+    local_index:  the global protein indices of its rows (sequence of ints);  total: global protein count.
+    Returns the (total, T) tensor on `dst`, None elsewhere.  Shards are padded to the largest shard so that a single
+    fixed-size gather is issued (7 peers write into rank 0 over 7 distinct xGMI links in parallel)."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        out = torch.empty((total, local_scores.shape[1]), dtype=local_scores.dtype, device=local_scores.device)
+        out[torch.as_tensor(list(local_index), dtype=torch.long, device=local_scores.device)] = local_scores
+        return out
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = local_scores.device
+    n_local, T = local_scores.shape
+    counts = torch.zeros(world, dtype=torch.long, device=dev)
+    counts[rank] = n_local
+    dist.all_reduce(counts, group=group)          # tiny: agree on shard sizes
+    n_max = int(counts.max().item())
+    payload = torch.zeros((n_max, T), dtype=local_scores.dtype, device=dev)
+    payload[:n_local] = local_scores
+    idx = torch.full((n_max,), -1, dtype=torch.long, device=dev)
+    idx[:n_local] = torch.as_tensor(list(local_index), dtype=torch.long, device=dev)
+    if rank == dst:
+        bufs = [torch.empty_like(payload) for _ in range(world)]
+        ibufs = [torch.empty_like(idx) for _ in range(world)]
+    else:
+        bufs = ibufs = None
+    dist.gather(payload, bufs, dst=dst, group=group)
+    dist.gather(idx, ibufs, dst=dst, group=group)
+    if rank != dst:
+        return None
+    out = torch.empty((total, T), dtype=local_scores.dtype, device=dev)
+    for b, i in zip(bufs, ibufs):
+        keep = i >= 0
+        out[i[keep]] = b[keep]
+    return out

@@ -1,0 +1,114 @@
+"""Weight containers for the DeepFRI GCN (the arithmetic the reference keeps in external .onnx files,
+reference mDeepFRI/__init__.py:47-80, mDeepFRI/utils.py:119-151).
+
+`.mdfw` is the native container read by libmdfri_hip (mdf_model_load):
+    bytes 0..7   b"MDFW0001"
+    u32          n_tensors
+    n x entry    { char name[32] (NUL padded); u32 ndim; u64 dims[4]; u64 offset_from_file_start }
+    raw little-endian float32 data (each tensor 64-byte aligned)
+Tensor names: W_aa (26,E)  W_gc1 (E,C1)  W_gc2 (C1,C2)  W_gc3 (C2,C3)  W_fc (C1+C2+C3,F)  b_fc (F)
+              W_out (F,2T)  b_out (2T)        -- Keras orientation (in_features, out_features).
+`.npz` files with the same keys are accepted too.
+
+Real `.onnx` files are not parsed yet: the shipped models also contain an LSTM language-model branch that this
+build does not implement ("next" row 1); `resolve_model_path` therefore looks for a
+`.mdfw`/`.npz` sibling of a given `.onnx` path and fails loudly otherwise.
+"""
+from __future__ import annotations
+
+import os
+import struct
+
+import numpy as np
+
+MAGIC = b"MDFW0001"
+ORDER = ("W_aa", "W_gc1", "W_gc2", "W_gc3", "W_fc", "b_fc", "W_out", "b_out")
+_ENTRY = struct.Struct("<32sI4QQ")
+
+
+def save_mdfw(path: str, weights: dict) -> None:
+    names = [k for k in ORDER if k in weights]
+    arrays = [np.ascontiguousarray(weights[k], dtype="<f4") for k in names]
+    head = len(MAGIC) + 4 + _ENTRY.size * len(names)
+    offsets, off = [], (head + 63) // 64 * 64
+    for a in arrays:
+        offsets.append(off)
+        off = (off + a.nbytes + 63) // 64 * 64
+    with open(path, "wb") as f:
+        f.write(MAGIC)
+        f.write(struct.pack("<I", len(names)))
+        for n, a, o in zip(names, arrays, offsets):
+            dims = list(a.shape) + [0] * (4 - a.ndim)
+            f.write(_ENTRY.pack(n.encode(), a.ndim, *dims, o))
+        for a, o in zip(arrays, offsets):
+            f.seek(o)
+            f.write(a.tobytes())
+
+
+def load_mdfw(path: str) -> dict:
+    with open(path, "rb") as f:
+        buf = f.read()
+    if buf[:8] != MAGIC:
+        raise OSError(f"{path} is not an MDFW0001 container")
+    (n,) = struct.unpack_from("<I", buf, 8)
+    out = {}
+    for i in range(n):
+        name, ndim, d0, d1, d2, d3, off = _ENTRY.unpack_from(buf, 12 + i * _ENTRY.size)
+        shape = (d0, d1, d2, d3)[:ndim]
+        cnt = int(np.prod(shape))
+        out[name.rstrip(b"\0").decode()] = np.frombuffer(buf, dtype="<f4", count=cnt, offset=off).reshape(shape).copy()
+    return out
+
+
+def validate(weights: dict) -> dict:
+    """Check shapes and return the topology {embed, gc_dims, fc_dim, n_terms}."""
+    w = weights
+    for k in ("W_aa", "W_gc1", "W_fc", "b_fc", "W_out", "b_out"):
+        if k not in w:
+            raise ValueError(f"weights: missing tensor {k}")
+    if w["W_aa"].ndim != 2 or w["W_aa"].shape[0] != 26:
+        raise ValueError("weights: W_aa must be (26, E)")
+    prev, gc = w["W_aa"].shape[1], []
+    k = 1
+    while f"W_gc{k}" in w:
+        a = w[f"W_gc{k}"]
+        if a.ndim != 2 or a.shape[0] != prev:
+            raise ValueError(f"weights: W_gc{k} has shape {a.shape}, expected ({prev}, C)")
+        prev = a.shape[1]
+        gc.append(prev)
+        k += 1
+    if not 1 <= len(gc) <= 3:
+        raise ValueError("weights: 1..3 GraphConv layers supported")
+    if w["W_fc"].shape != (sum(gc), w["b_fc"].shape[0]):
+        raise ValueError("weights: W_fc / b_fc shape mismatch")
+    if w["W_out"].shape[0] != w["W_fc"].shape[1] or w["W_out"].shape[1] % 2 or w["b_out"].shape[0] != w["W_out"].shape[1]:
+        raise ValueError("weights: W_out / b_out shape mismatch")
+    return {"embed": int(w["W_aa"].shape[1]), "gc_dims": gc, "fc_dim": int(w["W_fc"].shape[1]),
+            "n_terms": int(w["W_out"].shape[1] // 2)}
+
+
+def resolve_model_path(model_path: str) -> str:
+    """Map the path the pipeline passes to Predictor (an .onnx file name, reference pipeline.py:549-584) to a
+    container this build can read."""
+    if model_path.endswith((".mdfw", ".npz")):
+        if not os.path.exists(model_path):
+            raise FileNotFoundError(model_path)
+        return model_path
+    stem = os.path.splitext(model_path)[0]
+    for ext in (".mdfw", ".npz"):
+        if os.path.exists(stem + ext):
+            return stem + ext
+    raise FileNotFoundError(
+        f"no '.mdfw' or '.npz' weight container found next to {model_path!r}; ONNX files are not parsed by this "
+        f"build (write one with mDeepFRI.weights.save_mdfw)")
+
+
+def load_weights(model_path: str) -> dict:
+    p = resolve_model_path(model_path)
+    if p.endswith(".npz"):
+        with np.load(p) as z:
+            w = {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
+    else:
+        w = load_mdfw(p)
+    validate(w)
+    return w

@@ -1,0 +1,213 @@
+"""GPU parity: contact-map kernels (through the C ABI / the drop-in Python API) vs the golden vectors of the
+compiled reference and vs the C oracle.  Bit-exact everywhere (integer / index work and f32 bit patterns)."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import cmap_oracle as orc
+from conftest import gstr
+from mDeepFRI import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+class Aln:
+    def __init__(self, coords, q, t):
+        self.coords, self.gapped_sequence, self.gapped_target = coords, q, t
+        self.target_name, self.query_name = "target.pdb", "query"
+
+
+def test_pairwise_goldens_bit_exact(cmap_golden):
+    from mDeepFRI.contact_map_utils import pairwise_sqeuclidean
+    keys = [k[:-2] for k in cmap_golden.files if k.startswith("pairwise/") and k.endswith("/X")]
+    assert len(keys) >= 8
+    for k in keys:
+        X = np.ascontiguousarray(cmap_golden[k + "/X"])
+        D = pairwise_sqeuclidean(X)
+        exp = cmap_golden[k + "/D"]
+        assert D.dtype == np.float32 and D.shape == exp.shape, k
+        assert np.array_equal(D.view(np.uint32), exp.view(np.uint32)), k
+
+
+def test_pairwise_reference_kat():
+    # reference mDeepFRI/tests/test_contact_map_utils.py:15-25
+    from mDeepFRI.contact_map_utils import pairwise_sqeuclidean
+    np.random.seed(42)
+    expected = np.array([[0, 1.01354558, 0.12442072], [1.01354558, 0, 0.99467713], [0.12442072, 0.99467713, 0]], dtype=np.float32)
+    result = pairwise_sqeuclidean(np.random.rand(3, 3).astype(np.float32))
+    assert np.allclose(result, expected)
+
+
+def test_pairwise_rejects_wrong_buffers():
+    from mDeepFRI.contact_map_utils import pairwise_sqeuclidean
+    with pytest.raises(ValueError):
+        pairwise_sqeuclidean(np.zeros((3, 3), dtype=np.float64))
+    with pytest.raises(ValueError):
+        pairwise_sqeuclidean(np.asfortranarray(np.zeros((3, 4), dtype=np.float32)))
+
+
+@pytest.mark.parametrize("n", [127, 128, 129, 1024, 2048])
+def test_pairwise_random_vs_oracle(n):
+    from mDeepFRI.contact_map_utils import pairwise_sqeuclidean
+    X = synthetic.random_walk_coords(np.random.default_rng(n), n)
+    D = pairwise_sqeuclidean(X)
+    assert np.array_equal(D.view(np.uint32), orc.pairwise_sqeuclidean(X).view(np.uint32))
+    assert np.array_equal(D, D.T) and np.all(np.diag(D) == 0)
+
+
+def test_pairwise_nan_rows_keep_zero_diagonal():
+    from mDeepFRI.contact_map_utils import pairwise_sqeuclidean
+    X = np.array([[0, 0, 0], [np.nan, 1, 2], [3, 4, np.inf]], dtype=np.float32)
+    D, E = pairwise_sqeuclidean(X), orc.pairwise_sqeuclidean(X)
+    assert np.array_equal(D.view(np.uint32), E.view(np.uint32))
+
+
+def test_align_golden_cases_bit_exact(cmap_golden):
+    from mDeepFRI.contact_map_utils import align_contact_map
+    for n in [str(x) for x in cmap_golden["index/align"]]:
+        out = align_contact_map(gstr(cmap_golden[n + "/q"]), gstr(cmap_golden[n + "/t"]), cmap_golden[n + "/pairs"],
+                                int(cmap_golden[n + "/gen"]))
+        exp = cmap_golden[n + "/out"]
+        assert out.dtype == np.int32 and out.shape == exp.shape, n
+        assert np.array_equal(out, exp), n
+
+
+def test_align_rejects_int64_pairs():
+    from mDeepFRI.contact_map_utils import align_contact_map
+    with pytest.raises(ValueError):
+        align_contact_map("AB", "AB", np.array([[0, 1]], dtype=np.int64))
+
+
+def test_chain_golden_cases(cmap_golden):
+    """coords -> sparse -> aligned, per-call API, against the reference's outputs (sha256 of the exact bytes)."""
+    from mDeepFRI.bio_utils import build_align_contact_map, calculate_contact_map
+    from mDeepFRI.contact_map_utils import align_contact_map, pairwise_sqeuclidean
+    for n in [str(x) for x in cmap_golden["index/chain"]]:
+        coords = np.ascontiguousarray(cmap_golden[n + "/coords"])
+        q, t, gen = gstr(cmap_golden[n + "/q"]), gstr(cmap_golden[n + "/t"]), int(cmap_golden[n + "/gen"])
+        assert sha(pairwise_sqeuclidean(coords)) == gstr(cmap_golden[n + "/sha_D"]), n
+        sparse = calculate_contact_map(coords, 6.0, mode="sparse")
+        assert sparse.dtype == np.int32 and sha(sparse) == gstr(cmap_golden[n + "/sha_sparse"]), n
+        out = align_contact_map(q, t, sparse, gen)
+        assert sha(out) == gstr(cmap_golden[n + "/sha_out"]), n
+        _, fused = build_align_contact_map(Aln(coords, q, t), 6.0, gen)
+        assert sha(fused) == gstr(cmap_golden[n + "/sha_out"]), n
+
+
+def test_calculate_contact_map_matrix_mode_and_threshold_edge():
+    from mDeepFRI.bio_utils import calculate_contact_map
+    coords = np.array([[0, 0, 0], [6, 0, 0], [0, 5.9999, 0], [3, 4, 0]], dtype=np.float32)
+    cm = calculate_contact_map(coords, 6.0)
+    assert np.array_equal(cm, orc.calculate_contact_map(coords, 6.0))
+    assert cm[0, 1] == 0 and cm[0, 2] == 1 and cm[0, 3] == 1  # strict '<': exactly 6 A is not a contact
+    for thr in (0.0, 3.8, 4.5, 6.1, 10.0):
+        X = synthetic.random_walk_coords(np.random.default_rng(5), 200)
+        assert np.array_equal(calculate_contact_map(X, thr), orc.calculate_contact_map(X, thr)), thr
+        assert np.array_equal(calculate_contact_map(X, thr, mode="sparse"), orc.calculate_contact_map(X, thr, mode="sparse")), thr
+
+
+def test_build_align_missing_coords_returns_none():
+    from mDeepFRI.bio_utils import build_align_contact_map
+    a = Aln(None, "AC", "AC")
+    assert build_align_contact_map(a) == (a, None)
+
+
+def test_fuzz_align_and_fused_vs_oracle():
+    from mDeepFRI.bio_utils import build_align_contact_map
+    from mDeepFRI.contact_map_utils import align_contact_map
+    rng = np.random.default_rng(2024)
+    for it in range(40):
+        L = int(rng.integers(1, 300))
+        seq = synthetic.random_sequence(rng, L)
+        q, t, lt = synthetic.mutate_alignment(rng, seq, float(rng.choice([0.0, 0.05, 0.3])))
+        coords = synthetic.random_walk_coords(rng, lt).reshape(-1, 3)
+        gen = int(rng.integers(0, 5))
+        thr = float(rng.choice([4.0, 6.0, 8.0]))
+        _, fused = build_align_contact_map(Aln(coords, q, t), thr, gen)
+        assert np.array_equal(fused, orc.build_align_contact_map(coords, q, t, thr, gen)), it
+        pairs = rng.integers(-2, lt + 3, size=(int(rng.integers(0, 5 * L)), 2)).astype(np.int32)
+        assert np.array_equal(align_contact_map(q, t, pairs, gen), orc.align_contact_map(q, t, pairs, gen)), it
+
+
+def test_fused_handles_coords_shorter_and_longer_than_alignment():
+    from mDeepFRI.bio_utils import build_align_contact_map
+    rng = np.random.default_rng(8)
+    seq = synthetic.random_sequence(rng, 50)
+    q, t, lt = synthetic.mutate_alignment(rng, seq, 0.1)
+    for n_coords in (lt - 7, lt + 9):
+        coords = synthetic.random_walk_coords(rng, n_coords)
+        _, fused = build_align_contact_map(Aln(coords, q, t), 6.0, 2)
+        assert np.array_equal(fused, orc.build_align_contact_map(coords, q, t, 6.0, 2)), n_coords
+
+
+@pytest.mark.parametrize("L", [1024, 2048])
+def test_full_size_properties(L):
+    """Size-independent properties at BASELINE.json sizes: symmetry for coords-derived maps, unit diagonal,
+    identity alignment == thresholded distance map, idempotence through sparsify -> align."""
+    from mDeepFRI.bio_utils import build_align_contact_map, calculate_contact_map
+    from mDeepFRI.contact_map_utils import align_contact_map
+    rng = np.random.default_rng(L)
+    seq = synthetic.random_sequence(rng, L)
+    coords = synthetic.random_walk_coords(rng, L)
+    _, cm = build_align_contact_map(Aln(coords, seq, seq), 6.0, 2)
+    assert cm.shape == (L, L) and np.array_equal(cm, cm.T) and np.all(np.diag(cm) == 1)
+    assert np.array_equal(cm, calculate_contact_map(coords, 6.0))
+    sparse = calculate_contact_map(coords, 6.0, mode="sparse")
+    assert np.all(np.diff(sparse[:, 0].astype(np.int64) * L + sparse[:, 1]) > 0)  # row-major sorted, unique
+    assert np.array_equal(align_contact_map(seq, seq, sparse), cm)
+    assert np.array_equal(cm, orc.build_align_contact_map(coords, seq, seq, 6.0, 2))
+
+
+def test_contact_map_classes_reference_tests():
+    # reference mDeepFRI/tests/test_conctact_map.py:8-41
+    from mDeepFRI.contact_map import CAlphaCoordinates
+    coords = np.array([[1, 2, 3], [4, 5, 6]])
+    assert np.array_equal(CAlphaCoordinates("test", coords).coords, coords)
+    with pytest.raises(ValueError, match="Coordinates are not 3D."):
+        CAlphaCoordinates("test", np.array([[1, 2], [3, 4]]))
+    ac = CAlphaCoordinates("test", np.array([[0, 0, 0], [1, 1, 1]]))
+    dm = ac.calculate_distance_map(distance="sqeuclidean")
+    assert np.allclose(np.sqrt(dm.distance_map), np.array([[0, np.sqrt(3)], [np.sqrt(3), 0]], dtype=np.float32))
+    with pytest.raises(NotImplementedError, match="Distance metric not implemented."):
+        ac.calculate_distance_map(distance="euclidean")
+    cm = CAlphaCoordinates("test", np.array([[0, 0, 0], [5, 0, 0], [10, 0, 0]])).calculate_contact_map(threshold=6.0)
+    assert np.array_equal(cm.cmap, np.array([[1, 1, 0], [1, 1, 1], [0, 1, 1]]))
+    assert np.array_equal(cm.sparsify(), np.argwhere(cm.cmap == 1).astype(np.int32))
+
+
+def test_seq2onehot_reference_tests_and_alphabet():
+    # reference mDeepFRI/tests/test_predict.py:8-33
+    from mDeepFRI.predict import seq2onehot
+    r = seq2onehot("")
+    assert r.shape == (0, 26) and r.dtype == np.float32
+    assert np.all(seq2onehot("D") == np.array([[0, 1] + [0] * 24]))
+    exp = np.zeros((4, 26), np.float32)
+    exp[np.arange(4), np.arange(4)] = 1
+    assert np.all(seq2onehot("-DGU") == exp)
+    with pytest.raises(ValueError):
+        seq2onehot("J")
+    alpha = "-DGULNTKHYWCPVSOIEFXQABZRM"
+    assert np.array_equal(seq2onehot(alpha), np.eye(26, dtype=np.float32))
+    with pytest.raises(ValueError, match="Invalid character in sequence: j"):
+        seq2onehot("ACjDE*")
+    long = synthetic.random_sequence(np.random.default_rng(0), 3000)
+    assert np.array_equal(seq2onehot(long), orc.seq2onehot(long))
+
+
+def test_batched_build_align_contact_maps_matches_per_call():
+    from mDeepFRI.batch import build_align_contact_maps
+    prots = synthetic.synthetic_proteins(seed=3, count=37, length=(20, 400), indel_rate=0.07)
+    alns = [Aln(p["coords"], p["q_aln"], p["t_aln"]) for p in prots]
+    alns.insert(5, Aln(None, "AC", "AC"))
+    res = build_align_contact_maps(alns, 6.0, 2, max_rows=4096)
+    assert len(res) == len(alns) and res[5] == (alns[5], None)
+    for a, (ra, cm) in zip(alns, res):
+        assert ra is a
+        if a.coords is not None:
+            assert cm.dtype == np.int32
+            assert np.array_equal(cm, orc.build_align_contact_map(a.coords, a.gapped_sequence, a.gapped_target, 6.0, 2))

@@ -1,0 +1,208 @@
+"""GPU parity: DeepFRI GCN forward (HIP) vs the CPU restatement oracle/gcn_oracle.py.
+Tolerance: 1e-4 absolute on the scores (BASELINE.json north_star; reference notebook atol 10e-5).
+The oracle itself is *parity unpinned* against the reference's ONNX path (see its header)."""
+import numpy as np
+import pytest
+
+import cmap_oracle as orc
+import gcn_oracle
+from conftest import gstr
+from mDeepFRI import synthetic
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def mf():
+    from mDeepFRI.predict import Predictor
+    w = synthetic.glorot_gcn_weights(seed=0, n_terms=synthetic.GO_TERMS["mf"])
+    return w, Predictor("synthetic-mf.onnx", weights=w)
+
+
+@pytest.fixture(scope="module")
+def cc():
+    from mDeepFRI.predict import Predictor
+    w = synthetic.glorot_gcn_weights(seed=2, n_terms=synthetic.GO_TERMS["cc"])
+    return w, Predictor("synthetic-cc.onnx", weights=w)
+
+
+def test_predictor_public_surface(mf):
+    _, pred = mf
+    assert pred.model_path == "synthetic-mf.onnx" and pred.threads == 1
+    assert pred.input_names == ["cmap", "seq"] and pred.session is not None
+    with pytest.raises(NotImplementedError):
+        pred.forward_pass("ACD")
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        pred.forward_pass("AJD", np.eye(3, dtype=np.int32))
+    with pytest.raises(ValueError):
+        pred.forward_pass("ACD", np.eye(4, dtype=np.int32))
+
+
+def test_forward_pass_golden_cases(gcn_golden, mf, cc):
+    for n in [str(x) for x in gcn_golden["index/gcn"]]:
+        w, pred = mf if "/mf_" in n else cc
+        seq = gstr(gcn_golden[n + "/seq"])
+        L = len(seq)
+        cm = np.unpackbits(gcn_golden[n + "/cmap_bits"], axis=1)[:, :L].astype(np.int32)
+        y = pred.forward_pass(seq, cm)
+        assert y.dtype == np.float32 and y.shape == (pred.n_terms,)
+        err64 = np.max(np.abs(y.astype(np.float64) - gcn_golden[n + "/y64"]))
+        err32 = np.max(np.abs(y - gcn_oracle.gcn_forward(w, seq, cm)))
+        assert err64 < TOL and err32 < TOL, (n, err64, err32)
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.float32, np.int64, np.float64, np.uint8, np.bool_, np.int16])
+def test_forward_pass_accepts_cmap_dtypes(mf, dtype):
+    w, pred = mf
+    rng = np.random.default_rng(1)
+    seq = synthetic.random_sequence(rng, 90)
+    cm = orc.calculate_contact_map(synthetic.random_walk_coords(rng, 90), 6.0)
+    y = pred.forward_pass(seq, cm.astype(dtype))
+    assert np.max(np.abs(y - gcn_oracle.gcn_forward(w, seq, cm))) < TOL
+
+
+def test_forward_pass_general_float_and_asymmetric_maps(mf):
+    """forward_pass takes any (L,L) numeric matrix (reference docstring: 'binary or distance-based'): weighted,
+    non-symmetric maps with a non-unit diagonal go through the same normalisation as the oracle."""
+    w, pred = mf
+    rng = np.random.default_rng(77)
+    L = 150
+    seq = synthetic.random_sequence(rng, L)
+    A = (rng.random((L, L)) < 0.1) * rng.random((L, L))
+    np.fill_diagonal(A, 3.0)
+    A = A.astype(np.float32)
+    y = pred.forward_pass(seq, A)
+    assert np.max(np.abs(y - gcn_oracle.gcn_forward(w, seq, A))) < TOL
+
+
+@pytest.mark.parametrize("L", [1, 2, 31, 32, 33, 127, 128, 129, 512, 1024])
+def test_forward_pass_lengths(mf, L):
+    w, pred = mf
+    rng = np.random.default_rng(100 + L)
+    seq = synthetic.random_sequence(rng, L)
+    cm = orc.calculate_contact_map(synthetic.random_walk_coords(rng, L), 6.0)
+    y = pred.forward_pass(seq, cm)
+    ref = gcn_oracle.gcn_forward(w, seq, cm)
+    assert np.max(np.abs(y - ref)) < TOL, L
+    assert np.mean((ref > 0.02) & (ref < 0.98)) > 0.3  # the check is not vacuous (scores are not saturated)
+
+
+def test_all_26_letters(mf):
+    w, pred = mf
+    seq = "-DGULNTKHYWCPVSOIEFXQABZRM" * 3
+    rng = np.random.default_rng(4)
+    cm = orc.calculate_contact_map(synthetic.random_walk_coords(rng, len(seq)), 6.0)
+    assert np.max(np.abs(pred.forward_pass(seq, cm) - gcn_oracle.gcn_forward(w, seq, cm))) < TOL
+
+
+def _engine(preds, **kw):
+    from mDeepFRI.batch import HotPathEngine
+    return HotPathEngine(preds, device=0, **kw)
+
+
+def test_fused_batch_vs_oracle_and_per_call(mf, cc):
+    """coords + alignment + sequence -> scores in one fused batch == oracle chain == per-call drop-in chain."""
+    from mDeepFRI.batch import PackedProteins
+    (wm, pm), (wc, pc) = mf, cc
+    prots = synthetic.synthetic_proteins(seed=21, count=24, length=(30, 300), indel_rate=0.06)
+    eng = _engine({"mf": pm, "cc": pc}, max_rows=2048)
+    pk = PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots],
+                             [p["t_aln"] for p in prots], max_rows=2048)
+    assert len(pk.chunks) > 1
+    db = eng.upload(pk)
+    scores, logits = eng.forward_alignments(db, want_logits=True)
+    eng.check(db)
+    s_mf, s_cc = scores["mf"].cpu().numpy(), scores["cc"].cpu().numpy()
+    z_mf = logits["mf"].cpu().numpy()
+    for i, p in enumerate(prots):
+        cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
+        y_mf, im = gcn_oracle.gcn_forward(wm, p["seq"], cm, dtype=np.float64, return_intermediates=True)
+        assert np.max(np.abs(s_mf[i] - y_mf)) < TOL, i
+        assert np.max(np.abs(s_cc[i] - gcn_oracle.gcn_forward(wc, p["seq"], cm))) < TOL, i
+        # pre-softmax logits: tighter, saturation-proof check
+        z64 = (im["f"] @ wm["W_out"].astype(np.float64) + wm["b_out"]).reshape(-1)
+        assert np.max(np.abs(z_mf[i] - z64)) < 2e-3 * max(1.0, np.abs(z64).max()), i
+        assert np.max(np.abs(s_mf[i] - pm.forward_pass(p["seq"], cm))) < 2e-6, i
+
+
+def test_dense_batch_path_matches_per_call(mf):
+    from mDeepFRI.batch import PackedProteins
+    w, pred = mf
+    prots = synthetic.synthetic_proteins(seed=5, count=9, length=(40, 200))
+    cms = [orc.calculate_contact_map(p["coords"], 6.0) for p in prots]
+    eng = _engine({"mf": pred}, max_rows=1024)
+    pk = PackedProteins.pack([p["seq"] for p in prots], max_rows=1024)
+    db = eng.upload(pk)
+    s = eng.forward_dense(db, cms)["mf"]
+    eng.check(db)
+    s = s.cpu().numpy()
+    for i, p in enumerate(prots):
+        assert np.max(np.abs(s[i] - gcn_oracle.gcn_forward(w, p["seq"], cms[i]))) < TOL, i
+
+
+def test_batch_flags_invalid_residue(mf):
+    from mDeepFRI.batch import PackedProteins
+    _, pred = mf
+    prots = synthetic.synthetic_proteins(seed=6, count=3, length=50)
+    seqs = [p["seq"] for p in prots]
+    seqs[1] = seqs[1][:10] + "J" + seqs[1][11:]
+    q = list(seqs)
+    eng = _engine({"mf": pred})
+    pk = PackedProteins.pack(seqs, [p["coords"] for p in prots], q, q)
+    db = eng.upload(pk)
+    eng.forward_alignments(db)
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        eng.check(db)
+
+
+def test_csr_overflow_is_detected_and_recovered(mf):
+    from mDeepFRI import _hip
+    from mDeepFRI.batch import PackedProteins
+    w, pred = mf
+    prots = synthetic.synthetic_proteins(seed=9, count=4, length=120)
+    eng = _engine({"mf": pred}, nnz_per_row=2)
+    pk = PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots],
+                             [p["t_aln"] for p in prots])
+    db = eng.upload(pk)
+    eng.forward_alignments(db)
+    with pytest.raises(_hip.CapacityError):
+        eng.check(db)
+    out = eng.run_alignments(pk)["mf"]  # grows the capacity and re-runs
+    cm = orc.build_align_contact_map(prots[0]["coords"], prots[0]["q_aln"], prots[0]["t_aln"], 6.0, 2)
+    assert np.max(np.abs(out[0] - gcn_oracle.gcn_forward(w, prots[0]["seq"], cm))) < TOL
+
+
+def test_full_size_batch_properties(mf):
+    """BASELINE config shape (L=512 batch): permutation equivariance across the batch and batch-size independence --
+    properties that need no oracle at full size -- plus an oracle spot check."""
+    from mDeepFRI.batch import PackedProteins
+    w, pred = mf
+    prots = synthetic.synthetic_proteins(seed=44, count=96, length=512)
+    eng = _engine({"mf": pred})
+
+    def run(sel):
+        pk = PackedProteins.pack([prots[i]["seq"] for i in sel], [prots[i]["coords"] for i in sel],
+                                 [prots[i]["q_aln"] for i in sel], [prots[i]["t_aln"] for i in sel])
+        return eng.run_alignments(pk)["mf"]
+
+    full = run(list(range(96)))
+    perm = list(np.random.default_rng(0).permutation(96))
+    assert np.array_equal(run(perm), full[perm])        # bitwise: no cross-protein coupling, deterministic pooling
+    assert np.array_equal(run([7]), full[[7]])
+    for i in (0, 95):
+        cm = orc.build_align_contact_map(prots[i]["coords"], prots[i]["q_aln"], prots[i]["t_aln"], 6.0, 2)
+        assert np.max(np.abs(full[i] - gcn_oracle.gcn_forward(w, prots[i]["seq"], cm))) < TOL
+
+
+def test_model_file_round_trip(tmp_path, mf):
+    from mDeepFRI import weights
+    from mDeepFRI.predict import Predictor
+    w, pred = mf
+    path = tmp_path / "DeepFRI-SYNTH_GraphConv_gcd_512-512-512_fcd_1024_ca_10.0_mf.mdfw"
+    weights.save_mdfw(str(path), w)
+    p2 = Predictor(str(path).replace(".mdfw", ".onnx"))  # the pipeline passes the .onnx name; the sibling .mdfw is used
+    rng = np.random.default_rng(12)
+    seq = synthetic.random_sequence(rng, 64)
+    cm = orc.calculate_contact_map(synthetic.random_walk_coords(rng, 64), 6.0)
+    assert np.array_equal(p2.forward_pass(seq, cm), pred.forward_pass(seq, cm))
