@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py -- proteins/sec of the fused hot path (C-alpha coords + alignment + sequence -> GO scores) on MI355X.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1: launched through torch.distributed.run)
+One JSON line on rank 0.  A "step" is one pass of the hot path over the whole workload of BASELINE.json configs[2]
+-- 10 000 synthetic L=512 proteins, three GO heads (MF+BP+CC) -- per GPU (weak scaling: every rank owns its own
+10 000 proteins), inputs resident in HBM before the timed region, results left on the device; with N>1 each step
+ends with the RCCL gather of the (10 000, 2752) score block of every rank to rank 0.
+
+Extra objects on the line (tier contract):
+  roofline      dominant kernel (H.W fp32-MFMA GEMM): algorithmic flops per launch / mean launch duration measured with
+                HIP events on the launch stream inside the timed region (mdf_timing_* hooks of the library)
+  roofline_ax   the same for the A.X aggregation kernel against the HBM roofline (the north_star's named kernel)
+  cpu_baseline  the oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "metagenomic-deepfri_amd"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
+MODES = ("mf", "bp", "cc")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--proteins", type=int, default=10000, help="proteins per GPU per step (configs[2]: 10000)")
+    ap.add_argument("--length", type=int, default=512)
+    ap.add_argument("--chunk-rows", type=int, default=32768, help="residue rows per fused chunk")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def make_workload(seed, count, L):
+    """configs[2] inputs: uniform 20-letter sequences, 3.8 A random-walk C-alpha traces rounded to 3 decimals,
+    identity alignments.  Vectorised version of mDeepFRI.synthetic.synthetic_proteins."""
+    from mDeepFRI import synthetic
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer(synthetic.AA20.encode(), dtype=np.uint8)
+    idx = rng.integers(0, 20, size=(count, L))
+    seq_bytes = letters[idx]
+    seqs = [bytes(r).decode() for r in seq_bytes]
+    v = rng.standard_normal((count, L, 3))
+    v /= np.linalg.norm(v, axis=2, keepdims=True) + 1e-12
+    xyz = np.round(np.cumsum(v * 3.8, axis=1), 3).astype(np.float32)
+    return seqs, [xyz[i] for i in range(count)]
+
+
+def cpu_baseline(seqs, coords, weights, budget_s):
+    """Oracle chain (oracle/cmap_oracle.c + oracle/gcn_oracle.py) on host cores: 1 thread = the configuration the
+    reference ships, then all cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import cmap_oracle
+    import gcn_oracle
+    from threadpoolctl import threadpool_limits
+
+    def run(limit, budget):
+        n, t0 = 0, time.perf_counter()
+        with threadpool_limits(limits=limit):
+            while n < len(seqs) and (time.perf_counter() - t0 < budget or n < 2):
+                cm = cmap_oracle.build_align_contact_map(coords[n], seqs[n], seqs[n], 6.0, 2)
+                for m in MODES:
+                    gcn_oracle.gcn_forward(weights[m], seqs[n], cm)
+                n += 1
+        return n, time.perf_counter() - t0
+
+    n1, t1 = run(1, budget_s * 0.7)
+    ncores = os.cpu_count() or 1
+    na, ta = run(None, budget_s * 0.3)
+    return {"value": n1 / t1, "unit": "proteins/s", "cores": 1, "kind": "port",
+            "sample": f"{n1} of the step's L={len(seqs[0])} proteins, contact map + 3 GO heads each, {t1:.1f} s, numpy/BLAS pinned to 1 thread",
+            "all_cores": {"value": na / ta, "cores": ncores, "sample": f"{na} proteins, {ta:.1f} s, BLAS threads unrestricted"},
+            "published_anchor": "reference weight_convert/inference_times.csv.gz: 0.13 s/protein/model/core at L~512 (ORT CPU, model incl. LSTM LM)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from mDeepFRI import _hip, batch, sharding, synthetic
+    from mDeepFRI.predict import Predictor
+
+    weights = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=synthetic.GO_TERMS[m]) for i, m in enumerate(MODES)}
+    preds = {m: Predictor(f"synthetic-{m}", weights=weights[m], device=local_rank) for m in MODES}
+    T_total = sum(p.n_terms for p in preds.values())
+
+    seqs, coords = make_workload(42 + 2 + 1000 * rank, args.proteins, args.length)  # seed = 42 + config index (+rank)
+    eng = batch.HotPathEngine(preds, device=local_rank, max_rows=args.chunk_rows)
+    pk = batch.PackedProteins.pack(seqs, coords, seqs, seqs, max_rows=args.chunk_rows)
+    db = eng.upload(pk)
+    lib = _hip.lib()
+    global_index = list(range(rank * args.proteins, (rank + 1) * args.proteins))
+
+    def step():
+        out = eng.forward_alignments(db)
+        if world > 1:
+            block = torch.cat([out[m] for m in MODES], dim=1)
+            sharding.gather_scores(block, global_index, total=world * args.proteins, dst=0)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.check(db)  # invalid residues / CSR overflow would surface here
+    timing = not args.no_kernel_timing
+    lib.mdf_timing_reset()
+    lib.mdf_timing_enable(1 if timing else 0)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.mdf_timing_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng.check(db)
+
+    if rank == 0:
+        def read(kind):
+            n, ms = _hip.c_int64(0), _hip.ctypes.c_double(0.0)
+            lib.mdf_timing_read(kind.encode(), n, ms)
+            return int(n.value), float(ms.value)
+
+        R = pk.chunks[0].rows                        # rows per launch (all chunks but the last are equal)
+        rows_total = sum(c.rows for c in pk.chunks)
+        roof, roof_ax, kernels = None, None, {}
+        if timing:
+            for kname in ("gemm", "gemm1", "ax", "cmap", "head"):
+                n, ms = read(kname)
+                kernels[kname] = {"launches": n, "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / max(n, 1), 2)}
+            n_g, ms_g = read("gemm")
+            n_a, ms_a = read("ax")
+            # algorithmic work of ALL timed launches / their summed duration (== per-launch figure / mean duration)
+            C = 512
+            launches_per_step = 2 * len(MODES)       # layers 2 and 3, per GO head, per chunk
+            flops = 2.0 * rows_total * C * C * launches_per_step * args.steps
+            if n_g:
+                tf = flops / (ms_g * 1e-3) / 1e12
+                roof = {"kernel": "k_gemm_f32 (H.W, 128x128x32 tiles, v_mfma_f32_32x32x2_f32, ELU+pool epilogue)",
+                        "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                        "per_launch": {"rows": R, "flops": 2.0 * R * C * C, "avg_us": kernels["gemm"]["avg_us"]}}
+            if n_a:
+                # read Z (rows x 512 f32) once + write (rows x 512 f32) once per layer; CSR adjacency
+                # (4 B colidx + 4 B val per nnz + 4 B rowptr per row) added and stated
+                nnz_per_row = float(os.environ.get("MDFRI_BENCH_NNZ_PER_ROW", "0")) or eng_nnz_per_row(eng, db, pk)
+                bytes_launch_rows = 2 * 4 * C + 4 + 8 * nnz_per_row
+                gbs = bytes_launch_rows * rows_total * launches_per_step * args.steps / (ms_a * 1e-3) / 1e9
+                roof_ax = {"kernel": "k_aggregate<512> (A.X, CSR gather, one wave per residue row)", "bound": "hbm",
+                           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                           "traffic": None,
+                           "per_launch": {"rows": R, "bytes": bytes_launch_rows * R, "nnz_per_row": round(nnz_per_row, 2),
+                                          "avg_us": kernels["ax"]["avg_us"]}}
+        line = {
+            "metric": "proteins/sec (GCN+cmap) at L=512",
+            "value": round(world * args.proteins * args.steps / elapsed, 1),
+            "unit": "proteins/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"configs[2]: {args.proteins} synthetic L={args.length} proteins per GPU, GCN_MF+BP+CC "
+                                   f"(T={T_total}), fused cmap(6A, gen=2)+GCN, identity alignments",
+                       "proteins_per_gpu": args.proteins, "length": args.length, "go_heads": list(MODES),
+                       "chunk_rows": args.chunk_rows, "parallelism": f"shard{world}+gather" if world > 1 else "single"},
+            "roofline": roof,
+            "roofline_ax": roof_ax,
+            "kernels": kernels,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(seqs[:1024], coords[:1024], weights, args.cpu_seconds)
+            line["gpu_over_cpu_1core"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def eng_nnz_per_row(eng, db, pk):
+    """Mean CSR entries per residue row of the last chunk processed (rowptr[R] / R), read back from the device."""
+    rp = eng._bufs["rowptr"]
+    last = pk.chunks[-1]
+    return float(rp[last.rows].item()) / float(last.rows)
+
+
+if __name__ == "__main__":
+    main()

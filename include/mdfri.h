@@ -197,7 +197,7 @@ int mdf_gcn_head_dev(mdf_model *m, const float *pooled, int32_t B, float *scores
 
 /* Timing hook for bench.py: when enabled, the library brackets every launch of the named kernel class with
  * hipEvents on the stream it is launched on and accumulates count and milliseconds (read after a sync).
- * kernel: "ax" (A.X aggregation), "gemm" (H.W fp32 MFMA), "cmap" (fused contact map), "head". */
+ * kernel: "ax" (A.X aggregation), "gemm" (H.W fp32 MFMA, layers 2..3), "gemm1" (layer-1 S.T1 GEMM, K=32), "cmap" (fused contact map), "head". */
 int mdf_timing_enable(int on);
 int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms);
 int mdf_timing_reset(void);

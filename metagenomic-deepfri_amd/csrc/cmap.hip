@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
             const int c = counts[row0 + wid * 8 + k];
             pos[k] = run;
             di[k] = 1.0f / (1e-6f + sqrtf((float)c));
-            if (lane == 0) rowptr[row0 + wid * 8 + k] = run;
+            if (lane == 0) rowptr[row0 + wid * 8 + k] = (int)min((int64_t)run, nnz_cap);  // clamped: an overflowing batch stays in bounds (and is flagged)
             run += c;
         }
     }
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(1024) void k_scan_groups(const int32_t *__restrict_
     }
     if (threadIdx.x == 0) {
         const long long total = carry_s;
-        *rowptr_end = (int32_t)(total < 0x7fffffffLL ? total : 0x7fffffffLL);
+        *rowptr_end = (int32_t)(total < nnz_cap ? total : nnz_cap);
         if (total > nnz_cap || total >= 0x7fffffffLL) {
             status[0] = 1;
             status[1] = (int32_t)(total < 0x7fffffffLL ? total : 0x7fffffffLL);
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void k_dense_rows(const void *__restrict__ cma
         const bool mine = (r >> 3) == wid;
         if (FILL) {
             const int c = counts[row];
-            if (wid == 0 && lane == 0) rowptr[row] = run;
+            if (wid == 0 && lane == 0) rowptr[row] = (int)min((int64_t)run, nnz_cap);
             if (mine && i < Lq) {
                 const float di = 1.0f / (1e-6f + sqrtf(rowsum[row]));
                 int pos = run;

@@ -44,10 +44,10 @@ struct TimingState {
     };
     std::vector<Pair> pairs[TK_COUNT];      // recorded, not yet folded
     std::vector<Pair> free_list;            // reusable events
-    int64_t launches[TK_COUNT] = {0, 0, 0, 0};
-    double ms[TK_COUNT] = {0, 0, 0, 0};
+    int64_t launches[TK_COUNT] = {};
+    double ms[TK_COUNT] = {};
     Pair open[TK_COUNT];
-    bool is_open[TK_COUNT] = {false, false, false, false};
+    bool is_open[TK_COUNT] = {};
 };
 static TimingState g_t;
 
@@ -140,6 +140,7 @@ int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms)
     else if (!strcmp(kernel, "gemm")) k = TK_GEMM;
     else if (!strcmp(kernel, "cmap")) k = TK_CMAP;
     else if (!strcmp(kernel, "head")) k = TK_HEAD;
+    else if (!strcmp(kernel, "gemm1")) k = TK_GEMM1;
     if (k < 0) return fail(MDF_EINVAL, "mdf_timing_read: unknown kernel class '%s'", kernel);
     std::lock_guard<std::mutex> lk(g_t.mu);
     fold_locked();

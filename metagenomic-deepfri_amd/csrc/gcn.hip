@@ -23,7 +23,7 @@ struct mdf_model {
     int device = 0;
     int embed = 0, n_gc = 0, gc[3] = {0, 0, 0}, fc = 0, T = 0, feat = 0;
     int n_out_pad = 0;            // 2T rounded up to the GEMM's BN
-    float *T1 = nullptr;          // (26, gc0)      relu(W_aa) @ W_gc1, computed in double on the host
+    float *T1t = nullptr;         // (gc0, 32)      (relu(W_aa) @ W_gc1)^T, letters padded 26 -> 32; computed in double on the host
     float *Wt[3] = {nullptr, nullptr, nullptr};  // k>=1: (gc_k, gc_{k-1}) = W_gc{k+1}^T  ([N][K], K contiguous)
     float *Wfc_t = nullptr;       // (fc, feat)
     float *bfc = nullptr;         // (fc)
@@ -39,6 +39,7 @@ namespace mdf {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;  // LDS row stride 36 floats: conflict-free ds_read_b128
+static_assert(BK == 32, "k_gemm_f32 hand-unrolls exactly four k-groups of 8");
 constexpr int GEMM_LDS_BYTES = 2 /*buffers*/ * 2 /*A,B*/ * BM * LDT * 4;
 
 enum Epilogue { EPI_ELU_POOL_STORE = 0, EPI_ELU_POOL = 1, EPI_BIAS_RELU = 2, EPI_BIAS_SOFTMAX2 = 3 };
@@ -79,26 +80,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
 
-    // staging assignment: float4 index f = tid + 256*i, row = f/8, col4 = f%8
+    // staging assignment: float4 index f = tid + 256*i, row = f/8, col4 = f%8.  Loads are unconditional (rows past M
+    // are clamped to M-1: their products land in accumulator rows that are never stored) -- a per-load `row < M ? load : 0`
+    // select makes hipcc branch around every load and drain vmcnt(0) after it, serialising the whole prefetch.
     const int srow = tid >> 3, scol = (tid & 7) * 4;
-    float4 ra[4], rb[4];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            const int gm = m0 + r;
-            ra[i] = gm < M ? *reinterpret_cast<const float4 *>(A + (size_t)gm * lda + k0 + scol) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[i] = *reinterpret_cast<const float4 *>(Bt + (size_t)(n0 + r) * ldb + k0 + scol);
-        }
-    };
-    auto store_tile = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            *reinterpret_cast<float4 *>(As + (buf * BM + r) * LDT + scol) = ra[i];
-            *reinterpret_cast<float4 *>(Bs + (buf * BN + r) * LDT + scol) = rb[i];
-        }
-    };
+    // explicit scalars (no arrays / lambdas): hipcc left the array form of this prefetch buffer in scratch memory
+    const float *ap0 = A + (size_t)min(m0 + srow, M - 1) * lda + scol;
+    const float *ap1 = A + (size_t)min(m0 + srow + 32, M - 1) * lda + scol;
+    const float *ap2 = A + (size_t)min(m0 + srow + 64, M - 1) * lda + scol;
+    const float *ap3 = A + (size_t)min(m0 + srow + 96, M - 1) * lda + scol;
+    const float *bp0 = Bt + (size_t)(n0 + srow) * ldb + scol;
+    const size_t bstep = (size_t)32 * ldb;
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define MDF_LOAD_TILE(k0)                                               \
+    ra0 = *reinterpret_cast<const float4 *>(ap0 + (k0));                \
+    ra1 = *reinterpret_cast<const float4 *>(ap1 + (k0));                \
+    ra2 = *reinterpret_cast<const float4 *>(ap2 + (k0));                \
+    ra3 = *reinterpret_cast<const float4 *>(ap3 + (k0));                \
+    rb0 = *reinterpret_cast<const float4 *>(bp0 + (k0));                \
+    rb1 = *reinterpret_cast<const float4 *>(bp0 + bstep + (k0));        \
+    rb2 = *reinterpret_cast<const float4 *>(bp0 + 2 * bstep + (k0));    \
+    rb3 = *reinterpret_cast<const float4 *>(bp0 + 3 * bstep + (k0));
+#define MDF_STORE_TILE(buf)                                                                   \
+    *reinterpret_cast<float4 *>(As + ((buf) * BM + srow) * LDT + scol) = ra0;                 \
+    *reinterpret_cast<float4 *>(As + ((buf) * BM + srow + 32) * LDT + scol) = ra1;            \
+    *reinterpret_cast<float4 *>(As + ((buf) * BM + srow + 64) * LDT + scol) = ra2;            \
+    *reinterpret_cast<float4 *>(As + ((buf) * BM + srow + 96) * LDT + scol) = ra3;            \
+    *reinterpret_cast<float4 *>(Bs + ((buf) * BN + srow) * LDT + scol) = rb0;                 \
+    *reinterpret_cast<float4 *>(Bs + ((buf) * BN + srow + 32) * LDT + scol) = rb1;            \
+    *reinterpret_cast<float4 *>(Bs + ((buf) * BN + srow + 64) * LDT + scol) = rb2;            \
+    *reinterpret_cast<float4 *>(Bs + ((buf) * BN + srow + 96) * LDT + scol) = rb3;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -109,34 +120,46 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     const int nk = K / BK;
-    load_tile(0);
-    store_tile(0);
+    MDF_LOAD_TILE(0)
+    MDF_STORE_TILE(0)
     __syncthreads();
 
     const int frow = lane & 31, fk = (lane >> 5) * 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
+        if (kt + 1 < nk) { MDF_LOAD_TILE((kt + 1) * BK) }
         const float *Ab = As + (cur * BM + wm * 64 + frow) * LDT + fk;
         const float *Bb = Bs + (cur * BN + wn * 64 + frow) * LDT + fk;
-#pragma unroll
-        for (int kg = 0; kg < BK / 8; ++kg) {
-            const float4 a0 = *reinterpret_cast<const float4 *>(Ab + kg * 8);
-            const float4 a1 = *reinterpret_cast<const float4 *>(Ab + 32 * LDT + kg * 8);
-            const float4 b0 = *reinterpret_cast<const float4 *>(Bb + kg * 8);
-            const float4 b1 = *reinterpret_cast<const float4 *>(Bb + 32 * LDT + kg * 8);
-#define MDF_MFMA4(c)                                                                          \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b0.c, acc[0][0], 0, 0, 0);          \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b1.c, acc[0][1], 0, 0, 0);          \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b0.c, acc[1][0], 0, 0, 0);          \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b1.c, acc[1][1], 0, 0, 0);
-            MDF_MFMA4(x) MDF_MFMA4(y) MDF_MFMA4(z) MDF_MFMA4(w)
+        // fragments of k-group kg+1 are fetched from LDS while the 16 MFMAs of k-group kg issue
+        float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
+#define MDF_FRAGS(a0, a1, b0, b1, kg)                                              \
+    a0 = *reinterpret_cast<const float4 *>(Ab + (kg) * 8);                         \
+    a1 = *reinterpret_cast<const float4 *>(Ab + 32 * LDT + (kg) * 8);              \
+    b0 = *reinterpret_cast<const float4 *>(Bb + (kg) * 8);                         \
+    b1 = *reinterpret_cast<const float4 *>(Bb + 32 * LDT + (kg) * 8);
+#define MDF_MFMA4(a0, a1, b0, b1, e)                                                         \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b0.e, acc[0][0], 0, 0, 0);        \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b1.e, acc[0][1], 0, 0, 0);        \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b0.e, acc[1][0], 0, 0, 0);        \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b1.e, acc[1][1], 0, 0, 0);
+#define MDF_MFMA16(a0, a1, b0, b1) MDF_MFMA4(a0, a1, b0, b1, x) MDF_MFMA4(a0, a1, b0, b1, y) MDF_MFMA4(a0, a1, b0, b1, z) MDF_MFMA4(a0, a1, b0, b1, w)
+        MDF_FRAGS(pa0, pa1, pb0, pb1, 0)
+        MDF_FRAGS(qa0, qa1, qb0, qb1, 1)
+        MDF_MFMA16(pa0, pa1, pb0, pb1)
+        MDF_FRAGS(pa0, pa1, pb0, pb1, 2)
+        MDF_MFMA16(qa0, qa1, qb0, qb1)
+        MDF_FRAGS(qa0, qa1, qb0, qb1, 3)
+        MDF_MFMA16(pa0, pa1, pb0, pb1)
+        MDF_MFMA16(qa0, qa1, qb0, qb1)
+#undef MDF_FRAGS
 #undef MDF_MFMA4
-        }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+#undef MDF_MFMA16
+        if (kt + 1 < nk) { MDF_STORE_TILE(cur ^ 1) }
         __syncthreads();
     }
 
+#undef MDF_LOAD_TILE
+#undef MDF_STORE_TILE
     // ---- epilogue.  C/D layout of the 32x32 MFMA: lane l, register r -> col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
     const int lcol = lane & 31, lrow = 4 * (lane >> 5);
 #pragma unroll
@@ -244,73 +267,51 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, 
     for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(out + (size_t)row * C + v * 256 + lane * 4) = acc[v];
 }
 
-// ---- layer 1: H1[i,:] = elu(sum_e val[e] * T1[seq[colidx[e]],:]) with the 26 x C table in LDS; one block per
-// 32-row group (wave = 8 consecutive rows), which also emits the group's pooled partial sums.
-template <int C>
-__global__ __launch_bounds__(256) void k_layer1(const float *__restrict__ T1, const uint8_t *__restrict__ seq_idx,
-                                                const int32_t *__restrict__ rowptr, const int32_t *__restrict__ colidx,
-                                                const float *__restrict__ val, float *__restrict__ H1,
-                                                float *__restrict__ pool_partial, int R)
+// ---- layer 1 operand: S[i, a] = sum_{e in row i, seq[colidx[e]] == a} val[e]   (= (Ahat . onehot)[i, a]), 32 columns
+// (26 letters + zero padding), so that H1 = elu(S . T1) runs on the MFMA GEMM with K = 32.  One wave per row; lane a
+// (< 32) accumulates letter a; neighbours are fetched 64 at a time and replayed in CSR order through readlane, which
+// keeps the f32 summation order deterministic (no LDS atomics).
+__global__ __launch_bounds__(256) void k_letter_sums(const uint8_t *__restrict__ seq_idx, const int32_t *__restrict__ rowptr,
+                                                     const int32_t *__restrict__ colidx, const float *__restrict__ val,
+                                                     float *__restrict__ S, int R)
 {
-    constexpr int NV = C / 256;
-    __shared__ __attribute__((aligned(16))) float tab[26 * C];
-    __shared__ __attribute__((aligned(16))) float red[4 * C];
-    for (int i = threadIdx.x; i < 26 * C / 4; i += 256)
-        reinterpret_cast<float4 *>(tab)[i] = reinterpret_cast<const float4 *>(T1)[i];
-    __syncthreads();
-    const int b = blockIdx.x, x = b & 7, q = b >> 3;
-    const int g = ((q >> 2) * 8 + x) * 4 + (q & 3);  // 32-row group, same XCD placement as the 128-row tiles
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    float4 ps[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) ps[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g * 32 < R) {
-        for (int r = 0; r < 8; ++r) {
-            const int row = g * 32 + wid * 8 + r;
-            const int e0 = rowptr[row], e1 = rowptr[row + 1];
-            float4 acc[NV];
-#pragma unroll
-            for (int v = 0; v < NV; ++v) acc[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = e0; e < e1; ++e) {
-                const int a = min((int)seq_idx[colidx[e]], 25);
-                const float w = val[e];
-#pragma unroll
-                for (int v = 0; v < NV; ++v) {
-                    const float4 t = *reinterpret_cast<const float4 *>(tab + a * C + v * 256 + lane * 4);
-                    acc[v].x = fmaf(w, t.x, acc[v].x);
-                    acc[v].y = fmaf(w, t.y, acc[v].y);
-                    acc[v].z = fmaf(w, t.z, acc[v].z);
-                    acc[v].w = fmaf(w, t.w, acc[v].w);
-                }
-            }
-#pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                float4 h;
-                h.x = elu1(acc[v].x); h.y = elu1(acc[v].y); h.z = elu1(acc[v].z); h.w = elu1(acc[v].w);
-                *reinterpret_cast<float4 *>(H1 + (size_t)row * C + v * 256 + lane * 4) = h;
-                ps[v].x += h.x; ps[v].y += h.y; ps[v].z += h.z; ps[v].w += h.w;
-            }
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= R) return;
+    const int lane = threadIdx.x & 63;
+    const int e0 = rowptr[row], e1 = rowptr[row + 1];
+    float c = 0.0f;
+    for (int base = e0; base < e1; base += 64) {
+        const int n = min(64, e1 - base);
+        int a = 31;
+        float v = 0.0f;
+        if (lane < n) {
+            a = min((int)seq_idx[colidx[base + lane]], 31);
+            v = val[base + lane];
+        }
+        for (int k = 0; k < n; ++k) {
+            const int ak = __shfl(a, k, 64);
+            const float vk = __shfl(v, k, 64);
+            c += (lane == ak) ? vk : 0.0f;
         }
     }
-#pragma unroll
-    for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(red + wid * C + v * 256 + lane * 4) = ps[v];
-    __syncthreads();
-    if (g * 32 < R) {
-        for (int c = threadIdx.x; c < C; c += 256)
-            pool_partial[(size_t)g * C + c] = ((red[c] + red[C + c]) + red[2 * C + c]) + red[3 * C + c];
-    }
+    if (lane < 32) S[(size_t)row * 32 + lane] = (lane < 26) ? c : 0.0f;
 }
 
-// pooled[p, off + c] = sum over the 32-row groups of protein p of partial[g, c]
-__global__ void k_pool_reduce(const float *__restrict__ partial, int C, const int32_t *__restrict__ row_off,
-                              float *__restrict__ pooled, int feat, int off)
+// pooled[p, off_k + c] = sum over the 32-row groups of protein p of partial_k[g, c], all GraphConv layers in one launch
+struct PoolArgs {
+    const float *partial[3];
+    int C[3], off[3];
+};
+__global__ void k_pool_reduce(PoolArgs a, const int32_t *__restrict__ row_off, float *__restrict__ pooled, int feat)
 {
-    const int p = blockIdx.x;
+    const int p = blockIdx.x, k = blockIdx.y;
     const int g0 = row_off[p] >> 5, g1 = row_off[p + 1] >> 5;
+    const float *partial = a.partial[k];
+    const int C = a.C[k];
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float s = 0.0f;
         for (int g = g0; g < g1; ++g) s += partial[(size_t)g * C + c];
-        pooled[(size_t)p * feat + off + c] = s;
+        pooled[(size_t)p * feat + a.off[k] + c] = s;
     }
 }
 
@@ -368,7 +369,7 @@ static size_t gcn_ws_bytes(const mdf_model *m, int64_t R)
         cmax = std::max(cmax, m->gc[k]);
         part += align_up((size_t)(R / 32) * m->gc[k] * 4, 256);
     }
-    return 3 * align_up((size_t)R * cmax * 4, 256) + part + 4096;
+    return 3 * align_up((size_t)R * cmax * 4, 256) + align_up((size_t)R * 32 * 4, 256) + part + 4096;
 }
 
 }  // namespace mdf
@@ -415,9 +416,10 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
                 double *ar = acc.data() + (size_t)a * C0;
                 for (int c = 0; c < C0; ++c) ar[c] += x * (double)wr[c];
             }
-        std::vector<float> t1(acc.size());
-        for (size_t i = 0; i < acc.size(); ++i) t1[i] = (float)acc[i];
-        rc = upload(&m->T1, t1.data(), t1.size());
+        std::vector<float> t1t((size_t)C0 * 32, 0.0f);
+        for (int a = 0; a < 26; ++a)
+            for (int c = 0; c < C0; ++c) t1t[(size_t)c * 32 + a] = (float)acc[(size_t)a * C0 + c];
+        rc = upload(&m->T1t, t1t.data(), t1t.size());
     }
     for (int k = 1; k < w->n_gc && rc == MDF_OK; ++k) {
         auto t = transpose(w->W_gc[k], w->gc_dims[k - 1], w->gc_dims[k], w->gc_dims[k]);
@@ -448,7 +450,7 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
 void mdf_model_free(mdf_model *m)
 {
     if (!m) return;
-    (void)hipFree(m->T1);
+    (void)hipFree(m->T1t);
     for (int k = 0; k < 3; ++k) (void)hipFree(m->Wt[k]);
     (void)hipFree(m->Wfc_t);
     (void)hipFree(m->bfc);
@@ -553,18 +555,22 @@ int mdf_gcn_embed_pool_dev(mdf_model *m, const uint8_t *seq_idx, const int32_t *
     int cmax = 0;
     for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
     float *Ha = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax);
+    float *S = cv.take<float>((size_t)R * 32);
     float *partial[3] = {nullptr, nullptr, nullptr};
     for (int k = 0; k < m->n_gc; ++k) partial[k] = cv.take<float>((size_t)(R / 32) * m->gc[k]);
     const int Ri = (int)R, MT = Ri / 128;
     const int tiles8 = (MT + 7) / 8;
-
-    // layer 1 (folded embedding)
+    // layer 1 (folded embedding): S = Ahat . onehot (R x 32), then H1 = elu(S . T1) on the MFMA GEMM (K = 32)
     {
-        const int blocks = 8 * 4 * tiles8;
+        hipLaunchKernelGGL(k_letter_sums, dim3((Ri + 3) / 4), dim3(256), 0, st, seq_idx, rowptr, colidx, val, S, Ri);
+        ScopedTiming tm(TK_GEMM1, st);
         const int C0 = m->gc[0];
-#define MDF_L1(CC) hipLaunchKernelGGL(k_layer1<CC>, dim3(blocks), dim3(256), 0, st, m->T1, seq_idx, rowptr, colidx, val, Ha, partial[0], Ri)
-        if (C0 == 256) MDF_L1(256); else if (C0 == 512) MDF_L1(512); else return fail(MDF_EINVAL, "layer 1 width %d unsupported (256 or 512)", C0);
-#undef MDF_L1
+        int rc;
+        if (m->n_gc == 1)
+            rc = launch_gemm<EPI_ELU_POOL>(S, 32, m->T1t, 32, Ri, C0, 32, nullptr, C0, nullptr, partial[0], nullptr, C0, st);
+        else
+            rc = launch_gemm<EPI_ELU_POOL_STORE>(S, 32, m->T1t, 32, Ri, C0, 32, Ha, C0, nullptr, partial[0], nullptr, C0, st);
+        if (rc) return rc;
     }
     float *Hin = Ha, *Hout = Hb;
     for (int k = 1; k < m->n_gc; ++k) {
@@ -588,11 +594,15 @@ int mdf_gcn_embed_pool_dev(mdf_model *m, const uint8_t *seq_idx, const int32_t *
         }
         std::swap(Hin, Hout);
     }
+    PoolArgs pa;
     int off = 0;
-    for (int k = 0; k < m->n_gc; ++k) {
-        hipLaunchKernelGGL(k_pool_reduce, dim3(B), dim3(256), 0, st, partial[k], m->gc[k], row_off, pooled, m->feat, off);
-        off += m->gc[k];
+    for (int k = 0; k < 3; ++k) {
+        pa.partial[k] = k < m->n_gc ? partial[k] : nullptr;
+        pa.C[k] = k < m->n_gc ? m->gc[k] : 0;
+        pa.off[k] = off;
+        off += pa.C[k];
     }
+    hipLaunchKernelGGL(k_pool_reduce, dim3(B, m->n_gc), dim3(256), 0, st, pa, row_off, pooled, m->feat);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
