@@ -155,6 +155,12 @@ def main():
         R = pk.chunks[0].rows                        # rows per launch (all chunks but the last are equal)
         rows_total = sum(c.rows for c in pk.chunks)
         roof, roof_ax, kernels = None, None, {}
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json); same rows per launch only
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if traffic.get("rows_per_launch") != R:
+                traffic = {}
+        except OSError:
+            traffic = {}
         if timing:
             for kname in ("gemm", "gemm1", "ax", "cmap", "head"):
                 n, ms = read(kname)
@@ -169,7 +175,7 @@ def main():
                 tf = flops / (ms_g * 1e-3) / 1e12
                 roof = {"kernel": "k_gemm_f32 (H.W, 128x128x32 tiles, v_mfma_f32_32x32x2_f32, ELU+pool epilogue)",
                         "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": None,
+                        "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": traffic.get("gemm_mean_bytes"),
                         "per_launch": {"rows": R, "flops": 2.0 * R * C * C, "avg_us": kernels["gemm"]["avg_us"]}}
             if n_a:
                 # read Z (rows x 512 f32) once + write (rows x 512 f32) once per layer; CSR adjacency
@@ -179,7 +185,7 @@ def main():
                 gbs = bytes_launch_rows * rows_total * launches_per_step * args.steps / (ms_a * 1e-3) / 1e9
                 roof_ax = {"kernel": "k_aggregate<512> (A.X, CSR gather, one wave per residue row)", "bound": "hbm",
                            "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                           "traffic": None,
+                           "traffic": (traffic.get("k_aggregate<512>") or {}).get("bytes"),
                            "per_launch": {"rows": R, "bytes": bytes_launch_rows * R, "nnz_per_row": round(nnz_per_row, 2),
                                           "avg_us": kernels["ax"]["avg_us"]}}
         line = {
