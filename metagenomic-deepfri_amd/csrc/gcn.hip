@@ -38,15 +38,18 @@ namespace mdf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32, LDT = BK + 4;  // LDS row stride 36 floats: conflict-free ds_read_b128
+constexpr int BM = 128, BN = 128, BK = 32;
 static_assert(BK == 32, "k_gemm_f32 hand-unrolls exactly four k-groups of 8");
-constexpr int GEMM_LDS_BYTES = 2 /*buffers*/ * 2 /*A,B*/ * BM * LDT * 4;
+constexpr int GEMM_LDS_BYTES = 2 /*buffers*/ * 2 /*A,B*/ * BM * BK * 4;  // 64 KiB: two workgroups per CU
 
 // EPI_L1_* are EPI_ELU_POOL_STORE / EPI_ELU_POOL under another symbol, so that profiles tell the K=32 layer-1 launches
 // from the K=512 H.W launches.
 enum Epilogue { EPI_ELU_POOL_STORE = 0, EPI_ELU_POOL = 1, EPI_BIAS_RELU = 2, EPI_BIAS_SOFTMAX2 = 3, EPI_L1_STORE = 4, EPI_L1 = 5 };
 
-__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : expf(x) - 1.0f; }
+// ELU with the hardware exponential (v_exp_f32 on x*log2(e), ~1 ulp of exp2): for x <= 0 the result lies in (-1, 0] and
+// the absolute error is < 2e-7, far inside the 1e-4 score budget; libm expf costs ~40 VALU instructions per element and
+// made the GEMM epilogue (64 elements per lane) ~12 % of the tile time.
+__device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
 
 // XCD-aware tile order: block b runs on XCD b%8 (observed placement; used for L2 affinity only).  The NT column
 // tiles of one 128-row tile are issued back to back on the same XCD so that the A rows are fetched into that
@@ -58,111 +61,25 @@ __device__ __forceinline__ void tile_of_block(int b, int NT, int &mt, int &nt)
     mt = (q / NT) * 8 + x;
 }
 
-// C[M,N] = epilogue(A[M,K] . Bt[N,K]^T).  A rows >= M read as zero.  N % 128 == 0, K % 32 == 0 (host-checked).
-// 256 threads = 4 waves in a 2x2 grid; each wave owns a 64x64 sub-tile = 2x2 MFMA 32x32 tiles (64 accumulator
-// VGPRs).  Operands are staged global -> VGPR -> LDS (double-buffered, one barrier per k-tile): while the MFMAs of
-// k-tile t run, the loads of k-tile t+1 are in flight.  Fragment reads are ds_read_b128: lane l takes row (l&31)
-// and 4 consecutive k at (l>>5)*4, so the two k-slots of one 32x32x2 MFMA are k and k+4 -- any pairing is valid as
-// long as A and B agree.
+// C[M,N] = epilogue(A[M,K] . Bt[N,K]^T).  N % 128 == 0, K % 32 == 0 (host-checked); rows >= M are computed on
+// clamped addresses and never stored.
+//
+// Persistent kernel: the grid is 2 workgroups per CU and every workgroup walks its share of the 128x128 output tiles
+// (XCD-aware order, tile_of_block).  256 threads = 4 waves in a 2x2 grid; each wave owns a 64x64 sub-tile = 2x2
+// v_mfma_f32_32x32x2_f32 tiles (64 accumulator VGPRs).  Operands are staged global -> VGPR -> LDS, double-buffered
+// with one barrier per k-tile, and the (tile, k) sequence is ONE flat software pipeline: during the last k-tile of an
+// output tile the first k-tile of the NEXT output tile is already being fetched, so neither a block launch nor a
+// prologue load sits between two tiles -- only the epilogue, whose stores drain behind the next tile's MFMAs.
+// (The one-tile-per-block form of this kernel lost ~20 % to synchronised prologue/epilogue phases: all 512 resident
+// blocks loaded, computed and stored in lock-step.)
+// Fragment reads are ds_read_b128: lane l takes row (l&31) and 4 consecutive k at (l>>5)*4, so the two k-slots of one
+// 32x32x2 MFMA are k and k+4 -- any pairing is valid as long as A and B agree.
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb,
-                                                     int M, int N, int K, float *__restrict__ C, int ldc,
-                                                     const float *__restrict__ bias, float *__restrict__ pool_partial,
-                                                     float *__restrict__ logits, int n_real)
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane, int M, int N,
+                                              float *__restrict__ C, int ldc, const float *__restrict__ bias,
+                                              float *__restrict__ pool_partial, float *__restrict__ logits, int n_real)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                   // [2][BM][LDT]
-    float *Bs = smem + 2 * BM * LDT;    // [2][BN][LDT]
-
-    int mt, nt;
-    tile_of_block(blockIdx.x, N / BN, mt, nt);
-    const int m0 = mt * BM, n0 = nt * BN;
-    if (m0 >= M) return;
-
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
-
-    // staging assignment: float4 index f = tid + 256*i, row = f/8, col4 = f%8.  Loads are unconditional (rows past M
-    // are clamped to M-1: their products land in accumulator rows that are never stored) -- a per-load `row < M ? load : 0`
-    // select makes hipcc branch around every load and drain vmcnt(0) after it, serialising the whole prefetch.
-    const int srow = tid >> 3, scol = (tid & 7) * 4;
-    // explicit scalars (no arrays / lambdas): hipcc left the array form of this prefetch buffer in scratch memory
-    const float *ap0 = A + (size_t)min(m0 + srow, M - 1) * lda + scol;
-    const float *ap1 = A + (size_t)min(m0 + srow + 32, M - 1) * lda + scol;
-    const float *ap2 = A + (size_t)min(m0 + srow + 64, M - 1) * lda + scol;
-    const float *ap3 = A + (size_t)min(m0 + srow + 96, M - 1) * lda + scol;
-    const float *bp0 = Bt + (size_t)(n0 + srow) * ldb + scol;
-    const size_t bstep = (size_t)32 * ldb;
-    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define MDF_LOAD_TILE(k0)                                               \
-    ra0 = *reinterpret_cast<const float4 *>(ap0 + (k0));                \
-    ra1 = *reinterpret_cast<const float4 *>(ap1 + (k0));                \
-    ra2 = *reinterpret_cast<const float4 *>(ap2 + (k0));                \
-    ra3 = *reinterpret_cast<const float4 *>(ap3 + (k0));                \
-    rb0 = *reinterpret_cast<const float4 *>(bp0 + (k0));                \
-    rb1 = *reinterpret_cast<const float4 *>(bp0 + bstep + (k0));        \
-    rb2 = *reinterpret_cast<const float4 *>(bp0 + 2 * bstep + (k0));    \
-    rb3 = *reinterpret_cast<const float4 *>(bp0 + 3 * bstep + (k0));
-#define MDF_STORE_TILE(buf)                                                                   \
-    *reinterpret_cast<float4 *>(As + ((buf) * BM + srow) * LDT + scol) = ra0;                 \
-    *reinterpret_cast<float4 *>(As + ((buf) * BM + srow + 32) * LDT + scol) = ra1;            \
-    *reinterpret_cast<float4 *>(As + ((buf) * BM + srow + 64) * LDT + scol) = ra2;            \
-    *reinterpret_cast<float4 *>(As + ((buf) * BM + srow + 96) * LDT + scol) = ra3;            \
-    *reinterpret_cast<float4 *>(Bs + ((buf) * BN + srow) * LDT + scol) = rb0;                 \
-    *reinterpret_cast<float4 *>(Bs + ((buf) * BN + srow + 32) * LDT + scol) = rb1;            \
-    *reinterpret_cast<float4 *>(Bs + ((buf) * BN + srow + 64) * LDT + scol) = rb2;            \
-    *reinterpret_cast<float4 *>(Bs + ((buf) * BN + srow + 96) * LDT + scol) = rb3;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-
-    const int nk = K / BK;
-    MDF_LOAD_TILE(0)
-    MDF_STORE_TILE(0)
-    __syncthreads();
-
-    const int frow = lane & 31, fk = (lane >> 5) * 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) { MDF_LOAD_TILE((kt + 1) * BK) }
-        const float *Ab = As + (cur * BM + wm * 64 + frow) * LDT + fk;
-        const float *Bb = Bs + (cur * BN + wn * 64 + frow) * LDT + fk;
-        // fragments of k-group kg+1 are fetched from LDS while the 16 MFMAs of k-group kg issue
-        float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;
-#define MDF_FRAGS(a0, a1, b0, b1, kg)                                              \
-    a0 = *reinterpret_cast<const float4 *>(Ab + (kg) * 8);                         \
-    a1 = *reinterpret_cast<const float4 *>(Ab + 32 * LDT + (kg) * 8);              \
-    b0 = *reinterpret_cast<const float4 *>(Bb + (kg) * 8);                         \
-    b1 = *reinterpret_cast<const float4 *>(Bb + 32 * LDT + (kg) * 8);
-#define MDF_MFMA4(a0, a1, b0, b1, e)                                                         \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b0.e, acc[0][0], 0, 0, 0);        \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.e, b1.e, acc[0][1], 0, 0, 0);        \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b0.e, acc[1][0], 0, 0, 0);        \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.e, b1.e, acc[1][1], 0, 0, 0);
-#define MDF_MFMA16(a0, a1, b0, b1) MDF_MFMA4(a0, a1, b0, b1, x) MDF_MFMA4(a0, a1, b0, b1, y) MDF_MFMA4(a0, a1, b0, b1, z) MDF_MFMA4(a0, a1, b0, b1, w)
-        MDF_FRAGS(pa0, pa1, pb0, pb1, 0)
-        MDF_FRAGS(qa0, qa1, qb0, qb1, 1)
-        MDF_MFMA16(pa0, pa1, pb0, pb1)
-        MDF_FRAGS(pa0, pa1, pb0, pb1, 2)
-        MDF_MFMA16(qa0, qa1, qb0, qb1)
-        MDF_FRAGS(qa0, qa1, qb0, qb1, 3)
-        MDF_MFMA16(pa0, pa1, pb0, pb1)
-        MDF_MFMA16(qa0, qa1, qb0, qb1)
-#undef MDF_FRAGS
-#undef MDF_MFMA4
-#undef MDF_MFMA16
-        if (kt + 1 < nk) { MDF_STORE_TILE(cur ^ 1) }
-        __syncthreads();
-    }
-
-#undef MDF_LOAD_TILE
-#undef MDF_STORE_TILE
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: lane l, register r -> col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
+    // C/D layout of the 32x32 MFMA: lane l, register r -> col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
     const int lcol = lane & 31, lrow = 4 * (lane >> 5);
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -207,6 +124,207 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A
             }
         }
     }
+}
+
+#ifdef MDF_PROBE_TIMING
+__device__ unsigned long long *g_probe_kt = nullptr;   // [grid][64]: shader-clock stamp at every k-tile start
+__device__ unsigned long long *g_probe_buf = nullptr;  // [grid][4]: realtime start/end (100 MHz), shader cycles start/end
+#endif
+
+// Position of a workgroup in its flat (output tile, k-tile) sequence.
+struct TileCursor {
+    int t, mt, nt, kt;
+};
+__device__ __forceinline__ void cursor_advance(TileCursor &c, int nk, int NT, int M, int total, int stride)
+{
+    if (c.t >= total) return;  // exhausted: stay on the last slot (reads through it are clamped and harmless)
+    if (++c.kt < nk) return;
+    c.kt = 0;
+    for (c.t += stride; c.t < total; c.t += stride) {
+        tile_of_block(c.t, NT, c.mt, c.nt);
+        if (c.mt * BM < M) return;
+    }
+}
+
+// The k-tile schedule.  Operands go global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, no
+// staging VGPRs, no ds_write pass), two LDS buffers, one barrier per k-tile: while the 64 MFMAs of position i run, the
+// 8 DMA instructions of position i+1 fill the other buffer; the only waits are vmcnt(0) + s_barrier at the end of a
+// position and the first fragment read behind it.  The LDS image of a DMA is lane-linear (base + lane*16 B), so rows
+// are unpadded 128 B and bank conflicts are removed with an XOR swizzle applied on the SOURCE address and again on the
+// fragment read: 16-byte slot s of row r lives at slot s ^ ((r>>1)&7); a ds_read_b128 lane group (16 rows, one logical
+// slot) then covers all 16 slots of the 256-B bank row.  Every memory instruction is issued directly behind an MFMA (in
+// its 64-cycle shadow) and pinned there with sched_barrier.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+// One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS[lds_byte_addr + lane*16].  Issued as
+// inline asm on purpose: with the builtin, hipcc treats every later ds_read as a possible reader of the DMA target and
+// drains vmcnt(0) in front of it, which serialises the prefetch with the MFMAs.  The asm form is invisible to that
+// bookkeeping; completion is awaited explicitly (s_waitcnt vmcnt(0) + barrier) before the buffer is read.  M0 carries
+// the LDS base and is compiler-reserved: it is saved and restored inside the same statement.
+__device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_byte_addr)
+                 : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const float *p)
+{
+    return __builtin_amdgcn_readfirstlane((unsigned)(size_t)((lds_void_t *)p));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb,
+                                                     int M, int N, int K, float *__restrict__ C, int ldc,
+                                                     const float *__restrict__ bias, float *__restrict__ pool_partial,
+                                                     float *__restrict__ logits, int n_real, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A 128x32 | B 128x32], unpadded rows
+#ifdef MDF_PROBE_TIMING
+    const unsigned long long probe_t0 = wall_clock64(), probe_c0 = clock64();
+    int probe_n = 0;
+#endif
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 1, wn = wid & 1;
+    const int NT = N / BN, nk = K / BK, stride = gridDim.x;
+
+    TileCursor cc;  // compute cursor
+    cc.kt = 0;
+    int n_mine = 0;
+    {
+        int first = -1, mt, nt;
+        for (int t = blockIdx.x; t < total_tiles; t += stride) {
+            tile_of_block(t, NT, mt, nt);
+            if (mt * BM < M) {
+                if (first < 0) { first = t; cc.t = t; cc.mt = mt; cc.nt = nt; }
+                ++n_mine;
+            }
+        }
+        if (first < 0) return;
+    }
+    int rem = n_mine * nk;   // positions left, including the current one
+    TileCursor pc = cc;      // prefetch cursor: one position ahead of cc
+
+    // DMA roles: wave w moves rows [32w, 32w+32) of the A tile and of the B tile, 8 rows (1 KiB) per instruction.
+    // lane -> (row within the 8-row piece, physical slot); logical (source) slot = physical ^ swizzle(row).
+    const int drow = lane >> 3, dslot = lane & 7;
+    int dcol[4];  // source column (floats) per piece i: rows 32w + 8i + drow -> ((row>>1)&7) = (4i + (lane>>4)) & 7
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dcol[i] = (dslot ^ ((4 * i + (lane >> 4)) & 7)) * 4;
+    // fragment read offsets (floats) inside a tile image: row R, logical slot kg*2 + (lane>>5)
+    const int frow = lane & 31;
+    int foffA[2][4], foffB[2][4];
+#pragma unroll
+    for (int tmn = 0; tmn < 2; ++tmn)
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const int ra = wm * 64 + tmn * 32 + frow, rb = wn * 64 + tmn * 32 + frow;
+            const int s = kg * 2 + (lane >> 5);
+            foffA[tmn][kg] = ra * 32 + ((s ^ ((ra >> 1) & 7)) << 2);
+            foffB[tmn][kg] = rb * 32 + ((s ^ ((rb >> 1) & 7)) << 2);
+        }
+
+#define MDF_DMA_PIECE(i, gA_, gB_, ldsA_, ldsB_)                                           \
+    glds16((gA_) + a_off##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024));                 \
+    glds16((gB_) + b_off##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024));
+    // per-position source bases (wave-uniform part) + per-lane offsets; rows past M clamp to M-1 (never stored)
+#define MDF_DMA_SETUP(cur_)                                                                                         \
+    const float *gA_ = A + (size_t)(cur_).kt * BK;                                                                  \
+    const float *gB_ = Bt + (size_t)((cur_).nt * BN) * ldb + (size_t)(cur_).kt * BK;                                \
+    const int rA_ = (cur_).mt * BM + wid * 32 + drow;                                                               \
+    const size_t a_off0 = (size_t)min(rA_, M - 1) * lda + dcol[0], a_off1 = (size_t)min(rA_ + 8, M - 1) * lda + dcol[1],      \
+                 a_off2 = (size_t)min(rA_ + 16, M - 1) * lda + dcol[2], a_off3 = (size_t)min(rA_ + 24, M - 1) * lda + dcol[3]; \
+    const size_t b_off0 = (size_t)(wid * 32 + drow) * ldb + dcol[0], b_off1 = (size_t)(wid * 32 + drow + 8) * ldb + dcol[1],   \
+                 b_off2 = (size_t)(wid * 32 + drow + 16) * ldb + dcol[2], b_off3 = (size_t)(wid * 32 + drow + 24) * ldb + dcol[3];
+#define MDF_SB __builtin_amdgcn_sched_barrier(0);
+#define MDF_MF(tm, tn, a, b) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tm][tn], 0, 0, 0);
+#define MDF_KGROUP(a0, a1, b0, b1, X0, X1, X2, X3, Y0, Y1, Y2, Y3)                     \
+    MDF_MF(0, 0, a0.x, b0.x) X0 MDF_SB MDF_MF(0, 1, a0.x, b1.x) X1 MDF_SB              \
+    MDF_MF(1, 0, a1.x, b0.x) X2 MDF_SB MDF_MF(1, 1, a1.x, b1.x) X3 MDF_SB              \
+    MDF_MF(0, 0, a0.y, b0.y) Y0 MDF_SB MDF_MF(0, 1, a0.y, b1.y) Y1 MDF_SB              \
+    MDF_MF(1, 0, a1.y, b0.y) Y2 MDF_SB MDF_MF(1, 1, a1.y, b1.y) Y3 MDF_SB              \
+    MDF_MF(0, 0, a0.z, b0.z) MDF_MF(0, 1, a0.z, b1.z) MDF_MF(1, 0, a1.z, b0.z) MDF_MF(1, 1, a1.z, b1.z) \
+    MDF_MF(0, 0, a0.w, b0.w) MDF_MF(0, 1, a0.w, b1.w) MDF_MF(1, 0, a1.w, b0.w) MDF_MF(1, 1, a1.w, b1.w)
+#define MDF_RD(dst, base, off) dst = *reinterpret_cast<const float4 *>((base) + (off));
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const unsigned lds_base = lds_addr_of(smem);
+    // prologue: position 0 -> buffer 0
+    {
+        MDF_DMA_SETUP(pc)
+        const unsigned ldsA = lds_base, ldsB = lds_base + BM * BK * 4;
+        MDF_DMA_PIECE(0, gA_, gB_, ldsA, ldsB) MDF_DMA_PIECE(1, gA_, gB_, ldsA, ldsB)
+        MDF_DMA_PIECE(2, gA_, gB_, ldsA, ldsB) MDF_DMA_PIECE(3, gA_, gB_, ldsA, ldsB)
+        cursor_advance(pc, nk, NT, M, total_tiles, stride);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+#ifdef MDF_PROBE_TIMING
+#define MDF_PROBE_STAMP if (g_probe_kt && threadIdx.x == 0 && probe_n < 64) g_probe_kt[64ull * blockIdx.x + probe_n++] = clock64();
+#else
+#define MDF_PROBE_STAMP
+#endif
+    // one position: compute from buffer CUR while the DMA of the next position fills buffer CUR^1 (past the end the DMA
+    // re-reads the last slot into a buffer nobody reads: unconditional code keeps the wait counts exact)
+#define MDF_POSITION(CUR)                                                                                          \
+    {                                                                                                              \
+        MDF_PROBE_STAMP                                                                                            \
+        const float *Ab = smem + (CUR) * (2 * BM * BK);                                                            \
+        const float *Bb = Ab + BM * BK;                                                                            \
+        const unsigned ldsA = lds_base + ((CUR) ^ 1) * (2 * BM * BK * 4), ldsB = ldsA + BM * BK * 4;               \
+        MDF_DMA_SETUP(pc)                                                                                          \
+        float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;                                                             \
+        MDF_RD(pa0, Ab, foffA[0][0]) MDF_RD(pa1, Ab, foffA[1][0]) MDF_RD(pb0, Bb, foffB[0][0]) MDF_RD(pb1, Bb, foffB[1][0]) \
+        MDF_SB                                                                                                     \
+        MDF_KGROUP(pa0, pa1, pb0, pb1, MDF_RD(qa0, Ab, foffA[0][1]), MDF_RD(qa1, Ab, foffA[1][1]), MDF_RD(qb0, Bb, foffB[0][1]), \
+                   MDF_RD(qb1, Bb, foffB[1][1]), MDF_DMA_PIECE(0, gA_, gB_, ldsA, ldsB), , MDF_DMA_PIECE(1, gA_, gB_, ldsA, ldsB), ) \
+        MDF_KGROUP(qa0, qa1, qb0, qb1, MDF_RD(pa0, Ab, foffA[0][2]), MDF_RD(pa1, Ab, foffA[1][2]), MDF_RD(pb0, Bb, foffB[0][2]), \
+                   MDF_RD(pb1, Bb, foffB[1][2]), MDF_DMA_PIECE(2, gA_, gB_, ldsA, ldsB), , MDF_DMA_PIECE(3, gA_, gB_, ldsA, ldsB), ) \
+        MDF_KGROUP(pa0, pa1, pb0, pb1, MDF_RD(qa0, Ab, foffA[0][3]), MDF_RD(qa1, Ab, foffA[1][3]), MDF_RD(qb0, Bb, foffB[0][3]), \
+                   MDF_RD(qb1, Bb, foffB[1][3]), , , , )                                                           \
+        MDF_KGROUP(qa0, qa1, qb0, qb1, , , , , , , , )                                                             \
+        cursor_advance(pc, nk, NT, M, total_tiles, stride);                                                        \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's DMA has landed */                          \
+        __syncthreads();                                                                                           \
+        if (cc.kt == nk - 1) {                                                                                     \
+            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, logits, n_real); \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)            \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;                                \
+        }                                                                                                          \
+        --rem;                                                                                                     \
+        if (rem > 0) cursor_advance(cc, nk, NT, M, total_tiles, stride);                                           \
+    }
+
+    while (true) {
+        MDF_POSITION(0)
+        if (rem == 0) break;
+        MDF_POSITION(1)
+        if (rem == 0) break;
+    }
+#ifdef MDF_PROBE_TIMING
+    if (g_probe_buf && threadIdx.x == 0) {
+        unsigned long long *o = g_probe_buf + 4ull * blockIdx.x;
+        o[0] = probe_t0; o[1] = wall_clock64(); o[2] = probe_c0; o[3] = clock64();
+    }
+#endif
+#undef MDF_PROBE_STAMP
+#undef MDF_POSITION
+#undef MDF_RD
+#undef MDF_KGROUP
+#undef MDF_MF
+#undef MDF_SB
+#undef MDF_DMA_SETUP
+#undef MDF_DMA_PIECE
 }
 
 // ---- A.X aggregation: out[i,:] = sum_e val[e] * H[colidx[e],:]  over the CSR row i.  One wave per row, lane l owns
@@ -332,6 +450,19 @@ static int set_gemm_attr_once()
     return MDF_OK;
 }
 
+// persistent grid: 2 workgroups per CU (LDS: 2 x 72 KiB), a multiple of 8 so that block b stays on XCD b%8
+static int gemm_resident_blocks()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        n = std::max(8, 2 * cus / 8 * 8);
+        if (const char *e = getenv("MDFRI_GEMM_BLOCKS")) n = std::max(8, atoi(e) / 8 * 8);  // developer override
+    }
+    return n;
+}
+
 template <int EPI>
 static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M, int N, int K, float *C, int ldc,
                        const float *bias, float *pool_partial, float *logits, int n_real, hipStream_t st)
@@ -339,9 +470,10 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     MDF_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d", M, N, K);
     if (int rc = set_gemm_attr_once()) return rc;
     const int MT = (M + BM - 1) / BM, NT = N / BN;
-    const int blocks = 8 * NT * ((MT + 7) / 8);
+    const int total = 8 * NT * ((MT + 7) / 8);               // tile slots in XCD-aware order (some may lie past M)
+    const int blocks = std::min(total, gemm_resident_blocks());
     hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3(blocks), dim3(256), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
-                       pool_partial, logits, n_real);
+                       pool_partial, logits, n_real, total);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }

@@ -1,6 +1,7 @@
 // gemm_probe.hip -- developer tool (not part of the library): times k_gemm_f32 / k_aggregate variants on random data
 // and checks a sample of outputs against a double-precision host reference.
 //   build:  make -C metagenomic-deepfri_amd/csrc probe      run:  metagenomic-deepfri_amd/lib/gemm_probe [M] [iters]
+#define MDF_PROBE_TIMING 1
 #include "../gcn.hip"
 
 #include <random>
@@ -36,7 +37,7 @@ static float time_us(F f, int iters)
 int main(int argc, char **argv)
 {
     const int M = argc > 1 ? atoi(argv[1]) : 32768, iters = argc > 2 ? atoi(argv[2]) : 20;
-    const int N = 512, K = 512;
+    const int N = 512, K = argc > 3 ? atoi(argv[3]) : 512;
     std::mt19937 rng(1);
     std::uniform_real_distribution<float> u(-1.f, 1.f);
     std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
@@ -50,11 +51,84 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
     const double flops = 2.0 * M * N * K;
+    {
+        int nb = -1;
+        (void)set_gemm_attr_once();
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gemm_f32<EPI_ELU_POOL>, 256, GEMM_LDS_BYTES);
+        printf("occupancy query: %d blocks/CU (%s), LDS %d B, grid %d\n", nb, hipGetErrorString(e), GEMM_LDS_BYTES, gemm_resident_blocks());
+    }
 
+    // clock governor warm-up: ~0.3 s of back-to-back GEMMs before anything is timed
+    for (int i = 0; i < 2000; ++i) launch_gemm<EPI_ELU_POOL>(dA, K, dB, K, M, N, K, nullptr, N, nullptr, dP, nullptr, N, 0);
+    CK(hipDeviceSynchronize());
     float t0 = time_us([&] { launch_gemm<EPI_ELU_POOL_STORE>(dA, K, dB, K, M, N, K, dC, N, nullptr, dP, nullptr, N, 0); }, iters);
-    printf("k_gemm_f32<ELU_POOL_STORE>  M=%d: %8.2f us  %6.1f TF\n", M, t0, flops / t0 * 1e-6);
+    printf("k_gemm_f32<ELU_POOL_STORE>  M=%d K=%d: %8.2f us  %6.1f TF\n", M, K, t0, flops / t0 * 1e-6);
     float t1 = time_us([&] { launch_gemm<EPI_ELU_POOL>(dA, K, dB, K, M, N, K, nullptr, N, nullptr, dP, nullptr, N, 0); }, iters);
-    printf("k_gemm_f32<ELU_POOL>        M=%d: %8.2f us  %6.1f TF\n", M, t1, flops / t1 * 1e-6);
+    printf("k_gemm_f32<ELU_POOL>        M=%d K=%d: %8.2f us  %6.1f TF\n", M, K, t1, flops / t1 * 1e-6);
+
+    {   // per-workgroup timeline of one launch: realtime (100 MHz) and shader-clock stamps
+        const int G = gemm_resident_blocks();
+        unsigned long long *dT;
+        CK(hipMalloc(&dT, (size_t)G * 32));
+        CK(hipMemset(dT, 0, (size_t)G * 32));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_buf), &dT, sizeof(dT)));
+        unsigned long long *dK;
+        CK(hipMalloc(&dK, (size_t)G * 64 * 8));
+        CK(hipMemset(dK, 0, (size_t)G * 64 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_kt), &dK, sizeof(dK)));
+        launch_gemm<EPI_ELU_POOL>(dA, K, dB, K, M, N, K, nullptr, N, nullptr, dP, nullptr, N, 0);
+        CK(hipDeviceSynchronize());
+        {
+            std::vector<unsigned long long> hK((size_t)G * 64);
+            CK(hipMemcpy(hK.data(), dK, hK.size() * 8, hipMemcpyDeviceToHost));
+            for (int g : {0, 1, 255, 256, 300, 511}) {
+                if (g >= G) continue;
+                printf("  wg %3d k-tile deltas (cycles):", g);
+                for (int i = 1; i < 64 && hK[64ull * g + i]; ++i) printf(" %llu", hK[64ull * g + i] - hK[64ull * g + i - 1]);
+                printf("\n");
+            }
+            unsigned long long *nulk = nullptr;
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_kt), &nulk, sizeof(nulk)));
+        }
+        std::vector<unsigned long long> hT((size_t)G * 4);
+        CK(hipMemcpy(hT.data(), dT, hT.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        double fsum = 0, dmin = 1e30, dmax = 0, dsum = 0, smax = 0;
+        int n = 0;
+        for (int g = 0; g < G; ++g) {
+            if (!hT[4 * g + 1]) continue;
+            t0 = std::min(t0, hT[4 * g]);
+            t1 = std::max(t1, hT[4 * g + 1]);
+        }
+        for (int g = 0; g < G; ++g) {
+            if (!hT[4 * g + 1]) continue;
+            const double dur_us = (hT[4 * g + 1] - hT[4 * g]) / 100.0;
+            const double ghz = (double)(hT[4 * g + 3] - hT[4 * g + 2]) / (dur_us * 1e3);
+            fsum += ghz; dsum += dur_us; dmin = std::min(dmin, dur_us); dmax = std::max(dmax, dur_us);
+            smax = std::max(smax, (hT[4 * g] - t0) / 100.0);
+            ++n;
+        }
+        printf("timeline: %d workgroups, span %.1f us, wg duration min/avg/max %.1f/%.1f/%.1f us, latest start +%.1f us, shader clock %.3f GHz\n",
+               n, (t1 - t0) / 100.0, dmin, dsum / n, dmax, smax, fsum / n);
+        unsigned long long *nul = nullptr;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_buf), &nul, sizeof(nul)));
+    }
+
+    {   // row-pitch sweep: does a 2 KiB operand pitch camp on a few L2/HBM channels?
+        for (int pad : {0, 16, 32, 64, 96, 160}) {
+            const int ld = K + pad;
+            float *pA, *pB, *pC;
+            CK(hipMalloc(&pA, (size_t)M * ld * 4));
+            CK(hipMalloc(&pB, (size_t)N * ld * 4));
+            CK(hipMalloc(&pC, (size_t)M * (N + pad) * 4));
+            CK(hipMemcpy2D(pA, (size_t)ld * 4, hA.data(), (size_t)K * 4, (size_t)K * 4, M, hipMemcpyHostToDevice));
+            CK(hipMemcpy2D(pB, (size_t)ld * 4, hB.data(), (size_t)K * 4, (size_t)K * 4, N, hipMemcpyHostToDevice));
+            float ta = time_us([&] { launch_gemm<EPI_ELU_POOL>(pA, ld, pB, ld, M, N, K, nullptr, N, nullptr, dP, nullptr, N, 0); }, iters);
+            float tb = time_us([&] { launch_gemm<EPI_ELU_POOL_STORE>(pA, ld, pB, ld, M, N, K, pC, N + pad, nullptr, dP, nullptr, N, 0); }, iters);
+            printf("  pitch K+%-3d: no-store %8.2f us %6.1f TF | store %8.2f us %6.1f TF\n", pad, ta, flops / ta * 1e-6, tb, flops / tb * 1e-6);
+            (void)hipFree(pA); (void)hipFree(pB); (void)hipFree(pC);
+        }
+    }
 
     // correctness sample (store variant)
     launch_gemm<EPI_ELU_POOL_STORE>(dA, K, dB, K, M, N, K, dC, N, nullptr, dP, nullptr, N, 0);
