@@ -181,12 +181,23 @@ int mdf_dense_to_csr_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_
                          float *val, int64_t nnz_cap, int32_t *status, void *workspace, size_t workspace_bytes,
                          void *stream);
 
-/* GraphConv stack + sum pooling for the rows of a batch:  pooled[p] = sum_rows concat(H1,H2,H3)  (B, feature_dim).
+/* Layer-1 operand, shared by every GO head: letter_sums[i][a] = sum of val over the CSR entries of row i whose column
+ * residue is letter a  (= (Ahat . onehot)[i][a]); (R, 32) f32, columns 26..31 zero.  With the embedding folded at model
+ * load (relu(onehot W_aa) W_gc1 is a 26-row table), GraphConv layer 1 is elu(letter_sums . table). */
+int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
+                        float *letter_sums, void *stream);
+
+/* GraphConv stack for R residue rows.  Output: per-32-row-group partial sums of concat(H1,H2,H3):
+ * partial (R/32, feature_dim) f32 -- the deterministic first level of the sum pooling (H3 itself never reaches HBM).
  * workspace: mdf_gcn_workspace_bytes(model, R) bytes. */
 size_t mdf_gcn_workspace_bytes(const mdf_model *m, int64_t R);
-int mdf_gcn_embed_pool_dev(mdf_model *m, const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx,
-                           const float *val, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
-                           float *pooled, void *workspace, size_t workspace_bytes, void *stream);
+int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
+                      int64_t R, float *partial, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Second level of the sum pooling: pooled[p] = sum of partial[g] over g in [grp_off[p], grp_off[p+1])  -> (B, feature_dim).
+ * grp_off (B+1, int32, device) counts 32-row groups (row_off / 32, plus the group base of the protein's chunk when the
+ * partials of several chunks share one array). */
+int mdf_gcn_pool_dev(mdf_model *m, const float *partial, const int32_t *grp_off, int32_t B, float *pooled, void *stream);
 
 /* GO head for B pooled vectors: relu(g W_fc + b_fc) W_out + b_out -> pair softmax -> channel 0 (predict.pyx:100).
  * scores: (B, T) f32.  logits (optional, may be NULL): (B, 2T) pre-softmax, for tolerance studies.

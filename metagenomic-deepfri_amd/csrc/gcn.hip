@@ -77,7 +77,7 @@ __device__ __forceinline__ void tile_of_block(int b, int NT, int &mt, int &nt)
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane, int M, int N,
                                               float *__restrict__ C, int ldc, const float *__restrict__ bias,
-                                              float *__restrict__ pool_partial, float *__restrict__ logits, int n_real)
+                                              float *__restrict__ pool_partial, int ldp, float *__restrict__ logits, int n_real)
 {
     // C/D layout of the 32x32 MFMA: lane l, register r -> col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
     const int lcol = lane & 31, lrow = 4 * (lane >> 5);
@@ -97,7 +97,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], int m0, int n
                     if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_L1_STORE) C[(size_t)row * ldc + col] = v;
                 }
                 s += __shfl_xor(s, 32, 64);
-                if (lane < 32) pool_partial[(size_t)(rbase >> 5) * N + col] = s;
+                if (lane < 32) pool_partial[(size_t)(rbase >> 5) * ldp + col] = s;
             } else if (EPI == EPI_BIAS_RELU) {
                 const float bv = bias[col];
 #pragma unroll
@@ -177,7 +177,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const float *p)
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb,
                                                      int M, int N, int K, float *__restrict__ C, int ldc,
-                                                     const float *__restrict__ bias, float *__restrict__ pool_partial,
+                                                     const float *__restrict__ bias, float *__restrict__ pool_partial, int ldp,
                                                      float *__restrict__ logits, int n_real, int total_tiles)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A 128x32 | B 128x32], unpadded rows
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's DMA has landed */                          \
         __syncthreads();                                                                                           \
         if (cc.kt == nk - 1) {                                                                                     \
-            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, logits, n_real); \
+            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, ldp, logits, n_real); \
             _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)            \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;                                \
         }                                                                                                          \
@@ -417,21 +417,16 @@ __global__ __launch_bounds__(256) void k_letter_sums(const uint8_t *__restrict__
     if (lane < 32) S[(size_t)row * 32 + lane] = (lane < 26) ? c : 0.0f;
 }
 
-// pooled[p, off_k + c] = sum over the 32-row groups of protein p of partial_k[g, c], all GraphConv layers in one launch
-struct PoolArgs {
-    const float *partial[3];
-    int C[3], off[3];
-};
-__global__ void k_pool_reduce(PoolArgs a, const int32_t *__restrict__ row_off, float *__restrict__ pooled, int feat)
+// pooled[p, c] = sum over the 32-row groups [grp_off[p], grp_off[p+1]) of partial[g, c]   (c over all GraphConv layers);
+// fixed summation order -> deterministic.
+__global__ void k_pool_reduce(const float *__restrict__ partial, const int32_t *__restrict__ grp_off, float *__restrict__ pooled, int feat)
 {
-    const int p = blockIdx.x, k = blockIdx.y;
-    const int g0 = row_off[p] >> 5, g1 = row_off[p + 1] >> 5;
-    const float *partial = a.partial[k];
-    const int C = a.C[k];
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int p = blockIdx.x;
+    const int g0 = grp_off[p], g1 = grp_off[p + 1];
+    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < feat; c += gridDim.y * blockDim.x) {
         float s = 0.0f;
-        for (int g = g0; g < g1; ++g) s += partial[(size_t)g * C + c];
-        pooled[(size_t)p * feat + a.off[k] + c] = s;
+        for (int g = g0; g < g1; ++g) s += partial[(size_t)g * feat + c];
+        pooled[(size_t)p * feat + c] = s;
     }
 }
 
@@ -465,7 +460,7 @@ static int gemm_resident_blocks()
 
 template <int EPI>
 static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M, int N, int K, float *C, int ldc,
-                       const float *bias, float *pool_partial, float *logits, int n_real, hipStream_t st)
+                       const float *bias, float *pool_partial, int ldp, float *logits, int n_real, hipStream_t st)
 {
     MDF_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d", M, N, K);
     if (int rc = set_gemm_attr_once()) return rc;
@@ -473,7 +468,7 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     const int total = 8 * NT * ((MT + 7) / 8);               // tile slots in XCD-aware order (some may lie past M)
     const int blocks = std::min(total, gemm_resident_blocks());
     hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3(blocks), dim3(256), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
-                       pool_partial, logits, n_real, total);
+                       pool_partial, ldp, logits, n_real, total);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -500,12 +495,8 @@ struct GcnWs {
 static size_t gcn_ws_bytes(const mdf_model *m, int64_t R)
 {
     int cmax = 0;
-    size_t part = 0;
-    for (int k = 0; k < m->n_gc; ++k) {
-        cmax = std::max(cmax, m->gc[k]);
-        part += align_up((size_t)(R / 32) * m->gc[k] * 4, 256);
-    }
-    return 3 * align_up((size_t)R * cmax * 4, 256) + align_up((size_t)R * 32 * 4, 256) + part + 4096;
+    for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
+    return 3 * align_up((size_t)R * cmax * 4, 256) + 4096;
 }
 
 }  // namespace mdf
@@ -677,38 +668,43 @@ int mdf_model_load(const char *path, int device, mdf_model **out)
 
 size_t mdf_gcn_workspace_bytes(const mdf_model *m, int64_t R) { return m ? gcn_ws_bytes(m, R) : 0; }
 
-int mdf_gcn_embed_pool_dev(mdf_model *m, const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx,
-                           const float *val, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
-                           float *pooled, void *workspace, size_t workspace_bytes, void *stream)
+int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
+                        float *letter_sums, void *stream)
 {
-    (void)Lq;
-    MDF_REQUIRE(m && seq_idx && rowptr && colidx && val && row_off && pooled && workspace, "gcn_embed_pool_dev: NULL argument");
-    MDF_REQUIRE(B > 0 && R > 0 && R % 128 == 0 && R < 0x7fffffff, "gcn_embed_pool_dev: bad layout (B=%d, R=%lld)", B, (long long)R);
+    MDF_REQUIRE(seq_idx && rowptr && colidx && val && letter_sums, "letter_sums_dev: NULL argument");
+    MDF_REQUIRE(R > 0 && R % 128 == 0 && R < 0x7fffffff, "letter_sums_dev: bad row count %lld", (long long)R);
+    hipLaunchKernelGGL(k_letter_sums, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), seq_idx, rowptr,
+                       colidx, val, letter_sums, (int)R);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
+                      int64_t R, float *partial, void *workspace, size_t workspace_bytes, void *stream)
+{
+    MDF_REQUIRE(m && letter_sums && rowptr && colidx && val && partial && workspace, "gcn_embed_dev: NULL argument");
+    MDF_REQUIRE(R > 0 && R % 128 == 0 && R < 0x7fffffff, "gcn_embed_dev: bad row count %lld", (long long)R);
     if (workspace_bytes < gcn_ws_bytes(m, R))
-        return fail(MDF_ECAPACITY, "gcn_embed_pool_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, gcn_ws_bytes(m, R));
+        return fail(MDF_ECAPACITY, "gcn_embed_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, gcn_ws_bytes(m, R));
     hipStream_t st = static_cast<hipStream_t>(stream);
     Carver cv(workspace, workspace_bytes);
     int cmax = 0;
     for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
     float *Ha = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax);
-    float *S = cv.take<float>((size_t)R * 32);
-    float *partial[3] = {nullptr, nullptr, nullptr};
-    for (int k = 0; k < m->n_gc; ++k) partial[k] = cv.take<float>((size_t)(R / 32) * m->gc[k]);
-    const int Ri = (int)R, MT = Ri / 128;
-    const int tiles8 = (MT + 7) / 8;
-    // layer 1 (folded embedding): S = Ahat . onehot (R x 32), then H1 = elu(S . T1) on the MFMA GEMM (K = 32)
+    const int Ri = (int)R, MT = Ri / 128, tiles8 = (MT + 7) / 8, feat = m->feat;
+    // layer 1 (folded embedding): H1 = elu(S . T1) on the MFMA GEMM (K = 32), S = Ahat . onehot from mdf_letter_sums_dev
     {
-        hipLaunchKernelGGL(k_letter_sums, dim3((Ri + 3) / 4), dim3(256), 0, st, seq_idx, rowptr, colidx, val, S, Ri);
         ScopedTiming tm(TK_GEMM1, st);
         const int C0 = m->gc[0];
         int rc;
         if (m->n_gc == 1)
-            rc = launch_gemm<EPI_L1>(S, 32, m->T1t, 32, Ri, C0, 32, nullptr, C0, nullptr, partial[0], nullptr, C0, st);
+            rc = launch_gemm<EPI_L1>(letter_sums, 32, m->T1t, 32, Ri, C0, 32, nullptr, C0, nullptr, partial, feat, nullptr, C0, st);
         else
-            rc = launch_gemm<EPI_L1_STORE>(S, 32, m->T1t, 32, Ri, C0, 32, Ha, C0, nullptr, partial[0], nullptr, C0, st);
+            rc = launch_gemm<EPI_L1_STORE>(letter_sums, 32, m->T1t, 32, Ri, C0, 32, Ha, C0, nullptr, partial, feat, nullptr, C0, st);
         if (rc) return rc;
     }
     float *Hin = Ha, *Hout = Hb;
+    int off = m->gc[0];
     for (int k = 1; k < m->n_gc; ++k) {
         const int Cin = m->gc[k - 1], Cout = m->gc[k];
         {
@@ -723,22 +719,22 @@ int mdf_gcn_embed_pool_dev(mdf_model *m, const uint8_t *seq_idx, const int32_t *
             const bool last = k == m->n_gc - 1;
             int rc;
             if (last)
-                rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial[k], nullptr, Cout, st);
+                rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
             else
-                rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial[k], nullptr, Cout, st);
+                rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
             if (rc) return rc;
         }
+        off += Cout;
         std::swap(Hin, Hout);
     }
-    PoolArgs pa;
-    int off = 0;
-    for (int k = 0; k < 3; ++k) {
-        pa.partial[k] = k < m->n_gc ? partial[k] : nullptr;
-        pa.C[k] = k < m->n_gc ? m->gc[k] : 0;
-        pa.off[k] = off;
-        off += pa.C[k];
-    }
-    hipLaunchKernelGGL(k_pool_reduce, dim3(B, m->n_gc), dim3(256), 0, st, pa, row_off, pooled, m->feat);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+int mdf_gcn_pool_dev(mdf_model *m, const float *partial, const int32_t *grp_off, int32_t B, float *pooled, void *stream)
+{
+    MDF_REQUIRE(m && partial && grp_off && pooled && B > 0, "gcn_pool_dev: bad argument");
+    hipLaunchKernelGGL(k_pool_reduce, dim3(B, 2), dim3(256), 0, static_cast<hipStream_t>(stream), partial, grp_off, pooled, m->feat);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -753,8 +749,8 @@ int mdf_gcn_head_dev(mdf_model *m, const float *pooled, int32_t B, float *scores
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *f = static_cast<float *>(workspace);
     ScopedTiming tm(TK_HEAD, st);
-    if (int rc = launch_gemm<EPI_BIAS_RELU>(pooled, m->feat, m->Wfc_t, m->feat, B, m->fc, m->feat, f, m->fc, m->bfc, nullptr, nullptr, m->fc, st)) return rc;
-    if (int rc = launch_gemm<EPI_BIAS_SOFTMAX2>(f, m->fc, m->Wout_t, m->fc, B, m->n_out_pad, m->fc, scores, m->T, m->bout, nullptr, logits, 2 * m->T, st)) return rc;
+    if (int rc = launch_gemm<EPI_BIAS_RELU>(pooled, m->feat, m->Wfc_t, m->feat, B, m->fc, m->feat, f, m->fc, m->bfc, nullptr, 0, nullptr, m->fc, st)) return rc;
+    if (int rc = launch_gemm<EPI_BIAS_SOFTMAX2>(f, m->fc, m->Wout_t, m->fc, B, m->n_out_pad, m->fc, scores, m->T, m->bout, nullptr, 0, logits, 2 * m->T, st)) return rc;
     return MDF_OK;
 }
 
@@ -778,7 +774,7 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     const size_t o_desc = take(256), o_seq = take((size_t)L), o_idx = take((size_t)R), o_cm = take((size_t)L * L * es),
                  o_rp = take((size_t)(R + 1) * 4), o_ci = take((size_t)nnz_cap * 4), o_va = take((size_t)nnz_cap * 4),
                  o_cws = take(cws), o_gws = take(gws), o_hws = take(hws), o_pool = take((size_t)m->feat * 4),
-                 o_sc = take((size_t)m->T * 4);
+                 o_sc = take((size_t)m->T * 4), o_S = take((size_t)R * 32 * 4), o_part = take((size_t)(R / 32) * m->feat * 4);
     if (m->host_ws_bytes < o) {
         (void)hipFree(m->host_ws);
         m->host_ws = nullptr;
@@ -788,13 +784,14 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     }
     char *b = static_cast<char *>(m->host_ws);
     struct Desc {
-        int32_t Lq[2], row_off[2], seq_off[2], bad[2], status[4];
+        int32_t Lq[2], row_off[2], seq_off[2], bad[2], status[4], grp_off[2];
         int64_t cmap_off[1];
     } d;
     memset(&d, 0, sizeof(d));
     d.Lq[0] = (int32_t)L;
     d.row_off[0] = row_off[0];
     d.row_off[1] = row_off[1];
+    d.grp_off[1] = (int32_t)(R / 32);
     MDF_HIP(hipMemcpyAsync(b + o_desc, &d, sizeof(d), hipMemcpyHostToDevice, nullptr));
     MDF_HIP(hipMemcpyAsync(b + o_seq, seq, (size_t)L, hipMemcpyHostToDevice, nullptr));
     MDF_HIP(hipMemcpyAsync(b + o_cm, cmap, (size_t)L * L * es, hipMemcpyHostToDevice, nullptr));
@@ -807,7 +804,10 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     if (int rc = mdf_dense_to_csr_dev(b + o_cm, cmap_dtype, dd->cmap_off, dd->Lq, dd->row_off, 1, R, d_rp, d_ci, d_va, nnz_cap,
                                       dd->status, b + o_cws, cws, nullptr))
         return rc;
-    if (int rc = mdf_gcn_embed_pool_dev(m, d_idx, d_rp, d_ci, d_va, dd->Lq, dd->row_off, 1, R, d_pool, b + o_gws, gws, nullptr)) return rc;
+    float *d_S = reinterpret_cast<float *>(b + o_S), *d_part = reinterpret_cast<float *>(b + o_part);
+    if (int rc = mdf_letter_sums_dev(d_idx, d_rp, d_ci, d_va, R, d_S, nullptr)) return rc;
+    if (int rc = mdf_gcn_embed_dev(m, d_S, d_rp, d_ci, d_va, R, d_part, b + o_gws, gws, nullptr)) return rc;
+    if (int rc = mdf_gcn_pool_dev(m, d_part, dd->grp_off, 1, d_pool, nullptr)) return rc;
     if (int rc = mdf_gcn_head_dev(m, d_pool, 1, d_sc, nullptr, b + o_hws, hws, nullptr)) return rc;
     Desc back;
     MDF_HIP(hipMemcpy(&back, b + o_desc, sizeof(back), hipMemcpyDeviceToHost));

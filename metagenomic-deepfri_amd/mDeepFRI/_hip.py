@@ -67,8 +67,9 @@ SIGNATURES = {
     "mdf_dense_to_csr_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p,
                                      c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdf_gcn_workspace_bytes": (c_size_t, [c_void_p, c_int64]),
-    "mdf_gcn_embed_pool_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
-                                       c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_letter_sums_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mdf_gcn_embed_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_gcn_pool_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "mdf_head_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
     "mdf_gcn_head_dev": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdf_timing_enable": (c_int, [c_int]),

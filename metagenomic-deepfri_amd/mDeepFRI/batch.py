@@ -41,6 +41,17 @@ class Chunk:
     p1: int
     rows: int              # R of this chunk (multiple of 128)
     row_off_pos: int       # start of this chunk's row_off (p1-p0+1 entries) in PackedProteins.chunk_row_off
+    segment: int = 0       # pooling segment this chunk belongs to
+    group_base: int = 0    # first 32-row group of this chunk inside its segment's partial-sum array
+
+
+@dataclass
+class Segment:
+    """Consecutive chunks whose per-group partial sums share one array and are pooled by one launch per GO head."""
+    p0: int
+    p1: int
+    groups: int            # 32-row groups in the segment
+    grp_off_pos: int       # start of the segment's grp_off (p1-p0+1 entries) in PackedProteins.grp_off
 
 
 @dataclass
@@ -57,13 +68,15 @@ class PackedProteins:
     aln_off: np.ndarray | None = None
     chunks: list = field(default_factory=list)
     chunk_row_off: np.ndarray | None = None
+    segments: list = field(default_factory=list)
+    grp_off: np.ndarray | None = None
 
     @property
     def B(self) -> int:
         return len(self.seqs)
 
     @classmethod
-    def pack(cls, seqs, coords=None, q_alns=None, t_alns=None, max_rows: int = 32768):
+    def pack(cls, seqs, coords=None, q_alns=None, t_alns=None, max_rows: int = 32768, max_segment_groups: int = 1 << 19):
         seqs = list(seqs)
         if not seqs:
             raise ValueError("empty batch")
@@ -95,10 +108,10 @@ class PackedProteins:
             pk.q_aln = np.frombuffer(b"".join(qb), dtype=np.uint8).copy()
             pk.t_aln = np.frombuffer(b"".join(tb), dtype=np.uint8).copy()
             pk.aln_off = _offsets([len(q) for q in qb])
-        pk._plan(max_rows)
+        pk._plan(max_rows, max_segment_groups)
         return pk
 
-    def _plan(self, max_rows: int):
+    def _plan(self, max_rows: int, max_segment_groups: int = 1 << 19):
         L = _hip.lib()
         self.chunks, offs = [], []
         p0, B = 0, self.B
@@ -117,6 +130,30 @@ class PackedProteins:
             offs.append(ro)
             p0 = p1
         self.chunk_row_off = np.concatenate(offs)
+        # pooling segments: protein p's 32-row groups are [grp_off[p], grp_off[p+1]) inside its segment's partial array
+        self.segments, goffs = [], []
+        cur, seg_groups, seg_first = [], 0, 0
+        for ci, ch in enumerate(self.chunks):
+            g = ch.rows // 32
+            if cur and seg_groups + g > max_segment_groups:
+                self._close_segment(cur, seg_groups, goffs)
+                cur, seg_groups = [], 0
+            ch.segment, ch.group_base = len(self.segments), seg_groups
+            cur.append(ci)
+            seg_groups += g
+        self._close_segment(cur, seg_groups, goffs)
+        self.grp_off = np.concatenate(goffs)
+
+    def _close_segment(self, chunk_ids, groups, goffs):
+        first, last = self.chunks[chunk_ids[0]], self.chunks[chunk_ids[-1]]
+        off = np.empty(last.p1 - first.p0 + 1, dtype=np.int32)
+        for ci in chunk_ids:
+            ch = self.chunks[ci]
+            ro = self.chunk_row_off[ch.row_off_pos:ch.row_off_pos + (ch.p1 - ch.p0) + 1]
+            off[ch.p0 - first.p0:ch.p1 - first.p0] = ch.group_base + ro[:-1] // 32
+        off[-1] = groups
+        self.segments.append(Segment(first.p0, last.p1, int(groups), sum(len(o) for o in goffs)))
+        goffs.append(off)
 
     @property
     def max_chunk_rows(self) -> int:
@@ -142,6 +179,7 @@ class DeviceBatch:
         self.seq_bytes = up(packed.seq_bytes)
         self.seq_off = up(packed.seq_off)
         self.chunk_row_off = up(packed.chunk_row_off)
+        self.grp_off = up(packed.grp_off)
         self.coords = self.coord_off = self.q_aln = self.t_aln = self.aln_off = None
         if packed.coords is not None:
             self.coords, self.coord_off = up(packed.coords), up(packed.coord_off)
@@ -186,6 +224,7 @@ class HotPathEngine:
                 "colidx": torch.empty(cap, dtype=torch.int32, device=dev),
                 "val": torch.empty(cap, dtype=torch.float32, device=dev),
                 "seq_idx": torch.empty(rows, dtype=torch.uint8, device=dev),
+                "lsum": torch.empty(rows * 32, dtype=torch.float32, device=dev),
                 "cws": torch.empty(self.L.mdf_cmap_workspace_bytes(1 << 20, rows), dtype=torch.uint8, device=dev),
                 "gws": torch.empty(gws, dtype=torch.uint8, device=dev),
             }
@@ -201,14 +240,44 @@ class HotPathEngine:
         return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
     # -- stages ------------------------------------------------------------------------------------------------------
-    def _gcn_chunk(self, db: DeviceBatch, ch: Chunk, pooled: dict, st):
-        b, Bc = self._bufs, ch.p1 - ch.p0
+    def _gcn_chunk(self, db: DeviceBatch, ch: Chunk, partial: dict, st):
+        """letter sums once per chunk (shared by every head), then the GraphConv stack of each head; the per-group
+        partial sums land in the head's segment array."""
+        b = self._bufs
+        _hip.check(self.L.mdf_letter_sums_dev(_p(b["seq_idx"]), _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]), ch.rows,
+                                              _p(b["lsum"]), st))
         for mode, pred in self.predictors.items():
             feat = pred.session.topology["feature_dim"]
-            _hip.check(self.L.mdf_gcn_embed_pool_dev(
-                pred.session.handle, _p(b["seq_idx"]), _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]), _p(db.Lq, ch.p0),
-                _p(db.chunk_row_off, ch.row_off_pos), Bc, ch.rows, _p(pooled[mode], ch.p0 * feat), _p(b["gws"]),
-                b["gws"].numel(), st))
+            _hip.check(self.L.mdf_gcn_embed_dev(pred.session.handle, _p(b["lsum"]), _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]),
+                                                ch.rows, _p(partial[mode], ch.group_base * feat), _p(b["gws"]), b["gws"].numel(), st))
+
+    def _pool_segment(self, db: DeviceBatch, seg: Segment, partial: dict, pooled: dict, st):
+        for mode, pred in self.predictors.items():
+            feat = pred.session.topology["feature_dim"]
+            _hip.check(self.L.mdf_gcn_pool_dev(pred.session.handle, _p(partial[mode]), _p(db.grp_off, seg.grp_off_pos), seg.p1 - seg.p0,
+                                               _p(pooled[mode], seg.p0 * feat), st))
+
+    def _alloc_partial(self, db):
+        torch = _torch()
+        g = max(sg.groups for sg in db.packed.segments)
+        key = ("partial", g)
+        if self._bufs.get("partial_key") != key:
+            self._bufs["partial"] = {m: torch.empty(g * p.session.topology["feature_dim"], dtype=torch.float32, device=self.device)
+                                     for m, p in self.predictors.items()}
+            self._bufs["partial_key"] = key
+        return self._bufs["partial"]
+
+    def _run_chunks(self, db: DeviceBatch, stage_chunk, st):
+        """Common driver: per chunk `stage_chunk(ci, ch)` builds seq_idx + CSR, then the GCN stack; segments are pooled
+        as soon as their last chunk has been issued."""
+        pooled, partial = self._alloc_pooled(db), self._alloc_partial(db)
+        chunks, segs = db.packed.chunks, db.packed.segments
+        for ci, ch in enumerate(chunks):
+            stage_chunk(ci, ch)
+            self._gcn_chunk(db, ch, partial, st)
+            if ci + 1 == len(chunks) or chunks[ci + 1].segment != ch.segment:
+                self._pool_segment(db, segs[ch.segment], partial, pooled, st)
+        return pooled
 
     def _heads(self, db: DeviceBatch, pooled: dict, want_logits: bool, st):
         torch = _torch()
@@ -238,8 +307,8 @@ class HotPathEngine:
         with torch.cuda.device(self.device):
             self._ensure(db.packed.max_chunk_rows, db.B)
             b, st = self._bufs, self._stream()
-            pooled = self._alloc_pooled(db)
-            for ci, ch in enumerate(db.packed.chunks):
+
+            def stage(ci, ch):
                 Bc = ch.p1 - ch.p0
                 ro = _p(db.chunk_row_off, ch.row_off_pos)
                 _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
@@ -248,7 +317,8 @@ class HotPathEngine:
                     _p(db.coords), _p(db.coord_off, ch.p0), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off, ch.p0), _p(db.Lq, ch.p0), ro,
                     Bc, ch.rows, self.threshold, self.generated_contacts, _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]),
                     self._nnz_cap, _p(db.status, ci * 4), _p(b["cws"]), b["cws"].numel(), st))
-                self._gcn_chunk(db, ch, pooled, st)
+
+            pooled = self._run_chunks(db, stage, st)
             return self._heads(db, pooled, want_logits, st)
 
     def forward_dense(self, db: DeviceBatch, cmaps, want_logits: bool = False):
@@ -260,8 +330,9 @@ class HotPathEngine:
         with torch.cuda.device(self.device):
             self._ensure(db.packed.max_chunk_rows, db.B)
             b, st = self._bufs, self._stream()
-            pooled = self._alloc_pooled(db)
-            for ci, ch in enumerate(db.packed.chunks):
+            keep = []  # device copies of the maps must outlive the asynchronous kernels that read them
+
+            def stage(ci, ch):
                 Bc = ch.p1 - ch.p0
                 ro = _p(db.chunk_row_off, ch.row_off_pos)
                 flat, offs = [], [0]
@@ -272,16 +343,17 @@ class HotPathEngine:
                         raise ValueError(f"protein {p}: cmap shape {A.shape} != ({Lp},{Lp})")
                     flat.append(np.ascontiguousarray(A, dtype=np.float32 if A.dtype.kind == "f" else np.int32).reshape(-1))
                     offs.append(offs[-1] + Lp * Lp)
-                kinds = {a.dtype for a in flat}
-                if len(kinds) > 1:
+                if len({a.dtype for a in flat}) > 1:
                     flat = [a.astype(np.float32) for a in flat]
                 host = np.concatenate(flat)
                 d_maps = torch.from_numpy(host).to(self.device)
                 d_off = torch.from_numpy(np.asarray(offs[:-1], dtype=np.int64)).to(self.device)
+                keep.append((d_maps, d_off))
                 nnz_needed = int(sum(int(np.count_nonzero(a)) for a in flat)) + ch.rows
                 if nnz_needed > self._nnz_cap:
-                    self._bufs["colidx"] = torch.empty(nnz_needed, dtype=torch.int32, device=self.device)
-                    self._bufs["val"] = torch.empty(nnz_needed, dtype=torch.float32, device=self.device)
+                    torch.cuda.current_stream(self.device).synchronize()
+                    b["colidx"] = torch.empty(nnz_needed, dtype=torch.int32, device=self.device)
+                    b["val"] = torch.empty(nnz_needed, dtype=torch.float32, device=self.device)
                     self._nnz_cap = nnz_needed
                 _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
                                                      _p(b["seq_idx"]), _p(db.bad, ci * 2), st))
@@ -289,9 +361,14 @@ class HotPathEngine:
                 _hip.check(self.L.mdf_dense_to_csr_dev(_p(d_maps), dt, _p(d_off), _p(db.Lq, ch.p0), ro, Bc, ch.rows, _p(b["rowptr"]),
                                                        _p(b["colidx"]), _p(b["val"]), self._nnz_cap, _p(db.status, ci * 4),
                                                        _p(b["cws"]), b["cws"].numel(), st))
-                self._gcn_chunk(db, ch, pooled, st)
-                torch.cuda.current_stream(self.device).synchronize()  # d_maps / d_off are freed on loop exit
-            return self._heads(db, pooled, want_logits, st)
+                if len(keep) > 2:  # bound the device memory held by uploaded maps
+                    torch.cuda.current_stream(self.device).synchronize()
+                    del keep[:-1]
+
+            pooled = self._run_chunks(db, stage, st)
+            out = self._heads(db, pooled, want_logits, st)
+            torch.cuda.current_stream(self.device).synchronize()
+            return out
 
     def check(self, db: DeviceBatch):
         """Synchronise and raise what the asynchronous stages flagged (invalid residue, CSR overflow)."""

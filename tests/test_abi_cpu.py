@@ -129,6 +129,14 @@ def test_packing_and_chunk_plan():
         assert ch.rows <= 1024 + 128 or ch.p1 - ch.p0 == 1
         covered += list(range(ch.p0, ch.p1))
     assert covered == list(range(20))
+    # pooling segments: every protein's 32-row groups form a contiguous, ordered range inside its segment
+    pk2 = PackedProteins.pack([p["seq"] for p in prots], max_rows=1024, max_segment_groups=64)
+    assert len(pk2.segments) > 1 and [s.p0 for s in pk2.segments][0] == 0 and pk2.segments[-1].p1 == 20
+    for sg in pk2.segments:
+        off = pk2.grp_off[sg.grp_off_pos:sg.grp_off_pos + (sg.p1 - sg.p0) + 1]
+        assert off[0] == 0 and off[-1] == sg.groups and np.all(np.diff(off) > 0) and sg.groups <= 64
+        assert np.all(np.diff(off)[:-1] * 32 >= pk2.Lq[sg.p0:sg.p1 - 1])
+    assert sum(c.rows // 32 for c in pk2.chunks) == sum(s.groups for s in pk2.segments)
     with pytest.raises(ValueError, match="does not spell"):
         PackedProteins.pack(["ACD"], [prots[0]["coords"]], ["AC-"], ["ACD"])
 
