@@ -38,9 +38,9 @@ namespace mdf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 32;
-static_assert(BK == 32, "k_gemm_f32 hand-unrolls exactly four k-groups of 8");
-constexpr int GEMM_LDS_BYTES = 2 /*buffers*/ * 2 /*A,B*/ * BM * BK * 4;  // 64 KiB: two workgroups per CU
+constexpr int BM = 256, BN = 256, BK = 32;   // GEMM tile (see k_gemm_f32)
+constexpr int GEMM_THREADS = 512;
+constexpr int GEMM_LDS_BYTES = 2 /*buffers*/ * (BM + BN) * BK * 4;  // 128 KiB: one workgroup per CU
 
 // EPI_L1_* are EPI_ELU_POOL_STORE / EPI_ELU_POOL under another symbol, so that profiles tell the K=32 layer-1 launches
 // from the K=512 H.W launches.
@@ -75,17 +75,17 @@ __device__ __forceinline__ void tile_of_block(int b, int NT, int &mt, int &nt)
 // Fragment reads are ds_read_b128: lane l takes row (l&31) and 4 consecutive k at (l>>5)*4, so the two k-slots of one
 // 32x32x2 MFMA are k and k+4 -- any pairing is valid as long as A and B agree.
 template <int EPI>
-__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane, int M, int N,
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n0, int wm, int wn, int lane, int M, int N,
                                               float *__restrict__ C, int ldc, const float *__restrict__ bias,
                                               float *__restrict__ pool_partial, int ldp, float *__restrict__ logits, int n_real)
 {
     // C/D layout of the 32x32 MFMA: lane l, register r -> col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
     const int lcol = lane & 31, lrow = 4 * (lane >> 5);
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm) {
+    for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
         for (int tn = 0; tn < 2; ++tn) {
-            const int rbase = m0 + wm * 64 + tm * 32;
+            const int rbase = m0 + wm * 128 + tm * 32;
             const int col = n0 + wn * 64 + tn * 32 + lcol;
             if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_L1_STORE || EPI == EPI_L1) {
                 float s = 0.0f;
@@ -128,6 +128,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], int m0, int n
 
 #ifdef MDF_PROBE_TIMING
 __device__ unsigned long long *g_probe_kt = nullptr;   // [grid][64]: shader-clock stamp at every k-tile start
+__device__ unsigned long long *g_probe_fine = nullptr; // [8]: stamps inside position 5 of workgroup 0
 __device__ unsigned long long *g_probe_buf = nullptr;  // [grid][4]: realtime start/end (100 MHz), shader cycles start/end
 #endif
 
@@ -146,14 +147,24 @@ __device__ __forceinline__ void cursor_advance(TileCursor &c, int nk, int NT, in
     }
 }
 
-// The k-tile schedule.  Operands go global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, no
-// staging VGPRs, no ds_write pass), two LDS buffers, one barrier per k-tile: while the 64 MFMAs of position i run, the
-// 8 DMA instructions of position i+1 fill the other buffer; the only waits are vmcnt(0) + s_barrier at the end of a
-// position and the first fragment read behind it.  The LDS image of a DMA is lane-linear (base + lane*16 B), so rows
-// are unpadded 128 B and bank conflicts are removed with an XOR swizzle applied on the SOURCE address and again on the
-// fragment read: 16-byte slot s of row r lives at slot s ^ ((r>>1)&7); a ds_read_b128 lane group (16 rows, one logical
-// slot) then covers all 16 slots of the 256-B bank row.  Every memory instruction is issued directly behind an MFMA (in
-// its 64-cycle shadow) and pinned there with sched_barrier.
+// k_gemm_f32: C[M,N] = epilogue(A[M,K] . Bt[N,K]^T), fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
+// N % 256 == 0, K % 32 == 0 (host-checked); rows >= M are computed on clamped addresses and never stored.
+//
+// Geometry.  One 512-thread workgroup per CU owns a 256 x 256 output tile: 8 waves as 2 (M) x 4 (N), each wave a
+// 128 x 64 sub-tile = 4 x 2 MFMA tiles (128 accumulator VGPRs), two waves per SIMD.  The tile size is set by the
+// CU's global->LDS fill rate (~10 B/clk/CU): a 128x128 tile needs 8 B/clk/CU to keep the fp32 matrix pipe fed
+// (measured: LDS-DMA landing 3-4 us late, 79 % MFMA utilisation); 256x256 needs 4 B/clk/CU.
+// Staging.  Operands go global -> LDS directly (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging
+// VGPRs, no ds_write pass) into two 64 KiB LDS buffers, one barrier per k-tile of 32: while the 128 MFMAs per wave of
+// position i run, the 8 DMA instructions per wave of position i+1 fill the other buffer.  The (tile, k-tile) sequence
+// of a workgroup is ONE flat software pipeline (persistent kernel), so no launch or prologue sits between two tiles.
+// LDS image.  A DMA writes lane-linear (base + lane*16 B), so rows are unpadded 128 B and bank conflicts are removed
+// with an XOR swizzle applied on the SOURCE address and again on the fragment read: 16-byte slot s of row r lives at
+// slot s ^ ((r>>1)&7); a ds_read_b128 lane group (16 rows, one logical slot) then covers all 16 slots of the 256-B
+// bank row.  Lane l reads row (l&31) and 4 consecutive k at slot kg*2 + (l>>5): the two k-slots of one 32x32x2 MFMA
+// are k and k+4 -- any pairing is valid as long as A and B agree.
+// Issue order.  A wave issues in order and an MFMA holds the matrix pipe 64 cycles, so every memory instruction sits
+// directly behind an MFMA, in its shadow, pinned with sched_barrier.
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 // One LDS-DMA instruction: 64 lanes x 16 B from per-lane global addresses to LDS[lds_byte_addr + lane*16].  Issued as
@@ -175,19 +186,19 @@ __device__ __forceinline__ unsigned lds_addr_of(const float *p)
 }
 
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb,
-                                                     int M, int N, int K, float *__restrict__ C, int ldc,
-                                                     const float *__restrict__ bias, float *__restrict__ pool_partial, int ldp,
-                                                     float *__restrict__ logits, int n_real, int total_tiles)
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt,
+                                                              int ldb, int M, int N, int K, float *__restrict__ C, int ldc,
+                                                              const float *__restrict__ bias, float *__restrict__ pool_partial,
+                                                              int ldp, float *__restrict__ logits, int n_real, int total_tiles)
 {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A 128x32 | B 128x32], unpadded rows
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A 256x32 | B 256x32], unpadded rows
 #ifdef MDF_PROBE_TIMING
     const unsigned long long probe_t0 = wall_clock64(), probe_c0 = clock64();
     int probe_n = 0;
 #endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid >> 2, wn = wid & 3;
     const int NT = N / BN, nk = K / BK, stride = gridDim.x;
 
     TileCursor cc;  // compute cursor
@@ -208,97 +219,118 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A
     TileCursor pc = cc;      // prefetch cursor: one position ahead of cc
 
     // DMA roles: wave w moves rows [32w, 32w+32) of the A tile and of the B tile, 8 rows (1 KiB) per instruction.
-    // lane -> (row within the 8-row piece, physical slot); logical (source) slot = physical ^ swizzle(row).
+    // lane -> (row within the 8-row piece, physical slot); logical (source) slot = physical ^ swizzle(row), with
+    // swizzle(32w + 8i + drow) = ((row>>1)&7) = (4i + (lane>>4)) & 7.
     const int drow = lane >> 3, dslot = lane & 7;
-    int dcol[4];  // source column (floats) per piece i: rows 32w + 8i + drow -> ((row>>1)&7) = (4i + (lane>>4)) & 7
+    int dcol[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dcol[i] = (dslot ^ ((4 * i + (lane >> 4)) & 7)) * 4;
-    // fragment read offsets (floats) inside a tile image: row R, logical slot kg*2 + (lane>>5)
-    const int frow = lane & 31;
-    int foffA[2][4], foffB[2][4];
+    // fragment reads: row R = (wave base) + 32*tile + (lane&31); swizzle(R) = ((lane&31)>>1)&7 for every tile, so the
+    // per-lane part is one base + four k-group slot offsets; the tile index is an immediate (tile * 4 KiB).
+    const int frow = lane & 31, fswz = (frow >> 1) & 7;
+    const int fbaseA = (wm * 128 + frow) * 32, fbaseB = (wn * 64 + frow) * 32;
+    int fkg[4];
 #pragma unroll
-    for (int tmn = 0; tmn < 2; ++tmn)
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            const int ra = wm * 64 + tmn * 32 + frow, rb = wn * 64 + tmn * 32 + frow;
-            const int s = kg * 2 + (lane >> 5);
-            foffA[tmn][kg] = ra * 32 + ((s ^ ((ra >> 1) & 7)) << 2);
-            foffB[tmn][kg] = rb * 32 + ((s ^ ((rb >> 1) & 7)) << 2);
-        }
+    for (int kg = 0; kg < 4; ++kg) fkg[kg] = ((kg * 2 + (lane >> 5)) ^ fswz) << 2;
 
-#define MDF_DMA_PIECE(i, gA_, gB_, ldsA_, ldsB_)                                           \
-    glds16((gA_) + a_off##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024));                 \
-    glds16((gB_) + b_off##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024));
-    // per-position source bases (wave-uniform part) + per-lane offsets; rows past M clamp to M-1 (never stored)
+    // per-lane DMA source pointers of the position the prefetch cursor points at; recomputed (pure VALU/SALU work) in
+    // the last k-group of every position for the DMA issued at the head of the next one.  Rows past M clamp to M-1.
+    const float *sa0, *sa1, *sa2, *sa3, *sb0, *sb1, *sb2, *sb3;
 #define MDF_DMA_SETUP(cur_)                                                                                         \
-    const float *gA_ = A + (size_t)(cur_).kt * BK;                                                                  \
-    const float *gB_ = Bt + (size_t)((cur_).nt * BN) * ldb + (size_t)(cur_).kt * BK;                                \
-    const int rA_ = (cur_).mt * BM + wid * 32 + drow;                                                               \
-    const size_t a_off0 = (size_t)min(rA_, M - 1) * lda + dcol[0], a_off1 = (size_t)min(rA_ + 8, M - 1) * lda + dcol[1],      \
-                 a_off2 = (size_t)min(rA_ + 16, M - 1) * lda + dcol[2], a_off3 = (size_t)min(rA_ + 24, M - 1) * lda + dcol[3]; \
-    const size_t b_off0 = (size_t)(wid * 32 + drow) * ldb + dcol[0], b_off1 = (size_t)(wid * 32 + drow + 8) * ldb + dcol[1],   \
-                 b_off2 = (size_t)(wid * 32 + drow + 16) * ldb + dcol[2], b_off3 = (size_t)(wid * 32 + drow + 24) * ldb + dcol[3];
+    {                                                                                                               \
+        const float *gA_ = A + (size_t)(cur_).kt * BK;                                                              \
+        const float *gB_ = Bt + (size_t)((cur_).nt * BN + wid * 32 + drow) * ldb + (size_t)(cur_).kt * BK;          \
+        const int rA_ = (cur_).mt * BM + wid * 32 + drow;                                                           \
+        sa0 = gA_ + (size_t)min(rA_, M - 1) * lda + dcol[0];                                                        \
+        sa1 = gA_ + (size_t)min(rA_ + 8, M - 1) * lda + dcol[1];                                                    \
+        sa2 = gA_ + (size_t)min(rA_ + 16, M - 1) * lda + dcol[2];                                                   \
+        sa3 = gA_ + (size_t)min(rA_ + 24, M - 1) * lda + dcol[3];                                                   \
+        sb0 = gB_ + dcol[0];                                                                                        \
+        sb1 = gB_ + (size_t)8 * ldb + dcol[1];                                                                      \
+        sb2 = gB_ + (size_t)16 * ldb + dcol[2];                                                                     \
+        sb3 = gB_ + (size_t)24 * ldb + dcol[3];                                                                     \
+    }
+#define MDF_DMA_PIECE(i, ldsA_, ldsB_)                                       \
+    glds16(sa##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024));               \
+    glds16(sb##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024));
 #define MDF_SB __builtin_amdgcn_sched_barrier(0);
 #define MDF_MF(tm, tn, a, b) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tm][tn], 0, 0, 0);
-#define MDF_KGROUP(a0, a1, b0, b1, X0, X1, X2, X3, Y0, Y1, Y2, Y3)                     \
-    MDF_MF(0, 0, a0.x, b0.x) X0 MDF_SB MDF_MF(0, 1, a0.x, b1.x) X1 MDF_SB              \
-    MDF_MF(1, 0, a1.x, b0.x) X2 MDF_SB MDF_MF(1, 1, a1.x, b1.x) X3 MDF_SB              \
-    MDF_MF(0, 0, a0.y, b0.y) Y0 MDF_SB MDF_MF(0, 1, a0.y, b1.y) Y1 MDF_SB              \
-    MDF_MF(1, 0, a1.y, b0.y) Y2 MDF_SB MDF_MF(1, 1, a1.y, b1.y) Y3 MDF_SB              \
-    MDF_MF(0, 0, a0.z, b0.z) MDF_MF(0, 1, a0.z, b1.z) MDF_MF(1, 0, a1.z, b0.z) MDF_MF(1, 1, a1.z, b1.z) \
-    MDF_MF(0, 0, a0.w, b0.w) MDF_MF(0, 1, a0.w, b1.w) MDF_MF(1, 0, a1.w, b0.w) MDF_MF(1, 1, a1.w, b1.w)
-#define MDF_RD(dst, base, off) dst = *reinterpret_cast<const float4 *>((base) + (off));
+    // fragments of one k-group: A tiles 0..3 (F##a0..a3), B tiles 0..1 (F##b0, F##b1)
+#define MDF_FRAG_DECL(F) float4 F##a0, F##a1, F##a2, F##a3, F##b0, F##b1;
+#define MDF_RDA(F, t, kg, base) F##a##t = *reinterpret_cast<const float4 *>((base) + (t) * 1024 + fkg[kg]);
+#define MDF_RDB(F, t, kg, base) F##b##t = *reinterpret_cast<const float4 *>((base) + (t) * 1024 + fkg[kg]);
+    // 8 MFMAs on one k element e of fragments F; X0..X7 are issued behind MFMA 0..7
+#define MDF_K8(F, e, X0, X1, X2, X3, X4, X5, X6, X7)                                                   \
+    MDF_MF(0, 0, F##a0.e, F##b0.e) X0 MDF_SB MDF_MF(0, 1, F##a0.e, F##b1.e) X1 MDF_SB                    \
+    MDF_MF(1, 0, F##a1.e, F##b0.e) X2 MDF_SB MDF_MF(1, 1, F##a1.e, F##b1.e) X3 MDF_SB                    \
+    MDF_MF(2, 0, F##a2.e, F##b0.e) X4 MDF_SB MDF_MF(2, 1, F##a2.e, F##b1.e) X5 MDF_SB                    \
+    MDF_MF(3, 0, F##a3.e, F##b0.e) X6 MDF_SB MDF_MF(3, 1, F##a3.e, F##b1.e) X7 MDF_SB
+#define MDF_K8_PLAIN(F, e)                                                                             \
+    MDF_MF(0, 0, F##a0.e, F##b0.e) MDF_MF(0, 1, F##a0.e, F##b1.e) MDF_MF(1, 0, F##a1.e, F##b0.e) MDF_MF(1, 1, F##a1.e, F##b1.e) \
+    MDF_MF(2, 0, F##a2.e, F##b0.e) MDF_MF(2, 1, F##a2.e, F##b1.e) MDF_MF(3, 0, F##a3.e, F##b0.e) MDF_MF(3, 1, F##a3.e, F##b1.e)
 
-    f32x16 acc[2][2];
+    f32x16 acc[4][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     const unsigned lds_base = lds_addr_of(smem);
-    // prologue: position 0 -> buffer 0
+    MDF_FRAG_DECL(p) MDF_FRAG_DECL(q)
+    // prologue: position 0 -> buffer 0; pointers for position 1; first fragments
     {
         MDF_DMA_SETUP(pc)
         const unsigned ldsA = lds_base, ldsB = lds_base + BM * BK * 4;
-        MDF_DMA_PIECE(0, gA_, gB_, ldsA, ldsB) MDF_DMA_PIECE(1, gA_, gB_, ldsA, ldsB)
-        MDF_DMA_PIECE(2, gA_, gB_, ldsA, ldsB) MDF_DMA_PIECE(3, gA_, gB_, ldsA, ldsB)
+        MDF_DMA_PIECE(0, ldsA, ldsB) MDF_DMA_PIECE(1, ldsA, ldsB) MDF_DMA_PIECE(2, ldsA, ldsB) MDF_DMA_PIECE(3, ldsA, ldsB)
         cursor_advance(pc, nk, NT, M, total_tiles, stride);
+        MDF_DMA_SETUP(pc)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const float *A0 = smem + fbaseA, *B0 = smem + BM * BK + fbaseB;
+        MDF_RDA(p, 0, 0, A0) MDF_RDB(p, 0, 0, B0) MDF_RDB(p, 1, 0, B0) MDF_RDA(p, 1, 0, A0) MDF_RDA(p, 2, 0, A0) MDF_RDA(p, 3, 0, A0)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
 #ifdef MDF_PROBE_TIMING
 #define MDF_PROBE_STAMP if (g_probe_kt && threadIdx.x == 0 && probe_n < 64) g_probe_kt[64ull * blockIdx.x + probe_n++] = clock64();
 #else
 #define MDF_PROBE_STAMP
 #endif
-    // one position: compute from buffer CUR while the DMA of the next position fills buffer CUR^1 (past the end the DMA
-    // re-reads the last slot into a buffer nobody reads: unconditional code keeps the wait counts exact)
+    // One position.  Entry state: fragments p = k-group 0 of this position (read during the previous position's last
+    // k-group), DMA pointers of the next position ready.  The barrier sits BEFORE the last k-group: by then every wave
+    // has issued its last read of buffer CUR (k-group 3 fragments, fetched during k-group 2) and its DMA of the next
+    // position has had three k-groups to land, so one barrier covers both hazards -- and the last k-group's MFMA shadows
+    // hide the next position's first fragment reads and its DMA address arithmetic.  No wait is left at the boundary.
+    // (Past the end the DMA re-reads the last slot into a buffer nobody reads: branch-free schedule.)
 #define MDF_POSITION(CUR)                                                                                          \
     {                                                                                                              \
         MDF_PROBE_STAMP                                                                                            \
-        const float *Ab = smem + (CUR) * (2 * BM * BK);                                                            \
-        const float *Bb = Ab + BM * BK;                                                                            \
-        const unsigned ldsA = lds_base + ((CUR) ^ 1) * (2 * BM * BK * 4), ldsB = ldsA + BM * BK * 4;               \
-        MDF_DMA_SETUP(pc)                                                                                          \
-        float4 pa0, pa1, pb0, pb1, qa0, qa1, qb0, qb1;                                                             \
-        MDF_RD(pa0, Ab, foffA[0][0]) MDF_RD(pa1, Ab, foffA[1][0]) MDF_RD(pb0, Bb, foffB[0][0]) MDF_RD(pb1, Bb, foffB[1][0]) \
-        MDF_SB                                                                                                     \
-        MDF_KGROUP(pa0, pa1, pb0, pb1, MDF_RD(qa0, Ab, foffA[0][1]), MDF_RD(qa1, Ab, foffA[1][1]), MDF_RD(qb0, Bb, foffB[0][1]), \
-                   MDF_RD(qb1, Bb, foffB[1][1]), MDF_DMA_PIECE(0, gA_, gB_, ldsA, ldsB), , MDF_DMA_PIECE(1, gA_, gB_, ldsA, ldsB), ) \
-        MDF_KGROUP(qa0, qa1, qb0, qb1, MDF_RD(pa0, Ab, foffA[0][2]), MDF_RD(pa1, Ab, foffA[1][2]), MDF_RD(pb0, Bb, foffB[0][2]), \
-                   MDF_RD(pb1, Bb, foffB[1][2]), MDF_DMA_PIECE(2, gA_, gB_, ldsA, ldsB), , MDF_DMA_PIECE(3, gA_, gB_, ldsA, ldsB), ) \
-        MDF_KGROUP(pa0, pa1, pb0, pb1, MDF_RD(qa0, Ab, foffA[0][3]), MDF_RD(qa1, Ab, foffA[1][3]), MDF_RD(qb0, Bb, foffB[0][3]), \
-                   MDF_RD(qb1, Bb, foffB[1][3]), , , , )                                                           \
-        MDF_KGROUP(qa0, qa1, qb0, qb1, , , , , , , , )                                                             \
-        cursor_advance(pc, nk, NT, M, total_tiles, stride);                                                        \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's DMA has landed */                          \
+        const float *Ab = smem + (CUR) * ((BM + BN) * BK) + fbaseA;                                                \
+        const float *Bb = smem + (CUR) * ((BM + BN) * BK) + BM * BK + fbaseB;                                      \
+        const float *An = smem + ((CUR) ^ 1) * ((BM + BN) * BK) + fbaseA;                                          \
+        const float *Bn = smem + ((CUR) ^ 1) * ((BM + BN) * BK) + BM * BK + fbaseB;                                \
+        const unsigned ldsA = lds_base + ((CUR) ^ 1) * ((BM + BN) * BK * 4), ldsB = ldsA + BM * BK * 4;            \
+        /* k-group 0 on p; q <- k-group 1; the whole DMA of the next position */                                    \
+        MDF_K8(p, x, MDF_RDA(q, 0, 1, Ab), MDF_RDB(q, 0, 1, Bb), MDF_RDB(q, 1, 1, Bb), MDF_RDA(q, 1, 1, Ab), MDF_RDA(q, 2, 1, Ab), MDF_RDA(q, 3, 1, Ab), , ) \
+        MDF_K8(p, y, MDF_DMA_PIECE(0, ldsA, ldsB), , MDF_DMA_PIECE(1, ldsA, ldsB), , MDF_DMA_PIECE(2, ldsA, ldsB), , MDF_DMA_PIECE(3, ldsA, ldsB), ) \
+        MDF_K8_PLAIN(p, z) MDF_K8_PLAIN(p, w)                                                                      \
+        /* k-group 1 on q; p <- k-group 2 */                                                                       \
+        MDF_K8(q, x, MDF_RDA(p, 0, 2, Ab), MDF_RDB(p, 0, 2, Bb), MDF_RDB(p, 1, 2, Bb), MDF_RDA(p, 1, 2, Ab), MDF_RDA(p, 2, 2, Ab), MDF_RDA(p, 3, 2, Ab), , ) \
+        MDF_K8_PLAIN(q, y) MDF_K8_PLAIN(q, z) MDF_K8_PLAIN(q, w)                                                   \
+        /* k-group 2 on p; q <- k-group 3 (last reads of buffer CUR) */                                            \
+        MDF_K8(p, x, MDF_RDA(q, 0, 3, Ab), MDF_RDB(q, 0, 3, Bb), MDF_RDB(q, 1, 3, Bb), MDF_RDA(q, 1, 3, Ab), MDF_RDA(q, 2, 3, Ab), MDF_RDA(q, 3, 3, Ab), , ) \
+        MDF_K8_PLAIN(p, y) MDF_K8_PLAIN(p, z) MDF_K8_PLAIN(p, w)                                                   \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's DMA of the next position has landed */     \
         __syncthreads();                                                                                           \
+        /* k-group 3 on q; p <- k-group 0 of the NEXT position (buffer CUR^1); next DMA's address arithmetic */     \
+        MDF_K8(q, x, MDF_RDA(p, 0, 0, An), MDF_RDB(p, 0, 0, Bn), MDF_RDB(p, 1, 0, Bn), MDF_RDA(p, 1, 0, An), MDF_RDA(p, 2, 0, An), MDF_RDA(p, 3, 0, An), , ) \
+        cursor_advance(pc, nk, NT, M, total_tiles, stride);                                                        \
+        MDF_DMA_SETUP(pc)                                                                                          \
+        MDF_K8_PLAIN(q, y) MDF_K8_PLAIN(q, z) MDF_K8_PLAIN(q, w)                                                   \
         if (cc.kt == nk - 1) {                                                                                     \
             gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, ldp, logits, n_real); \
-            _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)            \
+            _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)            \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;                                \
         }                                                                                                          \
         --rem;                                                                                                     \
@@ -319,8 +351,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_f32(const float *__restrict__ A
 #endif
 #undef MDF_PROBE_STAMP
 #undef MDF_POSITION
-#undef MDF_RD
-#undef MDF_KGROUP
+#undef MDF_K8
+#undef MDF_K8_PLAIN
+#undef MDF_RDA
+#undef MDF_RDB
+#undef MDF_FRAG_DECL
 #undef MDF_MF
 #undef MDF_SB
 #undef MDF_DMA_SETUP
@@ -445,14 +480,14 @@ static int set_gemm_attr_once()
     return MDF_OK;
 }
 
-// persistent grid: 2 workgroups per CU (LDS: 2 x 72 KiB), a multiple of 8 so that block b stays on XCD b%8
+// persistent grid: one 512-thread workgroup per CU (LDS: 128 KiB), a multiple of 8 so that block b stays on XCD b%8
 static int gemm_resident_blocks()
 {
     static int n = 0;
     if (!n) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        n = std::max(8, 2 * cus / 8 * 8);
+        n = std::max(8, cus / 8 * 8);
         if (const char *e = getenv("MDFRI_GEMM_BLOCKS")) n = std::max(8, atoi(e) / 8 * 8);  // developer override
     }
     return n;
@@ -467,7 +502,7 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     const int MT = (M + BM - 1) / BM, NT = N / BN;
     const int total = 8 * NT * ((MT + 7) / 8);               // tile slots in XCD-aware order (some may lie past M)
     const int blocks = std::min(total, gemm_resident_blocks());
-    hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3(blocks), dim3(256), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
+    hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
                        pool_partial, ldp, logits, n_real, total);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
@@ -529,7 +564,7 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
     m->fc = w->fc_dim;
     m->T = w->n_terms;
     m->feat = feat;
-    m->n_out_pad = (2 * w->n_terms + BN - 1) / BN * BN;
+    m->n_out_pad = (2 * w->n_terms + BN - 1) / BN * BN;  // output layer padded to whole GEMM column tiles
     int rc = MDF_OK;
     {
         // T1 = relu(W_aa) @ W_gc1 in double, rounded once to f32

@@ -17,6 +17,63 @@ using namespace mdf;
         }                                                                              \
     } while (0)
 
+// global -> LDS/VGPR fill-rate microbenchmark: every CU's workgroup (512 threads) fetches 64 KiB per "position" with the
+// GEMM's access shapes and nothing else.  MODE 0: LDS-DMA, operand pattern (8 rows x 128 B per instruction, 2 KiB pitch);
+// 1: LDS-DMA, contiguous 1 KiB per instruction; 2: global_load_dwordx4 -> VGPR, operand pattern; 3: -> VGPR, contiguous.
+template <int MODE>
+__global__ __launch_bounds__(512) void k_fill_rate(const float *__restrict__ A, int lda, int M, int positions, float *__restrict__ sink,
+                                                   unsigned long long *__restrict__ stamps)
+{
+    f32x16 macc[8];
+    for (int t = 0; t < 8; ++t)
+        for (int r = 0; r < 16; ++r) macc[t][r] = 0.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds_base = lds_addr_of(smem);
+    const int row0 = (blockIdx.x * 256) % (M - 256);
+    float4 accv = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < positions; ++p) {
+        const int k0 = (p * 32) % lda;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {   // 8 pieces of 1 KiB per wave = 64 KiB per workgroup
+            const float *src;
+            if (MODE == 0 || MODE == 2 || MODE >= 4) src = A + (size_t)(row0 + (wid * 8 + i) % 32 * 8 + (lane >> 3)) * lda + k0 + (lane & 7) * 4;
+            else src = A + (size_t)(row0 + (p & 7) * 32) * lda + (size_t)((wid * 8 + i) * 256 + lane * 4);
+            if (MODE < 2 || MODE >= 4) glds16(src, lds_base + (unsigned)(((p & 1) * 64 + wid * 8 + i) * 1024));
+            else {
+                const float4 v = *reinterpret_cast<const float4 *>(src);
+                accv.x += v.x; accv.y += v.y; accv.z += v.z; accv.w += v.w;
+            }
+        }
+        if (MODE >= 4) {   // 4: + 128 register-only MFMAs per wave between the DMA issue and the wait; 5: + LDS fragment reads too
+            const float *lb = smem + (p & 1 ? 0 : 16384) + (lane & 31) * 32 + (lane >> 5) * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 fa = make_float4(1.f, 2.f, 3.f, 4.f), fb = fa;
+                if (MODE == 5) {
+                    fa = *reinterpret_cast<const float4 *>(lb + g * 8);
+                    fb = *reinterpret_cast<const float4 *>(lb + 8192 + g * 8);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, macc[t], 0, 0, 0);
+                    macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, macc[t], 0, 0, 0);
+                    macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, macc[t], 0, 0, 0);
+                    macc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, macc[t], 0, 0, 0);
+                }
+            }
+            if (stamps && blockIdx.x == 0 && threadIdx.x == 0 && p == 5) stamps[0] = clock64();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (MODE >= 4 && stamps && blockIdx.x == 0 && threadIdx.x == 0 && p == 5) stamps[1] = clock64();
+        __syncthreads();
+    }
+    float keep = accv.x;
+    if (MODE >= 4)
+        for (int t = 0; t < 8; ++t) keep += macc[t][0];
+    if (sink && keep == 12345.678f) sink[threadIdx.x] = keep + smem[threadIdx.x];
+}
+
 template <typename F>
 static float time_us(F f, int iters)
 {
@@ -54,16 +111,16 @@ int main(int argc, char **argv)
     {
         int nb = -1;
         (void)set_gemm_attr_once();
-        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gemm_f32<EPI_ELU_POOL>, 256, GEMM_LDS_BYTES);
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_gemm_f32<EPI_ELU_POOL>, GEMM_THREADS, GEMM_LDS_BYTES);
         printf("occupancy query: %d blocks/CU (%s), LDS %d B, grid %d\n", nb, hipGetErrorString(e), GEMM_LDS_BYTES, gemm_resident_blocks());
     }
 
     // clock governor warm-up: ~0.3 s of back-to-back GEMMs before anything is timed
-    for (int i = 0; i < 2000; ++i) launch_gemm<EPI_ELU_POOL>(dA, K, dB, K, M, N, K, nullptr, N, nullptr, dP, nullptr, N, 0);
+    for (int i = 0; i < 2000; ++i) launch_gemm<EPI_ELU_POOL>(dA, K, dB, K, M, N, K, nullptr, N, nullptr, dP, N, nullptr, N, 0);
     CK(hipDeviceSynchronize());
-    float t0 = time_us([&] { launch_gemm<EPI_ELU_POOL_STORE>(dA, K, dB, K, M, N, K, dC, N, nullptr, dP, nullptr, N, 0); }, iters);
+    float t0 = time_us([&] { launch_gemm<EPI_ELU_POOL_STORE>(dA, K, dB, K, M, N, K, dC, N, nullptr, dP, N, nullptr, N, 0); }, iters);
     printf("k_gemm_f32<ELU_POOL_STORE>  M=%d K=%d: %8.2f us  %6.1f TF\n", M, K, t0, flops / t0 * 1e-6);
-    float t1 = time_us([&] { launch_gemm<EPI_ELU_POOL>(dA, K, dB, K, M, N, K, nullptr, N, nullptr, dP, nullptr, N, 0); }, iters);
+    float t1 = time_us([&] { launch_gemm<EPI_ELU_POOL>(dA, K, dB, K, M, N, K, nullptr, N, nullptr, dP, N, nullptr, N, 0); }, iters);
     printf("k_gemm_f32<ELU_POOL>        M=%d K=%d: %8.2f us  %6.1f TF\n", M, K, t1, flops / t1 * 1e-6);
 
     {   // per-workgroup timeline of one launch: realtime (100 MHz) and shader-clock stamps
@@ -76,7 +133,11 @@ int main(int argc, char **argv)
         CK(hipMalloc(&dK, (size_t)G * 64 * 8));
         CK(hipMemset(dK, 0, (size_t)G * 64 * 8));
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_kt), &dK, sizeof(dK)));
-        launch_gemm<EPI_ELU_POOL>(dA, K, dB, K, M, N, K, nullptr, N, nullptr, dP, nullptr, N, 0);
+        unsigned long long *dF;
+        CK(hipMalloc(&dF, 64));
+        CK(hipMemset(dF, 0, 64));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_fine), &dF, sizeof(dF)));
+        launch_gemm<EPI_ELU_POOL>(dA, K, dB, K, M, N, K, nullptr, N, nullptr, dP, N, nullptr, N, 0);
         CK(hipDeviceSynchronize());
         {
             std::vector<unsigned long long> hK((size_t)G * 64);
@@ -87,7 +148,12 @@ int main(int argc, char **argv)
                 for (int i = 1; i < 64 && hK[64ull * g + i]; ++i) printf(" %llu", hK[64ull * g + i] - hK[64ull * g + i - 1]);
                 printf("\n");
             }
+            unsigned long long hF[8];
+            CK(hipMemcpy(hF, dF, 64, hipMemcpyDeviceToHost));
+            printf("  fine stamps (cycles): setup %llu | mfma-stream %llu | vmcnt %llu | barrier %llu\n", hF[1] - hF[0], hF[2] - hF[1], hF[3] - hF[2], hF[4] - hF[3]);
             unsigned long long *nulk = nullptr;
+            CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_fine), &nulk, sizeof(nulk)));
+
             CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_kt), &nulk, sizeof(nulk)));
         }
         std::vector<unsigned long long> hT((size_t)G * 4);
@@ -114,6 +180,25 @@ int main(int argc, char **argv)
         CK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe_buf), &nul, sizeof(nul)));
     }
 
+    {   // fill-rate microbenchmark
+        const int P = 64;
+#define FILL_RUN(x)                                                                                                   \
+    {                                                                                                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fill_rate<x>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072); \
+        float tt = time_us([&] { hipLaunchKernelGGL(k_fill_rate<x>, dim3(256), dim3(512), 131072, 0, dA, K, M, P, (float *)nullptr, dStamp); }, 20); \
+        printf("  fill mode %d: %8.2f us per launch, %.2f us per 64 KiB position, %.1f GB/s per CU, %.2f TB/s chip\n", x, tt, tt / P, 65536.0 / (tt / P) * 1e-3, 256 * 65536.0 / (tt / P) * 1e-6); \
+    }
+        unsigned long long *dStamp, hS[2];
+        CK(hipMalloc(&dStamp, 16));
+        FILL_RUN(0) FILL_RUN(1) FILL_RUN(2) FILL_RUN(3)
+        FILL_RUN(4)
+        CK(hipMemcpy(hS, dStamp, 16, hipMemcpyDeviceToHost));
+        printf("    mode 4: vmcnt(0) wait after the MFMAs: %llu cycles\n", hS[1] - hS[0]);
+        FILL_RUN(5)
+        CK(hipMemcpy(hS, dStamp, 16, hipMemcpyDeviceToHost));
+        printf("    mode 5: vmcnt(0) wait after the MFMAs: %llu cycles\n", hS[1] - hS[0]);
+    }
+
     {   // row-pitch sweep: does a 2 KiB operand pitch camp on a few L2/HBM channels?
         for (int pad : {0, 16, 32, 64, 96, 160}) {
             const int ld = K + pad;
@@ -123,15 +208,15 @@ int main(int argc, char **argv)
             CK(hipMalloc(&pC, (size_t)M * (N + pad) * 4));
             CK(hipMemcpy2D(pA, (size_t)ld * 4, hA.data(), (size_t)K * 4, (size_t)K * 4, M, hipMemcpyHostToDevice));
             CK(hipMemcpy2D(pB, (size_t)ld * 4, hB.data(), (size_t)K * 4, (size_t)K * 4, N, hipMemcpyHostToDevice));
-            float ta = time_us([&] { launch_gemm<EPI_ELU_POOL>(pA, ld, pB, ld, M, N, K, nullptr, N, nullptr, dP, nullptr, N, 0); }, iters);
-            float tb = time_us([&] { launch_gemm<EPI_ELU_POOL_STORE>(pA, ld, pB, ld, M, N, K, pC, N + pad, nullptr, dP, nullptr, N, 0); }, iters);
+            float ta = time_us([&] { launch_gemm<EPI_ELU_POOL>(pA, ld, pB, ld, M, N, K, nullptr, N, nullptr, dP, N, nullptr, N, 0); }, iters);
+            float tb = time_us([&] { launch_gemm<EPI_ELU_POOL_STORE>(pA, ld, pB, ld, M, N, K, pC, N + pad, nullptr, dP, N, nullptr, N, 0); }, iters);
             printf("  pitch K+%-3d: no-store %8.2f us %6.1f TF | store %8.2f us %6.1f TF\n", pad, ta, flops / ta * 1e-6, tb, flops / tb * 1e-6);
             (void)hipFree(pA); (void)hipFree(pB); (void)hipFree(pC);
         }
     }
 
     // correctness sample (store variant)
-    launch_gemm<EPI_ELU_POOL_STORE>(dA, K, dB, K, M, N, K, dC, N, nullptr, dP, nullptr, N, 0);
+    launch_gemm<EPI_ELU_POOL_STORE>(dA, K, dB, K, M, N, K, dC, N, nullptr, dP, N, nullptr, N, 0);
     std::vector<float> hC((size_t)M * N);
     CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
     double maxerr = 0;
