@@ -368,13 +368,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
 template <int C>
 __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, const int32_t *__restrict__ rowptr,
                                                    const int32_t *__restrict__ colidx, const float *__restrict__ val,
-                                                   float *__restrict__ out, int R)
+                                                   float *__restrict__ out, int R, int sb_log, int nt_store)
 {
     constexpr int NV = C / 256;
+    // XCD placement (block b runs on XCD b%8): a 2^sb_log-row super-block stays on one XCD, so that the neighbour rows
+    // its blocks gather are, for the most part, fetched into that XCD's L2 once.
     const int b = blockIdx.x, x = b & 7, q = b >> 3;
-    const int mt = (q >> 5) * 8 + x;                       // 128-row tile
+    const int per_sb = 1 << (sb_log - 2);                  // blocks (4 rows each) per super-block
+    const int sb = (q / per_sb) * 8 + x;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row = mt * 128 + (q & 31) * 4 + wid;
+    const int row = (sb << sb_log) + (q % per_sb) * 4 + wid;
     if (row >= R) return;
     const int lane = threadIdx.x & 63;
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
@@ -418,8 +421,17 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, 
             acc[v].w = fmaf(w, h.w, acc[v].w);
         }
     }
+    if (nt_store) {  // the aggregated rows are not re-read by this kernel: keep them out of the way of the gathered rows
 #pragma unroll
-    for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(out + (size_t)row * C + v * 256 + lane * 4) = acc[v];
+        for (int v = 0; v < NV; ++v) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f t = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
+            __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(out + (size_t)row * C + v * 256 + lane * 4));  // one 16-B nt store
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(out + (size_t)row * C + v * 256 + lane * 4) = acc[v];
+    }
 }
 
 // ---- layer 1 operand: S[i, a] = sum_{e in row i, seq[colidx[e]] == a} val[e]   (= (Ahat . onehot)[i, a]), 32 columns
@@ -726,7 +738,7 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
     int cmax = 0;
     for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
     float *Ha = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax);
-    const int Ri = (int)R, MT = Ri / 128, tiles8 = (MT + 7) / 8, feat = m->feat;
+    const int Ri = (int)R, feat = m->feat;
     // layer 1 (folded embedding): H1 = elu(S . T1) on the MFMA GEMM (K = 32), S = Ahat . onehot from mdf_letter_sums_dev
     {
         ScopedTiming tm(TK_GEMM1, st);
@@ -744,8 +756,14 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
         const int Cin = m->gc[k - 1], Cout = m->gc[k];
         {
             ScopedTiming tm(TK_AX, st);
-            const int blocks = 8 * 32 * tiles8;
-#define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, Ri)
+            // developer knobs; defaults: 512-row super-blocks per XCD, and non-temporal output stores once input + output
+            // slabs no longer fit the 256 MiB Infinity Cache together (measured: +12 % at 65536 rows, -2 % at 32768)
+            static const int sb_log = getenv("MDFRI_AX_SB_LOG") ? atoi(getenv("MDFRI_AX_SB_LOG")) : 9;
+            static const int nt_env = getenv("MDFRI_AX_NT") ? atoi(getenv("MDFRI_AX_NT")) : -1;
+            const int nt_store = nt_env >= 0 ? nt_env : ((size_t)Ri * Cin * 8 > (size_t)200 << 20);
+            const int n_sb = (Ri + (1 << sb_log) - 1) >> sb_log;
+            const int blocks = 8 * (1 << (sb_log - 2)) * ((n_sb + 7) / 8);
+#define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, Ri, sb_log, nt_store)
             if (Cin == 256) MDF_AX(256); else if (Cin == 512) MDF_AX(512); else MDF_AX(1024);
 #undef MDF_AX
         }
