@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--chunk-rows", type=int, default=65536, help="residue rows per fused chunk (multiples of 32768 = full rounds of 256x256 GEMM tiles on 256 CUs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--force-device", type=int, default=None, help="testing aid: put every rank on this device ordinal")
     return ap.parse_args()
 
 
@@ -94,11 +96,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.force_device is not None:
+        local_rank = args.force_device
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from mDeepFRI import _hip, batch, sharding, synthetic
     from mDeepFRI.predict import Predictor
@@ -141,7 +148,7 @@ def main():
     elapsed = time.perf_counter() - t0
     lib.mdf_timing_enable(0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     eng.check(db)

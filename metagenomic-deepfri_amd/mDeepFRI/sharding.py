@@ -44,6 +44,8 @@ def gather_scores(local_scores, local_index, total: int, dst: int = 0, group=Non
         out[torch.as_tensor(list(local_index), dtype=torch.long, device=local_scores.device)] = local_scores
         return out
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if dist.get_backend(group) == "gloo" and local_scores.is_cuda:
+        local_scores = local_scores.cpu()  # gloo has no device gather; RCCL ("nccl") gathers in HBM over xGMI
     dev = local_scores.device
     n_local, T = local_scores.shape
     counts = torch.zeros(world, dtype=torch.long, device=dev)
