@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--chunk-rows", type=int, default=65536, help="residue rows per fused chunk (multiples of 32768 = full rounds of 256x256 GEMM tiles on 256 CUs)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--workload", default="configs2", choices=["configs2", "mixed"],
+                    help="configs2 (headline): fixed length, identity alignments; mixed: configs[3]-style L~U[128,1024] with 5%% indels")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-device", type=int, default=None, help="testing aid: put every rank on this device ordinal")
     return ap.parse_args()
@@ -114,9 +116,16 @@ def main():
     preds = {m: Predictor(f"synthetic-{m}", weights=weights[m], device=local_rank) for m in MODES}
     T_total = sum(p.n_terms for p in preds.values())
 
-    seqs, coords = make_workload(42 + 2 + 1000 * rank, args.proteins, args.length)  # seed = 42 + config index (+rank)
+    if args.workload == "mixed":   # configs[3] shape: ragged lengths, gapped alignments (sorted by length as pipeline.py:529)
+        prots = synthetic.synthetic_proteins(42 + 3 + 1000 * rank, args.proteins, (128, 1024), indel_rate=0.05)
+        prots.sort(key=lambda p: len(p["seq"]))
+        seqs, coords = [p["seq"] for p in prots], [p["coords"] for p in prots]
+        q_alns, t_alns = [p["q_aln"] for p in prots], [p["t_aln"] for p in prots]
+    else:
+        seqs, coords = make_workload(42 + 2 + 1000 * rank, args.proteins, args.length)  # seed = 42 + config index (+rank)
+        q_alns = t_alns = seqs
     eng = batch.HotPathEngine(preds, device=local_rank, max_rows=args.chunk_rows)
-    pk = batch.PackedProteins.pack(seqs, coords, seqs, seqs, max_rows=args.chunk_rows)
+    pk = batch.PackedProteins.pack(seqs, coords, q_alns, t_alns, max_rows=args.chunk_rows)
     db = eng.upload(pk)
     lib = _hip.lib()
     global_index = list(range(rank * args.proteins, (rank + 1) * args.proteins))
@@ -208,8 +217,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"configs[2]: {args.proteins} synthetic L={args.length} proteins per GPU, GCN_MF+BP+CC "
-                                   f"(T={T_total}), fused cmap(6A, gen=2)+GCN, identity alignments",
+            "config": {"workload": (f"configs[2]: {args.proteins} synthetic L={args.length} proteins per GPU, GCN_MF+BP+CC "
+                                    f"(T={T_total}), fused cmap(6A, gen=2)+GCN, identity alignments") if args.workload == "configs2" else
+                                   (f"configs[3]-style: {args.proteins} synthetic proteins per GPU, L~U[128,1024], 5% indels, "
+                                    f"GCN_MF+BP+CC (T={T_total}), fused cmap align(6A, gen=2)+GCN"),
                        "proteins_per_gpu": args.proteins, "length": args.length, "go_heads": list(MODES),
                        "chunk_rows": args.chunk_rows, "parallelism": f"shard{world}+gather" if world > 1 else "single"},
             "roofline": roof,
@@ -217,7 +228,7 @@ def main():
             "kernels": kernels,
         }
         if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(seqs[:1024], coords[:1024], weights, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(seqs[:1024], coords[:1024], weights, args.cpu_seconds) if args.workload == "configs2" else None
             line["gpu_over_cpu_1core"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         else:
             line["cpu_baseline"] = None

@@ -206,6 +206,16 @@ size_t mdf_head_workspace_bytes(const mdf_model *m, int32_t B);
 int mdf_gcn_head_dev(mdf_model *m, const float *pooled, int32_t B, float *scores, float *logits,
                      void *workspace, size_t workspace_bytes, void *stream);
 
+/* Output stage next to the path (mDeepFRI/pipeline.py:696-705, 733-740: results.tsv keeps, per protein, the terms with
+ * float(score) >= 0.1 sorted by score descending; Python's sort is stable, so equal scores keep term order).
+ * scores: (B, T) f32.  offsets: (B+1) int32 out; term_idx / kept_scores: `capacity` entries, protein p's terms at
+ * [offsets[p], offsets[p+1]).  status: device int32[4], zero-initialised: [0] != 0 -> capacity too small (needed count
+ * in [1]).  T <= 8192.  workspace: mdf_filter_workspace_bytes(B). */
+size_t mdf_filter_workspace_bytes(int32_t B);
+int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float threshold, int32_t *offsets, int32_t *term_idx,
+                          float *kept_scores, int64_t capacity, int32_t *status, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
 /* Timing hook for bench.py: when enabled, the library brackets every launch of the named kernel class with
  * hipEvents on the stream it is launched on and accumulates count and milliseconds (read after a sync).
  * kernel: "ax" (A.X aggregation), "gemm" (H.W fp32 MFMA, layers 2..3), "gemm1" (layer-1 S.T1 GEMM, K=32), "cmap" (fused contact map), "head". */
