@@ -49,7 +49,7 @@ def test_compute_fails_loudly_without_gpu():
     with pytest.raises(_hip.MdfriError):
         seq2onehot("ACD")
     with pytest.raises(_hip.MdfriError):
-        Predictor("x.onnx", weights=synthetic.glorot_gcn_weights(0, 8, embed=64, gc_dims=(256, 256, 256), fc_dim=128))
+        Predictor("x.onnx", weights=synthetic.glorot_gcn_weights(0, 8, embed=64, gc_dims=(256, 256, 256), fc_dim=256))
 
 
 def test_argument_validation_happens_before_the_device_is_touched():
