@@ -1,13 +1,15 @@
 // gcn.hip -- DeepFRI GCN forward on gfx950 (replaces the onnxruntime session of mDeepFRI/predict.pyx:50-102).
 //
 // Per batch of proteins laid out as residue rows (see mdfri.h "Residue-row layout"):
-//   layer 1   H1 = elu( Ahat . relu(onehot W_aa) . W1 )   -- folded: relu(onehot W_aa) W1 is a 26-row table T1
-//                                                            (one-hot rows select table rows), so layer 1 is a sparse
-//                                                            aggregation of T1 rows: H1[i] = elu(sum_j val_ij T1[seq_j])
-//   layer k   H_k = elu( (Ahat . H_{k-1}) . W_k )          -- k_aggregate (A.X, HBM-bound) then k_gemm (fp32 MFMA)
-//   pooling   g   = sum_rows concat(H1,H2,H3)              -- per-32-row partial sums written by the producing kernel
-//                                                            (deterministic, no atomics), folded by k_pool_reduce
-//   head      y   = softmax2( relu(g W_fc + b_fc) W_out + b_out )[:,0]   -- the same fp32 MFMA GEMM, other epilogues
+//   layer 1   H1 = elu( Ahat . relu(onehot W_aa) . W1 )   -- folded: one-hot rows select rows, so relu(onehot W_aa) W1
+//                                                            is a 26-row table T1 and Ahat . onehot a 26-column matrix
+//                                                            S (k_letter_sums, shared by all GO heads):
+//                                                            H1 = elu(S . T1), a K = 32 launch of the MFMA GEMM
+//   layer k   H_k = elu( (Ahat . H_{k-1}) . W_k )          -- k_aggregate (A.X, HBM/L2-bound) then k_gemm_f32 (fp32 MFMA)
+//   pooling   g   = sum_rows concat(H1,H2,H3)              -- per-32-row partial sums written by the producing GEMM
+//                                                            epilogue (deterministic, no atomics; H3 never reaches
+//                                                            HBM), folded per protein by k_pool_reduce
+//   head      y   = softmax2( relu(g W_fc + b_fc) W_out + b_out )[:,0]   -- the same GEMM kernel, other epilogues
 //
 // Arithmetic is fp32 throughout (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains); the reference tolerance is 1e-4
 // absolute on the scores (north_star), checked against oracle/gcn_oracle.py.

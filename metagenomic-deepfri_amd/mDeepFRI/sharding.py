@@ -70,3 +70,37 @@ def gather_scores(local_scores, local_index, total: int, dst: int = 0, group=Non
         keep = i >= 0
         out[i[keep]] = b[keep]
     return out
+
+
+def predict_sharded(engine, seqs, coords, q_alns, t_alns, modes=None, dst: int = 0, group=None, max_rows: int = 65536):
+    """Whole multi-GPU path for one workload known to every rank: deal proteins to ranks by cost, run the fused hot path
+    on this rank's shard with `engine` (a mDeepFRI.batch.HotPathEngine bound to this rank's GPU), gather once.
+    Returns {mode: (N, T) torch tensor in input order} on `dst`, None on the other ranks.  With an uninitialised
+    process group it degenerates to the single-GPU path."""
+    import torch
+    import torch.distributed as dist
+    from .batch import PackedProteins
+
+    n = len(seqs)
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = partition_by_cost([len(s) for s in seqs], world)[rank]
+    modes = list(modes or engine.predictors.keys())
+    widths = [engine.predictors[m].n_terms for m in modes]
+    if mine:
+        pk = PackedProteins.pack([seqs[i] for i in mine], [coords[i] for i in mine], [q_alns[i] for i in mine],
+                                 [t_alns[i] for i in mine], max_rows=max_rows)
+        db = engine.upload(pk)
+        out = engine.forward_alignments(db)
+        engine.check(db)
+        block = torch.cat([out[m] for m in modes], dim=1)
+    else:
+        block = torch.zeros((0, sum(widths)), dtype=torch.float32, device=engine.device)
+    full = gather_scores(block, mine, total=n, dst=dst, group=group)
+    if full is None:
+        return None
+    res, c = {}, 0
+    for m, w in zip(modes, widths):
+        res[m] = full[:, c:c + w]
+        c += w
+    return res
