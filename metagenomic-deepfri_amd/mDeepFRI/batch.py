@@ -111,6 +111,17 @@ class PackedProteins:
         pk._plan(max_rows, max_segment_groups)
         return pk
 
+    @classmethod
+    def from_alignments(cls, alignments, max_rows: int = 32768, max_segment_groups: int = 1 << 19):
+        """Pack objects carrying the AlignmentResult attributes the reference's path reads (query_sequence, coords,
+        gapped_sequence, gapped_target; reference alignment.py:106-150).  Entries without coordinates are skipped, as
+        pipeline.py:485 filters them; returns (packed, kept_indices)."""
+        keep = [i for i, a in enumerate(alignments) if a.coords is not None]
+        al = [alignments[i] for i in keep]
+        pk = cls.pack([a.gapped_sequence.replace("-", "") for a in al], [a.coords for a in al], [a.gapped_sequence for a in al],
+                      [a.gapped_target for a in al], max_rows=max_rows, max_segment_groups=max_segment_groups)
+        return pk, keep
+
     def _plan(self, max_rows: int, max_segment_groups: int = 1 << 19):
         L = _hip.lib()
         self.chunks, offs = [], []

@@ -169,3 +169,36 @@ def test_synthetic_generators_are_deterministic_and_pipeline_realistic():
         assert p["coords"].shape == (len(p["t_aln"].replace("-", "")), 3) and p["coords"].dtype == np.float32
         step = np.linalg.norm(np.diff(p["coords"], axis=0), axis=1)
         assert np.allclose(step, 3.8, atol=0.01)
+
+
+def test_insert_gaps_reference_kats_and_contract():
+    # reference mDeepFRI/tests/test_alignment.py:38-45
+    from mDeepFRI.alignment import AlignmentResult, insert_gaps
+    assert insert_gaps("AACT", "AAT", "MMDM") == ("AACT", "AA-T")
+    assert insert_gaps("AAT", "AATC", "MMMI") == ("AAT-", "AATC")
+    assert insert_gaps("AAT", "FGTC", "XXMI") == ("AAT-", "FGTC")
+    assert insert_gaps("", "", "") == ("", "") and insert_gaps("AC", "AC", "") == ("AC", "AC")
+
+    def ref(seq, tgt, aln):  # the semantics of list.insert on growing lists, including indices past the end
+        a, b = list(seq), list(tgt)
+        for i, c in enumerate(aln):
+            if c == "I":
+                a.insert(i, "-")
+            elif c == "D":
+                b.insert(i, "-")
+        return "".join(a), "".join(b)
+
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        seq = synthetic.random_sequence(rng, int(rng.integers(0, 12)))
+        tgt = synthetic.random_sequence(rng, int(rng.integers(0, 12)))
+        aln = "".join(rng.choice(list("MIDX"), size=int(rng.integers(0, 20))))
+        assert insert_gaps(seq, tgt, aln) == ref(seq, tgt, aln)
+    r = AlignmentResult("q", "AACT", "t.pdb", "AAT", "MMDM", 0.9, 0.8, 0.7, "pdb100", coords=None)
+    assert (r.gapped_sequence, r.gapped_target, r.coords) == ("AACT", "AA-T", None)
+    from mDeepFRI.batch import PackedProteins
+    rs = [AlignmentResult("q1", "AACT", "t1", "AAT", "MMDM", coords=np.zeros((3, 3), np.float32)),
+          AlignmentResult("q2", "AAT", "t2", "AATC", "MMMI", coords=None),
+          AlignmentResult("q3", "AAT", "t3", "AATC", "MMMI", coords=np.zeros((4, 3), np.float32))]
+    pk, keep = PackedProteins.from_alignments(rs)
+    assert keep == [0, 2] and pk.seqs == ["AACT", "AAT"] and list(pk.Lq) == [4, 3] and list(pk.coord_off) == [0, 3, 7]
