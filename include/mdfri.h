@@ -216,8 +216,10 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
                           float *kept_scores, int64_t capacity, int32_t *status, void *workspace, size_t workspace_bytes,
                           void *stream);
 
-/* Timing hook for bench.py: when enabled, the library brackets every launch of the named kernel class with
- * hipEvents on the stream it is launched on and accumulates count and milliseconds (read after a sync).
+/* Timing hook for bench.py: mdf_timing_enable(n), n = 0 off, n >= 1: the library brackets every n-th launch of each
+ * kernel class with hipEvents on the stream it is launched on and accumulates count and milliseconds of the sampled
+ * launches (read after a sync).  An event pair costs GPU time between kernels (~6 % of the step when every launch is
+ * timed), hence the sampling.
  * kernel: "ax" (A.X aggregation), "gemm" (H.W fp32 MFMA, layers 2..3), "gemm1" (layer-1 S.T1 GEMM, K=32), "cmap" (fused contact map), "head". */
 int mdf_timing_enable(int on);
 int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms);
