@@ -90,6 +90,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n
             const int rbase = m0 + wm * 128 + tm * 32;
             const int col = n0 + wn * 64 + tn * 32 + lcol;
             if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_L1_STORE || EPI == EPI_L1) {
+                // M is a multiple of 32 here (residue rows) but not of the 256-row tile: 32-row blocks past M are
+                // neither stored nor pooled (wave-uniform test)
+                if (rbase >= M) continue;
                 float s = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {

@@ -83,6 +83,24 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own HIP/HSA runtime.  If libmdfri_hip.so pulled in the system runtime first, a later
+    `import torch` would bind to it by SONAME and find no usable device (two ROCm versions in one process).  Loading
+    torch's copy first -- located without importing torch -- makes both share one runtime, whatever the import order."""
+    if os.environ.get("MDFRI_NO_TORCH_HIP_PRELOAD"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if not spec or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass  # fall back to the system ROCm runtime
+
+
 def lib() -> ctypes.CDLL:
     """Load libmdfri_hip.so; raise ImportError with the build recipe when it is missing."""
     global _lib
@@ -92,6 +110,7 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} not found: the HIP extension has not been built and mDeepFRI (MI355X) has no CPU "
                 f"fallback.  Build it with `make -C {os.path.join(os.path.dirname(_PKG_DIR), 'csrc')}` "
                 f"(or `python -c 'import __graft_entry__ as g; g.build()'` from the repository root).")
+        _preload_torch_hip_runtime()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch

@@ -206,3 +206,58 @@ def test_model_file_round_trip(tmp_path, mf):
     seq = synthetic.random_sequence(rng, 64)
     cm = orc.calculate_contact_map(synthetic.random_walk_coords(rng, 64), 6.0)
     assert np.array_equal(p2.forward_pass(seq, cm), pred.forward_pass(seq, cm))
+
+
+def test_rows_not_multiple_of_gemm_tile_do_not_write_out_of_bounds(mf):
+    """R (multiple of 128) need not be a multiple of the 256-row GEMM tile: the half-empty last tile must neither store
+    activations nor pool partials past R.  Canary-padded buffers around the workspace and the partial array."""
+    import ctypes
+    import torch
+    from mDeepFRI import _hip
+    w, pred = mf
+    L = _hip.lib()
+    h = pred.session.handle
+    R, feat = 384, pred.session.topology["feature_dim"]   # 1.5 tiles
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(0)
+    # a trivial adjacency: every row its own neighbour (self loops only), letter sums = one-hot of a fixed letter
+    grp = torch.arange(R + 1, dtype=torch.int32, device=dev)
+    col = torch.arange(R, dtype=torch.int32, device=dev)
+    val = torch.ones(R, dtype=torch.float32, device=dev)
+    S = torch.zeros((R, 32), dtype=torch.float32, device=dev)
+    S[:, 5] = 1.0
+    ws_bytes = L.mdf_gcn_workspace_bytes(h, R)
+    pad = 1 << 16
+    ws = torch.full((ws_bytes + 2 * pad,), 0x5A, dtype=torch.uint8, device=dev)
+    part = torch.full((R // 32 * feat + 2 * pad,), 777.0, dtype=torch.float32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _hip.check(L.mdf_gcn_embed_dev(h, _hip.ptr(S), _hip.ptr(grp), _hip.ptr(col), _hip.ptr(val), R,
+                                   ctypes.c_void_p(part.data_ptr() + pad * 4), ctypes.c_void_p(ws.data_ptr() + pad), ws_bytes, st))
+    torch.cuda.synchronize()
+    assert bool((ws[:pad] == 0x5A).all()) and bool((ws[pad + ws_bytes:] == 0x5A).all())
+    assert bool((part[:pad] == 777.0).all()) and bool((part[pad + R // 32 * feat:] == 777.0).all())
+    assert bool(torch.isfinite(part[pad:pad + R // 32 * feat]).all())
+
+
+def test_library_first_then_torch_share_one_hip_runtime():
+    """Import-order regression: creating a Predictor (libmdfri_hip -> HIP) BEFORE torch is imported used to leave
+    torch.cuda unavailable (system ROCm runtime loaded first, torch's bundled one shadowed)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = (
+        "import sys, os; sys.path.insert(0, os.path.join(%r, 'metagenomic-deepfri_amd'))\n"
+        "from mDeepFRI import synthetic\n"
+        "from mDeepFRI.predict import Predictor\n"
+        "p = Predictor('syn', weights=synthetic.glorot_gcn_weights(0, 16))\n"
+        "assert 'torch' not in sys.modules\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "from mDeepFRI import batch\n"
+        "e = batch.HotPathEngine({'mf': p}, device=0)\n"
+        "prots = synthetic.synthetic_proteins(1, 3, 50)\n"
+        "pk = batch.PackedProteins.pack([q['seq'] for q in prots], [q['coords'] for q in prots], [q['q_aln'] for q in prots], [q['t_aln'] for q in prots])\n"
+        "print(e.run_alignments(pk)['mf'].shape)\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "(3, 16)" in out.stdout
