@@ -44,6 +44,8 @@ def parse():
                          "kernels: timing every launch lowers the step rate by ~6 %%)")
     ap.add_argument("--workload", default="configs2", choices=["configs2", "mixed"],
                     help="configs2 (headline): fixed length, identity alignments; mixed: configs[3]-style L~U[128,1024] with 5%% indels")
+    ap.add_argument("--verify", type=int, default=4,
+                    help="after the timed region, check this many proteins of the step against the oracle (untimed; 0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-device", type=int, default=None, help="testing aid: put every rank on this device ordinal")
     return ap.parse_args()
@@ -232,6 +234,22 @@ def main():
             "roofline_ax": roof_ax,
             "kernels": kernels,
         }
+        if args.verify > 0:
+            # parity spot check on the very outputs of the timed steps (oracle = checker, outside the timed region)
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import cmap_oracle
+            import gcn_oracle
+            pick = np.linspace(0, args.proteins - 1, args.verify).astype(int)
+            worst = 0.0
+            for i in pick:
+                cm = cmap_oracle.build_align_contact_map(coords[i], q_alns[i], t_alns[i], 6.0, 2)
+                for m in MODES:
+                    ref = gcn_oracle.gcn_forward(weights[m], seqs[i], cm)
+                    worst = max(worst, float(np.max(np.abs(out[m][i].cpu().numpy() - ref))))
+            line["verify"] = {"proteins": int(args.verify), "heads": list(MODES), "max_abs_err_vs_oracle": worst, "tolerance": 1e-4}
+            if not worst < 1e-4:
+                print(json.dumps(line), flush=True)
+                raise SystemExit(f"parity check failed: max |score - oracle| = {worst}")
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(seqs[:1024], coords[:1024], weights, args.cpu_seconds) if args.workload == "configs2" else None
             line["gpu_over_cpu_1core"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
