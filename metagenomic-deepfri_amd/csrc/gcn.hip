@@ -190,7 +190,9 @@ __device__ __forceinline__ unsigned lds_addr_of(const float *p)
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)((lds_void_t *)p));
 }
 
-template <int EPI>
+// ABL != 0: timing ablations for tools/gemm_probe.hip only (results are wrong by construction): 1 = no DMA,
+// 2 = + no LDS fragment reads, 3 = + no barrier
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt,
                                                               int ldb, int M, int N, int K, float *__restrict__ C, int ldc,
                                                               const float *__restrict__ bias, float *__restrict__ pool_partial,
@@ -256,14 +258,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
         sb3 = gB_ + (size_t)24 * ldb + dcol[3];                                                                     \
     }
 #define MDF_DMA_PIECE(i, ldsA_, ldsB_)                                       \
-    glds16(sa##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024));               \
-    glds16(sb##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024));
+    if (ABL == 0) {                                                            \
+        glds16(sa##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024));           \
+        glds16(sb##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024));           \
+    }
 #define MDF_SB __builtin_amdgcn_sched_barrier(0);
 #define MDF_MF(tm, tn, a, b) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tm][tn], 0, 0, 0);
     // fragments of one k-group: A tiles 0..3 (F##a0..a3), B tiles 0..1 (F##b0, F##b1)
 #define MDF_FRAG_DECL(F) float4 F##a0, F##a1, F##a2, F##a3, F##b0, F##b1;
-#define MDF_RDA(F, t, kg, base) F##a##t = *reinterpret_cast<const float4 *>((base) + (t) * 1024 + fkg[kg]);
-#define MDF_RDB(F, t, kg, base) F##b##t = *reinterpret_cast<const float4 *>((base) + (t) * 1024 + fkg[kg]);
+#define MDF_RDA(F, t, kg, base) if (ABL < 2) F##a##t = *reinterpret_cast<const float4 *>((base) + (t) * 1024 + fkg[kg]);
+#define MDF_RDB(F, t, kg, base) if (ABL < 2) F##b##t = *reinterpret_cast<const float4 *>((base) + (t) * 1024 + fkg[kg]);
     // 8 MFMAs on one k element e of fragments F; X0..X7 are issued behind MFMA 0..7
 #define MDF_K8(F, e, X0, X1, X2, X3, X4, X5, X6, X7)                                                   \
     MDF_MF(0, 0, F##a0.e, F##b0.e) X0 MDF_SB MDF_MF(0, 1, F##a0.e, F##b1.e) X1 MDF_SB                    \
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
 
     const unsigned lds_base = lds_addr_of(smem);
     MDF_FRAG_DECL(p) MDF_FRAG_DECL(q)
+    if (ABL >= 2) { pa0 = pa1 = pa2 = pa3 = pb0 = pb1 = qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = make_float4(1.f, 2.f, 3.f, 4.f); }
     // prologue: position 0 -> buffer 0; pointers for position 1; first fragments
     {
         MDF_DMA_SETUP(pc)
@@ -327,7 +332,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
         MDF_K8(p, x, MDF_RDA(q, 0, 3, Ab), MDF_RDB(q, 0, 3, Bb), MDF_RDB(q, 1, 3, Bb), MDF_RDA(q, 1, 3, Ab), MDF_RDA(q, 2, 3, Ab), MDF_RDA(q, 3, 3, Ab), , ) \
         MDF_K8_PLAIN(p, y) MDF_K8_PLAIN(p, z) MDF_K8_PLAIN(p, w)                                                   \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's DMA of the next position has landed */     \
-        __syncthreads();                                                                                           \
+        if (ABL < 3) __syncthreads();                                                                              \
         /* k-group 3 on q; p <- k-group 0 of the NEXT position (buffer CUR^1); next DMA's address arithmetic */     \
         MDF_K8(q, x, MDF_RDA(p, 0, 0, An), MDF_RDB(p, 0, 0, Bn), MDF_RDB(p, 1, 0, Bn), MDF_RDA(p, 1, 0, An), MDF_RDA(p, 2, 0, An), MDF_RDA(p, 3, 0, An), , ) \
         cursor_advance(pc, nk, NT, M, total_tiles, stride);                                                        \
