@@ -87,7 +87,24 @@ def cpu_baseline(seqs, coords, weights, budget_s):
     n1, t1 = run(1, budget_s * 0.7)
     ncores = os.cpu_count() or 1
     na, ta = run(None, budget_s * 0.3)
-    return {"value": n1 / t1, "unit": "proteins/s", "cores": 1, "kind": "port",
+    # contact-map stage alone through the REAL reference kernels (oracle/_ref: the reference's contact_map_utils.pyx compiled
+    # with its own flags by oracle/build_ref.py), glued as reference bio_utils.py:196-227,348-385 does, 1 thread
+    ref_stage = None
+    try:
+        import build_ref
+        ref = build_ref.load()
+        if ref is not None:
+            m, t0 = 0, time.perf_counter()
+            while m < min(len(seqs), 200) and time.perf_counter() - t0 < 2.0:
+                D = ref.pairwise_sqeuclidean(coords[m])
+                sparse = np.argwhere((D < 6.0**2).astype(np.int32) == 1).astype(np.int32)
+                ref.align_contact_map(seqs[m], seqs[m], sparse, 2)
+                m += 1
+            ref_stage = {"kind": "reference", "ms_per_protein": round(1e3 * (time.perf_counter() - t0) / max(m, 1), 3),
+                         "sample": f"{m} proteins, pairwise_sqeuclidean + threshold/argwhere + align_contact_map, 1 thread"}
+    except Exception as e:  # the compiled reference is optional on the GPU box
+        ref_stage = {"kind": "reference", "error": str(e)[:200]}
+    return {"cmap_stage_reference": ref_stage, "value": n1 / t1, "unit": "proteins/s", "cores": 1, "kind": "port",
             "sample": f"{n1} of the step's L={len(seqs[0])} proteins, contact map + 3 GO heads each, {t1:.1f} s, numpy/BLAS pinned to 1 thread",
             "all_cores": {"value": na / ta, "cores": ncores, "sample": f"{na} proteins, {ta:.1f} s, BLAS threads unrestricted"},
             "published_anchor": "reference weight_convert/inference_times.csv.gz: 0.13 s/protein/model/core at L~512 (ORT CPU, model incl. LSTM LM)"}
