@@ -111,6 +111,11 @@ typedef struct {
     const float *b_fc;    /* (fc_dim) */
     const float *W_out;   /* (fc_dim, 2*n_terms) */
     const float *b_out;   /* (2*n_terms) */
+    /* language-model branch of the released models; lm_dim = 0: none.
+     * X0 = relu(onehot.W_aa + lm_h.W_lm + b_lm), lm_h = LSTM2 output of mdf_lm_forward_dev. */
+    int32_t lm_dim;       /* width of the language-model features (512) */
+    const float *W_lm;    /* (lm_dim, embed) */
+    const float *b_lm;    /* (embed) */
 } mdf_gcn_weights;
 
 /* Upload weights to `device` and pre-pack them (transposed GEMM operands, folded embedding table). */
@@ -121,6 +126,34 @@ void mdf_model_free(mdf_model *m);
 int mdf_model_num_terms(const mdf_model *m);
 int mdf_model_feature_dim(const mdf_model *m); /* sum(gc_dims): width of the pooled feature vector */
 int mdf_model_device(const mdf_model *m);
+int mdf_model_lm_dim(const mdf_model *m);      /* 0: no language-model branch */
+
+/* ------------------------------------------------------------------------------------------------
+ * LSTM language model feeding the GCN embedding of the released DeepFRI models.  The reference has no
+ * code for it: it is part of the ONNX graph run at mDeepFRI/predict.pyx:98 (two stacked LSTM(512),
+ * Keras gate order i,f,c,o; see oracle/lm_oracle.py for the exact arithmetic restated).
+ * One mdf_lm is shared by all GO heads whose files carry the same frozen LM weights. */
+typedef struct mdf_lm mdf_lm;
+typedef struct {
+    int32_t hidden;                    /* H: units of both LSTM layers, multiple of 64 */
+    const float *W1, *U1, *b1;         /* LSTM1: kernel (26,4H), recurrent kernel (H,4H), bias (4H) */
+    const float *W2, *U2, *b2;         /* LSTM2: kernel (H,4H),  recurrent kernel (H,4H), bias (4H) */
+} mdf_lm_weights;
+int mdf_lm_create(const mdf_lm_weights *w, int device, mdf_lm **out);
+void mdf_lm_free(mdf_lm *lm);
+int mdf_lm_hidden(const mdf_lm *lm);
+/* Attach (or detach with NULL) the LM used by mdf_gcn_forward_host for a model with lm_dim > 0; not owned. */
+int mdf_model_attach_lm(mdf_model *m, mdf_lm *lm);
+size_t mdf_lm_workspace_bytes(const mdf_lm *lm, int32_t B, int32_t Lmax);
+/* LSTM2 output for B proteins at once (device pointers unless noted).  Proteins must be ordered by
+ * non-increasing length; protein b's residues are seq_idx[prot_row[b] .. +len[b]) (indices 0..25 from
+ * mdf_seq_encode_dev) and its features are written to h_out[(prot_row[b]+t), 0..H) -- i.e. h_out is a
+ * residue-row array (R, H) and rows that belong to no residue are left untouched.
+ * len_host (HOST pointer) and len_dev hold the same B lengths.  Every time step is one launch per layer of
+ * the MFMA GEMM over the still-active proteins, the LSTM cell fused in its epilogue. */
+int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_row, const int32_t *len_dev,
+                       const int32_t *len_host, int32_t B, float *h_out, void *workspace, size_t workspace_bytes,
+                       void *stream);
 
 /* mDeepFRI/predict.pyx:75-102  Predictor.forward_pass(seqres, cmap)  -- GCN branch, one protein, host buffers.
  * seq: L ASCII residues; cmap: (L,L) C-contiguous, dtype by cmap_dtype (MDF_DT_*), cast to f32 as predict.pyx:88.
@@ -194,6 +227,12 @@ size_t mdf_gcn_workspace_bytes(const mdf_model *m, int64_t R);
 int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
                       int64_t R, float *partial, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same stage for a model with a language-model branch (lm_dim > 0): X0 = relu(lm_h.W_lm + b_lm + W_aa[seq_idx]) on the
+ * MFMA GEMM (table row added in the epilogue), then every GraphConv layer as A.X + H.W (layer 1 over `embed` channels).
+ * seq_idx (R) from mdf_seq_encode_dev, lm_h (R, lm_dim) from mdf_lm_forward_dev.  workspace: mdf_gcn_workspace_bytes. */
+int mdf_gcn_embed_lm_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h, const int32_t *rowptr, const int32_t *colidx,
+                         const float *val, int64_t R, float *partial, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Second level of the sum pooling: pooled[p] = sum of partial[g] over g in [grp_off[p], grp_off[p+1])  -> (B, feature_dim).
  * grp_off (B+1, int32, device) counts 32-row groups (row_off / 32, plus the group base of the protein's chunk when the
  * partials of several chunks share one array). */
@@ -220,7 +259,8 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
  * kernel class with hipEvents on the stream it is launched on and accumulates count and milliseconds of the sampled
  * launches (read after a sync).  An event pair costs GPU time between kernels (~6 % of the step when every launch is
  * timed), hence the sampling.
- * kernel: "ax" (A.X aggregation), "gemm" (H.W fp32 MFMA, layers 2..3), "gemm1" (layer-1 S.T1 GEMM, K=32), "cmap" (fused contact map), "head". */
+ * kernel: "ax" (A.X aggregation), "gemm" (H.W fp32 MFMA, layers 2..3), "gemm1" (layer-1 S.T1 GEMM, K=32), "cmap" (fused contact map), "head",
+ * "lstm" (one language-model time step: both LSTM layers), "embed" (language-model embedding GEMM). */
 int mdf_timing_enable(int on);
 int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms);
 int mdf_timing_reset(void);

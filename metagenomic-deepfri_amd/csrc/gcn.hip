@@ -31,6 +31,12 @@ struct mdf_model {
     float *bfc = nullptr;         // (fc)
     float *Wout_t = nullptr;      // (n_out_pad, fc), rows >= 2T zero
     float *bout = nullptr;        // (n_out_pad)
+    // language-model branch (lm_dim > 0): X0 = relu(lm_h . W_lm + b_lm + W_aa[letter]); layer 1 is then not foldable
+    int lm_dim = 0;
+    float *Wlm_t = nullptr;       // (embed, lm_dim)  W_lm^T
+    float *T0 = nullptr;          // (32, embed)      rows < 26: W_aa[a] + b_lm, rows 26..31 zero
+    float *Wgc1_t = nullptr;      // (gc0, embed)     W_gc1^T
+    mdf_lm *lm = nullptr;         // attached language model (not owned), used by mdf_gcn_forward_host
     // session scratch of mdf_gcn_forward_host (grown on demand)
     void *host_ws = nullptr;
     size_t host_ws_bytes = 0;
@@ -46,7 +52,24 @@ constexpr int GEMM_LDS_BYTES = 2 /*buffers*/ * (BM + BN) * BK * 4;  // 128 KiB: 
 
 // EPI_L1_* are EPI_ELU_POOL_STORE / EPI_ELU_POOL under another symbol, so that profiles tell the K=32 layer-1 launches
 // from the K=512 H.W launches.
-enum Epilogue { EPI_ELU_POOL_STORE = 0, EPI_ELU_POOL = 1, EPI_BIAS_RELU = 2, EPI_BIAS_SOFTMAX2 = 3, EPI_L1_STORE = 4, EPI_L1 = 5 };
+// EPI_LSTM_TAB / EPI_LSTM_BIAS: one time step of an LSTM layer (language-model branch, see "LSTM language model" below);
+// EPI_EMBED: X0 = relu(A . Bt^T + table[letter[row]]).
+enum Epilogue {
+    EPI_ELU_POOL_STORE = 0, EPI_ELU_POOL = 1, EPI_BIAS_RELU = 2, EPI_BIAS_SOFTMAX2 = 3, EPI_L1_STORE = 4, EPI_L1 = 5,
+    EPI_LSTM_TAB = 6, EPI_LSTM_BIAS = 7, EPI_EMBED = 8
+};
+
+// Extra operands of the language-model epilogues (ignored, and compiled out, for the others).
+struct GemmAux {
+    const float *A2 = nullptr;         // EPI_LSTM_BIAS: k-tiles >= ksplit are read from A2 (row pitch lda), i.e. C = [A | A2] . Bt^T
+    int ksplit = 0;
+    const float *table = nullptr;      // EPI_LSTM_TAB / EPI_EMBED: (32, N) additive rows, selected per output row by letters[row]
+    const uint8_t *letters = nullptr;  // (M) residue indices 0..25 (anything larger reads the zero rows 26..31)
+    float *cstate = nullptr;           // EPI_LSTM_*: (M, N/4) cell state, updated in place
+};
+
+// sigmoid / tanh on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error < 3e-7.
+__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 
 // ELU with the hardware exponential (v_exp_f32 on x*log2(e), ~1 ulp of exp2): for x <= 0 the result lies in (-1, 0] and
 // the absolute error is < 2e-7, far inside the 1e-4 score budget; libm expf costs ~40 VALU instructions per element and
@@ -79,10 +102,57 @@ __device__ __forceinline__ void tile_of_block(int b, int NT, int &mt, int &nt)
 template <int EPI>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n0, int wm, int wn, int lane, int M, int N,
                                               float *__restrict__ C, int ldc, const float *__restrict__ bias,
-                                              float *__restrict__ pool_partial, int ldp, float *__restrict__ logits, int n_real)
+                                              float *__restrict__ pool_partial, int ldp, float *__restrict__ logits, int n_real,
+                                              const GemmAux &aux)
 {
     // C/D layout of the 32x32 MFMA: lane l, register r -> col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5)
     const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+    if (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS) {
+        // LSTM cell.  The 4H gate columns are stored permuted (lstm_col_of) so that the wave's two 32-column MFMA tiles
+        // hold, for 16 hidden units u: tile 0 = [i(u) | f(u)], tile 1 = [g(u) | o(u)] (16 lanes each).  Lane l < 16 of a
+        // 32-lane group therefore owns (i, g) of one (row, unit), lane l+16 owns (f, o): each applies its two
+        // activations, the halves swap one value (f*c_prev <-> i*g), both form c_t, the upper half writes h_t, the lower c_t.
+        const int H = N >> 2;
+        const int half = (lcol >> 4) & 1;
+        const int unit = (n0 >> 2) + wn * 16 + (lcol & 15);
+        const int col0 = n0 + wn * 64 + lcol, col1 = col0 + 32;
+        float b0 = 0.0f, b1 = 0.0f;
+        if (EPI == EPI_LSTM_BIAS) {
+            b0 = bias[col0];
+            b1 = bias[col1];
+        }
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int rbase = m0 + wm * 128 + tm * 32;
+            if (rbase >= M) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+                const int rr = min(row, M - 1);
+                float a0 = acc[tm][0][r], a1 = acc[tm][1][r];
+                if (EPI == EPI_LSTM_TAB) {
+                    const float *trow = aux.table + (size_t)min((int)aux.letters[rr], 31) * N;
+                    a0 += trow[col0];
+                    a1 += trow[col1];
+                } else {
+                    a0 += b0;
+                    a1 += b1;
+                }
+                const float s0 = sigmoid_fast(a0);                       // i | f
+                const float sg = sigmoid_fast(half ? a1 : 2.0f * a1);
+                const float x1 = half ? sg : 2.0f * sg - 1.0f;           // g = tanh(a1) | o
+                const float cprev = aux.cstate[(size_t)rr * H + unit];
+                const float mine = half ? s0 * cprev : s0 * x1;          // f*c_prev | i*g
+                const float cn = mine + __shfl_xor(mine, 16, 64);
+                const float th = 2.0f * sigmoid_fast(2.0f * cn) - 1.0f;  // tanh(c_t)
+                if (row < M) {
+                    if (half) C[(size_t)row * ldc + unit] = x1 * th;
+                    else aux.cstate[(size_t)row * H + unit] = cn;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
@@ -103,6 +173,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n
                 }
                 s += __shfl_xor(s, 32, 64);
                 if (lane < 32) pool_partial[(size_t)(rbase >> 5) * ldp + col] = s;
+            } else if (EPI == EPI_EMBED) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+                    if (row < M) {
+                        const float tv = aux.table[(size_t)min((int)aux.letters[row], 31) * N + col];
+                        C[(size_t)row * ldc + col] = fmaxf(acc[tm][tn][r] + tv, 0.0f);
+                    }
+                }
             } else if (EPI == EPI_BIAS_RELU) {
                 const float bv = bias[col];
 #pragma unroll
@@ -196,7 +275,8 @@ template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt,
                                                               int ldb, int M, int N, int K, float *__restrict__ C, int ldc,
                                                               const float *__restrict__ bias, float *__restrict__ pool_partial,
-                                                              int ldp, float *__restrict__ logits, int n_real, int total_tiles)
+                                                              int ldp, float *__restrict__ logits, int n_real, int total_tiles,
+                                                              GemmAux aux)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A 256x32 | B 256x32], unpadded rows
 #ifdef MDF_PROBE_TIMING
@@ -245,7 +325,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
     const float *sa0, *sa1, *sa2, *sa3, *sb0, *sb1, *sb2, *sb3;
 #define MDF_DMA_SETUP(cur_)                                                                                         \
     {                                                                                                               \
-        const float *gA_ = A + (size_t)(cur_).kt * BK;                                                              \
+        const float *gA_ = (EPI == EPI_LSTM_BIAS && (cur_).kt >= aux.ksplit)                                        \
+                               ? aux.A2 + (size_t)((cur_).kt - aux.ksplit) * BK                                     \
+                               : A + (size_t)(cur_).kt * BK;                                                        \
         const float *gB_ = Bt + (size_t)((cur_).nt * BN + wid * 32 + drow) * ldb + (size_t)(cur_).kt * BK;          \
         const int rA_ = (cur_).mt * BM + wid * 32 + drow;                                                           \
         sa0 = gA_ + (size_t)min(rA_, M - 1) * lda + dcol[0];                                                        \
@@ -339,7 +421,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
         MDF_DMA_SETUP(pc)                                                                                          \
         MDF_K8_PLAIN(q, y) MDF_K8_PLAIN(q, z) MDF_K8_PLAIN(q, w)                                                   \
         if (cc.kt == nk - 1) {                                                                                     \
-            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, ldp, logits, n_real); \
+            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, ldp, logits, n_real, aux); \
             _Pragma("unroll") for (int a = 0; a < 4; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b)            \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;                                \
         }                                                                                                          \
@@ -487,6 +569,29 @@ __global__ void k_pool_reduce(const float *__restrict__ partial, const int32_t *
     }
 }
 
+// ---- LSTM language model: layout helpers -------------------------------------------------------------------------------
+// The recurrence runs time-major: block t of a (Lmax+1, B, H) array holds h_t of all B proteins (block 0 = zeros), so that
+// the A operand of step t (h_{t-1} of the still-active proteins, a prefix because proteins are sorted by length) is one
+// contiguous row range.  let_tm[t*B + b] = residue t of protein b (31 = past its end).
+__global__ void k_lm_pack_letters(const uint8_t *__restrict__ seq_idx, const int64_t *__restrict__ prot_row,
+                                  const int32_t *__restrict__ len, int B, int Lmax, uint8_t *__restrict__ let_tm)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * Lmax) return;
+    const int t = (int)(i / B), b = (int)(i % B);
+    let_tm[i] = t < len[b] ? seq_idx[prot_row[b] + t] : (uint8_t)31;
+}
+// residue-row layout <- time-major blocks 1..Lmax: out[prot_row[b] + t, :] = h_tm[(t+1)*B + b, :]
+__global__ __launch_bounds__(128) void k_lm_unpack(const float *__restrict__ h_tm, const int64_t *__restrict__ prot_row,
+                                                   const int32_t *__restrict__ len, int B, int H, float *__restrict__ out)
+{
+    const int t = blockIdx.x, b = blockIdx.y;
+    if (t >= len[b]) return;
+    const float4 *src = reinterpret_cast<const float4 *>(h_tm + ((size_t)(t + 1) * B + b) * H);
+    float4 *dst = reinterpret_cast<float4 *>(out + (size_t)(prot_row[b] + t) * H);
+    for (int i = threadIdx.x; i < H / 4; i += blockDim.x) dst[i] = src[i];
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 static int set_gemm_attr_once()
 {
@@ -498,6 +603,9 @@ static int set_gemm_attr_once()
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_BIAS_SOFTMAX2>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_L1_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_L1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_LSTM_TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_LSTM_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return MDF_OK;
 }
@@ -517,7 +625,8 @@ static int gemm_resident_blocks()
 
 template <int EPI>
 static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M, int N, int K, float *C, int ldc,
-                       const float *bias, float *pool_partial, int ldp, float *logits, int n_real, hipStream_t st)
+                       const float *bias, float *pool_partial, int ldp, float *logits, int n_real, hipStream_t st,
+                       const GemmAux &aux = GemmAux())
 {
     MDF_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d", M, N, K);
     if (int rc = set_gemm_attr_once()) return rc;
@@ -525,7 +634,7 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     const int total = 8 * NT * ((MT + 7) / 8);               // tile slots in XCD-aware order (some may lie past M)
     const int blocks = std::min(total, gemm_resident_blocks());
     hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
-                       pool_partial, ldp, logits, n_real, total);
+                       pool_partial, ldp, logits, n_real, total, aux);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -553,7 +662,80 @@ static size_t gcn_ws_bytes(const mdf_model *m, int64_t R)
 {
     int cmax = 0;
     for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
-    return 3 * align_up((size_t)R * cmax * 4, 256) + 4096;
+    size_t b = 3 * align_up((size_t)R * cmax * 4, 256) + 4096;
+    if (m->lm_dim > 0) b += 2 * align_up((size_t)R * m->embed * 4, 256);  // X0 and Ahat.X0
+    return b;
+}
+
+// Ahat . H over `Cin` channels (k_aggregate)
+static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, const int32_t *colidx, const float *val, float *AH,
+                            int Ri, hipStream_t st)
+{
+    ScopedTiming tm(TK_AX, st);
+    // developer knobs; defaults: 512-row super-blocks per XCD, and non-temporal output stores once input + output
+    // slabs no longer fit the 256 MiB Infinity Cache together (measured: +12 % at 65536 rows, -2 % at 32768)
+    static const int sb_log = getenv("MDFRI_AX_SB_LOG") ? atoi(getenv("MDFRI_AX_SB_LOG")) : 9;
+    static const int nt_env = getenv("MDFRI_AX_NT") ? atoi(getenv("MDFRI_AX_NT")) : -1;
+    const int nt_store = nt_env >= 0 ? nt_env : ((size_t)Ri * Cin * 8 > (size_t)200 << 20);
+    const int n_sb = (Ri + (1 << sb_log) - 1) >> sb_log;
+    const int blocks = 8 * (1 << (sb_log - 2)) * ((n_sb + 7) / 8);
+#define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, Ri, sb_log, nt_store)
+    if (Cin == 256) MDF_AX(256); else if (Cin == 512) MDF_AX(512); else MDF_AX(1024);
+#undef MDF_AX
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+// GraphConv layers 2..n_gc on top of H1 (in Hin): H_k = elu((Ahat . H_{k-1}) . W_k), pooled partial sums at `partial + off`
+static int gcn_upper_layers(mdf_model *m, float *Hin, float *Hout, float *AH, const int32_t *rowptr, const int32_t *colidx,
+                            const float *val, int Ri, float *partial, hipStream_t st)
+{
+    const int feat = m->feat;
+    int off = m->gc[0];
+    for (int k = 1; k < m->n_gc; ++k) {
+        const int Cin = m->gc[k - 1], Cout = m->gc[k];
+        if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st)) return rc;
+        {
+            ScopedTiming tm(TK_GEMM, st);
+            const bool last = k == m->n_gc - 1;
+            int rc;
+            if (last)
+                rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
+            else
+                rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
+            if (rc) return rc;
+        }
+        off += Cout;
+        std::swap(Hin, Hout);
+    }
+    return MDF_OK;
+}
+
+// ---- LSTM language model ------------------------------------------------------------------------------------------------
+}  // namespace mdf
+
+struct mdf_lm {
+    int device = 0, H = 0;
+    float *U1t = nullptr;     // (4H, H)   recurrent kernel of LSTM1, transposed, gate columns permuted (lstm_col_of)
+    float *tab1 = nullptr;    // (32, 4H)  W1[a] + b1 per letter (rows 26..31 zero), permuted
+    float *W2U2t = nullptr;   // (4H, 2H)  [W2 ; U2]^T of LSTM2, permuted
+    float *b2p = nullptr;     // (4H)      b2, permuted
+};
+
+namespace mdf {
+
+// Keras column (gate block g in i,f,c,o order, unit u) of the permuted GEMM column p; see the EPI_LSTM_* epilogue.
+static inline int lstm_col_of(int p, int H)
+{
+    const int nt = p / BN, wn = (p % BN) / 64, tn = (p % 64) / 32, half = (p % 32) / 16, j = p % 16;
+    return (tn * 2 + half) * H + nt * 64 + wn * 16 + j;
+}
+
+static size_t lm_ws_bytes(const mdf_lm *lm, int64_t B, int64_t Lmax)
+{
+    const size_t H = (size_t)lm->H;
+    return 2 * align_up((size_t)(Lmax + 1) * B * H * 4, 256) + 2 * align_up((size_t)B * H * 4, 256) +
+           align_up((size_t)Lmax * B, 256) + 4096;
 }
 
 }  // namespace mdf
@@ -576,6 +758,11 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
         feat += w->gc_dims[k];
     }
     MDF_REQUIRE(w->W_aa && w->W_fc && w->b_fc && w->W_out && w->b_out, "model_create: NULL weight pointer");
+    if (w->lm_dim != 0) {
+        MDF_REQUIRE(w->lm_dim > 0 && w->lm_dim % BK == 0 && w->W_lm && w->b_lm, "model_create: bad language-model embedding (lm_dim=%d)", w->lm_dim);
+        MDF_REQUIRE(w->embed == 256 || w->embed == 512 || w->embed == 1024,
+                    "model_create: with a language-model branch the embedding width must be 256, 512 or 1024 (got %d)", w->embed);
+    }
     if (int rc = require_device()) return rc;
     MDF_HIP(hipSetDevice(device));
     mdf_model *m = new mdf_model();
@@ -623,6 +810,23 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
         std::copy(w->b_out, w->b_out + 2 * w->n_terms, b.begin());
         rc = upload(&m->bout, b.data(), b.size());
     }
+    if (rc == MDF_OK && w->lm_dim > 0) {
+        // language-model branch: keep the embedding and layer 1 unfolded
+        const int E = w->embed, Hl = w->lm_dim, C0 = w->gc_dims[0];
+        m->lm_dim = Hl;
+        auto t = transpose(w->W_lm, Hl, E, E);
+        rc = upload(&m->Wlm_t, t.data(), t.size());
+        if (rc == MDF_OK) {
+            std::vector<float> t0((size_t)32 * E, 0.0f);
+            for (int a = 0; a < 26; ++a)
+                for (int e = 0; e < E; ++e) t0[(size_t)a * E + e] = w->W_aa[(size_t)a * E + e] + w->b_lm[e];
+            rc = upload(&m->T0, t0.data(), t0.size());
+        }
+        if (rc == MDF_OK) {
+            auto g = transpose(w->W_gc[0], E, C0, C0);
+            rc = upload(&m->Wgc1_t, g.data(), g.size());
+        }
+    }
     if (rc != MDF_OK) {
         mdf_model_free(m);
         return rc;
@@ -640,6 +844,9 @@ void mdf_model_free(mdf_model *m)
     (void)hipFree(m->bfc);
     (void)hipFree(m->Wout_t);
     (void)hipFree(m->bout);
+    (void)hipFree(m->Wlm_t);
+    (void)hipFree(m->T0);
+    (void)hipFree(m->Wgc1_t);
     (void)hipFree(m->host_ws);
     delete m;
 }
@@ -647,6 +854,152 @@ void mdf_model_free(mdf_model *m)
 int mdf_model_num_terms(const mdf_model *m) { return m ? m->T : fail(MDF_EINVAL, "model is NULL"); }
 int mdf_model_feature_dim(const mdf_model *m) { return m ? m->feat : fail(MDF_EINVAL, "model is NULL"); }
 int mdf_model_device(const mdf_model *m) { return m ? m->device : fail(MDF_EINVAL, "model is NULL"); }
+int mdf_model_lm_dim(const mdf_model *m) { return m ? m->lm_dim : fail(MDF_EINVAL, "model is NULL"); }
+
+int mdf_model_attach_lm(mdf_model *m, mdf_lm *lm)
+{
+    MDF_REQUIRE(m, "model_attach_lm: model is NULL");
+    MDF_REQUIRE(!lm || (m->lm_dim == lm->H && m->device == lm->device),
+                "model_attach_lm: the model expects lm_dim=%d on device %d", m->lm_dim, m->device);
+    m->lm = lm;
+    return MDF_OK;
+}
+
+int mdf_lm_create(const mdf_lm_weights *w, int device, mdf_lm **out)
+{
+    MDF_REQUIRE(w && out, "lm_create: NULL argument");
+    MDF_REQUIRE(w->hidden > 0 && w->hidden % 64 == 0, "lm_create: hidden=%d must be a positive multiple of 64", w->hidden);
+    MDF_REQUIRE(w->W1 && w->U1 && w->b1 && w->W2 && w->U2 && w->b2, "lm_create: NULL weight pointer");
+    if (int rc = require_device()) return rc;
+    MDF_HIP(hipSetDevice(device));
+    const int H = w->hidden, G = 4 * H;
+    mdf_lm *lm = new mdf_lm();
+    lm->device = device;
+    lm->H = H;
+    std::vector<float> u1t((size_t)G * H), tab((size_t)32 * G, 0.0f), w2u2t((size_t)G * 2 * H), b2p((size_t)G);
+    for (int p = 0; p < G; ++p) {
+        const int kc = lstm_col_of(p, H);
+        for (int k = 0; k < H; ++k) {
+            u1t[(size_t)p * H + k] = w->U1[(size_t)k * G + kc];
+            w2u2t[(size_t)p * 2 * H + k] = w->W2[(size_t)k * G + kc];
+            w2u2t[(size_t)p * 2 * H + H + k] = w->U2[(size_t)k * G + kc];
+        }
+        for (int a = 0; a < 26; ++a) tab[(size_t)a * G + p] = w->W1[(size_t)a * G + kc] + w->b1[kc];
+        b2p[p] = w->b2[kc];
+    }
+    int rc = upload(&lm->U1t, u1t.data(), u1t.size());
+    if (rc == MDF_OK) rc = upload(&lm->tab1, tab.data(), tab.size());
+    if (rc == MDF_OK) rc = upload(&lm->W2U2t, w2u2t.data(), w2u2t.size());
+    if (rc == MDF_OK) rc = upload(&lm->b2p, b2p.data(), b2p.size());
+    if (rc != MDF_OK) {
+        mdf_lm_free(lm);
+        return rc;
+    }
+    *out = lm;
+    return MDF_OK;
+}
+
+void mdf_lm_free(mdf_lm *lm)
+{
+    if (!lm) return;
+    (void)hipFree(lm->U1t);
+    (void)hipFree(lm->tab1);
+    (void)hipFree(lm->W2U2t);
+    (void)hipFree(lm->b2p);
+    delete lm;
+}
+
+int mdf_lm_hidden(const mdf_lm *lm) { return lm ? lm->H : fail(MDF_EINVAL, "lm is NULL"); }
+
+size_t mdf_lm_workspace_bytes(const mdf_lm *lm, int32_t B, int32_t Lmax) { return lm && B > 0 && Lmax > 0 ? lm_ws_bytes(lm, B, Lmax) : 0; }
+
+int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_row, const int32_t *len_dev, const int32_t *len_host,
+                       int32_t B, float *h_out, void *workspace, size_t workspace_bytes, void *stream)
+{
+    MDF_REQUIRE(lm && seq_idx && prot_row && len_dev && len_host && h_out && workspace, "lm_forward_dev: NULL argument");
+    MDF_REQUIRE(B > 0 && B <= 65535, "lm_forward_dev: B=%d not in 1..65535", B);
+    for (int b = 0; b < B; ++b) {
+        MDF_REQUIRE(len_host[b] > 0, "lm_forward_dev: empty sequence at %d", b);
+        MDF_REQUIRE(b == 0 || len_host[b] <= len_host[b - 1], "lm_forward_dev: proteins must be sorted by non-increasing length");
+    }
+    const int Lmax = len_host[0], H = lm->H;
+    if (workspace_bytes < lm_ws_bytes(lm, B, Lmax))
+        return fail(MDF_ECAPACITY, "lm_forward_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, lm_ws_bytes(lm, B, Lmax));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver cv(workspace, workspace_bytes);
+    const size_t blk = (size_t)B * H;
+    float *h1 = cv.take<float>((size_t)(Lmax + 1) * blk), *h2 = cv.take<float>((size_t)(Lmax + 1) * blk);
+    float *c1 = cv.take<float>(blk), *c2 = cv.take<float>(blk);
+    uint8_t *let_tm = cv.take<uint8_t>((size_t)Lmax * B);
+    MDF_HIP(hipMemsetAsync(h1, 0, blk * 4, st));
+    MDF_HIP(hipMemsetAsync(h2, 0, blk * 4, st));
+    MDF_HIP(hipMemsetAsync(c1, 0, blk * 4, st));
+    MDF_HIP(hipMemsetAsync(c2, 0, blk * 4, st));
+    {
+        const size_t n = (size_t)B * Lmax;
+        hipLaunchKernelGGL(k_lm_pack_letters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seq_idx, prot_row, len_dev, B, Lmax, let_tm);
+        MDF_HIP(hipGetLastError());
+    }
+    int active = B;   // proteins with length > t form a prefix
+    for (int t = 0; t < Lmax; ++t) {
+        while (active > 0 && len_host[active - 1] <= t) --active;
+        ScopedTiming tm(TK_LSTM, st);
+        GemmAux a1;
+        a1.table = lm->tab1;
+        a1.letters = let_tm + (size_t)t * B;
+        a1.cstate = c1;
+        if (int rc = launch_gemm<EPI_LSTM_TAB>(h1 + t * blk, H, lm->U1t, H, active, 4 * H, H, h1 + (t + 1) * blk, H, nullptr, nullptr, 0,
+                                               nullptr, 0, st, a1))
+            return rc;
+        GemmAux a2;
+        a2.A2 = h2 + t * blk;
+        a2.ksplit = H / BK;
+        a2.cstate = c2;
+        if (int rc = launch_gemm<EPI_LSTM_BIAS>(h1 + (t + 1) * blk, H, lm->W2U2t, 2 * H, active, 4 * H, 2 * H, h2 + (t + 1) * blk, H, lm->b2p,
+                                                nullptr, 0, nullptr, 0, st, a2))
+            return rc;
+    }
+    hipLaunchKernelGGL(k_lm_unpack, dim3(Lmax, B), dim3(128), 0, st, h2, prot_row, len_dev, B, H, h_out);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+int mdf_gcn_embed_lm_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h, const int32_t *rowptr, const int32_t *colidx,
+                         const float *val, int64_t R, float *partial, void *workspace, size_t workspace_bytes, void *stream)
+{
+    MDF_REQUIRE(m && seq_idx && lm_h && rowptr && colidx && val && partial && workspace, "gcn_embed_lm_dev: NULL argument");
+    MDF_REQUIRE(m->lm_dim > 0, "gcn_embed_lm_dev: this model has no language-model branch; use mdf_gcn_embed_dev");
+    MDF_REQUIRE(R > 0 && R % 128 == 0 && R < 0x7fffffff, "gcn_embed_lm_dev: bad row count %lld", (long long)R);
+    if (workspace_bytes < gcn_ws_bytes(m, R))
+        return fail(MDF_ECAPACITY, "gcn_embed_lm_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, gcn_ws_bytes(m, R));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver cv(workspace, workspace_bytes);
+    int cmax = 0;
+    for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
+    float *Ha = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax);
+    float *X0 = cv.take<float>((size_t)R * m->embed), *AX = cv.take<float>((size_t)R * m->embed);
+    const int Ri = (int)R, E = m->embed, C0 = m->gc[0], feat = m->feat;
+    {
+        // X0 = relu(lm_h . W_lm + (W_aa[letter] + b_lm)): MFMA GEMM (K = lm_dim), table row added in the epilogue
+        ScopedTiming tm(TK_EMBED, st);
+        GemmAux a;
+        a.table = m->T0;
+        a.letters = seq_idx;
+        if (int rc = launch_gemm<EPI_EMBED>(lm_h, m->lm_dim, m->Wlm_t, m->lm_dim, Ri, E, m->lm_dim, X0, E, nullptr, nullptr, 0, nullptr, E, st, a))
+            return rc;
+    }
+    if (int rc = launch_aggregate(X0, E, rowptr, colidx, val, AX, Ri, st)) return rc;
+    {
+        ScopedTiming tm(TK_GEMM, st);
+        int rc;
+        if (m->n_gc == 1)
+            rc = launch_gemm<EPI_ELU_POOL>(AX, E, m->Wgc1_t, E, Ri, C0, E, nullptr, C0, nullptr, partial, feat, nullptr, C0, st);
+        else
+            rc = launch_gemm<EPI_ELU_POOL_STORE>(AX, E, m->Wgc1_t, E, Ri, C0, E, Ha, C0, nullptr, partial, feat, nullptr, C0, st);
+        if (rc) return rc;
+    }
+    return gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st);
+}
 
 /* .mdfw container: "MDFW0001" | u32 n | n x { char name[32]; u32 ndim; u64 dims[4]; u64 offset } | raw f32 data */
 int mdf_model_load(const char *path, int device, mdf_model **out)
@@ -720,6 +1073,13 @@ int mdf_model_load(const char *path, int device, mdf_model **out)
     w.W_out = reinterpret_cast<const float *>(buf.data() + e.offset);
     if (!find("b_out", e) || (int)e.dims[0] != 2 * w.n_terms) return fail(MDF_EIO, "model_load: b_out missing or wrong shape");
     w.b_out = reinterpret_cast<const float *>(buf.data() + e.offset);
+    if (find("W_lm", e)) {  // language-model branch of the released models (optional)
+        if (e.ndim != 2 || (int)e.dims[1] != w.embed) return fail(MDF_EIO, "model_load: W_lm has the wrong shape");
+        w.lm_dim = (int32_t)e.dims[0];
+        w.W_lm = reinterpret_cast<const float *>(buf.data() + e.offset);
+        if (!find("b_lm", e) || (int)e.dims[0] != w.embed) return fail(MDF_EIO, "model_load: b_lm missing or wrong shape");
+        w.b_lm = reinterpret_cast<const float *>(buf.data() + e.offset);
+    }
     return mdf_model_create(&w, device, out);
 }
 
@@ -749,6 +1109,7 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
     for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
     float *Ha = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax);
     const int Ri = (int)R, feat = m->feat;
+    MDF_REQUIRE(m->lm_dim == 0, "gcn_embed_dev: this model has a language-model branch; use mdf_gcn_embed_lm_dev");
     // layer 1 (folded embedding): H1 = elu(S . T1) on the MFMA GEMM (K = 32), S = Ahat . onehot from mdf_letter_sums_dev
     {
         ScopedTiming tm(TK_GEMM1, st);
@@ -760,36 +1121,7 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
             rc = launch_gemm<EPI_L1_STORE>(letter_sums, 32, m->T1t, 32, Ri, C0, 32, Ha, C0, nullptr, partial, feat, nullptr, C0, st);
         if (rc) return rc;
     }
-    float *Hin = Ha, *Hout = Hb;
-    int off = m->gc[0];
-    for (int k = 1; k < m->n_gc; ++k) {
-        const int Cin = m->gc[k - 1], Cout = m->gc[k];
-        {
-            ScopedTiming tm(TK_AX, st);
-            // developer knobs; defaults: 512-row super-blocks per XCD, and non-temporal output stores once input + output
-            // slabs no longer fit the 256 MiB Infinity Cache together (measured: +12 % at 65536 rows, -2 % at 32768)
-            static const int sb_log = getenv("MDFRI_AX_SB_LOG") ? atoi(getenv("MDFRI_AX_SB_LOG")) : 9;
-            static const int nt_env = getenv("MDFRI_AX_NT") ? atoi(getenv("MDFRI_AX_NT")) : -1;
-            const int nt_store = nt_env >= 0 ? nt_env : ((size_t)Ri * Cin * 8 > (size_t)200 << 20);
-            const int n_sb = (Ri + (1 << sb_log) - 1) >> sb_log;
-            const int blocks = 8 * (1 << (sb_log - 2)) * ((n_sb + 7) / 8);
-#define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, Ri, sb_log, nt_store)
-            if (Cin == 256) MDF_AX(256); else if (Cin == 512) MDF_AX(512); else MDF_AX(1024);
-#undef MDF_AX
-        }
-        {
-            ScopedTiming tm(TK_GEMM, st);
-            const bool last = k == m->n_gc - 1;
-            int rc;
-            if (last)
-                rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
-            else
-                rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
-            if (rc) return rc;
-        }
-        off += Cout;
-        std::swap(Hin, Hout);
-    }
+    if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st)) return rc;
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -830,14 +1162,17 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     int32_t Lq[1] = {(int32_t)L}, row_off[2];
     const int64_t R = mdf_layout_rows(Lq, 1, row_off);
     const int64_t nnz_cap = std::min<int64_t>(L * L, 0x7ffffff0);
+    MDF_REQUIRE(m->lm_dim == 0 || m->lm, "gcn_forward_host: the model has a language-model branch but no mdf_lm is attached (mdf_model_attach_lm)");
     const size_t cws = mdf_cmap_workspace_bytes(1, R), gws = gcn_ws_bytes(m, R), hws = mdf_head_workspace_bytes(m, 1);
+    const size_t lws = m->lm_dim ? lm_ws_bytes(m->lm, 1, L) : 0;
     // layout of the session scratch
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     const size_t o_desc = take(256), o_seq = take((size_t)L), o_idx = take((size_t)R), o_cm = take((size_t)L * L * es),
                  o_rp = take((size_t)(R + 1) * 4), o_ci = take((size_t)nnz_cap * 4), o_va = take((size_t)nnz_cap * 4),
                  o_cws = take(cws), o_gws = take(gws), o_hws = take(hws), o_pool = take((size_t)m->feat * 4),
-                 o_sc = take((size_t)m->T * 4), o_S = take((size_t)R * 32 * 4), o_part = take((size_t)(R / 32) * m->feat * 4);
+                 o_sc = take((size_t)m->T * 4), o_S = take((size_t)R * 32 * 4), o_part = take((size_t)(R / 32) * m->feat * 4),
+                 o_lws = take(lws), o_lmh = take(m->lm_dim ? (size_t)R * m->lm_dim * 4 : 0);
     if (m->host_ws_bytes < o) {
         (void)hipFree(m->host_ws);
         m->host_ws = nullptr;
@@ -848,7 +1183,7 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     char *b = static_cast<char *>(m->host_ws);
     struct Desc {
         int32_t Lq[2], row_off[2], seq_off[2], bad[2], status[4], grp_off[2];
-        int64_t cmap_off[1];
+        int64_t cmap_off[1], prot_row[1];
     } d;
     memset(&d, 0, sizeof(d));
     d.Lq[0] = (int32_t)L;
@@ -868,8 +1203,14 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
                                       dd->status, b + o_cws, cws, nullptr))
         return rc;
     float *d_S = reinterpret_cast<float *>(b + o_S), *d_part = reinterpret_cast<float *>(b + o_part);
-    if (int rc = mdf_letter_sums_dev(d_idx, d_rp, d_ci, d_va, R, d_S, nullptr)) return rc;
-    if (int rc = mdf_gcn_embed_dev(m, d_S, d_rp, d_ci, d_va, R, d_part, b + o_gws, gws, nullptr)) return rc;
+    if (m->lm_dim) {
+        float *d_lmh = reinterpret_cast<float *>(b + o_lmh);
+        if (int rc = mdf_lm_forward_dev(m->lm, d_idx, dd->prot_row, dd->Lq, Lq, 1, d_lmh, b + o_lws, lws, nullptr)) return rc;
+        if (int rc = mdf_gcn_embed_lm_dev(m, d_idx, d_lmh, d_rp, d_ci, d_va, R, d_part, b + o_gws, gws, nullptr)) return rc;
+    } else {
+        if (int rc = mdf_letter_sums_dev(d_idx, d_rp, d_ci, d_va, R, d_S, nullptr)) return rc;
+        if (int rc = mdf_gcn_embed_dev(m, d_S, d_rp, d_ci, d_va, R, d_part, b + o_gws, gws, nullptr)) return rc;
+    }
     if (int rc = mdf_gcn_pool_dev(m, d_part, dd->grp_off, 1, d_pool, nullptr)) return rc;
     if (int rc = mdf_gcn_head_dev(m, d_pool, 1, d_sc, nullptr, b + o_hws, hws, nullptr)) return rc;
     Desc back;

@@ -185,7 +185,7 @@ int main(int argc, char **argv)
 #define ABL_RUN(x)                                                                                                              \
     {                                                                                                                           \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_ELU_POOL, x>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES); \
-        float tt = time_us([&] { hipLaunchKernelGGL((k_gemm_f32<EPI_ELU_POOL, x>), dim3(G), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dA, K, dB, K, M, N, K, (float *)nullptr, N, (const float *)nullptr, dP, N, (float *)nullptr, N, total); }, iters); \
+        float tt = time_us([&] { hipLaunchKernelGGL((k_gemm_f32<EPI_ELU_POOL, x>), dim3(G), dim3(GEMM_THREADS), GEMM_LDS_BYTES, 0, dA, K, dB, K, M, N, K, (float *)nullptr, N, (const float *)nullptr, dP, N, (float *)nullptr, N, total, GemmAux()); }, iters); \
         printf("  ablation %d: %8.2f us  %6.1f TF\n", x, tt, flops / tt * 1e-6);                                               \
     }
         ABL_RUN(0) ABL_RUN(1) ABL_RUN(2) ABL_RUN(3)

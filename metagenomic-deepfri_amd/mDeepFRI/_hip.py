@@ -32,6 +32,15 @@ class GcnWeights(ctypes.Structure):
         ("embed", c_int32), ("n_gc", c_int32), ("gc_dims", c_int32 * 3), ("fc_dim", c_int32), ("n_terms", c_int32),
         ("W_aa", POINTER(c_float)), ("W_gc", POINTER(c_float) * 3), ("W_fc", POINTER(c_float)),
         ("b_fc", POINTER(c_float)), ("W_out", POINTER(c_float)), ("b_out", POINTER(c_float)),
+        ("lm_dim", c_int32), ("W_lm", POINTER(c_float)), ("b_lm", POINTER(c_float)),
+    ]
+
+
+class LmWeights(ctypes.Structure):
+    _fields_ = [
+        ("hidden", c_int32),
+        ("W1", POINTER(c_float)), ("U1", POINTER(c_float)), ("b1", POINTER(c_float)),
+        ("W2", POINTER(c_float)), ("U2", POINTER(c_float)), ("b2", POINTER(c_float)),
     ]
 
 
@@ -56,6 +65,15 @@ SIGNATURES = {
     "mdf_model_num_terms": (c_int, [c_void_p]),
     "mdf_model_feature_dim": (c_int, [c_void_p]),
     "mdf_model_device": (c_int, [c_void_p]),
+    "mdf_model_lm_dim": (c_int, [c_void_p]),
+    "mdf_lm_create": (c_int, [POINTER(LmWeights), c_int, POINTER(c_void_p)]),
+    "mdf_lm_free": (None, [c_void_p]),
+    "mdf_lm_hidden": (c_int, [c_void_p]),
+    "mdf_model_attach_lm": (c_int, [c_void_p, c_void_p]),
+    "mdf_lm_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int32]),
+    "mdf_lm_forward_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_gcn_embed_lm_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
     "mdf_gcn_forward_host": (c_int, [c_void_p, c_char_p, c_int64, c_void_p, c_int, c_void_p, _i64p]),
     "mdf_layout_rows": (c_int64, [c_void_p, c_int32, c_void_p]),
     "mdf_seq_encode_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),

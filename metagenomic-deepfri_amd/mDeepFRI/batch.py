@@ -209,7 +209,7 @@ class HotPathEngine:
     (`predictors`: {mode: mDeepFRI.predict.Predictor}; all heads share the contact-map stage)."""
 
     def __init__(self, predictors: dict, device: int = 0, max_rows: int = 32768, nnz_per_row: int = 40,
-                 threshold: float = 6.0, generated_contacts: int = 2):
+                 threshold: float = 6.0, generated_contacts: int = 2, lm_batch: int = 8192, lm_workspace_gib: float = 48.0):
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("HotPathEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -222,6 +222,15 @@ class HotPathEngine:
         self.generated_contacts = int(generated_contacts)
         self._rows_alloc = 0
         self._bufs = {}
+        # heads with a language-model branch, grouped by the (shared) LanguageModel they are attached to; the LSTM runs
+        # once per group over `lm_batch` proteins at a time (every time step is one GEMM over all of them)
+        self.lms = []
+        for p in self.predictors.values():
+            lm = getattr(p.session, "lm", None)
+            if lm is not None and all(lm is not x for x in self.lms):
+                self.lms.append(lm)
+        self.lm_batch = int(lm_batch)
+        self.lm_workspace_bytes = int(lm_workspace_gib * 2**30)
 
     # -- memory ------------------------------------------------------------------------------------------------------
     def _ensure(self, rows: int, n_proteins: int):
@@ -251,16 +260,70 @@ class HotPathEngine:
         return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
     # -- stages ------------------------------------------------------------------------------------------------------
-    def _gcn_chunk(self, db: DeviceBatch, ch: Chunk, partial: dict, st):
-        """letter sums once per chunk (shared by every head), then the GraphConv stack of each head; the per-group
-        partial sums land in the head's segment array."""
+    def _gcn_chunk(self, db: DeviceBatch, ch: Chunk, partial: dict, st, seq_ptr, lm_h=None):
+        """letter sums once per chunk (shared by every head without a language model), then the GraphConv stack of each
+        head; the per-group partial sums land in the head's segment array.  `lm_h`: {LanguageModel: pointer to this
+        chunk's (rows, H) language-model features}."""
         b = self._bufs
-        _hip.check(self.L.mdf_letter_sums_dev(_p(b["seq_idx"]), _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]), ch.rows,
-                                              _p(b["lsum"]), st))
+        if any(getattr(p.session, "lm", None) is None for p in self.predictors.values()):
+            _hip.check(self.L.mdf_letter_sums_dev(seq_ptr, _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]), ch.rows, _p(b["lsum"]), st))
         for mode, pred in self.predictors.items():
             feat = pred.session.topology["feature_dim"]
-            _hip.check(self.L.mdf_gcn_embed_dev(pred.session.handle, _p(b["lsum"]), _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]),
-                                                ch.rows, _p(partial[mode], ch.group_base * feat), _p(b["gws"]), b["gws"].numel(), st))
+            lm = getattr(pred.session, "lm", None)
+            if lm is None:
+                _hip.check(self.L.mdf_gcn_embed_dev(pred.session.handle, _p(b["lsum"]), _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]),
+                                                    ch.rows, _p(partial[mode], ch.group_base * feat), _p(b["gws"]), b["gws"].numel(), st))
+            else:
+                _hip.check(self.L.mdf_gcn_embed_lm_dev(pred.session.handle, seq_ptr, lm_h[id(lm)], _p(b["rowptr"]), _p(b["colidx"]),
+                                                       _p(b["val"]), ch.rows, _p(partial[mode], ch.group_base * feat), _p(b["gws"]),
+                                                       b["gws"].numel(), st))
+
+    # -- language model ------------------------------------------------------------------------------------------------
+    def _lm_batches(self, packed: PackedProteins):
+        """Consecutive chunk ranges [c0, c1) whose proteins run through the LSTM together: at most `lm_batch` proteins and
+        a time-major workspace (2 x (Lmax+1) x B x H floats) within `lm_workspace_bytes`."""
+        H = max(lm.hidden for lm in self.lms)
+        out, c0, nb, lmax = [], 0, 0, 0
+        for ci, ch in enumerate(packed.chunks):
+            n = ch.p1 - ch.p0
+            l = int(packed.Lq[ch.p0:ch.p1].max())
+            nb2, lmax2 = nb + n, max(lmax, l)
+            if ci > c0 and (nb2 > min(self.lm_batch, 65535) or 8 * (lmax2 + 1) * nb2 * H > self.lm_workspace_bytes):
+                out.append((c0, ci))
+                c0, nb2, lmax2 = ci, n, l
+            nb, lmax = nb2, lmax2
+        out.append((c0, len(packed.chunks)))
+        return out
+
+    def _lm_forward(self, db: DeviceBatch, c0: int, c1: int, bases, seq_all, st):
+        """LSTM features of every protein in chunks [c0, c1) -> {id(lm): (rows_total, H) tensor} in residue-row layout."""
+        torch = _torch()
+        pk = db.packed
+        chunks = pk.chunks[c0:c1]
+        rows_total = bases[-1]
+        prot_row = np.concatenate([bases[k] + pk.chunk_row_off[ch.row_off_pos:ch.row_off_pos + (ch.p1 - ch.p0)].astype(np.int64)
+                                   for k, ch in enumerate(chunks)])
+        lens = pk.Lq[chunks[0].p0:chunks[-1].p1]
+        order = np.argsort(-lens.astype(np.int64), kind="stable")
+        lens_h = np.ascontiguousarray(lens[order], dtype=np.int32)
+        d_rows = torch.from_numpy(np.ascontiguousarray(prot_row[order])).to(self.device)
+        d_lens = torch.from_numpy(lens_h).to(self.device)
+        B, Lmax = len(lens_h), int(lens_h[0])
+        out = {}
+        for lm in self.lms:
+            need = self.L.mdf_lm_workspace_bytes(lm.handle, B, Lmax)
+            if self._bufs.get("lm_ws") is None or self._bufs["lm_ws"].numel() < need:
+                self._bufs["lm_ws"] = None
+                self._bufs["lm_ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            key = ("lm_h", id(lm))
+            if self._bufs.get(key) is None or self._bufs[key].numel() < rows_total * lm.hidden:
+                self._bufs[key] = None
+                self._bufs[key] = torch.zeros(rows_total * lm.hidden, dtype=torch.float32, device=self.device)
+            _hip.check(self.L.mdf_lm_forward_dev(lm.handle, _p(seq_all), _p(d_rows), _p(d_lens), _hip.ptr(lens_h), B, _p(self._bufs[key]),
+                                                 _p(self._bufs["lm_ws"]), self._bufs["lm_ws"].numel(), st))
+            out[id(lm)] = self._bufs[key]
+        self._keep = (d_rows, d_lens, lens_h)  # outlive the asynchronous launches
+        return out
 
     def _pool_segment(self, db: DeviceBatch, seg: Segment, partial: dict, pooled: dict, st):
         for mode, pred in self.predictors.items():
@@ -278,16 +341,73 @@ class HotPathEngine:
             self._bufs["partial_key"] = key
         return self._bufs["partial"]
 
-    def _run_chunks(self, db: DeviceBatch, stage_chunk, st):
-        """Common driver: per chunk `stage_chunk(ci, ch)` builds seq_idx + CSR, then the GCN stack; segments are pooled
-        as soon as their last chunk has been issued."""
+    def lm_features(self, packed: PackedProteins, which: int = 0):
+        """Language-model features (LSTM2 output) of every protein of `packed`: list of (L_p, H) float32 arrays.  For
+        inspection and tests; the scoring paths keep these on the device."""
+        torch = _torch()
+        lm = self.lms[which]
+        db = self.upload(packed)
+        res = []
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            keep_lms, self.lms = self.lms, [lm]
+            try:
+                for c0, c1 in self._lm_batches(packed):
+                    chunks = packed.chunks[c0:c1]
+                    bases = [0]
+                    for ch in chunks:
+                        bases.append(bases[-1] + ch.rows)
+                    seq_all = torch.empty(bases[-1], dtype=torch.uint8, device=self.device)
+                    for k, ch in enumerate(chunks):
+                        _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0),
+                                                             _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows,
+                                                             _p(seq_all, bases[k]), _p(db.bad, (c0 + k) * 2), st))
+                    feats = self._lm_forward(db, c0, c1, bases, seq_all, st)[id(lm)]
+                    torch.cuda.current_stream(self.device).synchronize()
+                    host = feats[:bases[-1] * lm.hidden].view(bases[-1], lm.hidden).cpu().numpy()
+                    for k, ch in enumerate(chunks):
+                        ro = packed.chunk_row_off[ch.row_off_pos:ch.row_off_pos + (ch.p1 - ch.p0)]
+                        for j, p in enumerate(range(ch.p0, ch.p1)):
+                            r0 = bases[k] + int(ro[j])
+                            res.append(host[r0:r0 + int(packed.Lq[p])].copy())
+            finally:
+                self.lms = keep_lms
+        return res
+
+    def _run_chunks(self, db: DeviceBatch, encode, build_csr, st):
+        """Common driver: per chunk `encode(ci, ch, seq_ptr)` writes the residue indices and `build_csr(ci, ch)` the
+        adjacency, then the GCN stack runs; segments are pooled as soon as their last chunk has been issued.  With a
+        language model the chunks are taken `lm_batch` proteins at a time: all of them are encoded first, the LSTM runs
+        over the whole group, then the per-chunk stages follow."""
+        torch = _torch()
         pooled, partial = self._alloc_pooled(db), self._alloc_partial(db)
         chunks, segs = db.packed.chunks, db.packed.segments
-        for ci, ch in enumerate(chunks):
-            stage_chunk(ci, ch)
-            self._gcn_chunk(db, ch, partial, st)
+        b = self._bufs
+
+        def tail(ci, ch, seq_ptr, lm_h):
+            build_csr(ci, ch)
+            self._gcn_chunk(db, ch, partial, st, seq_ptr, lm_h)
             if ci + 1 == len(chunks) or chunks[ci + 1].segment != ch.segment:
                 self._pool_segment(db, segs[ch.segment], partial, pooled, st)
+
+        if not self.lms:
+            for ci, ch in enumerate(chunks):
+                encode(ci, ch, _p(b["seq_idx"]))
+                tail(ci, ch, _p(b["seq_idx"]), None)
+            return pooled
+        for c0, c1 in self._lm_batches(db.packed):
+            bases = [0]
+            for ch in chunks[c0:c1]:
+                bases.append(bases[-1] + ch.rows)
+            if b.get("seq_all") is None or b["seq_all"].numel() < bases[-1]:
+                b["seq_all"] = torch.empty(bases[-1], dtype=torch.uint8, device=self.device)
+            for k, ci in enumerate(range(c0, c1)):
+                encode(ci, chunks[ci], _p(b["seq_all"], bases[k]))
+            feats = self._lm_forward(db, c0, c1, bases, b["seq_all"], st)
+            hid = {id(lm): lm.hidden for lm in self.lms}
+            for k, ci in enumerate(range(c0, c1)):
+                lm_h = {key: _p(t, bases[k] * hid[key]) for key, t in feats.items()}
+                tail(ci, chunks[ci], _p(b["seq_all"], bases[k]), lm_h)
         return pooled
 
     def _heads(self, db: DeviceBatch, pooled: dict, want_logits: bool, st):
@@ -319,17 +439,20 @@ class HotPathEngine:
             self._ensure(db.packed.max_chunk_rows, db.B)
             b, st = self._bufs, self._stream()
 
-            def stage(ci, ch):
+            def encode(ci, ch, seq_ptr):
+                _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0),
+                                                     _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows, seq_ptr,
+                                                     _p(db.bad, ci * 2), st))
+
+            def build_csr(ci, ch):
                 Bc = ch.p1 - ch.p0
                 ro = _p(db.chunk_row_off, ch.row_off_pos)
-                _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
-                                                     _p(b["seq_idx"]), _p(db.bad, ci * 2), st))
                 _hip.check(self.L.mdf_cmap_csr_dev(
                     _p(db.coords), _p(db.coord_off, ch.p0), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off, ch.p0), _p(db.Lq, ch.p0), ro,
                     Bc, ch.rows, self.threshold, self.generated_contacts, _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]),
                     self._nnz_cap, _p(db.status, ci * 4), _p(b["cws"]), b["cws"].numel(), st))
 
-            pooled = self._run_chunks(db, stage, st)
+            pooled = self._run_chunks(db, encode, build_csr, st)
             return self._heads(db, pooled, want_logits, st)
 
     def forward_dense(self, db: DeviceBatch, cmaps, want_logits: bool = False):
@@ -343,7 +466,12 @@ class HotPathEngine:
             b, st = self._bufs, self._stream()
             keep = []  # device copies of the maps must outlive the asynchronous kernels that read them
 
-            def stage(ci, ch):
+            def encode(ci, ch, seq_ptr):
+                _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0),
+                                                     _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows, seq_ptr,
+                                                     _p(db.bad, ci * 2), st))
+
+            def build_csr(ci, ch):
                 Bc = ch.p1 - ch.p0
                 ro = _p(db.chunk_row_off, ch.row_off_pos)
                 flat, offs = [], [0]
@@ -366,8 +494,6 @@ class HotPathEngine:
                     b["colidx"] = torch.empty(nnz_needed, dtype=torch.int32, device=self.device)
                     b["val"] = torch.empty(nnz_needed, dtype=torch.float32, device=self.device)
                     self._nnz_cap = nnz_needed
-                _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
-                                                     _p(b["seq_idx"]), _p(db.bad, ci * 2), st))
                 dt = _hip.DT_F32 if host.dtype == np.float32 else _hip.DT_I32
                 _hip.check(self.L.mdf_dense_to_csr_dev(_p(d_maps), dt, _p(d_off), _p(db.Lq, ch.p0), ro, Bc, ch.rows, _p(b["rowptr"]),
                                                        _p(b["colidx"]), _p(b["val"]), self._nnz_cap, _p(db.status, ci * 4),
@@ -376,7 +502,7 @@ class HotPathEngine:
                     torch.cuda.current_stream(self.device).synchronize()
                     del keep[:-1]
 
-            pooled = self._run_chunks(db, stage, st)
+            pooled = self._run_chunks(db, encode, build_csr, st)
             out = self._heads(db, pooled, want_logits, st)
             torch.cuda.current_stream(self.device).synchronize()
             return out

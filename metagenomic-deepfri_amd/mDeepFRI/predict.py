@@ -3,7 +3,9 @@ Runtime session replaced by hand-written HIP kernels (libmdfri_hip.so).  No onnx
 from __future__ import annotations
 
 import ctypes
+import hashlib
 import os
+import weakref
 
 import numpy as np
 
@@ -39,9 +41,10 @@ class _Session:
         def __init__(self, name):
             self.name = name
 
-    def __init__(self, handle, topology):
+    def __init__(self, handle, topology, lm=None):
         self.handle = handle
         self.topology = topology
+        self.lm = lm  # LanguageModel the handle points at (kept alive here), or None
 
     def get_inputs(self):
         return [self._Input("cmap"), self._Input("seq")]
@@ -51,6 +54,46 @@ class _Session:
         if h:
             try:
                 _hip.lib().mdf_model_free(h)
+            except Exception:
+                pass
+
+
+class LanguageModel:
+    """The frozen LSTM language model inside the released DeepFRI GCN files (two stacked LSTM layers; part of the ONNX
+    graph the reference runs at predict.pyx:98).  Every GO head's file carries the same copy, so identical weights
+    share one device-side mdf_lm (`LanguageModel.shared`)."""
+
+    _shared = weakref.WeakValueDictionary()
+
+    def __init__(self, weights: dict, device: int = 0):
+        w = {k: np.ascontiguousarray(weights[k], dtype=np.float32) for k in _weights.LM_KEYS}
+        self.hidden = int(w["lm_U1"].shape[0])
+        self.device = int(device)
+        s = _hip.LmWeights()
+        s.hidden = self.hidden
+        fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))  # noqa: E731
+        s.W1, s.U1, s.b1 = fp(w["lm_W1"]), fp(w["lm_U1"]), fp(w["lm_b1"])
+        s.W2, s.U2, s.b2 = fp(w["lm_W2"]), fp(w["lm_U2"]), fp(w["lm_b2"])
+        self.handle = ctypes.c_void_p()
+        _hip.check(_hip.lib().mdf_lm_create(ctypes.byref(s), self.device, ctypes.byref(self.handle)))
+
+    @classmethod
+    def shared(cls, weights: dict, device: int = 0) -> "LanguageModel":
+        h = hashlib.sha1()
+        for k in _weights.LM_KEYS:
+            h.update(np.ascontiguousarray(weights[k], dtype=np.float32).tobytes())
+        key = (int(device), h.hexdigest())
+        lm = cls._shared.get(key)
+        if lm is None:
+            lm = cls(weights, device)
+            cls._shared[key] = lm
+        return lm
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                _hip.lib().mdf_lm_free(h)
             except Exception:
                 pass
 
@@ -66,6 +109,9 @@ def create_model_handle(weights: dict, device: int = 0):
         s.gc_dims[k] = c
         s.W_gc[k] = fp(w[f"W_gc{k + 1}"])
     s.W_aa, s.W_fc, s.b_fc, s.W_out, s.b_out = fp(w["W_aa"]), fp(w["W_fc"]), fp(w["b_fc"]), fp(w["W_out"]), fp(w["b_out"])
+    s.lm_dim = topo["lm_dim"]
+    if topo["lm_dim"]:
+        s.W_lm, s.b_lm = fp(w["W_lm"]), fp(w["b_lm"])
     handle = ctypes.c_void_p()
     _hip.check(_hip.lib().mdf_model_create(ctypes.byref(s), int(device), ctypes.byref(handle)))
     return handle, topo
@@ -91,17 +137,26 @@ class Predictor(object):
 
     def _load_model(self):
         L = _hip.lib()
-        if self._weights is not None:
-            handle, _ = create_model_handle(self._weights, self.device)
+        w = self._weights
+        if w is not None:
+            handle, _ = create_model_handle(w, self.device)
         else:
             path = _weights.resolve_model_path(self.model_path)
             if path.endswith(".mdfw"):  # native container: read by the library itself
                 handle = ctypes.c_void_p()
                 _hip.check(L.mdf_model_load(path.encode(), self.device, ctypes.byref(handle)))
+                if L.mdf_model_lm_dim(handle) > 0:
+                    w = _weights.load_mdfw(path)  # the language-model tensors are uploaded from here
             else:
-                handle, _ = create_model_handle(_weights.load_weights(path), self.device)
-        topo = {"n_terms": int(L.mdf_model_num_terms(handle)), "feature_dim": int(L.mdf_model_feature_dim(handle))}
-        self.session = _Session(handle, topo)
+                w = _weights.load_weights(path)
+                handle, _ = create_model_handle(w, self.device)
+        topo = {"n_terms": int(L.mdf_model_num_terms(handle)), "feature_dim": int(L.mdf_model_feature_dim(handle)),
+                "lm_dim": int(L.mdf_model_lm_dim(handle))}
+        lm = None
+        if topo["lm_dim"]:
+            lm = LanguageModel.shared(w, self.device)
+            _hip.check(L.mdf_model_attach_lm(handle, lm.handle))
+        self.session = _Session(handle, topo, lm)
         self.input_names = [node.name for node in self.session.get_inputs()]
         self._weights = None
 

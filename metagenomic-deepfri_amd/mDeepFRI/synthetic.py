@@ -77,6 +77,29 @@ def glorot_gcn_weights(seed: int = 0, n_terms: int = 489, embed: int = 1024, gc_
     return w
 
 
+def glorot_lm_weights(seed: int = 1000, hidden: int = 512, embed: int = 1024) -> dict:
+    """Random-init language-model branch: two LSTM layers (Keras defaults: Glorot kernel, orthogonal recurrent kernel,
+    zero bias with unit forget bias) and the LM_embedding Dense.  Keys as mDeepFRI.weights."""
+    rng = np.random.default_rng(seed)
+
+    def orthogonal(n, m):
+        q, r = np.linalg.qr(rng.standard_normal((max(n, m), min(n, m))))
+        q = q * np.sign(np.diag(r))
+        return (q if n >= m else q.T).astype(np.float32)[:n, :m]
+
+    H = hidden
+    w = {}
+    for name, fan_in in (("1", 26), ("2", H)):
+        w[f"lm_W{name}"] = glorot_uniform(rng, fan_in, 4 * H)
+        w[f"lm_U{name}"] = np.concatenate([orthogonal(H, H) for _ in range(4)], axis=1)
+        b = rng.uniform(-0.05, 0.05, size=(4 * H,)).astype(np.float32)
+        b[H:2 * H] += 1.0
+        w[f"lm_b{name}"] = b
+    w["W_lm"] = glorot_uniform(rng, H, embed)
+    w["b_lm"] = rng.uniform(-0.05, 0.05, size=(embed,)).astype(np.float32)
+    return w
+
+
 def synthetic_proteins(seed: int, count: int, length, indel_rate: float = 0.0):
     """List of dicts {id, seq, coords, q_aln, t_aln}.  `length` is an int or a (lo, hi) inclusive range."""
     rng = np.random.default_rng(seed)

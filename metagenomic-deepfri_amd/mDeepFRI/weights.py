@@ -8,6 +8,8 @@ reference mDeepFRI/__init__.py:47-80, mDeepFRI/utils.py:119-151).
     raw little-endian float32 data (each tensor 64-byte aligned)
 Tensor names: W_aa (26,E)  W_gc1 (E,C1)  W_gc2 (C1,C2)  W_gc3 (C2,C3)  W_fc (C1+C2+C3,F)  b_fc (F)
               W_out (F,2T)  b_out (2T)        -- Keras orientation (in_features, out_features).
+Optional language-model branch (the released models have it), Keras orientation and gate
+order i,f,c,o:  W_lm (H,E)  b_lm (E)  lm_W1 (26,4H)  lm_U1 (H,4H)  lm_b1 (4H)  lm_W2 (H,4H)  lm_U2 (H,4H)  lm_b2 (4H).
 `.npz` files with the same keys are accepted too.
 
 Real `.onnx` files are not parsed yet: the shipped models also contain an LSTM language-model branch that this
@@ -22,7 +24,9 @@ import struct
 import numpy as np
 
 MAGIC = b"MDFW0001"
-ORDER = ("W_aa", "W_gc1", "W_gc2", "W_gc3", "W_fc", "b_fc", "W_out", "b_out")
+ORDER = ("W_aa", "W_gc1", "W_gc2", "W_gc3", "W_fc", "b_fc", "W_out", "b_out",
+         "W_lm", "b_lm", "lm_W1", "lm_U1", "lm_b1", "lm_W2", "lm_U2", "lm_b2")
+LM_KEYS = ("lm_W1", "lm_U1", "lm_b1", "lm_W2", "lm_U2", "lm_b2")
 _ENTRY = struct.Struct("<32sI4QQ")
 
 
@@ -83,8 +87,22 @@ def validate(weights: dict) -> dict:
         raise ValueError("weights: W_fc / b_fc shape mismatch")
     if w["W_out"].shape[0] != w["W_fc"].shape[1] or w["W_out"].shape[1] % 2 or w["b_out"].shape[0] != w["W_out"].shape[1]:
         raise ValueError("weights: W_out / b_out shape mismatch")
+    lm_dim = 0
+    if "W_lm" in w or any(k in w for k in LM_KEYS):
+        for k in ("W_lm", "b_lm") + LM_KEYS:
+            if k not in w:
+                raise ValueError(f"weights: language-model branch is incomplete, missing {k}")
+        lm_dim = int(w["W_lm"].shape[0])
+        E = int(w["W_aa"].shape[1])
+        if w["W_lm"].shape != (lm_dim, E) or w["b_lm"].shape != (E,):
+            raise ValueError("weights: W_lm / b_lm shape mismatch")
+        H4 = 4 * lm_dim
+        want = {"lm_W1": (26, H4), "lm_U1": (lm_dim, H4), "lm_b1": (H4,), "lm_W2": (lm_dim, H4), "lm_U2": (lm_dim, H4), "lm_b2": (H4,)}
+        for k, shp in want.items():
+            if tuple(w[k].shape) != shp:
+                raise ValueError(f"weights: {k} has shape {tuple(w[k].shape)}, expected {shp}")
     return {"embed": int(w["W_aa"].shape[1]), "gc_dims": gc, "fc_dim": int(w["W_fc"].shape[1]),
-            "n_terms": int(w["W_out"].shape[1] // 2)}
+            "n_terms": int(w["W_out"].shape[1] // 2), "lm_dim": lm_dim}
 
 
 def resolve_model_path(model_path: str) -> str:

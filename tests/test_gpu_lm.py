@@ -1,0 +1,116 @@
+"""GPU parity of the language-model branch against oracle/lm_oracle.py, through the C ABI.
+The oracle for this branch is PARITY UNPINNED (see its header): these tests prove the HIP path computes the restated
+Keras arithmetic, not that it matches a released .onnx file."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _weights(seed, hidden, embed, gc, fc, T):
+    from mDeepFRI import synthetic
+    w = synthetic.glorot_gcn_weights(seed=seed, n_terms=T, embed=embed, gc_dims=gc, fc_dim=fc)
+    w.update(synthetic.glorot_lm_weights(seed=1000, hidden=hidden, embed=embed))
+    return w
+
+
+def _proteins(seed, lengths):
+    from mDeepFRI import synthetic
+    rng = np.random.default_rng(seed)
+    seqs = [synthetic.random_sequence(rng, L) for L in lengths]
+    coords = [synthetic.random_walk_coords(rng, L) for L in lengths]
+    return seqs, coords
+
+
+def _cmap(xyz, thr=6.0):
+    d = ((xyz[:, None, :] - xyz[None, :, :])**2).sum(-1)
+    return (d < thr * thr).astype(np.int32)
+
+
+@pytest.mark.parametrize("hidden,lengths", [(64, [1, 7, 33, 70, 70, 2]), (512, [40, 90, 13])])
+def test_lstm_features_match_oracle(hidden, lengths):
+    import lm_oracle
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.predict import Predictor
+    w = _weights(3, hidden, 256, (256,), 256, 20)
+    seqs, _ = _proteins(11, lengths)
+    eng = HotPathEngine({"mf": Predictor("synthetic", weights=w)}, max_rows=128)   # several chunks, one LSTM batch
+    got = eng.lm_features(PackedProteins.pack(seqs, max_rows=128))
+    assert len(got) == len(seqs)
+    for s, g in zip(seqs, got):
+        ref = lm_oracle.lm_forward(w, s)
+        assert g.shape == ref.shape
+        np.testing.assert_allclose(g, ref, atol=2e-5, rtol=0)
+
+
+def test_lstm_batches_are_independent():
+    """A protein's features do not depend on what it is batched with, nor on the LSTM batch boundaries."""
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.predict import Predictor
+    w = _weights(3, 64, 256, (256,), 256, 20)
+    seqs, _ = _proteins(5, [50, 20, 64, 31, 8, 64, 3])
+    pred = Predictor("synthetic", weights=w)
+    a = HotPathEngine({"mf": pred}, max_rows=128).lm_features(PackedProteins.pack(seqs, max_rows=128))
+    b = HotPathEngine({"mf": pred}, max_rows=128, lm_batch=2).lm_features(PackedProteins.pack(seqs, max_rows=128))
+    for k, s in enumerate(seqs):
+        alone = HotPathEngine({"mf": pred}).lm_features(PackedProteins.pack([s]))[0]
+        np.testing.assert_array_equal(a[k], alone)
+        np.testing.assert_array_equal(b[k], alone)
+
+
+def test_forward_pass_with_language_model():
+    """Per-call API (Predictor.forward_pass, reference predict.pyx:75-102) on a model with the LM branch."""
+    import lm_oracle
+    from mDeepFRI.predict import Predictor
+    w = _weights(7, 64, 256, (256, 256), 256, 33)
+    seqs, coords = _proteins(2, [57, 130])
+    pred = Predictor("synthetic", weights=w)
+    for s, c in zip(seqs, coords):
+        A = _cmap(c)
+        ref = lm_oracle.gcn_lm_forward(w, s, A)
+        got = pred.forward_pass(s, A)
+        assert np.abs(got - ref).max() < 1e-4        # north_star tolerance on GO scores
+
+
+def test_engine_scores_with_language_model_full_size():
+    """Batched fused path, shipped topology (LSTM 2x512 -> 1024 embedding -> 512-512-512 -> 1024), two heads sharing
+    one language model, mixed with a head that has none."""
+    import cmap_oracle
+    import gcn_oracle
+    import lm_oracle
+    from mDeepFRI import synthetic
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.predict import Predictor
+    lm = synthetic.glorot_lm_weights(seed=1000, hidden=512, embed=1024)
+    heads = {}
+    for k, (mode, T) in enumerate((("mf", 489), ("cc", 320))):
+        w = synthetic.glorot_gcn_weights(seed=20 + k, n_terms=T)
+        w.update(lm)
+        w["W_lm"] = synthetic.glorot_uniform(np.random.default_rng(50 + k), 512, 1024)   # LM_embedding is per head
+        heads[mode] = w
+    heads["plain"] = synthetic.glorot_gcn_weights(seed=30, n_terms=77)
+    preds = {m: Predictor("synthetic", weights=w) for m, w in heads.items()}
+    assert preds["mf"].session.lm is preds["cc"].session.lm and preds["plain"].session.lm is None
+    prot = synthetic.synthetic_proteins(seed=4, count=6, length=(33, 200), indel_rate=0.05)
+    eng = HotPathEngine(preds, max_rows=256)
+    pk = PackedProteins.pack([d["seq"] for d in prot], [d["coords"] for d in prot], [d["q_aln"] for d in prot],
+                             [d["t_aln"] for d in prot], max_rows=256)
+    out = eng.run_alignments(pk)
+    for p, d in enumerate(prot):
+        A = cmap_oracle.build_align_contact_map(d["coords"], d["q_aln"], d["t_aln"], 6.0, 2)
+        for m, w in heads.items():
+            ref = lm_oracle.gcn_lm_forward(w, d["seq"], A) if "W_lm" in w else gcn_oracle.gcn_forward(w, d["seq"], A)
+            assert np.abs(out[m][p] - ref).max() < 1e-4, (m, p)
+
+
+def test_mdfw_roundtrip_with_language_model(tmp_path):
+    from mDeepFRI import weights as W
+    from mDeepFRI.predict import Predictor
+    w = _weights(9, 64, 256, (256,), 256, 12)
+    path = str(tmp_path / "lm_model.mdfw")
+    W.save_mdfw(path, w)
+    seqs, coords = _proteins(8, [45])
+    A = _cmap(coords[0])
+    a = Predictor(path).forward_pass(seqs[0], A)
+    b = Predictor("synthetic", weights=w).forward_pass(seqs[0], A)
+    np.testing.assert_array_equal(a, b)
