@@ -46,6 +46,9 @@ def parse():
                     help="configs2 (headline): fixed length, identity alignments; mixed: configs[3]-style L~U[128,1024] with 5%% indels")
     ap.add_argument("--verify", type=int, default=4,
                     help="after the timed region, check this many proteins of the step against the oracle (untimed; 0 = skip)")
+    ap.add_argument("--lm", action="store_true",
+                    help="give every GO head the language-model branch of the released models (shared 2x512 LSTM + per-head "
+                         "LM embedding; SURVEY.md section 8f row 1).  Not the BASELINE.json configuration: an extra measurement.")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-device", type=int, default=None, help="testing aid: put every rank on this device ordinal")
     return ap.parse_args()
@@ -80,7 +83,11 @@ def cpu_baseline(seqs, coords, weights, budget_s):
             while n < len(seqs) and (time.perf_counter() - t0 < budget or n < 2):
                 cm = cmap_oracle.build_align_contact_map(coords[n], seqs[n], seqs[n], 6.0, 2)
                 for m in MODES:
-                    gcn_oracle.gcn_forward(weights[m], seqs[n], cm)
+                    if "W_lm" in weights[m]:
+                        import lm_oracle
+                        lm_oracle.gcn_lm_forward(weights[m], seqs[n], cm)   # (the oracle re-runs the shared LSTM per head, as the reference's three ONNX sessions do)
+                    else:
+                        gcn_oracle.gcn_forward(weights[m], seqs[n], cm)
                 n += 1
         return n, time.perf_counter() - t0
 
@@ -135,6 +142,11 @@ def main():
     from mDeepFRI.predict import Predictor
 
     weights = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=synthetic.GO_TERMS[m]) for i, m in enumerate(MODES)}
+    if args.lm:
+        lm = synthetic.glorot_lm_weights(seed=1000)
+        for i, m in enumerate(MODES):
+            weights[m].update(lm)
+            weights[m]["W_lm"] = synthetic.glorot_uniform(np.random.default_rng(2000 + i), 512, 1024)  # LM_embedding is per head
     preds = {m: Predictor(f"synthetic-{m}", weights=weights[m], device=local_rank) for m in MODES}
     T_total = sum(p.n_terms for p in preds.values())
 
@@ -200,7 +212,7 @@ def main():
         except OSError:
             traffic = {}
         if timing:
-            for kname in ("gemm", "gemm1", "ax", "cmap", "head"):
+            for kname in ("gemm", "gemm1", "ax", "cmap", "head") + (("lstm", "lstm2", "embed") if args.lm else ()):
                 n, ms = read(kname)
                 kernels[kname] = {"launches": n, "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / max(n, 1), 2)}
             n_g, ms_g = read("gemm")
@@ -210,7 +222,8 @@ def main():
             C = 512
             rows_launch = rows_total / len(pk.chunks)
             if n_g:
-                flops_launch = 2.0 * rows_launch * C * C
+                # with --lm the class also holds the unfolded layer-1 launch (K = 1024): mean over the three layers
+                flops_launch = 2.0 * rows_launch * C * ((1024 + C + C) / 3.0 if args.lm else C)
                 tf = flops_launch / (ms_g / n_g * 1e-3) / 1e12
                 roof = {"kernel": "k_gemm_f32 (H.W, 256x256x32 tiles, v_mfma_f32_32x32x2_f32, LDS-DMA staging, ELU+pool epilogue)",
                         "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
@@ -229,7 +242,7 @@ def main():
                            "per_launch": {"rows": R, "bytes": bytes_launch_rows * R, "nnz_per_row": round(nnz_per_row, 2),
                                           "avg_us": kernels["ax"]["avg_us"], "timed_launches": n_a}}
         line = {
-            "metric": "proteins/sec (GCN+cmap) at L=512",
+            "metric": "proteins/sec (GCN+cmap) at L=512" + (" [with LSTM language model]" if args.lm else ""),
             "value": round(world * args.proteins * args.steps / elapsed, 1),
             "unit": "proteins/s",
             "n_gpus": world,
@@ -246,7 +259,7 @@ def main():
                                    (f"configs[3]-style: {args.proteins} synthetic proteins per GPU, L~U[128,1024], 5% indels, "
                                     f"GCN_MF+BP+CC (T={T_total}), fused cmap align(6A, gen=2)+GCN"),
                        "proteins_per_gpu": args.proteins, "length": args.length, "go_heads": list(MODES),
-                       "chunk_rows": args.chunk_rows, "parallelism": f"shard{world}+gather" if world > 1 else "single"},
+                       "language_model": bool(args.lm), "chunk_rows": args.chunk_rows, "parallelism": f"shard{world}+gather" if world > 1 else "single"},
             "roofline": roof,
             "roofline_ax": roof_ax,
             "kernels": kernels,
@@ -261,7 +274,11 @@ def main():
             for i in pick:
                 cm = cmap_oracle.build_align_contact_map(coords[i], q_alns[i], t_alns[i], 6.0, 2)
                 for m in MODES:
-                    ref = gcn_oracle.gcn_forward(weights[m], seqs[i], cm)
+                    if args.lm:
+                        import lm_oracle
+                        ref = lm_oracle.gcn_lm_forward(weights[m], seqs[i], cm)
+                    else:
+                        ref = gcn_oracle.gcn_forward(weights[m], seqs[i], cm)
                     worst = max(worst, float(np.max(np.abs(out[m][i].cpu().numpy() - ref))))
             line["verify"] = {"proteins": int(args.verify), "heads": list(MODES), "max_abs_err_vs_oracle": worst, "tolerance": 1e-4}
             if not worst < 1e-4:

@@ -260,7 +260,8 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
  * launches (read after a sync).  An event pair costs GPU time between kernels (~6 % of the step when every launch is
  * timed), hence the sampling.
  * kernel: "ax" (A.X aggregation), "gemm" (H.W fp32 MFMA, layers 2..3), "gemm1" (layer-1 S.T1 GEMM, K=32), "cmap" (fused contact map), "head",
- * "lstm" (one language-model time step: both LSTM layers), "embed" (language-model embedding GEMM). */
+ * "lstm" / "lstm2" (one time step of language-model layer 1 / layer 2; the two run concurrently on two streams, so their
+ * durations include the contention), "embed" (language-model embedding GEMM). */
 int mdf_timing_enable(int on);
 int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms);
 int mdf_timing_reset(void);

@@ -37,7 +37,7 @@ int fail(int code, const char *fmt, ...);
 int require_device();
 
 // ---- launch timing (mdf_timing_*) -----------------------------------------------------------------------------
-enum TimedKernel { TK_AX = 0, TK_GEMM = 1, TK_CMAP = 2, TK_HEAD = 3, TK_GEMM1 = 4, TK_LSTM = 5, TK_EMBED = 6, TK_COUNT = 7 };
+enum TimedKernel { TK_AX = 0, TK_GEMM = 1, TK_CMAP = 2, TK_HEAD = 3, TK_GEMM1 = 4, TK_LSTM = 5, TK_EMBED = 6, TK_LSTM2 = 7, TK_COUNT = 8 };
 bool timing_on();
 // Record an event pair around a launch on `stream`; no-ops when timing is disabled.
 void timing_begin(TimedKernel k, hipStream_t stream);

@@ -79,8 +79,17 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x)
 // XCD-aware tile order: block b runs on XCD b%8 (observed placement; used for L2 affinity only).  The NT column
 // tiles of one 128-row tile are issued back to back on the same XCD so that the A rows are fetched into that
 // XCD's L2 once; row tile t lives on XCD t%8 in every kernel of the layer chain.
+// (PLAIN, used by the LSTM steps whose M is only a few row tiles: nt = b % NT, mt = b / NT -- with NT = 8 column tiles
+// every XCD keeps one column slice of the recurrent matrix in its L2 and all XCDs get the same number of live tiles; the
+// XCD-aware order gives XCD x the row tiles mt = x (mod 8), a 3:2 imbalance at MT = 20.)
+template <bool PLAIN = false>
 __device__ __forceinline__ void tile_of_block(int b, int NT, int &mt, int &nt)
 {
+    if (PLAIN) {
+        nt = b % NT;
+        mt = b / NT;
+        return;
+    }
     const int x = b & 7, q = b >> 3;
     nt = q % NT;
     mt = (q / NT) * 8 + x;
@@ -220,13 +229,14 @@ __device__ unsigned long long *g_probe_buf = nullptr;  // [grid][4]: realtime st
 struct TileCursor {
     int t, mt, nt, kt;
 };
+template <bool PLAIN = false>
 __device__ __forceinline__ void cursor_advance(TileCursor &c, int nk, int NT, int M, int total, int stride)
 {
     if (c.t >= total) return;  // exhausted: stay on the last slot (reads through it are clamped and harmless)
     if (++c.kt < nk) return;
     c.kt = 0;
     for (c.t += stride; c.t < total; c.t += stride) {
-        tile_of_block(c.t, NT, c.mt, c.nt);
+        tile_of_block<PLAIN>(c.t, NT, c.mt, c.nt);
         if (c.mt * BM < M) return;
     }
 }
@@ -287,6 +297,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wid >> 2, wn = wid & 3;
     const int NT = N / BN, nk = K / BK, stride = gridDim.x;
+    constexpr bool PLAIN = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
 
     TileCursor cc;  // compute cursor
     cc.kt = 0;
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
     {
         int first = -1, mt, nt;
         for (int t = blockIdx.x; t < total_tiles; t += stride) {
-            tile_of_block(t, NT, mt, nt);
+            tile_of_block<PLAIN>(t, NT, mt, nt);
             if (mt * BM < M) {
                 if (first < 0) { first = t; cc.t = t; cc.mt = mt; cc.nt = nt; }
                 ++n_mine;
@@ -376,7 +387,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
         MDF_DMA_SETUP(pc)
         const unsigned ldsA = lds_base, ldsB = lds_base + BM * BK * 4;
         MDF_DMA_PIECE(0, ldsA, ldsB) MDF_DMA_PIECE(1, ldsA, ldsB) MDF_DMA_PIECE(2, ldsA, ldsB) MDF_DMA_PIECE(3, ldsA, ldsB)
-        cursor_advance(pc, nk, NT, M, total_tiles, stride);
+        cursor_advance<PLAIN>(pc, nk, NT, M, total_tiles, stride);
         MDF_DMA_SETUP(pc)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
         if (ABL < 3) __syncthreads();                                                                              \
         /* k-group 3 on q; p <- k-group 0 of the NEXT position (buffer CUR^1); next DMA's address arithmetic */     \
         MDF_K8(q, x, MDF_RDA(p, 0, 0, An), MDF_RDB(p, 0, 0, Bn), MDF_RDB(p, 1, 0, Bn), MDF_RDA(p, 1, 0, An), MDF_RDA(p, 2, 0, An), MDF_RDA(p, 3, 0, An), , ) \
-        cursor_advance(pc, nk, NT, M, total_tiles, stride);                                                        \
+        cursor_advance<PLAIN>(pc, nk, NT, M, total_tiles, stride);                                                        \
         MDF_DMA_SETUP(pc)                                                                                          \
         MDF_K8_PLAIN(q, y) MDF_K8_PLAIN(q, z) MDF_K8_PLAIN(q, w)                                                   \
         if (cc.kt == nk - 1) {                                                                                     \
@@ -426,7 +437,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;                                \
         }                                                                                                          \
         --rem;                                                                                                     \
-        if (rem > 0) cursor_advance(cc, nk, NT, M, total_tiles, stride);                                           \
+        if (rem > 0) cursor_advance<PLAIN>(cc, nk, NT, M, total_tiles, stride);                                           \
     }
 
     while (true) {
@@ -631,7 +642,8 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     MDF_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d", M, N, K);
     if (int rc = set_gemm_attr_once()) return rc;
     const int MT = (M + BM - 1) / BM, NT = N / BN;
-    const int total = 8 * NT * ((MT + 7) / 8);               // tile slots in XCD-aware order (some may lie past M)
+    const bool plain = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
+    const int total = plain ? MT * NT : 8 * NT * ((MT + 7) / 8);  // tile slots (in XCD-aware order some lie past M)
     const int blocks = std::min(total, gemm_resident_blocks());
     hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
                        pool_partial, ldp, logits, n_real, total, aux);
@@ -720,6 +732,10 @@ struct mdf_lm {
     float *tab1 = nullptr;    // (32, 4H)  W1[a] + b1 per letter (rows 26..31 zero), permuted
     float *W2U2t = nullptr;   // (4H, 2H)  [W2 ; U2]^T of LSTM2, permuted
     float *b2p = nullptr;     // (4H)      b2, permuted
+    // LSTM2 runs on its own stream, one step behind LSTM1 (see mdf_lm_forward_dev)
+    hipStream_t s2 = nullptr;
+    hipEvent_t ev[64] = {};
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
 };
 
 namespace mdf {
@@ -891,6 +907,12 @@ int mdf_lm_create(const mdf_lm_weights *w, int device, mdf_lm **out)
     if (rc == MDF_OK) rc = upload(&lm->tab1, tab.data(), tab.size());
     if (rc == MDF_OK) rc = upload(&lm->W2U2t, w2u2t.data(), w2u2t.size());
     if (rc == MDF_OK) rc = upload(&lm->b2p, b2p.data(), b2p.size());
+    if (rc == MDF_OK && hipStreamCreateWithFlags(&lm->s2, hipStreamNonBlocking) != hipSuccess) rc = fail(MDF_ENODEVICE, "lm_create: cannot create a stream");
+    for (int i = 0; i < 64 && rc == MDF_OK; ++i)
+        if (hipEventCreateWithFlags(&lm->ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(MDF_ENODEVICE, "lm_create: cannot create an event");
+    if (rc == MDF_OK && (hipEventCreateWithFlags(&lm->ev_in, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&lm->ev_out, hipEventDisableTiming) != hipSuccess))
+        rc = fail(MDF_ENODEVICE, "lm_create: cannot create an event");
     if (rc != MDF_OK) {
         mdf_lm_free(lm);
         return rc;
@@ -906,6 +928,11 @@ void mdf_lm_free(mdf_lm *lm)
     (void)hipFree(lm->tab1);
     (void)hipFree(lm->W2U2t);
     (void)hipFree(lm->b2p);
+    if (lm->s2) (void)hipStreamDestroy(lm->s2);
+    for (int i = 0; i < 64; ++i)
+        if (lm->ev[i]) (void)hipEventDestroy(lm->ev[i]);
+    if (lm->ev_in) (void)hipEventDestroy(lm->ev_in);
+    if (lm->ev_out) (void)hipEventDestroy(lm->ev_out);
     delete lm;
 }
 
@@ -940,25 +967,40 @@ int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_r
         hipLaunchKernelGGL(k_lm_pack_letters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seq_idx, prot_row, len_dev, B, Lmax, let_tm);
         MDF_HIP(hipGetLastError());
     }
+    // Two chains: LSTM1 steps on the caller's stream, LSTM2 steps on lm->s2, step t of LSTM2 waiting for step t of LSTM1
+    // only.  LSTM1(t+1) and LSTM2(t) are independent, and an LSTM2 tile (K = 2H) takes twice as long as an LSTM1 tile:
+    // run together they fill the CUs for batches well below one full round of 256 tiles per layer.
+    hipStream_t s2 = lm->s2;
+    MDF_HIP(hipEventRecord(lm->ev_in, st));
+    MDF_HIP(hipStreamWaitEvent(s2, lm->ev_in, 0));
     int active = B;   // proteins with length > t form a prefix
     for (int t = 0; t < Lmax; ++t) {
         while (active > 0 && len_host[active - 1] <= t) --active;
-        ScopedTiming tm(TK_LSTM, st);
-        GemmAux a1;
-        a1.table = lm->tab1;
-        a1.letters = let_tm + (size_t)t * B;
-        a1.cstate = c1;
-        if (int rc = launch_gemm<EPI_LSTM_TAB>(h1 + t * blk, H, lm->U1t, H, active, 4 * H, H, h1 + (t + 1) * blk, H, nullptr, nullptr, 0,
-                                               nullptr, 0, st, a1))
-            return rc;
-        GemmAux a2;
-        a2.A2 = h2 + t * blk;
-        a2.ksplit = H / BK;
-        a2.cstate = c2;
-        if (int rc = launch_gemm<EPI_LSTM_BIAS>(h1 + (t + 1) * blk, H, lm->W2U2t, 2 * H, active, 4 * H, 2 * H, h2 + (t + 1) * blk, H, lm->b2p,
-                                                nullptr, 0, nullptr, 0, st, a2))
-            return rc;
+        {
+            ScopedTiming tm(TK_LSTM, st);
+            GemmAux a1;
+            a1.table = lm->tab1;
+            a1.letters = let_tm + (size_t)t * B;
+            a1.cstate = c1;
+            if (int rc = launch_gemm<EPI_LSTM_TAB>(h1 + t * blk, H, lm->U1t, H, active, 4 * H, H, h1 + (t + 1) * blk, H, nullptr, nullptr,
+                                                   0, nullptr, 0, st, a1))
+                return rc;
+        }
+        MDF_HIP(hipEventRecord(lm->ev[t & 63], st));
+        MDF_HIP(hipStreamWaitEvent(s2, lm->ev[t & 63], 0));
+        {
+            ScopedTiming tm(TK_LSTM2, s2);
+            GemmAux a2;
+            a2.A2 = h2 + t * blk;
+            a2.ksplit = H / BK;
+            a2.cstate = c2;
+            if (int rc = launch_gemm<EPI_LSTM_BIAS>(h1 + (t + 1) * blk, H, lm->W2U2t, 2 * H, active, 4 * H, 2 * H, h2 + (t + 1) * blk, H,
+                                                    lm->b2p, nullptr, 0, nullptr, 0, s2, a2))
+                return rc;
+        }
     }
+    MDF_HIP(hipEventRecord(lm->ev_out, s2));
+    MDF_HIP(hipStreamWaitEvent(st, lm->ev_out, 0));
     hipLaunchKernelGGL(k_lm_unpack, dim3(Lmax, B), dim3(128), 0, st, h2, prot_row, len_dev, B, H, h_out);
     MDF_HIP(hipGetLastError());
     return MDF_OK;

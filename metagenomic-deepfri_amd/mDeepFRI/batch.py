@@ -281,19 +281,26 @@ class HotPathEngine:
     # -- language model ------------------------------------------------------------------------------------------------
     def _lm_batches(self, packed: PackedProteins):
         """Consecutive chunk ranges [c0, c1) whose proteins run through the LSTM together: at most `lm_batch` proteins and
-        a time-major workspace (2 x (Lmax+1) x B x H floats) within `lm_workspace_bytes`."""
+        a time-major workspace (2 x (Lmax+1) x B x H floats) within `lm_workspace_bytes`.  The proteins are dealt evenly
+        over the fewest such groups: an LSTM time step costs whole rounds of 256x256 tiles, so a small trailing group
+        would cost as much as a full one."""
         H = max(lm.hidden for lm in self.lms)
-        out, c0, nb, lmax = [], 0, 0, 0
-        for ci, ch in enumerate(packed.chunks):
-            n = ch.p1 - ch.p0
-            l = int(packed.Lq[ch.p0:ch.p1].max())
-            nb2, lmax2 = nb + n, max(lmax, l)
-            if ci > c0 and (nb2 > min(self.lm_batch, 65535) or 8 * (lmax2 + 1) * nb2 * H > self.lm_workspace_bytes):
-                out.append((c0, ci))
-                c0, nb2, lmax2 = ci, n, l
-            nb, lmax = nb2, lmax2
-        out.append((c0, len(packed.chunks)))
-        return out
+        cap = min(self.lm_batch, 65535)
+        n_groups = max(1, -(-packed.B // cap))
+        while True:
+            target = -(-packed.B // n_groups)
+            out, c0, nb, lmax, ok = [], 0, 0, 0, True
+            for ci, ch in enumerate(packed.chunks):
+                n = ch.p1 - ch.p0
+                l = int(packed.Lq[ch.p0:ch.p1].max())
+                if ci > c0 and (nb + n > cap or nb >= target or 8 * (max(lmax, l) + 1) * (nb + n) * H > self.lm_workspace_bytes):
+                    out.append((c0, ci))
+                    c0, nb, lmax = ci, 0, 0
+                nb, lmax = nb + n, max(lmax, l)
+            out.append((c0, len(packed.chunks)))
+            if len(out) <= n_groups or n_groups >= len(packed.chunks):
+                return out
+            n_groups = len(out)   # memory or chunk granularity forced more groups: re-balance for that count
 
     def _lm_forward(self, db: DeviceBatch, c0: int, c1: int, bases, seq_all, st):
         """LSTM features of every protein in chunks [c0, c1) -> {id(lm): (rows_total, H) tensor} in residue-row layout."""

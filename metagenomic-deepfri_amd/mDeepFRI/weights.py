@@ -12,9 +12,11 @@ Optional language-model branch (the released models have it; SURVEY.md section 8
 order i,f,c,o:  W_lm (H,E)  b_lm (E)  lm_W1 (26,4H)  lm_U1 (H,4H)  lm_b1 (4H)  lm_W2 (H,4H)  lm_U2 (H,4H)  lm_b2 (4H).
 `.npz` files with the same keys are accepted too.
 
-Real `.onnx` files are not parsed yet: the shipped models also contain an LSTM language-model branch that this
-build does not implement ("next" row 1); `resolve_model_path` therefore looks for a
-`.mdfw`/`.npz` sibling of a given `.onnx` path and fails loudly otherwise.
+`.onnx` files (what the reference's pipeline passes, pipeline.py:549-584) are read by mDeepFRI.onnx_reader -- a
+structural extraction of the tensors above from the tf2onnx graph, no onnx / onnxruntime needed.  `resolve_model_path`
+prefers a `.mdfw`/`.npz` sibling of the given path (convert once with `python -m mDeepFRI.onnx_reader model.onnx`) and
+falls back to parsing the `.onnx` itself.  The reader has been exercised on schema-conformant files only, never on a
+released DeepFRI file (none is available offline): it refuses graphs it does not recognise.
 """
 from __future__ import annotations
 
@@ -116,9 +118,10 @@ def resolve_model_path(model_path: str) -> str:
     for ext in (".mdfw", ".npz"):
         if os.path.exists(stem + ext):
             return stem + ext
+    if model_path.endswith(".onnx") and os.path.exists(model_path):
+        return model_path
     raise FileNotFoundError(
-        f"no '.mdfw' or '.npz' weight container found next to {model_path!r}; ONNX files are not parsed by this "
-        f"build (write one with mDeepFRI.weights.save_mdfw)")
+        f"{model_path!r}: no such model file, and no '.mdfw' / '.npz' weight container with the same stem")
 
 
 def load_weights(model_path: str) -> dict:
@@ -126,6 +129,9 @@ def load_weights(model_path: str) -> dict:
     if p.endswith(".npz"):
         with np.load(p) as z:
             w = {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
+    elif p.endswith(".onnx"):
+        from . import onnx_reader
+        w = onnx_reader.extract_gcn_weights(onnx_reader.parse_model(p))
     else:
         w = load_mdfw(p)
     validate(w)
