@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--timing-period", type=int, default=8,
                     help="bracket every n-th launch of each kernel class with HIP events (an event pair costs GPU time between "
                          "kernels: timing every launch lowers the step rate by ~6 %%)")
-    ap.add_argument("--workload", default="configs2", choices=["configs2", "mixed"],
+    ap.add_argument("--workload", default="configs2", choices=["configs2", "mixed", "cnn"],
                     help="configs2 (headline): fixed length, identity alignments; mixed: configs[3]-style L~U[128,1024] with 5%% indels")
     ap.add_argument("--verify", type=int, default=4,
                     help="after the timed region, check this many proteins of the step against the oracle (untimed; 0 = skip)")
@@ -140,6 +140,9 @@ def main():
 
     from mDeepFRI import _hip, batch, sharding, synthetic
     from mDeepFRI.predict import Predictor
+
+    if args.workload == "cnn":
+        return bench_cnn(args, rank, local_rank, world, dev)
 
     weights = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=synthetic.GO_TERMS[m]) for i, m in enumerate(MODES)}
     if args.lm:
@@ -289,6 +292,81 @@ def main():
             line["gpu_over_cpu_1core"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
         else:
             line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_cnn(args, rank, local_rank, world, dev):
+    """Extra measurement (not the BASELINE.json metric): the sequence-only CNN models the reference runs on proteins without a
+    structural hit (pipeline.py:600-648), 3 heads, upstream DeepCNN default topology, same synthetic sequences."""
+    import torch
+    import torch.distributed as dist
+    from mDeepFRI import _hip, batch, synthetic
+    from mDeepFRI.predict import Predictor
+    weights = {m: synthetic.glorot_cnn_weights(seed=i, n_terms=synthetic.GO_TERMS[m]) for i, m in enumerate(MODES)}
+    preds = {m: Predictor(f"synthetic-cnn-{m}", weights=weights[m], device=local_rank) for m in MODES}
+    seqs, _ = make_workload(42 + 2 + 1000 * rank, args.proteins, args.length)
+    eng = batch.SequenceEngine(preds, device=local_rank)
+    db = batch.DeviceBatch(batch.PackedProteins.pack(seqs, max_rows=1 << 20), dev)
+    lib = _hip.lib()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.forward(db)
+    fence()
+    eng.check(db)
+    lib.mdf_timing_reset()
+    lib.mdf_timing_enable(0 if args.no_kernel_timing else 1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.forward(db)
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.mdf_timing_enable(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        n, ms = _hip.c_int64(0), _hip.ctypes.c_double(0.0)
+        lib.mdf_timing_read(b"cnn", n, ms)
+        line = {"metric": "proteins/sec (sequence-only CNN) at L=%d" % args.length, "value": round(world * args.proteins * args.steps / elapsed, 1),
+                "unit": "proteins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{args.proteins} synthetic L={args.length} sequences per GPU, DeepCNN MF+BP+CC (4 Conv1D branches "
+                                       f"120/100/80/60 x 5/10/15/20, BatchNorm, max pool, FuncPredictor)", "go_heads": list(MODES)},
+                "kernels": {"cnn": {"launches": int(n.value), "total_ms": round(ms.value, 3), "avg_us": round(1e3 * ms.value / max(n.value, 1), 2)}}}
+        if args.verify > 0:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import cnn_oracle
+            worst = 0.0
+            for i in np.linspace(0, args.proteins - 1, args.verify).astype(int):
+                for m in MODES:
+                    worst = max(worst, float(np.max(np.abs(out[m][i].cpu().numpy() - cnn_oracle.cnn_forward(weights[m], seqs[i])))))
+            line["verify"] = {"proteins": int(args.verify), "max_abs_err_vs_oracle": worst, "tolerance": 1e-4}
+            if not worst < 1e-4:
+                raise SystemExit(f"parity check failed: {worst}")
+        if world == 1 and args.cpu_seconds > 0:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import cnn_oracle
+            from threadpoolctl import threadpool_limits
+            k, t1 = 0, time.perf_counter()
+            with threadpool_limits(limits=1):
+                while k < len(seqs) and time.perf_counter() - t1 < args.cpu_seconds * 0.5:
+                    for m in MODES:
+                        cnn_oracle.cnn_forward(weights[m], seqs[k])
+                    k += 1
+            line["cpu_baseline"] = {"value": k / (time.perf_counter() - t1), "unit": "proteins/s", "cores": 1, "kind": "port",
+                                    "sample": f"{k} sequences, 3 heads each, numpy oracle",
+                                    "published_anchor": "reference weight_convert/inference_times.csv.gz: ~0.018 s/protein/model/core at L~512 (ORT CPU)"}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

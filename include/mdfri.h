@@ -167,6 +167,37 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
                          float *scores, int64_t *bad_idx);
 
 /* ------------------------------------------------------------------------------------------------
+ * Sequence-only CNN model: mDeepFRI/predict.pyx:91-100, Predictor.forward_pass(seqres) with cmap=None (the
+ * reference feeds the one-hot sequence alone to the `DeepCNN-MERGED_{mode}.onnx` session; caller
+ * pipeline.py:600-648).  n parallel Conv1D('same') branches over the one-hot sequence -> concat -> BatchNorm ->
+ * relu -> global max pool -> FuncPredictor; arithmetic restated in oracle/cnn_oracle.py. */
+typedef struct mdf_cnn mdf_cnn;
+typedef struct {
+    int32_t n_branch;
+    const int32_t *kernel_len;      /* (n_branch) */
+    const int32_t *filters;         /* (n_branch) */
+    const int32_t *pad_left;        /* (n_branch) zeros left of the sequence, or NULL for TensorFlow 'same': (k-1)/2 */
+    const float *const *W;          /* n_branch pointers, each (kernel_len, 26, filters)  -- Keras Conv1D kernel layout */
+    const float *const *b;          /* n_branch pointers, each (filters) */
+    const float *bn_gamma, *bn_beta, *bn_mean, *bn_var;   /* (sum filters) BatchNormalization, inference form */
+    float bn_eps;
+    int32_t n_terms;
+    const float *W_out;             /* (sum filters, 2*n_terms) */
+    const float *b_out;             /* (2*n_terms) */
+} mdf_cnn_weights;
+int mdf_cnn_create(const mdf_cnn_weights *w, int device, mdf_cnn **out);
+void mdf_cnn_free(mdf_cnn *m);
+int mdf_cnn_num_terms(const mdf_cnn *m);
+int mdf_cnn_channels(const mdf_cnn *m);
+/* One protein, host buffers (the per-call shape of predict.pyx:75-102).  scores: (T) f32. */
+int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, int64_t *bad_idx);
+/* B proteins in residue-row layout (see below): seq_idx (R) from mdf_seq_encode_dev, Lq / row_off device int32.
+ * scores: (B, T) f32.  workspace: mdf_cnn_workspace_bytes(m, B). */
+size_t mdf_cnn_workspace_bytes(const mdf_cnn *m, int32_t B);
+int mdf_cnn_forward_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, const int32_t *row_off, int32_t B,
+                        float *scores, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Batched device API (the counterpart of pipeline.py:476-481 Pool.map(build_align_contact_map) and
  * pipeline.py:292-319 _run_prediction_loop, for B proteins at once).
  *
@@ -261,7 +292,7 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
  * timed), hence the sampling.
  * kernel: "ax" (A.X aggregation), "gemm" (H.W fp32 MFMA, layers 2..3), "gemm1" (layer-1 S.T1 GEMM, K=32), "cmap" (fused contact map), "head",
  * "lstm" / "lstm2" (one time step of language-model layer 1 / layer 2; the two run concurrently on two streams, so their
- * durations include the contention), "embed" (language-model embedding GEMM). */
+ * durations include the contention), "embed" (language-model embedding GEMM), "cnn" (sequence-only CNN: conv + max pool). */
 int mdf_timing_enable(int on);
 int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms);
 int mdf_timing_reset(void);

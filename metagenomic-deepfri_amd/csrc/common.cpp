@@ -149,6 +149,7 @@ int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms)
     else if (!strcmp(kernel, "lstm")) k = TK_LSTM;
     else if (!strcmp(kernel, "embed")) k = TK_EMBED;
     else if (!strcmp(kernel, "lstm2")) k = TK_LSTM2;
+    else if (!strcmp(kernel, "cnn")) k = TK_CNN;
     if (k < 0) return fail(MDF_EINVAL, "mdf_timing_read: unknown kernel class '%s'", kernel);
     std::lock_guard<std::mutex> lk(g_t.mu);
     fold_locked();

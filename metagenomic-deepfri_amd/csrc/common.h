@@ -37,7 +37,7 @@ int fail(int code, const char *fmt, ...);
 int require_device();
 
 // ---- launch timing (mdf_timing_*) -----------------------------------------------------------------------------
-enum TimedKernel { TK_AX = 0, TK_GEMM = 1, TK_CMAP = 2, TK_HEAD = 3, TK_GEMM1 = 4, TK_LSTM = 5, TK_EMBED = 6, TK_LSTM2 = 7, TK_COUNT = 8 };
+enum TimedKernel { TK_AX = 0, TK_GEMM = 1, TK_CMAP = 2, TK_HEAD = 3, TK_GEMM1 = 4, TK_LSTM = 5, TK_EMBED = 6, TK_LSTM2 = 7, TK_CNN = 8, TK_COUNT = 9 };
 bool timing_on();
 // Record an event pair around a launch on `stream`; no-ops when timing is disabled.
 void timing_begin(TimedKernel k, hipStream_t stream);
@@ -76,5 +76,10 @@ struct Carver {
     }
     bool ok() const { return off <= cap; }
 };
+
+// scores[M, T] = pair-softmax channel 0 of (A[M,K] . Wt[Npad,K]^T + bias[Npad]) on the fp32 MFMA GEMM of gcn.hip
+// (FuncPredictor output layer; columns (2t, 2t+1) are the two channels of term t).  K % 32 == 0, Npad % 256 == 0.
+int launch_head_softmax2(const float *A, int lda, const float *Wt, int ldb, int M, int Npad, int K, float *scores, int T,
+                         const float *bias, hipStream_t st);
 
 }  // namespace mdf

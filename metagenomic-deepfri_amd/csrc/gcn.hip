@@ -723,6 +723,12 @@ static int gcn_upper_layers(mdf_model *m, float *Hin, float *Hout, float *AH, co
     return MDF_OK;
 }
 
+int launch_head_softmax2(const float *A, int lda, const float *Wt, int ldb, int M, int Npad, int K, float *scores, int T,
+                         const float *bias, hipStream_t st)
+{
+    return launch_gemm<EPI_BIAS_SOFTMAX2>(A, lda, Wt, ldb, M, Npad, K, scores, T, bias, nullptr, 0, nullptr, 2 * T, st);
+}
+
 // ---- LSTM language model ------------------------------------------------------------------------------------------------
 }  // namespace mdf
 

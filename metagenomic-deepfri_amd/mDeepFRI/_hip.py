@@ -44,6 +44,15 @@ class LmWeights(ctypes.Structure):
     ]
 
 
+class CnnWeights(ctypes.Structure):
+    _fields_ = [
+        ("n_branch", c_int32), ("kernel_len", POINTER(c_int32)), ("filters", POINTER(c_int32)), ("pad_left", POINTER(c_int32)),
+        ("W", POINTER(POINTER(c_float))), ("b", POINTER(POINTER(c_float))),
+        ("bn_gamma", POINTER(c_float)), ("bn_beta", POINTER(c_float)), ("bn_mean", POINTER(c_float)), ("bn_var", POINTER(c_float)),
+        ("bn_eps", c_float), ("n_terms", c_int32), ("W_out", POINTER(c_float)), ("b_out", POINTER(c_float)),
+    ]
+
+
 _f32p, _i32p, _i64p, _u8p = POINTER(c_float), POINTER(c_int32), POINTER(c_int64), POINTER(c_uint8)
 
 # name -> (restype, argtypes); every symbol include/mdfri.h declares
@@ -74,6 +83,13 @@ SIGNATURES = {
     "mdf_lm_forward_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdf_gcn_embed_lm_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),
+    "mdf_cnn_create": (c_int, [POINTER(CnnWeights), c_int, POINTER(c_void_p)]),
+    "mdf_cnn_free": (None, [c_void_p]),
+    "mdf_cnn_num_terms": (c_int, [c_void_p]),
+    "mdf_cnn_channels": (c_int, [c_void_p]),
+    "mdf_cnn_forward_host": (c_int, [c_void_p, c_char_p, c_int64, c_void_p, _i64p]),
+    "mdf_cnn_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
+    "mdf_cnn_forward_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdf_gcn_forward_host": (c_int, [c_void_p, c_char_p, c_int64, c_void_p, c_int, c_void_p, _i64p]),
     "mdf_layout_rows": (c_int64, [c_void_p, c_int32, c_void_p]),
     "mdf_seq_encode_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),

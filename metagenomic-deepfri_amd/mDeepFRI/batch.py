@@ -547,6 +547,63 @@ class HotPathEngine:
         return {m: t.cpu().numpy() for m, t in out.items()}
 
 
+class SequenceEngine:
+    """Sequence-only CNN models for batches of proteins on one GPU: the batched counterpart of the reference's CNN loop
+    over the unaligned queries (pipeline.py:600-648, `_run_prediction_loop(predictor=cnn, ...)`).
+    `predictors`: {mode: Predictor built from a DeepCNN model}."""
+
+    def __init__(self, predictors: dict, device: int = 0, max_rows: int = 1 << 20):
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise RuntimeError("SequenceEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
+        for m, p in predictors.items():
+            if p.session.kind != "cnn":
+                raise ValueError(f"predictor {m!r} is not a sequence-only (CNN) model")
+        self.L = _hip.lib()
+        self.predictors = dict(predictors)
+        self.device = torch.device(f"cuda:{device}")
+        self.max_rows = int(max_rows)
+
+    def forward(self, db: DeviceBatch) -> dict:
+        """{mode: (B, T) float32 scores on the device}; asynchronous on the current stream (`check(db)` syncs)."""
+        torch = _torch()
+        pk = db.packed
+        with torch.cuda.device(self.device):
+            st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            rows = pk.max_chunk_rows
+            nmax = max(ch.p1 - ch.p0 for ch in pk.chunks)
+            seq_idx = torch.empty(rows, dtype=torch.uint8, device=self.device)
+            ws = torch.empty(max(self.L.mdf_cnn_workspace_bytes(p.session.handle, nmax) for p in self.predictors.values()),
+                             dtype=torch.uint8, device=self.device)
+            out = {m: torch.empty((db.B, p.n_terms), dtype=torch.float32, device=self.device) for m, p in self.predictors.items()}
+            for ci, ch in enumerate(pk.chunks):
+                Bc = ch.p1 - ch.p0
+                ro = _p(db.chunk_row_off, ch.row_off_pos)
+                _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
+                                                     _p(seq_idx), _p(db.bad, ci * 2), st))
+                for m, p in self.predictors.items():
+                    _hip.check(self.L.mdf_cnn_forward_dev(p.session.handle, _p(seq_idx), _p(db.Lq, ch.p0), ro, Bc,
+                                                          _p(out[m], ch.p0 * p.n_terms), _p(ws), ws.numel(), st))
+            self._keep = (seq_idx, ws)
+            return out
+
+    def check(self, db: DeviceBatch):
+        torch = _torch()
+        torch.cuda.current_stream(self.device).synchronize()
+        bad = db.bad.cpu().numpy()
+        for ci, ch in enumerate(db.packed.chunks):
+            if bad[ci, 0] != 0:
+                p = ch.p0 + int(bad[ci, 0]) - 1
+                raise ValueError(f"Invalid character in sequence: {db.packed.seqs[p][int(bad[ci, 1])]}")
+
+    def run(self, seqs) -> dict:
+        """Convenience: pack, upload, run, validate -> {mode: np.ndarray (B, T)}."""
+        db = DeviceBatch(PackedProteins.pack(seqs, max_rows=self.max_rows), self.device)
+        out = self.forward(db)
+        self.check(db)
+        return {m: t.cpu().numpy() for m, t in out.items()}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # batched build_align_contact_map (reference output format)
 # ---------------------------------------------------------------------------------------------------------------------

@@ -11,6 +11,10 @@ tensors by the STRUCTURE of the graph, not by tensor names (tf2onnx names depend
     MatMul chain (E,C1) (C1,C2) (C2,C3)   -> W_gc1..3   (GraphConv kernels, no bias)
     MatMul/Gemm (C1+C2+C3, F) + bias      -> W_fc, b_fc
     MatMul/Gemm (F, 2T) + bias            -> W_out, b_out
+  sequence-only DeepCNN files (any Conv node present):
+    Conv nodes with constant kernels      -> cnn_W{b} (k,26,F), cnn_b{b}, cnn_pad{b} (from pads / auto_pad)
+    BatchNormalization                    -> bn_gamma, bn_beta, bn_mean, bn_var, bn_eps
+    MatMul/Gemm (sum F, 2T) + bias        -> W_out, b_out
 
 STATUS: validated against files written with Google's protobuf encoder from the same schema (tests/test_onnx_reader_cpu.py),
 NOT against a released DeepFRI file -- none is available offline.  `extract_gcn_weights`
@@ -25,7 +29,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-__all__ = ["parse_model", "extract_gcn_weights", "load_onnx_weights", "OnnxFormatError"]
+__all__ = ["parse_model", "extract_gcn_weights", "extract_cnn_weights", "extract_weights", "load_onnx_weights", "OnnxFormatError"]
 
 
 class OnnxFormatError(ValueError):
@@ -383,9 +387,82 @@ def extract_gcn_weights(g: Graph) -> dict:
     return {k_: np.ascontiguousarray(v, dtype=np.float32) for k_, v in w.items()}
 
 
+def extract_cnn_weights(g: Graph) -> dict:
+    """Graph of a sequence-only DeepCNN -> weight dict (keys of mDeepFRI.weights.validate_cnn)."""
+    const = _constants(g)
+    consumers = {}
+    for nd in g.nodes:
+        for i in nd.inputs:
+            consumers.setdefault(i, []).append(nd)
+    w, b = {}, 0
+    for nd in g.nodes:
+        if nd.op_type != "Conv":
+            continue
+        if len(nd.inputs) < 2 or nd.inputs[1] not in const:
+            raise OnnxFormatError(f"Conv node {nd.name!r}: kernel is not a constant")
+        K = np.asarray(const[nd.inputs[1]], np.float32)          # (F, C, k) or a Conv2D form of it, (F, C, 1, k) / (F, C, k, 1)
+        spatial = [d for d in K.shape[2:] if d != 1]
+        if K.ndim not in (3, 4) or K.shape[1] != 26 or len(spatial) > 1:
+            raise OnnxFormatError(f"Conv node {nd.name!r}: kernel shape {K.shape} is not a 1-D convolution over 26 channels")
+        k = spatial[0] if spatial else 1
+        axis = 0 if K.ndim == 3 else [i for i, d in enumerate(K.shape[2:]) if d == k][-1] if spatial else 0
+        K3 = K.reshape(K.shape[0], 26, k)
+        if any(v != 1 for v in (nd.attrs.get("strides") or [1])) or any(v != 1 for v in (nd.attrs.get("dilations") or [1])) \
+                or nd.attrs.get("group", 1) != 1:
+            raise OnnxFormatError(f"Conv node {nd.name!r}: strides / dilations / groups other than 1 are not supported")
+        auto = nd.attrs.get("auto_pad", b"NOTSET")
+        auto = auto.decode() if isinstance(auto, bytes) else auto
+        pads = nd.attrs.get("pads")
+        if auto == "SAME_UPPER":
+            left = (k - 1) // 2
+        elif auto == "SAME_LOWER":
+            left = (k - 1) - (k - 1) // 2
+        elif pads:
+            n_sp = len(pads) // 2
+            left, right = int(pads[axis]), int(pads[n_sp + axis])
+            if left + right != k - 1:
+                raise OnnxFormatError(f"Conv node {nd.name!r}: pads {pads} do not keep the sequence length (kernel {k})")
+        elif k == 1:
+            left = 0
+        else:
+            raise OnnxFormatError(f"Conv node {nd.name!r}: 'valid' padding is not the DeepCNN architecture")
+        bias = None
+        if len(nd.inputs) >= 3 and nd.inputs[2] in const:
+            bias = np.asarray(const[nd.inputs[2]], np.float32).reshape(-1)
+        else:
+            for c in consumers.get(nd.outputs[0], []):
+                if c.op_type == "Add":
+                    other = [i for i in c.inputs if i != nd.outputs[0]]
+                    if len(other) == 1 and other[0] in const and const[other[0]].size == K.shape[0]:
+                        bias = np.asarray(const[other[0]], np.float32).reshape(-1)
+        b += 1
+        w[f"cnn_W{b}"] = np.ascontiguousarray(K3.transpose(2, 1, 0))     # ONNX (F, C, k) -> Keras (k, C, F)
+        w[f"cnn_b{b}"] = bias if bias is not None else np.zeros(K.shape[0], np.float32)
+        w[f"cnn_pad{b}"] = np.array([left], dtype=np.float32)
+    C = sum(w[f"cnn_b{j}"].shape[0] for j in range(1, b + 1))
+    bns = [nd for nd in g.nodes if nd.op_type == "BatchNormalization"]
+    if len(bns) != 1 or any(i not in const for i in bns[0].inputs[1:5]):
+        raise OnnxFormatError(f"expected one BatchNormalization node with constant parameters, found {len(bns)}")
+    gamma, beta, mean, var = (np.asarray(const[i], np.float32).reshape(-1) for i in bns[0].inputs[1:5])
+    if gamma.size != C:
+        raise OnnxFormatError(f"BatchNormalization over {gamma.size} channels, the Conv branches have {C}")
+    w["bn_gamma"], w["bn_beta"], w["bn_mean"], w["bn_var"] = gamma, beta, mean, var
+    w["bn_eps"] = np.array([bns[0].attrs.get("epsilon", 1e-5)], dtype=np.float32)      # ONNX default 1e-5
+    dense = [(W, bias) for W, bias, _ in _dense_layers(g, const) if W.shape[0] == C]
+    if len(dense) != 1 or dense[0][1] is None or dense[0][0].shape[1] % 2:
+        raise OnnxFormatError(f"expected one FuncPredictor Dense ({C}, 2T) with bias, found {[d[0].shape for d in dense]}")
+    w["W_out"], w["b_out"] = dense[0]
+    return {k_: np.ascontiguousarray(v, dtype=np.float32) for k_, v in w.items()}
+
+
+def extract_weights(g: Graph) -> dict:
+    """CNN or GCN weight dict, decided by the presence of Conv nodes."""
+    return extract_cnn_weights(g) if any(nd.op_type == "Conv" for nd in g.nodes) else extract_gcn_weights(g)
+
+
 def load_onnx_weights(path: str) -> dict:
     from . import weights as _weights
-    w = extract_gcn_weights(parse_model(path))
+    w = extract_weights(parse_model(path))
     _weights.validate(w)
     return w
 

@@ -41,19 +41,20 @@ class _Session:
         def __init__(self, name):
             self.name = name
 
-    def __init__(self, handle, topology, lm=None):
+    def __init__(self, handle, topology, lm=None, kind="gcn"):
         self.handle = handle
         self.topology = topology
         self.lm = lm  # LanguageModel the handle points at (kept alive here), or None
+        self.kind = kind  # "gcn": mdf_model (inputs cmap, seq);  "cnn": mdf_cnn (input seq only, predict.pyx:91-95)
 
     def get_inputs(self):
-        return [self._Input("cmap"), self._Input("seq")]
+        return [self._Input("seq")] if self.kind == "cnn" else [self._Input("cmap"), self._Input("seq")]
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
         if h:
             try:
-                _hip.lib().mdf_model_free(h)
+                (_hip.lib().mdf_cnn_free if self.kind == "cnn" else _hip.lib().mdf_model_free)(h)
             except Exception:
                 pass
 
@@ -117,6 +118,36 @@ def create_model_handle(weights: dict, device: int = 0):
     return handle, topo
 
 
+def create_cnn_handle(weights: dict, device: int = 0):
+    """CNN weight dict (see mDeepFRI.weights) -> (mdf_cnn* as c_void_p, topology)."""
+    topo = _weights.validate_cnn(weights)
+    n = len(topo["filters"])
+    fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))  # noqa: E731
+    keep = []
+
+    def f32(key):
+        a = np.ascontiguousarray(weights[key], dtype=np.float32)
+        keep.append(a)
+        return a
+
+    s = _hip.CnnWeights()
+    s.n_branch = n
+    klen = (ctypes.c_int32 * n)(*topo["kernel_lens"])
+    filt = (ctypes.c_int32 * n)(*topo["filters"])
+    pads = (ctypes.c_int32 * n)(*[int(np.asarray(weights.get(f"cnn_pad{b + 1}", (topo["kernel_lens"][b] - 1) // 2)).reshape(-1)[0])
+                                  for b in range(n)])
+    Ws = (ctypes.POINTER(ctypes.c_float) * n)(*[fp(f32(f"cnn_W{b + 1}")) for b in range(n)])
+    bs = (ctypes.POINTER(ctypes.c_float) * n)(*[fp(f32(f"cnn_b{b + 1}")) for b in range(n)])
+    s.kernel_len, s.filters, s.pad_left, s.W, s.b = klen, filt, pads, Ws, bs
+    s.bn_gamma, s.bn_beta, s.bn_mean, s.bn_var = fp(f32("bn_gamma")), fp(f32("bn_beta")), fp(f32("bn_mean")), fp(f32("bn_var"))
+    s.bn_eps = float(np.asarray(weights.get("bn_eps", 1e-3)).reshape(-1)[0])
+    s.n_terms = topo["n_terms"]
+    s.W_out, s.b_out = fp(f32("W_out")), fp(f32("b_out"))
+    handle = ctypes.c_void_p()
+    _hip.check(_hip.lib().mdf_cnn_create(ctypes.byref(s), int(device), ctypes.byref(handle)))
+    return handle, topo
+
+
 class Predictor(object):
     """reference predict.pyx:50-102.  Public attributes as there: model_path, threads, session, input_names.
 
@@ -138,18 +169,23 @@ class Predictor(object):
     def _load_model(self):
         L = _hip.lib()
         w = self._weights
+        if w is None:
+            path = _weights.resolve_model_path(self.model_path)
+            if not (path.endswith(".mdfw") and "cnn_W1" not in _weights.mdfw_names(path)):
+                w = _weights.load_weights(path)
+        if w is not None and _weights.model_kind(w) == "cnn":   # sequence-only model (reference pipeline.py:600-648)
+            handle, topo = create_cnn_handle(w, self.device)
+            self.session = _Session(handle, {"n_terms": topo["n_terms"], "feature_dim": topo["channels"], "lm_dim": 0}, None, "cnn")
+            self.input_names = [node.name for node in self.session.get_inputs()]
+            self._weights = None
+            return
         if w is not None:
             handle, _ = create_model_handle(w, self.device)
-        else:
-            path = _weights.resolve_model_path(self.model_path)
-            if path.endswith(".mdfw"):  # native container: read by the library itself
-                handle = ctypes.c_void_p()
-                _hip.check(L.mdf_model_load(path.encode(), self.device, ctypes.byref(handle)))
-                if L.mdf_model_lm_dim(handle) > 0:
-                    w = _weights.load_mdfw(path)  # the language-model tensors are uploaded from here
-            else:
-                w = _weights.load_weights(path)
-                handle, _ = create_model_handle(w, self.device)
+        else:  # native GCN container: read by the library itself
+            handle = ctypes.c_void_p()
+            _hip.check(L.mdf_model_load(path.encode(), self.device, ctypes.byref(handle)))
+            if L.mdf_model_lm_dim(handle) > 0:
+                w = _weights.load_mdfw(path)  # the language-model tensors are uploaded from here
         topo = {"n_terms": int(L.mdf_model_num_terms(handle)), "feature_dim": int(L.mdf_model_feature_dim(handle)),
                 "lm_dim": int(L.mdf_model_lm_dim(handle))}
         lm = None
@@ -166,14 +202,26 @@ class Predictor(object):
 
     def forward_pass(self, seqres: str, cmap=None) -> np.ndarray:
         """reference predict.pyx:75-102, GCN branch: float32 (T,) = softmax(...)[:, :, 0].reshape(-1)."""
-        if cmap is None:
-            raise NotImplementedError(
-                "sequence-only (CNN) models are outside this build's hot path (SURVEY.md section 8f row 2); "
-                "pass the contact map")
         if not isinstance(seqres, str):
             raise TypeError("seqres must be str")
         b = seqres.encode("ascii")
         L = len(b)
+        if self.session.kind == "cnn":
+            # reference predict.pyx:91-95: the one-hot sequence is the only input of the DeepCNN session
+            if cmap is not None:
+                raise ValueError("this is a sequence-only (CNN) model: it takes no contact map")
+            if L == 0:
+                raise ValueError("empty sequence")
+            scores = np.empty((self.n_terms,), dtype=np.float32)
+            bad = _hip.c_int64(-1)
+            rc = _hip.lib().mdf_cnn_forward_host(self.session.handle, b, L, _hip.ptr(scores), bad)
+            if rc == _hip.MDF_EBADCHAR:
+                raise ValueError(f"Invalid character in sequence: {seqres[bad.value]}")
+            _hip.check(rc)
+            return scores
+        if cmap is None:
+            raise ValueError("this is a GCN model (inputs cmap, seq): pass the contact map; sequence-only prediction needs a "
+                             "DeepCNN model file")
         A = np.asarray(cmap)
         if A.ndim != 2 or A.shape != (L, L):
             raise ValueError(f"cmap has shape {A.shape}, expected ({L}, {L}) for a sequence of length {L}")

@@ -100,6 +100,27 @@ def glorot_lm_weights(seed: int = 1000, hidden: int = 512, embed: int = 1024) ->
     return w
 
 
+def glorot_cnn_weights(seed: int = 0, n_terms: int = 489, filters=(120, 100, 80, 60), kernel_lens=(5, 10, 15, 20)) -> dict:
+    """Random-init sequence-only DeepCNN weights (upstream DeepCNN defaults: four parallel Conv1D branches over the one-hot
+    sequence, BatchNorm with non-trivial moving statistics, FuncPredictor).  Keys as mDeepFRI.weights."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for b, (F, k) in enumerate(zip(filters, kernel_lens), start=1):
+        lim = np.sqrt(6.0 / (k * 26 + k * F))
+        w[f"cnn_W{b}"] = rng.uniform(-lim, lim, size=(k, 26, F)).astype(np.float32)
+        w[f"cnn_b{b}"] = rng.uniform(-0.05, 0.05, size=(F,)).astype(np.float32)
+    C = int(sum(filters))
+    w["bn_gamma"] = rng.uniform(0.5, 1.5, size=(C,)).astype(np.float32)
+    w["bn_gamma"][::7] *= -1.0                       # negative scales happen in trained models; max-pool must see them after BN
+    w["bn_beta"] = rng.uniform(-0.2, 0.2, size=(C,)).astype(np.float32)
+    w["bn_mean"] = rng.uniform(-0.1, 0.1, size=(C,)).astype(np.float32)
+    w["bn_var"] = rng.uniform(0.01, 0.2, size=(C,)).astype(np.float32)
+    w["bn_eps"] = np.array([1e-3], dtype=np.float32)
+    w["W_out"] = glorot_uniform(rng, C, 2 * n_terms)
+    w["b_out"] = rng.uniform(-0.05, 0.05, size=(2 * n_terms,)).astype(np.float32)
+    return w
+
+
 def synthetic_proteins(seed: int, count: int, length, indel_rate: float = 0.0):
     """List of dicts {id, seq, coords, q_aln, t_aln}.  `length` is an int or a (lo, hi) inclusive range."""
     rng = np.random.default_rng(seed)

@@ -10,6 +10,9 @@ Tensor names: W_aa (26,E)  W_gc1 (E,C1)  W_gc2 (C1,C2)  W_gc3 (C2,C3)  W_fc (C1+
               W_out (F,2T)  b_out (2T)        -- Keras orientation (in_features, out_features).
 Optional language-model branch (the released models have it), Keras orientation and gate
 order i,f,c,o:  W_lm (H,E)  b_lm (E)  lm_W1 (26,4H)  lm_U1 (H,4H)  lm_b1 (4H)  lm_W2 (H,4H)  lm_U2 (H,4H)  lm_b2 (4H).
+Sequence-only CNN models (`DeepCNN-MERGED_{mode}`, reference __init__.py:68; run when cmap is None, predict.pyx:91-95) use
+another key set: cnn_W{b} (k_b,26,F_b)  cnn_b{b} (F_b)  [cnn_pad{b} scalar]  bn_gamma/bn_beta/bn_mean/bn_var (sum F_b)
+bn_eps (1)  W_out (sum F_b, 2T)  b_out (2T);  `model_kind(weights)` tells the two apart.
 `.npz` files with the same keys are accepted too.
 
 `.onnx` files (what the reference's pipeline passes, pipeline.py:549-584) are read by mDeepFRI.onnx_reader -- a
@@ -33,7 +36,7 @@ _ENTRY = struct.Struct("<32sI4QQ")
 
 
 def save_mdfw(path: str, weights: dict) -> None:
-    names = [k for k in ORDER if k in weights]
+    names = [k for k in ORDER if k in weights] + sorted(k for k in weights if k not in ORDER)
     arrays = [np.ascontiguousarray(weights[k], dtype="<f4") for k in names]
     head = len(MAGIC) + 4 + _ENTRY.size * len(names)
     offsets, off = [], (head + 63) // 64 * 64
@@ -51,6 +54,17 @@ def save_mdfw(path: str, weights: dict) -> None:
             f.write(a.tobytes())
 
 
+def mdfw_names(path: str) -> list:
+    """Tensor names of a .mdfw container (directory only)."""
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if head[:8] != MAGIC:
+            raise OSError(f"{path} is not an MDFW0001 container")
+        (n,) = struct.unpack_from("<I", head, 8)
+        d = f.read(n * _ENTRY.size)
+    return [_ENTRY.unpack_from(d, i * _ENTRY.size)[0].rstrip(b"\0").decode() for i in range(n)]
+
+
 def load_mdfw(path: str) -> dict:
     with open(path, "rb") as f:
         buf = f.read()
@@ -66,9 +80,39 @@ def load_mdfw(path: str) -> dict:
     return out
 
 
-def validate(weights: dict) -> dict:
-    """Check shapes and return the topology {embed, gc_dims, fc_dim, n_terms}."""
+def model_kind(weights: dict) -> str:
+    """"cnn" for a sequence-only DeepCNN weight set, "gcn" otherwise."""
+    return "cnn" if "cnn_W1" in weights else "gcn"
+
+
+def validate_cnn(weights: dict) -> dict:
+    """Check a CNN weight set and return {kind, kernel_lens, filters, channels, n_terms}."""
     w = weights
+    ks, fs, b = [], [], 1
+    while f"cnn_W{b}" in w:
+        W = w[f"cnn_W{b}"]
+        if W.ndim != 3 or W.shape[1] != 26:
+            raise ValueError(f"weights: cnn_W{b} must be (kernel_len, 26, filters), got {tuple(W.shape)}")
+        if f"cnn_b{b}" not in w or tuple(w[f"cnn_b{b}"].shape) != (W.shape[2],):
+            raise ValueError(f"weights: cnn_b{b} missing or not ({W.shape[2]},)")
+        ks.append(int(W.shape[0]))
+        fs.append(int(W.shape[2]))
+        b += 1
+    C = sum(fs)
+    for k in ("bn_gamma", "bn_beta", "bn_mean", "bn_var"):
+        if k not in w or tuple(w[k].shape) != (C,):
+            raise ValueError(f"weights: {k} missing or not ({C},)")
+    if "W_out" not in w or "b_out" not in w or w["W_out"].ndim != 2 or w["W_out"].shape[0] != C or w["W_out"].shape[1] % 2 \
+            or tuple(w["b_out"].shape) != (w["W_out"].shape[1],):
+        raise ValueError("weights: W_out / b_out shape mismatch")
+    return {"kind": "cnn", "kernel_lens": ks, "filters": fs, "channels": C, "n_terms": int(w["W_out"].shape[1] // 2)}
+
+
+def validate(weights: dict) -> dict:
+    """Check shapes and return the topology {embed, gc_dims, fc_dim, n_terms, lm_dim} (GCN) -- or validate_cnn's for a CNN."""
+    w = weights
+    if model_kind(w) == "cnn":
+        return validate_cnn(w)
     for k in ("W_aa", "W_gc1", "W_fc", "b_fc", "W_out", "b_out"):
         if k not in w:
             raise ValueError(f"weights: missing tensor {k}")
@@ -131,7 +175,7 @@ def load_weights(model_path: str) -> dict:
             w = {k: np.asarray(z[k], dtype=np.float32) for k in z.files}
     elif p.endswith(".onnx"):
         from . import onnx_reader
-        w = onnx_reader.extract_gcn_weights(onnx_reader.parse_model(p))
+        w = onnx_reader.extract_weights(onnx_reader.parse_model(p))
     else:
         w = load_mdfw(p)
     validate(w)

@@ -173,3 +173,38 @@ def deepfri_gcn_model(w: dict, raw=True, use_gemm_head=False) -> bytes:
     z = b.node("Reshape", [z, b.const(np.array([-1, w["W_out"].shape[1] // 2, 2], np.int64), "shape", raw)])
     b.output(b.node("Softmax", [z], axis=-1))
     return b.serialize()
+
+
+def deepcnn_model(w: dict, conv2d_form=False, explicit_pads=False) -> bytes:
+    """An ONNX graph with the op sequence tf2onnx emits for the sequence-only DeepCNN (parallel Conv1D branches over the
+    one-hot sequence, concat, BatchNormalization, relu, global max pool, FuncPredictor).  conv2d_form: kernels as (F,C,1,k)
+    the way tf2onnx lowers Conv1D through Conv2D; explicit_pads: `pads` attribute instead of auto_pad=SAME_UPPER."""
+    b = GraphBuilder()
+    seq = b.input("seq")
+    x = b.node("Transpose", [seq], perm=[0, 2, 1])
+    if conv2d_form:
+        x = b.node("Unsqueeze", [x, b.const(np.array([2], np.int64), "axes")])
+    branches, k = [], 1
+    while f"cnn_W{k}" in w:
+        W = w[f"cnn_W{k}"].transpose(2, 1, 0)                       # Keras (k, C, F) -> ONNX (F, C, k)
+        klen = W.shape[2]
+        left = int(np.asarray(w.get(f"cnn_pad{k}", (klen - 1) // 2)).reshape(-1)[0])
+        if conv2d_form:
+            W = W[:, :, None, :]
+        attrs = {"kernel_shape": ([1, klen] if conv2d_form else [klen])}
+        if explicit_pads:
+            attrs["pads"] = [0, left, 0, klen - 1 - left] if conv2d_form else [left, klen - 1 - left]
+        else:
+            attrs["auto_pad"] = b"SAME_UPPER"
+        branches.append(b.node("Conv", [x, b.const(np.ascontiguousarray(W), f"conv1d_{k}/kernel"), b.const(w[f"cnn_b{k}"], f"conv1d_{k}/bias")], **attrs))
+        k += 1
+    cat = b.node("Concat", branches, axis=1)
+    bn = b.node("BatchNormalization", [cat, b.const(w["bn_gamma"], "bn/gamma"), b.const(w["bn_beta"], "bn/beta"),
+                                       b.const(w["bn_mean"], "bn/mean"), b.const(w["bn_var"], "bn/var")],
+                epsilon=float(np.asarray(w["bn_eps"]).reshape(-1)[0]))
+    pooled = b.node("GlobalMaxPool", [b.node("Relu", [bn])])
+    pooled = b.node("Flatten", [pooled], axis=1)
+    z = b.node("Add", [b.node("MatMul", [pooled, b.const(w["W_out"], "labels/kernel")]), b.const(w["b_out"], "labels/bias")])
+    z = b.node("Reshape", [z, b.const(np.array([-1, w["W_out"].shape[1] // 2, 2], np.int64), "shape")])
+    b.output(b.node("Softmax", [z], axis=-1))
+    return b.serialize()

@@ -87,3 +87,22 @@ def test_lstm_gate_reorder_matches_oracle_semantics():
         h = o * np.tanh(c)
         ref.append(h)
     np.testing.assert_allclose(lm_oracle.lstm_forward(x, Wk, Uk, bk), np.array(ref), atol=1e-6)
+
+
+@pytest.mark.parametrize("conv2d_form", [False, True])
+@pytest.mark.parametrize("explicit_pads", [False, True])
+def test_extracts_the_sequence_only_cnn(conv2d_form, explicit_pads):
+    from mDeepFRI import onnx_reader, synthetic, weights
+    w = synthetic.glorot_cnn_weights(seed=4, n_terms=9)
+    if explicit_pads:
+        w["cnn_pad3"] = np.array([9], dtype=np.float32)      # a non-default split of the 14 padding zeros of kernel 15
+    g = onnx_reader.parse_model(onnx_writer.deepcnn_model(w, conv2d_form=conv2d_form, explicit_pads=explicit_pads))
+    assert g.inputs == ["seq"]
+    got = onnx_reader.extract_weights(g)
+    topo = weights.validate(got)
+    assert topo["kind"] == "cnn" and topo["kernel_lens"] == [5, 10, 15, 20] and topo["filters"] == [120, 100, 80, 60]
+    for k in w:
+        np.testing.assert_array_equal(got[k].reshape(-1), np.asarray(w[k], np.float32).reshape(-1), err_msg=k)
+    for b, klen in enumerate((5, 10, 15, 20), start=1):
+        want = w.get(f"cnn_pad{b}", [(klen - 1) // 2])
+        assert int(got[f"cnn_pad{b}"][0]) == int(np.asarray(want).reshape(-1)[0])
