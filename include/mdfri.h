@@ -192,9 +192,9 @@ int mdf_cnn_channels(const mdf_cnn *m);
 /* One protein, host buffers (the per-call shape of predict.pyx:75-102).  scores: (T) f32. */
 int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, int64_t *bad_idx);
 /* B proteins in residue-row layout (see below): seq_idx (R) from mdf_seq_encode_dev, Lq / row_off device int32.
- * scores: (B, T) f32.  workspace: mdf_cnn_workspace_bytes(m, B). */
-size_t mdf_cnn_workspace_bytes(const mdf_cnn *m, int32_t B);
-int mdf_cnn_forward_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, const int32_t *row_off, int32_t B,
+ * R = row_off[B] (total rows).  scores: (B, T) f32.  workspace: mdf_cnn_workspace_bytes(m, B, R). */
+size_t mdf_cnn_workspace_bytes(const mdf_cnn *m, int32_t B, int64_t R);
+int mdf_cnn_forward_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
                         float *scores, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

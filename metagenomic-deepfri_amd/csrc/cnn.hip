@@ -13,6 +13,7 @@
 // gcn.hip.  Arithmetic fp32; oracle: oracle/cnn_oracle.py (parity unpinned, see its header).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -26,6 +27,7 @@ struct CnnTile {
 
 struct mdf_cnn {
     int device = 0, n_branch = 0, C = 0, Cpad = 0, T = 0, n_out_pad = 0, n_tiles = 0;
+    int n_lds_tiles = 0, lds_bytes = 0;   // tiles [0, n_lds_tiles) run through k_cnn_conv_pool_lds (longest kernels first)
     std::vector<float *> W;          // per branch, device
     mdf::CnnTile *tiles = nullptr;   // device
     float *bias = nullptr, *scale = nullptr, *shift = nullptr;   // (C) conv bias, folded BatchNorm
@@ -66,6 +68,88 @@ __global__ __launch_bounds__(256) void k_cnn_conv_pool(const uint8_t *__restrict
     red[w][lane] = best;
     __syncthreads();
     if (w == 0 && live) pooled[(size_t)p * Cpad + t.ch0 + lane] = fmaxf(fmaxf(red[0][lane], red[1][lane]), fmaxf(red[2][lane], red[3][lane]));
+}
+
+// The same computation with the tile's table staged in LDS: (k, 27, 64) floats (row 26 = zeros for positions outside the
+// sequence), loaded once per workgroup of 16 waves, which then walks work items.  A work item is one 32-row group of the
+// residue-row layout (row_off is 32-aligned, so a group belongs to one protein: k_cnn_group_owner): lane i holds the byte
+// offset of the table row of the letter at window position i (32 + k - 1 <= 64 letters); a tap's offset reaches the scalar
+// unit through v_readlane and selects one conflict-free 256-byte LDS row.  The running max of a group is merged into
+// pooled with an integer atomicMax (the values are >= 0, where float order = int order; max is order-independent, so the
+// result is deterministic).  The L1/L2 form above moves the same rows through the vector cache (7 TB/s measured, the
+// bound of that kernel); here the limit is VALU issue (readlane + address add + accumulate per tap).  k <= CNN_LDS_MAX_K.
+constexpr int CNN_LDS_MAX_K = 21;   // 21 * 27 * 64 * 4 B = 145 KiB of the 160 KiB LDS
+constexpr int CNN_LDS_THREADS = 1024;
+
+__global__ void k_cnn_group_owner(const int32_t *__restrict__ Lq, const int32_t *__restrict__ row_off, int B, int32_t *__restrict__ owner)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    const int g0 = row_off[p] >> 5, g1 = (row_off[p] + Lq[p] + 31) >> 5;
+    for (int g = g0; g < g1; ++g) owner[g] = p;
+}
+
+__global__ __launch_bounds__(CNN_LDS_THREADS) void k_cnn_conv_pool_lds(const uint8_t *__restrict__ seq_idx, const int32_t *__restrict__ Lq,
+                                                                       const int32_t *__restrict__ row_off,
+                                                                       const int32_t *__restrict__ owner, int n_groups,
+                                                                       const CnnTile *__restrict__ tiles, const float *__restrict__ bias,
+                                                                       const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                       float *__restrict__ pooled, int Cpad)
+{
+    extern __shared__ __attribute__((aligned(16))) float tab[];   // [k][27][64]
+    const CnnTile t = tiles[blockIdx.y];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < t.k * 27 * 64; i += CNN_LDS_THREADS) {
+        const int c = i & 63, ja = i >> 6, j = ja / 27, a = ja - j * 27;
+        tab[i] = (a < 26 && t.f0 + c < t.F) ? t.W[(size_t)(j * 32 + a) * t.F + t.f0 + c] : 0.0f;
+    }
+    __syncthreads();
+    const bool live = t.f0 + lane < t.F;
+    const int cc = t.ch0 + (live ? lane : 0);
+    const float b = bias[cc], sc = scale[cc], sh = shift[cc];
+    const char *tl = reinterpret_cast<const char *>(tab + lane);
+    constexpr int WAVES = CNN_LDS_THREADS / 64;
+    for (int g = blockIdx.x * WAVES + w; g < n_groups; g += gridDim.x * WAVES) {
+        const int p = owner[g];
+        if (p < 0) continue;
+        const int r0 = row_off[p], L = Lq[p], q0 = g * 32 - r0;
+        const uint8_t *s = seq_idx + r0;
+        const int qi = q0 - t.left + lane;
+        int aoff = 26 * 256;                                      // byte offset of the letter's row inside a tap's 27 rows
+        if (qi >= 0 && qi < L) aoff = min((int)s[qi], 26) * 256;
+        const int np = min(32, L - q0);
+        float best = 0.0f;
+        // four residues at a time, four taps at a time: 16 independent LDS reads in flight per wave
+#define MDF_TAP(P, J) (*reinterpret_cast<const float *>(tl + (J) * (27 * 256) + __builtin_amdgcn_readlane(aoff, (P) + (J))))
+        for (int pp = 0; pp < np; pp += 4) {
+            float acc0 = b, acc1 = b, acc2 = b, acc3 = b;
+            int j = 0;
+            for (; j + 4 <= t.k; j += 4) {
+                const float v00 = MDF_TAP(pp, j), v01 = MDF_TAP(pp, j + 1), v02 = MDF_TAP(pp, j + 2), v03 = MDF_TAP(pp, j + 3);
+                const float v10 = MDF_TAP(pp + 1, j), v11 = MDF_TAP(pp + 1, j + 1), v12 = MDF_TAP(pp + 1, j + 2), v13 = MDF_TAP(pp + 1, j + 3);
+                const float v20 = MDF_TAP(pp + 2, j), v21 = MDF_TAP(pp + 2, j + 1), v22 = MDF_TAP(pp + 2, j + 2), v23 = MDF_TAP(pp + 2, j + 3);
+                const float v30 = MDF_TAP(pp + 3, j), v31 = MDF_TAP(pp + 3, j + 1), v32 = MDF_TAP(pp + 3, j + 2), v33 = MDF_TAP(pp + 3, j + 3);
+                acc0 = (((acc0 + v00) + v01) + v02) + v03;
+                acc1 = (((acc1 + v10) + v11) + v12) + v13;
+                acc2 = (((acc2 + v20) + v21) + v22) + v23;
+                acc3 = (((acc3 + v30) + v31) + v32) + v33;
+            }
+            for (; j < t.k; ++j) {
+                acc0 += MDF_TAP(pp, j);
+                acc1 += MDF_TAP(pp + 1, j);
+                acc2 += MDF_TAP(pp + 2, j);
+                acc3 += MDF_TAP(pp + 3, j);
+            }
+            // residues pp+1.. may lie past the end of the protein (np is not a multiple of 4): computed on in-window
+            // letters, not counted
+            best = fmaxf(best, acc0 * sc + sh);
+            if (pp + 1 < np) best = fmaxf(best, acc1 * sc + sh);
+            if (pp + 2 < np) best = fmaxf(best, acc2 * sc + sh);
+            if (pp + 3 < np) best = fmaxf(best, acc3 * sc + sh);
+        }
+#undef MDF_TAP
+        if (live && best > 0.0f) atomicMax(reinterpret_cast<int *>(pooled + (size_t)p * Cpad + t.ch0 + lane), __float_as_int(best));
+    }
 }
 
 static int upload_f(float **dst, const float *src, size_t count)
@@ -125,6 +209,16 @@ int mdf_cnn_create(const mdf_cnn_weights *w, int device, mdf_cnn **out)
         scale[c] = (float)sc;
         shift[c] = (float)((double)w->bn_beta[c] - (double)w->bn_mean[c] * sc);
     }
+    // LDS-staged tiles first, longest kernel first (they are dispatched first and take longest); the rest use the cache form
+    std::stable_sort(tiles.begin(), tiles.end(), [](const CnnTile &a, const CnnTile &b) {
+        const bool la = a.k <= CNN_LDS_MAX_K, lb = b.k <= CNN_LDS_MAX_K;
+        return la != lb ? la : (la ? a.k > b.k : false);
+    });
+    for (const CnnTile &t : tiles)
+        if (t.k <= CNN_LDS_MAX_K) {
+            ++m->n_lds_tiles;
+            m->lds_bytes = std::max(m->lds_bytes, t.k * 27 * 64 * 4);
+        }
     m->n_tiles = (int)tiles.size();
     if (rc == MDF_OK && hipMalloc(reinterpret_cast<void **>(&m->tiles), tiles.size() * sizeof(CnnTile)) != hipSuccess) rc = fail(MDF_ENOMEM, "cnn_create: out of device memory");
     if (rc == MDF_OK && hipMemcpy(m->tiles, tiles.data(), tiles.size() * sizeof(CnnTile), hipMemcpyHostToDevice) != hipSuccess) rc = fail(MDF_ENODEVICE, "cnn_create: upload failed");
@@ -167,22 +261,47 @@ void mdf_cnn_free(mdf_cnn *m)
 int mdf_cnn_num_terms(const mdf_cnn *m) { return m ? m->T : fail(MDF_EINVAL, "cnn is NULL"); }
 int mdf_cnn_channels(const mdf_cnn *m) { return m ? m->C : fail(MDF_EINVAL, "cnn is NULL"); }
 
-size_t mdf_cnn_workspace_bytes(const mdf_cnn *m, int32_t B) { return m && B > 0 ? align_up((size_t)B * m->Cpad * 4, 256) + 256 : 0; }
+size_t mdf_cnn_workspace_bytes(const mdf_cnn *m, int32_t B, int64_t R)
+{
+    return m && B > 0 && R > 0 ? align_up((size_t)B * m->Cpad * 4, 256) + align_up((size_t)(R / 32 + 1) * 4, 256) + 256 : 0;
+}
 
-int mdf_cnn_forward_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, const int32_t *row_off, int32_t B, float *scores,
-                        void *workspace, size_t workspace_bytes, void *stream)
+int mdf_cnn_forward_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                        float *scores, void *workspace, size_t workspace_bytes, void *stream)
 {
     MDF_REQUIRE(m && seq_idx && Lq && row_off && scores && workspace, "cnn_forward_dev: NULL argument");
-    MDF_REQUIRE(B > 0, "cnn_forward_dev: B=%d", B);
-    if (workspace_bytes < mdf_cnn_workspace_bytes(m, B)) return fail(MDF_ECAPACITY, "cnn_forward_dev: workspace too small");
+    MDF_REQUIRE(B > 0 && R > 0 && R % 32 == 0 && R < 0x7fffffff, "cnn_forward_dev: B=%d R=%lld", B, (long long)R);
+    if (workspace_bytes < mdf_cnn_workspace_bytes(m, B, R)) return fail(MDF_ECAPACITY, "cnn_forward_dev: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    float *pooled = static_cast<float *>(workspace);
-    MDF_HIP(hipMemsetAsync(pooled, 0, (size_t)B * m->Cpad * 4, st));   // channels C..Cpad stay zero
+    Carver cv(workspace, workspace_bytes);
+    float *pooled = cv.take<float>((size_t)B * m->Cpad);
+    int32_t *owner = cv.take<int32_t>((size_t)(R / 32));
+    const int n_groups = (int)(R / 32);
+    MDF_HIP(hipMemsetAsync(pooled, 0, (size_t)B * m->Cpad * 4, st));   // relu floor; channels C..Cpad stay zero
     {
         ScopedTiming tm(TK_CNN, st);
-        hipLaunchKernelGGL(k_cnn_conv_pool, dim3((unsigned)B, (unsigned)m->n_tiles), dim3(256), 0, st, seq_idx, Lq, row_off, m->tiles,
-                           m->bias, m->scale, m->shift, pooled, m->Cpad);
-        MDF_HIP(hipGetLastError());
+        static const bool no_lds = getenv("MDFRI_CNN_NO_LDS") != nullptr;   // developer knob: force the cache form
+        const int n_lds = no_lds ? 0 : m->n_lds_tiles;
+        if (n_lds > 0) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cnn_conv_pool_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            CNN_LDS_MAX_K * 27 * 64 * 4));
+                attr_done = true;
+            }
+            MDF_HIP(hipMemsetAsync(owner, 0xff, (size_t)n_groups * 4, st));   // -1: group belongs to no protein
+            hipLaunchKernelGGL(k_cnn_group_owner, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, Lq, row_off, B, owner);
+            // workgroups per tile: each keeps the table in LDS and walks 32-row groups, 16 at a time
+            const int wgs = std::max(1, std::min((n_groups + 63) / 64, 256));
+            hipLaunchKernelGGL(k_cnn_conv_pool_lds, dim3((unsigned)wgs, (unsigned)n_lds), dim3(CNN_LDS_THREADS), (size_t)m->lds_bytes, st, seq_idx,
+                               Lq, row_off, owner, n_groups, m->tiles, m->bias, m->scale, m->shift, pooled, m->Cpad);
+            MDF_HIP(hipGetLastError());
+        }
+        if (m->n_tiles > n_lds) {
+            hipLaunchKernelGGL(k_cnn_conv_pool, dim3((unsigned)B, (unsigned)(m->n_tiles - n_lds)), dim3(256), 0, st, seq_idx, Lq, row_off,
+                               m->tiles + n_lds, m->bias, m->scale, m->shift, pooled, m->Cpad);
+            MDF_HIP(hipGetLastError());
+        }
     }
     ScopedTiming tm(TK_HEAD, st);
     return launch_head_softmax2(pooled, m->Cpad, m->Wout_t, m->Cpad, B, m->n_out_pad, m->Cpad, scores, m->T, m->bout, st);
@@ -198,7 +317,7 @@ int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, 
     int32_t Lq[1] = {(int32_t)L}, row_off[2];
     const int64_t R = mdf_layout_rows(Lq, 1, row_off);
     if (R < 0) return (int)R;
-    const size_t ws = mdf_cnn_workspace_bytes(m, 1);
+    const size_t ws = mdf_cnn_workspace_bytes(m, 1, R);
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
     const size_t o_desc = take(256), o_seq = take((size_t)L), o_idx = take((size_t)R), o_ws = take(ws), o_sc = take((size_t)m->T * 4);
@@ -223,7 +342,7 @@ int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, 
     uint8_t *d_idx = reinterpret_cast<uint8_t *>(b + o_idx);
     float *d_sc = reinterpret_cast<float *>(b + o_sc);
     if (int rc = mdf_seq_encode_dev(b + o_seq, dd->seq_off, dd->Lq, dd->row_off, 1, R, d_idx, dd->bad, nullptr)) return rc;
-    if (int rc = mdf_cnn_forward_dev(m, d_idx, dd->Lq, dd->row_off, 1, d_sc, b + o_ws, ws, nullptr)) return rc;
+    if (int rc = mdf_cnn_forward_dev(m, d_idx, dd->Lq, dd->row_off, 1, R, d_sc, b + o_ws, ws, nullptr)) return rc;
     Desc back;
     MDF_HIP(hipMemcpy(&back, b + o_desc, sizeof(back), hipMemcpyDeviceToHost));
     if (back.bad[0] != 0) {

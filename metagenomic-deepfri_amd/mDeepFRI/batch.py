@@ -573,7 +573,7 @@ class SequenceEngine:
             rows = pk.max_chunk_rows
             nmax = max(ch.p1 - ch.p0 for ch in pk.chunks)
             seq_idx = torch.empty(rows, dtype=torch.uint8, device=self.device)
-            ws = torch.empty(max(self.L.mdf_cnn_workspace_bytes(p.session.handle, nmax) for p in self.predictors.values()),
+            ws = torch.empty(max(self.L.mdf_cnn_workspace_bytes(p.session.handle, nmax, rows) for p in self.predictors.values()),
                              dtype=torch.uint8, device=self.device)
             out = {m: torch.empty((db.B, p.n_terms), dtype=torch.float32, device=self.device) for m, p in self.predictors.items()}
             for ci, ch in enumerate(pk.chunks):
@@ -582,7 +582,7 @@ class SequenceEngine:
                 _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
                                                      _p(seq_idx), _p(db.bad, ci * 2), st))
                 for m, p in self.predictors.items():
-                    _hip.check(self.L.mdf_cnn_forward_dev(p.session.handle, _p(seq_idx), _p(db.Lq, ch.p0), ro, Bc,
+                    _hip.check(self.L.mdf_cnn_forward_dev(p.session.handle, _p(seq_idx), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
                                                           _p(out[m], ch.p0 * p.n_terms), _p(ws), ws.numel(), st))
             self._keep = (seq_idx, ws)
             return out
