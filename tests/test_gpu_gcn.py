@@ -31,7 +31,7 @@ def test_predictor_public_surface(mf):
     _, pred = mf
     assert pred.model_path == "synthetic-mf.onnx" and pred.threads == 1
     assert pred.input_names == ["cmap", "seq"] and pred.session is not None
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="pass the contact map"):   # a GCN file has two inputs; sequence-only needs a DeepCNN file
         pred.forward_pass("ACD")
     with pytest.raises(ValueError, match="Invalid character in sequence: J"):
         pred.forward_pass("AJD", np.eye(3, dtype=np.int32))
