@@ -60,3 +60,52 @@ def test_two_ranks_equal_single_process():
     single = eng.run_alignments(pk)["mf"]
     assert sharded.shape == single.shape == (40, 64)
     assert np.array_equal(sharded, single)   # bitwise: results do not depend on which rank / batch a protein lands in
+
+
+def _worker_filtered(rank, world, port, q):
+    import torch.distributed as dist
+    from mDeepFRI import batch, sharding, synthetic
+    from mDeepFRI.predict import Predictor
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        prots = synthetic.synthetic_proteins(seed=78, count=30, length=(40, 300), indel_rate=0.05)
+        w = synthetic.glorot_gcn_weights(seed=0, n_terms=200)
+        eng = batch.HotPathEngine({"mf": Predictor("syn", weights=w, device=0)}, device=0, max_rows=4096)
+        res = sharding.predict_sharded_filtered(eng, [p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots],
+                                                [p["t_aln"] for p in prots], threshold=0.1, max_rows=4096)
+        if rank == 0:
+            q.put([x.cpu().numpy() for x in res["mf"]])
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_filtered_gather_equals_single_process_filter():
+    """The compacted gather (output stage before the collective) delivers exactly what filtering the full single-process
+    score matrix gives."""
+    import torch.multiprocessing as mp
+    from mDeepFRI import batch, synthetic
+    from mDeepFRI.output import filter_scores
+    from mDeepFRI.predict import Predictor
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_filtered, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    off, terms, scores = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    prots = synthetic.synthetic_proteins(seed=78, count=30, length=(40, 300), indel_rate=0.05)
+    w = synthetic.glorot_gcn_weights(seed=0, n_terms=200)
+    eng = batch.HotPathEngine({"mf": Predictor("syn", weights=w, device=0)}, device=0, max_rows=4096)
+    pk = batch.PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots],
+                                   [p["t_aln"] for p in prots], max_rows=4096)
+    db = eng.upload(pk)
+    out = eng.forward_alignments(db)
+    eng.check(db)
+    o1, t1, s1 = (x.cpu().numpy() for x in filter_scores(out["mf"], threshold=0.1))
+    assert off[-1] > 0 and np.array_equal(off, o1) and np.array_equal(terms, t1) and np.array_equal(scores, s1)

@@ -70,3 +70,59 @@ def test_gather_world_size_2_gloo(n):
         assert p.exitcode == 0
     exp = np.stack([np.full(T, float(i)) + np.arange(T) / 100.0 for i in range(n)]).astype(np.float32)
     assert np.array_equal(out, exp)
+
+
+def _csr_of(i, T):
+    """deterministic fake output of protein i: (terms, scores)"""
+    k = (i * 7) % 5            # 0..4 kept terms (some proteins keep none)
+    terms = [(i + 3 * j) % T for j in range(k)]
+    return terms, [1.0 - 0.1 * j - i / 1000.0 for j in range(k)]
+
+
+def _worker_csr(rank, world, port, n, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = sharding.partition_by_cost([50 + (i * 37) % 400 for i in range(n)], world)[rank]
+        off, terms, scores = [0], [], []
+        for i in mine:
+            t, s = _csr_of(i, T)
+            terms += t
+            scores += s
+            off.append(len(terms))
+        out = sharding.gather_filtered(torch.tensor(off, dtype=torch.int32), torch.tensor(terms, dtype=torch.int32),
+                                       torch.tensor(scores, dtype=torch.float32), mine, total=n, dst=0)
+        if rank == 0:
+            q.put([x.numpy() for x in out])
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [1, 9, 50])
+def test_gather_filtered_world_size_2_gloo(n):
+    T = 11
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_csr, args=(r, 2, port, n, T, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    off, terms, scores = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert off.shape == (n + 1,) and off[0] == 0
+    for i in range(n):
+        t, s = _csr_of(i, T)
+        assert list(terms[off[i]:off[i + 1]]) == t
+        assert np.array_equal(scores[off[i]:off[i + 1]], np.asarray(s, dtype=np.float32))
+
+
+def test_gather_filtered_single_process():
+    off = torch.tensor([0, 2, 2, 3], dtype=torch.int32)
+    t = torch.tensor([5, 1, 9], dtype=torch.int32)
+    s = torch.tensor([0.9, 0.5, 0.3])
+    goff, gt, gs = sharding.gather_filtered(off, t, s, [2, 0, 1], total=3)
+    assert goff.tolist() == [0, 0, 1, 3] and gt.tolist() == [9, 5, 1] and gs.tolist() == pytest.approx([0.3, 0.9, 0.5])
