@@ -261,3 +261,19 @@ def test_library_first_then_torch_share_one_hip_runtime():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "(3, 16)" in out.stdout
+
+
+def test_protein_longer_than_a_chunk(mf):
+    """A protein longer than max_rows gets an oversized chunk of its own; neighbours of other lengths share the batch."""
+    from mDeepFRI.batch import PackedProteins
+    w, pred = mf
+    prots = synthetic.synthetic_proteins(seed=55, count=1, length=40) + synthetic.synthetic_proteins(seed=56, count=1, length=2500, indel_rate=0.02) \
+        + synthetic.synthetic_proteins(seed=57, count=2, length=(100, 200))
+    eng = _engine({"mf": pred}, max_rows=1024)
+    pk = PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots],
+                             [p["t_aln"] for p in prots], max_rows=1024)
+    assert max(c.rows for c in pk.chunks) > 1024
+    out = eng.run_alignments(pk)["mf"]
+    for i, p in enumerate(prots):
+        cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
+        assert np.max(np.abs(out[i] - gcn_oracle.gcn_forward(w, p["seq"], cm))) < TOL, i
