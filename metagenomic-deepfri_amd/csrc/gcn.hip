@@ -603,6 +603,181 @@ __global__ __launch_bounds__(128) void k_lm_unpack(const float *__restrict__ h_t
     for (int i = threadIdx.x; i < H / 4; i += blockDim.x) dst[i] = src[i];
 }
 
+// ---- LSTM language model, small batches: persistent kernel --------------------------------------------------------------
+// For a handful of proteins (the per-call API runs ONE) a time step is far too little work for a 256x256 MFMA tile per
+// CU: the GEMM form costs >= 250 us per step whatever the batch.  Here the whole recurrence is ONE launch: workgroup c owns
+// hidden units 2c, 2c+1 of both layers, i.e. 8 gate columns per layer, and keeps their weight columns (U1, W2, U2:
+// (H + 2H) x 8 floats) in REGISTERS for all time steps -- lane l of every wave holds rows k = l, l+64, ...; wave w serves
+// proteins b = w, w+4, ... .  Phase s computes LSTM1 step s and LSTM2 step s-1 (both read h1[s-1]): per protein 24*H/64
+// FMAs per lane, a 64-lane reduce-scatter butterfly of the 16 gate pre-activations (21 shuffles), four cells in four lanes (cell state in
+// LDS), h written to the time-major blocks every workgroup reads in the next phase.  Phases are separated by a
+// device-wide barrier (one atomic counter; the grid is <= 512 small workgroups, all resident).  The spin is bounded: if
+// the barrier ever fails to complete the kernel raises an abort flag instead of hanging the GPU.
+constexpr int LSTM_P_MAX_B = 1024;   // cell state and lengths of the group live in LDS
+constexpr int LSTM_P_DEFAULT_B = 512; // groups up to this size take the persistent form by default (measured crossover)
+
+// sync layout (unsigned words, one 128-byte line each): line 0 = abort flag, lines 1..16 = arrival counters of the 16
+// workgroup classes (blockIdx % 16), line 17 = class-completion counter, lines 18..33 = per-class copies of the phase
+// number.  Arrivals are spread over 16 lines (same-address atomics serialise in L2; 256 arrivals on one word plus 256
+// pollers cost ~15 us per phase), the last arrival of a class bumps line 17, the last class publishes the phase into
+// the 16 poll lines, and a workgroup polls only its class's line.
+constexpr int LSTM_SYNC_WORDS = 34 * 32;
+__device__ __forceinline__ void lstm_grid_barrier(unsigned *sync, unsigned phase)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_thread_fence(__ATOMIC_RELEASE);   // h writes of this workgroup -> device scope
+        const unsigned cls = blockIdx.x & 15, n_cls = min(gridDim.x, 16u);
+        const unsigned members = (gridDim.x - cls + 15) / 16;
+        const unsigned a = __hip_atomic_fetch_add(sync + 32 * (1 + cls), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a + 1 == phase * members) {
+            const unsigned c = __hip_atomic_fetch_add(sync + 32 * 17, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c + 1 == phase * n_cls)
+                for (unsigned k = 0; k < n_cls; ++k) __hip_atomic_store(sync + 32 * (18 + k), phase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned spins = 0;
+        while (__hip_atomic_load(sync + 32 * (18 + cls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 22) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // give up loudly, never hang
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);       // drop stale lines of the other workgroups' h from this CU's vector cache
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void k_lstm_persistent(const float *__restrict__ U1, const float *__restrict__ W2,
+                                                         const float *__restrict__ U2, const float *__restrict__ tab1,
+                                                         const float *__restrict__ b2, const uint8_t *__restrict__ let_tm,
+                                                         const int32_t *__restrict__ len, int B, int Lmax, float *h1, float *h2,
+                                                         const int64_t *__restrict__ prot_row, float *__restrict__ h_out,
+                                                         unsigned *sync)
+{
+    constexpr int KL = H / 64, G = 4 * H;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int u0 = blockIdx.x * 2;
+    float wU1[KL][8], wW2[KL][8], wU2[KL][8];
+#pragma unroll
+    for (int i = 0; i < KL; ++i)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const size_t at = (size_t)(lane + 64 * i) * G + (c >> 1) * H + u0 + (c & 1);   // column (gate c>>1, unit u0 + (c&1))
+            wU1[i][c] = U1[at];
+            wW2[i][c] = W2[at];
+            wU2[i][c] = U2[at];
+        }
+    __shared__ float cst[2][2][LSTM_P_MAX_B];   // [layer][unit of this workgroup][protein]
+    __shared__ int lens[LSTM_P_MAX_B];
+    __shared__ float tabs[32][8];               // LSTM1 input projection + bias of this workgroup's 8 gate columns, per letter
+    if (threadIdx.x < 256) tabs[threadIdx.x >> 3][threadIdx.x & 7] = tab1[(size_t)(threadIdx.x >> 3) * G + ((threadIdx.x & 7) >> 1) * H + u0 + (threadIdx.x & 1)];
+    for (int i = threadIdx.x; i < B; i += 256) {
+        lens[i] = len[i];
+        cst[0][0][i] = cst[0][1][i] = cst[1][0][i] = cst[1][1][i] = 0.0f;
+    }
+    __syncthreads();
+    const size_t blk = (size_t)B * H;
+    for (int s = 0; s <= Lmax; ++s) {
+        // operands of the next protein are fetched while the current one is reduced (the per-protein chain -- h loads, FMAs,
+        // butterfly, cell -- is latency-bound otherwise); reading one protein past the group is harmless (clamped)
+        float nx1[KL], nx2[KL];
+        int nlet;
+        {
+            const int b0 = min(w, B - 1);
+            const float *q1 = h1 + (size_t)s * blk + (size_t)b0 * H + lane, *q2 = h2 + (size_t)(s > 0 ? s - 1 : 0) * blk + (size_t)b0 * H + lane;
+#pragma unroll
+            for (int i = 0; i < KL; ++i) {
+                nx1[i] = q1[64 * i];
+                nx2[i] = q2[64 * i];
+            }
+            nlet = let_tm[(size_t)min(s, Lmax - 1) * B + b0];
+        }
+        for (int b = w; b < B; b += 4) {
+            const int lb = lens[b];
+            const bool do1 = s < lb, do2 = s >= 1 && s - 1 < lb;   // wave-uniform
+            if (!do1 && !do2) break;                               // sorted by length: the rest of the group is finished too
+            float cx1[KL], cx2[KL];
+            const int clet = nlet;
+#pragma unroll
+            for (int i = 0; i < KL; ++i) {
+                cx1[i] = nx1[i];
+                cx2[i] = nx2[i];
+            }
+            {
+                const int bn = min(b + 4, B - 1);
+                const float *q1 = h1 + (size_t)s * blk + (size_t)bn * H + lane, *q2 = h2 + (size_t)(s > 0 ? s - 1 : 0) * blk + (size_t)bn * H + lane;
+#pragma unroll
+                for (int i = 0; i < KL; ++i) {
+                    nx1[i] = q1[64 * i];
+                    nx2[i] = q2[64 * i];
+                }
+                nlet = let_tm[(size_t)min(s, Lmax - 1) * B + bn];
+            }
+            float p[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) p[c] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < KL; ++i) {
+                const float x1 = cx1[i], x2 = cx2[i];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    p[c] = fmaf(wU1[i][c], x1, p[c]);
+                    p[8 + c] = fmaf(wW2[i][c], x1, p[8 + c]);
+                    p[8 + c] = fmaf(wU2[i][c], x2, p[8 + c]);
+                }
+            }
+            // reduce-scatter butterfly: each exchange halves the values a lane carries (8+4+2+1 shuffles), two plain steps
+            // finish; lane = layer*32 + gate*8 + unit*4 + r then holds the full pre-activation p[layer*8 + gate*2 + unit]
+            float q8[8], q4[4], q2[2], z;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const bool up = lane & 32;
+                q8[c] = (up ? p[8 + c] : p[c]) + __shfl_xor(up ? p[c] : p[8 + c], 32, 64);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool up = lane & 16;
+                q4[c] = (up ? q8[4 + c] : q8[c]) + __shfl_xor(up ? q8[c] : q8[4 + c], 16, 64);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bool up = lane & 8;
+                q2[c] = (up ? q4[2 + c] : q4[c]) + __shfl_xor(up ? q4[c] : q4[2 + c], 8, 64);
+            }
+            {
+                const bool up = lane & 4;
+                z = (up ? q2[1] : q2[0]) + __shfl_xor(up ? q2[0] : q2[1], 4, 64);
+            }
+            z += __shfl_xor(z, 2, 64);
+            z += __shfl_xor(z, 1, 64);
+            // the four gates of (layer, unit) sit 8 lanes apart; lanes 0, 4, 32, 36 finish one cell each
+            const int base = lane & 36;
+            float zi = __shfl(z, base, 64), zf = __shfl(z, base + 8, 64), zg = __shfl(z, base + 16, 64), zo = __shfl(z, base + 24, 64);
+            if ((lane & 27) == 0) {
+                const int layer = lane >> 5, cu = (lane >> 2) & 1, uc = u0 + cu;
+                if (layer == 0 && do1) {
+                    const float *tr = tabs[min(clet, 31)] + cu;
+                    zi += tr[0]; zf += tr[2]; zg += tr[4]; zo += tr[6];
+                    const float cn = sigmoid_fast(zf) * cst[0][cu][b] + sigmoid_fast(zi) * (2.0f * sigmoid_fast(2.0f * zg) - 1.0f);
+                    cst[0][cu][b] = cn;
+                    h1[(size_t)(s + 1) * blk + (size_t)b * H + uc] = sigmoid_fast(zo) * (2.0f * sigmoid_fast(2.0f * cn) - 1.0f);
+                }
+                if (layer == 1 && do2) {
+                    zi += b2[0 * H + uc]; zf += b2[1 * H + uc]; zg += b2[2 * H + uc]; zo += b2[3 * H + uc];
+                    const float cn = sigmoid_fast(zf) * cst[1][cu][b] + sigmoid_fast(zi) * (2.0f * sigmoid_fast(2.0f * zg) - 1.0f);
+                    cst[1][cu][b] = cn;
+                    const float hv = sigmoid_fast(zo) * (2.0f * sigmoid_fast(2.0f * cn) - 1.0f);
+                    h2[(size_t)s * blk + (size_t)b * H + uc] = hv;
+                    h_out[(size_t)(prot_row[b] + s - 1) * H + uc] = hv;
+                }
+            }
+        }
+        if (s < Lmax) lstm_grid_barrier(sync, (unsigned)(s + 1));
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------
 static int set_gemm_attr_once()
 {
@@ -742,6 +917,11 @@ struct mdf_lm {
     hipStream_t s2 = nullptr;
     hipEvent_t ev[64] = {};
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // small-batch (persistent) form: Keras-layout copies + grid-barrier state
+    float *kU1 = nullptr, *kW2 = nullptr, *kU2 = nullptr;   // (H, 4H) each
+    float *ktab1 = nullptr;                                  // (32, 4H)  W1[a] + b1, rows 26..31 zero
+    float *kb2 = nullptr;                                    // (4H)
+    unsigned *sync = nullptr;                                // barrier state, see lstm_grid_barrier
 };
 
 namespace mdf {
@@ -913,6 +1093,17 @@ int mdf_lm_create(const mdf_lm_weights *w, int device, mdf_lm **out)
     if (rc == MDF_OK) rc = upload(&lm->tab1, tab.data(), tab.size());
     if (rc == MDF_OK) rc = upload(&lm->W2U2t, w2u2t.data(), w2u2t.size());
     if (rc == MDF_OK) rc = upload(&lm->b2p, b2p.data(), b2p.size());
+    if (rc == MDF_OK) rc = upload(&lm->kU1, w->U1, (size_t)H * G);
+    if (rc == MDF_OK) rc = upload(&lm->kW2, w->W2, (size_t)H * G);
+    if (rc == MDF_OK) rc = upload(&lm->kU2, w->U2, (size_t)H * G);
+    if (rc == MDF_OK) {
+        std::vector<float> kt((size_t)32 * G, 0.0f);
+        for (int a = 0; a < 26; ++a)
+            for (int c = 0; c < G; ++c) kt[(size_t)a * G + c] = w->W1[(size_t)a * G + c] + w->b1[c];
+        rc = upload(&lm->ktab1, kt.data(), kt.size());
+    }
+    if (rc == MDF_OK) rc = upload(&lm->kb2, w->b2, (size_t)G);
+    if (rc == MDF_OK && hipMalloc(reinterpret_cast<void **>(&lm->sync), LSTM_SYNC_WORDS * 4) != hipSuccess) rc = fail(MDF_ENOMEM, "lm_create: out of device memory");
     if (rc == MDF_OK && hipStreamCreateWithFlags(&lm->s2, hipStreamNonBlocking) != hipSuccess) rc = fail(MDF_ENODEVICE, "lm_create: cannot create a stream");
     for (int i = 0; i < 64 && rc == MDF_OK; ++i)
         if (hipEventCreateWithFlags(&lm->ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(MDF_ENODEVICE, "lm_create: cannot create an event");
@@ -934,6 +1125,12 @@ void mdf_lm_free(mdf_lm *lm)
     (void)hipFree(lm->tab1);
     (void)hipFree(lm->W2U2t);
     (void)hipFree(lm->b2p);
+    (void)hipFree(lm->kU1);
+    (void)hipFree(lm->kW2);
+    (void)hipFree(lm->kU2);
+    (void)hipFree(lm->ktab1);
+    (void)hipFree(lm->kb2);
+    (void)hipFree(lm->sync);
     if (lm->s2) (void)hipStreamDestroy(lm->s2);
     for (int i = 0; i < 64; ++i)
         if (lm->ev[i]) (void)hipEventDestroy(lm->ev[i]);
@@ -972,6 +1169,44 @@ int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_r
         const size_t n = (size_t)B * Lmax;
         hipLaunchKernelGGL(k_lm_pack_letters, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, seq_idx, prot_row, len_dev, B, Lmax, let_tm);
         MDF_HIP(hipGetLastError());
+    }
+    // small groups: the whole recurrence in one persistent launch (k_lstm_persistent)
+    {
+        const char *e = getenv("MDFRI_LM_PERSISTENT_MAX_B");   // developer knob: 0 forces the GEMM form
+        const int max_b = e ? std::min(atoi(e), LSTM_P_MAX_B) : LSTM_P_DEFAULT_B;
+        bool fits = B <= max_b && (H == 64 || H == 128 || H == 256 || H == 512 || H == 1024);
+        if (fits) {
+            // every workgroup must be resident at once (device-wide barrier): grid <= CUs x workgroups per CU
+            int per_cu = 0, cus = 0, dev = 0;
+            const void *fn = H == 64    ? reinterpret_cast<const void *>(&k_lstm_persistent<64>)
+                             : H == 128 ? reinterpret_cast<const void *>(&k_lstm_persistent<128>)
+                             : H == 256 ? reinterpret_cast<const void *>(&k_lstm_persistent<256>)
+                             : H == 512 ? reinterpret_cast<const void *>(&k_lstm_persistent<512>)
+                                        : reinterpret_cast<const void *>(&k_lstm_persistent<1024>);
+            MDF_HIP(hipGetDevice(&dev));
+            MDF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            MDF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0));
+            fits = (long long)per_cu * cus >= H / 2;
+        }
+        if (fits) {
+            MDF_HIP(hipMemsetAsync(lm->sync, 0, LSTM_SYNC_WORDS * 4, st));
+            {
+                ScopedTiming tm(TK_LSTM, st);
+#define MDF_LSTM_P(HH)                                                                                                          \
+    hipLaunchKernelGGL(k_lstm_persistent<HH>, dim3(HH / 2), dim3(256), 0, st, lm->kU1, lm->kW2, lm->kU2, lm->ktab1, lm->kb2, let_tm, \
+                       len_dev, B, Lmax, h1, h2, prot_row, h_out, lm->sync)
+                if (H == 64) MDF_LSTM_P(64); else if (H == 128) MDF_LSTM_P(128); else if (H == 256) MDF_LSTM_P(256);
+                else if (H == 512) MDF_LSTM_P(512); else MDF_LSTM_P(1024);
+#undef MDF_LSTM_P
+                MDF_HIP(hipGetLastError());
+            }
+            // a handful of proteins: latency path, so waiting here costs nothing -- and a barrier that gave up must surface
+            unsigned flags[1] = {0};
+            MDF_HIP(hipMemcpyAsync(flags, lm->sync, sizeof(flags), hipMemcpyDeviceToHost, st));
+            MDF_HIP(hipStreamSynchronize(st));
+            if (flags[0] != 0) return fail(MDF_ENODEVICE, "lm_forward_dev: the device-wide barrier of the persistent LSTM kernel timed out");
+            return MDF_OK;
+        }
     }
     // Two chains: LSTM1 steps on the caller's stream, LSTM2 steps on lm->s2, step t of LSTM2 waiting for step t of LSTM1
     // only.  LSTM1(t+1) and LSTM2(t) are independent, and an LSTM2 tile (K = 2H) takes twice as long as an LSTM1 tile:

@@ -7,6 +7,17 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["persistent", "gemm"], autouse=True)
+def lstm_form(request, monkeypatch):
+    """Every test runs twice: small groups through the one-launch persistent LSTM kernel (default for <= 16 proteins) and
+    through the per-time-step MFMA GEMM form used for large groups (forced with the developer knob)."""
+    if request.param == "gemm":
+        monkeypatch.setenv("MDFRI_LM_PERSISTENT_MAX_B", "0")
+    else:
+        monkeypatch.delenv("MDFRI_LM_PERSISTENT_MAX_B", raising=False)
+    return request.param
+
+
 def _weights(seed, hidden, embed, gc, fc, T):
     from mDeepFRI import synthetic
     w = synthetic.glorot_gcn_weights(seed=seed, n_terms=T, embed=embed, gc_dims=gc, fc_dim=fc)
@@ -128,3 +139,21 @@ def test_predictor_loads_an_onnx_file(tmp_path):
     a = Predictor(str(path)).forward_pass(seqs[0], A)
     b = Predictor("synthetic", weights=w).forward_pass(seqs[0], A)
     np.testing.assert_array_equal(a, b)
+
+
+def test_lstm_forms_agree(monkeypatch):
+    """The per-time-step GEMM form and the one-launch persistent form compute the same features (different summation order,
+    hence a tolerance), for a group and for single proteins."""
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.predict import Predictor
+    w = _weights(3, 64, 256, (256,), 256, 20)
+    seqs, _ = _proteins(17, [30 + 3 * i for i in range(20)])
+    pred = Predictor("synthetic", weights=w)
+    monkeypatch.setenv("MDFRI_LM_PERSISTENT_MAX_B", "0")
+    gemm = HotPathEngine({"mf": pred}).lm_features(PackedProteins.pack(seqs))
+    monkeypatch.delenv("MDFRI_LM_PERSISTENT_MAX_B", raising=False)
+    pers = HotPathEngine({"mf": pred}).lm_features(PackedProteins.pack(seqs))
+    for k in range(20):
+        np.testing.assert_allclose(gemm[k], pers[k], atol=2e-5, rtol=0)
+    for k in (0, 7, 19):   # the persistent form is batch-invariant bit for bit
+        np.testing.assert_array_equal(pers[k], HotPathEngine({"mf": pred}).lm_features(PackedProteins.pack([seqs[k]]))[0])
