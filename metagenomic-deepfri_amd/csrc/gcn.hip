@@ -11,8 +11,13 @@
 //                                                            HBM), folded per protein by k_pool_reduce
 //   head      y   = softmax2( relu(g W_fc + b_fc) W_out + b_out )[:,0]   -- the same GEMM kernel, other epilogues
 //
+// Models with the language-model branch of the released DeepFRI files (lm_dim > 0) add, in front:
+//   LSTM x 2  h1, h2 over the residues          -- large groups: one MFMA GEMM launch per time step and layer, the cell
+//                                                  fused in the epilogue (EPI_LSTM_*); small groups: k_lstm_persistent
+//   embedding X0 = relu(h2 W_lm + b_lm + W_aa[letter])  -- EPI_EMBED; layer 1 is then A.X over `embed` channels + H.W
+//
 // Arithmetic is fp32 throughout (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains); the reference tolerance is 1e-4
-// absolute on the scores (north_star), checked against oracle/gcn_oracle.py.
+// absolute on the scores (north_star), checked against oracle/gcn_oracle.py (and oracle/lm_oracle.py).
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
