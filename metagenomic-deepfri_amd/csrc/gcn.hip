@@ -74,7 +74,7 @@ struct GemmAux {
 };
 
 // sigmoid / tanh on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error < 3e-7.
-__device__ __forceinline__ float sigmoid_fast(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // (__frcp_rn expands to a full IEEE division)
 
 // ELU with the hardware exponential (v_exp_f32 on x*log2(e), ~1 ulp of exp2): for x <= 0 the result lies in (-1, 0] and
 // the absolute error is < 2e-7, far inside the 1e-4 score budget; libm expf costs ~40 VALU instructions per element and
@@ -139,29 +139,46 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n
         for (int tm = 0; tm < 4; ++tm) {
             const int rbase = m0 + wm * 128 + tm * 32;
             if (rbase >= M) continue;
+            // three passes over the 16 rows of this MFMA tile so that the loads, the lane exchanges and the stores are each
+            // issued back to back (one row at a time left ~3 waits per element and 40 % of the step in the epilogue)
+            constexpr int RB = (EPI == EPI_LSTM_TAB) ? 8 : 16;   // rows per pass (the table form carries two more values per row)
+            float *const obase = half ? C : aux.cstate;           // the upper half-lanes write h_t, the lower ones c_t
+            const int opitch = half ? ldc : H;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
-                const int rr = min(row, M - 1);
-                float a0 = acc[tm][0][r], a1 = acc[tm][1][r];
-                if (EPI == EPI_LSTM_TAB) {
-                    const float *trow = aux.table + (size_t)min((int)aux.letters[rr], 31) * N;
-                    a0 += trow[col0];
-                    a1 += trow[col1];
-                } else {
-                    a0 += b0;
-                    a1 += b1;
+            for (int r0 = 0; r0 < 16; r0 += RB) {
+                float cp[RB], t0[RB], t1[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int r = r0 + q;
+                    const int rr = min(rbase + (r & 3) + 8 * (r >> 2) + lrow, M - 1);
+                    cp[q] = aux.cstate[(size_t)rr * H + unit];
+                    if (EPI == EPI_LSTM_TAB) {
+                        const float *trow = aux.table + (size_t)min((int)aux.letters[rr], 31) * N;
+                        t0[q] = trow[col0];
+                        t1[q] = trow[col1];
+                    } else {
+                        t0[q] = b0;
+                        t1[q] = b1;
+                    }
                 }
-                const float s0 = sigmoid_fast(a0);                       // i | f
-                const float sg = sigmoid_fast(half ? a1 : 2.0f * a1);
-                const float x1 = half ? sg : 2.0f * sg - 1.0f;           // g = tanh(a1) | o
-                const float cprev = aux.cstate[(size_t)rr * H + unit];
-                const float mine = half ? s0 * cprev : s0 * x1;          // f*c_prev | i*g
-                const float cn = mine + __shfl_xor(mine, 16, 64);
-                const float th = 2.0f * sigmoid_fast(2.0f * cn) - 1.0f;  // tanh(c_t)
-                if (row < M) {
-                    if (half) C[(size_t)row * ldc + unit] = x1 * th;
-                    else aux.cstate[(size_t)row * H + unit] = cn;
+                float x1[RB], mine[RB], other[RB];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const float a0 = acc[tm][0][r0 + q] + t0[q], a1 = acc[tm][1][r0 + q] + t1[q];
+                    const float s0 = sigmoid_fast(a0);                       // i | f
+                    const float sg = sigmoid_fast(half ? a1 : 2.0f * a1);
+                    x1[q] = half ? sg : 2.0f * sg - 1.0f;                    // g = tanh(a1) | o
+                    mine[q] = half ? s0 * cp[q] : s0 * x1[q];                // f*c_prev | i*g
+                }
+#pragma unroll
+                for (int q = 0; q < RB; ++q) other[q] = __shfl_xor(mine[q], 16, 64);
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const int r = r0 + q;
+                    const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+                    const float cn = mine[q] + other[q];
+                    const float th = 2.0f * sigmoid_fast(2.0f * cn) - 1.0f;  // tanh(c_t)
+                    if (row < M) obase[(size_t)row * opitch + unit] = half ? x1[q] * th : cn;   // one store per lane, selected address
                 }
             }
         }
