@@ -184,6 +184,29 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n
         }
         return;
     }
+    if (EPI == EPI_EMBED) {
+        // X0 = relu(acc + table[letter[row]]): M is a multiple of 32 (residue rows), so whole 32-row MFMA tiles are either
+        // stored or skipped; the 16 letters of a tile are fetched once, then the table values, then the stores
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int rbase = m0 + wm * 128 + tm * 32;
+            if (rbase >= M) continue;
+            int lt[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lt[r] = min((int)aux.letters[rbase + (r & 3) + 8 * (r >> 2) + lrow], 31) * N;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int col = n0 + wn * 64 + tn * 32 + lcol;
+                float tv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tv[r] = aux.table[lt[r] + col];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    C[(size_t)(rbase + (r & 3) + 8 * (r >> 2) + lrow) * ldc + col] = fmaxf(acc[tm][tn][r] + tv[r], 0.0f);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < 4; ++tm) {
 #pragma unroll
@@ -204,15 +227,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n
                 }
                 s += __shfl_xor(s, 32, 64);
                 if (lane < 32) pool_partial[(size_t)(rbase >> 5) * ldp + col] = s;
-            } else if (EPI == EPI_EMBED) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
-                    if (row < M) {
-                        const float tv = aux.table[(size_t)min((int)aux.letters[row], 31) * N + col];
-                        C[(size_t)row * ldc + col] = fmaxf(acc[tm][tn][r] + tv, 0.0f);
-                    }
-                }
             } else if (EPI == EPI_BIAS_RELU) {
                 const float bv = bias[col];
 #pragma unroll
