@@ -658,11 +658,16 @@ constexpr int LSTM_P_DEFAULT_B = 512; // groups up to this size take the persist
 // pollers cost ~15 us per phase), the last arrival of a class bumps line 17, the last class publishes the phase into
 // the 16 poll lines, and a workgroup polls only its class's line.
 constexpr int LSTM_SYNC_WORDS = 34 * 32;
+// Hand-off protocol (MI355X_MICROARCH.md, inter-workgroup visibility): plain h stores -> __syncthreads -> ONE lane: agent
+// release (buffer_wbl2: the XCD L2s are not coherent with each other) -> explicit s_waitcnt vmcnt(0) (the compiler may
+// drop the one behind the write-back, letting the arrival overtake it) -> relaxed agent atomics for arrival / publish /
+// poll -> ONE agent acquire (invalidates this CU's L1) -> __syncthreads -> plain loads.
 __device__ __forceinline__ void lstm_grid_barrier(unsigned *sync, unsigned phase)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __atomic_thread_fence(__ATOMIC_RELEASE);   // h writes of this workgroup -> device scope
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned cls = blockIdx.x & 15, n_cls = min(gridDim.x, 16u);
         const unsigned members = (gridDim.x - cls + 15) / 16;
         const unsigned a = __hip_atomic_fetch_add(sync + 32 * (1 + cls), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -679,9 +684,9 @@ __device__ __forceinline__ void lstm_grid_barrier(unsigned *sync, unsigned phase
                 break;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);       // drop stale lines of the other workgroups' h from this CU's vector cache
 }
 
 template <int H>
@@ -1240,8 +1245,14 @@ int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_r
             unsigned flags[1] = {0};
             MDF_HIP(hipMemcpyAsync(flags, lm->sync, sizeof(flags), hipMemcpyDeviceToHost, st));
             MDF_HIP(hipStreamSynchronize(st));
-            if (flags[0] != 0) return fail(MDF_ENODEVICE, "lm_forward_dev: the device-wide barrier of the persistent LSTM kernel timed out");
-            return MDF_OK;
+            if (flags[0] == 0) return MDF_OK;
+            // the device-wide barrier gave up (workgroups not co-resident: the CUs were shared with other work): redo the group
+            // with the per-time-step GEMM form below, which needs no residency
+            static bool warned = false;
+            if (!warned) fprintf(stderr, "libmdfri_hip: persistent LSTM barrier timed out; using the per-step GEMM form\n");
+            warned = true;
+            MDF_HIP(hipMemsetAsync(h1, 0, blk * 4, st));
+            MDF_HIP(hipMemsetAsync(h2, 0, blk * 4, st));
         }
     }
     // Two chains: LSTM1 steps on the caller's stream, LSTM2 steps on lm->s2, step t of LSTM2 waiting for step t of LSTM1
