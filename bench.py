@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--lm", action="store_true",
                     help="give every GO head the language-model branch of the released models (shared 2x512 LSTM + per-head "
                          "LM embedding; SURVEY.md section 8f row 1).  Not the BASELINE.json configuration: an extra measurement.")
+    ap.add_argument("--end-to-end", type=int, default=0, metavar="N",
+                    help="also stream N batches of --proteins from HOST lists through mDeepFRI.stream.AlignmentStream (packing, "
+                         "PCIe upload, compute, PCIe download of the scores) and report the PCIe-inclusive rate next to `value`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-device", type=int, default=None, help="testing aid: put every rank on this device ordinal")
     return ap.parse_args()
@@ -287,6 +290,23 @@ def main():
             if not worst < 1e-4:
                 print(json.dumps(line), flush=True)
                 raise SystemExit(f"parity check failed: max |score - oracle| = {worst}")
+        if world == 1 and args.end_to_end > 0 and args.workload == "configs2":
+            from mDeepFRI.stream import AlignmentStream
+            items = []
+            for k in range(args.end_to_end):
+                s2, c2 = make_workload(777 + k, args.proteins, args.length)
+                items += [(a, b, a, a) for a, b in zip(s2, c2)]
+            stream = AlignmentStream(eng, batch_size=args.proteins, max_rows=args.chunk_rows)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_out = 0
+            for _, res in stream.run(items):
+                n_out += res[MODES[0]].shape[0]
+            dt = time.perf_counter() - t0
+            assert n_out == len(items)
+            line["end_to_end"] = {"value": round(len(items) / dt, 1), "unit": "proteins/s", "batches": args.end_to_end,
+                                  "note": "host lists in -> host float32 score arrays out: packing thread + PCIe upload + compute + "
+                                          "PCIe download, batches pipelined (mDeepFRI.stream.AlignmentStream); never `value`"}
         if world == 1 and args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(seqs[:1024], coords[:1024], weights, args.cpu_seconds) if args.workload == "configs2" else None
             line["gpu_over_cpu_1core"] = round(line["value"] / line["cpu_baseline"]["value"], 1)

@@ -518,13 +518,16 @@ class HotPathEngine:
         """Synchronise and raise what the asynchronous stages flagged (invalid residue, CSR overflow)."""
         torch = _torch()
         torch.cuda.current_stream(self.device).synchronize()
-        bad = db.bad.cpu().numpy()
-        for ci, ch in enumerate(db.packed.chunks):
+        self.raise_flags(db.packed, db.bad.cpu().numpy(), db.status.cpu().numpy())
+
+    def raise_flags(self, packed: PackedProteins, bad, st):
+        """Turn the per-chunk device flags (host copies: bad (n_chunks, 2), status (n_chunks, 4)) into the exceptions the
+        per-call API raises."""
+        for ci, ch in enumerate(packed.chunks):
             if bad[ci, 0] != 0:
                 p = ch.p0 + int(bad[ci, 0]) - 1
-                c = db.packed.seqs[p][int(bad[ci, 1])]
+                c = packed.seqs[p][int(bad[ci, 1])]
                 raise ValueError(f"Invalid character in sequence: {c}")
-        st = db.status.cpu().numpy()
         if (st[:, 0] != 0).any():
             need = int(st[:, 1].max())
             raise _hip.CapacityError(_hip.MDF_ECAPACITY,

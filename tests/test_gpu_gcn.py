@@ -277,3 +277,35 @@ def test_protein_longer_than_a_chunk(mf):
     for i, p in enumerate(prots):
         cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
         assert np.max(np.abs(out[i] - gcn_oracle.gcn_forward(w, p["seq"], cm))) < TOL, i
+
+
+def test_alignment_stream_matches_one_batch(mf, cc):
+    """Host-in / host-out streaming runner: several device batches, a producer thread packing ahead, results in input order
+    and bitwise equal to one big batch; objects with the AlignmentResult attributes are accepted as well as tuples."""
+    from mDeepFRI.batch import PackedProteins
+    from mDeepFRI.stream import AlignmentStream
+    (wm, pm), (wc, pc) = mf, cc
+    prots = synthetic.synthetic_proteins(seed=31, count=53, length=(20, 260), indel_rate=0.05)
+    eng = _engine({"mf": pm, "cc": pc}, max_rows=2048)
+    items = [(p["seq"], p["coords"], p["q_aln"], p["t_aln"]) for p in prots]
+
+    class Aln:
+        def __init__(self, p):
+            self.coords, self.gapped_sequence, self.gapped_target = p["coords"], p["q_aln"], p["t_aln"]
+
+    stream = AlignmentStream(eng, batch_size=10, max_rows=2048)
+    firsts, got = [], {"mf": [], "cc": []}
+    for first, res in stream.run(items[:25] + [Aln(p) for p in prots[25:]]):
+        firsts.append(first)
+        for m in got:
+            got[m].append(res[m])
+    assert firsts == [0, 10, 20, 30, 40, 50]
+    pk = PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots],
+                             [p["t_aln"] for p in prots], max_rows=2048)
+    ref = eng.run_alignments(pk)
+    for m in got:
+        assert np.array_equal(np.concatenate(got[m]), ref[m])
+    bad = list(items)
+    bad[37] = ("ACDJ", bad[37][1][:4], "ACDJ", "ACDJ")
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        stream.run_all(bad)
