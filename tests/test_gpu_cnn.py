@@ -68,3 +68,14 @@ def test_cnn_container_round_trip(tmp_path):
     np.testing.assert_array_equal(a, b)
     import cnn_oracle
     assert np.abs(a - cnn_oracle.cnn_forward(w, s)).max() < 1e-4
+
+
+def test_sequence_engine_flags_invalid_residue():
+    from mDeepFRI import synthetic
+    from mDeepFRI.batch import SequenceEngine
+    from mDeepFRI.predict import Predictor
+    eng = SequenceEngine({"mf": Predictor("synthetic-cnn", weights=synthetic.glorot_cnn_weights(seed=1, n_terms=7))}, max_rows=256)
+    seqs = _seqs(2, [40, 300, 12])
+    seqs[1] = seqs[1][:100] + "j" + seqs[1][101:]            # lowercase is invalid (reference tests/test_predict.py)
+    with pytest.raises(ValueError, match="Invalid character in sequence: j"):
+        eng.run(seqs)

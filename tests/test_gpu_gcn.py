@@ -309,3 +309,16 @@ def test_alignment_stream_matches_one_batch(mf, cc):
     bad[37] = ("ACDJ", bad[37][1][:4], "ACDJ", "ACDJ")
     with pytest.raises(ValueError, match="Invalid character in sequence: J"):
         stream.run_all(bad)
+
+
+def test_alignment_stream_recovers_from_csr_overflow(mf):
+    """A batch denser than the planned CSR capacity is redone with a larger one; the stream still delivers every batch in order."""
+    from mDeepFRI.batch import PackedProteins
+    from mDeepFRI.stream import AlignmentStream
+    w, pred = mf
+    prots = synthetic.synthetic_proteins(seed=41, count=12, length=(60, 120))
+    items = [(p["seq"], p["coords"], p["q_aln"], p["t_aln"]) for p in prots]
+    eng = _engine({"mf": pred}, max_rows=1024, nnz_per_row=2)            # far too small: ~12 neighbours per residue
+    got = AlignmentStream(eng, batch_size=5, max_rows=1024).run_all(items)["mf"]
+    ref = _engine({"mf": pred}, max_rows=1024).run_alignments(PackedProteins.pack(*zip(*items), max_rows=1024))["mf"]
+    assert np.array_equal(got, ref)
