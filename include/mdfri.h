@@ -194,6 +194,12 @@ int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, 
 /* B proteins in residue-row layout (see below): seq_idx (R) from mdf_seq_encode_dev, Lq / row_off device int32.
  * R = row_off[B] (total rows).  scores: (B, T) f32.  workspace: mdf_cnn_workspace_bytes(m, B, R). */
 size_t mdf_cnn_workspace_bytes(const mdf_cnn *m, int32_t B, int64_t R);
+/* The two halves of mdf_cnn_forward_dev, for callers that pool chunk by chunk and run the output layer once over all
+ * proteins: pooled is (B, mdf_cnn_padded_channels) f32; mdf_cnn_pool_dev needs a workspace of 4*(R/32+1) bytes rounded up to 256. */
+int mdf_cnn_padded_channels(const mdf_cnn *m);
+int mdf_cnn_pool_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                     float *pooled, void *workspace, size_t workspace_bytes, void *stream);
+int mdf_cnn_head_dev(mdf_cnn *m, const float *pooled, int32_t B, float *scores, void *stream);
 int mdf_cnn_forward_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
                         float *scores, void *workspace, size_t workspace_bytes, void *stream);
 

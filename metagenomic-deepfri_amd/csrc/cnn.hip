@@ -263,48 +263,66 @@ int mdf_cnn_channels(const mdf_cnn *m) { return m ? m->C : fail(MDF_EINVAL, "cnn
 
 size_t mdf_cnn_workspace_bytes(const mdf_cnn *m, int32_t B, int64_t R)
 {
-    return m && B > 0 && R > 0 ? align_up((size_t)B * m->Cpad * 4, 256) + align_up((size_t)(R / 32 + 1) * 4, 256) + 256 : 0;
+    return m && B > 0 && R > 0 ? align_up((size_t)B * m->Cpad * 4, 256) + 2 * align_up((size_t)(R / 32 + 1) * 4, 256) + 256 : 0;
+}
+
+int mdf_cnn_padded_channels(const mdf_cnn *m) { return m ? m->Cpad : fail(MDF_EINVAL, "cnn is NULL"); }
+
+int mdf_cnn_pool_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                     float *pooled, void *workspace, size_t workspace_bytes, void *stream)
+{
+    MDF_REQUIRE(m && seq_idx && Lq && row_off && pooled && workspace, "cnn_pool_dev: NULL argument");
+    MDF_REQUIRE(B > 0 && R > 0 && R % 32 == 0 && R < 0x7fffffff, "cnn_pool_dev: B=%d R=%lld", B, (long long)R);
+    if (workspace_bytes < align_up((size_t)(R / 32 + 1) * 4, 256)) return fail(MDF_ECAPACITY, "cnn_pool_dev: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int32_t *owner = static_cast<int32_t *>(workspace);
+    const int n_groups = (int)(R / 32);
+    MDF_HIP(hipMemsetAsync(pooled, 0, (size_t)B * m->Cpad * 4, st));   // relu floor; channels C..Cpad stay zero
+    ScopedTiming tm(TK_CNN, st);
+    static const bool no_lds = getenv("MDFRI_CNN_NO_LDS") != nullptr;   // developer knob: force the cache form
+    const int n_lds = no_lds ? 0 : m->n_lds_tiles;
+    if (n_lds > 0) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cnn_conv_pool_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        CNN_LDS_MAX_K * 27 * 64 * 4));
+            attr_done = true;
+        }
+        MDF_HIP(hipMemsetAsync(owner, 0xff, (size_t)n_groups * 4, st));   // -1: group belongs to no protein
+        hipLaunchKernelGGL(k_cnn_group_owner, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, Lq, row_off, B, owner);
+        // workgroups per tile: each keeps the table in LDS and walks 32-row groups, 16 at a time
+        const int wgs = std::max(1, std::min((n_groups + 63) / 64, 256));
+        hipLaunchKernelGGL(k_cnn_conv_pool_lds, dim3((unsigned)wgs, (unsigned)n_lds), dim3(CNN_LDS_THREADS), (size_t)m->lds_bytes, st, seq_idx, Lq,
+                           row_off, owner, n_groups, m->tiles, m->bias, m->scale, m->shift, pooled, m->Cpad);
+        MDF_HIP(hipGetLastError());
+    }
+    if (m->n_tiles > n_lds) {
+        hipLaunchKernelGGL(k_cnn_conv_pool, dim3((unsigned)B, (unsigned)(m->n_tiles - n_lds)), dim3(256), 0, st, seq_idx, Lq, row_off,
+                           m->tiles + n_lds, m->bias, m->scale, m->shift, pooled, m->Cpad);
+        MDF_HIP(hipGetLastError());
+    }
+    return MDF_OK;
+}
+
+int mdf_cnn_head_dev(mdf_cnn *m, const float *pooled, int32_t B, float *scores, void *stream)
+{
+    MDF_REQUIRE(m && pooled && scores && B > 0, "cnn_head_dev: bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    ScopedTiming tm(TK_HEAD, st);
+    return launch_head_softmax2(pooled, m->Cpad, m->Wout_t, m->Cpad, B, m->n_out_pad, m->Cpad, scores, m->T, m->bout, st);
 }
 
 int mdf_cnn_forward_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
                         float *scores, void *workspace, size_t workspace_bytes, void *stream)
 {
-    MDF_REQUIRE(m && seq_idx && Lq && row_off && scores && workspace, "cnn_forward_dev: NULL argument");
-    MDF_REQUIRE(B > 0 && R > 0 && R % 32 == 0 && R < 0x7fffffff, "cnn_forward_dev: B=%d R=%lld", B, (long long)R);
+    MDF_REQUIRE(m && workspace, "cnn_forward_dev: NULL argument");
+    MDF_REQUIRE(B > 0 && R > 0, "cnn_forward_dev: B=%d R=%lld", B, (long long)R);
     if (workspace_bytes < mdf_cnn_workspace_bytes(m, B, R)) return fail(MDF_ECAPACITY, "cnn_forward_dev: workspace too small");
-    hipStream_t st = static_cast<hipStream_t>(stream);
     Carver cv(workspace, workspace_bytes);
     float *pooled = cv.take<float>((size_t)B * m->Cpad);
-    int32_t *owner = cv.take<int32_t>((size_t)(R / 32));
-    const int n_groups = (int)(R / 32);
-    MDF_HIP(hipMemsetAsync(pooled, 0, (size_t)B * m->Cpad * 4, st));   // relu floor; channels C..Cpad stay zero
-    {
-        ScopedTiming tm(TK_CNN, st);
-        static const bool no_lds = getenv("MDFRI_CNN_NO_LDS") != nullptr;   // developer knob: force the cache form
-        const int n_lds = no_lds ? 0 : m->n_lds_tiles;
-        if (n_lds > 0) {
-            static bool attr_done = false;
-            if (!attr_done) {
-                MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cnn_conv_pool_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            CNN_LDS_MAX_K * 27 * 64 * 4));
-                attr_done = true;
-            }
-            MDF_HIP(hipMemsetAsync(owner, 0xff, (size_t)n_groups * 4, st));   // -1: group belongs to no protein
-            hipLaunchKernelGGL(k_cnn_group_owner, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, Lq, row_off, B, owner);
-            // workgroups per tile: each keeps the table in LDS and walks 32-row groups, 16 at a time
-            const int wgs = std::max(1, std::min((n_groups + 63) / 64, 256));
-            hipLaunchKernelGGL(k_cnn_conv_pool_lds, dim3((unsigned)wgs, (unsigned)n_lds), dim3(CNN_LDS_THREADS), (size_t)m->lds_bytes, st, seq_idx,
-                               Lq, row_off, owner, n_groups, m->tiles, m->bias, m->scale, m->shift, pooled, m->Cpad);
-            MDF_HIP(hipGetLastError());
-        }
-        if (m->n_tiles > n_lds) {
-            hipLaunchKernelGGL(k_cnn_conv_pool, dim3((unsigned)B, (unsigned)(m->n_tiles - n_lds)), dim3(256), 0, st, seq_idx, Lq, row_off,
-                               m->tiles + n_lds, m->bias, m->scale, m->shift, pooled, m->Cpad);
-            MDF_HIP(hipGetLastError());
-        }
-    }
-    ScopedTiming tm(TK_HEAD, st);
-    return launch_head_softmax2(pooled, m->Cpad, m->Wout_t, m->Cpad, B, m->n_out_pad, m->Cpad, scores, m->T, m->bout, st);
+    int32_t *owner = cv.take<int32_t>((size_t)(R / 32 + 1));
+    if (int rc = mdf_cnn_pool_dev(m, seq_idx, Lq, row_off, B, R, pooled, owner, align_up((size_t)(R / 32 + 1) * 4, 256), stream)) return rc;
+    return mdf_cnn_head_dev(m, pooled, B, scores, stream);
 }
 
 int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, int64_t *bad_idx)

@@ -89,6 +89,9 @@ SIGNATURES = {
     "mdf_cnn_channels": (c_int, [c_void_p]),
     "mdf_cnn_forward_host": (c_int, [c_void_p, c_char_p, c_int64, c_void_p, _i64p]),
     "mdf_cnn_workspace_bytes": (c_size_t, [c_void_p, c_int32, c_int64]),
+    "mdf_cnn_padded_channels": (c_int, [c_void_p]),
+    "mdf_cnn_pool_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_cnn_head_dev": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "mdf_cnn_forward_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdf_gcn_forward_host": (c_int, [c_void_p, c_char_p, c_int64, c_void_p, c_int, c_void_p, _i64p]),
     "mdf_layout_rows": (c_int64, [c_void_p, c_int32, c_void_p]),

@@ -574,20 +574,24 @@ class SequenceEngine:
         with torch.cuda.device(self.device):
             st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
             rows = pk.max_chunk_rows
-            nmax = max(ch.p1 - ch.p0 for ch in pk.chunks)
             seq_idx = torch.empty(rows, dtype=torch.uint8, device=self.device)
-            ws = torch.empty(max(self.L.mdf_cnn_workspace_bytes(p.session.handle, nmax, rows) for p in self.predictors.values()),
-                             dtype=torch.uint8, device=self.device)
+            ws = torch.empty((rows // 32 + 1) * 4 + 512, dtype=torch.uint8, device=self.device)
             out = {m: torch.empty((db.B, p.n_terms), dtype=torch.float32, device=self.device) for m, p in self.predictors.items()}
+            # conv + max pool chunk by chunk into one (B, C) array per head; the output layer then runs ONCE per head over all
+            # proteins (a 2 048-protein chunk is too few rows to fill the GEMM's 256-row tiles on 256 CUs)
+            cpad = {m: int(self.L.mdf_cnn_padded_channels(p.session.handle)) for m, p in self.predictors.items()}
+            pooled = {m: torch.empty((db.B, cpad[m]), dtype=torch.float32, device=self.device) for m in self.predictors}
             for ci, ch in enumerate(pk.chunks):
                 Bc = ch.p1 - ch.p0
                 ro = _p(db.chunk_row_off, ch.row_off_pos)
                 _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
                                                      _p(seq_idx), _p(db.bad, ci * 2), st))
                 for m, p in self.predictors.items():
-                    _hip.check(self.L.mdf_cnn_forward_dev(p.session.handle, _p(seq_idx), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
-                                                          _p(out[m], ch.p0 * p.n_terms), _p(ws), ws.numel(), st))
-            self._keep = (seq_idx, ws)
+                    _hip.check(self.L.mdf_cnn_pool_dev(p.session.handle, _p(seq_idx), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
+                                                       _p(pooled[m], ch.p0 * cpad[m]), _p(ws), ws.numel(), st))
+            for m, p in self.predictors.items():
+                _hip.check(self.L.mdf_cnn_head_dev(p.session.handle, _p(pooled[m]), db.B, _p(out[m]), st))
+            self._keep = (seq_idx, ws, pooled)
             return out
 
     def check(self, db: DeviceBatch):
