@@ -55,6 +55,9 @@ int mdf_pairwise_sqeuclidean_f32(const float *X, int64_t n, int64_t m, float *D,
  * out[e] = (D[e] < thr) ? 1 : 0 for `count` elements; thr is the already squared threshold as f32
  * (NumPy>=2 compares an f32 array with a Python float in f32). */
 int mdf_threshold_lt_i32(const float *D, int64_t count, float thr, int32_t *out);
+/* The same comparison in float64: what NumPy does for a float64 distance map, and for an integer or float16 one compared
+ * with a Python float (the binding converts those to float64, which is exact for them). */
+int mdf_threshold_lt_f64_i32(const double *D, int64_t count, double thr, int32_t *out);
 
 /* mDeepFRI/contact_map.py:88-95  ContactMap.sparsify  /  mDeepFRI/bio_utils.py:222-223
  * np.argwhere(cmap == 1).astype(int32): row-major sorted (N,2) index pairs of an (n,n) int32 matrix.
@@ -218,10 +221,11 @@ int64_t mdf_layout_rows(const int32_t *Lq, int32_t B, int32_t *row_off);
 
 /* Residue letters -> alphabet index per row (the sparse form of seq2onehot, predict.pyx:17-48).
  * seqs: packed query sequences, protein p at bytes [seq_off[p], seq_off[p]+Lq[p]); seq_idx: (R) uint8, 255 on
- * padding rows.  *bad (device int32[2], zero-initialised by the caller) receives {protein+1, position} of the
- * first invalid byte seen (any one of them if several). */
+ * padding rows.  *bad (ONE device int64, initialised to -1 by the caller) receives (protein << 32 | position) of the
+ * FIRST invalid byte -- lowest protein, then lowest position, as the reference's serial scan reports it
+ * (predict.pyx:36-46) -- by a 64-bit atomic minimum, or stays -1. */
 int mdf_seq_encode_dev(const char *seqs, const int32_t *seq_off, const int32_t *Lq, const int32_t *row_off,
-                       int32_t B, int64_t R, uint8_t *seq_idx, int32_t *bad, void *stream);
+                       int32_t B, int64_t R, uint8_t *seq_idx, int64_t *bad, void *stream);
 
 /* Fused contact-map stage for B proteins: C-alpha coords + gapped alignments -> normalised adjacency in CSR,
  * i.e. bio_utils.py:348-385 (a1+a2+a3) followed by GraphConv's normalisation

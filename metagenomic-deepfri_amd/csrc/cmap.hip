@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void k_pairwise_sqeuclidean(const float *__res
     }
 }
 
-__global__ void k_threshold_lt(const float *__restrict__ D, int64_t count, float thr, int32_t *__restrict__ out)
+template <typename T>
+__global__ void k_threshold_lt(const T *__restrict__ D, int64_t count, T thr, int32_t *__restrict__ out)
 {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (int64_t)gridDim.x * blockDim.x)
         out[e] = D[e] < thr ? 1 : 0;
@@ -570,7 +571,7 @@ __global__ void k_seq2onehot(const char *__restrict__ seq, int64_t L, float *__r
 
 __global__ void k_seq_encode(const char *__restrict__ seqs, const int32_t *__restrict__ seq_off,
                              const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off, int B,
-                             uint8_t *__restrict__ seq_idx, int32_t *__restrict__ bad)
+                             uint8_t *__restrict__ seq_idx, unsigned long long *__restrict__ bad)
 {
     const int p = blockIdx.x;
     const int r0 = row_off[p], r1 = row_off[p + 1], Lq = Lq_arr[p];
@@ -580,8 +581,9 @@ __global__ void k_seq_encode(const char *__restrict__ seqs, const int32_t *__res
         if (i < Lq) {
             c = aa_code((unsigned char)s[i]);
             if (c < 0) {
-                bad[0] = p + 1;
-                bad[1] = i;
+                // one 64-bit key per offender, smallest wins: lowest protein, then lowest position -- the byte the reference's
+                // serial scan reports first (predict.pyx:36-46), whatever the order in which threads get here
+                atomicMin(bad, ((unsigned long long)(unsigned)p << 32) | (unsigned)i);
                 c = 255;
             }
         }
@@ -655,6 +657,25 @@ static int argwhere_run(Pred pred, int64_t n, char *ws, int32_t *pairs, int64_t 
     return MDF_OK;
 }
 
+template <typename T>
+static int threshold_lt_host(const T *D, int64_t count, T thr, int32_t *out)
+{
+    MDF_REQUIRE(count >= 0 && ((D && out) || count == 0), "threshold_lt: bad arguments");
+    if (int rc = require_device()) return rc;
+    if (count == 0) return MDF_OK;
+    const size_t bi = (size_t)count * sizeof(T), bo = (size_t)count * 4;
+    Scratch &s = scratch(0);
+    if (int rc = s.reserve(align_up(bi, 256) + align_up(bo, 256))) return rc;
+    T *dD = static_cast<T *>(s.ptr);
+    int32_t *dO = reinterpret_cast<int32_t *>(static_cast<char *>(s.ptr) + align_up(bi, 256));
+    MDF_HIP(hipMemcpy(dD, D, bi, hipMemcpyHostToDevice));
+    const int blocks = (int)std::min<int64_t>((count + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_threshold_lt<T>, dim3(blocks), dim3(256), 0, 0, dD, count, thr, dO);
+    MDF_HIP(hipGetLastError());
+    MDF_HIP(hipMemcpy(out, dO, bo, hipMemcpyDeviceToHost));
+    return MDF_OK;
+}
+
 }  // namespace mdf
 
 using namespace mdf;
@@ -684,23 +705,8 @@ int mdf_pairwise_sqeuclidean_f32(const float *X, int64_t n, int64_t m, float *D,
     return MDF_OK;
 }
 
-int mdf_threshold_lt_i32(const float *D, int64_t count, float thr, int32_t *out)
-{
-    MDF_REQUIRE(count >= 0 && ((D && out) || count == 0), "threshold_lt: bad arguments");
-    if (int rc = require_device()) return rc;
-    if (count == 0) return MDF_OK;
-    const size_t b = (size_t)count * 4;
-    Scratch &s = scratch(0);
-    if (int rc = s.reserve(2 * align_up(b, 256))) return rc;
-    float *dD = static_cast<float *>(s.ptr);
-    int32_t *dO = reinterpret_cast<int32_t *>(static_cast<char *>(s.ptr) + align_up(b, 256));
-    MDF_HIP(hipMemcpy(dD, D, b, hipMemcpyHostToDevice));
-    const int blocks = (int)std::min<int64_t>((count + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_threshold_lt, dim3(blocks), dim3(256), 0, 0, dD, count, thr, dO);
-    MDF_HIP(hipGetLastError());
-    MDF_HIP(hipMemcpy(out, dO, b, hipMemcpyDeviceToHost));
-    return MDF_OK;
-}
+int mdf_threshold_lt_i32(const float *D, int64_t count, float thr, int32_t *out) { return threshold_lt_host<float>(D, count, thr, out); }
+int mdf_threshold_lt_f64_i32(const double *D, int64_t count, double thr, int32_t *out) { return threshold_lt_host<double>(D, count, thr, out); }
 
 int mdf_argwhere_eq1_i32(const int32_t *cmap, int64_t n, int32_t *pairs, int64_t capacity, int64_t *n_pairs)
 {
@@ -951,11 +957,12 @@ int mdf_seq2onehot(const char *seq, int64_t L, float *out, int64_t *bad_idx)
 }
 
 int mdf_seq_encode_dev(const char *seqs, const int32_t *seq_off, const int32_t *Lq, const int32_t *row_off, int32_t B,
-                       int64_t R, uint8_t *seq_idx, int32_t *bad, void *stream)
+                       int64_t R, uint8_t *seq_idx, int64_t *bad, void *stream)
 {
     if (int rc = check_layout(B, R)) return rc;
     MDF_REQUIRE(seqs && seq_off && Lq && row_off && seq_idx && bad, "seq_encode_dev: NULL argument");
-    hipLaunchKernelGGL(k_seq_encode, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), seqs, seq_off, Lq, row_off, B, seq_idx, bad);
+    hipLaunchKernelGGL(k_seq_encode, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), seqs, seq_off, Lq, row_off, B, seq_idx,
+                       reinterpret_cast<unsigned long long *>(bad));
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }

@@ -35,6 +35,7 @@ struct mdf_cnn {
     float *bout = nullptr;           // (n_out_pad)
     void *host_ws = nullptr;         // session scratch of mdf_cnn_forward_host
     size_t host_ws_bytes = 0;
+    std::mutex mu;                   // serialises mdf_cnn_forward_host (shared scratch, NULL stream)
 };
 
 namespace mdf {
@@ -282,11 +283,15 @@ int mdf_cnn_pool_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, cons
     static const bool no_lds = getenv("MDFRI_CNN_NO_LDS") != nullptr;   // developer knob: force the cache form
     const int n_lds = no_lds ? 0 : m->n_lds_tiles;
     if (n_lds > 0) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cnn_conv_pool_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        CNN_LDS_MAX_K * 27 * 64 * 4));
-            attr_done = true;
+        {
+            static PerDeviceOnce once;   // per-device function attribute
+            std::lock_guard<std::mutex> lk(once.mu);
+            bool &attr_done = once.done[current_device()];
+            if (!attr_done) {
+                MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cnn_conv_pool_lds), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            CNN_LDS_MAX_K * 27 * 64 * 4));
+                attr_done = true;
+            }
         }
         MDF_HIP(hipMemsetAsync(owner, 0xff, (size_t)n_groups * 4, st));   // -1: group belongs to no protein
         hipLaunchKernelGGL(k_cnn_group_owner, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, Lq, row_off, B, owner);
@@ -331,7 +336,9 @@ int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, 
     MDF_REQUIRE(L < (1 << 30), "cnn_forward_host: L=%lld too long", (long long)L);
     if (bad_idx) *bad_idx = -1;
     if (int rc = require_device()) return rc;
-    MDF_HIP(hipSetDevice(m->device));
+    std::lock_guard<std::mutex> session_lock(m->mu);   // one host-path call per model at a time (scratch, NULL stream)
+    DeviceGuard on_device(m->device);                   // restored on return
+    MDF_HIP(on_device.err);
     int32_t Lq[1] = {(int32_t)L}, row_off[2];
     const int64_t R = mdf_layout_rows(Lq, 1, row_off);
     if (R < 0) return (int)R;
@@ -348,9 +355,11 @@ int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, 
     }
     char *b = static_cast<char *>(m->host_ws);
     struct Desc {
-        int32_t Lq[2], row_off[2], seq_off[2], bad[2];
+        int32_t Lq[2], row_off[2], seq_off[2];
+        int64_t bad[1];
     } d;
     memset(&d, 0, sizeof(d));
+    d.bad[0] = -1;
     d.Lq[0] = (int32_t)L;
     d.row_off[0] = row_off[0];
     d.row_off[1] = row_off[1];
@@ -363,9 +372,10 @@ int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, 
     if (int rc = mdf_cnn_forward_dev(m, d_idx, dd->Lq, dd->row_off, 1, R, d_sc, b + o_ws, ws, nullptr)) return rc;
     Desc back;
     MDF_HIP(hipMemcpy(&back, b + o_desc, sizeof(back), hipMemcpyDeviceToHost));
-    if (back.bad[0] != 0) {
-        if (bad_idx) *bad_idx = back.bad[1];
-        return fail(MDF_EBADCHAR, "Invalid character in sequence at index %d", back.bad[1]);
+    if (back.bad[0] != -1) {
+        const long long pos = back.bad[0] & 0xffffffffLL;   // one protein: the key is the position of the first invalid byte
+        if (bad_idx) *bad_idx = pos;
+        return fail(MDF_EBADCHAR, "Invalid character in sequence at index %lld", pos);
     }
     MDF_HIP(hipMemcpy(scores, d_sc, (size_t)m->T * 4, hipMemcpyDeviceToHost));
     return MDF_OK;

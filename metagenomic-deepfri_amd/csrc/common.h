@@ -62,6 +62,35 @@ Scratch &scratch(int slot);  // a few independent slots per thread
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- device bookkeeping ---------------------------------------------------------------------------------------------
+constexpr int MDF_MAX_DEVICES = 64;
+inline int current_device()
+{
+    int d = 0;
+    return hipGetDevice(&d) == hipSuccess && d >= 0 && d < MDF_MAX_DEVICES ? d : 0;
+}
+// "Done once" flags keyed by device ordinal: function attributes (the dynamic-LDS limit) and the CU count belong to a
+// device, not to the process -- a second engine on another GPU of the same process must set them again.
+struct PerDeviceOnce {
+    std::mutex mu;
+    bool done[MDF_MAX_DEVICES] = {};
+};
+// Makes `device` current for the scope of a host (per-call) entry point and restores the caller's device on exit: the
+// per-call API must not change the current device of the thread that calls it (torch keeps its own notion of it).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) err = hipSetDevice(device); else prev = -1;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
 // Bump allocator over a caller-provided workspace.
 struct Carver {
     char *base;

@@ -19,6 +19,7 @@
 // Arithmetic is fp32 throughout (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains); the reference tolerance is 1e-4
 // absolute on the scores (north_star), checked against oracle/gcn_oracle.py (and oracle/lm_oracle.py).
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -42,9 +43,11 @@ struct mdf_model {
     float *T0 = nullptr;          // (32, embed)      rows < 26: W_aa[a] + b_lm, rows 26..31 zero
     float *Wgc1_t = nullptr;      // (gc0, embed)     W_gc1^T
     mdf_lm *lm = nullptr;         // attached language model (not owned), used by mdf_gcn_forward_host
-    // session scratch of mdf_gcn_forward_host (grown on demand)
+    // session scratch of mdf_gcn_forward_host (grown on demand); `mu` serialises the host path: the reference's
+    // session.run is thread-safe and ctypes releases the GIL, so two Python threads may call one Predictor concurrently
     void *host_ws = nullptr;
     size_t host_ws_bytes = 0;
+    std::mutex mu;
 };
 
 namespace mdf {
@@ -679,7 +682,7 @@ __device__ __forceinline__ void lstm_grid_barrier(unsigned *sync, unsigned phase
         unsigned spins = 0;
         while (__hip_atomic_load(sync + 32 * (18 + cls), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < phase) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 22) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+            if (++spins > (1u << 16) || __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                 __hip_atomic_store(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // give up loudly, never hang
                 break;
             }
@@ -822,7 +825,10 @@ __global__ __launch_bounds__(256) void k_lstm_persistent(const float *__restrict
 // ---- host side ----------------------------------------------------------------------------------------------------
 static int set_gemm_attr_once()
 {
-    static bool done = false;
+    static PerDeviceOnce once;   // the 128 KiB dynamic-LDS limit is a per-device function attribute
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(once.mu);
+    bool &done = once.done[dev];
     if (done) return MDF_OK;
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_ELU_POOL_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_ELU_POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
@@ -840,12 +846,15 @@ static int set_gemm_attr_once()
 // persistent grid: one 512-thread workgroup per CU (LDS: 128 KiB), a multiple of 8 so that block b stays on XCD b%8
 static int gemm_resident_blocks()
 {
-    static int n = 0;
+    static std::atomic<int> per_dev[MDF_MAX_DEVICES];   // zero-initialised; keyed by device ordinal (CU counts may differ)
+    const int dev = current_device();
+    int n = per_dev[dev].load(std::memory_order_relaxed);
     if (!n) {
-        int dev = 0, cus = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         n = std::max(8, cus / 8 * 8);
         if (const char *e = getenv("MDFRI_GEMM_BLOCKS")) n = std::max(8, atoi(e) / 8 * 8);  // developer override
+        per_dev[dev].store(n, std::memory_order_relaxed);
     }
     return n;
 }
@@ -963,6 +972,9 @@ struct mdf_lm {
     float *ktab1 = nullptr;                                  // (32, 4H)  W1[a] + b1, rows 26..31 zero
     float *kb2 = nullptr;                                    // (4H)
     unsigned *sync = nullptr;                                // barrier state, see lstm_grid_barrier
+    // One mdf_lm (one sync block, one s2 stream, one event ring) is shared by every GO head whose file carries the same
+    // LM weights; ctypes releases the GIL, so two threads may reach mdf_lm_forward_dev at once: serialised here.
+    std::mutex mu;
 };
 
 namespace mdf {
@@ -1197,6 +1209,7 @@ int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_r
     if (workspace_bytes < lm_ws_bytes(lm, B, Lmax))
         return fail(MDF_ECAPACITY, "lm_forward_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, lm_ws_bytes(lm, B, Lmax));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lm_lock(lm->mu);
     Carver cv(workspace, workspace_bytes);
     const size_t blk = (size_t)B * H;
     float *h1 = cv.take<float>((size_t)(Lmax + 1) * blk), *h2 = cv.take<float>((size_t)(Lmax + 1) * blk);
@@ -1216,10 +1229,11 @@ int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_r
         const char *e = getenv("MDFRI_LM_PERSISTENT_MAX_B");   // developer knob: 0 forces the GEMM form
         const int max_b = e ? std::min(atoi(e), LSTM_P_MAX_B) : LSTM_P_DEFAULT_B;
         bool fits = B <= max_b && (H == 64 || H == 128 || H == 256 || H == 512 || H == 1024);
+        const void *fn = nullptr;
         if (fits) {
             // every workgroup must be resident at once (device-wide barrier): grid <= CUs x workgroups per CU
             int per_cu = 0, cus = 0, dev = 0;
-            const void *fn = H == 64    ? reinterpret_cast<const void *>(&k_lstm_persistent<64>)
+            fn = H == 64    ? reinterpret_cast<const void *>(&k_lstm_persistent<64>)
                              : H == 128 ? reinterpret_cast<const void *>(&k_lstm_persistent<128>)
                              : H == 256 ? reinterpret_cast<const void *>(&k_lstm_persistent<256>)
                              : H == 512 ? reinterpret_cast<const void *>(&k_lstm_persistent<512>)
@@ -1232,15 +1246,25 @@ int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_r
         if (fits) {
             MDF_HIP(hipMemsetAsync(lm->sync, 0, LSTM_SYNC_WORDS * 4, st));
             {
+                // Cooperative launch: the runtime itself refuses a grid that cannot be co-resident (the occupancy estimate
+                // above is only valid on an idle GPU); a refused launch falls through to the per-step GEMM form.
                 ScopedTiming tm(TK_LSTM, st);
-#define MDF_LSTM_P(HH)                                                                                                          \
-    hipLaunchKernelGGL(k_lstm_persistent<HH>, dim3(HH / 2), dim3(256), 0, st, lm->kU1, lm->kW2, lm->kU2, lm->ktab1, lm->kb2, let_tm, \
-                       len_dev, B, Lmax, h1, h2, prot_row, h_out, lm->sync)
-                if (H == 64) MDF_LSTM_P(64); else if (H == 128) MDF_LSTM_P(128); else if (H == 256) MDF_LSTM_P(256);
-                else if (H == 512) MDF_LSTM_P(512); else MDF_LSTM_P(1024);
-#undef MDF_LSTM_P
-                MDF_HIP(hipGetLastError());
+                const float *aU1 = lm->kU1, *aW2 = lm->kW2, *aU2 = lm->kU2, *atab = lm->ktab1, *ab2 = lm->kb2;
+                const uint8_t *alet = let_tm;
+                int aB = B, aL = Lmax;
+                float *ah1 = h1, *ah2 = h2;
+                unsigned *async_ = lm->sync;
+                void *args[] = {&aU1, &aW2, &aU2, &atab, &ab2, &alet, &len_dev, &aB, &aL, &ah1, &ah2, &prot_row, &h_out, &async_};
+                const hipError_t le = hipLaunchCooperativeKernel(fn, dim3(H / 2), dim3(256), args, 0, st);
+                if (le == hipErrorCooperativeLaunchTooLarge || le == hipErrorLaunchOutOfResources) {
+                    (void)hipGetLastError();
+                    fits = false;
+                } else {
+                    MDF_HIP(le);
+                }
             }
+        }
+        if (fits) {
             // a handful of proteins: latency path, so waiting here costs nothing -- and a barrier that gave up must surface
             unsigned flags[1] = {0};
             MDF_HIP(hipMemcpyAsync(flags, lm->sync, sizeof(flags), hipMemcpyDeviceToHost, st));
@@ -1359,6 +1383,9 @@ int mdf_model_load(const char *path, int device, mdf_model **out)
     };
     const size_t esz = 32 + 4 + 8 * 5;
     if (12 + (size_t)n * esz > (size_t)sz) return fail(MDF_EIO, "model_load: truncated directory in '%s'", path);
+    // A container is untrusted input: every directory entry is validated before a pointer into `buf` is formed --
+    // rank 1..4, every dimension in 1..INT32_MAX, element count and byte range computed with overflow checks, data
+    // 4-byte aligned (it is read through a float pointer) and inside the file.
     auto find = [&](const char *name, Entry &e) -> bool {
         for (uint32_t i = 0; i < n; ++i) {
             const char *p = buf.data() + 12 + (size_t)i * esz;
@@ -1367,9 +1394,15 @@ int mdf_model_load(const char *path, int device, mdf_model **out)
                 memcpy(&e.ndim, p + 32, 4);
                 memcpy(e.dims, p + 36, 32);
                 memcpy(&e.offset, p + 68, 8);
+                if (e.ndim < 1 || e.ndim > 4) return false;
                 uint64_t cnt = 1;
-                for (uint32_t d = 0; d < e.ndim && d < 4; ++d) cnt *= e.dims[d];
-                return e.ndim >= 1 && e.ndim <= 4 && e.offset + cnt * 4 <= (uint64_t)sz;
+                for (uint32_t d = 0; d < e.ndim; ++d) {
+                    if (e.dims[d] == 0 || e.dims[d] > 0x7fffffffull) return false;
+                    if (__builtin_mul_overflow(cnt, e.dims[d], &cnt)) return false;
+                }
+                uint64_t bytes = 0, end = 0;
+                if (__builtin_mul_overflow(cnt, (uint64_t)4, &bytes) || __builtin_add_overflow(e.offset, bytes, &end)) return false;
+                return e.offset % 4 == 0 && e.offset >= 12 + (uint64_t)n * esz && end <= (uint64_t)sz;
             }
         }
         return false;
@@ -1487,7 +1520,9 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     MDF_REQUIRE(cmap_dtype >= MDF_DT_I32 && cmap_dtype <= MDF_DT_U8, "gcn_forward_host: unknown cmap dtype %d", cmap_dtype);
     if (bad_idx) *bad_idx = -1;
     if (int rc = require_device()) return rc;
-    MDF_HIP(hipSetDevice(m->device));
+    std::lock_guard<std::mutex> session_lock(m->mu);   // one host-path call per model at a time (scratch, NULL stream)
+    DeviceGuard on_device(m->device);                   // restored on return: the caller's current device is not ours to change
+    MDF_HIP(on_device.err);
     const int64_t es = cmap_dtype == MDF_DT_U8 ? 1 : (cmap_dtype == MDF_DT_I64 || cmap_dtype == MDF_DT_F64) ? 8 : 4;
     int32_t Lq[1] = {(int32_t)L}, row_off[2];
     const int64_t R = mdf_layout_rows(Lq, 1, row_off);
@@ -1512,10 +1547,11 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     }
     char *b = static_cast<char *>(m->host_ws);
     struct Desc {
-        int32_t Lq[2], row_off[2], seq_off[2], bad[2], status[4], grp_off[2];
-        int64_t cmap_off[1], prot_row[1];
+        int32_t Lq[2], row_off[2], seq_off[2], status[4], grp_off[2];
+        int64_t bad[1], cmap_off[1], prot_row[1];
     } d;
     memset(&d, 0, sizeof(d));
+    d.bad[0] = -1;
     d.Lq[0] = (int32_t)L;
     d.row_off[0] = row_off[0];
     d.row_off[1] = row_off[1];
@@ -1545,9 +1581,10 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     if (int rc = mdf_gcn_head_dev(m, d_pool, 1, d_sc, nullptr, b + o_hws, hws, nullptr)) return rc;
     Desc back;
     MDF_HIP(hipMemcpy(&back, b + o_desc, sizeof(back), hipMemcpyDeviceToHost));
-    if (back.bad[0] != 0) {
-        if (bad_idx) *bad_idx = back.bad[1];
-        return fail(MDF_EBADCHAR, "Invalid character in sequence at index %d", back.bad[1]);
+    if (back.bad[0] != -1) {
+        const long long pos = back.bad[0] & 0xffffffffLL;   // one protein: the key is the position of the first invalid byte
+        if (bad_idx) *bad_idx = pos;
+        return fail(MDF_EBADCHAR, "Invalid character in sequence at index %lld", pos);
     }
     if (back.status[0] != 0) return fail(MDF_ECAPACITY, "gcn_forward_host: CSR overflow (%d entries)", back.status[1]);
     MDF_HIP(hipMemcpy(scores, d_sc, (size_t)m->T * 4, hipMemcpyDeviceToHost));

@@ -128,10 +128,14 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
     MDF_REQUIRE(B > 0 && T > 0 && T <= FILTER_MAX_T, "filter_scores_dev: need B > 0 and 0 < T <= %d (B=%d, T=%d)", FILTER_MAX_T, B, T);
     MDF_REQUIRE(capacity > 0 && capacity < 0x7fffffff, "filter_scores_dev: capacity out of range");
     if (workspace_bytes < mdf_filter_workspace_bytes(B)) return fail(MDF_ECAPACITY, "filter_scores_dev: workspace too small");
-    static bool attr = false;
-    if (!attr) {
-        MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fill), hipFuncAttributeMaxDynamicSharedMemorySize, FILTER_MAX_T * 8));
-        attr = true;
+    {
+        static PerDeviceOnce once;   // per-device function attribute
+        std::lock_guard<std::mutex> lk(once.mu);
+        bool &attr = once.done[current_device()];
+        if (!attr) {
+            MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_filter_fill), hipFuncAttributeMaxDynamicSharedMemorySize, FILTER_MAX_T * 8));
+            attr = true;
+        }
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     int32_t *counts = static_cast<int32_t *>(workspace);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "mdf_device_count": (c_int, []),
     "mdf_pairwise_sqeuclidean_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int]),
     "mdf_threshold_lt_i32": (c_int, [c_void_p, c_int64, c_float, c_void_p]),
+    "mdf_threshold_lt_f64_i32": (c_int, [c_void_p, c_int64, c_double, c_void_p]),
     "mdf_argwhere_eq1_i32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, _i64p]),
     "mdf_calculate_contact_map": (c_int, [c_void_p, c_int64, c_double, c_void_p, c_void_p, c_int64, _i64p]),
     "mdf_align_len": (c_int, [c_char_p, c_char_p, c_int64, _i64p]),

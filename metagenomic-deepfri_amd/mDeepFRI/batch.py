@@ -197,11 +197,20 @@ class DeviceBatch:
             self.q_aln, self.t_aln, self.aln_off = up(packed.q_aln), up(packed.t_aln), up(packed.aln_off)
         n = len(packed.chunks)
         self.status = torch.zeros((n, 4), dtype=torch.int32, device=device)
-        self.bad = torch.zeros((n, 2), dtype=torch.int32, device=device)
+        self.bad = torch.full((n,), -1, dtype=torch.int64, device=device)   # per chunk: (protein << 32 | position) of the first invalid byte
 
     @property
     def B(self):
         return self.packed.B
+
+
+def first_invalid_residue(packed: PackedProteins, bad) -> None:
+    """Raise the reference's ValueError for the lowest (protein, position) flagged by mdf_seq_encode_dev, if any."""
+    for ci, ch in enumerate(packed.chunks):
+        key = int(bad[ci])
+        if key != -1:
+            p, pos = ch.p0 + (key >> 32), key & 0xffffffff
+            raise ValueError(f"Invalid character in sequence: {packed.seqs[p][pos]}")
 
 
 class HotPathEngine:
@@ -368,7 +377,7 @@ class HotPathEngine:
                     for k, ch in enumerate(chunks):
                         _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0),
                                                              _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows,
-                                                             _p(seq_all, bases[k]), _p(db.bad, (c0 + k) * 2), st))
+                                                             _p(seq_all, bases[k]), _p(db.bad, c0 + k), st))
                     feats = self._lm_forward(db, c0, c1, bases, seq_all, st)[id(lm)]
                     torch.cuda.current_stream(self.device).synchronize()
                     host = feats[:bases[-1] * lm.hidden].view(bases[-1], lm.hidden).cpu().numpy()
@@ -449,7 +458,7 @@ class HotPathEngine:
             def encode(ci, ch, seq_ptr):
                 _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0),
                                                      _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows, seq_ptr,
-                                                     _p(db.bad, ci * 2), st))
+                                                     _p(db.bad, ci), st))
 
             def build_csr(ci, ch):
                 Bc = ch.p1 - ch.p0
@@ -476,7 +485,7 @@ class HotPathEngine:
             def encode(ci, ch, seq_ptr):
                 _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0),
                                                      _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows, seq_ptr,
-                                                     _p(db.bad, ci * 2), st))
+                                                     _p(db.bad, ci), st))
 
             def build_csr(ci, ch):
                 Bc = ch.p1 - ch.p0
@@ -521,13 +530,10 @@ class HotPathEngine:
         self.raise_flags(db.packed, db.bad.cpu().numpy(), db.status.cpu().numpy())
 
     def raise_flags(self, packed: PackedProteins, bad, st):
-        """Turn the per-chunk device flags (host copies: bad (n_chunks, 2), status (n_chunks, 4)) into the exceptions the
-        per-call API raises."""
-        for ci, ch in enumerate(packed.chunks):
-            if bad[ci, 0] != 0:
-                p = ch.p0 + int(bad[ci, 0]) - 1
-                c = packed.seqs[p][int(bad[ci, 1])]
-                raise ValueError(f"Invalid character in sequence: {c}")
+        """Turn the per-chunk device flags (host copies: bad (n_chunks,) int64, status (n_chunks, 4)) into the exceptions the
+        per-call API raises.  Chunks hold consecutive proteins, so the first flagged chunk carries the first invalid byte of
+        the whole batch: what the reference's serial loop would have hit first (predict.pyx:36-46)."""
+        first_invalid_residue(packed, bad)
         if (st[:, 0] != 0).any():
             need = int(st[:, 1].max())
             raise _hip.CapacityError(_hip.MDF_ECAPACITY,
@@ -585,7 +591,7 @@ class SequenceEngine:
                 Bc = ch.p1 - ch.p0
                 ro = _p(db.chunk_row_off, ch.row_off_pos)
                 _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
-                                                     _p(seq_idx), _p(db.bad, ci * 2), st))
+                                                     _p(seq_idx), _p(db.bad, ci), st))
                 for m, p in self.predictors.items():
                     _hip.check(self.L.mdf_cnn_pool_dev(p.session.handle, _p(seq_idx), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
                                                        _p(pooled[m], ch.p0 * cpad[m]), _p(ws), ws.numel(), st))
@@ -597,11 +603,7 @@ class SequenceEngine:
     def check(self, db: DeviceBatch):
         torch = _torch()
         torch.cuda.current_stream(self.device).synchronize()
-        bad = db.bad.cpu().numpy()
-        for ci, ch in enumerate(db.packed.chunks):
-            if bad[ci, 0] != 0:
-                p = ch.p0 + int(bad[ci, 0]) - 1
-                raise ValueError(f"Invalid character in sequence: {db.packed.seqs[p][int(bad[ci, 1])]}")
+        first_invalid_residue(db.packed, db.bad.cpu().numpy())
 
     def run(self, seqs) -> dict:
         """Convenience: pack, upload, run, validate -> {mode: np.ndarray (B, T)}."""

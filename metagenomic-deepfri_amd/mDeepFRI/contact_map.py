@@ -64,13 +64,21 @@ class DistanceMap:
         _reject_unless(_mirror_image_equal(distance_map), "Distance map is not symmetric.")
 
     def calculate_contacts(self, threshold):
-        d = np.ascontiguousarray(self.distance_map)
-        if d.dtype != np.float32:
-            # the device compares in float32 -- exactly what NumPy >= 2 does for the float32 maps the distance kernel
-            # returns; any other dtype would silently change the precision of the comparison
-            raise ValueError(f"Buffer dtype mismatch, expected 'float32' but got '{d.dtype.name}'")
+        # reference contact_map.py:74: `(distance_map < threshold).astype(np.int32)` for a map of ANY dtype.  NumPy >= 2
+        # gives a Python-float threshold the dtype of a floating-point map (float32 for the maps the distance kernel
+        # returns, float16 -> the threshold is rounded to float16) and compares integer / bool maps in float64.  The device
+        # has a float32 and a float64 comparison; float16 / integer values are exact in float64.
+        d = np.asarray(self.distance_map)
+        if d.dtype.kind not in "fiub":
+            raise TypeError(f"'<' not supported between a distance map of dtype {d.dtype} and a threshold")
         flags = np.empty(d.shape, dtype=np.int32)
-        _hip.check(_hip.lib().mdf_threshold_lt_i32(_hip.ptr(d), d.size, np.float32(threshold), _hip.ptr(flags)))
+        if d.dtype == np.float32:
+            d = np.ascontiguousarray(d)
+            _hip.check(_hip.lib().mdf_threshold_lt_i32(_hip.ptr(d), d.size, np.float32(threshold), _hip.ptr(flags)))
+        else:
+            thr = float(d.dtype.type(threshold)) if d.dtype.kind == "f" and isinstance(threshold, (int, float)) else float(threshold)
+            d = np.ascontiguousarray(d, dtype=np.float64)
+            _hip.check(_hip.lib().mdf_threshold_lt_f64_i32(_hip.ptr(d), d.size, thr, _hip.ptr(flags)))
         return ContactMap(flags)
 
 

@@ -202,3 +202,54 @@ def test_insert_gaps_reference_kats_and_contract():
           AlignmentResult("q3", "AAT", "t3", "AATC", "MMMI", coords=np.zeros((4, 3), np.float32))]
     pk, keep = PackedProteins.from_alignments(rs)
     assert keep == [0, 2] and pk.seqs == ["AACT", "AAT"] and list(pk.Lq) == [4, 3] and list(pk.coord_off) == [0, 3, 7]
+
+
+def test_model_load_rejects_corrupt_containers(tmp_path):
+    """mdf_model_load treats a .mdfw as untrusted input: wrapped element counts, unaligned or out-of-file offsets, zero or
+    oversized dimensions and bad ranks must give MDF_EIO before any pointer into the file is formed (the checks run before
+    the device is needed, so this is a CPU test; a VALID file then fails with ENODEVICE here, not with EIO)."""
+    import struct
+    L = _hip.lib()
+    w = synthetic.glorot_gcn_weights(0, 8, embed=64, gc_dims=(256, 256, 256), fc_dim=256)
+    good = tmp_path / "good.mdfw"
+    weights.save_mdfw(str(good), w)
+    raw = bytearray(good.read_bytes())
+    entry = struct.Struct("<32sI4QQ")
+    names = [entry.unpack_from(raw, 12 + i * entry.size)[0].rstrip(b"\0").decode() for i in range(struct.unpack_from("<I", raw, 8)[0])]
+
+    def patched(name, **kw):
+        b = bytearray(raw)
+        at = 12 + names.index(name) * entry.size
+        nm, ndim, d0, d1, d2, d3, off = entry.unpack_from(b, at)
+        f = dict(ndim=ndim, d0=d0, d1=d1, d2=d2, d3=d3, off=off)
+        f.update(kw)
+        entry.pack_into(b, at, nm, f["ndim"], f["d0"], f["d1"], f["d2"], f["d3"], f["off"])
+        return bytes(b)
+
+    cases = {
+        "wrapping element count": patched("W_aa", d0=26, d1=2**62),                 # 26 * 2^62 * 4 wraps in u64
+        "dimension above INT32_MAX": patched("W_fc", d1=2**31),
+        "zero dimension": patched("W_gc2", d1=0),
+        "rank 0": patched("b_fc", ndim=0),
+        "rank 5": patched("b_fc", ndim=5),
+        "unaligned offset": patched("W_out", off=entry.unpack_from(raw, 12 + names.index("W_out") * entry.size)[6] + 2),
+        "offset past the end": patched("b_out", off=len(raw) + 4096),
+        "offset + size wraps": patched("b_out", off=2**64 - 4),
+        "offset inside the directory": patched("W_aa", off=16),
+        "truncated file": bytes(raw[:len(raw) // 2]),
+        "directory longer than the file": bytes(raw[:8]) + struct.pack("<I", 2**31) + bytes(raw[12:]),
+    }
+    for what, blob in cases.items():
+        p = tmp_path / "bad.mdfw"
+        p.write_bytes(blob)
+        h = ctypes.c_void_p()
+        rc = L.mdf_model_load(str(p).encode(), 0, ctypes.byref(h))
+        assert rc == _hip.MDF_EIO, (what, rc, _hip.last_error())
+        assert not h.value
+    h = ctypes.c_void_p()
+    rc = L.mdf_model_load(str(good).encode(), 0, ctypes.byref(h))
+    if _hip.device_count() == 0:
+        assert rc == _hip.MDF_ENODEVICE, _hip.last_error()
+    else:
+        assert rc == 0
+        L.mdf_model_free(h)

@@ -185,6 +185,26 @@ def test_contact_map_classes_reference_tests():
     assert np.array_equal(cm.sparsify(), np.argwhere(cm.cmap == 1).astype(np.int32))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.float16, np.int32, np.int64, np.uint8])
+def test_distance_map_calculate_contacts_accepts_any_real_dtype(dtype):
+    """reference contact_map.py:74 is `(distance_map < threshold).astype(int32)` for a map of any dtype; expected values are
+    NumPy's own comparison (float32 maps compare in float32, everything else in float64)."""
+    from mDeepFRI.contact_map import DistanceMap
+    rng = np.random.default_rng(12)
+    a = rng.random((70, 70)) * 80
+    d = ((a + a.T) / 2)
+    np.fill_diagonal(d, 0)
+    d = d.astype(dtype)
+    d[3, 5] = d[5, 3] = 36        # exactly on the threshold: strict '<' keeps it out
+    for thr in (36.0, 36.5, 6.0**2 + 1e-9):
+        got = DistanceMap(d).calculate_contacts(thr).cmap
+        assert got.dtype == np.int32 and np.array_equal(got, (d < thr).astype(np.int32)), (dtype, thr)
+    # a float64 map whose entries differ from the threshold only beyond float32 precision: must compare in float64
+    e = np.array([[0.0, 36.0 - 1e-12], [36.0 - 1e-12, 0.0]])
+    assert np.array_equal(DistanceMap(e).calculate_contacts(36.0).cmap, [[1, 1], [1, 1]])
+    assert np.array_equal(DistanceMap(e.astype(np.float32)).calculate_contacts(36.0).cmap, [[1, 0], [0, 1]])
+
+
 def test_seq2onehot_reference_tests_and_alphabet():
     # reference mDeepFRI/tests/test_predict.py:8-33
     from mDeepFRI.predict import seq2onehot

@@ -39,6 +39,38 @@ def test_predictor_public_surface(mf):
         pred.forward_pass("ACD", np.eye(4, dtype=np.int32))
 
 
+def test_invalid_residue_is_the_first_one_per_call(mf):
+    """reference predict.pyx:36-46 scans left to right and raises on the FIRST invalid byte; with several offenders the
+    device's 64-bit atomic minimum must report that one, whichever thread gets there first."""
+    _, pred = mf
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        pred.forward_pass("AJD*Z", np.eye(5, dtype=np.int32))
+    seq = "ACDE" * 200 + "*" + "j" * 300 + "J" * 200 + "ACD"
+    for _ in range(20):
+        with pytest.raises(ValueError, match=r"Invalid character in sequence: \*"):
+            pred.forward_pass(seq, np.eye(len(seq), dtype=np.int32))
+
+
+@pytest.mark.parametrize("max_rows", [128, 65536])
+def test_invalid_residue_in_a_batch_is_the_lowest_protein_lowest_position(mf, max_rows):
+    """Bad letters in proteins 7 and 3 (one chunk, and spread over several chunks): the batch reports protein 3's first one,
+    as the reference's serial loop over the proteins would."""
+    from mDeepFRI.batch import PackedProteins
+    _, pred = mf
+    prots = synthetic.synthetic_proteins(seed=8, count=12, length=(60, 120))
+    seqs = [p["seq"] for p in prots]
+    seqs[7] = "J" + seqs[7][1:]
+    s3 = list(seqs[3])
+    s3[40], s3[2], s3[17] = "x", "*", "j"
+    seqs[3] = "".join(s3)
+    eng = _engine({"mf": pred}, max_rows=max_rows)
+    pk = PackedProteins.pack(seqs, [p["coords"] for p in prots], seqs, seqs, max_rows=max_rows)
+    assert (len(pk.chunks) > 4) == (max_rows == 128)
+    for _ in range(5):
+        with pytest.raises(ValueError, match=r"Invalid character in sequence: \*"):
+            eng.run_alignments(pk)
+
+
 def test_forward_pass_golden_cases(gcn_golden, mf, cc):
     for n in [str(x) for x in gcn_golden["index/gcn"]]:
         w, pred = mf if "/mf_" in n else cc
@@ -123,7 +155,8 @@ def test_fused_batch_vs_oracle_and_per_call(mf, cc):
         # pre-softmax logits: tighter, saturation-proof check
         z64 = (im["f"] @ wm["W_out"].astype(np.float64) + wm["b_out"]).reshape(-1)
         assert np.max(np.abs(z_mf[i] - z64)) < 2e-3 * max(1.0, np.abs(z64).max()), i
-        assert np.max(np.abs(s_mf[i] - pm.forward_pass(p["seq"], cm))) < 2e-6, i
+        # the per-call drop-in runs the same kernels in the same summation order: identical, not merely close
+        assert np.array_equal(s_mf[i], pm.forward_pass(p["seq"], cm)), i
 
 
 def test_dense_batch_path_matches_per_call(mf):
