@@ -1,6 +1,10 @@
-"""Test helper: write ONNX ModelProto files with Google's protobuf encoder from a schema declared here (the public
-onnx.proto3 field numbers for the messages a tf2onnx export of the DeepFRI GCN uses).  Independent of
-mDeepFRI/onnx_reader.py, which decodes the wire format by hand."""
+"""Export weight dicts (mDeepFRI.weights) as ONNX ModelProto files: the op sequence of a tf2onnx export of the DeepFRI GCN /
+DeepCNN Keras models, with typed graph inputs/outputs, so that the files are (a) what mDeepFRI.onnx_reader must be able to
+read back and (b) runnable by a real onnxruntime -- bench.py does exactly that whenever `import onnxruntime` succeeds on the
+box, which makes ORT-CPU on these files the reference-configuration leg of the measurement (reference predict.pyx:62-73,98)
+and the first external check of oracle/gcn_oracle.py.  No `onnx` package is needed: the messages are encoded with Google's
+protobuf runtime from a schema declared here (the public onnx.proto3 field numbers).  Independent of mDeepFRI/onnx_reader.py,
+which decodes the wire format by hand."""
 import numpy as np
 from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
 
@@ -31,7 +35,11 @@ def _schema():
                            ("strings", 9, _F.TYPE_BYTES, R, None), ("type", 20, _F.TYPE_INT32, O, None)])
     msg("NodeProto", [("input", 1, _F.TYPE_STRING, R, None), ("output", 2, _F.TYPE_STRING, R, None), ("name", 3, _F.TYPE_STRING, O, None),
                       ("op_type", 4, _F.TYPE_STRING, O, None), ("attribute", 5, _F.TYPE_MESSAGE, R, "AttributeProto")])
-    msg("ValueInfoProto", [("name", 1, _F.TYPE_STRING, O, None)])
+    msg("Dimension", [("dim_value", 1, _F.TYPE_INT64, O, None), ("dim_param", 2, _F.TYPE_STRING, O, None)])
+    msg("TensorShapeProto", [("dim", 1, _F.TYPE_MESSAGE, R, "Dimension")])
+    msg("TypeTensor", [("elem_type", 1, _F.TYPE_INT32, O, None), ("shape", 2, _F.TYPE_MESSAGE, O, "TensorShapeProto")])
+    msg("TypeProto", [("tensor_type", 1, _F.TYPE_MESSAGE, O, "TypeTensor")])
+    msg("ValueInfoProto", [("name", 1, _F.TYPE_STRING, O, None), ("type", 2, _F.TYPE_MESSAGE, O, "TypeProto")])
     msg("GraphProto", [("node", 1, _F.TYPE_MESSAGE, R, "NodeProto"), ("name", 2, _F.TYPE_STRING, O, None),
                        ("initializer", 5, _F.TYPE_MESSAGE, R, "TensorProto"), ("input", 11, _F.TYPE_MESSAGE, R, "ValueInfoProto"),
                        ("output", 12, _F.TYPE_MESSAGE, R, "ValueInfoProto")])
@@ -62,12 +70,25 @@ class GraphBuilder:
         self._n += 1
         return f"{stem}:{self._n}"
 
-    def input(self, name):
-        self.g.input.add().name = name
+    @staticmethod
+    def _typed(vi, name, shape):
+        """float32 tensor value info; `shape` entries are ints or symbolic names (TypeProto.Tensor, onnx.proto3)."""
+        vi.name = name
+        if shape is not None:
+            vi.type.tensor_type.elem_type = 1
+            for d in shape:
+                dim = vi.type.tensor_type.shape.dim.add()
+                if isinstance(d, str):
+                    dim.dim_param = d
+                else:
+                    dim.dim_value = int(d)
+
+    def input(self, name, shape=None):
+        self._typed(self.g.input.add(), name, shape)
         return name
 
-    def output(self, name):
-        self.g.output.add().name = name
+    def output(self, name, shape=None):
+        self._typed(self.g.output.add(), name, shape)
 
     def const(self, arr, stem="const", raw=True):
         arr = np.asarray(arr)
@@ -137,7 +158,7 @@ def deepfri_gcn_model(w: dict, raw=True, use_gemm_head=False) -> bytes:
     """An ONNX graph with the op sequence tf2onnx emits for the DeepFRI GCN (Keras functional model: LSTM language model,
     AA/LM embeddings, GraphConv layers with adjacency normalisation, sum pooling, dense head, pair softmax)."""
     b = GraphBuilder()
-    cmap, seq = b.input("cmap"), b.input("seq")
+    cmap, seq = b.input("cmap", [1, "L", "L"]), b.input("seq", [1, "L", 26])   # the two feeds of predict.pyx:82-90
     x_aa = b.node("MatMul", [seq, b.const(w["W_aa"], "AA_embedding/kernel", raw)])
     if "lm_W1" in w:
         h = b.node("Transpose", [seq], perm=[1, 0, 2])
@@ -150,16 +171,19 @@ def deepfri_gcn_model(w: dict, raw=True, use_gemm_head=False) -> bytes:
         x_lm = b.node("Add", [b.node("MatMul", [h, b.const(w["W_lm"], "LM_embedding/kernel", raw)]), b.const(w["b_lm"], "LM_embedding/bias", raw)])
         x_aa = b.node("Add", [x_lm, x_aa])
     x = b.node("Relu", [x_aa])
-    # adjacency normalisation (constants that are NOT weights: eps, ones) -- the reader must ignore them
-    eye = b.node("EyeLike", [cmap])
-    a_hat = b.node("Add", [b.node("Sub", [cmap, b.node("Mul", [cmap, eye])]), eye])
-    deg = b.node("ReduceSum", [a_hat, b.const(np.array([2], np.int64), "axes", raw)], keepdims=0)
+    # adjacency normalisation of GraphConv, arithmetically complete (constants that are NOT weights -- eps, one, axes -- must be
+    # ignored by the reader):  A' = A - A*I + I;  d = 1 / (sqrt(rowsum A') + 1e-6);  Ahat = diag(d) A' diag(d)
+    a2 = b.node("Squeeze", [cmap, b.const(np.array([0], np.int64), "axes", raw)])                   # (L, L): EyeLike wants rank 2
+    eye = b.node("EyeLike", [a2])
+    a_hat = b.node("Add", [b.node("Sub", [a2, b.node("Mul", [a2, eye])]), eye])
+    deg = b.node("ReduceSum", [a_hat, b.const(np.array([1], np.int64), "axes", raw)], keepdims=1)    # (L, 1)
     dinv = b.node("Div", [b.const(np.array(1.0, np.float32), "one", raw),
                           b.node("Add", [b.node("Sqrt", [deg]), b.const(np.array(1e-6, np.float32), "eps", raw)])])
+    a_norm = b.node("Mul", [b.node("Mul", [a_hat, dinv]), b.node("Transpose", [dinv], perm=[1, 0])])  # rows, then columns
+    a_norm = b.node("Unsqueeze", [a_norm, b.const(np.array([0], np.int64), "axes", raw)])            # (1, L, L)
     feats, k = [], 1
     while f"W_gc{k}" in w:
-        ax = b.node("MatMul", [a_hat, x])      # (simplified: the diag scalings are element-wise ops on dinv)
-        ax = b.node("Mul", [ax, dinv])
+        ax = b.node("MatMul", [a_norm, x])                                                           # batch_dot(Ahat, H)
         x = b.node("Elu", [b.node("MatMul", [ax, b.const(w[f"W_gc{k}"], f"GraphConv_{k}/kernel", raw)])], alpha=1.0)
         feats.append(x)
         k += 1
@@ -171,7 +195,7 @@ def deepfri_gcn_model(w: dict, raw=True, use_gemm_head=False) -> bytes:
         f = b.node("Relu", [b.node("Add", [b.node("MatMul", [pooled, b.const(w["W_fc"], "dense/kernel", raw)]), b.const(w["b_fc"], "dense/bias", raw)])])
     z = b.node("Add", [b.node("MatMul", [f, b.const(w["W_out"], "labels/kernel", raw)]), b.const(w["b_out"], "labels/bias", raw)])
     z = b.node("Reshape", [z, b.const(np.array([-1, w["W_out"].shape[1] // 2, 2], np.int64), "shape", raw)])
-    b.output(b.node("Softmax", [z], axis=-1))
+    b.output(b.node("Softmax", [z], axis=-1), [1, w["W_out"].shape[1] // 2, 2])
     return b.serialize()
 
 
@@ -180,7 +204,7 @@ def deepcnn_model(w: dict, conv2d_form=False, explicit_pads=False) -> bytes:
     one-hot sequence, concat, BatchNormalization, relu, global max pool, FuncPredictor).  conv2d_form: kernels as (F,C,1,k)
     the way tf2onnx lowers Conv1D through Conv2D; explicit_pads: `pads` attribute instead of auto_pad=SAME_UPPER."""
     b = GraphBuilder()
-    seq = b.input("seq")
+    seq = b.input("seq", [1, "L", 26])
     x = b.node("Transpose", [seq], perm=[0, 2, 1])
     if conv2d_form:
         x = b.node("Unsqueeze", [x, b.const(np.array([2], np.int64), "axes")])
@@ -206,5 +230,5 @@ def deepcnn_model(w: dict, conv2d_form=False, explicit_pads=False) -> bytes:
     pooled = b.node("Flatten", [pooled], axis=1)
     z = b.node("Add", [b.node("MatMul", [pooled, b.const(w["W_out"], "labels/kernel")]), b.const(w["b_out"], "labels/bias")])
     z = b.node("Reshape", [z, b.const(np.array([-1, w["W_out"].shape[1] // 2, 2], np.int64), "shape")])
-    b.output(b.node("Softmax", [z], axis=-1))
+    b.output(b.node("Softmax", [z], axis=-1), [1, w["W_out"].shape[1] // 2, 2])
     return b.serialize()

@@ -30,111 +30,164 @@ def partition_by_cost(lengths, world_size: int):
 
 
 def gather_scores(local_scores, local_index, total: int, dst: int = 0, group=None):
-    """Gather per-rank score blocks to `dst` and restore the original protein order.
+    """Gather per-rank score blocks to `dst` and restore the original protein order (one-shot form of DenseGatherPlan).
 
     local_scores: torch tensor (n_local, T) on this rank's device (CUDA for nccl, CPU for gloo);
     local_index:  the global protein indices of its rows (sequence of ints);  total: global protein count.
     Returns the (total, T) tensor on `dst`, None elsewhere.  Shards are padded to the largest shard so that a single
     fixed-size gather is issued (7 peers write into rank 0 over 7 distinct xGMI links in parallel)."""
-    import torch
-    import torch.distributed as dist
-
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        out = torch.empty((total, local_scores.shape[1]), dtype=local_scores.dtype, device=local_scores.device)
-        out[torch.as_tensor(list(local_index), dtype=torch.long, device=local_scores.device)] = local_scores
-        return out
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if dist.get_backend(group) == "gloo" and local_scores.is_cuda:
-        local_scores = local_scores.cpu()  # gloo has no device gather; RCCL ("nccl") gathers in HBM over xGMI
-    dev = local_scores.device
-    n_local, T = local_scores.shape
-    counts = torch.zeros(world, dtype=torch.long, device=dev)
-    counts[rank] = n_local
-    dist.all_reduce(counts, group=group)          # tiny: agree on shard sizes
-    n_max = int(counts.max().item())
-    payload = torch.zeros((n_max, T), dtype=local_scores.dtype, device=dev)
-    payload[:n_local] = local_scores
-    idx = torch.full((n_max,), -1, dtype=torch.long, device=dev)
-    idx[:n_local] = torch.as_tensor(list(local_index), dtype=torch.long, device=dev)
-    if rank == dst:
-        bufs = [torch.empty_like(payload) for _ in range(world)]
-        ibufs = [torch.empty_like(idx) for _ in range(world)]
-    else:
-        bufs = ibufs = None
-    dist.gather(payload, bufs, dst=dst, group=group)
-    dist.gather(idx, ibufs, dst=dst, group=group)
-    if rank != dst:
-        return None
-    out = torch.empty((total, T), dtype=local_scores.dtype, device=dev)
-    for b, i in zip(bufs, ibufs):
-        keep = i >= 0
-        out[i[keep]] = b[keep]
-    return out
+    return DenseGatherPlan(local_scores.shape[0], local_scores.shape[1], local_index, total, local_scores.device,
+                           dtype=local_scores.dtype, dst=dst, group=group).run(local_scores)
 
 
 def gather_filtered(offsets, term_idx, kept, local_index, total: int, dst: int = 0, group=None):
     """Gather the COMPACTED output of the ranks (mDeepFRI.output.filter_scores: per local protein the terms with score >=
     threshold, sorted as results.tsv wants them) instead of the dense (n_local, T) score blocks: a few dozen (term, score)
-    pairs per protein leave each GPU, ~100x less than the dense rows.
+    pairs per protein leave each GPU, ~100x less than the dense rows.  One-shot form of
+    FilteredGatherPlan.
 
     offsets (n_local+1) int32, term_idx (nnz) int32, kept (nnz) float32: torch tensors of this rank (CUDA for nccl);
     local_index: global protein index of each local row.  Returns (offsets (total+1) int32, term_idx, kept) in global
-    protein order on `dst`, None elsewhere.  Two tiny collectives agree on the padded sizes, then one gather per array."""
-    import torch
-    import torch.distributed as dist
+    protein order on `dst`, None elsewhere."""
+    return FilteredGatherPlan(local_index, total, offsets.device, dst=dst, group=group).run(offsets, term_idx, kept)
 
-    dev = offsets.device
-    cnt = (offsets[1:] - offsets[:-1]).to(torch.int64)
-    gidx = torch.as_tensor(list(local_index), dtype=torch.long, device=dev)
 
-    def assemble(blocks):
-        counts = torch.zeros(total, dtype=torch.int64, device=blocks[0][0].device)
-        for i, c, _, _ in blocks:
-            counts[i] = c
-        goff = torch.zeros(total + 1, dtype=torch.int64, device=counts.device)
+class DenseGatherPlan:
+    """Everything about the dense gather that does not depend on the scores, computed ONCE: shard sizes (one tiny
+    all_gather), the padded payload / receive buffers, and on `dst` the row index that puts every rank's rows back into
+    input order.  `run(block)` is then: copy into the payload, ONE dist.gather, one index_copy_ -- no host sync, no
+    Python loop over proteins or ranks' rows (bench.py keeps the plan across steps)."""
+
+    def __init__(self, n_local: int, width: int, local_index, total: int, device, dtype=None, dst: int = 0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dst, self.group, self.total, self.width = dst, group, int(total), int(width)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        dtype = dtype or torch.float32
+        self.via_host = self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+        dev = torch.device("cpu") if self.via_host else torch.device(device)   # gloo has no device gather; RCCL gathers in HBM
+        self.dev, self.n_local = dev, int(n_local)
+        idx = torch.as_tensor(np.asarray(list(local_index), dtype=np.int64), device=dev)
+        if self.world == 1:
+            self.order = idx
+            self.out = torch.empty((self.total, self.width), dtype=dtype, device=dev)
+            return
+        counts = torch.zeros(self.world, dtype=torch.long, device=dev)
+        counts[self.rank] = self.n_local
+        dist.all_reduce(counts, group=group)                   # once per plan: agree on shard sizes
+        self.counts = [int(c) for c in counts.tolist()]
+        self.n_max = max(max(self.counts), 1)
+        self.payload = torch.zeros((self.n_max, self.width), dtype=dtype, device=dev)
+        pad_idx = torch.full((self.n_max,), -1, dtype=torch.long, device=dev)
+        pad_idx[:self.n_local] = idx
+        is_dst = self.rank == dst
+        ibufs = [torch.empty_like(pad_idx) for _ in range(self.world)] if is_dst else None
+        dist.gather(pad_idx, ibufs, dst=dst, group=group)      # once per plan: who owns which input row
+        self.recv = self.out = self.src_rows = self.dst_rows = None
+        if is_dst:
+            self.recv = torch.empty((self.world, self.n_max, self.width), dtype=dtype, device=dev)
+            self.recv_list = list(self.recv.unbind(0))
+            flat = torch.stack(ibufs).reshape(-1)
+            self.src_rows = torch.nonzero(flat >= 0).reshape(-1)
+            self.dst_rows = flat[self.src_rows]
+            self.out = torch.empty((self.total, self.width), dtype=dtype, device=dev)
+
+    def run(self, block):
+        """block: (n_local, width) scores of this rank.  Returns the (total, width) tensor in input order on `dst`, None
+        elsewhere.  Asynchronous on the device for the nccl backend."""
+        import torch.distributed as dist
+        if self.world == 1:
+            self.out.index_copy_(0, self.order, block.to(self.dev))
+            return self.out
+        if self.n_local:
+            self.payload[:self.n_local].copy_(block, non_blocking=True)
+        dist.gather(self.payload, self.recv_list if self.rank == self.dst else None, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        self.out.index_copy_(0, self.dst_rows, self.recv.reshape(-1, self.width).index_select(0, self.src_rows))
+        return self.out
+
+
+class FilteredGatherPlan:
+    """The compacted gather (gather_filtered) with its host work hoisted: the first `run` agrees on the sizes (it has to
+    read the survivor counts back once); later runs reuse padded buffers with 25 % headroom and touch the host only if a
+    rank's survivors outgrow them (flagged by the sizes exchanged on the device, re-planned on the next call).
+    Output as gather_filtered: (offsets (total+1) int32, term_idx, kept) in input order on `dst`."""
+
+    def __init__(self, local_index, total: int, device, dst: int = 0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.dst, self.group, self.total = dst, group, int(total)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.via_host = self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
+        self.dev = torch.device("cpu") if self.via_host else torch.device(device)
+        self.local_index = list(local_index)
+        self.z_cap = 0
+        self.dense = DenseGatherPlan(len(self.local_index), 1, self.local_index, total, self.dev, dtype=torch.int64, dst=dst, group=group)
+
+    def run(self, offsets, term_idx, kept):
+        import torch
+        import torch.distributed as dist
+        cnt = (offsets[1:] - offsets[:-1]).to(torch.int64).to(self.dev)
+        term_idx, kept = term_idx.to(self.dev), kept.to(self.dev)
+        if self.world == 1:
+            counts = self.dense.run(cnt.reshape(-1, 1)).reshape(-1)
+            goff = torch.zeros(self.total + 1, dtype=torch.int64, device=self.dev)
+            torch.cumsum(counts, 0, out=goff[1:])
+            return _place_filtered(goff, [(self.dense.order, cnt, term_idx, kept)], self.dev)
+        z = int(term_idx.numel())
+        if self.z_cap == 0 or z > self.z_cap:               # first call (or outgrown): agree on a padded size, with headroom
+            zs = torch.zeros(self.world, dtype=torch.long, device=self.dev)
+            zs[self.rank] = z
+            dist.all_reduce(zs, group=self.group)
+            self.z_cap = max(int(zs.max().item()) * 5 // 4, 1)
+            self.t_pay = torch.zeros(self.z_cap, dtype=torch.int32, device=self.dev)
+            self.s_pay = torch.zeros(self.z_cap, dtype=torch.float32, device=self.dev)
+            if self.rank == self.dst:
+                self.t_recv = [torch.empty_like(self.t_pay) for _ in range(self.world)]
+                self.s_recv = [torch.empty_like(self.s_pay) for _ in range(self.world)]
+        # NOTE: a rank whose survivors outgrow z_cap between calls re-plans on its own next call; all ranks see the same data
+        # every step in bench.py, and predict_sharded_filtered builds a fresh plan per call.
+        counts = self.dense.run(cnt.reshape(-1, 1))          # per-protein survivor counts in input order (dst only)
+        self.t_pay[:z].copy_(term_idx, non_blocking=True)
+        self.s_pay[:z].copy_(kept, non_blocking=True)
+        is_dst = self.rank == self.dst
+        dist.gather(self.t_pay, self.t_recv if is_dst else None, dst=self.dst, group=self.group)
+        dist.gather(self.s_pay, self.s_recv if is_dst else None, dst=self.dst, group=self.group)
+        if not is_dst:
+            return None
+        counts = counts.reshape(-1)
+        goff = torch.zeros(self.total + 1, dtype=torch.int64, device=self.dev)
         torch.cumsum(counts, 0, out=goff[1:])
-        n = int(goff[-1].item())
-        out_t = torch.empty(n, dtype=torch.int32, device=counts.device)
-        out_s = torch.empty(n, dtype=torch.float32, device=counts.device)
-        for i, c, t, s in blocks:
-            if t.numel() == 0:
-                continue
-            lo = torch.cumsum(c, 0) - c                                   # start of each protein inside the rank's payload
-            dest = torch.repeat_interleave(goff[i] - lo, c) + torch.arange(t.numel(), device=t.device)
-            out_t[dest] = t
-            out_s[dest] = s
-        return goff.to(torch.int32), out_t, out_s
+        d = self.dense
+        blocks, flat_rows = [], d.dst_rows
+        start = 0
+        for r in range(self.world):
+            n_r = d.counts[r]
+            rows = flat_rows[start:start + n_r]
+            start += n_r
+            blocks.append((rows, counts[rows], self.t_recv[r], self.s_recv[r]))
+        return _place_filtered(goff, blocks, self.dev)
 
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return assemble([(gidx, cnt, term_idx, kept)])
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    if dist.get_backend(group) == "gloo" and dev.type == "cuda":
-        cnt, gidx, term_idx, kept = cnt.cpu(), gidx.cpu(), term_idx.cpu(), kept.cpu()   # gloo has no device gather
-        dev = cnt.device
-    sizes = torch.zeros((world, 2), dtype=torch.long, device=dev)
-    sizes[rank, 0], sizes[rank, 1] = cnt.numel(), term_idx.numel()
-    dist.all_reduce(sizes, group=group)
-    n_max, z_max = int(sizes[:, 0].max().item()), max(int(sizes[:, 1].max().item()), 1)
 
-    def pad(x, n, fill, dtype):
-        out = torch.full((n,), fill, dtype=dtype, device=dev)
-        out[:x.numel()] = x
-        return out
-
-    payload = [pad(gidx, n_max, -1, torch.long), pad(cnt, n_max, 0, torch.long), pad(term_idx, z_max, 0, torch.int32),
-               pad(kept, z_max, 0, torch.float32)]
-    got = []
-    for x in payload:
-        bufs = [torch.empty_like(x) for _ in range(world)] if rank == dst else None
-        dist.gather(x, bufs, dst=dst, group=group)
-        got.append(bufs)
-    if rank != dst:
-        return None
-    blocks = []
-    for r in range(world):
-        n_r, z_r = int(sizes[r, 0].item()), int(sizes[r, 1].item())
-        blocks.append((got[0][r][:n_r], got[1][r][:n_r], got[2][r][:z_r], got[3][r][:z_r]))
-    return assemble(blocks)
+def _place_filtered(goff, blocks, dev):
+    """Scatter per-rank compacted payloads into global protein order.  blocks: (global rows of the rank's proteins in payload
+    order, their counts, term payload, score payload); payloads may carry padding behind the rank's survivors."""
+    import torch
+    n = int(goff[-1].item())
+    out_t = torch.empty(n, dtype=torch.int32, device=dev)
+    out_s = torch.empty(n, dtype=torch.float32, device=dev)
+    for rows, c, t, s in blocks:
+        z = int(c.sum().item())
+        if z == 0:
+            continue
+        lo = torch.cumsum(c, 0) - c                                   # start of each protein inside the rank's payload
+        dest = torch.repeat_interleave(goff[rows] - lo, c) + torch.arange(z, device=dev)
+        out_t[dest] = t[:z]
+        out_s[dest] = s[:z]
+    return goff.to(torch.int32), out_t, out_s
 
 
 def predict_sharded(engine, seqs, coords, q_alns, t_alns, modes=None, dst: int = 0, group=None, max_rows: int = 65536):
@@ -161,7 +214,7 @@ def predict_sharded(engine, seqs, coords, q_alns, t_alns, modes=None, dst: int =
         block = torch.cat([out[m] for m in modes], dim=1)
     else:
         block = torch.zeros((0, sum(widths)), dtype=torch.float32, device=engine.device)
-    full = gather_scores(block, mine, total=n, dst=dst, group=group)
+    full = DenseGatherPlan(len(mine), sum(widths), mine, n, engine.device, dst=dst, group=group).run(block)
     if full is None:
         return None
     res, c = {}, 0
@@ -201,5 +254,5 @@ def predict_sharded_filtered(engine, seqs, coords, q_alns, t_alns, threshold: fl
             off = torch.zeros(1, dtype=torch.int32, device=engine.device)
             ti = torch.zeros(0, dtype=torch.int32, device=engine.device)
             kept = torch.zeros(0, dtype=torch.float32, device=engine.device)
-        res[m] = gather_filtered(off, ti, kept, mine, total=n, dst=dst, group=group)
+        res[m] = FilteredGatherPlan(mine, n, engine.device, dst=dst, group=group).run(off, ti, kept)
     return res if rank == dst else None

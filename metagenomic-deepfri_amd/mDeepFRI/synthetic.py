@@ -135,3 +135,65 @@ def synthetic_proteins(seed: int, count: int, length, indel_rate: float = 0.0):
         coords = random_walk_coords(rng, lt)
         out.append({"id": f"syn{seed}_{i}", "seq": seq, "coords": coords, "q_aln": q_aln, "t_aln": t_aln})
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Large workloads (BASELINE.json configs[3] / configs[4]): vectorised per protein, and seeded per protein so that every rank of
+# a sharded run can generate exactly its own shard (lengths are drawn first, from one stream, so that all ranks agree on them).
+# ---------------------------------------------------------------------------------------------------------------------
+_AA20_BYTES = np.frombuffer(AA20.encode(), dtype=np.uint8)
+
+
+def uniform_lengths(seed: int, count: int, lo: int = 128, hi: int = 1024) -> np.ndarray:
+    """configs[3]: L ~ U{lo..hi} (inclusive)."""
+    return np.random.default_rng(seed).integers(lo, hi + 1, size=count).astype(np.int32)
+
+
+def histogram_lengths(seed: int, count: int) -> np.ndarray:
+    """configs[4]: lengths drawn from the empirical length histogram of the reference's test proteome
+    (mDeepFRI/tests/data/GCA_000731455.1.proteins.fa.gz, clipped to [30, 2048]; data/gca_000731455_length_hist.json, made by
+    tools/make_length_histogram.py): a bin by its frequency, then uniform inside the 8-residue bin."""
+    import json
+    import os
+    h = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "gca_000731455_length_hist.json")))
+    counts = np.asarray(h["counts"], dtype=np.float64)
+    rng = np.random.default_rng(seed)
+    bins = rng.choice(len(counts), size=count, p=counts / counts.sum())
+    L = h["first_bin_start"] + bins * h["bin_width"] + rng.integers(0, h["bin_width"], size=count)
+    return np.clip(L, h["clip"][0], h["clip"][1]).astype(np.int32)
+
+
+def bulk_protein(seed: int, index: int, length: int, indel_rate: float = 0.0):
+    """One synthetic protein, same distribution as synthetic_proteins(): (seq, coords (Lt,3) f32, gapped query, gapped target).
+    The generator is seeded by (seed, index): independent of which rank asks and of the order in which proteins are made."""
+    rng = np.random.default_rng([int(seed), int(index)])
+    L = int(length)
+    res = _AA20_BYTES[rng.integers(0, 20, size=L)]
+    seq = res.tobytes().decode()
+    if indel_rate > 0:
+        extra = rng.random(L) < indel_rate          # an extra target residue (query gap) in front of residue i
+        ins = rng.random(L) < indel_rate            # residue i is an insertion (target gap)
+        pos = np.arange(L) + np.cumsum(extra)       # alignment column of residue i
+        q = np.full(L + int(extra.sum()), 45, dtype=np.uint8)
+        t = q.copy()
+        q[pos] = res
+        t[pos] = np.where(ins, 45, res)
+        t[pos[extra] - 1] = _AA20_BYTES[rng.integers(0, 20, size=int(extra.sum()))]
+        lt = len(q) - int(ins.sum())
+        q_aln, t_aln = q.tobytes().decode(), t.tobytes().decode()
+    else:
+        q_aln = t_aln = seq
+        lt = L
+    v = rng.standard_normal((lt, 3))
+    v /= np.linalg.norm(v, axis=1, keepdims=True) + 1e-12
+    coords = np.round(np.cumsum(v * 3.8, axis=0), 3).astype(np.float32)
+    return seq, coords, q_aln, t_aln
+
+
+def bulk_proteins(seed: int, lengths, indices, indel_rate: float = 0.0):
+    """Columns (seqs, coords, q_alns, t_alns) for the proteins `indices` of a workload whose lengths are `lengths`."""
+    cols = ([], [], [], [])
+    for i in indices:
+        for c, x in zip(cols, bulk_protein(seed, i, lengths[i], indel_rate)):
+            c.append(x)
+    return cols

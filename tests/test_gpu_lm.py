@@ -129,7 +129,7 @@ def test_mdfw_roundtrip_with_language_model(tmp_path):
 
 def test_predictor_loads_an_onnx_file(tmp_path):
     """The path the reference's pipeline passes (an .onnx file, pipeline.py:549-584) is read directly by mDeepFRI.onnx_reader."""
-    import onnx_writer
+    from mDeepFRI import onnx_writer
     from mDeepFRI.predict import Predictor
     w = _weights(13, 64, 256, (256, 256), 256, 21)
     path = tmp_path / "DeepFRI-MERGED_GraphConv_gcd_512-512-512_fcd_1024_ca_10.0_mf.onnx"

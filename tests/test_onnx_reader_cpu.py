@@ -1,10 +1,10 @@
 """mDeepFRI.onnx_reader (hand-written protobuf decoding + structural weight extraction) against files written by Google's
-protobuf encoder (tests/onnx_writer.py).  CPU only.  No released DeepFRI .onnx file is available offline: what is proven
+protobuf encoder (mDeepFRI/onnx_writer.py).  CPU only.  No released DeepFRI .onnx file is available offline: what is proven
 here is wire-format decoding and the structural mapping on a graph with tf2onnx's op sequence."""
 import numpy as np
 import pytest
 
-import onnx_writer
+from mDeepFRI import onnx_writer
 
 
 def _weights(lm: bool):
@@ -106,3 +106,49 @@ def test_extracts_the_sequence_only_cnn(conv2d_form, explicit_pads):
     for b, klen in enumerate((5, 10, 15, 20), start=1):
         want = w.get(f"cnn_pad{b}", [(klen - 1) // 2])
         assert int(got[f"cnn_pad{b}"][0]) == int(np.asarray(want).reshape(-1)[0])
+
+
+# ---- the exported graphs, executed op by op under ONNX operator semantics, against the oracles --------------------------------
+def _one_hot(seq):
+    import cmap_oracle
+    return cmap_oracle.seq2onehot(seq)
+
+
+@pytest.mark.parametrize("lm", [False, True])
+@pytest.mark.parametrize("gemm", [False, True])
+def test_exported_gcn_graph_computes_what_the_oracle_states(lm, gemm):
+    """What onnxruntime would return for the exported file (tests/onnx_numpy_runtime.py interprets the graph per the ONNX
+    operator spec) == oracle/gcn_oracle.py / lm_oracle.py on the same weights and inputs, through the reference's call
+    convention (predict.pyx:82-100: A (1,L,L) f32, S (1,L,26) f32, out[0][:, :, 0].reshape(-1)).  This is the check a real ORT
+    run of the same file will repeat on a box that has onnxruntime (bench.py probes for it)."""
+    import gcn_oracle
+    import lm_oracle
+    import onnx_numpy_runtime
+    from mDeepFRI import onnx_reader, synthetic
+    w = _weights(lm)
+    g = onnx_reader.parse_model(onnx_writer.deepfri_gcn_model(w, use_gemm_head=gemm))
+    rng = np.random.default_rng(31)
+    for L, dense in ((37, False), (64, True)):
+        seq = synthetic.random_sequence(rng, L)
+        if dense:   # the reference notebook's recipe: random 0/1, non-symmetric, arbitrary diagonal
+            A = rng.integers(0, 2, size=(L, L)).astype(np.float32)
+        else:
+            import cmap_oracle
+            A = cmap_oracle.calculate_contact_map(synthetic.random_walk_coords(rng, L), 6.0).astype(np.float32)
+        out = onnx_numpy_runtime.run(g, {"cmap": A.reshape(1, L, L), "seq": _one_hot(seq).reshape(1, L, 26)})
+        y = out[0][:, :, 0].reshape(-1)
+        ref = (lm_oracle.gcn_lm_forward if lm else gcn_oracle.gcn_forward)(w, seq, A, dtype=np.float64)
+        assert y.shape == ref.shape and np.max(np.abs(y - ref)) < 1e-9, (lm, gemm, L)
+
+
+@pytest.mark.parametrize("conv2d_form,explicit_pads", [(False, False), (True, True)])
+def test_exported_cnn_graph_computes_what_the_oracle_states(conv2d_form, explicit_pads):
+    import cnn_oracle
+    import onnx_numpy_runtime
+    from mDeepFRI import onnx_reader, synthetic
+    w = synthetic.glorot_cnn_weights(seed=2, n_terms=13, filters=(24, 16, 8), kernel_lens=(5, 10, 15))
+    g = onnx_reader.parse_model(onnx_writer.deepcnn_model(w, conv2d_form=conv2d_form, explicit_pads=explicit_pads))
+    seq = synthetic.random_sequence(np.random.default_rng(3), 41)
+    y = onnx_numpy_runtime.run(g, {"seq": _one_hot(seq).reshape(1, len(seq), 26)})[0][:, :, 0].reshape(-1)
+    ref = cnn_oracle.cnn_forward(w, seq, dtype=np.float64) if "dtype" in cnn_oracle.cnn_forward.__code__.co_varnames else cnn_oracle.cnn_forward(w, seq)
+    assert np.max(np.abs(y - ref)) < 1e-6

@@ -46,6 +46,13 @@ def _worker(rank, world, port, lengths, T, q):
         # stand-in for the per-rank hot path: row i holds values derived from the global protein index
         local = torch.stack([torch.full((T,), float(i)) + torch.arange(T) / 100.0 for i in mine]) if mine else torch.zeros((0, T))
         out = sharding.gather_scores(local, mine, total=len(lengths), dst=0)
+        # the plan form bench.py keeps across steps: several runs with different payloads through ONE plan
+        plan = sharding.DenseGatherPlan(len(mine), T, mine, len(lengths), "cpu", dst=0)
+        for k in (1, 2, 3):
+            again = plan.run(local * k)
+            assert (again is None) == (rank != 0)
+            if rank == 0:
+                assert torch.equal(again, out * k)
         if rank == 0:
             q.put(out.numpy())
         else:
@@ -92,6 +99,12 @@ def _worker_csr(rank, world, port, n, T, q):
             off.append(len(terms))
         out = sharding.gather_filtered(torch.tensor(off, dtype=torch.int32), torch.tensor(terms, dtype=torch.int32),
                                        torch.tensor(scores, dtype=torch.float32), mine, total=n, dst=0)
+        plan = sharding.FilteredGatherPlan(mine, n, "cpu", dst=0)
+        for _ in range(3):   # re-used plan: padded buffers sized on the first run
+            again = plan.run(torch.tensor(off, dtype=torch.int32), torch.tensor(terms, dtype=torch.int32), torch.tensor(scores, dtype=torch.float32))
+            assert (again is None) == (rank != 0)
+            if rank == 0:
+                assert all(torch.equal(a, b) for a, b in zip(again, out))
         if rank == 0:
             q.put([x.numpy() for x in out])
         else:
