@@ -1,21 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- proteins/sec of the fused hot path (C-alpha coords + alignment + sequence -> GO scores) on MI355X.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1: launched through torch.distributed.run)
-One JSON line on rank 0.  A "step" is one pass of the hot path over the whole workload of BASELINE.json configs[2]
--- 10 000 synthetic L=512 proteins, three GO heads (MF+BP+CC) -- per GPU (weak scaling: every rank owns its own
-10 000 proteins), inputs resident in HBM before the timed region, results left on the device; with N>1 each step
-ends with the RCCL gather of the (10 000, 2752) score block of every rank to rank 0.
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 works both ways: under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or as a bare
+  `python bench.py --gpus N` -- then this process, which never touches the GPU, starts N fresh rank processes itself and
+  fails loudly if fewer than N devices are visible.
+One JSON line on rank 0.  A "step" is one pass of the hot path over the whole workload, inputs resident in HBM before the
+timed region:
 
-Extra objects on the line (tier contract):
-  roofline      dominant kernel (H.W fp32-MFMA GEMM): algorithmic flops per launch / mean launch duration measured with
-                HIP events on the launch stream inside the timed region (mdf_timing_* hooks of the library)
+  --workload configs2  (default; BASELINE.json configs[2], the configuration the metric is quoted on) 10 000 synthetic L=512
+                       proteins, MF+BP+CC heads, PER GPU (weak scaling); N > 1 ends every step with the RCCL gather of each rank's
+                       (10 000, 2752) score block to rank 0 (DenseGatherPlan: one collective, no host work in the step)
+  --workload configs3  BASELINE.json configs[3]: 100 000 proteins, L ~ U{128..1024} (seed 46), 5 % indels, dealt to the N ranks by
+                       cost (STRONG scaling), every rank filters its scores on the GPU (score >= 0.1, results.tsv order) and ONE
+                       gather per head moves only the survivors (sharding.FilteredGatherPlan)
+  --workload configs4  BASELINE.json configs[4]: 500 000 proteins, lengths from the committed histogram of the reference's test
+                       proteome (clipped to [30, 2048]), otherwise as configs3
+  --workload mixed     configs[3]-shaped, 10 000 proteins per GPU (weak scaling)
+  --workload cnn       the sequence-only CNN models (extra measurement)
+
+Objects on the line (tier contract):
+  roofline      dominant kernel (H.W fp32-MFMA GEMM): algorithmic flops per launch / mean launch duration measured with HIP events
+                on the launch stream inside the timed region (mdf_timing_* hooks of the library)
   roofline_ax   the same for the A.X aggregation kernel against the HBM roofline (the north_star's named kernel)
-  cpu_baseline  the oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample
+  cpu_baseline  the oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample: one thread
+                (the configuration the reference ships) and a pool of single-thread worker processes (the reference's own
+                parallelism, pipeline.py:476-481); real onnxruntime-CPU on the exported synthetic weights when ORT is importable
+  by_length / mixed / end_to_end   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix, and the
+                PCIe-inclusive host-lists-in / host-arrays-out rate -- never `value`
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,310 +45,526 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
 MODES = ("mf", "bp", "cc")
+STRONG = {"configs3": (100000, 46), "configs4": (500000, 47)}   # workload -> (proteins, seed = 42 + 1-based config number)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--proteins", type=int, default=10000, help="proteins per GPU per step (configs[2]: 10000)")
+    ap.add_argument("--proteins", type=int, default=None,
+                    help="proteins per GPU per step for the weak workloads (default 10000 = configs[2]); TOTAL proteins for configs3/configs4 "
+                         "(default 100000 / 500000)")
     ap.add_argument("--length", type=int, default=512)
     ap.add_argument("--chunk-rows", type=int, default=65536, help="residue rows per fused chunk (multiples of 32768 = full rounds of 256x256 GEMM tiles on 256 CUs)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="single-thread worker processes of the all-core leg (0 = min(cores, 32))")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--timing-period", type=int, default=8,
                     help="bracket every n-th launch of each kernel class with HIP events (an event pair costs GPU time between "
                          "kernels: timing every launch lowers the step rate by ~6 %%)")
-    ap.add_argument("--workload", default="configs2", choices=["configs2", "mixed", "cnn"],
-                    help="configs2 (headline): fixed length, identity alignments; mixed: configs[3]-style L~U[128,1024] with 5%% indels")
+    ap.add_argument("--workload", default="configs2", choices=["configs2", "configs3", "configs4", "mixed", "cnn"])
     ap.add_argument("--verify", type=int, default=4,
                     help="after the timed region, check this many proteins of the step against the oracle (untimed; 0 = skip)")
     ap.add_argument("--lm", action="store_true",
                     help="give every GO head the language-model branch of the released models (shared 2x512 LSTM + per-head "
                          "LM embedding; SURVEY.md section 8f row 1).  Not the BASELINE.json configuration: an extra measurement.")
-    ap.add_argument("--end-to-end", type=int, default=0, metavar="N",
-                    help="also stream N batches of --proteins from HOST lists through mDeepFRI.stream.AlignmentStream (packing, "
-                         "PCIe upload, compute, PCIe download of the scores) and report the PCIe-inclusive rate next to `value`")
+    ap.add_argument("--no-extras", action="store_true", help="N = 1 default run: skip the by_length / mixed / end_to_end mini-runs")
+    ap.add_argument("--end-to-end", type=int, default=2, metavar="N", help="batches of the end_to_end mini-run (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-device", type=int, default=None, help="testing aid: put every rank on this device ordinal")
-    return ap.parse_args()
+    ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one single-thread worker of the all-core leg
+    return ap.parse_args(argv)
 
 
-def make_workload(seed, count, L):
-    """configs[2] inputs: uniform 20-letter sequences, 3.8 A random-walk C-alpha traces rounded to 3 decimals,
-    identity alignments.  Vectorised version of mDeepFRI.synthetic.synthetic_proteins."""
+# ---------------------------------------------------------------------------------------------------------------------
+# self-launch: a parent that has made no GPU call starts the N rank processes (never a re-exec of a process that touched HIP)
+# ---------------------------------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    import torch
+    visible = torch.cuda.device_count()     # counts devices without initialising the GPU
+    if args.force_device is None and visible < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} requested but only {visible} HIP device(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in procs:       # a dead rank would leave the others waiting in a collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------------------------------------------------
+def make_fixed_length(seed, count, L):
+    """configs[2] inputs: uniform 20-letter sequences, 3.8 A random-walk C-alpha traces rounded to 3 decimals, identity
+    alignments.  Vectorised over the batch."""
     from mDeepFRI import synthetic
     rng = np.random.default_rng(seed)
     letters = np.frombuffer(synthetic.AA20.encode(), dtype=np.uint8)
-    idx = rng.integers(0, 20, size=(count, L))
-    seq_bytes = letters[idx]
+    seq_bytes = letters[rng.integers(0, 20, size=(count, L))]
     seqs = [bytes(r).decode() for r in seq_bytes]
     v = rng.standard_normal((count, L, 3))
     v /= np.linalg.norm(v, axis=2, keepdims=True) + 1e-12
     xyz = np.round(np.cumsum(v * 3.8, axis=1), 3).astype(np.float32)
-    return seqs, [xyz[i] for i in range(count)]
+    return seqs, [xyz[i] for i in range(count)], seqs, seqs
 
 
-def cpu_baseline(seqs, coords, weights, budget_s):
-    """Oracle chain (oracle/cmap_oracle.c + oracle/gcn_oracle.py) on host cores: 1 thread = the configuration the
-    reference ships, then all cores."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+def make_mixed(seed, count):
+    """configs[3]-shaped: L ~ U{128..1024}, 5 % indels, sorted by length as pipeline.py:529 sorts its work list."""
+    from mDeepFRI import synthetic
+    L = synthetic.uniform_lengths(seed, count)
+    order = np.argsort(L, kind="stable")
+    return synthetic.bulk_proteins(seed, L, order, indel_rate=0.05)
+
+
+def oracle_paths():
+    p = os.path.join(ROOT, "oracle")
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# cpu_baseline
+# ---------------------------------------------------------------------------------------------------------------------
+def _oracle_loop(seqs, coords, weights, budget_s, lm):
+    oracle_paths()
     import cmap_oracle
     import gcn_oracle
-    from threadpoolctl import threadpool_limits
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s or n < 2:
+        i = n % len(seqs)
+        cm = cmap_oracle.build_align_contact_map(coords[i], seqs[i], seqs[i], 6.0, 2)
+        for m in MODES:
+            if lm:
+                import lm_oracle
+                lm_oracle.gcn_lm_forward(weights[m], seqs[i], cm)   # (the oracle re-runs the shared LSTM per head, as the reference's three ONNX sessions do)
+            else:
+                gcn_oracle.gcn_forward(weights[m], seqs[i], cm)
+        n += 1
+    return n, time.perf_counter() - t0
 
-    def run(limit, budget):
-        n, t0 = 0, time.perf_counter()
-        with threadpool_limits(limits=limit):
-            while n < len(seqs) and (time.perf_counter() - t0 < budget or n < 2):
-                cm = cmap_oracle.build_align_contact_map(coords[n], seqs[n], seqs[n], 6.0, 2)
-                for m in MODES:
-                    if "W_lm" in weights[m]:
-                        import lm_oracle
-                        lm_oracle.gcn_lm_forward(weights[m], seqs[n], cm)   # (the oracle re-runs the shared LSTM per head, as the reference's three ONNX sessions do)
-                    else:
-                        gcn_oracle.gcn_forward(weights[m], seqs[n], cm)
-                n += 1
-        return n, time.perf_counter() - t0
 
-    n1, t1 = run(1, budget_s * 0.7)
-    ncores = os.cpu_count() or 1
-    na, ta = run(None, budget_s * 0.3)
-    # contact-map stage alone through the REAL reference kernels (oracle/_ref: the reference's contact_map_utils.pyx compiled
-    # with its own flags by oracle/build_ref.py), glued as reference bio_utils.py:196-227,348-385 does, 1 thread
-    ref_stage = None
+def cpu_worker(spec):
+    """One single-thread worker of the all-core leg (a fresh child process: BLAS pinned to one thread by its environment)."""
+    seed, length, budget, lm = spec.split(",")
+    from mDeepFRI import synthetic
+    weights = make_weights(bool(int(lm)))
+    seqs, coords, _, _ = make_fixed_length(int(seed), 8, int(length))
+    del synthetic
+    n, t = _oracle_loop(seqs, coords, weights, float(budget), bool(int(lm)))
+    print(json.dumps({"n": n, "t": t}), flush=True)
+
+
+def make_weights(lm):
+    from mDeepFRI import synthetic
+    weights = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=synthetic.GO_TERMS[m]) for i, m in enumerate(MODES)}
+    if lm:
+        lmw = synthetic.glorot_lm_weights(seed=1000)
+        for i, m in enumerate(MODES):
+            weights[m].update(lmw)
+            weights[m]["W_lm"] = synthetic.glorot_uniform(np.random.default_rng(2000 + i), 512, 1024)  # LM_embedding is per head
+    return weights
+
+
+def ort_leg(seqs, coords, weights, budget_s):
+    """Real onnxruntime-CPU, single thread, batch 1 -- the reference's shipped configuration (predict.pyx:62-73,98; SURVEY.md
+    section 0.6) -- on the synthetic weights exported by mDeepFRI.onnx_writer.  Only when `import onnxruntime` works here."""
     try:
-        import build_ref
-        ref = build_ref.load()
-        if ref is not None:
-            m, t0 = 0, time.perf_counter()
-            while m < min(len(seqs), 200) and time.perf_counter() - t0 < 2.0:
-                D = ref.pairwise_sqeuclidean(coords[m])
-                sparse = np.argwhere((D < 6.0**2).astype(np.int32) == 1).astype(np.int32)
-                ref.align_contact_map(seqs[m], seqs[m], sparse, 2)
-                m += 1
-            ref_stage = {"kind": "reference", "ms_per_protein": round(1e3 * (time.perf_counter() - t0) / max(m, 1), 3),
-                         "sample": f"{m} proteins, pairwise_sqeuclidean + threshold/argwhere + align_contact_map, 1 thread"}
-    except Exception as e:  # the compiled reference is optional on the GPU box
-        ref_stage = {"kind": "reference", "error": str(e)[:200]}
-    return {"cmap_stage_reference": ref_stage, "value": n1 / t1, "unit": "proteins/s", "cores": 1, "kind": "port",
-            "sample": f"{n1} of the step's L={len(seqs[0])} proteins, contact map + 3 GO heads each, {t1:.1f} s, numpy/BLAS pinned to 1 thread",
-            "all_cores": {"value": na / ta, "cores": ncores, "sample": f"{na} proteins, {ta:.1f} s, BLAS threads unrestricted"},
-            "published_anchor": "reference weight_convert/inference_times.csv.gz: 0.13 s/protein/model/core at L~512 (ORT CPU, model incl. LSTM LM)"}
+        import onnxruntime as rt
+    except Exception as e:
+        return {"available": False, "probe": f"import onnxruntime: {type(e).__name__}"}
+    try:
+        oracle_paths()
+        import cmap_oracle
+        import gcn_oracle
+        from mDeepFRI import onnx_writer
+        so = rt.SessionOptions()
+        so.intra_op_num_threads = so.inter_op_num_threads = 1
+        sess = {m: rt.InferenceSession(onnx_writer.deepfri_gcn_model(weights[m]), so, providers=["CPUExecutionProvider"]) for m in MODES}
+        names = {m: [i.name for i in s.get_inputs()] for m, s in sess.items()}
+        n, worst, t0 = 0, 0.0, time.perf_counter()
+        while n < len(seqs) and (time.perf_counter() - t0 < budget_s or n < 2):
+            L = len(seqs[n])
+            cm = cmap_oracle.build_align_contact_map(coords[n], seqs[n], seqs[n], 6.0, 2)
+            A = cm.reshape(1, L, L).astype(np.float32)
+            S = cmap_oracle.seq2onehot(seqs[n]).reshape(1, L, 26)
+            for m in MODES:
+                y = sess[m].run(None, {names[m][0]: A, names[m][1]: S})[0][:, :, 0].reshape(-1)
+                if n < 2:   # external check of the oracle (untimed cost is small): ORT vs oracle/gcn_oracle.py
+                    worst = max(worst, float(np.max(np.abs(y - gcn_oracle.gcn_forward(weights[m], seqs[n], cm)))))
+            n += 1
+        dt = time.perf_counter() - t0
+        return {"available": True, "version": rt.__version__, "value": n / dt, "unit": "proteins/s", "cores": 1, "kind": "reference-runtime",
+                "sample": f"{n} proteins, contact map (C oracle) + 3 ONNX sessions each, intra_op=inter_op=1",
+                "max_abs_diff_ort_vs_oracle": worst}
+    except Exception as e:   # an ORT that cannot run the export is a finding, not a crash of the benchmark
+        return {"available": True, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+
+
+def cpu_baseline(seqs, coords, weights, args):
+    """Oracle chain (oracle/cmap_oracle.c + oracle/gcn_oracle.py) on this box's host cores."""
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=1):
+        n1, t1 = _oracle_loop(seqs, coords, weights, args.cpu_seconds, args.lm)
+    ncores = os.cpu_count() or 1
+    workers = args.cpu_workers or min(ncores, 32)
+    L = len(seqs[0])
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    spec = lambda k: f"{9000 + k},{L},{args.cpu_seconds * 0.6},{int(args.lm)}"  # noqa: E731
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", spec(k)], env=env, stdout=subprocess.PIPE, text=True)
+             for k in range(workers)]
+    rates, fails = [], 0
+    for p in procs:
+        out, _ = p.communicate()
+        try:
+            r = json.loads(out.strip().splitlines()[-1])
+            rates.append(r["n"] / r["t"])
+        except Exception:
+            fails += 1
+    pool = {"value": float(sum(rates)), "unit": "proteins/s", "cores": len(rates), "host_cores_visible": ncores,
+            "sample": f"{len(rates)} single-thread worker processes (the reference's Pool of 1-thread workers, pipeline.py:476-481), "
+                      f"{args.cpu_seconds * 0.6:.0f} s each, wall {time.perf_counter() - t0:.0f} s" + (f", {fails} workers failed" if fails else "")}
+    return {"value": n1 / t1, "unit": "proteins/s", "cores": 1, "kind": "port",
+            "sample": f"{n1} of the step's L={L} proteins, contact map + 3 GO heads each, {t1:.1f} s, numpy/BLAS pinned to 1 thread "
+                      f"(= the configuration the reference ships: ORT intra_op=1, batch 1)",
+            "process_pool": pool,
+            "onnxruntime": ort_leg(seqs, coords, weights, args.cpu_seconds * 0.5),
+            "cmap_stage_reference": {"kind": "reference", "ms_per_protein": 1.39, "measured": "build container, round 1, 1 thread, L=512",
+                                     "note": "constant: the compiled reference (oracle/_ref) does not travel to the GPU box"},
+            "published_anchor": "reference weight_convert/inference_times.csv.gz: 0.13 s/protein/model/core at L~512 (ORT CPU)"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# timed runs
+# ---------------------------------------------------------------------------------------------------------------------
+class Ctx:
+    pass
+
+
+def timed_run(ctx, eng, db, steps, warmup, after=None, timing_period=8):
+    """W warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns (seconds (max over ranks), last out)."""
+    import torch
+    import torch.distributed as dist
+
+    def step():
+        out = eng.forward_alignments(db)
+        if after is not None:
+            after(out)
+        return out
+
+    def fence():
+        if ctx.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    fence()
+    eng.check(db)  # invalid residues / CSR overflow would surface here
+    ctx.lib.mdf_timing_reset()
+    ctx.lib.mdf_timing_enable(max(1, timing_period) if timing_period > 0 else 0)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.lib.mdf_timing_enable(0)
+    if ctx.world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    eng.check(db)
+    return elapsed, out
+
+
+def read_kernels(ctx, names):
+    from mDeepFRI import _hip
+    out = {}
+    for k in names:
+        n, ms = _hip.c_int64(0), _hip.ctypes.c_double(0.0)
+        ctx.lib.mdf_timing_read(k.encode(), n, ms)
+        out[k] = {"launches": int(n.value), "total_ms": round(ms.value, 3), "avg_us": round(1e3 * ms.value / max(n.value, 1), 2)}
+    return out
+
+
+def rooflines(ctx, eng, pk, kernels, lm):
+    """roofline objects of the two named kernels from the library's sampled HIP-event timings of THIS run."""
+    R = pk.chunks[0].rows                        # rows per launch (all chunks but the last are equal)
+    rows_launch = sum(c.rows for c in pk.chunks) / len(pk.chunks)
+    roof = roof_ax = None
+    try:  # HBM bytes per launch: a CONSTANT from the committed rocprofv3 PMC passes (profiles/traffic.json), valid for the same rows per launch only
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if traffic.get("rows_per_launch") != R:
+            traffic = {}
+    except OSError:
+        traffic = {}
+    src = "profiles/traffic.json (rocprofv3 --pmc pass of an earlier run of this command; not a counter of this run)"
+    C = 512
+    g, a = kernels.get("gemm", {}), kernels.get("ax", {})
+    if g.get("launches"):
+        # with --lm the class also holds the unfolded layer-1 launch (K = 1024): mean over the three layers
+        flops_launch = 2.0 * rows_launch * C * ((1024 + C + C) / 3.0 if lm else C)
+        tf = flops_launch / (g["avg_us"] * 1e-6) / 1e12
+        roof = {"kernel": "k_gemm_f32 (H.W, 256x256x32 tiles, v_mfma_f32_32x32x2_f32, LDS-DMA staging, ELU+pool epilogue)",
+                "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+                "traffic": traffic.get("gemm_mean_bytes"), "traffic_source": src if traffic else None,
+                "per_launch": {"rows": R, "flops": 2.0 * R * C * C, "avg_us": g["avg_us"], "timed_launches": g["launches"]}}
+    if a.get("launches"):
+        # SURVEY.md section 8d: read Z (rows x 512 f32) once + write (rows x 512 f32) once per layer; CSR adjacency (4 B colidx
+        # + 4 B val per entry + 4 B rowptr per row) added and stated
+        rp = eng._bufs["rowptr"]
+        nnz_per_row = float(rp[pk.chunks[-1].rows].item()) / float(pk.chunks[-1].rows)
+        bytes_row = 2 * 4 * C + 4 + 8 * nnz_per_row
+        gbs = bytes_row * rows_launch / (a["avg_us"] * 1e-6) / 1e9
+        roof_ax = {"kernel": "k_aggregate<512> (A.X, CSR gather, one wave per residue row)", "bound": "hbm", "achieved": round(gbs, 1),
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                   "traffic": (traffic.get("k_aggregate<512>") or {}).get("bytes"), "traffic_source": src if traffic else None,
+                   "per_launch": {"rows": R, "bytes": bytes_row * R, "nnz_per_row": round(nnz_per_row, 2), "avg_us": a["avg_us"],
+                                  "timed_launches": a["launches"]}}
+    return roof, roof_ax
+
+
+def verify(seqs, coords, q_alns, t_alns, weights, out, n, lm, index=None):
+    """Parity spot check on the very outputs of the timed steps (oracle = checker, outside the timed region)."""
+    oracle_paths()
+    import cmap_oracle
+    import gcn_oracle
+    worst = 0.0
+    for i in np.linspace(0, len(seqs) - 1, n).astype(int):
+        cm = cmap_oracle.build_align_contact_map(coords[i], q_alns[i], t_alns[i], 6.0, 2)
+        for m in MODES:
+            if lm:
+                import lm_oracle
+                ref = lm_oracle.gcn_lm_forward(weights[m], seqs[i], cm)
+            else:
+                ref = gcn_oracle.gcn_forward(weights[m], seqs[i], cm)
+            got = out[m][i if index is None else index[i]]
+            worst = max(worst, float(np.max(np.abs(got.cpu().numpy() - ref))))
+    return {"proteins": int(n), "heads": list(MODES), "max_abs_err_vs_oracle": worst, "tolerance": 1e-4}
+
+
+def mini_run(ctx, eng, cols, chunk_rows, steps=2, warmup=1, lm=False):
+    """A short untimed-contract run of another workload on the same engine: proteins/s + the two rooflines."""
+    from mDeepFRI import batch
+    pk = batch.PackedProteins.pack(*cols, max_rows=chunk_rows)
+    db = eng.upload(pk)
+    elapsed, _ = timed_run(ctx, eng, db, steps, warmup, timing_period=4)
+    kernels = read_kernels(ctx, ("gemm", "ax"))
+    roof, roof_ax = rooflines(ctx, eng, pk, kernels, lm)
+    n = len(cols[0])
+    return {"value": round(n * steps / elapsed, 1), "unit": "proteins/s", "proteins": n, "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
+            "mean_length": round(float(np.mean([len(s) for s in cols[0]])), 1),
+            "roofline": {k: roof[k] for k in ("achieved", "unit", "frac")} if roof else None,
+            "roofline_ax": {k: roof_ax[k] for k in ("achieved", "unit", "frac")} if roof_ax else None}
 
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        return cpu_worker(args.cpu_worker)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
+
+    cpu_leg = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.cpu_seconds > 0 and args.workload == "configs2":
+        # the CPU legs run BEFORE this process makes its first GPU call: they start single-thread worker processes
+        n_cpu = 256
+        c_seqs, c_coords, _, _ = make_fixed_length(42 + 2, args.proteins or 10000, args.length)   # the first proteins of the step's workload
+        cpu_leg = cpu_baseline(c_seqs[:n_cpu], c_coords[:n_cpu], make_weights(args.lm), args)
+        del c_seqs, c_coords
+
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
+    ctx = Ctx()
+    ctx.rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    ctx.backend = args.backend
+    if ctx.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}")
     if args.force_device is not None:
         local_rank = args.force_device
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {ctx.rank}: device {local_rank} requested but {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
-    if world > 1:
+    ctx.dev = dev = torch.device(f"cuda:{local_rank}")
+    if ctx.world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=ctx.rank, world_size=ctx.world, device_id=dev)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(args.backend, rank=ctx.rank, world_size=ctx.world)
+        ctx.world = dist.get_world_size()     # as the backend (RCCL) saw it
 
     from mDeepFRI import _hip, batch, sharding, synthetic
+    from mDeepFRI.output import filter_scores
     from mDeepFRI.predict import Predictor
+    ctx.lib = _hip.lib()
 
     if args.workload == "cnn":
-        return bench_cnn(args, rank, local_rank, world, dev)
+        return bench_cnn(args, ctx, local_rank)
 
-    weights = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=synthetic.GO_TERMS[m]) for i, m in enumerate(MODES)}
-    if args.lm:
-        lm = synthetic.glorot_lm_weights(seed=1000)
-        for i, m in enumerate(MODES):
-            weights[m].update(lm)
-            weights[m]["W_lm"] = synthetic.glorot_uniform(np.random.default_rng(2000 + i), 512, 1024)  # LM_embedding is per head
+    weights = make_weights(args.lm)
     preds = {m: Predictor(f"synthetic-{m}", weights=weights[m], device=local_rank) for m in MODES}
     T_total = sum(p.n_terms for p in preds.values())
-
-    if args.workload == "mixed":   # configs[3] shape: ragged lengths, gapped alignments (sorted by length as pipeline.py:529)
-        prots = synthetic.synthetic_proteins(42 + 3 + 1000 * rank, args.proteins, (128, 1024), indel_rate=0.05)
-        prots.sort(key=lambda p: len(p["seq"]))
-        seqs, coords = [p["seq"] for p in prots], [p["coords"] for p in prots]
-        q_alns, t_alns = [p["q_aln"] for p in prots], [p["t_aln"] for p in prots]
-    else:
-        seqs, coords = make_workload(42 + 2 + 1000 * rank, args.proteins, args.length)  # seed = 42 + config index (+rank)
-        q_alns = t_alns = seqs
     eng = batch.HotPathEngine(preds, device=local_rank, max_rows=args.chunk_rows)
+
+    strong = args.workload in STRONG
+    after, local_index = None, None
+    if strong:
+        total, seed = STRONG[args.workload]
+        total = args.proteins or total
+        lengths = synthetic.uniform_lengths(seed, total) if args.workload == "configs3" else synthetic.histogram_lengths(seed, total)
+        mine = sharding.partition_by_cost(lengths, ctx.world)[ctx.rank]    # sorted by length inside the shard (pipeline.py:529)
+        cols = synthetic.bulk_proteins(seed, lengths, mine, indel_rate=0.05)
+        n_local, n_job = len(mine), total
+        plans = {m: sharding.FilteredGatherPlan(mine, total, dev, dst=0) for m in MODES}
+        gathered = {}
+
+        def after(out):   # output stage on every rank, then ONE gather of the survivors per head
+            for m in MODES:
+                off, ti, kept = filter_scores(out[m], threshold=0.1, capacity_per_protein=preds[m].n_terms)
+                gathered[m] = plans[m].run(off, ti, kept)
+    else:
+        n_local = args.proteins or 10000
+        n_job = n_local * ctx.world
+        if args.workload == "mixed":
+            cols = make_mixed(42 + 4 + 1000 * ctx.rank, n_local)
+        else:
+            cols = make_fixed_length(42 + 2 + 1000 * ctx.rank, n_local, args.length)  # seed = 42 + config index (+rank)
+        if ctx.world > 1:
+            local_index = list(range(ctx.rank * n_local, (ctx.rank + 1) * n_local))
+            plan = sharding.DenseGatherPlan(n_local, T_total, local_index, n_job, dev, dst=0)
+            gathered = {}
+
+            def after(out):
+                gathered["all"] = plan.run(torch.cat([out[m] for m in MODES], dim=1))
+    seqs, coords, q_alns, t_alns = cols
     pk = batch.PackedProteins.pack(seqs, coords, q_alns, t_alns, max_rows=args.chunk_rows)
     db = eng.upload(pk)
-    lib = _hip.lib()
-    global_index = list(range(rank * args.proteins, (rank + 1) * args.proteins))
 
-    def step():
-        out = eng.forward_alignments(db)
-        if world > 1:
-            block = torch.cat([out[m] for m in MODES], dim=1)
-            sharding.gather_scores(block, global_index, total=world * args.proteins, dst=0)
-        return out
+    timing_period = 0 if args.no_kernel_timing else args.timing_period
+    elapsed, out = timed_run(ctx, eng, db, args.steps, args.warmup, after=after, timing_period=timing_period)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    eng.check(db)  # invalid residues / CSR overflow would surface here
-    timing = not args.no_kernel_timing
-    lib.mdf_timing_reset()
-    lib.mdf_timing_enable(max(1, args.timing_period) if timing else 0)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    lib.mdf_timing_enable(0)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    eng.check(db)
-
-    if rank == 0:
-        def read(kind):
-            n, ms = _hip.c_int64(0), _hip.ctypes.c_double(0.0)
-            lib.mdf_timing_read(kind.encode(), n, ms)
-            return int(n.value), float(ms.value)
-
-        R = pk.chunks[0].rows                        # rows per launch (all chunks but the last are equal)
-        rows_total = sum(c.rows for c in pk.chunks)
-        roof, roof_ax, kernels = None, None, {}
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/traffic.json); same rows per launch only
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if traffic.get("rows_per_launch") != R:
-                traffic = {}
-        except OSError:
-            traffic = {}
-        if timing:
-            for kname in ("gemm", "gemm1", "ax", "cmap", "head") + (("lstm", "lstm2", "embed") if args.lm else ()):
-                n, ms = read(kname)
-                kernels[kname] = {"launches": n, "total_ms": round(ms, 3), "avg_us": round(1e3 * ms / max(n, 1), 2)}
-            n_g, ms_g = read("gemm")
-            n_a, ms_a = read("ax")
-            # algorithmic work of one launch (mean rows per chunk; all chunks but the last are equal) / mean duration of
-            # the launches that were bracketed with HIP events (every --timing-period-th one, on the launch stream)
-            C = 512
-            rows_launch = rows_total / len(pk.chunks)
-            if n_g:
-                # with --lm the class also holds the unfolded layer-1 launch (K = 1024): mean over the three layers
-                flops_launch = 2.0 * rows_launch * C * ((1024 + C + C) / 3.0 if args.lm else C)
-                tf = flops_launch / (ms_g / n_g * 1e-3) / 1e12
-                roof = {"kernel": "k_gemm_f32 (H.W, 256x256x32 tiles, v_mfma_f32_32x32x2_f32, LDS-DMA staging, ELU+pool epilogue)",
-                        "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": round(tf / MFMA_F32_PEAK_TF, 4), "traffic": traffic.get("gemm_mean_bytes"),
-                        "per_launch": {"rows": R, "flops": 2.0 * R * C * C, "avg_us": kernels["gemm"]["avg_us"],
-                                       "timed_launches": n_g}}
-            if n_a:
-                # SURVEY.md section 8d: read Z (rows x 512 f32) once + write (rows x 512 f32) once per layer; CSR adjacency
-                # (4 B colidx + 4 B val per nnz + 4 B rowptr per row) added and stated
-                nnz_per_row = float(os.environ.get("MDFRI_BENCH_NNZ_PER_ROW", "0")) or eng_nnz_per_row(eng, db, pk)
-                bytes_launch_rows = 2 * 4 * C + 4 + 8 * nnz_per_row
-                gbs = bytes_launch_rows * rows_launch / (ms_a / n_a * 1e-3) / 1e9
-                roof_ax = {"kernel": "k_aggregate<512> (A.X, CSR gather, one wave per residue row)", "bound": "hbm",
-                           "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                           "traffic": (traffic.get("k_aggregate<512>") or {}).get("bytes"),
-                           "per_launch": {"rows": R, "bytes": bytes_launch_rows * R, "nnz_per_row": round(nnz_per_row, 2),
-                                          "avg_us": kernels["ax"]["avg_us"], "timed_launches": n_a}}
+    if ctx.rank == 0:
+        kernels = read_kernels(ctx, ("gemm", "gemm1", "ax", "cmap", "head") + (("lstm", "lstm2", "embed") if args.lm else ())) if timing_period else {}
+        roof, roof_ax = rooflines(ctx, eng, pk, kernels, args.lm)
+        mean_len = float(np.mean([len(s) for s in seqs]))
+        what = {
+            "configs2": f"configs[2]: {n_local} synthetic L={args.length} proteins per GPU, GCN_MF+BP+CC (T={T_total}), fused cmap(6A, gen=2)+GCN, identity alignments",
+            "mixed": f"configs[3]-shaped: {n_local} synthetic proteins per GPU, L~U[128,1024], 5% indels, GCN_MF+BP+CC (T={T_total}), fused cmap align(6A, gen=2)+GCN",
+            "configs3": f"configs[3]: {n_job} synthetic proteins in total, L~U[128,1024] (seed 46), 5% indels, dealt to {ctx.world} rank(s) by cost, "
+                        f"GCN_MF+BP+CC (T={T_total}), fused cmap align+GCN, GPU filter (score>=0.1) + one gather of the survivors per head",
+            "configs4": f"configs[4]: {n_job} synthetic proteins in total, lengths from the reference test proteome's histogram clipped to [30,2048] (seed 47), "
+                        f"5% indels, dealt to {ctx.world} rank(s) by cost, GCN_MF+BP+CC (T={T_total}), fused cmap align+GCN, GPU filter + one gather per head",
+        }[args.workload]
         line = {
             "metric": "proteins/sec (GCN+cmap) at L=512" + (" [with LSTM language model]" if args.lm else ""),
-            "value": round(world * args.proteins * args.steps / elapsed, 1),
+            "value": round(n_job * args.steps / elapsed, 1),
             "unit": "proteins/s",
-            "n_gpus": world,
+            "n_gpus": ctx.world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": (f"configs[2]: {args.proteins} synthetic L={args.length} proteins per GPU, GCN_MF+BP+CC "
-                                    f"(T={T_total}), fused cmap(6A, gen=2)+GCN, identity alignments") if args.workload == "configs2" else
-                                   (f"configs[3]-style: {args.proteins} synthetic proteins per GPU, L~U[128,1024], 5% indels, "
-                                    f"GCN_MF+BP+CC (T={T_total}), fused cmap align(6A, gen=2)+GCN"),
-                       "proteins_per_gpu": args.proteins, "length": args.length, "go_heads": list(MODES),
-                       "language_model": bool(args.lm), "chunk_rows": args.chunk_rows, "parallelism": f"shard{world}+gather" if world > 1 else "single"},
+            "config": {"workload": what, "proteins_total": n_job, "proteins_rank0": n_local, "mean_length_rank0": round(mean_len, 1),
+                       "length": args.length if args.workload == "configs2" else None, "go_heads": list(MODES), "language_model": bool(args.lm),
+                       "chunk_rows": args.chunk_rows,
+                       "parallelism": (f"shard{ctx.world}+gather" if ctx.world > 1 else "single"), "backend": args.backend if ctx.world > 1 else None},
             "roofline": roof,
             "roofline_ax": roof_ax,
             "kernels": kernels,
         }
+        if strong:
+            line["gathered_survivors"] = {m: int(gathered[m][1].numel()) for m in MODES}
         if args.verify > 0:
-            # parity spot check on the very outputs of the timed steps (oracle = checker, outside the timed region)
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import cmap_oracle
-            import gcn_oracle
-            pick = np.linspace(0, args.proteins - 1, args.verify).astype(int)
-            worst = 0.0
-            for i in pick:
-                cm = cmap_oracle.build_align_contact_map(coords[i], q_alns[i], t_alns[i], 6.0, 2)
-                for m in MODES:
-                    if args.lm:
-                        import lm_oracle
-                        ref = lm_oracle.gcn_lm_forward(weights[m], seqs[i], cm)
-                    else:
-                        ref = gcn_oracle.gcn_forward(weights[m], seqs[i], cm)
-                    worst = max(worst, float(np.max(np.abs(out[m][i].cpu().numpy() - ref))))
-            line["verify"] = {"proteins": int(args.verify), "heads": list(MODES), "max_abs_err_vs_oracle": worst, "tolerance": 1e-4}
-            if not worst < 1e-4:
+            line["verify"] = verify(seqs, coords, q_alns, t_alns, weights, out, args.verify, args.lm)
+            if strong:   # and what rank 0 holds after the gather == filtering rank 0's own scores (its proteins sit at `mine`)
+                off_g, ti_g, sc_g = (x.cpu().numpy() for x in gathered[MODES[0]])
+                off_l, ti_l, sc_l = (x.cpu().numpy() for x in filter_scores(out[MODES[0]], threshold=0.1, capacity_per_protein=preds[MODES[0]].n_terms))
+                ok = all(np.array_equal(ti_g[off_g[g]:off_g[g + 1]], ti_l[off_l[k]:off_l[k + 1]]) and
+                         np.array_equal(sc_g[off_g[g]:off_g[g + 1]], sc_l[off_l[k]:off_l[k + 1]])
+                         for k, g in list(enumerate(mine))[::max(1, len(mine) // 64)])
+                line["verify"]["gather_restores_input_order"] = bool(ok)
+                if not ok:
+                    print(json.dumps(line), flush=True)
+                    raise SystemExit("gathered survivors differ from the local filter")
+            if not line["verify"]["max_abs_err_vs_oracle"] < 1e-4:
                 print(json.dumps(line), flush=True)
-                raise SystemExit(f"parity check failed: max |score - oracle| = {worst}")
-        if world == 1 and args.end_to_end > 0 and args.workload == "configs2":
-            from mDeepFRI.stream import AlignmentStream
-            items = []
-            for k in range(args.end_to_end):
-                s2, c2 = make_workload(777 + k, args.proteins, args.length)
-                items += [(a, b, a, a) for a, b in zip(s2, c2)]
-            stream = AlignmentStream(eng, batch_size=args.proteins, max_rows=args.chunk_rows)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n_out = 0
-            for _, res in stream.run(items):
-                n_out += res[MODES[0]].shape[0]
-            dt = time.perf_counter() - t0
-            assert n_out == len(items)
-            line["end_to_end"] = {"value": round(len(items) / dt, 1), "unit": "proteins/s", "batches": args.end_to_end,
-                                  "note": "host lists in -> host float32 score arrays out: packing thread + PCIe upload + compute + "
-                                          "PCIe download, batches pipelined (mDeepFRI.stream.AlignmentStream); never `value`"}
-        if world == 1 and args.cpu_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(seqs[:1024], coords[:1024], weights, args.cpu_seconds) if args.workload == "configs2" else None
-            line["gpu_over_cpu_1core"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
-        else:
-            line["cpu_baseline"] = None
+                raise SystemExit(f"parity check failed: max |score - oracle| = {line['verify']['max_abs_err_vs_oracle']}")
+        if ctx.world == 1 and args.workload == "configs2" and not args.no_extras and not args.lm:
+            # the rest of the north_star's measurement list on the same engine, each a short run of its own (never `value`)
+            line["by_length"] = {str(L): mini_run(ctx, eng, make_fixed_length(42 + 2 + L, n_local, L), args.chunk_rows) for L in (256, 1024)}
+            line["mixed"] = mini_run(ctx, eng, make_mixed(42 + 4, n_local), args.chunk_rows)
+            if args.end_to_end > 0:
+                from mDeepFRI.stream import AlignmentStream
+                items = []
+                for k in range(args.end_to_end):
+                    s2, c2, _, _ = make_fixed_length(777 + k, n_local, args.length)
+                    items += [(a, b, a, a) for a, b in zip(s2, c2)]
+                stream = AlignmentStream(eng, batch_size=n_local, max_rows=args.chunk_rows)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n_out = sum(res[MODES[0]].shape[0] for _, res in stream.run(items))
+                dt = time.perf_counter() - t0
+                assert n_out == len(items)
+                line["end_to_end"] = {"value": round(len(items) / dt, 1), "unit": "proteins/s", "batches": args.end_to_end,
+                                      "note": "PCIe-inclusive: host lists in -> host float32 score arrays out (packing thread + upload + compute + "
+                                              "download, batches pipelined; mDeepFRI.stream.AlignmentStream); never `value`"}
+        line["cpu_baseline"] = cpu_leg
+        if cpu_leg:
+            line["gpu_over_cpu_1core"] = round(line["value"] / cpu_leg["value"], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if ctx.world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def bench_cnn(args, rank, local_rank, world, dev):
+def bench_cnn(args, ctx, local_rank):
     """Extra measurement (not the BASELINE.json metric): the sequence-only CNN models the reference runs on proteins without a
     structural hit (pipeline.py:600-648), 3 heads, upstream DeepCNN default topology, same synthetic sequences."""
     import torch
     import torch.distributed as dist
     from mDeepFRI import _hip, batch, synthetic
     from mDeepFRI.predict import Predictor
+    rank, world, dev = ctx.rank, ctx.world, ctx.dev
+    n_local = args.proteins or 10000
     weights = {m: synthetic.glorot_cnn_weights(seed=i, n_terms=synthetic.GO_TERMS[m]) for i, m in enumerate(MODES)}
     preds = {m: Predictor(f"synthetic-cnn-{m}", weights=weights[m], device=local_rank) for m in MODES}
-    seqs, _ = make_workload(42 + 2 + 1000 * rank, args.proteins, args.length)
+    seqs = make_fixed_length(42 + 2 + 1000 * rank, n_local, args.length)[0]
     eng = batch.SequenceEngine(preds, device=local_rank)
     db = batch.DeviceBatch(batch.PackedProteins.pack(seqs, max_rows=1 << 20), dev)
-    lib = _hip.lib()
+    lib = ctx.lib
 
     def fence():
         if world > 1:
@@ -357,25 +591,25 @@ def bench_cnn(args, rank, local_rank, world, dev):
     if rank == 0:
         n, ms = _hip.c_int64(0), _hip.ctypes.c_double(0.0)
         lib.mdf_timing_read(b"cnn", n, ms)
-        line = {"metric": "proteins/sec (sequence-only CNN) at L=%d" % args.length, "value": round(world * args.proteins * args.steps / elapsed, 1),
+        line = {"metric": "proteins/sec (sequence-only CNN) at L=%d" % args.length, "value": round(world * n_local * args.steps / elapsed, 1),
                 "unit": "proteins/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"{args.proteins} synthetic L={args.length} sequences per GPU, DeepCNN MF+BP+CC (4 Conv1D branches "
+                "config": {"workload": f"{n_local} synthetic L={args.length} sequences per GPU, DeepCNN MF+BP+CC (4 Conv1D branches "
                                        f"120/100/80/60 x 5/10/15/20, BatchNorm, max pool, FuncPredictor)", "go_heads": list(MODES)},
                 "kernels": {"cnn": {"launches": int(n.value), "total_ms": round(ms.value, 3), "avg_us": round(1e3 * ms.value / max(n.value, 1), 2)}}}
         if args.verify > 0:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            oracle_paths()
             import cnn_oracle
             worst = 0.0
-            for i in np.linspace(0, args.proteins - 1, args.verify).astype(int):
+            for i in np.linspace(0, n_local - 1, args.verify).astype(int):
                 for m in MODES:
                     worst = max(worst, float(np.max(np.abs(out[m][i].cpu().numpy() - cnn_oracle.cnn_forward(weights[m], seqs[i])))))
             line["verify"] = {"proteins": int(args.verify), "max_abs_err_vs_oracle": worst, "tolerance": 1e-4}
             if not worst < 1e-4:
                 raise SystemExit(f"parity check failed: {worst}")
         if world == 1 and args.cpu_seconds > 0:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            oracle_paths()
             import cnn_oracle
             from threadpoolctl import threadpool_limits
             k, t1 = 0, time.perf_counter()
@@ -391,13 +625,6 @@ def bench_cnn(args, rank, local_rank, world, dev):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def eng_nnz_per_row(eng, db, pk):
-    """Mean CSR entries per residue row of the last chunk processed (rowptr[R] / R), read back from the device."""
-    rp = eng._bufs["rowptr"]
-    last = pk.chunks[-1]
-    return float(rp[last.rows].item()) / float(last.rows)
 
 
 if __name__ == "__main__":

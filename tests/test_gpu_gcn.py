@@ -228,6 +228,34 @@ def test_full_size_batch_properties(mf):
         assert np.max(np.abs(full[i] - gcn_oracle.gcn_forward(w, prots[i]["seq"], cm))) < TOL
 
 
+def test_configs1_workload_1000_proteins_L256_mf(mf):
+    """BASELINE.json configs[1]: 1 000 synthetic L=256 proteins, GCN_MF, one GPU.  The oracle checks a sample (it needs
+    ~15 ms per protein); ALL 1 000 are covered by size-independent properties: the result of every protein is bitwise
+    independent of the order, the chunking and the company it is batched with."""
+    from mDeepFRI.batch import PackedProteins
+    w, pred = mf
+    n, L = 1000, 256
+    lengths = np.full(n, L, dtype=np.int32)
+    seqs, coords, q_alns, t_alns = synthetic.bulk_proteins(43, lengths, range(n))        # seed = 42 + config index
+    eng = _engine({"mf": pred}, max_rows=65536)
+
+    def run(sel, max_rows):
+        pk = PackedProteins.pack([seqs[i] for i in sel], [coords[i] for i in sel], [q_alns[i] for i in sel], [t_alns[i] for i in sel],
+                                 max_rows=max_rows)
+        return eng.run_alignments(pk)["mf"], len(pk.chunks)
+
+    full, n_chunks = run(range(n), 65536)
+    assert full.shape == (n, pred.n_terms) and n_chunks == 4 and np.isfinite(full).all()
+    for i in np.linspace(0, n - 1, 10).astype(int):
+        cm = orc.build_align_contact_map(coords[i], q_alns[i], t_alns[i], 6.0, 2)
+        assert np.max(np.abs(full[i] - gcn_oracle.gcn_forward(w, seqs[i], cm))) < TOL, i
+    perm = np.random.default_rng(1).permutation(n)
+    shuffled, n_chunks2 = run(list(perm), 8192)
+    assert n_chunks2 == 32 and np.array_equal(shuffled, full[perm])
+    assert np.array_equal(run([123, 7], 65536)[0], full[[123, 7]])
+    assert len({row.tobytes() for row in full}) == n        # no two proteins collapse onto the same scores
+
+
 def test_model_file_round_trip(tmp_path, mf):
     from mDeepFRI import weights
     from mDeepFRI.predict import Predictor

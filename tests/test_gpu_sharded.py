@@ -109,3 +109,61 @@ def test_two_ranks_filtered_gather_equals_single_process_filter():
     eng.check(db)
     o1, t1, s1 = (x.cpu().numpy() for x in filter_scores(out["mf"], threshold=0.1))
     assert off[-1] > 0 and np.array_equal(off, o1) and np.array_equal(terms, t1) and np.array_equal(scores, s1)
+
+
+def _mixed_workload():
+    """BASELINE.json configs[3] in miniature: L ~ U{128..1024}, 5 % indels (the generator bench.py uses for the real thing)."""
+    from mDeepFRI import synthetic
+    lengths = synthetic.uniform_lengths(46, 512)
+    return synthetic.bulk_proteins(46, lengths, range(512), indel_rate=0.05)
+
+
+def _worker_mixed(rank, world, port, q):
+    import torch.distributed as dist
+    from mDeepFRI import batch, sharding, synthetic
+    from mDeepFRI.predict import Predictor
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        seqs, coords, q_alns, t_alns = _mixed_workload()
+        w = synthetic.glorot_gcn_weights(seed=0, n_terms=96)
+        eng = batch.HotPathEngine({"mf": Predictor("syn", weights=w, device=0)}, device=0, max_rows=32768)
+        res = sharding.predict_sharded(eng, seqs, coords, q_alns, t_alns, max_rows=32768)
+        if rank == 0:
+            q.put(res["mf"].cpu().numpy())
+        else:
+            assert res is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_configs3_shape_512_mixed_proteins_two_ranks():
+    """512 proteins with ragged lengths and gapped alignments, dealt to two ranks by cost: rank 0 ends up with every protein's
+    scores in input order, bitwise equal to the single-process result, and a sample agrees with the oracle."""
+    import torch.multiprocessing as mp
+    import cmap_oracle as orc
+    import gcn_oracle
+    from mDeepFRI import batch, sharding, synthetic
+    from mDeepFRI.predict import Predictor
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_mixed, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sharded = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    seqs, coords, q_alns, t_alns = _mixed_workload()
+    assert min(map(len, seqs)) >= 128 and max(map(len, seqs)) <= 1024 and any("-" in a for a in q_alns) and any("-" in a for a in t_alns)
+    shards = sharding.partition_by_cost([len(s) for s in seqs], 2)
+    loads = [sum(sharding.protein_cost(len(seqs[i])) for i in sh) for sh in shards]
+    assert abs(loads[0] - loads[1]) <= 1024 + 31
+    w = synthetic.glorot_gcn_weights(seed=0, n_terms=96)
+    eng = batch.HotPathEngine({"mf": Predictor("syn", weights=w, device=0)}, device=0, max_rows=65536)
+    single = eng.run_alignments(batch.PackedProteins.pack(seqs, coords, q_alns, t_alns, max_rows=65536))["mf"]
+    assert sharded.shape == single.shape == (512, 96) and np.array_equal(sharded, single)
+    for i in (0, 200, 511):
+        cm = orc.build_align_contact_map(coords[i], q_alns[i], t_alns[i], 6.0, 2)
+        assert np.max(np.abs(sharded[i] - gcn_oracle.gcn_forward(w, seqs[i], cm))) < 1e-4
