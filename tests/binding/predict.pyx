@@ -1,0 +1,219 @@
+# cython: language_level=3
+"""The binding a reference maintainer adds to mDeepFRI/predict.pyx (INTEGRATION.md section B), compiled: `seq2onehot` and the
+`cdef class Predictor` with the reference's public attributes (predict.pyx:50-60) and methods, the onnxruntime session replaced by
+the model handles of include/mdfri.h.  The weight tensors come from the pure-Python container readers of this build
+(mDeepFRI.weights: .mdfw / .npz / .onnx) and cross the boundary as plain float pointers (mdf_model_create / mdf_cnn_create /
+mdf_lm_create).  Builder-authored; no reference code."""
+import numpy as np
+
+cimport numpy as cnp
+from libc.stdint cimport int32_t, int64_t
+from libc.stdlib cimport free, malloc
+
+cnp.import_array()
+
+cdef extern from "mdfri.h":
+    ctypedef struct mdf_model
+    ctypedef struct mdf_lm
+    ctypedef struct mdf_cnn
+    ctypedef struct mdf_gcn_weights:
+        int32_t embed
+        int32_t n_gc
+        int32_t gc_dims[3]
+        int32_t fc_dim
+        int32_t n_terms
+        const float *W_aa
+        const float *W_gc[3]
+        const float *W_fc
+        const float *b_fc
+        const float *W_out
+        const float *b_out
+        int32_t lm_dim
+        const float *W_lm
+        const float *b_lm
+    ctypedef struct mdf_lm_weights:
+        int32_t hidden
+        const float *W1
+        const float *U1
+        const float *b1
+        const float *W2
+        const float *U2
+        const float *b2
+    ctypedef struct mdf_cnn_weights:
+        int32_t n_branch
+        const int32_t *kernel_len
+        const int32_t *filters
+        const int32_t *pad_left
+        const float *const *W
+        const float *const *b
+        const float *bn_gamma
+        const float *bn_beta
+        const float *bn_mean
+        const float *bn_var
+        float bn_eps
+        int32_t n_terms
+        const float *W_out
+        const float *b_out
+    const char *mdf_last_error()
+    int mdf_seq2onehot(const char *seq, int64_t L, float *out, int64_t *bad_idx) nogil
+    int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
+    void mdf_model_free(mdf_model *m)
+    int mdf_model_num_terms(const mdf_model *m)
+    int mdf_lm_create(const mdf_lm_weights *w, int device, mdf_lm **out)
+    void mdf_lm_free(mdf_lm *lm)
+    int mdf_model_attach_lm(mdf_model *m, mdf_lm *lm)
+    int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *cmap, int cmap_dtype, float *scores,
+                             int64_t *bad_idx) nogil
+    int mdf_cnn_create(const mdf_cnn_weights *w, int device, mdf_cnn **out)
+    void mdf_cnn_free(mdf_cnn *m)
+    int mdf_cnn_num_terms(const mdf_cnn *m)
+    int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, int64_t *bad_idx) nogil
+
+DEF MDF_EBADCHAR = -4
+DEF MDF_DT_F32 = 1
+
+
+cdef int _check(int rc) except -1:
+    if rc != 0:
+        msg = mdf_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)
+        raise RuntimeError(f"libmdfri_hip error {rc}: {msg}")
+    return 0
+
+
+cdef const float *_fp(cnp.ndarray a):
+    return <const float *>a.data
+
+
+cpdef cnp.ndarray[float, ndim=2] seq2onehot(str seq):
+    cdef bytes b = seq.encode("ascii")
+    cdef Py_ssize_t L = len(b)
+    cdef cnp.ndarray[float, ndim=2, mode="c"] out = np.zeros((L, 26), dtype=np.float32)
+    cdef int64_t bad = -1
+    cdef int rc = 0
+    cdef const char *sp = b
+    cdef float *op = <float *>out.data
+    if L > 0:
+        with nogil:
+            rc = mdf_seq2onehot(sp, L, op, &bad)
+    if rc == MDF_EBADCHAR:
+        raise ValueError(f"Invalid character in sequence: {seq[bad]}")
+    _check(rc)
+    return out
+
+
+cdef class Predictor(object):
+    cdef public str model_path
+    cdef public int threads
+    cdef public object session      # attribute kept for compatibility: a small description of what was loaded
+    cdef public list input_names
+    cdef mdf_model *_gcn
+    cdef mdf_lm *_lm
+    cdef mdf_cnn *_cnn
+    cdef int _T
+
+    def __init__(self, model_path: str, threads: int = 1, ):
+        self.model_path = model_path
+        self.threads = threads
+        self._load_model()
+
+    def _load_model(self):
+        from mDeepFRI import weights as W
+        w = W.load_weights(W.resolve_model_path(self.model_path))
+        arrs = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in w.items()}
+        if W.model_kind(w) == "cnn":
+            self._load_cnn(arrs, W.validate_cnn(w))
+            self.input_names = ["seq"]
+        else:
+            self._load_gcn(arrs, W.validate(w))
+            self.input_names = ["cmap", "seq"]
+        self.session = {"kind": "cnn" if self._cnn != NULL else "gcn", "n_terms": self._T, "device": 0}
+
+    cdef _load_gcn(self, dict a, dict topo):
+        cdef mdf_gcn_weights g
+        cdef mdf_lm_weights l
+        cdef int k
+        g.embed, g.n_gc, g.fc_dim, g.n_terms = topo["embed"], len(topo["gc_dims"]), topo["fc_dim"], topo["n_terms"]
+        for k in range(3):
+            g.gc_dims[k] = topo["gc_dims"][k] if k < g.n_gc else 0
+            g.W_gc[k] = _fp(a[f"W_gc{k + 1}"]) if k < g.n_gc else NULL
+        g.W_aa, g.W_fc, g.b_fc, g.W_out, g.b_out = _fp(a["W_aa"]), _fp(a["W_fc"]), _fp(a["b_fc"]), _fp(a["W_out"]), _fp(a["b_out"])
+        g.lm_dim = topo["lm_dim"]
+        g.W_lm = _fp(a["W_lm"]) if g.lm_dim else NULL
+        g.b_lm = _fp(a["b_lm"]) if g.lm_dim else NULL
+        _check(mdf_model_create(&g, 0, &self._gcn))
+        if g.lm_dim:
+            l.hidden = a["lm_U1"].shape[0]
+            l.W1, l.U1, l.b1 = _fp(a["lm_W1"]), _fp(a["lm_U1"]), _fp(a["lm_b1"])
+            l.W2, l.U2, l.b2 = _fp(a["lm_W2"]), _fp(a["lm_U2"]), _fp(a["lm_b2"])
+            _check(mdf_lm_create(&l, 0, &self._lm))
+            _check(mdf_model_attach_lm(self._gcn, self._lm))
+        self._T = mdf_model_num_terms(self._gcn)
+
+    cdef _load_cnn(self, dict a, dict topo):
+        cdef mdf_cnn_weights c
+        cdef int n = len(topo["filters"]), k
+        cdef int32_t *meta = <int32_t *>malloc(3 * n * sizeof(int32_t))
+        cdef const float **ptrs = <const float **>malloc(2 * n * sizeof(const float *))
+        if meta == NULL or ptrs == NULL:
+            free(meta)
+            free(ptrs)
+            raise MemoryError()
+        try:
+            for k in range(n):
+                meta[k] = topo["kernel_lens"][k]
+                meta[n + k] = topo["filters"][k]
+                meta[2 * n + k] = int(np.asarray(a.get(f"cnn_pad{k + 1}", (topo["kernel_lens"][k] - 1) // 2)).reshape(-1)[0])
+                ptrs[k] = _fp(a[f"cnn_W{k + 1}"])
+                ptrs[n + k] = _fp(a[f"cnn_b{k + 1}"])
+            c.n_branch, c.kernel_len, c.filters, c.pad_left = n, meta, meta + n, meta + 2 * n
+            c.W, c.b = ptrs, ptrs + n
+            c.bn_gamma, c.bn_beta, c.bn_mean, c.bn_var = _fp(a["bn_gamma"]), _fp(a["bn_beta"]), _fp(a["bn_mean"]), _fp(a["bn_var"])
+            c.bn_eps = float(np.asarray(a.get("bn_eps", 1e-3)).reshape(-1)[0])
+            c.n_terms = topo["n_terms"]
+            c.W_out, c.b_out = _fp(a["W_out"]), _fp(a["b_out"])
+            _check(mdf_cnn_create(&c, 0, &self._cnn))
+        finally:
+            free(meta)
+            free(ptrs)
+        self._T = mdf_cnn_num_terms(self._cnn)
+
+    def forward_pass(self, seqres: str, cmap = None):
+        cdef bytes b = seqres.encode("ascii")
+        cdef Py_ssize_t L = len(b)
+        cdef cnp.ndarray[float, ndim=1, mode="c"] y = np.empty(self._T, dtype=np.float32)
+        cdef cnp.ndarray A
+        cdef int64_t bad = -1
+        cdef int rc
+        cdef const char *sp = b
+        cdef float *yp = <float *>y.data
+        cdef const void *ap
+        if L == 0:
+            raise ValueError("empty sequence")
+        if cmap is not None:
+            if self._gcn == NULL:
+                raise ValueError("this is a sequence-only (CNN) model: it takes no contact map")
+            A = np.ascontiguousarray(cmap, dtype=np.float32)        # the reference casts with astype(np.float32) at this spot
+            if A.ndim != 2 or A.shape[0] != L or A.shape[1] != L:
+                raise ValueError(f"cmap has shape {(<object>A).shape}, expected ({L}, {L})")
+            ap = <const void *>A.data
+            with nogil:
+                rc = mdf_gcn_forward_host(self._gcn, sp, L, ap, MDF_DT_F32, yp, &bad)
+        else:
+            if self._cnn == NULL:
+                raise ValueError("this is a GCN model (inputs cmap, seq): pass the contact map")
+            with nogil:
+                rc = mdf_cnn_forward_host(self._cnn, sp, L, yp, &bad)
+        if rc == MDF_EBADCHAR:
+            raise ValueError(f"Invalid character in sequence: {seqres[bad]}")
+        _check(rc)
+        return y
+
+    def __dealloc__(self):
+        if self._gcn != NULL:
+            mdf_model_free(self._gcn)
+        if self._lm != NULL:
+            mdf_lm_free(self._lm)
+        if self._cnn != NULL:
+            mdf_cnn_free(self._cnn)

@@ -1,0 +1,102 @@
+"""The compiled reference-side binding (tests/binding/*.pyx -> Cython -> g++, linked with libmdfri_hip.so) on the GPU: the
+reference's own known-answer tests re-expressed (tests/test_contact_map_utils.py:15-25, tests/test_predict.py:9-33), the golden
+align cases, and the reference's forked-Pool call pattern for build_align_contact_map (pipeline.py:476-481)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cmap_oracle as orc
+import gcn_oracle
+from conftest import ROOT, gstr
+from mDeepFRI import synthetic, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def compiled():
+    import binding_loader
+    return binding_loader.load()
+
+
+def test_pairwise_sqeuclidean_reference_kat_and_goldens(compiled, cmap_golden):
+    cmu, _ = compiled
+    np.random.seed(42)                                  # reference tests/test_contact_map_utils.py:15-25
+    result = cmu.pairwise_sqeuclidean(np.random.rand(3, 3).astype(np.float32))
+    expected = np.array([[0, 1.01354558, 0.12442072], [1.01354558, 0, 0.99467713], [0.12442072, 0.99467713, 0]], dtype=np.float32)
+    assert np.allclose(result, expected)
+    rng = np.random.default_rng(5)
+    for n in (1, 64, 300):
+        X = synthetic.random_walk_coords(rng, n)
+        D = cmu.pairwise_sqeuclidean(X, threads=1)
+        assert D.dtype == np.float32 and np.array_equal(D.view(np.uint32), orc.pairwise_sqeuclidean(X).view(np.uint32))   # bit patterns
+
+
+def test_align_contact_map_golden_cases(compiled, cmap_golden):
+    cmu, _ = compiled
+    names = [str(x) for x in cmap_golden["index/align"]]
+    assert len(names) >= 20
+    for n in names:
+        out = cmu.align_contact_map(gstr(cmap_golden[n + "/q"]), gstr(cmap_golden[n + "/t"]), cmap_golden[n + "/pairs"],
+                                    int(cmap_golden[n + "/gen"]))
+        assert out.dtype == np.int32 and np.array_equal(out, cmap_golden[n + "/out"]), n
+    assert np.array_equal(cmu.align_contact_map("AB", "AB", np.array([[0, 1]], dtype=np.int32)), [[1, 1], [0, 1]])   # the .pyx-actual output
+
+
+def test_seq2onehot_reference_kats(compiled):
+    _, pr = compiled                                    # reference tests/test_predict.py:9-33
+    r = pr.seq2onehot("")
+    assert r.shape == (0, 26) and r.dtype == np.float32
+    exp = np.zeros((4, 26), np.float32)
+    exp[0, 21] = exp[1, 11] = exp[2, 1] = exp[3, 17] = 1
+    assert np.array_equal(pr.seq2onehot("ACDE"), exp)
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        pr.seq2onehot("AJD*Z")
+    with pytest.raises(ValueError, match="Invalid character in sequence: a"):
+        pr.seq2onehot("ACDa")
+    assert np.array_equal(pr.seq2onehot("-DGULNTKHYWCPVSOIEFXQABZRM"), np.eye(26, dtype=np.float32))
+
+
+def test_predictor_gcn_lm_and_cnn_through_the_compiled_class(compiled, tmp_path):
+    _, pr = compiled
+    from mDeepFRI.predict import Predictor as CtypesPredictor
+    rng = np.random.default_rng(3)
+    seq = synthetic.random_sequence(rng, 140)
+    cm = orc.calculate_contact_map(synthetic.random_walk_coords(rng, 140), 6.0)
+    w = synthetic.glorot_gcn_weights(seed=4, n_terms=33)
+    path = tmp_path / "DeepFRI-SYNTH_GraphConv_gcd_512-512-512_fcd_1024_ca_10.0_mf.mdfw"
+    weights.save_mdfw(str(path), w)
+    p = pr.Predictor(str(path).replace(".mdfw", ".onnx"), threads=1)      # the pipeline passes the .onnx name (pipeline.py:584)
+    assert p.model_path.endswith(".onnx") and p.threads == 1 and p.input_names == ["cmap", "seq"] and p.session is not None
+    y = p.forward_pass(seq, cm)
+    assert y.dtype == np.float32 and y.shape == (33,)
+    assert np.max(np.abs(y - gcn_oracle.gcn_forward(w, seq, cm))) < 1e-4
+    assert np.array_equal(y, CtypesPredictor("x", weights=w).forward_pass(seq, cm))      # both bindings, one library: identical
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        p.forward_pass("AJD*Z", np.eye(5, dtype=np.int32))
+    # language-model branch and the sequence-only CNN (predict.pyx:91-95: cmap=None)
+    import cnn_oracle
+    import lm_oracle
+    wl = synthetic.glorot_gcn_weights(seed=1, n_terms=20, embed=256, gc_dims=(256, 256), fc_dim=256)
+    wl.update(synthetic.glorot_lm_weights(seed=2, hidden=64, embed=256))
+    weights.save_mdfw(str(tmp_path / "lm.mdfw"), wl)
+    yl = pr.Predictor(str(tmp_path / "lm.mdfw")).forward_pass(seq, cm)
+    assert np.max(np.abs(yl - lm_oracle.gcn_lm_forward(wl, seq, cm))) < 1e-4
+    wc = synthetic.glorot_cnn_weights(seed=3, n_terms=20)
+    weights.save_mdfw(str(tmp_path / "DeepCNN-SYNTH_mf.mdfw"), wc)
+    pc = pr.Predictor(str(tmp_path / "DeepCNN-SYNTH_mf.onnx"))
+    assert pc.input_names == ["seq"]
+    assert np.max(np.abs(pc.forward_pass(seq) - cnn_oracle.cnn_forward(wc, seq))) < 1e-4
+
+
+def test_forked_pool_map_build_align_contact_map():
+    """reference pipeline.py:476-481 from a parent that has not touched the GPU (a fresh interpreter: this pytest process has)."""
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fork_pool_script.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n"] == 24 and out["none"] == 1 and out["ok"] == 23 and out["names"] == ["q0", "q1", "q2"]
