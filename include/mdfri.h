@@ -296,6 +296,47 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
                           float *kept_scores, int64_t capacity, int32_t *status, void *workspace, size_t workspace_bytes,
                           void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Alignment step in front of the path: global Needleman-Wunsch with affine gaps, the
+ * arithmetic the reference obtains from PyOpal at mDeepFRI/alignment.py:164-250
+ *     best_hit_database (:164-196)  aligner.align(query, database, mode="score", algorithm="nw")  -> mdf_nw_score_*
+ *     align_pairwise    (:198-221)  aligner.align(query, [target], mode="full", algorithm="nw")    -> mdf_nw_align_*
+ * Sequences are residue CODES (indices into the scoring matrix alphabet, < A <= 32), packed: sequence s occupies
+ * codes[seq_off[s] .. seq_off[s] + seq_len[s]).  A pair p aligns query sequence pair_q[p] with target sequence pair_t[p].
+ * matrix: (A, A) int32 row-major, matrix[q][t].  A gap of length n costs gap_open + (n - 1) * gap_extend (Opal's model).
+ * Operations: 'M' match, 'X' mismatch, 'D' query residue against a target gap, 'I' target residue against a query gap --
+ * the letters reference insert_gaps (alignment.py:38-62) consumes.  Co-optimal alignments are resolved as stated in
+ * oracle/nw_oracle.c (diagonal >= 'D' >= 'I'; opening a gap wins a tie against extending one); integer work, bit-exact
+ * with that oracle.  PyOpal itself is not available offline: parity with it is unpinned.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Host helper: per-pair offsets into the three per-pair buffers, P + 1 entries each (entry P = total; any may be NULL):
+ * bnd_off in int32 elements (2 * Lq per pair), trace_off in bytes, ops_off in bytes (capacity Lq + Lt per pair). */
+int mdf_nw_plan(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P, int64_t *bnd_off, int64_t *trace_off,
+                int64_t *ops_off);
+
+/* Scores of P pairs (device pointers; bnd: int32 workspace of bnd_off[P] elements).  One wave per pair. */
+int mdf_nw_score_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t,
+                     int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const int64_t *bnd_off, int32_t *bnd,
+                     int32_t *scores, void *stream);
+
+/* Full alignments of P pairs (device pointers).  trace: trace_off[P] bytes of workspace.  Pair p's operations are written to
+ * ops[ops_off[p+1] - op_len[p] .. ops_off[p+1]) (right-aligned inside the pair's capacity); q_aln / t_aln (optional, same
+ * layout) receive the gapped query / target strings spelled with `alphabet` (A letters, device) -- what insert_gaps would
+ * build.  n_match[p] = number of 'M' (identity = n_match / op_len, alignment.py:214); coverages of a global alignment are 1. */
+int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t,
+                     int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet, const int64_t *bnd_off,
+                     int32_t *bnd, const int64_t *trace_off, uint8_t *trace, const int64_t *ops_off, char *ops, char *q_aln, char *t_aln,
+                     int32_t *op_len, int32_t *n_match, int32_t *scores, void *stream);
+
+/* The same with host buffers (upload, run, download): n_seq sequences, P pairs; ops / q_aln / t_aln hold sum(Lq + Lt) bytes
+ * laid out as mdf_nw_plan's ops_off says; alphabet is a NUL-terminated string of A letters. */
+int mdf_nw_score_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
+                      const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int32_t *scores);
+int mdf_nw_align_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
+                      const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet,
+                      char *ops, char *q_aln, char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores);
+
 /* Timing hook for bench.py: mdf_timing_enable(n), n = 0 off, n >= 1: the library brackets every n-th launch of each
  * kernel class with hipEvents on the stream it is launched on and accumulates count and milliseconds of the sampled
  * launches (read after a sync).  An event pair costs GPU time between kernels (~6 % of the step when every launch is

@@ -1,0 +1,345 @@
+// nw.hip -- batched global (Needleman-Wunsch) alignment with affine gaps on gfx950: the step in front of the hot path
+// (SURVEY.md section 8f row 4).  Replaces the PyOpal calls of reference mDeepFRI/alignment.py:164-250:
+//     best_hit_database  (:164-196)  score mode over a query's candidate set            -> k_nw<false>
+//     align_pairwise     (:198-221)  full alignment: operation string, identity, coverages -> k_nw<true> + k_nw_traceback
+//
+// Integer dynamic programming, HBM/latency-light and VALU-bound -- no GEMM shape, no MFMA.  One WAVE per (query, target)
+// pair: the DP matrix is swept in vertical strips of 64 target columns, lane = column, the rows skewed so that lane l works
+// on row s - l at step s (an anti-diagonal per step).  Everything a cell needs lives in registers of its own lane (the
+// cell above: previous step) or of lane l-1 (the cell to the left: previous step; the diagonal: two steps back), so a step
+// is three DPP wave shifts + ~15 integer ops + one LDS lookup of the substitution score; the column between two strips goes
+// through a small L2-resident buffer, fetched 64 rows at a time.  Many pairs in flight per SIMD hide the LDS latency.
+// Full alignments additionally store one direction byte per cell (coalesced: 64 B per step, in sweep order) and a second
+// kernel walks back from the corner, one thread per pair, writing the operations (and the gapped strings) back to front.
+//
+// Recurrences and tie rules are those of oracle/nw_oracle.c (Opal's published model: a gap of length n costs
+// open + (n-1)*extend; at H diagonal >= vertical >= horizontal; inside a gap opening wins a tie) -- bit-exact integer work.
+// PARITY UNPINNED against PyOpal itself (absent offline), see the oracle's header.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace mdf {
+
+constexpr int NW_NEG = INT32_MIN / 2;
+constexpr int NW_LDA = 32;   // row pitch of the substitution matrix in LDS; alphabet size <= 32
+
+// lane l <- value of lane l-1 (previous lane of the wave); lane 0 <- fill.  DPP wave_shr:1 (gfx9 family: one VALU op).
+__device__ __forceinline__ int wave_shr1(int v, int fill)
+{
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ int ld_coherent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coherent(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// steps of one strip, padded: rows Lq skewed over 64 lanes
+__host__ __device__ __forceinline__ int64_t nw_strip_steps(int Lq) { return (int64_t)Lq + 64; }
+
+template <bool TRACE>
+__global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
+                                            const int32_t *__restrict__ seq_len, const int32_t *__restrict__ pair_q,
+                                            const int32_t *__restrict__ pair_t, int P, const int32_t *__restrict__ matrix, int A,
+                                            int go, int ge, const int64_t *__restrict__ bnd_off, int32_t *bnd,
+                                            const int64_t *__restrict__ trace_off, uint8_t *__restrict__ trace,
+                                            int32_t *__restrict__ scores)
+{
+    __shared__ int s_S[NW_LDA * NW_LDA];
+    for (int e = threadIdx.x; e < NW_LDA * NW_LDA; e += blockDim.x) {
+        const int r = e / NW_LDA, c = e % NW_LDA;
+        s_S[e] = (r < A && c < A) ? matrix[r * A + c] : 0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int iq = pair_q[p], it = pair_t[p];
+    const int Lq = seq_len[iq], Lt = seq_len[it];
+    const uint8_t *q = codes + seq_off[iq], *t = codes + seq_off[it];
+    if (Lq == 0 || Lt == 0) {   // degenerate: one all-gap run (or nothing)
+        if (lane == 0) scores[p] = (Lq + Lt == 0) ? 0 : -(go + (Lq + Lt - 1) * ge);
+        return;
+    }
+    int32_t *Hb = bnd + bnd_off[p], *Eb = Hb + Lq;   // H / E of the column left of the current strip, rows 1..Lq
+    uint8_t *tr = TRACE ? trace + trace_off[p] : nullptr;
+    const int n_strips = (Lt + 63) >> 6;
+    const int n_steps = Lq + 63;
+    for (int k = 0; k < n_strips; ++k) {
+        const int j = (k << 6) + lane;                 // my column: target residue j, DP column j + 1
+        const int tc = j < Lt ? (int)t[j] : 0;
+        int up = -(go + j * ge);                       // H[0][j+1]
+        int fup = NW_NEG;                              // F[0][j+1]
+        int diag = j == 0 ? 0 : -(go + (j - 1) * ge);  // H[0][j]
+        int h_out = NW_NEG, e_out = NW_NEG, qc = 0;
+        uint8_t *trk = TRACE ? tr + (int64_t)k * nw_strip_steps(Lq) * 64 : nullptr;
+        const bool pass_right = k + 1 < n_strips;
+        for (int s0 = 0; s0 < n_steps; s0 += 64) {
+            // this chunk's rows for lane 0: query residues and the boundary column
+            const int r = s0 + lane;
+            const int qchunk = r < Lq ? (int)q[r] : 0;
+            int hbchunk, ebchunk;
+            if (k == 0) {
+                hbchunk = -(go + r * ge);              // H[r+1][0]
+                ebchunk = NW_NEG;                      // E[r+1][0]
+            } else {
+                hbchunk = r < Lq ? ld_coherent(Hb + r) : NW_NEG;
+                ebchunk = r < Lq ? ld_coherent(Eb + r) : NW_NEG;
+            }
+            const int u_end = min(64, n_steps - s0);
+            for (int u = 0; u < u_end; ++u) {
+                const int s = s0 + u;
+                // what lane l-1 produced one step ago is this row's left neighbour; lane 0 takes the boundary column
+                const int left = wave_shr1(h_out, __builtin_amdgcn_readlane(hbchunk, u));
+                const int eleft = wave_shr1(e_out, __builtin_amdgcn_readlane(ebchunk, u));
+                qc = wave_shr1(qc, __builtin_amdgcn_readlane(qchunk, u));
+                const int i = s - lane;                // my row: query residue i, DP row i + 1
+                int code = 0;
+                if (i >= 0 && i < Lq) {
+                    const int e_open = left - go, e_ext = eleft - ge;
+                    const int f_open = up - go, f_ext = fup - ge;
+                    int e = e_open, f = f_open;
+                    if (e_ext > e_open) { e = e_ext; code |= 4; }
+                    if (f_ext > f_open) { f = f_ext; code |= 8; }
+                    int h = diag + s_S[qc * NW_LDA + tc];
+                    if (f > h) { h = f; code |= 1; }
+                    if (e > h) { h = e; code = (code & ~3) | 2; }
+                    diag = left;
+                    up = h;
+                    fup = f;
+                    h_out = h;
+                    e_out = e;
+                    if (pass_right && lane == 63) {
+                        st_coherent(Hb + i, h);
+                        st_coherent(Eb + i, e);
+                    }
+                    if (i == Lq - 1 && j == Lt - 1) scores[p] = h;
+                }
+                if (TRACE) trk[(int64_t)s * 64 + lane] = (uint8_t)code;   // 64 contiguous bytes per step
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the boundary column is complete before the next strip reads it
+    }
+}
+
+// One thread per pair: walk the direction bytes back from (Lq, Lt).  Operations (and, optionally, the gapped strings) are
+// written back to front into [ops_off[p+1] - n, ops_off[p+1]); op_len[p] = n, n_match[p] = number of 'M'.
+__global__ __launch_bounds__(64) void k_nw_traceback(const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
+                                                     const int32_t *__restrict__ seq_len, const int32_t *__restrict__ pair_q,
+                                                     const int32_t *__restrict__ pair_t, int P, const int64_t *__restrict__ trace_off,
+                                                     const uint8_t *__restrict__ trace, const int64_t *__restrict__ ops_off,
+                                                     const char *__restrict__ alphabet, char *__restrict__ ops,
+                                                     char *__restrict__ q_aln, char *__restrict__ t_aln,
+                                                     int32_t *__restrict__ op_len, int32_t *__restrict__ n_match)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const int iq = pair_q[p], it = pair_t[p];
+    const int Lq = seq_len[iq], Lt = seq_len[it];
+    const uint8_t *q = codes + seq_off[iq], *t = codes + seq_off[it];
+    const uint8_t *tr = trace + trace_off[p];
+    const int64_t strip = nw_strip_steps(Lq) * 64;
+    auto code_at = [&](int i, int j) -> int {   // DP cell (i, j), both >= 1
+        const int jj = j - 1, ln = jj & 63;
+        return tr[(int64_t)(jj >> 6) * strip + (int64_t)(i - 1 + ln) * 64 + ln];
+    };
+    int64_t w = ops_off[p + 1];
+    int i = Lq, j = Lt, n = 0, matches = 0, state = 0;   // state 0: H, 1: vertical gap ('D'), 2: horizontal gap ('I')
+    while (i > 0 || j > 0) {
+        char op, qa, ta;
+        if (state == 0) {
+            if (i == 0) { state = 2; continue; }
+            if (j == 0) { state = 1; continue; }
+            const int src = code_at(i, j) & 3;
+            if (src != 0) { state = src; continue; }
+            const bool same = q[i - 1] == t[j - 1];
+            op = same ? 'M' : 'X';
+            matches += same;
+            qa = alphabet[q[i - 1]];
+            ta = alphabet[t[j - 1]];
+            --i;
+            --j;
+        } else if (state == 1) {
+            const int ext = (j == 0) ? (i > 1) : ((code_at(i, j) >> 3) & 1);
+            op = 'D';
+            qa = alphabet[q[i - 1]];
+            ta = '-';
+            --i;
+            state = ext ? 1 : 0;
+        } else {
+            const int ext = (i == 0) ? (j > 1) : ((code_at(i, j) >> 2) & 1);
+            op = 'I';
+            qa = '-';
+            ta = alphabet[t[j - 1]];
+            --j;
+            state = ext ? 2 : 0;
+        }
+        --w;
+        ops[w] = op;
+        if (q_aln) q_aln[w] = qa;
+        if (t_aln) t_aln[w] = ta;
+        ++n;
+    }
+    op_len[p] = n;
+    n_match[p] = matches;
+}
+
+static int nw_check(const void *codes, const void *seq_off, const void *seq_len, const void *pq, const void *pt, int32_t P,
+                    const void *matrix, int32_t A, int go, int ge)
+{
+    MDF_REQUIRE(codes && seq_off && seq_len && pq && pt && matrix, "nw: NULL argument");
+    MDF_REQUIRE(P > 0, "nw: no pairs (P=%d)", P);
+    MDF_REQUIRE(A > 0 && A <= NW_LDA, "nw: alphabet size %d not in 1..%d", A, NW_LDA);
+    MDF_REQUIRE(go >= 0 && ge >= 0 && go < (1 << 20) && ge < (1 << 20), "nw: gap penalties must be non-negative (open=%d, extend=%d)", go, ge);
+    return MDF_OK;
+}
+
+}  // namespace mdf
+
+using namespace mdf;
+
+extern "C" {
+
+int mdf_nw_plan(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P, int64_t *bnd_off, int64_t *trace_off,
+                int64_t *ops_off)
+{
+    MDF_REQUIRE(seq_len && pair_q && pair_t && P >= 0, "nw_plan: bad arguments");
+    int64_t b = 0, tr = 0, o = 0;
+    for (int32_t p = 0; p < P; ++p) {
+        const int64_t Lq = seq_len[pair_q[p]], Lt = seq_len[pair_t[p]];
+        MDF_REQUIRE(Lq >= 0 && Lt >= 0 && Lq < (1 << 24) && Lt < (1 << 24), "nw_plan: sequence length out of range at pair %d", p);
+        if (bnd_off) bnd_off[p] = b;
+        if (trace_off) trace_off[p] = tr;
+        if (ops_off) ops_off[p] = o;
+        b += 2 * Lq;
+        tr += ((Lt + 63) / 64) * nw_strip_steps((int)Lq) * 64;
+        o += Lq + Lt;
+    }
+    if (bnd_off) bnd_off[P] = b;
+    if (trace_off) trace_off[P] = tr;
+    if (ops_off) ops_off[P] = o;
+    return MDF_OK;
+}
+
+int mdf_nw_score_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t,
+                     int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const int64_t *bnd_off, int32_t *bnd,
+                     int32_t *scores, void *stream)
+{
+    if (int rc = nw_check(codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend)) return rc;
+    MDF_REQUIRE(bnd_off && bnd && scores, "nw_score_dev: NULL argument");
+    hipLaunchKernelGGL(k_nw<false>, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), codes, seq_off, seq_len,
+                       pair_q, pair_t, P, matrix, A, gap_open, gap_extend, bnd_off, bnd, (const int64_t *)nullptr, (uint8_t *)nullptr, scores);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t,
+                     int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet, const int64_t *bnd_off,
+                     int32_t *bnd, const int64_t *trace_off, uint8_t *trace, const int64_t *ops_off, char *ops, char *q_aln, char *t_aln,
+                     int32_t *op_len, int32_t *n_match, int32_t *scores, void *stream)
+{
+    if (int rc = nw_check(codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend)) return rc;
+    MDF_REQUIRE(alphabet && bnd_off && bnd && trace_off && trace && ops_off && ops && op_len && n_match && scores, "nw_align_dev: NULL argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_nw<true>, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A,
+                       gap_open, gap_extend, bnd_off, bnd, trace_off, trace, scores);
+    hipLaunchKernelGGL(k_nw_traceback, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, st, codes, seq_off, seq_len, pair_q, pair_t, P, trace_off,
+                       (const uint8_t *)trace, ops_off, alphabet, ops, q_aln, t_aln, op_len, n_match);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+// Host-buffer forms (the per-call shape of alignment.py:164-221): upload, run, download.  n_seq sequences, P pairs.
+static int nw_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
+                   const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int go, int ge, const char *alphabet, char *ops,
+                   char *q_aln, char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores, bool full)
+{
+    if (int rc = nw_check(codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, go, ge)) return rc;
+    MDF_REQUIRE(n_seq > 0 && scores, "nw: bad arguments");
+    MDF_REQUIRE(!full || (alphabet && ops && op_len && n_match), "nw_align_host: NULL output");
+    for (int32_t p = 0; p < P; ++p)
+        MDF_REQUIRE(pair_q[p] >= 0 && pair_q[p] < n_seq && pair_t[p] >= 0 && pair_t[p] < n_seq, "nw: pair %d refers to a sequence out of range", p);
+    if (int rc = require_device()) return rc;
+    int64_t total = 0;
+    for (int32_t s = 0; s < n_seq; ++s) {
+        MDF_REQUIRE(seq_len[s] >= 0 && seq_off[s] >= 0, "nw: negative length/offset at sequence %d", s);
+        total = std::max<int64_t>(total, seq_off[s] + seq_len[s]);
+    }
+    for (int64_t b = 0; b < total; ++b) MDF_REQUIRE(codes[b] < A, "nw: residue code %d at byte %lld is outside the alphabet (size %d)", (int)codes[b], (long long)b, A);
+    std::vector<int64_t> bo((size_t)P + 1), to((size_t)P + 1), oo((size_t)P + 1);
+    if (int rc = mdf_nw_plan(seq_len, pair_q, pair_t, P, bo.data(), to.data(), oo.data())) return rc;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    const size_t o_codes = take((size_t)total + 1), o_soff = take((size_t)n_seq * 8), o_slen = take((size_t)n_seq * 4), o_pq = take((size_t)P * 4),
+                 o_pt = take((size_t)P * 4), o_mat = take((size_t)A * A * 4), o_bo = take(((size_t)P + 1) * 8), o_bnd = take((size_t)bo[P] * 4 + 4),
+                 o_sc = take((size_t)P * 4);
+    size_t o_to = 0, o_tr = 0, o_oo = 0, o_ops = 0, o_qa = 0, o_ta = 0, o_ol = 0, o_nm = 0, o_al = 0;
+    if (full) {
+        o_to = take(((size_t)P + 1) * 8);
+        o_tr = take((size_t)to[P] + 1);
+        o_oo = take(((size_t)P + 1) * 8);
+        o_ops = take((size_t)oo[P] + 1);
+        o_qa = take(q_aln ? (size_t)oo[P] + 1 : 1);
+        o_ta = take(t_aln ? (size_t)oo[P] + 1 : 1);
+        o_ol = take((size_t)P * 4);
+        o_nm = take((size_t)P * 4);
+        o_al = take(64);
+    }
+    Scratch &s = scratch(1);
+    if (int rc = s.reserve(o)) return rc;
+    char *b = static_cast<char *>(s.ptr);
+    MDF_HIP(hipMemcpy(b + o_codes, codes, (size_t)total, hipMemcpyHostToDevice));
+    MDF_HIP(hipMemcpy(b + o_soff, seq_off, (size_t)n_seq * 8, hipMemcpyHostToDevice));
+    MDF_HIP(hipMemcpy(b + o_slen, seq_len, (size_t)n_seq * 4, hipMemcpyHostToDevice));
+    MDF_HIP(hipMemcpy(b + o_pq, pair_q, (size_t)P * 4, hipMemcpyHostToDevice));
+    MDF_HIP(hipMemcpy(b + o_pt, pair_t, (size_t)P * 4, hipMemcpyHostToDevice));
+    MDF_HIP(hipMemcpy(b + o_mat, matrix, (size_t)A * A * 4, hipMemcpyHostToDevice));
+    MDF_HIP(hipMemcpy(b + o_bo, bo.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice));
+    auto D = [&](size_t off) { return b + off; };
+    int rc;
+    if (!full) {
+        rc = mdf_nw_score_dev((const uint8_t *)D(o_codes), (const int64_t *)D(o_soff), (const int32_t *)D(o_slen), (const int32_t *)D(o_pq),
+                              (const int32_t *)D(o_pt), P, (const int32_t *)D(o_mat), A, go, ge, (const int64_t *)D(o_bo), (int32_t *)D(o_bnd),
+                              (int32_t *)D(o_sc), nullptr);
+    } else {
+        char al[64] = {0};
+        memcpy(al, alphabet, std::min<size_t>(strlen(alphabet), 63));
+        MDF_HIP(hipMemcpy(b + o_al, al, 64, hipMemcpyHostToDevice));
+        MDF_HIP(hipMemcpy(b + o_to, to.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice));
+        MDF_HIP(hipMemcpy(b + o_oo, oo.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice));
+        rc = mdf_nw_align_dev((const uint8_t *)D(o_codes), (const int64_t *)D(o_soff), (const int32_t *)D(o_slen), (const int32_t *)D(o_pq),
+                              (const int32_t *)D(o_pt), P, (const int32_t *)D(o_mat), A, go, ge, D(o_al), (const int64_t *)D(o_bo),
+                              (int32_t *)D(o_bnd), (const int64_t *)D(o_to), (uint8_t *)D(o_tr), (const int64_t *)D(o_oo), D(o_ops),
+                              q_aln ? D(o_qa) : nullptr, t_aln ? D(o_ta) : nullptr, (int32_t *)D(o_ol), (int32_t *)D(o_nm), (int32_t *)D(o_sc),
+                              nullptr);
+    }
+    if (rc) return rc;
+    MDF_HIP(hipMemcpy(scores, D(o_sc), (size_t)P * 4, hipMemcpyDeviceToHost));
+    if (full) {
+        MDF_HIP(hipMemcpy(op_len, D(o_ol), (size_t)P * 4, hipMemcpyDeviceToHost));
+        MDF_HIP(hipMemcpy(n_match, D(o_nm), (size_t)P * 4, hipMemcpyDeviceToHost));
+        if (oo[P] > 0) {
+            MDF_HIP(hipMemcpy(ops, D(o_ops), (size_t)oo[P], hipMemcpyDeviceToHost));
+            if (q_aln) MDF_HIP(hipMemcpy(q_aln, D(o_qa), (size_t)oo[P], hipMemcpyDeviceToHost));
+            if (t_aln) MDF_HIP(hipMemcpy(t_aln, D(o_ta), (size_t)oo[P], hipMemcpyDeviceToHost));
+        }
+    }
+    return MDF_OK;
+}
+
+int mdf_nw_score_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
+                      const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int32_t *scores)
+{
+    return nw_host(codes, seq_off, seq_len, n_seq, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, nullptr, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, scores, false);
+}
+
+int mdf_nw_align_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
+                      const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet,
+                      char *ops, char *q_aln, char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores)
+{
+    return nw_host(codes, seq_off, seq_len, n_seq, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, alphabet, ops, q_aln, t_aln, op_len, n_match,
+                   scores, true);
+}
+
+}  // extern "C"

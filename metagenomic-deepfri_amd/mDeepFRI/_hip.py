@@ -113,6 +113,14 @@ SIGNATURES = {
     "mdf_filter_workspace_bytes": (c_size_t, [c_int32]),
     "mdf_filter_scores_dev": (c_int, [c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),
+    "mdf_nw_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "mdf_nw_score_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "mdf_nw_align_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdf_nw_score_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_void_p]),
+    "mdf_nw_align_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_char_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdf_timing_enable": (c_int, [c_int]),
     "mdf_timing_read": (c_int, [c_char_p, _i64p, POINTER(c_double)]),
     "mdf_timing_reset": (c_int, []),

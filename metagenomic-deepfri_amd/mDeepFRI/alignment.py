@@ -1,12 +1,21 @@
-"""Input side of the hot path: the two pieces of the reference's mDeepFRI/alignment.py that the path consumes --
-`insert_gaps` (alignment.py:38-62) and the `AlignmentResult` attribute contract (alignment.py:65-150) -- without the
-PyOpal aligner itself (out of scope: SURVEY.md section 2 row 8).  Lets callers build the batch API's inputs from
-(query, target, alignment string) triples exactly as the reference would."""
+"""Input side of the hot path, with the public names of the reference's mDeepFRI/alignment.py: `insert_gaps` (:38-62), the
+`AlignmentResult` carrier (:65-150), and the alignment step itself -- `best_hit_database` (:164-196), `align_pairwise`
+(:198-221), `pairwise_against_database` (:223-250) -- with PyOpal's SIMD Needleman-Wunsch replaced by the batched HIP kernels
+of csrc/nw.hip (one wave per pair).  `align_queries` is the batched counterpart of the reference's
+`Pool(threads).starmap(pairwise_against_database, ...)` (:266-320): ONE score launch over every (query, candidate) pair, the
+per-query arg-max, ONE full-alignment launch over the winners.
+
+Scoring matrices: the reference takes "VTML80" from the `scoring_matrices` package.  Neither that package nor any copy of the
+table exists offline, so a matrix is an INPUT here: `ScoringMatrix.from_name` asks `scoring_matrices` when it is importable,
+`ScoringMatrix.from_file` reads the NCBI text format, `ScoringMatrix.simple` builds match/mismatch tables.  Parity with PyOpal
+itself is unpinned (oracle/nw_oracle.c states the model and the tie rules used)."""
 from __future__ import annotations
 
 from typing import Optional, Tuple
 
 import numpy as np
+
+from . import _hip
 
 
 def insert_gaps(sequence: str, reference: str, alignment_string: str) -> Tuple[str, str]:
@@ -52,3 +61,242 @@ class AlignmentResult:
                 f"query_identity={self.query_identity}, query_coverage={self.query_coverage})")
 
     __str__ = __repr__
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# scoring matrices
+# ---------------------------------------------------------------------------------------------------------------------
+class ScoringMatrix:
+    """Substitution scores over an alphabet: `alphabet` (str, <= 32 letters) and `matrix` (int32 (A, A), matrix[q][t])."""
+
+    def __init__(self, alphabet: str, matrix, name: str = "custom"):
+        self.alphabet = str(alphabet)
+        self.matrix = np.ascontiguousarray(matrix, dtype=np.int32)
+        self.name = name
+        A = len(self.alphabet)
+        if not (0 < A <= 32) or self.matrix.shape != (A, A) or len(set(self.alphabet)) != A:
+            raise ValueError("scoring matrix must be (A, A) over an alphabet of A <= 32 distinct letters")
+        self._lut = np.full(256, 255, dtype=np.uint8)
+        for i, c in enumerate(self.alphabet):
+            self._lut[ord(c)] = i
+
+    @classmethod
+    def simple(cls, alphabet: str = "ARNDCQEGHILKMFPSTWYVBZX*", match: int = 5, mismatch: int = -4):
+        A = len(alphabet)
+        m = np.full((A, A), mismatch, dtype=np.int32)
+        np.fill_diagonal(m, match)
+        return cls(alphabet, m, name=f"simple({match},{mismatch})")
+
+    @classmethod
+    def from_file(cls, path: str):
+        """NCBI / EMBOSS text format: '#' comments, a header row of letters, then one row per letter."""
+        rows, header = [], None
+        with open(path) as f:
+            for line in f:
+                line = line.strip()
+                if not line or line.startswith("#"):
+                    continue
+                tok = line.split()
+                if header is None:
+                    header = tok
+                    continue
+                rows.append((tok[0], [int(float(x)) for x in tok[1:1 + len(header)]]))
+        if header is None or [r[0] for r in rows] != header:
+            raise ValueError(f"{path}: not a square substitution matrix in NCBI format")
+        return cls("".join(header), np.array([r[1] for r in rows], dtype=np.int32), name=path)
+
+    @classmethod
+    def from_name(cls, name: str):
+        """The reference's `ScoringMatrix.from_name(name)` (alignment.py:175): served by the `scoring_matrices` package when it
+        is installed; there is no built-in copy of VTML80 (no source for the table exists in this build's environment)."""
+        try:
+            from scoring_matrices import ScoringMatrix as _SM
+        except ImportError:
+            raise ImportError(f"scoring matrix {name!r}: the `scoring_matrices` package is not installed and no table is built in; "
+                              f"pass a ScoringMatrix (ScoringMatrix.from_file(path) reads the NCBI text format)") from None
+        sm = _SM.from_name(name)
+        return cls(sm.alphabet, np.array([list(r) for r in sm.matrix]).round().astype(np.int32), name=name)
+
+    def encode(self, seq: str) -> np.ndarray:
+        codes = self._lut[np.frombuffer(seq.encode("ascii"), dtype=np.uint8)]
+        if (codes == 255).any():
+            raise ValueError(f"character {seq[int(np.argmax(codes == 255))]!r} is not in the scoring matrix alphabet")
+        return codes
+
+
+def _matrix(scoring_matrix) -> ScoringMatrix:
+    return scoring_matrix if isinstance(scoring_matrix, ScoringMatrix) else ScoringMatrix.from_name(scoring_matrix)
+
+
+def _upper(seq):
+    return seq.upper() if seq else seq
+
+
+class _PairBatch:
+    """Encoded sequences + pair lists in the layout of mdf_nw_* (include/mdfri.h)."""
+
+    def __init__(self, sequences, sm: ScoringMatrix):
+        enc = [sm.encode(s) for s in sequences]
+        self.seq_len = np.array([len(e) for e in enc], dtype=np.int32)
+        self.seq_off = np.zeros(len(enc), dtype=np.int64)
+        if len(enc) > 1:
+            np.cumsum(self.seq_len[:-1], out=self.seq_off[1:])
+        self.codes = np.concatenate(enc) if enc else np.zeros(0, np.uint8)
+        if self.codes.size == 0:
+            self.codes = np.zeros(1, np.uint8)
+        self.sm = sm
+
+    def scores(self, pair_q, pair_t, gap_open, gap_extend) -> np.ndarray:
+        pq, pt = np.ascontiguousarray(pair_q, dtype=np.int32), np.ascontiguousarray(pair_t, dtype=np.int32)
+        out = np.empty(len(pq), dtype=np.int32)
+        if len(pq):
+            _hip.check(_hip.lib().mdf_nw_score_host(_hip.ptr(self.codes), _hip.ptr(self.seq_off), _hip.ptr(self.seq_len), len(self.seq_len),
+                                                   _hip.ptr(pq), _hip.ptr(pt), len(pq), _hip.ptr(self.sm.matrix), len(self.sm.alphabet),
+                                                   int(gap_open), int(gap_extend), _hip.ptr(out)))
+        return out
+
+    def align(self, pair_q, pair_t, gap_open, gap_extend, max_trace_bytes: int = 4 << 30):
+        """Full alignments -> dict of arrays: ops / q_aln / t_aln (flat uint8), off (P+1, int64: pair p's columns are
+        [off[p], off[p+1])), op_len, n_match, score.  Pairs are processed in groups whose direction bytes fit `max_trace_bytes`."""
+        L = _hip.lib()
+        pq, pt = np.ascontiguousarray(pair_q, dtype=np.int32), np.ascontiguousarray(pair_t, dtype=np.int32)
+        P = len(pq)
+        parts = []
+        cost = (self.seq_len[pt].astype(np.int64) + 63) // 64 * (self.seq_len[pq].astype(np.int64) + 64) * 64
+        p0 = 0
+        while p0 < P:
+            p1, acc = p0, 0
+            while p1 < P and (p1 == p0 or acc + cost[p1] <= max_trace_bytes):
+                acc += cost[p1]
+                p1 += 1
+            n = p1 - p0
+            q_, t_ = np.ascontiguousarray(pq[p0:p1]), np.ascontiguousarray(pt[p0:p1])
+            ops_off = np.zeros(n + 1, dtype=np.int64)
+            _hip.check(L.mdf_nw_plan(_hip.ptr(self.seq_len), _hip.ptr(q_), _hip.ptr(t_), n, None, None, _hip.ptr(ops_off)))
+            cap = max(int(ops_off[-1]), 1)
+            ops, qa, ta = (np.empty(cap, dtype=np.uint8) for _ in range(3))
+            op_len, n_match, score = (np.empty(n, dtype=np.int32) for _ in range(3))
+            _hip.check(L.mdf_nw_align_host(_hip.ptr(self.codes), _hip.ptr(self.seq_off), _hip.ptr(self.seq_len), len(self.seq_len), _hip.ptr(q_),
+                                           _hip.ptr(t_), n, _hip.ptr(self.sm.matrix), len(self.sm.alphabet), int(gap_open), int(gap_extend),
+                                           self.sm.alphabet.encode("ascii"), _hip.ptr(ops), _hip.ptr(qa), _hip.ptr(ta), _hip.ptr(op_len),
+                                           _hip.ptr(n_match), _hip.ptr(score)))
+            # compact: every pair's columns sit right-aligned in its capacity [ops_off[p], ops_off[p+1])
+            start = ops_off[1:] - op_len
+            off = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(op_len, out=off[1:])
+            idx = np.repeat(start - off[:-1], op_len) + np.arange(int(off[-1]), dtype=np.int64)
+            parts.append((ops[idx], qa[idx], ta[idx], op_len, n_match, score))
+            p0 = p1
+        cat = lambda k, dt: np.concatenate([p[k] for p in parts]) if parts else np.zeros(0, dt)  # noqa: E731
+        op_len = cat(3, np.int32)
+        off = np.zeros(P + 1, dtype=np.int64)
+        np.cumsum(op_len, out=off[1:])
+        return {"ops": cat(0, np.uint8), "q_aln": cat(1, np.uint8), "t_aln": cat(2, np.uint8), "off": off, "op_len": op_len,
+                "n_match": cat(4, np.int32), "score": cat(5, np.int32)}
+
+
+def _identity(n_match, op_len):
+    """pyopal FullResult.identity(): matches / alignment length, a C float there -- float32 here, then a Python float."""
+    return float(np.float32(n_match) / np.float32(max(int(op_len), 1)))
+
+
+def best_hit_database(query, target_sequences, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80"):
+    """reference alignment.py:164-196: (key, sequence) of the candidate with the highest global alignment score; the first one
+    wins a tie (Python's max over results in database order)."""
+    sm = _matrix(scoring_matrix)
+    query = _upper(query)
+    keys = list(target_sequences)
+    targets = [_upper(target_sequences[k]) for k in keys]
+    pb = _PairBatch([query] + targets, sm)
+    sc = pb.scores(np.zeros(len(keys), np.int32), np.arange(1, len(keys) + 1, dtype=np.int32), gap_open, gap_extend)
+    best = int(np.argmax(sc))
+    return keys[best], targets[best]
+
+
+def align_pairwise(query, target, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80"):
+    """reference alignment.py:198-221 -> (alignment string, identity, query coverage, target coverage)."""
+    sm = _matrix(scoring_matrix)
+    pb = _PairBatch([_upper(query), _upper(target)], sm)
+    r = pb.align([0], [1], gap_open, gap_extend)
+    return bytes(r["ops"]).decode(), _identity(r["n_match"][0], r["op_len"][0]), 1.0, 1.0   # a global alignment covers both sequences
+
+
+def pairwise_against_database(query_id, query_sequence, target_sequences, gap_open: int = 10, gap_extend: int = 1,
+                              scoring_matrix="VTML80") -> AlignmentResult:
+    """reference alignment.py:223-250."""
+    sm = _matrix(scoring_matrix)
+    query_sequence = _upper(query_sequence)
+    best_idx, best_target = best_hit_database(query_sequence, target_sequences, gap_open, gap_extend, sm)
+    alignment, identity, qc, tc = align_pairwise(query_sequence, best_target, gap_open, gap_extend, sm)
+    return AlignmentResult(query_id, query_sequence, best_idx, best_target, alignment, identity, query_coverage=qc, target_coverage=tc)
+
+
+class AlignedBatch:
+    """Struct-of-arrays result of `align_queries_arrays`: no per-protein Python objects.  Protein p's gapped strings are
+    q_aln[aln_off[p]:aln_off[p+1]] / t_aln[...]; `best` is the index of the winning candidate inside that query's list."""
+
+    def __init__(self, query_ids, query_sequences, target_keys, target_sequences, best, res):
+        self.query_ids, self.query_sequences, self.target_keys, self.target_sequences = query_ids, query_sequences, target_keys, target_sequences
+        self.best = best
+        self.ops, self.q_aln, self.t_aln, self.aln_off = res["ops"], res["q_aln"], res["t_aln"], res["off"]
+        self.op_len, self.n_match, self.score = res["op_len"], res["n_match"], res["score"]
+        self.identity = (self.n_match.astype(np.float32) / np.maximum(self.op_len, 1).astype(np.float32))
+
+    def __len__(self):
+        return len(self.query_ids)
+
+    def results(self):
+        """AlignmentResult objects, as the reference's pool returns them (alignment.py:313-320)."""
+        out = []
+        for p in range(len(self)):
+            a, b = int(self.aln_off[p]), int(self.aln_off[p + 1])
+            r = AlignmentResult.__new__(AlignmentResult)
+            AlignmentResult.__init__(r, self.query_ids[p], self.query_sequences[p], self.target_keys[p], self.target_sequences[p], "",
+                                     float(self.identity[p]), query_coverage=1.0, target_coverage=1.0)
+            r.alignment = bytes(self.ops[a:b]).decode()
+            r.gapped_sequence, r.gapped_target = bytes(self.q_aln[a:b]).decode(), bytes(self.t_aln[a:b]).decode()
+            out.append(r)
+        return out
+
+
+def align_queries_arrays(query_ids, query_sequences, target_sequences, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80") -> AlignedBatch:
+    """Batched `pairwise_against_database` over many queries (reference alignment.py:266-320: one pool task per query).
+    target_sequences: one {key: sequence} dict per query (its candidate set).  One score launch over all candidates, one
+    alignment launch over the winners; queries with an empty candidate set are not allowed (the reference never builds them)."""
+    sm = _matrix(scoring_matrix)
+    query_ids = list(query_ids)
+    qs = [_upper(s) for s in query_sequences]
+    keys = [list(d) for d in target_sequences]
+    if any(len(k) == 0 for k in keys):
+        raise ValueError("every query needs at least one candidate target")
+    # unique targets are encoded once (the same database entry is a candidate of many queries)
+    index, seqs = {}, list(qs)
+    pair_q, pair_t, first = [], [], np.zeros(len(qs) + 1, dtype=np.int64)
+    for qi, (d, ks) in enumerate(zip(target_sequences, keys)):
+        for k in ks:
+            t = _upper(d[k])
+            j = index.get((k, t))
+            if j is None:
+                j = index[(k, t)] = len(seqs)
+                seqs.append(t)
+            pair_q.append(qi)
+            pair_t.append(j)
+        first[qi + 1] = len(pair_q)
+    pb = _PairBatch(seqs, sm)
+    sc = pb.scores(pair_q, pair_t, gap_open, gap_extend)
+    # per-query arg-max, first maximum wins (Python's max): reduceat the maxima, then the first position that reaches them
+    seg_max = np.maximum.reduceat(sc, first[:-1])
+    is_max = sc == np.repeat(seg_max, np.diff(first))
+    pos = np.where(is_max, np.arange(len(sc)), len(sc))
+    best_pair = np.minimum.reduceat(pos, first[:-1])
+    best = (best_pair - first[:-1]).astype(np.int64)
+    bt = np.asarray(pair_t, dtype=np.int32)[best_pair]
+    res = pb.align(np.arange(len(qs), dtype=np.int32), bt, gap_open, gap_extend)
+    if not np.array_equal(res["score"], seg_max):
+        raise RuntimeError("internal error: full-alignment score differs from the score-mode score")
+    return AlignedBatch(query_ids, qs, [keys[q][int(b)] for q, b in enumerate(best)], [seqs[int(j)] for j in bt], best, res)
+
+
+def align_queries(query_ids, query_sequences, target_sequences, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80"):
+    """List of AlignmentResult, the return value of reference align_mmseqs_results' pool (alignment.py:313-320)."""
+    return align_queries_arrays(query_ids, query_sequences, target_sequences, gap_open, gap_extend, scoring_matrix).results()

@@ -122,6 +122,40 @@ class PackedProteins:
                       [a.gapped_target for a in al], max_rows=max_rows, max_segment_groups=max_segment_groups)
         return pk, keep
 
+    @classmethod
+    def from_aligned_batch(cls, batch, coords, max_rows: int = 32768, max_segment_groups: int = 1 << 19):
+        """Pack the struct-of-arrays output of mDeepFRI.alignment.align_queries_arrays (the GPU aligner) together with the
+        targets' C-alpha coordinates -- no AlignmentResult objects, no per-protein string handling: the gapped strings are
+        taken as the flat byte arrays the aligner produced.  coords: one float32 (Lt, 3) array per query (its best target's
+        trace), None where the structure is missing; returns (packed, kept_indices) like from_alignments."""
+        keep = [i for i, c in enumerate(coords) if c is not None]
+        if not keep:
+            raise ValueError("empty batch")
+        off = np.asarray(batch.aln_off, dtype=np.int64)
+        ln = (off[1:] - off[:-1])[keep]
+        sel = np.repeat(off[:-1][keep] - np.concatenate(([0], np.cumsum(ln)[:-1])), ln) + np.arange(int(ln.sum()), dtype=np.int64)
+        q_aln, t_aln = np.ascontiguousarray(batch.q_aln[sel]), np.ascontiguousarray(batch.t_aln[sel])
+        seqs = [batch.query_sequences[i] for i in keep]
+        Lq = np.array([len(s) for s in seqs], dtype=np.int32)
+        if (Lq <= 0).any():
+            raise ValueError("empty sequence in batch")
+        starts = np.concatenate(([0], np.cumsum(ln)))
+        nongap = np.add.reduceat((q_aln != 45).astype(np.int64), starts[:-1]) if len(ln) else np.zeros(0, np.int64)
+        if not np.array_equal(nongap, Lq):
+            raise ValueError("gapped queries do not spell the query sequences")
+        pk = cls(seqs=seqs, Lq=Lq, seq_bytes=np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8).copy(), seq_off=_offsets(Lq))
+        cs = []
+        for i in keep:
+            c = np.asarray(coords[i])
+            if c.dtype != np.float32 or c.ndim != 2 or c.shape[1] != 3:
+                raise ValueError("coordinates must be float32 (Lt,3)")
+            cs.append(c)
+        pk.coords = np.ascontiguousarray(np.concatenate(cs, axis=0))
+        pk.coord_off = _offsets([c.shape[0] for c in cs])
+        pk.q_aln, pk.t_aln, pk.aln_off = q_aln, t_aln, _offsets(ln)
+        pk._plan(max_rows, max_segment_groups)
+        return pk, keep
+
     def _plan(self, max_rows: int, max_segment_groups: int = 1 << 19):
         L = _hip.lib()
         self.chunks, offs = [], []

@@ -1,0 +1,145 @@
+"""GPU parity of the batched Needleman-Wunsch aligner (csrc/nw.hip through the C ABI) against oracle/nw_oracle.c: integer
+work, so scores, operation strings, gapped strings and match counts must be IDENTICAL.  Also the reference's own known answers
+for the alignment step (mDeepFRI/tests/test_alignment.py:9-48) through the drop-in functions, and the hand-over of the
+aligner's arrays to the fused contact-map + GCN path."""
+import numpy as np
+import pytest
+
+import nw_oracle as nwo
+from mDeepFRI import synthetic
+from mDeepFRI.alignment import (AlignmentResult, ScoringMatrix, align_pairwise, align_queries, align_queries_arrays, best_hit_database,
+                                insert_gaps, pairwise_against_database)
+
+pytestmark = pytest.mark.gpu
+ALPHA = "ARNDCQEGHILKMFPSTWYVBZX*"
+
+
+def _matrix(seed=7):
+    rng = np.random.default_rng(seed)
+    A = len(ALPHA)
+    m = rng.integers(-6, 4, size=(A, A))
+    m = (m + m.T) // 2
+    np.fill_diagonal(m, rng.integers(5, 13, size=A))
+    return ScoringMatrix(ALPHA, m, "random-symmetric")
+
+
+def _seq(rng, n):
+    return "".join(rng.choice(list(ALPHA[:20]), size=n))
+
+
+def _mutate(rng, s, rate=0.15):
+    out = []
+    for c in s:
+        r = rng.random()
+        if r < rate / 3:
+            continue
+        if r < 2 * rate / 3:
+            out.append(rng.choice(list(ALPHA[:20])))
+        out.append(c if rng.random() > rate else rng.choice(list(ALPHA[:20])))
+    return "".join(out) or "A"
+
+
+def test_reference_known_answers_through_the_drop_in_functions():
+    sm = _matrix()
+    query = "MAGFLKVVQLLAKYGSKAVQWAWANKGKILDWLNAGQAIDWVVS"            # reference tests/test_alignment.py:9-36
+    targets = dict(seq1="MESILDLQELETSEEESALMAASTVSNNC", seq2="MKKAVIVENKGCATCSIGAACLVDGPIPDFEIAGATGLFGLWG",
+                   seq3="MAGFLKVVQILAKYGSKAVQWAWANKGKILDWINAGQAIDWVVE", seq4="MAGFLKVVQILAKYGSKAVQWAWANKGKILDWINAGQAIDWVVE")
+    best_hit, _ = best_hit_database(query, targets, scoring_matrix=sm)
+    assert best_hit == "seq3"
+    alignment, iden, query_coverage, target_coverage = align_pairwise(query, targets["seq3"], scoring_matrix=sm)
+    assert alignment == "MMMMMMMMMXMMMMMMMMMMMMMMMMMMMMMMXMMMMMMMMMMX"
+    assert round(iden, 2) == 0.93 and round(query_coverage, 2) == 1.0 and target_coverage == 1.0
+    r = pairwise_against_database("q", query.lower(), targets, scoring_matrix=sm)      # the reference upper-cases its inputs
+    assert isinstance(r, AlignmentResult) and r.target_name == "seq3" and r.alignment == alignment and r.query_sequence == query
+    assert (r.gapped_sequence, r.gapped_target) == insert_gaps(query, targets["seq3"], alignment)
+
+
+@pytest.mark.parametrize("go,ge", [(10, 1), (3, 2), (0, 0)])
+def test_scores_and_alignments_equal_the_oracle(go, ge):
+    """lengths around the 64-column strip and the 64-row chunk boundaries, 1-residue sequences, very unequal lengths"""
+    sm = _matrix()
+    rng = np.random.default_rng(100 + go)
+    pairs = []
+    for lq, lt in [(1, 1), (1, 70), (70, 1), (2, 3), (63, 64), (64, 63), (64, 64), (65, 65), (128, 129), (127, 200), (300, 257), (700, 650), (33, 1000)]:
+        q = _seq(rng, lq)
+        pairs.append((q, _seq(rng, lt)))
+        pairs.append((q, (_mutate(rng, q) + _seq(rng, lt))[:lt]))
+    for q, t in pairs:
+        ops, iden, qc, tc = align_pairwise(q, t, go, ge, sm)
+        e_ops, e_iden, _, _, e_score = nwo.align_pairwise(q, t, sm.matrix, sm.alphabet, go, ge)
+        assert ops == e_ops and iden == e_iden and qc == tc == 1.0, (len(q), len(t))
+        assert nwo.score_of_alignment(q, t, ops, sm.matrix, sm.alphabet, go, ge) == e_score
+
+
+def test_batched_queries_against_candidate_sets():
+    """The batched counterpart of Pool.starmap(pairwise_against_database) (alignment.py:266-320): candidate sets of different
+    sizes, shared targets, exact ties (first candidate wins), results identical to the oracle and to the per-call functions."""
+    sm = _matrix(9)
+    rng = np.random.default_rng(5)
+    db = {f"t{k}": _seq(rng, int(rng.integers(40, 420))) for k in range(60)}
+    qids, qseqs, cands = [], [], []
+    for i in range(48):
+        home = f"t{int(rng.integers(0, 60))}"
+        q = _mutate(rng, db[home], 0.2)
+        ks = list(rng.choice(list(db), size=int(rng.integers(1, 9)), replace=False))
+        if home not in ks and i % 3:
+            ks.insert(int(rng.integers(0, len(ks) + 1)), home)
+        d = {k: db[k] for k in ks}
+        if i % 7 == 0:                     # an exact duplicate under another key, listed later: the first one must win
+            d[f"dup{i}"] = d[ks[0]]
+        qids.append(f"q{i}")
+        qseqs.append(q)
+        cands.append(d)
+    batch = align_queries_arrays(qids, qseqs, cands, scoring_matrix=sm)
+    res = batch.results()
+    assert len(res) == 48 and [r.query_name for r in res] == qids
+    for i, r in enumerate(res):
+        key, seq = nwo.best_hit_database(qseqs[i], cands[i], sm.matrix, sm.alphabet)
+        ops, iden, _, _, score = nwo.align_pairwise(qseqs[i], seq, sm.matrix, sm.alphabet)
+        assert r.target_name == key and r.target_sequence == seq and r.alignment == ops and r.query_identity == iden, i
+        assert int(batch.score[i]) == score and (r.gapped_sequence, r.gapped_target) == insert_gaps(qseqs[i], seq, ops)
+        assert r.query_coverage == 1.0 and r.target_coverage == 1.0
+    one = pairwise_against_database(qids[5], qseqs[5], cands[5], scoring_matrix=sm)
+    assert (one.target_name, one.alignment, one.query_identity) == (res[5].target_name, res[5].alignment, res[5].query_identity)
+    assert [r.alignment for r in align_queries(qids[:4], qseqs[:4], cands[:4], scoring_matrix=sm)] == [r.alignment for r in res[:4]]
+
+
+def test_letters_outside_the_matrix_alphabet_are_rejected():
+    sm = _matrix()
+    with pytest.raises(ValueError, match="not in the scoring matrix alphabet"):
+        align_pairwise("ACDU", "ACD", scoring_matrix=sm)
+
+
+def test_aligner_arrays_feed_the_fused_path_without_per_protein_objects():
+    """aligner output (flat byte arrays) -> PackedProteins.from_aligned_batch -> contact map + GCN == the same proteins packed
+    from AlignmentResult objects; and bit-exact contact maps vs the oracle for the aligner's gapped strings."""
+    import cmap_oracle as orc
+    from mDeepFRI.batch import HotPathEngine, PackedProteins, build_align_contact_maps
+    from mDeepFRI.predict import Predictor
+    sm = _matrix(3)
+    rng = np.random.default_rng(8)
+    db, xyz = {}, {}
+    for k in range(12):
+        db[f"t{k}"] = _seq(rng, int(rng.integers(50, 260)))
+        xyz[f"t{k}"] = synthetic.random_walk_coords(rng, len(db[f"t{k}"]))
+    qids = [f"q{i}" for i in range(20)]
+    homes = [f"t{int(rng.integers(0, 12))}" for _ in qids]
+    qseqs = [_mutate(rng, db[h], 0.12) for h in homes]
+    cands = [{k: db[k] for k in sorted(set([h] + list(rng.choice(list(db), size=3))))} for h in homes]
+    batch = align_queries_arrays(qids, qseqs, cands, scoring_matrix=sm)
+    coords = [xyz[k] for k in batch.target_keys]
+    coords[4] = None                                         # a hit without a structure is dropped, as pipeline.py:485 does
+    pk, kept = PackedProteins.from_aligned_batch(batch, coords, max_rows=2048)
+    assert kept == [i for i in range(20) if i != 4] and len(pk.chunks) > 1
+    res = batch.results()
+    for i, r in enumerate(res):
+        r.coords = coords[i]
+    pk2, kept2 = PackedProteins.from_alignments(res, max_rows=2048)
+    assert kept2 == kept
+    for f in ("Lq", "seq_bytes", "seq_off", "coords", "coord_off", "q_aln", "t_aln", "aln_off"):
+        assert np.array_equal(getattr(pk, f), getattr(pk2, f)), f
+    w = synthetic.glorot_gcn_weights(seed=0, n_terms=32)
+    eng = HotPathEngine({"mf": Predictor("syn", weights=w)}, max_rows=2048)
+    assert np.array_equal(eng.run_alignments(pk)["mf"], eng.run_alignments(pk2)["mf"])
+    for (a, cm), i in zip(build_align_contact_maps([res[i] for i in kept]), kept):
+        assert np.array_equal(cm, orc.build_align_contact_map(coords[i], res[i].gapped_sequence, res[i].gapped_target, 6.0, 2))
