@@ -136,14 +136,16 @@ class _PairBatch:
     """Encoded sequences + pair lists in the layout of mdf_nw_* (include/mdfri.h)."""
 
     def __init__(self, sequences, sm: ScoringMatrix):
-        enc = [sm.encode(s) for s in sequences]
-        self.seq_len = np.array([len(e) for e in enc], dtype=np.int32)
-        self.seq_off = np.zeros(len(enc), dtype=np.int64)
-        if len(enc) > 1:
+        """sequences: list of str, any case (the reference upper-cases every sequence it aligns, alignment.py:152-161); encoded in
+        one pass over their concatenation."""
+        self.seq_len = np.fromiter(map(len, sequences), dtype=np.int32, count=len(sequences))
+        self.seq_off = np.zeros(len(sequences), dtype=np.int64)
+        if len(sequences) > 1:
             np.cumsum(self.seq_len[:-1], out=self.seq_off[1:])
-        self.codes = np.concatenate(enc) if enc else np.zeros(0, np.uint8)
-        if self.codes.size == 0:
-            self.codes = np.zeros(1, np.uint8)
+        raw = np.frombuffer("".join(sequences).upper().encode("ascii"), dtype=np.uint8)
+        self.codes = sm._lut[raw] if raw.size else np.zeros(1, np.uint8)
+        if raw.size and (self.codes == 255).any():
+            raise ValueError(f"character {chr(int(raw[int(np.argmax(self.codes == 255))]))!r} is not in the scoring matrix alphabet")
         self.sm = sm
 
     def scores(self, pair_q, pair_t, gap_open, gap_extend) -> np.ndarray:
@@ -265,24 +267,26 @@ def align_queries_arrays(query_ids, query_sequences, target_sequences, gap_open:
     alignment launch over the winners; queries with an empty candidate set are not allowed (the reference never builds them)."""
     sm = _matrix(scoring_matrix)
     query_ids = list(query_ids)
-    qs = [_upper(s) for s in query_sequences]
+    seqs = list(query_sequences)
+    nq = len(seqs)
     keys = [list(d) for d in target_sequences]
     if any(len(k) == 0 for k in keys):
         raise ValueError("every query needs at least one candidate target")
     # unique targets are encoded once (the same database entry is a candidate of many queries)
-    index, seqs = {}, list(qs)
-    pair_q, pair_t, first = [], [], np.zeros(len(qs) + 1, dtype=np.int64)
+    index = {}
+    pair_q, pair_t, first = [], [], np.zeros(nq + 1, dtype=np.int64)
     for qi, (d, ks) in enumerate(zip(target_sequences, keys)):
         for k in ks:
-            t = _upper(d[k])
-            j = index.get((k, t))
+            t = d[k]
+            j = index.get(t)
             if j is None:
-                j = index[(k, t)] = len(seqs)
+                j = index[t] = len(seqs)
                 seqs.append(t)
             pair_q.append(qi)
             pair_t.append(j)
         first[qi + 1] = len(pair_q)
     pb = _PairBatch(seqs, sm)
+    qs = [_upper(s) for s in seqs[:nq]]
     sc = pb.scores(pair_q, pair_t, gap_open, gap_extend)
     # per-query arg-max, first maximum wins (Python's max): reduceat the maxima, then the first position that reaches them
     seg_max = np.maximum.reduceat(sc, first[:-1])
@@ -291,10 +295,10 @@ def align_queries_arrays(query_ids, query_sequences, target_sequences, gap_open:
     best_pair = np.minimum.reduceat(pos, first[:-1])
     best = (best_pair - first[:-1]).astype(np.int64)
     bt = np.asarray(pair_t, dtype=np.int32)[best_pair]
-    res = pb.align(np.arange(len(qs), dtype=np.int32), bt, gap_open, gap_extend)
+    res = pb.align(np.arange(nq, dtype=np.int32), bt, gap_open, gap_extend)
     if not np.array_equal(res["score"], seg_max):
         raise RuntimeError("internal error: full-alignment score differs from the score-mode score")
-    return AlignedBatch(query_ids, qs, [keys[q][int(b)] for q, b in enumerate(best)], [seqs[int(j)] for j in bt], best, res)
+    return AlignedBatch(query_ids, qs, [keys[q][int(b)] for q, b in enumerate(best)], [_upper(seqs[int(j)]) for j in bt], best, res)
 
 
 def align_queries(query_ids, query_sequences, target_sequences, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80"):

@@ -77,3 +77,33 @@ def build_align_contact_map(alignment, threshold: float = 6, generated_contacts:
     _hip.check(L.mdf_build_align_contact_map(_hip.ptr(X), X.shape[0], q, t, len(q), float(threshold),
                                              int(generated_contacts), _hip.ptr(out)))
     return (alignment, out)
+
+
+# three-letter -> one-letter codes of the 20 standard amino acids plus the ambiguity / rare codes biotite's ProteinSequence knows
+_THREE_TO_ONE = {"ALA": "A", "ARG": "R", "ASN": "N", "ASP": "D", "CYS": "C", "GLN": "Q", "GLU": "E", "GLY": "G", "HIS": "H", "ILE": "I",
+                 "LEU": "L", "LYS": "K", "MET": "M", "PHE": "F", "PRO": "P", "SER": "S", "THR": "T", "TRP": "W", "TYR": "Y", "VAL": "V",
+                 "ASX": "B", "GLX": "Z", "UNK": "X", "SEC": "U", "PYL": "O"}
+
+
+def get_residues_coordinates(structure, chain: str = "A", substitutions=None):
+    """reference bio_utils.py:230-255: (one-letter residues, C-alpha coordinates) of one chain -- the C-alpha feed of the hot
+    path.  `structure` is a biotite AtomArray or anything with the same per-atom NumPy attributes (chain_id, atom_name, hetero,
+    res_name, coord); the selection is one vectorised mask (chain == `chain`, atom "CA", not hetero), no per-atom Python.
+    Non-standard residue names are mapped through `substitutions` ({three-letter: standard three-letter}, e.g. pdbfixer's
+    table the reference embeds at bio_utils.py:49-193) before the one-letter conversion; unknown names raise, as biotite's
+    ProteinSequence does.  Coordinates are returned as the structure stores them (float32 (L, 3) for biotite)."""
+    chain_id = np.asarray(structure.chain_id)
+    if chain not in set(chain_id.tolist()):
+        raise ValueError(f"Chain {chain} not found in structure.")
+    keep = (chain_id == chain) & (np.asarray(structure.atom_name) == "CA") & ~np.asarray(structure.hetero, dtype=bool)
+    names = np.asarray(structure.res_name)[keep]
+    uniq, inverse = np.unique(names, return_inverse=True)
+    table = dict(_THREE_TO_ONE)
+    letters = []
+    for n in uniq.tolist():
+        std = (substitutions or {}).get(n, n)
+        if std not in table:
+            raise ValueError(f"'{n}' is not a known amino acid residue name")
+        letters.append(table[std])
+    residues = "".join(np.asarray(letters, dtype="<U1")[inverse].tolist()) if len(names) else ""
+    return residues, np.asarray(structure.coord)[keep]

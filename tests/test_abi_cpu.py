@@ -253,3 +253,29 @@ def test_model_load_rejects_corrupt_containers(tmp_path):
     else:
         assert rc == 0
         L.mdf_model_free(h)
+
+
+def test_get_residues_coordinates_selects_calpha_of_one_chain():
+    """reference bio_utils.py:230-255 on an AtomArray-like object (biotite is not installed: the function only needs the
+    per-atom arrays).  Mirrors the reference's tests/test_bio_utils.py:24-31 in kind: default chain, invalid chain."""
+    from types import SimpleNamespace
+    from mDeepFRI.bio_utils import get_residues_coordinates
+    rng = np.random.default_rng(0)
+    res = ["MET", "LEU", "LEU", "SER", "ALA", "MSE", "GLY"]
+    atoms = []
+    for ch in ("A", "B"):
+        for k, r in enumerate(res):
+            for a in ("N", "CA", "C", "O"):
+                atoms.append((ch, a, False, r))
+    atoms.append(("A", "CA", True, "CA"))         # a calcium ion: hetero, atom name CA -- must not be taken for a C-alpha
+    s = SimpleNamespace(chain_id=np.array([a[0] for a in atoms]), atom_name=np.array([a[1] for a in atoms]),
+                        hetero=np.array([a[2] for a in atoms]), res_name=np.array([a[3] for a in atoms]),
+                        coord=rng.random((len(atoms), 3)).astype(np.float32))
+    with pytest.raises(ValueError, match="is not a known amino acid"):
+        get_residues_coordinates(s)
+    seq, xyz = get_residues_coordinates(s, substitutions={"MSE": "MET"})
+    assert seq == "MLLSAMG" and xyz.shape == (7, 3) and xyz.dtype == np.float32
+    assert np.array_equal(xyz, s.coord[[1 + 4 * k for k in range(7)]])
+    assert get_residues_coordinates(s, "B", {"MSE": "MET"})[0] == "MLLSAMG"
+    with pytest.raises(ValueError, match="Chain C not found in structure."):
+        get_residues_coordinates(s, "C")
