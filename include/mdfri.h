@@ -232,14 +232,20 @@ int mdf_seq_encode_dev(const char *seqs, const int32_t *seq_off, const int32_t *
  *     A' = A - diag(A) + I,  d = 1/(1e-6 + sqrt(rowsum A')),  val[i][j] = (d[i]*A'[i][j])*d[j]
  * coords: packed (sum Lt,3) f32, protein p at residues [coord_off[p], coord_off[p+1]);
  * q_aln/t_aln: packed alignment bytes, protein p at [aln_off[p], aln_off[p+1]).
+ * max_len: the longest query (max Lq) of the batch -- sizes the per-row contact-bit words of the workspace.
  * Outputs: rowptr (R+1) int32, colidx/val (nnz_cap) with colidx as GLOBAL row numbers.
  * status: device int32[4], zero-initialised by the caller: [0] != 0 -> CSR overflow (needed nnz in [1]).
- * workspace: mdf_cmap_workspace_bytes(B, R) bytes of device scratch. */
-size_t mdf_cmap_workspace_bytes(int32_t B, int64_t R);
+ * seq_idx / letter_sums (both or neither): with the residue indices of mdf_seq_encode_dev given, the layer-1 operand of
+ * mdf_gcn_embed_dev (see mdf_letter_sums_dev) is written in the same pass as the CSR -- (R, 32) f32.
+ * The coordinates are read ONCE: a first kernel counts every row's contacts and stores the contact bits, the CSR is filled
+ * from the bits.  workspace: mdf_cmap_workspace_bytes(B, R, max_len) bytes of device scratch (max_len = 0: the size the
+ * dense-format and dense-to-CSR entry points below need). */
+size_t mdf_cmap_workspace_bytes(int32_t B, int64_t R, int32_t max_len);
 int mdf_cmap_csr_dev(const float *coords, const int32_t *coord_off, const char *q_aln, const char *t_aln,
-                     const int32_t *aln_off, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                     const int32_t *aln_off, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R, int32_t max_len,
                      double threshold, int generated_contacts, int32_t *rowptr, int32_t *colidx, float *val,
-                     int64_t nnz_cap, int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+                     int64_t nnz_cap, int32_t *status, const uint8_t *seq_idx, float *letter_sums, void *workspace,
+                     size_t workspace_bytes, void *stream);
 
 /* Same stage, reference output format: out[p] = (Lq[p],Lq[p]) int32 at element offset out_off[p] (int64, device).
  * The batched build_align_contact_map; bit-exact with the reference per protein. */

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_a
 // The contact term is symmetric for coords-derived pairs (argwhere yields (i,j) and (j,i)), so the one-directional
 // write of pyx:115 reproduces exactly this.
 // ------------------------------------------------------------------------------------------------------------------
-enum CmapMode { CM_COUNT = 0, CM_FILL_CSR = 1, CM_DENSE = 2 };
+enum CmapMode { CM_COUNT = 0, CM_DENSE = 2 };   // COUNT also stores every row's contact bits (64 columns per word) for k_cmap_fill
 
 __device__ __forceinline__ int find_protein(const int32_t *__restrict__ row_off, int B, int row)
 {
@@ -239,11 +239,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coords, const int32_t *__restrict__ coord_off,
                                                    const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off,
                                                    int B, const int32_t *__restrict__ q2t, float thr2, int gen,
-                                                   int32_t *__restrict__ counts,        // COUNT: out (R); FILL: in
+                                                   int32_t *__restrict__ counts,        // COUNT: out (R)
                                                    int32_t *__restrict__ group_sum,     // COUNT: out (R/32)
-                                                   const int32_t *__restrict__ group_base,  // FILL: in (R/32)
-                                                   int32_t *__restrict__ rowptr, int32_t *__restrict__ colidx,
-                                                   float *__restrict__ val, int64_t nnz_cap,
+                                                   unsigned long long *__restrict__ masks, int W,   // COUNT: out (R, W) contact bits
                                                    int32_t *__restrict__ dense_out, const int64_t *__restrict__ dense_off)
 {
     const int g = blockIdx.x;
@@ -270,8 +268,6 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
     int ti[8];
     float xi[8], yi[8], zi[8];
     int cnt[8];
-    int pos[8];
-    float di[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         const int i = i_first + r;
@@ -288,21 +284,6 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
         }
         ti[r] = t; xi[r] = x; yi[r] = y; zi[r] = z;
         cnt[r] = 0;
-        pos[r] = 0;
-        di[r] = 0.f;
-    }
-    if (MODE == CM_FILL_CSR) {
-        // row starts inside the group: exclusive prefix of the group's row counts (wave-uniform scalars)
-        int run = group_base[g];
-        for (int r = 0; r < wid * 8; ++r) run += counts[row0 + r];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int c = counts[row0 + wid * 8 + k];
-            pos[k] = run;
-            di[k] = 1.0f / (1e-6f + sqrtf((float)c));
-            if (lane == 0) rowptr[row0 + wid * 8 + k] = (int)min((int64_t)run, nnz_cap);  // clamped: an overflowing batch stays in bounds (and is flagged)
-            run += c;
-        }
     }
     int32_t *dense_p = nullptr;
     if (MODE == CM_DENSE) dense_p = dense_out + dense_off[p];
@@ -311,7 +292,8 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
         for (int j0 = 0; j0 < Lq; j0 += 64) {
             const int j = j0 + lane;
             int tj = -2;
-            float xj = 0.f, yj = 0.f, zj = 0.f, dj = 0.f;
+            float xj = 0.f, yj = 0.f, zj = 0.f;
+            unsigned long long my_mask = 0;   // COUNT: lane r keeps row r's word of this 64-column chunk
             if (j < Lq) {
                 tj = q2t_p[j];
                 if (tj >= Lt) tj = -3;
@@ -320,7 +302,6 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
                     yj = xyz[tj * 3 + 1];
                     zj = xyz[tj * 3 + 2];
                 }
-                if (MODE == CM_FILL_CSR) dj = 1.0f / (1e-6f + sqrtf((float)counts[r0 + j]));
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -343,20 +324,11 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
                     if (j < Lq) dense_p[(int64_t)i * Lq + j] = bit ? 1 : 0;
                 } else {
                     const unsigned long long mask = __ballot(bit);
-                    if (MODE == CM_COUNT) {
-                        cnt[r] += __popcll(mask);
-                    } else {
-                        if (bit) {
-                            const int64_t w = (int64_t)pos[r] + __popcll(mask & ((1ull << lane) - 1ull));
-                            if (w < nnz_cap) {
-                                colidx[w] = r0 + j;
-                                val[w] = (di[r] * 1.0f) * dj;
-                            }
-                        }
-                        pos[r] += __popcll(mask);
-                    }
+                    cnt[r] += __popcll(mask);
+                    if (lane == r) my_mask = mask;
                 }
             }
+            if (MODE == CM_COUNT && lane < 8 && i_first + lane < Lq) masks[(int64_t)(row0 + wid * 8 + lane) * W + (j0 >> 6)] = my_mask;
         }
         if (MODE == CM_COUNT && lane == 0) {
 #pragma unroll
@@ -413,6 +385,82 @@ __global__ __launch_bounds__(1024) void k_scan_groups(const int32_t *__restrict_
         if (total > nnz_cap || total >= 0x7fffffffLL) {
             status[0] = 1;
             status[1] = (int32_t)(total < 0x7fffffffLL ? total : 0x7fffffffLL);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// CSR fill from the stored contact bits (no second pass over the coordinates): block = 32-row group, wave = 8 rows, lane =
+// column of the current 64-bit word.  val = (d_i * 1) * d_j with d = 1 / (1e-6 + sqrt(row count)).  When `seq_idx` is given the
+// layer-1 operand of the GraphConv stack is produced in the same pass: letter_sums[row][a] = sum of val over the row's entries
+// whose column residue is letter a, accumulated in CSR (ascending column) order -- the arithmetic of k_letter_sums (gcn.hip),
+// without re-reading the CSR or a separate launch.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off, int B,
+                                                   const int32_t *__restrict__ counts, const int32_t *__restrict__ group_base,
+                                                   const unsigned long long *__restrict__ masks, int W, int32_t *__restrict__ rowptr,
+                                                   int32_t *__restrict__ colidx, float *__restrict__ val, int64_t nnz_cap,
+                                                   const uint8_t *__restrict__ seq_idx, float *__restrict__ letter_sums)
+{
+    // Work item = one 64-bit contact word (row, word index): a wave's 8 rows x Wp words are spread over its lanes, so the
+    // serial part of a lane is only the handful of set bits of ITS word.  Letter sums go through per-row LDS bins, visited in
+    // (word, bit) = ascending-column order: the summation order of the CSR, hence of k_letter_sums.
+    __shared__ float s_bins[32][32];
+    __shared__ int s_start[32];
+    const int g = blockIdx.x, row0 = g * 32;
+    const int p = find_protein(row_off, B, row0);
+    const int r0 = row_off[p], Lq = Lq_arr[p];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Wp = (Lq + 63) >> 6;
+    const int wrow0 = row0 + wid * 8;
+    int run = group_base[g];
+    for (int r = 0; r < wid * 8; ++r) run += counts[row0 + r];
+    for (int k = 0; k < 8; ++k) {
+        if (lane == 0) {
+            rowptr[wrow0 + k] = (int)min((int64_t)run, nnz_cap);  // clamped: an overflowing batch stays in bounds (and is flagged)
+            s_start[wid * 8 + k] = run;
+        }
+        run += counts[wrow0 + k];
+    }
+    for (int e = lane; e < 8 * 32; e += 64) s_bins[wid * 8 + (e >> 5)][e & 31] = 0.0f;
+    // (s_start / s_bins are private to this wave's 8 rows: program order within the wave is all the synchronisation needed)
+    const int n_items = 8 * Wp;
+    for (int t0 = 0; t0 < n_items; t0 += 64) {
+        const int t = t0 + lane;
+        const int r = t / Wp, w = t - r * Wp;
+        const int row = wrow0 + r;
+        const bool valid = t < n_items && (row - r0) < Lq;
+        unsigned long long word = 0;
+        int pos = 0;
+        float di = 0.0f;
+        if (valid) {
+            const unsigned long long *mrow = masks + (int64_t)row * W;
+            word = mrow[w];
+            pos = s_start[wid * 8 + r];
+            for (int w2 = 0; w2 < w; ++w2) pos += __popcll(mrow[w2]);
+            di = 1.0f / (1e-6f + sqrtf((float)counts[row]));
+        }
+        for (int ww = 0; ww < Wp; ++ww) {          // ascending word order keeps every (row, letter) sum in column order
+            if (w != ww) continue;
+            unsigned long long m = word;
+            while (m) {
+                const int j = (w << 6) + __builtin_ctzll(m);
+                m &= m - 1;
+                const float dj = 1.0f / (1e-6f + sqrtf((float)counts[r0 + j]));
+                const float v = (di * 1.0f) * dj;
+                if (pos < nnz_cap) {
+                    colidx[pos] = r0 + j;
+                    val[pos] = v;
+                }
+                ++pos;
+                if (seq_idx) s_bins[wid * 8 + r][min((int)seq_idx[r0 + j], 31)] += v;
+            }
+        }
+    }
+    if (letter_sums) {
+        for (int e = lane; e < 8 * 32; e += 64) {
+            const int k = e >> 5, a = e & 31;
+            letter_sums[(size_t)(wrow0 + k) * 32 + a] = (a < 26) ? s_bins[wid * 8 + k][a] : 0.0f;
         }
     }
 }
@@ -599,14 +647,16 @@ static inline float thr2_f32(double threshold) { return (float)(threshold * thre
 struct CmapWs {
     int32_t *q2t, *counts, *group_sum, *group_base;
     float *rowsum;
+    unsigned long long *masks;   // (R, W) contact bits, W = ceil(max_len / 64); only the CSR-from-coordinates path uses them
 };
-static size_t cmap_ws_bytes(int32_t B, int64_t R)
+static inline int mask_words(int32_t max_len) { return (std::max(max_len, 1) + 63) / 64; }
+static size_t cmap_ws_bytes(int32_t B, int64_t R, int32_t max_len)
 {
     (void)B;
     const size_t G = (size_t)(R / 32 + 1);
-    return 256 * 6 + (size_t)R * 4 * 3 + G * 4 * 2 + 4096;
+    return 256 * 7 + (size_t)R * 4 * 3 + G * 4 * 2 + (max_len > 0 ? (size_t)R * mask_words(max_len) * 8 : 0) + 4096;
 }
-static bool carve_cmap_ws(void *ws, size_t bytes, int64_t R, CmapWs &o)
+static bool carve_cmap_ws(void *ws, size_t bytes, int64_t R, int32_t max_len, CmapWs &o)
 {
     Carver c(ws, bytes);
     const size_t G = (size_t)(R / 32 + 1);
@@ -615,6 +665,7 @@ static bool carve_cmap_ws(void *ws, size_t bytes, int64_t R, CmapWs &o)
     o.rowsum = c.take<float>(R);
     o.group_sum = c.take<int32_t>(G);
     o.group_base = c.take<int32_t>(G);
+    o.masks = max_len > 0 ? c.take<unsigned long long>((size_t)R * mask_words(max_len)) : nullptr;
     return c.ok();
 }
 
@@ -817,33 +868,36 @@ int mdf_align_contact_map(const char *q_aln, const char *t_aln, int64_t La, cons
     return MDF_OK;
 }
 
-size_t mdf_cmap_workspace_bytes(int32_t B, int64_t R) { return cmap_ws_bytes(B, R); }
+size_t mdf_cmap_workspace_bytes(int32_t B, int64_t R, int32_t max_len) { return cmap_ws_bytes(B, R, max_len); }
 
 int mdf_cmap_csr_dev(const float *coords, const int32_t *coord_off, const char *q_aln, const char *t_aln,
-                     const int32_t *aln_off, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R,
+                     const int32_t *aln_off, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R, int32_t max_len,
                      double threshold, int generated_contacts, int32_t *rowptr, int32_t *colidx, float *val,
-                     int64_t nnz_cap, int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+                     int64_t nnz_cap, int32_t *status, const uint8_t *seq_idx, float *letter_sums, void *workspace,
+                     size_t workspace_bytes, void *stream)
 {
     if (int rc = check_layout(B, R)) return rc;
     MDF_REQUIRE(coords && coord_off && q_aln && t_aln && aln_off && Lq && row_off && rowptr && colidx && val && status && workspace,
                 "cmap_csr_dev: NULL argument");
     MDF_REQUIRE(nnz_cap > 0 && nnz_cap < 0x7fffffff, "cmap_csr_dev: nnz_cap out of range");
+    MDF_REQUIRE(max_len > 0, "cmap_csr_dev: max_len=%d must be the longest query of the batch", max_len);
+    MDF_REQUIRE((seq_idx != nullptr) == (letter_sums != nullptr), "cmap_csr_dev: seq_idx and letter_sums go together");
     CmapWs w;
-    if (!carve_cmap_ws(workspace, workspace_bytes, R, w))
-        return fail(MDF_ECAPACITY, "cmap_csr_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, cmap_ws_bytes(B, R));
+    if (!carve_cmap_ws(workspace, workspace_bytes, R, max_len, w))
+        return fail(MDF_ECAPACITY, "cmap_csr_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, cmap_ws_bytes(B, R, max_len));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int G = (int)(R / 32);
+    const int G = (int)(R / 32), W = mask_words(max_len);
     const float t2 = thr2_f32(threshold);
     ScopedTiming tm(TK_CMAP, st);
     hipLaunchKernelGGL(k_align_scan, dim3(B), dim3(256), 0, st, q_aln, t_aln, aln_off, row_off, w.q2t, (int32_t *)nullptr,
                        (int32_t *)nullptr, (int32_t *)nullptr);
+    // ONE pass over the coordinates: row counts + the contact bits themselves ...
     hipLaunchKernelGGL(k_cmap_rows<CM_COUNT>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t, t2,
-                       generated_contacts, w.counts, w.group_sum, (const int32_t *)nullptr, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (float *)nullptr, (int64_t)0, (int32_t *)nullptr, (const int64_t *)nullptr);
+                       generated_contacts, w.counts, w.group_sum, w.masks, W, (int32_t *)nullptr, (const int64_t *)nullptr);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
-    hipLaunchKernelGGL(k_cmap_rows<CM_FILL_CSR>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t, t2,
-                       generated_contacts, w.counts, (int32_t *)nullptr, (const int32_t *)w.group_base, rowptr, colidx, val,
-                       nnz_cap, (int32_t *)nullptr, (const int64_t *)nullptr);
+    // ... then the CSR (and the layer-1 letter sums) from the bits
+    hipLaunchKernelGGL(k_cmap_fill, dim3(G), dim3(256), 0, st, Lq, row_off, B, (const int32_t *)w.counts, (const int32_t *)w.group_base,
+                       (const unsigned long long *)w.masks, W, rowptr, colidx, val, nnz_cap, seq_idx, letter_sums);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -857,16 +911,16 @@ int mdf_cmap_dense_dev(const float *coords, const int32_t *coord_off, const char
     MDF_REQUIRE(coords && coord_off && q_aln && t_aln && aln_off && Lq && row_off && out && out_off && workspace,
                 "cmap_dense_dev: NULL argument");
     CmapWs w;
-    if (!carve_cmap_ws(workspace, workspace_bytes, R, w))
-        return fail(MDF_ECAPACITY, "cmap_dense_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, cmap_ws_bytes(B, R));
+    if (!carve_cmap_ws(workspace, workspace_bytes, R, 0, w))
+        return fail(MDF_ECAPACITY, "cmap_dense_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, cmap_ws_bytes(B, R, 0));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int G = (int)(R / 32);
     ScopedTiming tm(TK_CMAP, st);
     hipLaunchKernelGGL(k_align_scan, dim3(B), dim3(256), 0, st, q_aln, t_aln, aln_off, row_off, w.q2t, (int32_t *)nullptr,
                        (int32_t *)nullptr, (int32_t *)nullptr);
     hipLaunchKernelGGL(k_cmap_rows<CM_DENSE>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t,
-                       thr2_f32(threshold), generated_contacts, (int32_t *)nullptr, (int32_t *)nullptr, (const int32_t *)nullptr,
-                       (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr, (int64_t)0, out, out_off);
+                       thr2_f32(threshold), generated_contacts, (int32_t *)nullptr, (int32_t *)nullptr, (unsigned long long *)nullptr, 0, out,
+                       out_off);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -887,7 +941,7 @@ int mdf_build_align_contact_map(const float *coords, int64_t Lt, const char *q_a
     d.Lq[0] = (int32_t)Lq;
     const int64_t R = mdf_layout_rows(d.Lq, 1, d.row_off);
     d.dense_off[0] = 0;
-    const size_t wsb = cmap_ws_bytes(1, R);
+    const size_t wsb = cmap_ws_bytes(1, R, 0);
     const size_t o_desc = 0, o_xyz = 256, o_q = o_xyz + align_up((size_t)Lt * 12 + 4, 256), o_t = o_q + align_up((size_t)La, 256),
                  o_ws = o_t + align_up((size_t)La, 256), o_out = o_ws + align_up(wsb, 256), total = o_out + (size_t)Lq * Lq * 4;
     Scratch &s = scratch(0);
@@ -915,8 +969,8 @@ int mdf_dense_to_csr_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_
     MDF_REQUIRE(cmap_dtype >= MDF_DT_I32 && cmap_dtype <= MDF_DT_U8, "dense_to_csr_dev: unknown dtype %d", cmap_dtype);
     MDF_REQUIRE(nnz_cap > 0 && nnz_cap < 0x7fffffff, "dense_to_csr_dev: nnz_cap out of range");
     CmapWs w;
-    if (!carve_cmap_ws(workspace, workspace_bytes, R, w))
-        return fail(MDF_ECAPACITY, "dense_to_csr_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, cmap_ws_bytes(B, R));
+    if (!carve_cmap_ws(workspace, workspace_bytes, R, 0, w))
+        return fail(MDF_ECAPACITY, "dense_to_csr_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, cmap_ws_bytes(B, R, 0));
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int G = (int)(R / 32);
     hipLaunchKernelGGL(k_dense_rows<false>, dim3(G), dim3(256), 0, st, cmaps, cmap_dtype, cmap_off, Lq, row_off, B, w.counts,

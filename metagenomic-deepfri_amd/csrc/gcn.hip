@@ -1528,7 +1528,7 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     const int64_t R = mdf_layout_rows(Lq, 1, row_off);
     const int64_t nnz_cap = std::min<int64_t>(L * L, 0x7ffffff0);
     MDF_REQUIRE(m->lm_dim == 0 || m->lm, "gcn_forward_host: the model has a language-model branch but no mdf_lm is attached (mdf_model_attach_lm)");
-    const size_t cws = mdf_cmap_workspace_bytes(1, R), gws = gcn_ws_bytes(m, R), hws = mdf_head_workspace_bytes(m, 1);
+    const size_t cws = mdf_cmap_workspace_bytes(1, R, 0), gws = gcn_ws_bytes(m, R), hws = mdf_head_workspace_bytes(m, 1);
     const size_t lws = m->lm_dim ? lm_ws_bytes(m->lm, 1, L) : 0;
     // layout of the session scratch
     size_t o = 0;

@@ -263,7 +263,7 @@ class HotPathEngine:
         self.nnz_per_row = int(nnz_per_row)
         self.threshold = float(threshold)
         self.generated_contacts = int(generated_contacts)
-        self._rows_alloc = 0
+        self._rows_alloc = self._len_alloc = 0
         self._bufs = {}
         # heads with a language-model branch, grouped by the (shared) LanguageModel they are attached to; the LSTM runs
         # once per group over `lm_batch` proteins at a time (every time step is one GEMM over all of them)
@@ -276,9 +276,11 @@ class HotPathEngine:
         self.lm_workspace_bytes = int(lm_workspace_gib * 2**30)
 
     # -- memory ------------------------------------------------------------------------------------------------------
-    def _ensure(self, rows: int, n_proteins: int):
+    def _ensure(self, rows: int, n_proteins: int, max_len: int = 0):
         torch = _torch()
-        if rows > self._rows_alloc:
+        max_len = (int(max_len) + 63) // 64 * 64
+        if rows > self._rows_alloc or max_len > self._len_alloc:
+            rows, max_len = max(rows, self._rows_alloc), max(max_len, self._len_alloc)
             dev = self.device
             cap = rows * self.nnz_per_row
             gws = max(self.L.mdf_gcn_workspace_bytes(p.session.handle, rows) for p in self.predictors.values())
@@ -288,10 +290,10 @@ class HotPathEngine:
                 "val": torch.empty(cap, dtype=torch.float32, device=dev),
                 "seq_idx": torch.empty(rows, dtype=torch.uint8, device=dev),
                 "lsum": torch.empty(rows * 32, dtype=torch.float32, device=dev),
-                "cws": torch.empty(self.L.mdf_cmap_workspace_bytes(1 << 20, rows), dtype=torch.uint8, device=dev),
+                "cws": torch.empty(self.L.mdf_cmap_workspace_bytes(1 << 20, rows, max_len), dtype=torch.uint8, device=dev),
                 "gws": torch.empty(gws, dtype=torch.uint8, device=dev),
             }
-            self._rows_alloc, self._nnz_cap = rows, cap
+            self._rows_alloc, self._nnz_cap, self._len_alloc = rows, cap, max_len
         hws = max(self.L.mdf_head_workspace_bytes(p.session.handle, n_proteins) for p in self.predictors.values())
         if self._bufs.get("hws") is None or self._bufs["hws"].numel() < hws:
             self._bufs["hws"] = torch.empty(hws, dtype=torch.uint8, device=self.device)
@@ -303,12 +305,12 @@ class HotPathEngine:
         return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
     # -- stages ------------------------------------------------------------------------------------------------------
-    def _gcn_chunk(self, db: DeviceBatch, ch: Chunk, partial: dict, st, seq_ptr, lm_h=None):
+    def _gcn_chunk(self, db: DeviceBatch, ch: Chunk, partial: dict, st, seq_ptr, lm_h=None, have_lsum: bool = False):
         """letter sums once per chunk (shared by every head without a language model), then the GraphConv stack of each
         head; the per-group partial sums land in the head's segment array.  `lm_h`: {LanguageModel: pointer to this
         chunk's (rows, H) language-model features}."""
         b = self._bufs
-        if any(getattr(p.session, "lm", None) is None for p in self.predictors.values()):
+        if not have_lsum and any(getattr(p.session, "lm", None) is None for p in self.predictors.values()):
             _hip.check(self.L.mdf_letter_sums_dev(seq_ptr, _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]), ch.rows, _p(b["lsum"]), st))
         for mode, pred in self.predictors.items():
             feat = pred.session.topology["feature_dim"]
@@ -425,8 +427,8 @@ class HotPathEngine:
         return res
 
     def _run_chunks(self, db: DeviceBatch, encode, build_csr, st):
-        """Common driver: per chunk `encode(ci, ch, seq_ptr)` writes the residue indices and `build_csr(ci, ch)` the
-        adjacency, then the GCN stack runs; segments are pooled as soon as their last chunk has been issued.  With a
+        """Common driver: per chunk `encode(ci, ch, seq_ptr)` writes the residue indices and `build_csr(ci, ch, seq_ptr)` the
+        adjacency (returning True when it also produced the layer-1 letter sums), then the GCN stack runs; segments are pooled as soon as their last chunk has been issued.  With a
         language model the chunks are taken `lm_batch` proteins at a time: all of them are encoded first, the LSTM runs
         over the whole group, then the per-chunk stages follow."""
         torch = _torch()
@@ -435,8 +437,8 @@ class HotPathEngine:
         b = self._bufs
 
         def tail(ci, ch, seq_ptr, lm_h):
-            build_csr(ci, ch)
-            self._gcn_chunk(db, ch, partial, st, seq_ptr, lm_h)
+            have_lsum = bool(build_csr(ci, ch, seq_ptr))
+            self._gcn_chunk(db, ch, partial, st, seq_ptr, lm_h, have_lsum)
             if ci + 1 == len(chunks) or chunks[ci + 1].segment != ch.segment:
                 self._pool_segment(db, segs[ch.segment], partial, pooled, st)
 
@@ -486,21 +488,26 @@ class HotPathEngine:
             raise ValueError("batch was packed without coordinates/alignments")
         torch = _torch()
         with torch.cuda.device(self.device):
-            self._ensure(db.packed.max_chunk_rows, db.B)
+            max_len = int(db.packed.Lq.max())
+            self._ensure(db.packed.max_chunk_rows, db.B, max_len)
             b, st = self._bufs, self._stream()
+            want_lsum = any(getattr(p.session, "lm", None) is None for p in self.predictors.values())
 
             def encode(ci, ch, seq_ptr):
                 _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0),
                                                      _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows, seq_ptr,
                                                      _p(db.bad, ci), st))
 
-            def build_csr(ci, ch):
+            def build_csr(ci, ch, seq_ptr):
+                # contact stage: coordinates read once; the CSR fill also writes the layer-1 letter sums of the chunk
                 Bc = ch.p1 - ch.p0
                 ro = _p(db.chunk_row_off, ch.row_off_pos)
                 _hip.check(self.L.mdf_cmap_csr_dev(
                     _p(db.coords), _p(db.coord_off, ch.p0), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off, ch.p0), _p(db.Lq, ch.p0), ro,
-                    Bc, ch.rows, self.threshold, self.generated_contacts, _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]),
-                    self._nnz_cap, _p(db.status, ci * 4), _p(b["cws"]), b["cws"].numel(), st))
+                    Bc, ch.rows, max_len, self.threshold, self.generated_contacts, _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]),
+                    self._nnz_cap, _p(db.status, ci * 4), seq_ptr if want_lsum else None, _p(b["lsum"]) if want_lsum else None,
+                    _p(b["cws"]), b["cws"].numel(), st))
+                return want_lsum
 
             pooled = self._run_chunks(db, encode, build_csr, st)
             return self._heads(db, pooled, want_logits, st)
@@ -521,7 +528,7 @@ class HotPathEngine:
                                                      _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows, seq_ptr,
                                                      _p(db.bad, ci), st))
 
-            def build_csr(ci, ch):
+            def build_csr(ci, ch, seq_ptr):
                 Bc = ch.p1 - ch.p0
                 ro = _p(db.chunk_row_off, ch.row_off_pos)
                 flat, offs = [], [0]
@@ -684,7 +691,7 @@ def build_align_contact_maps(alignments, threshold: float = 6, generated_contact
     with torch.cuda.device(dev):
         db = DeviceBatch(pk, dev)
         st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        cws = torch.empty(L.mdf_cmap_workspace_bytes(pk.B, pk.max_chunk_rows), dtype=torch.uint8, device=dev)
+        cws = torch.empty(L.mdf_cmap_workspace_bytes(pk.B, pk.max_chunk_rows, 0), dtype=torch.uint8, device=dev)
         for ch in pk.chunks:
             sizes = pk.Lq[ch.p0:ch.p1].astype(np.int64)**2
             offs = np.zeros(len(sizes), dtype=np.int64)
