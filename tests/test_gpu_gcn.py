@@ -383,3 +383,34 @@ def test_alignment_stream_recovers_from_csr_overflow(mf):
     got = AlignmentStream(eng, batch_size=5, max_rows=1024).run_all(items)["mf"]
     ref = _engine({"mf": pred}, max_rows=1024).run_alignments(PackedProteins.pack(*zip(*items), max_rows=1024))["mf"]
     assert np.array_equal(got, ref)
+
+
+def test_forward_pass_from_several_threads(mf, cc):
+    """The reference's session.run is thread-safe and ctypes releases the GIL during the call: concurrent forward_pass calls on
+    ONE predictor (shared device scratch, NULL stream) and on two predictors must return exactly the single-threaded results."""
+    import threading
+    (wm, pm), (wc, pc) = mf, cc
+    rng = np.random.default_rng(17)
+    cases = []
+    for L in (40, 300, 97, 512, 33, 200, 150, 64):
+        cases.append((synthetic.random_sequence(rng, L), orc.calculate_contact_map(synthetic.random_walk_coords(rng, L), 6.0)))
+    expect = [(pm.forward_pass(s, c), pc.forward_pass(s, c)) for s, c in cases]
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(6):
+                for k in range(len(cases)):
+                    i = (k + tid * 3 + rep) % len(cases)
+                    pred, ref = (pm, expect[i][0]) if (tid + k) % 3 else (pc, expect[i][1])
+                    if not np.array_equal(pred.forward_pass(*cases[i]), ref):
+                        errors.append((tid, rep, i))
+        except Exception as e:      # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]

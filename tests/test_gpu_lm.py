@@ -157,3 +157,33 @@ def test_lstm_forms_agree(monkeypatch):
         np.testing.assert_allclose(gemm[k], pers[k], atol=2e-5, rtol=0)
     for k in (0, 7, 19):   # the persistent form is batch-invariant bit for bit
         np.testing.assert_array_equal(pers[k], HotPathEngine({"mf": pred}).lm_features(PackedProteins.pack([seqs[k]]))[0])
+
+
+def test_heads_sharing_one_language_model_from_two_threads():
+    """Every GO head whose file carries the same LM weights shares ONE device-side mdf_lm (sync words, second stream, event ring):
+    calls from two threads are serialised inside the library and return the single-threaded results."""
+    import threading
+    import lm_oracle
+    from mDeepFRI.predict import Predictor
+    w1, w2 = _weights(3, 64, 256, (256,), 256, 20), _weights(4, 64, 256, (256,), 256, 12)
+    p1, p2 = Predictor("lm-a", weights=w1), Predictor("lm-b", weights=w2)
+    assert p1.session.lm is p2.session.lm
+    seqs, coords = _proteins(5, [60, 35, 90])
+    cms = [_cmap(c) for c in coords]
+    expect = [[p.forward_pass(s, c) for s, c in zip(seqs, cms)] for p in (p1, p2)]
+    assert np.max(np.abs(expect[0][0] - lm_oracle.gcn_lm_forward(w1, seqs[0], cms[0]))) < 1e-4
+    bad = []
+
+    def worker(which):
+        p = (p1, p2)[which]
+        for rep in range(8):
+            for i, (s, c) in enumerate(zip(seqs, cms)):
+                if not np.array_equal(p.forward_pass(s, c), expect[which][i]):
+                    bad.append((which, rep, i))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not bad, bad[:5]
