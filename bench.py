@@ -485,7 +485,9 @@ def main():
                         f"5% indels, dealt to {ctx.world} rank(s) by cost, GCN_MF+BP+CC (T={T_total}), fused cmap align+GCN, GPU filter + one gather per head",
         }[args.workload]
         line = {
-            "metric": "proteins/sec (GCN+cmap) at L=512" + (" [with LSTM language model]" if args.lm else ""),
+            "metric": ("proteins/sec (GCN+cmap) at L=512" if args.workload == "configs2" and args.length == 512 else
+                       f"proteins/sec (GCN+cmap), {args.workload}" + (f" L={args.length}" if args.workload == "configs2" else "")) +
+                      (" [with LSTM language model]" if args.lm else ""),
             "value": round(n_job * args.steps / elapsed, 1),
             "unit": "proteins/s",
             "n_gpus": ctx.world,
