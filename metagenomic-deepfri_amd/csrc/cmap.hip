@@ -32,14 +32,22 @@ __global__ __launch_bounds__(256) void k_pairwise_sqeuclidean(const float *__res
 {
     const int64_t j = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const int64_t i0 = (int64_t)blockIdx.y * 64;
+    __shared__ float s_rows[64 * 3];
+    if (M3) {
+        const int t = threadIdx.y * 64 + threadIdx.x;
+        if (t < 192 && i0 * 3 + t < n * 3) s_rows[t] = X[i0 * 3 + t];
+        __syncthreads();
+    }
     if (j >= n) return;
     if (M3) {
+        // the tile's 64 row points go through LDS once (192 floats, one coalesced load) instead of three global loads per
+        // (row, column) pair; every thread of the block reaches the barrier (the early return above is per column)
         const float xj = X[j * 3 + 0], yj = X[j * 3 + 1], zj = X[j * 3 + 2];
         for (int r = threadIdx.y; r < 64; r += 4) {
             const int64_t i = i0 + r;
             if (i >= n) break;
             // reference order: d = 0; d = d + dx*dx; d = d + dy*dy; d = d + dz*dz  (0 + x == x exactly)
-            const float dx = X[i * 3 + 0] - xj, dy = X[i * 3 + 1] - yj, dz = X[i * 3 + 2] - zj;
+            const float dx = s_rows[r * 3 + 0] - xj, dy = s_rows[r * 3 + 1] - yj, dz = s_rows[r * 3 + 2] - zj;
             float d = dx * dx;
             d = d + dy * dy;
             d = d + dz * dz;
@@ -839,19 +847,21 @@ int mdf_align_contact_map(const char *q_aln, const char *t_aln, int64_t La, cons
     if (Lq == 0) return MDF_OK;  // (0,0) output
     MDF_REQUIRE(out, "align_contact_map: out is NULL");
     const int64_t R = (Lq + 127) / 128 * 128;
-    // scratch: q | t | q2t (R) | t2q (La) | nm | pairs | out
-    const size_t o_q = 0, o_t = align_up((size_t)La, 256), o_q2t = o_t + align_up((size_t)La, 256),
-                 o_t2q = o_q2t + align_up((size_t)R * 4, 256), o_meta = o_t2q + align_up((size_t)La * 4 + 4, 256),
-                 o_pairs = o_meta + 256, o_out = o_pairs + align_up((size_t)N * 8 + 8, 256),
-                 total = o_out + (size_t)Lq * Lq * 4;
+    // scratch: meta | q | t  (one pinned-staged upload)  | q2t (R) | t2q (La) | pairs | out
+    const size_t o_meta = 0, o_q = 256, o_t = o_q + align_up((size_t)La, 256), o_q2t = o_t + align_up((size_t)La, 256),
+                 o_t2q = o_q2t + align_up((size_t)R * 4, 256), o_pairs = o_t2q + align_up((size_t)La * 4 + 4, 256),
+                 o_out = o_pairs + align_up((size_t)N * 8 + 8, 256), total = o_out + (size_t)Lq * Lq * 4;
     Scratch &s = scratch(0);
     if (int rc = s.reserve(total)) return rc;
     char *b = static_cast<char *>(s.ptr);
-    MDF_HIP(hipMemcpy(b + o_q, q_aln, (size_t)La, hipMemcpyHostToDevice));
-    MDF_HIP(hipMemcpy(b + o_t, t_aln, (size_t)La, hipMemcpyHostToDevice));
-    if (N) MDF_HIP(hipMemcpy(b + o_pairs, pairs, (size_t)N * 8, hipMemcpyHostToDevice));
+    HostStage &hs = host_stage();
+    if (int rc = hs.reserve(o_q2t)) return rc;
     int32_t meta[8] = {0, (int32_t)La, 0, (int32_t)R, 0, 0, 0, 0};  // aln_off[2], row_off[2], nm, lq
-    MDF_HIP(hipMemcpy(b + o_meta, meta, sizeof(meta), hipMemcpyHostToDevice));
+    memcpy(hs.ptr + o_meta, meta, sizeof(meta));
+    memcpy(hs.ptr + o_q, q_aln, (size_t)La);
+    memcpy(hs.ptr + o_t, t_aln, (size_t)La);
+    MDF_HIP(hipMemcpyAsync(b, hs.ptr, o_t + (size_t)La, hipMemcpyHostToDevice, nullptr));
+    if (N) MDF_HIP(hipMemcpyAsync(b + o_pairs, pairs, (size_t)N * 8, hipMemcpyHostToDevice, nullptr));
     int32_t *d_meta = reinterpret_cast<int32_t *>(b + o_meta);
     int32_t *d_q2t = reinterpret_cast<int32_t *>(b + o_q2t), *d_t2q = reinterpret_cast<int32_t *>(b + o_t2q);
     int32_t *d_out = reinterpret_cast<int32_t *>(b + o_out);
@@ -947,10 +957,14 @@ int mdf_build_align_contact_map(const float *coords, int64_t Lt, const char *q_a
     Scratch &s = scratch(0);
     if (int rc = s.reserve(total)) return rc;
     char *b = static_cast<char *>(s.ptr);
-    MDF_HIP(hipMemcpy(b + o_desc, &d, sizeof(d), hipMemcpyHostToDevice));
-    if (Lt) MDF_HIP(hipMemcpy(b + o_xyz, coords, (size_t)Lt * 12, hipMemcpyHostToDevice));
-    MDF_HIP(hipMemcpy(b + o_q, q_aln, (size_t)La, hipMemcpyHostToDevice));
-    MDF_HIP(hipMemcpy(b + o_t, t_aln, (size_t)La, hipMemcpyHostToDevice));
+    // descriptors | coordinates | gapped query | gapped target: packed in pinned memory, ONE upload
+    HostStage &hs = host_stage();
+    if (int rc = hs.reserve(o_ws)) return rc;
+    memcpy(hs.ptr + o_desc, &d, sizeof(d));
+    if (Lt) memcpy(hs.ptr + o_xyz, coords, (size_t)Lt * 12);
+    memcpy(hs.ptr + o_q, q_aln, (size_t)La);
+    memcpy(hs.ptr + o_t, t_aln, (size_t)La);
+    MDF_HIP(hipMemcpyAsync(b, hs.ptr, o_t + (size_t)La, hipMemcpyHostToDevice, nullptr));
     const OneProtein *dd = reinterpret_cast<const OneProtein *>(b + o_desc);
     if (int rc = mdf_cmap_dense_dev(reinterpret_cast<const float *>(b + o_xyz), dd->coord_off, b + o_q, b + o_t, dd->aln_off, dd->Lq,
                                     dd->row_off, 1, R, threshold, generated_contacts, reinterpret_cast<int32_t *>(b + o_out),
@@ -990,23 +1004,32 @@ int mdf_seq2onehot(const char *seq, int64_t L, float *out, int64_t *bad_idx)
     if (int rc = require_device()) return rc;
     if (L == 0) return MDF_OK;
     const size_t ob = (size_t)L * 26 * 4;
+    // device: flag (256) | seq | one-hot rows;  the flag + sequence go up in one staged copy, flag + rows come back in one
+    const size_t o_seq = 256, o_out = o_seq + align_up((size_t)L, 256);
     Scratch &s = scratch(0);
-    if (int rc = s.reserve(align_up((size_t)L, 256) + 256 + ob)) return rc;
+    if (int rc = s.reserve(o_out + ob)) return rc;
+    HostStage &hs = host_stage();
+    if (int rc = hs.reserve(o_out + ob)) return rc;
     char *b = static_cast<char *>(s.ptr);
-    int32_t *d_bad = reinterpret_cast<int32_t *>(b + align_up((size_t)L, 256));
-    float *d_out = reinterpret_cast<float *>(b + align_up((size_t)L, 256) + 256);
-    int32_t init = 0x7fffffff;
-    MDF_HIP(hipMemcpy(b, seq, (size_t)L, hipMemcpyHostToDevice));
-    MDF_HIP(hipMemcpy(d_bad, &init, 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_seq2onehot, dim3((unsigned)std::min<int64_t>((L * 26 + 255) / 256, 4096)), dim3(256), 0, 0, b, L, d_out, d_bad);
+    int32_t *d_bad = reinterpret_cast<int32_t *>(b);
+    float *d_out = reinterpret_cast<float *>(b + o_out);
+    const int32_t init = 0x7fffffff;
+    memcpy(hs.ptr, &init, 4);
+    memcpy(hs.ptr + o_seq, seq, (size_t)L);
+    MDF_HIP(hipMemcpyAsync(b, hs.ptr, o_seq + (size_t)L, hipMemcpyHostToDevice, nullptr));
+    hipLaunchKernelGGL(k_seq2onehot, dim3((unsigned)std::min<int64_t>((L * 26 + 255) / 256, 4096)), dim3(256), 0, 0, b + o_seq, L, d_out, d_bad);
     MDF_HIP(hipGetLastError());
+    // flag and rows are not adjacent on the device (the sequence lies between): two async copies into pinned memory, one sync
+    MDF_HIP(hipMemcpyAsync(hs.ptr, d_bad, 4, hipMemcpyDeviceToHost, nullptr));
+    MDF_HIP(hipMemcpyAsync(hs.ptr + o_out, d_out, ob, hipMemcpyDeviceToHost, nullptr));
+    MDF_HIP(hipStreamSynchronize(nullptr));
     int32_t bad = 0;
-    MDF_HIP(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost));
+    memcpy(&bad, hs.ptr, 4);
     if (bad != 0x7fffffff) {
         if (bad_idx) *bad_idx = bad;
         return fail(MDF_EBADCHAR, "Invalid character in sequence at index %d", bad);
     }
-    MDF_HIP(hipMemcpy(out, d_out, ob, hipMemcpyDeviceToHost));
+    memcpy(out, hs.ptr + o_out, ob);
     return MDF_OK;
 }
 

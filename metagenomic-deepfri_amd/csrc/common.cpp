@@ -179,6 +179,24 @@ int Scratch::reserve(size_t need)
     return MDF_OK;
 }
 
+int HostStage::reserve(size_t need)
+{
+    if (ptr && bytes >= need) return MDF_OK;
+    if (ptr) (void)hipHostFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+    const size_t want = align_up(need + need / 2 + 4096, 4096);
+    MDF_HIP(hipHostMalloc(reinterpret_cast<void **>(&ptr), want, hipHostMallocDefault));
+    bytes = want;
+    return MDF_OK;
+}
+
+HostStage &host_stage()
+{
+    static thread_local HostStage h;
+    return h;
+}
+
 Scratch &scratch(int slot)
 {
     static thread_local Scratch s[8];

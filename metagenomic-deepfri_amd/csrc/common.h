@@ -60,6 +60,16 @@ struct Scratch {
 };
 Scratch &scratch(int slot);  // a few independent slots per thread
 
+// Per-thread PINNED host staging for the per-call entry points: their small arguments (descriptors, alignment strings,
+// coordinates) are packed here and cross PCIe in ONE copy instead of one synchronous hipMemcpy each, and small results come
+// back through it the same way (a copy from/to pageable memory costs a driver-side bounce per call).
+struct HostStage {
+    char *ptr = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need);
+};
+HostStage &host_stage();
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- device bookkeeping ---------------------------------------------------------------------------------------------

@@ -1556,8 +1556,13 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     d.row_off[0] = row_off[0];
     d.row_off[1] = row_off[1];
     d.grp_off[1] = (int32_t)(R / 32);
-    MDF_HIP(hipMemcpyAsync(b + o_desc, &d, sizeof(d), hipMemcpyHostToDevice, nullptr));
-    MDF_HIP(hipMemcpyAsync(b + o_seq, seq, (size_t)L, hipMemcpyHostToDevice, nullptr));
+    // descriptors + sequence: one upload from pinned staging (o_desc = 0 and o_seq follow each other); the map goes up from the
+    // caller's array as it is
+    HostStage &hs = host_stage();
+    if (int rc = hs.reserve(align_up(o_seq + (size_t)L, 256) + 256 + (size_t)m->T * 4 + 256)) return rc;
+    memcpy(hs.ptr + o_desc, &d, sizeof(d));
+    memcpy(hs.ptr + o_seq, seq, (size_t)L);
+    MDF_HIP(hipMemcpyAsync(b + o_desc, hs.ptr, o_seq + (size_t)L, hipMemcpyHostToDevice, nullptr));
     MDF_HIP(hipMemcpyAsync(b + o_cm, cmap, (size_t)L * L * es, hipMemcpyHostToDevice, nullptr));
     Desc *dd = reinterpret_cast<Desc *>(b + o_desc);
     uint8_t *d_idx = reinterpret_cast<uint8_t *>(b + o_idx);
@@ -1579,15 +1584,20 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     }
     if (int rc = mdf_gcn_pool_dev(m, d_part, dd->grp_off, 1, d_pool, nullptr)) return rc;
     if (int rc = mdf_gcn_head_dev(m, d_pool, 1, d_sc, nullptr, b + o_hws, hws, nullptr)) return rc;
+    // flags and scores come back together: two async copies into pinned memory, ONE synchronisation
     Desc back;
-    MDF_HIP(hipMemcpy(&back, b + o_desc, sizeof(back), hipMemcpyDeviceToHost));
+    char *hback = hs.ptr + align_up(o_seq + (size_t)L, 256);
+    MDF_HIP(hipMemcpyAsync(hback, b + o_desc, sizeof(back), hipMemcpyDeviceToHost, nullptr));
+    MDF_HIP(hipMemcpyAsync(hback + 256, d_sc, (size_t)m->T * 4, hipMemcpyDeviceToHost, nullptr));
+    MDF_HIP(hipStreamSynchronize(nullptr));
+    memcpy(&back, hback, sizeof(back));
     if (back.bad[0] != -1) {
         const long long pos = back.bad[0] & 0xffffffffLL;   // one protein: the key is the position of the first invalid byte
         if (bad_idx) *bad_idx = pos;
         return fail(MDF_EBADCHAR, "Invalid character in sequence at index %lld", pos);
     }
     if (back.status[0] != 0) return fail(MDF_ECAPACITY, "gcn_forward_host: CSR overflow (%d entries)", back.status[1]);
-    MDF_HIP(hipMemcpy(scores, d_sc, (size_t)m->T * 4, hipMemcpyDeviceToHost));
+    memcpy(scores, hback + 256, (size_t)m->T * 4);
     return MDF_OK;
 }
 
