@@ -504,6 +504,107 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
 #undef MDF_DMA_PIECE
 }
 
+
+// ---- k_gemm_f32_small: the same product for SMALL problems (per-call forward_pass: one protein; a handful of pooled
+// vectors in the GO head).  k_gemm_f32 needs >= 256 output tiles of 256 x 256 to fill the chip and one tile costs
+// K/32 x 6.8 us whatever M is -- a single L=512 protein keeps 4 CUs busy for 110 us per layer and the 1 x 1536 x 1024 head
+// layer takes 330 us on 4 CUs.  Here one WAVE owns one 32 x 32 output tile (an M=512, N=512 layer is 256 tiles on 256 CUs),
+// operands come straight from global memory / L2 (Bt is [N][K]: both operands are K-contiguous float4 loads), no LDS.
+// BIT-IDENTICAL to k_gemm_f32: the same v_mfma_f32_32x32x2_f32, fed the same k pairs (k, k+4) in the same ascending order,
+// and the same epilogue arithmetic -- so a protein scores the same through the per-call API and in a 10 000-protein batch.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f32_small(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
+                                                        int N, int K, float *__restrict__ C, int ldc, const float *__restrict__ bias,
+                                                        float *__restrict__ pool_partial, int ldp, float *__restrict__ logits, int n_real,
+                                                        GemmAux aux)
+{
+    const int lane = threadIdx.x & 63;
+    const int NT = N >> 5, MT = (M + 31) >> 5;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= MT * NT) return;
+    const int mt = t / NT, nt = t - mt * NT;
+    const int frow = lane & 31, khalf = lane >> 5;
+    const float *pa = A + (size_t)min(mt * 32 + frow, M - 1) * lda + khalf * 4;
+    const float *pb = Bt + (size_t)(nt * 32 + frow) * ldb + khalf * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int nkg = K >> 3;                     // k-groups of 8 (host-checked: K % 32 == 0, so nkg % 4 == 0)
+    float4 a[4], b[4], an[4], bn[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        a[u] = *reinterpret_cast<const float4 *>(pa + u * 8);
+        b[u] = *reinterpret_cast<const float4 *>(pb + u * 8);
+    }
+    for (int kg = 0; kg < nkg; kg += 4) {
+        const int kn = min(kg + 4, nkg - 4);    // the last iteration re-reads its own block (harmless)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            an[u] = *reinterpret_cast<const float4 *>(pa + (size_t)(kn + u) * 8);
+            bn[u] = *reinterpret_cast<const float4 *>(pb + (size_t)(kn + u) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = an[u];
+            b[u] = bn[u];
+        }
+    }
+    // epilogue: the arithmetic of gemm_epilogue<EPI> on one 32 x 32 MFMA tile (lane l, register r -> col l&31, row (r&3)+8*(r>>2)+4*(l>>5))
+    const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+    const int rbase = mt * 32, col = nt * 32 + lcol;
+    if (EPI == EPI_EMBED) {
+        int lt[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lt[r] = min((int)aux.letters[min(rbase + (r & 3) + 8 * (r >> 2) + lrow, M - 1)], 31) * N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+            if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[r] + aux.table[lt[r] + col], 0.0f);
+        }
+    } else if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_L1_STORE || EPI == EPI_L1) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+            const float v = elu1(acc[r]);
+            sum += v;
+            if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_L1_STORE) C[(size_t)row * ldc + col] = v;
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        if (lane < 32) pool_partial[(size_t)(rbase >> 5) * ldp + col] = sum;
+    } else if (EPI == EPI_BIAS_RELU) {
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+            if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[r] + bv, 0.0f);
+        }
+    } else {   // EPI_BIAS_SOFTMAX2
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+            const float z = acc[r] + bv;
+            const float zo = __shfl_xor(z, 1, 64);
+            if (row < M && col < n_real) {
+                if (logits) logits[(size_t)row * n_real + col] = z;
+                if ((col & 1) == 0) {
+                    const float mx = fmaxf(z, zo);
+                    const float e0 = expf(z - mx), e1 = expf(zo - mx);
+                    C[(size_t)row * ldc + (col >> 1)] = e0 / (e0 + e1);
+                }
+            }
+        }
+    }
+}
+
 // ---- A.X aggregation: out[i,:] = sum_e val[e] * H[colidx[e],:]  over the CSR row i.  One wave per row, lane l owns
 // channels [4l,4l+4) of every 256-channel slab (float4 loads/stores: 1 KiB per wave instruction).  Row index, CSR
 // bounds, column indices and values are wave-uniform -> scalar loads.  Row tiles follow the GEMM's XCD placement.
@@ -868,6 +969,18 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     if (int rc = set_gemm_attr_once()) return rc;
     const int MT = (M + BM - 1) / BM, NT = N / BN;
     const bool plain = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
+    if constexpr (EPI != EPI_LSTM_TAB && EPI != EPI_LSTM_BIAS) {
+        // small problems (fewer 256 x 256 tiles than a quarter of the CUs): one wave per 32 x 32 tile, bit-identical results
+        static const int small_env = getenv("MDFRI_GEMM_SMALL") ? atoi(getenv("MDFRI_GEMM_SMALL")) : -1;   // developer knob: 0 never, 1 always
+        const bool small = small_env >= 0 ? small_env != 0 : MT * NT * 4 < gemm_resident_blocks();
+        if (small) {
+            const int tiles = ((M + 31) / 32) * (N / 32);
+            hipLaunchKernelGGL(k_gemm_f32_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias, pool_partial, ldp,
+                               logits, n_real, aux);
+            MDF_HIP(hipGetLastError());
+            return MDF_OK;
+        }
+    }
     const int total = plain ? MT * NT : 8 * NT * ((MT + 7) / 8);  // tile slots (in XCD-aware order some lie past M)
     const int blocks = std::min(total, gemm_resident_blocks());
     hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,

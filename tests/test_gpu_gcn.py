@@ -223,6 +223,11 @@ def test_full_size_batch_properties(mf):
     perm = list(np.random.default_rng(0).permutation(96))
     assert np.array_equal(run(perm), full[perm])        # bitwise: no cross-protein coupling, deterministic pooling
     assert np.array_equal(run([7]), full[[7]])
+    # ... nor on the GEMM kernel it went through: the 96-protein batch runs the 256x256-tile kernel, a single protein (here and
+    # in the per-call API) the one-wave-per-32x32-tile kernel for small problems -- same MFMA k order, identical bits
+    for i in (3, 50):
+        cm_i = orc.build_align_contact_map(prots[i]["coords"], prots[i]["q_aln"], prots[i]["t_aln"], 6.0, 2)
+        assert np.array_equal(pred.forward_pass(prots[i]["seq"], cm_i), full[i])
     for i in (0, 95):
         cm = orc.build_align_contact_map(prots[i]["coords"], prots[i]["q_aln"], prots[i]["t_aln"], 6.0, 2)
         assert np.max(np.abs(full[i] - gcn_oracle.gcn_forward(w, prots[i]["seq"], cm))) < TOL
@@ -319,7 +324,9 @@ def test_library_first_then_torch_share_one_hip_runtime():
         "prots = synthetic.synthetic_proteins(1, 3, 50)\n"
         "pk = batch.PackedProteins.pack([q['seq'] for q in prots], [q['coords'] for q in prots], [q['q_aln'] for q in prots], [q['t_aln'] for q in prots])\n"
         "print(e.run_alignments(pk)['mf'].shape)\n" % ROOT)
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    # generous timeout: with HIP already initialised, `import torch` makes the runtime load every fat binary of libtorch_hip at
+    # once -- 2.5 s from a warm page cache, 200+ s from the cold image of a fresh box (tools/import_order_probe.py)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "(3, 16)" in out.stdout
 
