@@ -38,5 +38,10 @@ def gcn_golden():
     return np.load(os.path.join(GOLDEN, "gcn_golden.npz"))
 
 
+@pytest.fixture(scope="session")
+def nw_golden():
+    return np.load(os.path.join(GOLDEN, "nw_golden.npz"))
+
+
 def gstr(a) -> str:
     return bytes(np.asarray(a, dtype=np.uint8)).decode()

@@ -143,3 +143,43 @@ def test_aligner_arrays_feed_the_fused_path_without_per_protein_objects():
     assert np.array_equal(eng.run_alignments(pk)["mf"], eng.run_alignments(pk2)["mf"])
     for (a, cm), i in zip(build_align_contact_maps([res[i] for i in kept]), kept):
         assert np.array_equal(cm, orc.build_align_contact_map(coords[i], res[i].gapped_sequence, res[i].gapped_target, 6.0, 2))
+
+
+def test_committed_golden_vectors(nw_golden):
+    from conftest import gstr
+    sm = ScoringMatrix(gstr(nw_golden["alphabet"]), nw_golden["matrix"])
+    for n in [str(x) for x in nw_golden["index"]]:
+        q, t = gstr(nw_golden[n + "/q"]), gstr(nw_golden[n + "/t"])
+        go, ge = (int(v) for v in nw_golden[n + "/gap"])
+        ops, iden, qc, tc = align_pairwise(q, t, go, ge, sm)
+        assert ops == gstr(nw_golden[n + "/ops"]) and iden == float(nw_golden[n + "/identity"]) and qc == tc == 1.0, n
+
+
+def test_size_independent_properties_at_scale():
+    """6 000 pairs with metagenome-like lengths (the committed histogram): properties that need no oracle -- a symmetric matrix
+    gives score(q, t) == score(t, q); a sequence against itself scores the sum of its diagonal entries and aligns as all 'M';
+    every returned alignment is a valid global alignment whose re-computed score equals the reported optimum; the score-mode
+    kernel and the full-alignment kernel agree."""
+    from mDeepFRI.alignment import _PairBatch
+    sm = _matrix(11)
+    rng = np.random.default_rng(13)
+    lens = synthetic.histogram_lengths(5, 3000)
+    seqs = [_seq(rng, int(L)) for L in lens]
+    pb = _PairBatch(seqs, sm)
+    a = rng.integers(0, 3000, size=6000).astype(np.int32)
+    b = rng.integers(0, 3000, size=6000).astype(np.int32)
+    s_ab, s_ba = pb.scores(a, b, 10, 1), pb.scores(b, a, 10, 1)
+    assert np.array_equal(s_ab, s_ba)
+    idx = np.arange(3000, dtype=np.int32)
+    diag = np.array([int(sm.matrix[c, c].sum()) for c in (sm.encode(s) for s in seqs)])
+    assert np.array_equal(pb.scores(idx, idx, 10, 1), diag)
+    sel = np.arange(0, 6000, 15)
+    full = pb.align(a[sel], b[sel], 10, 1)
+    assert np.array_equal(full["score"], s_ab[sel])
+    for k, p in enumerate(sel[:120]):
+        lo, hi = int(full["off"][k]), int(full["off"][k + 1])
+        ops = bytes(full["ops"][lo:hi]).decode()
+        assert nwo.score_of_alignment(seqs[a[p]], seqs[b[p]], ops, sm.matrix, sm.alphabet) == int(s_ab[p]), p
+        assert int(full["n_match"][k]) == ops.count("M")
+    selfaln = pb.align(idx[:200], idx[:200], 10, 1)
+    assert all(bytes(selfaln["ops"][int(selfaln["off"][k]):int(selfaln["off"][k + 1])]) == b"M" * len(seqs[k]) for k in range(200))

@@ -139,3 +139,18 @@ def test_scoring_matrix_io(tmp_path):
     if importlib.util.find_spec("scoring_matrices") is None:      # the image has no copy of VTML80: asking for it by name must say so
         with pytest.raises(ImportError, match="scoring_matrices"):
             ScoringMatrix.from_name("VTML80")
+
+
+def test_oracle_reproduces_the_committed_golden_vectors(nw_golden):
+    """tests/golden/nw_golden.npz (made by make_nw_golden.py from this oracle) pins the oracle against silent changes of its tie
+    rules: operation strings, scores and identities of 18 seeded cases incl. the reference's known answer."""
+    from conftest import gstr
+    sm = ScoringMatrix(gstr(nw_golden["alphabet"]), nw_golden["matrix"])
+    names = [str(n) for n in nw_golden["index"]]
+    assert len(names) == 18 and "kat" in names
+    for n in names:
+        q, t = gstr(nw_golden[n + "/q"]), gstr(nw_golden[n + "/t"])
+        go, ge = (int(v) for v in nw_golden[n + "/gap"])
+        ops, iden, _, _, score = nwo.align_pairwise(q, t, sm.matrix, sm.alphabet, go, ge)
+        assert ops == gstr(nw_golden[n + "/ops"]) and score == int(nw_golden[n + "/score"]) and iden == float(nw_golden[n + "/identity"]), n
+    assert gstr(nw_golden["kat/ops"]) == "MMMMMMMMMXMMMMMMMMMMMMMMMMMMMMMMXMMMMMMMMMMX"

@@ -1,7 +1,6 @@
-"""A.X kernel probe: one mode per process (MDFRI_AX_DIRECT=1: one-wave-per-row gather form, default: LDS-staged form).
-Prints the mean launch time of the A.X kernel (HIP events around every launch) and a sha256 of all scores, so that two
-runs can be compared bit for bit.  Workloads: configs[2]-shaped (fixed L) and mixed lengths with indels, plus a dense random
-map through forward_pass (exercises the direct-gather branch of the LDS kernel)."""
+"""A.X kernel probe: mean launch time of the A.X kernel (HIP events around every launch) on four workload shapes plus a sha256 of
+all scores, so that two builds of the library (MDFRI_HIP_LIB=...) can be compared bit for bit.  The dense random maps at the end go
+through forward_pass (L/2 entries per row)."""
 import hashlib
 import os
 import sys
@@ -49,4 +48,4 @@ for L in (96, 700):
     seq = synthetic.random_sequence(rng, L)
     A = rng.integers(0, 2, size=(L, L)).astype(np.int32)
     h.update(pred.forward_pass(seq, A).tobytes())
-print("mode", "direct" if os.environ.get("MDFRI_AX_DIRECT") == "1" else "lds", "sha256", h.hexdigest(), flush=True)
+print("library", os.environ.get("MDFRI_HIP_LIB", "default"), "sha256", h.hexdigest(), flush=True)
