@@ -450,7 +450,7 @@ def main():
         def after(out):   # output stage on every rank, then ONE gather of the survivors per head
             for m in MODES:
                 off, ti, kept = filter_scores(out[m], threshold=0.1, capacity_per_protein=preds[m].n_terms)
-                gathered[m] = plans[m].run(off, ti, kept)
+                gathered[m] = plans[m].run(off, ti, kept, sizes_may_change=False)   # the same workload every step: sizes fixed by the first call
     else:
         n_local = args.proteins or 10000
         n_job = n_local * ctx.world

@@ -127,7 +127,11 @@ class FilteredGatherPlan:
         self.z_cap = 0
         self.dense = DenseGatherPlan(len(self.local_index), 1, self.local_index, total, self.dev, dtype=torch.int64, dst=dst, group=group)
 
-    def run(self, offsets, term_idx, kept):
+    def run(self, offsets, term_idx, kept, sizes_may_change: bool = True):
+        """sizes_may_change=True (default, always safe): every call agrees on the padded payload size with one tiny all-reduce and
+        one read-back.  False: the caller guarantees that no rank's survivor count exceeds what the first call planned for (e.g.
+        bench.py, which repeats the same workload) -- then a step has no host synchronisation at all; a rank that outgrows the
+        plan raises instead of silently desynchronising the collectives."""
         import torch
         import torch.distributed as dist
         cnt = (offsets[1:] - offsets[:-1]).to(torch.int64).to(self.dev)
@@ -138,18 +142,22 @@ class FilteredGatherPlan:
             torch.cumsum(counts, 0, out=goff[1:])
             return _place_filtered(goff, [(self.dense.order, cnt, term_idx, kept)], self.dev)
         z = int(term_idx.numel())
-        if self.z_cap == 0 or z > self.z_cap:               # first call (or outgrown): agree on a padded size, with headroom
+        if self.z_cap == 0 or sizes_may_change:             # a COLLECTIVE decision: every rank takes this branch together
             zs = torch.zeros(self.world, dtype=torch.long, device=self.dev)
             zs[self.rank] = z
             dist.all_reduce(zs, group=self.group)
-            self.z_cap = max(int(zs.max().item()) * 5 // 4, 1)
+            need = int(zs.max().item())
+        else:
+            need = 0
+            if z > self.z_cap:
+                raise RuntimeError(f"rank {self.rank}: {z} survivors exceed the planned {self.z_cap}; call run(..., sizes_may_change=True)")
+        if self.z_cap == 0 or need > self.z_cap:
+            self.z_cap = max(need * 5 // 4, 1)
             self.t_pay = torch.zeros(self.z_cap, dtype=torch.int32, device=self.dev)
             self.s_pay = torch.zeros(self.z_cap, dtype=torch.float32, device=self.dev)
             if self.rank == self.dst:
                 self.t_recv = [torch.empty_like(self.t_pay) for _ in range(self.world)]
                 self.s_recv = [torch.empty_like(self.s_pay) for _ in range(self.world)]
-        # NOTE: a rank whose survivors outgrow z_cap between calls re-plans on its own next call; all ranks see the same data
-        # every step in bench.py, and predict_sharded_filtered builds a fresh plan per call.
         counts = self.dense.run(cnt.reshape(-1, 1))          # per-protein survivor counts in input order (dst only)
         self.t_pay[:z].copy_(term_idx, non_blocking=True)
         self.s_pay[:z].copy_(kept, non_blocking=True)

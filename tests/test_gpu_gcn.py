@@ -347,6 +347,23 @@ def test_protein_longer_than_a_chunk(mf):
         assert np.max(np.abs(out[i] - gcn_oracle.gcn_forward(w, p["seq"], cm))) < TOL, i
 
 
+def test_protein_with_more_than_64_contact_words(mf):
+    """L = 4 500 needs 71 contact words per row: the CSR fill spreads a wave's 8 x 71 (row, word) items over several batches of 64
+    lanes and must keep every (row, letter) sum in ascending-column order across them -- checked bit for bit against the per-call
+    path (dense map -> k_dense_rows + k_letter_sums) and against the oracle within tolerance."""
+    from mDeepFRI.batch import PackedProteins
+    w, pred = mf
+    prots = synthetic.synthetic_proteins(seed=61, count=1, length=4500, indel_rate=0.01) + synthetic.synthetic_proteins(seed=62, count=2, length=(70, 90))
+    eng = _engine({"mf": pred}, max_rows=2048)
+    pk = PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots],
+                             [p["t_aln"] for p in prots], max_rows=2048)
+    out = eng.run_alignments(pk)["mf"]
+    for i, p in enumerate(prots):
+        cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
+        assert np.array_equal(out[i], pred.forward_pass(p["seq"], cm)), i
+        assert np.max(np.abs(out[i] - gcn_oracle.gcn_forward(w, p["seq"], cm))) < TOL, i
+
+
 def test_alignment_stream_matches_one_batch(mf, cc):
     """Host-in / host-out streaming runner: several device batches, a producer thread packing ahead, results in input order
     and bitwise equal to one big batch; objects with the AlignmentResult attributes are accepted as well as tuples."""
