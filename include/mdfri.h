@@ -321,19 +321,25 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
 int mdf_nw_plan(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P, int64_t *bnd_off, int64_t *trace_off,
                 int64_t *ops_off);
 
-/* Scores of P pairs (device pointers; bnd: int32 workspace of bnd_off[P] elements).  One wave per pair. */
+/* Host helper: length of the leading run of LARGE pairs (>= 512 x 512 cells) of a pair list ordered by decreasing size -- the
+ * n_long argument below.  Large pairs get a whole workgroup each (their 64-column strips run as a four-wave pipeline); with a
+ * single wave a 2 000 x 2 000 pair would outlive the rest of the launch by milliseconds.  0 is always valid. */
+int32_t mdf_nw_count_long(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P);
+
+/* Scores of P pairs (device pointers; bnd: int32 workspace of bnd_off[P] elements).  Pairs [0, n_long): one workgroup per pair;
+ * the others: one wave per pair. */
 int mdf_nw_score_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t,
-                     int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const int64_t *bnd_off, int32_t *bnd,
-                     int32_t *scores, void *stream);
+                     int32_t P, int32_t n_long, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const int64_t *bnd_off,
+                     int32_t *bnd, int32_t *scores, void *stream);
 
 /* Full alignments of P pairs (device pointers).  trace: trace_off[P] bytes of workspace.  Pair p's operations are written to
  * ops[ops_off[p+1] - op_len[p] .. ops_off[p+1]) (right-aligned inside the pair's capacity); q_aln / t_aln (optional, same
  * layout) receive the gapped query / target strings spelled with `alphabet` (A letters, device) -- what insert_gaps would
  * build.  n_match[p] = number of 'M' (identity = n_match / op_len, alignment.py:214); coverages of a global alignment are 1. */
 int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t,
-                     int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet, const int64_t *bnd_off,
-                     int32_t *bnd, const int64_t *trace_off, uint8_t *trace, const int64_t *ops_off, char *ops, char *q_aln, char *t_aln,
-                     int32_t *op_len, int32_t *n_match, int32_t *scores, void *stream);
+                     int32_t P, int32_t n_long, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet,
+                     const int64_t *bnd_off, int32_t *bnd, const int64_t *trace_off, uint8_t *trace, const int64_t *ops_off, char *ops, char *q_aln,
+                     char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores, void *stream);
 
 /* The same with host buffers (upload, run, download): n_seq sequences, P pairs; ops / q_aln / t_aln hold sum(Lq + Lt) bytes
  * laid out as mdf_nw_plan's ops_off says; alphabet is a NUL-terminated string of A letters. */

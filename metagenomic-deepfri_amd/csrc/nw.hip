@@ -16,6 +16,7 @@
 // open + (n-1)*extend; at H diagonal >= vertical >= horizontal; inside a gap opening wins a tie) -- bit-exact integer work.
 // PARITY UNPINNED against PyOpal itself (absent offline), see the oracle's header.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -24,6 +25,8 @@ namespace mdf {
 
 constexpr int NW_NEG = INT32_MIN / 2;
 constexpr int NW_LDA = 32;   // row pitch of the substitution matrix in LDS; alphabet size <= 32
+constexpr int NW_MAX_COOP_STRIPS = 2048;   // a cooperatively swept pair has at most this many 64-column strips (Lt <= 131 072)
+constexpr int64_t NW_COOP_MIN_CELLS = 512 * 512;   // pairs at least this large get a workgroup of their own
 
 // lane l <- value of lane l-1 (previous lane of the wave); lane 0 <- fill.  DPP wave_shr:1 (gfx9 family: one VALU op).
 __device__ __forceinline__ int wave_shr1(int v, int fill)
@@ -43,29 +46,38 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
                                             const int32_t *__restrict__ pair_t, int P, const int32_t *__restrict__ matrix, int A,
                                             int go, int ge, const int64_t *__restrict__ bnd_off, int32_t *bnd,
                                             const int64_t *__restrict__ trace_off, uint8_t *__restrict__ trace,
-                                            int32_t *__restrict__ scores)
+                                            int32_t *__restrict__ scores, int n_long)
 {
+    // Pairs [0, n_long) are LONG: one whole workgroup per pair, wave w sweeps strips w, w+4, ... and may enter a 64-row chunk of
+    // strip k as soon as strip k-1 has published the boundary values of those rows (s_prog, LDS) -- the strips of one matrix
+    // run as a pipeline four waves deep.  Without it a single 2 000 x 2 000 pair is a serial chain of ~67 000 steps on one wave
+    // that outlives everything else in the launch by milliseconds.  Pairs >= n_long: one wave per pair, four pairs per workgroup.
     __shared__ int s_S[NW_LDA * NW_LDA];
+    __shared__ int s_prog[NW_MAX_COOP_STRIPS];
     for (int e = threadIdx.x; e < NW_LDA * NW_LDA; e += blockDim.x) {
         const int r = e / NW_LDA, c = e % NW_LDA;
         s_S[e] = (r < A && c < A) ? matrix[r * A + c] : 0;
     }
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool coop = (int)blockIdx.x < n_long;
+    if (coop)
+        for (int e = threadIdx.x; e < NW_MAX_COOP_STRIPS; e += blockDim.x) s_prog[e] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int p = coop ? (int)blockIdx.x : n_long + ((int)blockIdx.x - n_long) * 4 + wid;
     if (p >= P) return;
     const int iq = pair_q[p], it = pair_t[p];
     const int Lq = seq_len[iq], Lt = seq_len[it];
     const uint8_t *q = codes + seq_off[iq], *t = codes + seq_off[it];
     if (Lq == 0 || Lt == 0) {   // degenerate: one all-gap run (or nothing)
-        if (lane == 0) scores[p] = (Lq + Lt == 0) ? 0 : -(go + (Lq + Lt - 1) * ge);
+        if (lane == 0 && (!coop || wid == 0)) scores[p] = (Lq + Lt == 0) ? 0 : -(go + (Lq + Lt - 1) * ge);
         return;
     }
     int32_t *Hb = bnd + bnd_off[p], *Eb = Hb + Lq;   // H / E of the column left of the current strip, rows 1..Lq
     uint8_t *tr = TRACE ? trace + trace_off[p] : nullptr;
     const int n_strips = (Lt + 63) >> 6;
     const int n_steps = Lq + 63;
-    for (int k = 0; k < n_strips; ++k) {
+    for (int k = coop ? wid : 0; k < n_strips; k += coop ? 4 : 1) {
         const int j = (k << 6) + lane;                 // my column: target residue j, DP column j + 1
         const int tc = j < Lt ? (int)t[j] : 0;
         int up = -(go + j * ge);                       // H[0][j+1]
@@ -74,6 +86,9 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
         int h_out = NW_NEG, e_out = NW_NEG, qc = 0;
         uint8_t *trk = TRACE ? tr + (int64_t)k * nw_strip_steps(Lq) * 64 : nullptr;
         const bool pass_right = k + 1 < n_strips;
+        // the substitution score of the NEXT step is looked up one step ahead (its query residue is known as soon as the shift
+        // register has moved), so that the LDS latency is off the step-to-step dependency chain
+        int qc_next = 0, sc_cur = 0;
         for (int s0 = 0; s0 < n_steps; s0 += 64) {
             // this chunk's rows for lane 0: query residues and the boundary column
             const int r = s0 + lane;
@@ -83,39 +98,68 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
                 hbchunk = -(go + r * ge);              // H[r+1][0]
                 ebchunk = NW_NEG;                      // E[r+1][0]
             } else {
+                if (coop) {   // rows [s0, s0 + 64) of the left neighbour strip must have been published
+                    const int need = min(Lq, s0 + 64);
+                    while (__hip_atomic_load(&s_prog[k - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
+                }
                 hbchunk = r < Lq ? ld_coherent(Hb + r) : NW_NEG;
                 ebchunk = r < Lq ? ld_coherent(Eb + r) : NW_NEG;
             }
+            if (s0 == 0) {
+                qc_next = wave_shr1(0, __builtin_amdgcn_readlane(qchunk, 0));
+                sc_cur = s_S[qc_next * NW_LDA + tc];
+            }
+            int hb_keep = 0, eb_keep = 0;              // lane u keeps what lane 63 produced at step s0 + u (row s0 + u - 63)
             const int u_end = min(64, n_steps - s0);
             for (int u = 0; u < u_end; ++u) {
                 const int s = s0 + u;
                 // what lane l-1 produced one step ago is this row's left neighbour; lane 0 takes the boundary column
                 const int left = wave_shr1(h_out, __builtin_amdgcn_readlane(hbchunk, u));
                 const int eleft = wave_shr1(e_out, __builtin_amdgcn_readlane(ebchunk, u));
-                qc = wave_shr1(qc, __builtin_amdgcn_readlane(qchunk, u));
+                qc = qc_next;
+                const int sc = sc_cur;
+                // shift the query residues for the next step and start its score lookup (the last step of a chunk needs the
+                // next chunk's first residue: fetched directly, it is a wave-uniform byte)
+                const int q_in = (u + 1 < 64) ? __builtin_amdgcn_readlane(qchunk, (u + 1) & 63) : (s + 1 < Lq ? (int)q[s + 1] : 0);
+                qc_next = wave_shr1(qc, q_in);
+                sc_cur = s_S[qc_next * NW_LDA + tc];
                 const int i = s - lane;                // my row: query residue i, DP row i + 1
+                const bool active = i >= 0 && i < Lq;
+                const int e_open = left - go, e_ext = eleft - ge;
+                const int f_open = up - go, f_ext = fup - ge;
                 int code = 0;
-                if (i >= 0 && i < Lq) {
-                    const int e_open = left - go, e_ext = eleft - ge;
-                    const int f_open = up - go, f_ext = fup - ge;
-                    int e = e_open, f = f_open;
-                    if (e_ext > e_open) { e = e_ext; code |= 4; }
-                    if (f_ext > f_open) { f = f_ext; code |= 8; }
-                    int h = diag + s_S[qc * NW_LDA + tc];
-                    if (f > h) { h = f; code |= 1; }
-                    if (e > h) { h = e; code = (code & ~3) | 2; }
-                    diag = left;
-                    up = h;
-                    fup = f;
-                    h_out = h;
-                    e_out = e;
-                    if (pass_right && lane == 63) {
-                        st_coherent(Hb + i, h);
-                        st_coherent(Eb + i, e);
-                    }
-                    if (i == Lq - 1 && j == Lt - 1) scores[p] = h;
+                int e = e_open, f = f_open;
+                if (e_ext > e_open) { e = e_ext; code |= 4; }
+                if (f_ext > f_open) { f = f_ext; code |= 8; }
+                int h = diag + sc;
+                if (f > h) { h = f; code |= 1; }
+                if (e > h) { h = e; code = (code & ~3) | 2; }
+                // state moves on only for lanes inside the matrix (selects, no branches)
+                diag = active ? left : diag;
+                up = active ? h : up;
+                fup = active ? f : fup;
+                h_out = active ? h : h_out;
+                e_out = active ? e : e_out;
+                if (pass_right) {
+                    const int h63 = __builtin_amdgcn_readlane(h_out, 63), e63 = __builtin_amdgcn_readlane(e_out, 63);
+                    hb_keep = lane == u ? h63 : hb_keep;
+                    eb_keep = lane == u ? e63 : eb_keep;
                 }
-                if (TRACE) trk[(int64_t)s * 64 + lane] = (uint8_t)code;   // 64 contiguous bytes per step
+                if (active && i == Lq - 1 && j == Lt - 1) scores[p] = h;
+                if (TRACE) trk[(int64_t)s * 64 + lane] = (uint8_t)(active ? code : 0);   // 64 contiguous bytes per step
+            }
+            if (pass_right) {
+                // lane 63 worked on row s0 + u - 63 at step s0 + u: one coalesced store of the chunk's boundary values
+                const int row = s0 + lane - 63;
+                if (lane < u_end && row >= 0 && row < Lq) {
+                    st_coherent(Hb + row, hb_keep);
+                    st_coherent(Eb + row, eb_keep);
+                }
+                if (coop) {   // publish: rows [0, s0 + u_end - 63) of this strip's right boundary are in memory
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (lane == 0)
+                        __hip_atomic_store(&s_prog[k], max(0, min(Lq, s0 + u_end - 63)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the boundary column is complete before the next strip reads it
@@ -200,6 +244,19 @@ using namespace mdf;
 
 extern "C" {
 
+int32_t mdf_nw_count_long(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P)
+{
+    if (!seq_len || !pair_q || !pair_t || P < 0) return fail(MDF_EINVAL, "nw_count_long: bad arguments");
+    static const int64_t min_cells = getenv("MDFRI_NW_COOP_MIN_CELLS") ? atoll(getenv("MDFRI_NW_COOP_MIN_CELLS")) : NW_COOP_MIN_CELLS;   // developer knob
+    int32_t n = 0;
+    while (n < P) {
+        const int64_t Lq = seq_len[pair_q[n]], Lt = seq_len[pair_t[n]];
+        if (Lq * Lt < min_cells || (Lt + 63) / 64 > NW_MAX_COOP_STRIPS) break;
+        ++n;
+    }
+    return n;
+}
+
 int mdf_nw_plan(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P, int64_t *bnd_off, int64_t *trace_off,
                 int64_t *ops_off)
 {
@@ -222,27 +279,30 @@ int mdf_nw_plan(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pa
 }
 
 int mdf_nw_score_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t,
-                     int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const int64_t *bnd_off, int32_t *bnd,
-                     int32_t *scores, void *stream)
+                     int32_t P, int32_t n_long, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const int64_t *bnd_off,
+                     int32_t *bnd, int32_t *scores, void *stream)
 {
     if (int rc = nw_check(codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend)) return rc;
     MDF_REQUIRE(bnd_off && bnd && scores, "nw_score_dev: NULL argument");
-    hipLaunchKernelGGL(k_nw<false>, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), codes, seq_off, seq_len,
-                       pair_q, pair_t, P, matrix, A, gap_open, gap_extend, bnd_off, bnd, (const int64_t *)nullptr, (uint8_t *)nullptr, scores);
+    MDF_REQUIRE(n_long >= 0 && n_long <= P, "nw_score_dev: n_long=%d not in 0..P", n_long);
+    hipLaunchKernelGGL(k_nw<false>, dim3((unsigned)(n_long + (P - n_long + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), codes, seq_off,
+                       seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, bnd_off, bnd, (const int64_t *)nullptr, (uint8_t *)nullptr,
+                       scores, n_long);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
 
 int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t,
-                     int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet, const int64_t *bnd_off,
-                     int32_t *bnd, const int64_t *trace_off, uint8_t *trace, const int64_t *ops_off, char *ops, char *q_aln, char *t_aln,
-                     int32_t *op_len, int32_t *n_match, int32_t *scores, void *stream)
+                     int32_t P, int32_t n_long, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet,
+                     const int64_t *bnd_off, int32_t *bnd, const int64_t *trace_off, uint8_t *trace, const int64_t *ops_off, char *ops, char *q_aln,
+                     char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores, void *stream)
 {
     if (int rc = nw_check(codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend)) return rc;
     MDF_REQUIRE(alphabet && bnd_off && bnd && trace_off && trace && ops_off && ops && op_len && n_match && scores, "nw_align_dev: NULL argument");
+    MDF_REQUIRE(n_long >= 0 && n_long <= P, "nw_align_dev: n_long=%d not in 0..P", n_long);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_nw<true>, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A,
-                       gap_open, gap_extend, bnd_off, bnd, trace_off, trace, scores);
+    hipLaunchKernelGGL(k_nw<true>, dim3((unsigned)(n_long + (P - n_long + 3) / 4)), dim3(256), 0, st, codes, seq_off, seq_len, pair_q, pair_t, P,
+                       matrix, A, gap_open, gap_extend, bnd_off, bnd, trace_off, trace, scores, n_long);
     hipLaunchKernelGGL(k_nw_traceback, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, st, codes, seq_off, seq_len, pair_q, pair_t, P, trace_off,
                        (const uint8_t *)trace, ops_off, alphabet, ops, q_aln, t_aln, op_len, n_match);
     MDF_HIP(hipGetLastError());
@@ -296,11 +356,12 @@ static int nw_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *
     MDF_HIP(hipMemcpy(b + o_mat, matrix, (size_t)A * A * 4, hipMemcpyHostToDevice));
     MDF_HIP(hipMemcpy(b + o_bo, bo.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice));
     auto D = [&](size_t off) { return b + off; };
+    const int32_t n_long = mdf_nw_count_long(seq_len, pair_q, pair_t, P);   // leading run of large pairs (callers order by decreasing size)
     int rc;
     if (!full) {
         rc = mdf_nw_score_dev((const uint8_t *)D(o_codes), (const int64_t *)D(o_soff), (const int32_t *)D(o_slen), (const int32_t *)D(o_pq),
-                              (const int32_t *)D(o_pt), P, (const int32_t *)D(o_mat), A, go, ge, (const int64_t *)D(o_bo), (int32_t *)D(o_bnd),
-                              (int32_t *)D(o_sc), nullptr);
+                              (const int32_t *)D(o_pt), P, n_long, (const int32_t *)D(o_mat), A, go, ge, (const int64_t *)D(o_bo),
+                              (int32_t *)D(o_bnd), (int32_t *)D(o_sc), nullptr);
     } else {
         char al[64] = {0};
         memcpy(al, alphabet, std::min<size_t>(strlen(alphabet), 63));
@@ -308,7 +369,7 @@ static int nw_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *
         MDF_HIP(hipMemcpy(b + o_to, to.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice));
         MDF_HIP(hipMemcpy(b + o_oo, oo.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice));
         rc = mdf_nw_align_dev((const uint8_t *)D(o_codes), (const int64_t *)D(o_soff), (const int32_t *)D(o_slen), (const int32_t *)D(o_pq),
-                              (const int32_t *)D(o_pt), P, (const int32_t *)D(o_mat), A, go, ge, D(o_al), (const int64_t *)D(o_bo),
+                              (const int32_t *)D(o_pt), P, n_long, (const int32_t *)D(o_mat), A, go, ge, D(o_al), (const int64_t *)D(o_bo),
                               (int32_t *)D(o_bnd), (const int64_t *)D(o_to), (uint8_t *)D(o_tr), (const int64_t *)D(o_oo), D(o_ops),
                               q_aln ? D(o_qa) : nullptr, t_aln ? D(o_ta) : nullptr, (int32_t *)D(o_ol), (int32_t *)D(o_nm), (int32_t *)D(o_sc),
                               nullptr);

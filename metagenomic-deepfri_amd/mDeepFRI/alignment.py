@@ -148,21 +148,32 @@ class _PairBatch:
             raise ValueError(f"character {chr(int(raw[int(np.argmax(self.codes == 255))]))!r} is not in the scoring matrix alphabet")
         self.sm = sm
 
+    def _by_cost(self, pq, pt):
+        """Launch order: largest DP matrices first.  One wave sweeps one pair, so a 2 000 x 2 000 pair started last would run on
+        alone for milliseconds after everything else has finished (longest-processing-time-first scheduling)."""
+        return np.argsort(-(self.seq_len[pq].astype(np.int64) * self.seq_len[pt].astype(np.int64)), kind="stable")
+
     def scores(self, pair_q, pair_t, gap_open, gap_extend) -> np.ndarray:
-        pq, pt = np.ascontiguousarray(pair_q, dtype=np.int32), np.ascontiguousarray(pair_t, dtype=np.int32)
+        pq, pt = np.asarray(pair_q, dtype=np.int32), np.asarray(pair_t, dtype=np.int32)
         out = np.empty(len(pq), dtype=np.int32)
         if len(pq):
+            order = self._by_cost(pq, pt)
+            pq, pt = np.ascontiguousarray(pq[order]), np.ascontiguousarray(pt[order])
+            sc = np.empty(len(pq), dtype=np.int32)
             _hip.check(_hip.lib().mdf_nw_score_host(_hip.ptr(self.codes), _hip.ptr(self.seq_off), _hip.ptr(self.seq_len), len(self.seq_len),
                                                    _hip.ptr(pq), _hip.ptr(pt), len(pq), _hip.ptr(self.sm.matrix), len(self.sm.alphabet),
-                                                   int(gap_open), int(gap_extend), _hip.ptr(out)))
+                                                   int(gap_open), int(gap_extend), _hip.ptr(sc)))
+            out[order] = sc
         return out
 
     def align(self, pair_q, pair_t, gap_open, gap_extend, max_trace_bytes: int = 4 << 30):
         """Full alignments -> dict of arrays: ops / q_aln / t_aln (flat uint8), off (P+1, int64: pair p's columns are
         [off[p], off[p+1])), op_len, n_match, score.  Pairs are processed in groups whose direction bytes fit `max_trace_bytes`."""
         L = _hip.lib()
-        pq, pt = np.ascontiguousarray(pair_q, dtype=np.int32), np.ascontiguousarray(pair_t, dtype=np.int32)
-        P = len(pq)
+        pq0, pt0 = np.asarray(pair_q, dtype=np.int32), np.asarray(pair_t, dtype=np.int32)
+        P = len(pq0)
+        order = self._by_cost(pq0, pt0) if P else np.zeros(0, np.int64)
+        pq, pt = np.ascontiguousarray(pq0[order]), np.ascontiguousarray(pt0[order])
         parts = []
         cost = (self.seq_len[pt].astype(np.int64) + 63) // 64 * (self.seq_len[pq].astype(np.int64) + 64) * 64
         p0 = 0
@@ -190,11 +201,18 @@ class _PairBatch:
             parts.append((ops[idx], qa[idx], ta[idx], op_len, n_match, score))
             p0 = p1
         cat = lambda k, dt: np.concatenate([p[k] for p in parts]) if parts else np.zeros(0, dt)  # noqa: E731
-        op_len = cat(3, np.int32)
+        # back to the caller's pair order: per-pair arrays by inverse permutation, the flat column arrays by a gather
+        len_s = cat(3, np.int32)
+        off_s = np.zeros(P + 1, dtype=np.int64)
+        np.cumsum(len_s, out=off_s[1:])
+        inv = np.empty(P, dtype=np.int64)
+        inv[order] = np.arange(P)
+        op_len = len_s[inv]
         off = np.zeros(P + 1, dtype=np.int64)
         np.cumsum(op_len, out=off[1:])
-        return {"ops": cat(0, np.uint8), "q_aln": cat(1, np.uint8), "t_aln": cat(2, np.uint8), "off": off, "op_len": op_len,
-                "n_match": cat(4, np.int32), "score": cat(5, np.int32)}
+        src = np.repeat(off_s[:-1][inv] - off[:-1], op_len) + np.arange(int(off[-1]), dtype=np.int64)
+        return {"ops": cat(0, np.uint8)[src], "q_aln": cat(1, np.uint8)[src], "t_aln": cat(2, np.uint8)[src], "off": off, "op_len": op_len,
+                "n_match": cat(4, np.int32)[inv], "score": cat(5, np.int32)[inv]}
 
 
 def _identity(n_match, op_len):
