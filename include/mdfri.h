@@ -234,7 +234,8 @@ int mdf_seq_encode_dev(const char *seqs, const int32_t *seq_off, const int32_t *
  * q_aln/t_aln: packed alignment bytes, protein p at [aln_off[p], aln_off[p+1]).
  * max_len: the longest query (max Lq) of the batch -- sizes the per-row contact-bit words of the workspace.
  * Outputs: rowptr (R+1) int32, colidx/val (nnz_cap) with colidx as GLOBAL row numbers.
- * status: device int32[4], zero-initialised by the caller: [0] != 0 -> CSR overflow (needed nnz in [1]).
+ * status: device int32[4], zero-initialised by the caller: [0] != 0 -> CSR overflow (needed nnz in [1]); [2] != 0 -> a query
+ * longer than max_len was met (its length in [2]): the result of that protein is invalid.
  * seq_idx / letter_sums (both or neither): with the residue indices of mdf_seq_encode_dev given, the layer-1 operand of
  * mdf_gcn_embed_dev (see mdf_letter_sums_dev) is written in the same pass as the CSR -- (R, 32) f32.
  * The coordinates are read ONCE: a first kernel counts every row's contacts and stores the contact bits, the CSR is filled

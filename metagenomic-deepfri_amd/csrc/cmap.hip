@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
                     if (lane == r) my_mask = mask;
                 }
             }
-            if (MODE == CM_COUNT && lane < 8 && i_first + lane < Lq) masks[(int64_t)(row0 + wid * 8 + lane) * W + (j0 >> 6)] = my_mask;
+            if (MODE == CM_COUNT && lane < 8 && i_first + lane < Lq && (j0 >> 6) < W)   // (a protein longer than max_len is flagged by k_cmap_fill)
+                masks[(int64_t)(row0 + wid * 8 + lane) * W + (j0 >> 6)] = my_mask;
         }
         if (MODE == CM_COUNT && lane == 0) {
 #pragma unroll
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
                                                    const int32_t *__restrict__ counts, const int32_t *__restrict__ group_base,
                                                    const unsigned long long *__restrict__ masks, int W, int32_t *__restrict__ rowptr,
                                                    int32_t *__restrict__ colidx, float *__restrict__ val, int64_t nnz_cap,
-                                                   const uint8_t *__restrict__ seq_idx, float *__restrict__ letter_sums)
+                                                   const uint8_t *__restrict__ seq_idx, float *__restrict__ letter_sums,
+                                                   int32_t *__restrict__ status)
 {
     // Work item = one 64-bit contact word (row, word index): a wave's 8 rows x Wp words are spread over its lanes, so the
     // serial part of a lane is only the handful of set bits of ITS word.  Letter sums go through per-row LDS bins, visited in
@@ -419,7 +421,11 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
     const int p = find_protein(row_off, B, row0);
     const int r0 = row_off[p], Lq = Lq_arr[p];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int Wp = (Lq + 63) >> 6;
+    int Wp = (Lq + 63) >> 6;
+    if (Wp > W) {   // the caller's max_len is smaller than this protein: stay inside the bit rows and say so (status[2])
+        if (threadIdx.x == 0) status[2] = Lq;
+        Wp = W;
+    }
     const int wrow0 = row0 + wid * 8;
     int run = group_base[g];
     for (int r = 0; r < wid * 8; ++r) run += counts[row0 + r];
@@ -907,7 +913,7 @@ int mdf_cmap_csr_dev(const float *coords, const int32_t *coord_off, const char *
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
     // ... then the CSR (and the layer-1 letter sums) from the bits
     hipLaunchKernelGGL(k_cmap_fill, dim3(G), dim3(256), 0, st, Lq, row_off, B, (const int32_t *)w.counts, (const int32_t *)w.group_base,
-                       (const unsigned long long *)w.masks, W, rowptr, colidx, val, nnz_cap, seq_idx, letter_sums);
+                       (const unsigned long long *)w.masks, W, rowptr, colidx, val, nnz_cap, seq_idx, letter_sums, status);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }

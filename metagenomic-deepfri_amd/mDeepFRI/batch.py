@@ -575,6 +575,8 @@ class HotPathEngine:
         per-call API raises.  Chunks hold consecutive proteins, so the first flagged chunk carries the first invalid byte of
         the whole batch: what the reference's serial loop would have hit first (predict.pyx:36-46)."""
         first_invalid_residue(packed, bad)
+        if (st[:, 2] != 0).any():
+            raise ValueError(f"a query of length {int(st[:, 2].max())} exceeds the max_len the contact stage was given")
         if (st[:, 0] != 0).any():
             need = int(st[:, 1].max())
             raise _hip.CapacityError(_hip.MDF_ECAPACITY,

@@ -236,3 +236,30 @@ def test_batched_build_align_contact_maps_matches_per_call():
         if a.coords is not None:
             assert cm.dtype == np.int32
             assert np.array_equal(cm, orc.build_align_contact_map(a.coords, a.gapped_sequence, a.gapped_target, 6.0, 2))
+
+
+def test_csr_stage_flags_a_query_longer_than_max_len():
+    """mdf_cmap_csr_dev sizes its contact-bit rows from `max_len`; a longer query must neither write out of its rows nor pass
+    silently: status[2] carries its length."""
+    import ctypes
+    import torch
+    from mDeepFRI import _hip
+    from mDeepFRI.batch import DeviceBatch, PackedProteins, _p
+    L = _hip.lib()
+    prots = synthetic.synthetic_proteins(seed=3, count=2, length=200)
+    pk = PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots], [p["t_aln"] for p in prots])
+    dev = torch.device("cuda:0")
+    db = DeviceBatch(pk, dev)
+    ch = pk.chunks[0]
+    R = ch.rows
+    for max_len, expect in ((200, 0), (100, 200)):
+        ws = torch.empty(L.mdf_cmap_workspace_bytes(2, R, max_len), dtype=torch.uint8, device=dev)
+        rowptr = torch.empty(R + 1, dtype=torch.int32, device=dev)
+        colidx = torch.empty(R * 40, dtype=torch.int32, device=dev)
+        val = torch.empty(R * 40, dtype=torch.float32, device=dev)
+        status = torch.zeros(4, dtype=torch.int32, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _hip.check(L.mdf_cmap_csr_dev(_p(db.coords), _p(db.coord_off), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off), _p(db.Lq), _p(db.chunk_row_off), 2, R,
+                                      max_len, 6.0, 2, _p(rowptr), _p(colidx), _p(val), R * 40, _p(status), None, None, _p(ws), ws.numel(), st))
+        torch.cuda.synchronize()
+        assert int(status[2].item()) == expect and int(status[0].item()) == 0
