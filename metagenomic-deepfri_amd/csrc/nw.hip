@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
     const int n_steps = Lq + 63;
     for (int k = coop ? wid : 0; k < n_strips; k += coop ? 4 : 1) {
         const int j = (k << 6) + lane;                 // my column: target residue j, DP column j + 1
-        const int tc = j < Lt ? (int)t[j] : 0;
+        const int tc = j < Lt ? min((int)t[j], NW_LDA - 1) : 0;   // (codes are validated by the host entry points; clamped so that a bad one cannot index outside the table)
         int up = -(go + j * ge);                       // H[0][j+1]
         int fup = NW_NEG;                              // F[0][j+1]
         int diag = j == 0 ? 0 : -(go + (j - 1) * ge);  // H[0][j]
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
         for (int s0 = 0; s0 < n_steps; s0 += 64) {
             // this chunk's rows for lane 0: query residues and the boundary column
             const int r = s0 + lane;
-            const int qchunk = r < Lq ? (int)q[r] : 0;
+            const int qchunk = r < Lq ? min((int)q[r], NW_LDA - 1) : 0;
             int hbchunk, ebchunk;
             if (k == 0) {
                 hbchunk = -(go + r * ge);              // H[r+1][0]
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
                 const int sc = sc_cur;
                 // shift the query residues for the next step and start its score lookup (the last step of a chunk needs the
                 // next chunk's first residue: fetched directly, it is a wave-uniform byte)
-                const int q_in = (u + 1 < 64) ? __builtin_amdgcn_readlane(qchunk, (u + 1) & 63) : (s + 1 < Lq ? (int)q[s + 1] : 0);
+                const int q_in = (u + 1 < 64) ? __builtin_amdgcn_readlane(qchunk, (u + 1) & 63) : (s + 1 < Lq ? min((int)q[s + 1], NW_LDA - 1) : 0);
                 qc_next = wave_shr1(qc, q_in);
                 sc_cur = s_S[qc_next * NW_LDA + tc];
                 const int i = s - lane;                // my row: query residue i, DP row i + 1
