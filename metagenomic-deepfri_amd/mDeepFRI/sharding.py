@@ -58,18 +58,22 @@ class DenseGatherPlan:
     input order.  `run(block)` is then: copy into the payload, ONE dist.gather, one index_copy_ -- no host sync, no
     Python loop over proteins or ranks' rows (bench.py keeps the plan across steps)."""
 
-    def __init__(self, n_local: int, width: int, local_index, total: int, device, dtype=None, dst: int = 0, group=None):
+    def __init__(self, n_local: int, width: int, local_index, total: int, device, dtype=None, dst: int = 0, group=None,
+                 collectives_for_one_rank: bool = False):
+        """collectives_for_one_rank: testing aid -- issue the real collectives even in a one-rank group (exercises the RCCL calls
+        on a single-GPU box, where two ranks cannot share the device)."""
         import torch
         import torch.distributed as dist
         self.dst, self.group, self.total, self.width = dst, group, int(total), int(width)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.single = self.world == 1 and not (collectives_for_one_rank and dist.is_initialized())
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         dtype = dtype or torch.float32
         self.via_host = self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
         dev = torch.device("cpu") if self.via_host else torch.device(device)   # gloo has no device gather; RCCL gathers in HBM
         self.dev, self.n_local = dev, int(n_local)
         idx = torch.as_tensor(np.asarray(list(local_index), dtype=np.int64), device=dev)
-        if self.world == 1:
+        if self.single:
             self.order = idx
             self.out = torch.empty((self.total, self.width), dtype=dtype, device=dev)
             return
@@ -97,7 +101,7 @@ class DenseGatherPlan:
         """block: (n_local, width) scores of this rank.  Returns the (total, width) tensor in input order on `dst`, None
         elsewhere.  Asynchronous on the device for the nccl backend."""
         import torch.distributed as dist
-        if self.world == 1:
+        if self.single:
             self.out.index_copy_(0, self.order, block.to(self.dev))
             return self.out
         if self.n_local:
@@ -115,17 +119,19 @@ class FilteredGatherPlan:
     rank's survivors outgrow them (flagged by the sizes exchanged on the device, re-planned on the next call).
     Output as gather_filtered: (offsets (total+1) int32, term_idx, kept) in input order on `dst`."""
 
-    def __init__(self, local_index, total: int, device, dst: int = 0, group=None):
+    def __init__(self, local_index, total: int, device, dst: int = 0, group=None, collectives_for_one_rank: bool = False):
         import torch
         import torch.distributed as dist
         self.dst, self.group, self.total = dst, group, int(total)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.single = self.world == 1 and not (collectives_for_one_rank and dist.is_initialized())
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.via_host = self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
         self.dev = torch.device("cpu") if self.via_host else torch.device(device)
         self.local_index = list(local_index)
         self.z_cap = 0
-        self.dense = DenseGatherPlan(len(self.local_index), 1, self.local_index, total, self.dev, dtype=torch.int64, dst=dst, group=group)
+        self.dense = DenseGatherPlan(len(self.local_index), 1, self.local_index, total, self.dev, dtype=torch.int64, dst=dst, group=group,
+                                     collectives_for_one_rank=collectives_for_one_rank)
 
     def run(self, offsets, term_idx, kept, sizes_may_change: bool = True):
         """sizes_may_change=True (default, always safe): every call agrees on the padded payload size with one tiny all-reduce and
@@ -136,7 +142,7 @@ class FilteredGatherPlan:
         import torch.distributed as dist
         cnt = (offsets[1:] - offsets[:-1]).to(torch.int64).to(self.dev)
         term_idx, kept = term_idx.to(self.dev), kept.to(self.dev)
-        if self.world == 1:
+        if self.single:
             counts = self.dense.run(cnt.reshape(-1, 1)).reshape(-1)
             goff = torch.zeros(self.total + 1, dtype=torch.int64, device=self.dev)
             torch.cumsum(counts, 0, out=goff[1:])

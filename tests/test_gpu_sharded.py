@@ -167,3 +167,48 @@ def test_configs3_shape_512_mixed_proteins_two_ranks():
     for i in (0, 200, 511):
         cm = orc.build_align_contact_map(coords[i], q_alns[i], t_alns[i], 6.0, 2)
         assert np.max(np.abs(sharded[i] - gcn_oracle.gcn_forward(w, seqs[i], cm))) < 1e-4
+
+
+def _worker_rccl_one_rank(q):
+    """One-rank RCCL group on the one GPU of the box (two ranks cannot share a device: 'Duplicate GPU detected'), with the plans
+    told to issue their collectives anyway: the actual RCCL calls of the multi-GPU path -- all_reduce of the shard sizes, gather of
+    int64 indices, float32 payloads and int32 terms into device buffers, barrier -- run for real."""
+    import torch
+    import torch.distributed as dist
+    from mDeepFRI import sharding
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        g = torch.Generator(device="cpu").manual_seed(1)
+        block = torch.rand((37, 11), generator=g).to(dev)
+        order = torch.randperm(37, generator=g).tolist()
+        plan = sharding.DenseGatherPlan(37, 11, order, 37, dev, collectives_for_one_rank=True)
+        assert not plan.single and plan.world == 1
+        for k in (1, 2):
+            out = plan.run(block * k)
+            torch.cuda.synchronize()
+            assert torch.equal(out[order], block * k)
+        off = torch.tensor([0, 2, 2, 5], dtype=torch.int32, device=dev)
+        ti = torch.tensor([5, 1, 9, 3, 4], dtype=torch.int32, device=dev)
+        sc = torch.tensor([0.9, 0.5, 0.3, 0.2, 0.15], device=dev)
+        fplan = sharding.FilteredGatherPlan([2, 0, 1], 3, dev, collectives_for_one_rank=True)
+        for flag in (True, False):
+            goff, gt, gs = fplan.run(off, ti, sc, sizes_may_change=flag)
+            assert goff.tolist() == [0, 0, 3, 5] and gt.tolist() == [9, 3, 4, 5, 1] and gs.is_cuda
+        dist.barrier()
+        q.put("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_of_the_gather_plans_on_one_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_rccl_one_rank, args=(q,))
+    p.start()
+    assert q.get(timeout=600) == "ok"
+    p.join(timeout=120)
+    assert p.exitcode == 0
