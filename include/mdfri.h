@@ -312,9 +312,11 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
  * codes[seq_off[s] .. seq_off[s] + seq_len[s]).  A pair p aligns query sequence pair_q[p] with target sequence pair_t[p].
  * matrix: (A, A) int32 row-major, matrix[q][t].  A gap of length n costs gap_open + (n - 1) * gap_extend (Opal's model).
  * Operations: 'M' match, 'X' mismatch, 'D' query residue against a target gap, 'I' target residue against a query gap --
- * the letters reference insert_gaps (alignment.py:38-62) consumes.  Co-optimal alignments are resolved as stated in
- * oracle/nw_oracle.c (diagonal >= 'D' >= 'I'; opening a gap wins a tie against extending one); integer work, bit-exact
- * with that oracle.  PyOpal itself is not available offline: parity with it is unpinned.
+ * the letters reference insert_gaps (alignment.py:38-62) consumes.  Which of several CO-OPTIMAL alignments is returned is set
+ * by `tie_rule` (3 bits; oracle/nw_oracle.c): bit 0 = at H a gap move wins a tie against the diagonal, bit 1 = 'I' wins a tie
+ * against 'D', bit 2 = extending a gap wins a tie against opening one; 0 (diagonal, then 'D', then 'I'; opening first) is the
+ * default.  Integer work, bit-exact with that oracle for every rule.  PyOpal itself is not available offline: which rule
+ * reproduces Opal's traceback is unpinned -- scores, best hits and unique optima do not depend on it.
  * ---------------------------------------------------------------------------------------------- */
 
 /* Host helper: per-pair offsets into the three per-pair buffers, P + 1 entries each (entry P = total; any may be NULL):
@@ -338,8 +340,8 @@ int mdf_nw_score_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t
  * layout) receive the gapped query / target strings spelled with `alphabet` (A letters, device) -- what insert_gaps would
  * build.  n_match[p] = number of 'M' (identity = n_match / op_len, alignment.py:214); coverages of a global alignment are 1. */
 int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t,
-                     int32_t P, int32_t n_long, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet,
-                     const int64_t *bnd_off, int32_t *bnd, const int64_t *trace_off, uint8_t *trace, const int64_t *ops_off, char *ops, char *q_aln,
+                     int32_t P, int32_t n_long, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int tie_rule,
+                     const char *alphabet, const int64_t *bnd_off, int32_t *bnd, const int64_t *trace_off, uint8_t *trace, const int64_t *ops_off, char *ops, char *q_aln,
                      char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores, void *stream);
 
 /* The same with host buffers (upload, run, download): n_seq sequences, P pairs; ops / q_aln / t_aln hold sum(Lq + Lt) bytes
@@ -347,8 +349,8 @@ int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t
 int mdf_nw_score_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
                       const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int32_t *scores);
 int mdf_nw_align_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
-                      const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet,
-                      char *ops, char *q_aln, char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores);
+                      const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int tie_rule,
+                      const char *alphabet, char *ops, char *q_aln, char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores);
 
 /* Timing hook for bench.py: mdf_timing_enable(n), n = 0 off, n >= 1: the library brackets every n-th launch of each
  * kernel class with hipEvents on the stream it is launched on and accumulates count and milliseconds of the sampled

@@ -13,7 +13,8 @@
 // kernel walks back from the corner, one thread per pair, writing the operations (and the gapped strings) back to front.
 //
 // Recurrences and tie rules are those of oracle/nw_oracle.c (Opal's published model: a gap of length n costs
-// open + (n-1)*extend; at H diagonal >= vertical >= horizontal; inside a gap opening wins a tie) -- bit-exact integer work.
+// open + (n-1)*extend; ties among co-optimal alignments resolved by the 3-bit `tie_rule` defined there, default 0: at H diagonal >=
+// vertical >= horizontal, inside a gap opening wins) -- bit-exact integer work.
 // PARITY UNPINNED against PyOpal itself (absent offline), see the oracle's header.
 #include <algorithm>
 #include <cstdlib>
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
                                             const int32_t *__restrict__ pair_t, int P, const int32_t *__restrict__ matrix, int A,
                                             int go, int ge, const int64_t *__restrict__ bnd_off, int32_t *bnd,
                                             const int64_t *__restrict__ trace_off, uint8_t *__restrict__ trace,
-                                            int32_t *__restrict__ scores, int n_long)
+                                            int32_t *__restrict__ scores, int n_long, int tie_rule)
 {
     // Pairs [0, n_long) are LONG: one whole workgroup per pair, wave w sweeps strips w, w+4, ... and may enter a 64-row chunk of
     // strip k as soon as strip k-1 has published the boundary values of those rows (s_prog, LDS) -- the strips of one matrix
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
         s_S[e] = (r < A && c < A) ? matrix[r * A + c] : 0;
     }
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool gap_first = tie_rule & 1, horiz_first = tie_rule & 2, ext_first = tie_rule & 4;   // see oracle/nw_oracle.c
     const bool coop = (int)blockIdx.x < n_long;
     if (coop)
         for (int e = threadIdx.x; e < NW_MAX_COOP_STRIPS; e += blockDim.x) s_prog[e] = 0;
@@ -128,12 +130,22 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
                 const int e_open = left - go, e_ext = eleft - ge;
                 const int f_open = up - go, f_ext = fup - ge;
                 int code = 0;
-                int e = e_open, f = f_open;
-                if (e_ext > e_open) { e = e_ext; code |= 4; }
-                if (f_ext > f_open) { f = f_ext; code |= 8; }
-                int h = diag + sc;
-                if (f > h) { h = f; code |= 1; }
-                if (e > h) { h = e; code = (code & ~3) | 2; }
+                int e, f, h;
+                if (TRACE) {   // the values are maxima whatever the tie rule says; only the recorded directions depend on it
+                    e = e_open, f = f_open;
+                    if (e_ext > e_open || (ext_first && e_ext == e_open)) { e = e_ext; code |= 4; }
+                    if (f_ext > f_open || (ext_first && f_ext == f_open)) { f = f_ext; code |= 8; }
+                    int src = 0;
+                    h = diag + sc;
+                    const int g1 = horiz_first ? e : f, g2 = horiz_first ? f : e;
+                    if (g1 > h || (gap_first && g1 == h)) { h = g1; src = horiz_first ? 2 : 1; }
+                    if (g2 > h || (gap_first && g2 == h && src == 0)) { h = g2; src = horiz_first ? 1 : 2; }
+                    code |= src;
+                } else {
+                    e = max(e_open, e_ext);
+                    f = max(f_open, f_ext);
+                    h = max(max(diag + sc, f), e);
+                }
                 // state moves on only for lanes inside the matrix (selects, no branches)
                 diag = active ? left : diag;
                 up = active ? h : up;
@@ -287,22 +299,23 @@ int mdf_nw_score_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t
     MDF_REQUIRE(n_long >= 0 && n_long <= P, "nw_score_dev: n_long=%d not in 0..P", n_long);
     hipLaunchKernelGGL(k_nw<false>, dim3((unsigned)(n_long + (P - n_long + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), codes, seq_off,
                        seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, bnd_off, bnd, (const int64_t *)nullptr, (uint8_t *)nullptr,
-                       scores, n_long);
+                       scores, n_long, 0);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
 
 int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t,
-                     int32_t P, int32_t n_long, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet,
+                     int32_t P, int32_t n_long, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int tie_rule, const char *alphabet,
                      const int64_t *bnd_off, int32_t *bnd, const int64_t *trace_off, uint8_t *trace, const int64_t *ops_off, char *ops, char *q_aln,
                      char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores, void *stream)
 {
+    MDF_REQUIRE(tie_rule >= 0 && tie_rule < 8, "nw_align_dev: tie_rule=%d not in 0..7", tie_rule);
     if (int rc = nw_check(codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend)) return rc;
     MDF_REQUIRE(alphabet && bnd_off && bnd && trace_off && trace && ops_off && ops && op_len && n_match && scores, "nw_align_dev: NULL argument");
     MDF_REQUIRE(n_long >= 0 && n_long <= P, "nw_align_dev: n_long=%d not in 0..P", n_long);
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_nw<true>, dim3((unsigned)(n_long + (P - n_long + 3) / 4)), dim3(256), 0, st, codes, seq_off, seq_len, pair_q, pair_t, P,
-                       matrix, A, gap_open, gap_extend, bnd_off, bnd, trace_off, trace, scores, n_long);
+                       matrix, A, gap_open, gap_extend, bnd_off, bnd, trace_off, trace, scores, n_long, tie_rule);
     hipLaunchKernelGGL(k_nw_traceback, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, st, codes, seq_off, seq_len, pair_q, pair_t, P, trace_off,
                        (const uint8_t *)trace, ops_off, alphabet, ops, q_aln, t_aln, op_len, n_match);
     MDF_HIP(hipGetLastError());
@@ -311,7 +324,7 @@ int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t
 
 // Host-buffer forms (the per-call shape of alignment.py:164-221): upload, run, download.  n_seq sequences, P pairs.
 static int nw_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
-                   const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int go, int ge, const char *alphabet, char *ops,
+                   const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int go, int ge, int tie_rule, const char *alphabet, char *ops,
                    char *q_aln, char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores, bool full)
 {
     if (int rc = nw_check(codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, go, ge)) return rc;
@@ -369,7 +382,7 @@ static int nw_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *
         MDF_HIP(hipMemcpy(b + o_to, to.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice));
         MDF_HIP(hipMemcpy(b + o_oo, oo.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice));
         rc = mdf_nw_align_dev((const uint8_t *)D(o_codes), (const int64_t *)D(o_soff), (const int32_t *)D(o_slen), (const int32_t *)D(o_pq),
-                              (const int32_t *)D(o_pt), P, n_long, (const int32_t *)D(o_mat), A, go, ge, D(o_al), (const int64_t *)D(o_bo),
+                              (const int32_t *)D(o_pt), P, n_long, (const int32_t *)D(o_mat), A, go, ge, tie_rule, D(o_al), (const int64_t *)D(o_bo),
                               (int32_t *)D(o_bnd), (const int64_t *)D(o_to), (uint8_t *)D(o_tr), (const int64_t *)D(o_oo), D(o_ops),
                               q_aln ? D(o_qa) : nullptr, t_aln ? D(o_ta) : nullptr, (int32_t *)D(o_ol), (int32_t *)D(o_nm), (int32_t *)D(o_sc),
                               nullptr);
@@ -391,15 +404,16 @@ static int nw_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *
 int mdf_nw_score_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
                       const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int32_t *scores)
 {
-    return nw_host(codes, seq_off, seq_len, n_seq, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, nullptr, nullptr, nullptr, nullptr, nullptr,
+    return nw_host(codes, seq_off, seq_len, n_seq, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, 0, nullptr, nullptr, nullptr, nullptr, nullptr,
                    nullptr, scores, false);
 }
 
 int mdf_nw_align_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
-                      const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, const char *alphabet,
-                      char *ops, char *q_aln, char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores)
+                      const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int tie_rule,
+                      const char *alphabet, char *ops, char *q_aln, char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores)
 {
-    return nw_host(codes, seq_off, seq_len, n_seq, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, alphabet, ops, q_aln, t_aln, op_len, n_match,
+    MDF_REQUIRE(tie_rule >= 0 && tie_rule < 8, "nw_align_host: tie_rule=%d not in 0..7", tie_rule);
+    return nw_host(codes, seq_off, seq_len, n_seq, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, tie_rule, alphabet, ops, q_aln, t_aln, op_len, n_match,
                    scores, true);
 }
 

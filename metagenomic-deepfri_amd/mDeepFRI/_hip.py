@@ -118,10 +118,10 @@ SIGNATURES = {
     "mdf_nw_count_long": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32]),
     "mdf_nw_score_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int, c_int, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
-    "mdf_nw_align_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int, c_int, c_void_p, c_void_p,
+    "mdf_nw_align_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdf_nw_score_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_void_p]),
-    "mdf_nw_align_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_char_p,
+    "mdf_nw_align_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_int, c_char_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "mdf_timing_enable": (c_int, [c_int]),
     "mdf_timing_read": (c_int, [c_char_p, _i64p, POINTER(c_double)]),

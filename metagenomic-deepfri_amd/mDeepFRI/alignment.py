@@ -166,7 +166,7 @@ class _PairBatch:
             out[order] = sc
         return out
 
-    def align(self, pair_q, pair_t, gap_open, gap_extend, max_trace_bytes: int = 4 << 30):
+    def align(self, pair_q, pair_t, gap_open, gap_extend, max_trace_bytes: int = 4 << 30, tie_rule: int = 0):
         """Full alignments -> dict of arrays: ops / q_aln / t_aln (flat uint8), off (P+1, int64: pair p's columns are
         [off[p], off[p+1])), op_len, n_match, score.  Pairs are processed in groups whose direction bytes fit `max_trace_bytes`."""
         L = _hip.lib()
@@ -190,7 +190,7 @@ class _PairBatch:
             ops, qa, ta = (np.empty(cap, dtype=np.uint8) for _ in range(3))
             op_len, n_match, score = (np.empty(n, dtype=np.int32) for _ in range(3))
             _hip.check(L.mdf_nw_align_host(_hip.ptr(self.codes), _hip.ptr(self.seq_off), _hip.ptr(self.seq_len), len(self.seq_len), _hip.ptr(q_),
-                                           _hip.ptr(t_), n, _hip.ptr(self.sm.matrix), len(self.sm.alphabet), int(gap_open), int(gap_extend),
+                                           _hip.ptr(t_), n, _hip.ptr(self.sm.matrix), len(self.sm.alphabet), int(gap_open), int(gap_extend), int(tie_rule),
                                            self.sm.alphabet.encode("ascii"), _hip.ptr(ops), _hip.ptr(qa), _hip.ptr(ta), _hip.ptr(op_len),
                                            _hip.ptr(n_match), _hip.ptr(score)))
             # compact: every pair's columns sit right-aligned in its capacity [ops_off[p], ops_off[p+1])
@@ -233,11 +233,14 @@ def best_hit_database(query, target_sequences, gap_open: int = 10, gap_extend: i
     return keys[best], targets[best]
 
 
-def align_pairwise(query, target, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80"):
+TIE_RULE = 0   # which co-optimal alignment is returned (3 bits, see include/mdfri.h / oracle/nw_oracle.c); PyOpal's choice is unpinned
+
+
+def align_pairwise(query, target, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80", tie_rule: int | None = None):
     """reference alignment.py:198-221 -> (alignment string, identity, query coverage, target coverage)."""
     sm = _matrix(scoring_matrix)
     pb = _PairBatch([_upper(query), _upper(target)], sm)
-    r = pb.align([0], [1], gap_open, gap_extend)
+    r = pb.align([0], [1], gap_open, gap_extend, tie_rule=TIE_RULE if tie_rule is None else tie_rule)
     return bytes(r["ops"]).decode(), _identity(r["n_match"][0], r["op_len"][0]), 1.0, 1.0   # a global alignment covers both sequences
 
 
@@ -313,7 +316,7 @@ def align_queries_arrays(query_ids, query_sequences, target_sequences, gap_open:
     best_pair = np.minimum.reduceat(pos, first[:-1])
     best = (best_pair - first[:-1]).astype(np.int64)
     bt = np.asarray(pair_t, dtype=np.int32)[best_pair]
-    res = pb.align(np.arange(nq, dtype=np.int32), bt, gap_open, gap_extend)
+    res = pb.align(np.arange(nq, dtype=np.int32), bt, gap_open, gap_extend, tie_rule=TIE_RULE)
     if not np.array_equal(res["score"], seg_max):
         raise RuntimeError("internal error: full-alignment score differs from the score-mode score")
     return AlignedBatch(query_ids, qs, [keys[q][int(b)] for q, b in enumerate(best)], [_upper(seqs[int(j)]) for j in bt], best, res)

@@ -18,9 +18,13 @@
  *     - identity = matches / alignment length, coverage = (end - start + 1) / length (always 1 for a global alignment).
  * What anchors it in the reference: tests/test_alignment.py:24-36 (best hit "seq3" = the FIRST of two equal maxima;
  * align_pairwise -> "MMMMMMMMMXMMMM...X", identity 0.93, query coverage 1.0), reproduced by tests/test_nw_oracle_cpu.py.
- * What stays open: which of several co-optimal alignments Opal's traceback returns.  THIS build's rule, stated once and
- * used identically by the HIP kernels (csrc/nw.hip):
- *     at H: diagonal (M/X) >= vertical (D) >= horizontal (I);   inside a gap: opening is preferred to extending on a tie.
+ * What stays open: which of several co-optimal alignments Opal's traceback returns.  The choice is a PARAMETER (`tie_rule`,
+ * three bits, identical semantics here and in the HIP kernels of csrc/nw.hip), so that it can be set to Opal's behaviour the
+ * day PyOpal can be run next to this code, without touching a kernel:
+ *     bit 0 (1): at H, a gap move wins a tie against the diagonal          (default 0: diagonal M/X first)
+ *     bit 1 (2): the horizontal move 'I' wins a tie against the vertical 'D' (default 0: 'D' first)
+ *     bit 2 (4): inside a gap, extending wins a tie against opening          (default 0: opening first)
+ * Scores, identities of unique optima and the best-hit choice do not depend on it.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -67,8 +71,9 @@ int32_t nwo_score(const uint8_t *q, int32_t Lq, const uint8_t *t, int32_t Lt, co
 /* Full alignment (alignment.py:211-219, mode="full").  ops: caller buffer of Lq + Lt bytes, receives the operations in
  * alignment order; returns their number.  *score, *n_match optional.  Tie rules: see the header. */
 int32_t nwo_align(const uint8_t *q, int32_t Lq, const uint8_t *t, int32_t Lt, const int32_t *S, int32_t A, int32_t go, int32_t ge,
-                  char *ops, int32_t *score, int32_t *n_match)
+                  int32_t tie_rule, char *ops, int32_t *score, int32_t *n_match)
 {
+    const int gap_first = tie_rule & 1, horiz_first = (tie_rule >> 1) & 1, ext_first = (tie_rule >> 2) & 1;
     const size_t W = (size_t)Lt + 1;
     uint8_t *tr = (uint8_t *)malloc((size_t)(Lq + 1) * W);   /* bits 0-1: source of H (0 diag, 1 vertical, 2 horizontal); 2: E extended; 3: F extended */
     int32_t *H = (int32_t *)malloc(W * sizeof(int32_t));
@@ -89,12 +94,16 @@ int32_t nwo_align(const uint8_t *q, int32_t Lq, const uint8_t *t, int32_t Lt, co
             const int32_t f_open = H[j] - go, f_ext = F[j] - ge;
             uint8_t code = 0;
             e = e_open;
-            if (e_ext > e_open) { e = e_ext; code |= 4; }
+            if (e_ext > e_open || (ext_first && e_ext == e_open)) { e = e_ext; code |= 4; }
             int32_t f = f_open;
-            if (f_ext > f_open) { f = f_ext; code |= 8; }
+            if (f_ext > f_open || (ext_first && f_ext == f_open)) { f = f_ext; code |= 8; }
             int32_t h = diag + Sr[t[j - 1]];
-            if (f > h) { h = f; code |= 1; }
-            if (e > h) { h = e; code = (uint8_t)((code & ~3) | 2); }
+            int src = 0;
+            const int32_t g1 = horiz_first ? e : f, g2 = horiz_first ? f : e;
+            const int id1 = horiz_first ? 2 : 1, id2 = horiz_first ? 1 : 2;
+            if (g1 > h || (gap_first && g1 == h)) { h = g1; src = id1; }
+            if (g2 > h || (gap_first && g2 == h && src == 0)) { h = g2; src = id2; }
+            code |= (uint8_t)src;
             diag = H[j];
             H[j] = h;
             F[j] = f;

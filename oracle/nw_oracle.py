@@ -21,7 +21,7 @@ def lib():
         L = ctypes.CDLL(_SO)
         common = [_u8p, ctypes.c_int32, _u8p, ctypes.c_int32, _i32p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
         L.nwo_score.argtypes, L.nwo_score.restype = common, ctypes.c_int32
-        L.nwo_align.argtypes, L.nwo_align.restype = common + [ctypes.c_char_p, _i32p, _i32p], ctypes.c_int32
+        L.nwo_align.argtypes, L.nwo_align.restype = common + [ctypes.c_int32, ctypes.c_char_p, _i32p, _i32p], ctypes.c_int32
         L.nwo_score_of_ops.argtypes, L.nwo_score_of_ops.restype = common + [ctypes.c_char_p, ctypes.c_int32], ctypes.c_int32
         _lib = L
     return _lib
@@ -50,12 +50,12 @@ def nw_score(q, t, matrix, alphabet, gap_open=10, gap_extend=1) -> int:
     return int(lib().nwo_score(*a))
 
 
-def align_pairwise(q, t, matrix, alphabet, gap_open=10, gap_extend=1):
+def align_pairwise(q, t, matrix, alphabet, gap_open=10, gap_extend=1, tie_rule=0):
     """alignment.py:198-221 -> (alignment string, identity, query coverage, target coverage); plus the score."""
     *keep, a = _args(q, t, matrix, alphabet, gap_open, gap_extend)
     ops = ctypes.create_string_buffer(len(q) + len(t) + 1)
     score, nm = ctypes.c_int32(0), ctypes.c_int32(0)
-    n = lib().nwo_align(*a, ops, ctypes.byref(score), ctypes.byref(nm))
+    n = lib().nwo_align(*a, int(tie_rule), ops, ctypes.byref(score), ctypes.byref(nm))
     s = ops.raw[:n].decode()
     identity = float(np.float32(nm.value) / np.float32(max(n, 1)))
     return s, identity, 1.0, 1.0, int(score.value)

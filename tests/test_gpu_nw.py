@@ -183,3 +183,18 @@ def test_size_independent_properties_at_scale():
         assert int(full["n_match"][k]) == ops.count("M")
     selfaln = pb.align(idx[:200], idx[:200], 10, 1)
     assert all(bytes(selfaln["ops"][int(selfaln["off"][k]):int(selfaln["off"][k + 1])]) == b"M" * len(seqs[k]) for k in range(200))
+
+
+@pytest.mark.parametrize("tie_rule", range(8))
+def test_every_tie_rule_matches_the_oracle(tie_rule):
+    """Which co-optimal alignment comes back is a parameter (PyOpal's own choice is unpinned): kernels == oracle for all 8 rules,
+    on a low-complexity alphabet with small scores, where ties are everywhere -- incl. a pair large enough for the cooperative
+    (workgroup per pair) sweep."""
+    sm = ScoringMatrix.simple(ALPHA, 2, -1)
+    rng = np.random.default_rng(40 + tie_rule)
+    for lq, lt in [(5, 9), (64, 64), (70, 131), (300, 280), (600, 520)]:
+        q = "".join(rng.choice(list("ARND"), size=lq))
+        t = "".join(rng.choice(list("ARND"), size=lt))
+        ops, iden, _, _ = align_pairwise(q, t, 2, 1, sm, tie_rule=tie_rule)
+        e_ops, e_iden, _, _, e_score = nwo.align_pairwise(q, t, sm.matrix, sm.alphabet, 2, 1, tie_rule)
+        assert ops == e_ops and iden == e_iden, (tie_rule, lq, lt)

@@ -154,3 +154,20 @@ def test_oracle_reproduces_the_committed_golden_vectors(nw_golden):
         ops, iden, _, _, score = nwo.align_pairwise(q, t, sm.matrix, sm.alphabet, go, ge)
         assert ops == gstr(nw_golden[n + "/ops"]) and score == int(nw_golden[n + "/score"]) and iden == float(nw_golden[n + "/identity"]), n
     assert gstr(nw_golden["kat/ops"]) == "MMMMMMMMMXMMMMMMMMMMMMMMMMMMMMMMXMMMMMMMMMMX"
+
+
+@pytest.mark.parametrize("tie_rule", range(8))
+def test_every_tie_rule_returns_an_optimal_alignment(tie_rule):
+    """The 3-bit tie rule only picks AMONG co-optimal alignments: for each of the 8 settings the returned string is a valid global
+    alignment whose score is the optimum; with ties present the settings really differ; rule 0 is the committed default."""
+    sm = ScoringMatrix.simple(ALPHA, 2, -1)          # small integers: many ties
+    rng = np.random.default_rng(17)
+    distinct = set()
+    for _ in range(25):
+        q = "".join(rng.choice(list("ARND"), size=rng.integers(3, 40)))
+        t = "".join(rng.choice(list("ARND"), size=rng.integers(3, 40)))
+        ops, iden, _, _, score = nwo.align_pairwise(q, t, sm.matrix, sm.alphabet, 2, 1, tie_rule)
+        assert score == nwo.nw_score(q, t, sm.matrix, sm.alphabet, 2, 1)
+        assert nwo.score_of_alignment(q, t, ops, sm.matrix, sm.alphabet, 2, 1) == score
+        distinct.add(ops != nwo.align_pairwise(q, t, sm.matrix, sm.alphabet, 2, 1, 0)[0])
+    assert (tie_rule == 0) == (distinct == {False})
