@@ -1,30 +1,43 @@
 // ax_pipe_probe.hip -- EXPERIMENT (not part of libmdfri_hip.so): the LDS-staged A.X as a software pipeline, on REAL adjacency.
-// tools/ax_pipe_probe.py builds the per-group records (distinct neighbour rows of every 32-row group + a stage offset per CSR
-// entry) from the CSR the library produced, runs this kernel and compares with a NumPy product.
+// tools/ax_pipe_probe.py builds the per-group records from the CSR the library produced, runs this kernel and compares with a
+// NumPy product.
 //
-// One persistent workgroup (8 waves) per CU owns consecutive 32-row groups; item = (group, 64-channel slice).  Stage ring of
-// NST slabs: while item i is accumulated from LDS, the neighbour-row slabs of the next NST-1 items are in flight by LDS-DMA.
-// The group records travel by LDS-DMA too (three record slots, fetched two groups ahead), so no vector register ever waits on
-// a global load and the only vmcnt waits are the counted ones below: "item i has landed" is s_waitcnt vmcnt(N) with N = LOADS
-// this wave has issued since item i's last piece (loads return in order; stores are left out of N because they may retire
-// out of order with respect to loads -- leaving them out only makes the wait conservative).
-// A wave accumulates four rows at a time (16 lanes x float4 = 64 channels per row); the (weight, stage offset) pairs of a
-// lane's row sit in registers for the eight items of a group, so the inner loop is independent ds_read_b128 + FMA only.
+// One persistent workgroup (8 waves) per CU owns consecutive 32-row groups; item = (group, 64-channel slice).  The U distinct
+// neighbour rows of a group ("union", mean 65 for 12.7 entries per row) are brought into an LDS stage ONCE per item by LDS-DMA
+// (ring of NST stages: items i+1 .. i+NST-1 are in flight while item i is consumed), instead of 12.7 gathers per row through L1.
+// The group records travel by LDS-DMA too, so no vector register ever waits on a global load and the only vmcnt waits are the
+// counted ones: "item i has landed" is s_waitcnt vmcnt(N) with N = loads this wave has issued since item i's last piece.
+//
+// Accumulation: the 32 x U block of Ahat that belongs to the group is small and dense enough (403 of 32 x 65 entries) to be
+// applied as a dense product on the matrix pipe: out^T (64 ch x 32 rows) = H_u^T (64 x U) . Ahat_g^T (U x 32), one 16 x 16
+// tile per wave (4 channel tiles x 2 row tiles), v_mfma_f32_16x16x4_f32 over k = union slot.  The Ahat operand of a lane
+// (U/4 floats) sits in registers for the eight items of a group, the H operand is one ds_read_b32 per MFMA at a constant
+// offset -- no per-entry address arithmetic, no row-length imbalance (the longest row of a group is 2-4x the mean on
+// random-walk chains and set the pace of every per-row scheme tried before).  The union is in ascending column order and an
+// MFMA is an fp32 FMA chain over k, so a row is summed in the same order as k_aggregate sums it (zero weights add exact zeros).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
 
 #ifndef AXP_ABL
-#define AXP_ABL 0   // timing ablations: 1 = no accumulation, 2 = no DMA, 3 = no stores (results wrong by construction)
+#define AXP_ABL 0   // timing ablations, bit mask: 1 = no accumulation, 2 = no DMA, 4 = no stores, 8 = Ahat operand loaded for the first group only,
+                    // 16 = two MFMA chains (even / odd k-steps) instead of one  (results wrong by construction except 16: other summation order)
 #endif
 #ifndef AXP_NST
 #define AXP_NST 3
 #endif
 #ifndef AXP_UMAX
-#define AXP_UMAX 176
+#define AXP_UMAX 128
+#endif
+#ifndef AXP_GR
+#define AXP_GR 32   // rows per group: 32 (8 waves, one workgroup per CU) or 16 (4 waves, two workgroups per CU when the LDS allows)
+#endif
+#ifndef AXP_WGS
+#define AXP_WGS 256
 #endif
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void glds16(const void *gsrc, unsigned lds_byte_addr)
 {
     unsigned keep;
@@ -46,26 +59,23 @@ __device__ __forceinline__ void wg_barrier()   // raw barrier: LDS traffic of th
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-constexpr int CH = 64, UMAX = AXP_UMAX, EMAX = 1024, NST = AXP_NST, KMAX = 24, NREC = 3;
-struct GroupRec {                // 7 KiB, the same bytes in global memory and in LDS
-    int rp[40];                  // rp[r] = first entry of row r relative to the group's first entry, rp[32] = entry count; rp[33] = U
-    int ucol[176];               // distinct neighbour rows (global row numbers)
-    float eval[EMAX];            // entry weights, CSR order
-    unsigned short eoff[EMAX];   // entry -> byte offset of its neighbour row inside a stage (index into ucol x 256)
-    char pad[7168 - 160 - 4 * 176 - 6 * EMAX];
-};
-static_assert(sizeof(GroupRec) == 7168, "record = seven 1-KiB DMA pieces");
+constexpr int CH = 64, UMAX = AXP_UMAX, NST = AXP_NST, NREC = 2, NJ = UMAX / 4, GR = AXP_GR, NW = GR / 4;
+static_assert(UMAX % 64 == 0, "the k loop is unrolled sixteen MFMAs at a time");
+// group record, the same bytes in global memory and in LDS:  int hdr[16] (hdr[0] = U) | int ucol[UMAX] | float what[UMAX][GR]
+// (what[u][r] = Ahat[row r of the group][union slot u], zero where there is no entry and for u >= U), padded to whole KiB
+constexpr int REC_BYTES = ((64 + 4 * UMAX + 4 * GR * UMAX + 1023) / 1024) * 1024;
+constexpr int REC_PIECES = REC_BYTES / 1024;
+constexpr int STAGE_BYTES = UMAX * CH * 4;
 
 template <int C>
-__global__ __launch_bounds__(512) void k_ax_pipe(const float *__restrict__ H, const GroupRec *__restrict__ recs, float *__restrict__ out, int G,
+__global__ __launch_bounds__(NW * 64) void k_ax_pipe(const float *__restrict__ H, const char *__restrict__ recs, float *__restrict__ out, int G,
                                                  int groups_per_wg)
 {
     constexpr int NS = C / CH;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const GroupRec *meta = reinterpret_cast<const GroupRec *>(smem_raw + (size_t)NST * UMAX * CH * 4);   // NREC records behind the stages
+    const char *rec_lds = smem_raw + NST * STAGE_BYTES;                                 // NREC records behind the stages
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)((lds_void_t *)smem_raw));
-    const unsigned meta_lds = lds0 + NST * UMAX * CH * 4;
     const int b = blockIdx.x, xcd = b & 7, jj = b >> 3;
     const int g_first = (xcd * (gridDim.x / 8) + jj) * groups_per_wg;
     const int ng = max(0, min(groups_per_wg, G - g_first));
@@ -74,122 +84,121 @@ __global__ __launch_bounds__(512) void k_ax_pipe(const float *__restrict__ H, co
     int loads = 0;             // DMA instructions this wave has issued so far
     int mark[NST];             // `loads` right after the pieces of the item occupying each stage
 
-    auto fetch_rec = [&](int g) {                                // group g's record -> slot g % NREC; waves 0..6 move one KiB each
-        if (wid < 7) {
-            glds16(reinterpret_cast<const char *>(recs + g_first + g) + wid * 1024 + lane * 16, meta_lds + (unsigned)((g % NREC) * 7168 + wid * 1024));
+    auto fetch_rec = [&](int g) {                                // group g's record -> slot g % NREC, one KiB per instruction
+        for (int p = wid; p < REC_PIECES; p += NW) {
+            glds16(recs + (size_t)(g_first + g) * REC_BYTES + p * 1024 + lane * 16, lds0 + (unsigned)(NST * STAGE_BYTES + (g % NREC) * REC_BYTES + p * 1024));
             ++loads;
         }
     };
     auto issue_dma = [&](int item) {
         const int g = item / NS, c = item % NS, st = item % NST;
-        const GroupRec &m = meta[g % NREC];
-        const int U = m.rp[33];
+        const int *hdr = reinterpret_cast<const int *>(rec_lds + (g % NREC) * REC_BYTES);
+        const int U = __builtin_amdgcn_readfirstlane(hdr[0]);
         const int pieces = (U + 3) >> 2;                         // 1 KiB = four 256-byte row slabs
-#if AXP_ABL != 2
-        for (int p = wid; p < pieces; p += 8) {
-            const int u = min(4 * p + (lane >> 4), U - 1);
-            glds16(H + (size_t)m.ucol[u] * C + c * CH + (lane & 15) * 4, lds0 + (unsigned)((st * UMAX * CH) * 4 + p * 1024));
+#if !(AXP_ABL & 2)
+        for (int p = wid; p < pieces; p += NW) {
+            // lane = (slot within the piece, 16-byte chunk); odd slots are stored with the chunk index xor 4, so that the two
+            // union rows a ds_read_b32 half-wave touches fall into different banks
+            const int r4 = lane >> 4, c16 = (lane & 15) ^ ((r4 & 1) << 2);
+            const int u = min(4 * p + r4, U - 1);
+            glds16(H + (size_t)hdr[16 + u] * C + c * CH + c16 * 4, lds0 + (unsigned)(st * STAGE_BYTES + p * 1024));
             ++loads;
         }
 #endif
         mark[st] = loads;
     };
 
-    // prologue: records of the first two groups, then the first NST-1 items
+    // prologue: record of the first group, then the first NST-1 items (all of group 0: NST - 1 < NS)
     fetch_rec(0);
-    if (ng > 1) fetch_rec(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();
 #pragma unroll
     for (int i = 0; i < NST - 1; ++i)
         if (i < items) issue_dma(i);
 
-    const int q = lane >> 4, lq = lane & 15;
-    float rw[KMAX];
-    unsigned ro[KMAX];
-    int e0r = 0, cntr = 0, kmax_w = 0;
+    // MFMA roles: wave = (channel tile ct, row tile nt); lane = (m = lane % 16, kq = lane / 16)
+    //   A[i = m][k = kq]  = H_u[slot 4j + kq][channel ct*16 + m]      (ds_read_b32)
+    //   B[k = kq][j = m]  = Ahat[row nt*16 + m][slot 4j + kq]         (registers, per group)
+    //   D[i = 4*kq + v][j = m] -> out[row nt*16 + m][channels ct*16 + 4*kq .. +4]
+    const int ct = wid & 3, nt = wid >> 2, m = lane & 15, kq = lane >> 4;
+    const unsigned a_lane = (unsigned)(kq * 256 + (((ct * 4 + (m >> 2)) ^ ((kq & 1) << 2)) * 16) + (m & 3) * 4);
+    float bw[NJ];
+    int nj = 0;
     for (int i = 0; i < items; ++i) {
         const int g = i / NS, c = i % NS, st = i % NST;
         wait_vmcnt_le(loads - mark[st]);
         wg_barrier();                                            // item i has landed for every wave; the stage of item i-1 is free
-        if (c == 1 && g + 2 < ng) fetch_rec(g + 2);              // slot of group g-1, finished; older than the DMA issued next, so the
-                                                                 // wait NST-1 iterations from now covers it, long before anyone reads it
+        if (c == 1 && g + 1 < ng) fetch_rec(g + 1);              // into the slot of group g-1 (finished); older than the DMA issued
+                                                                 // next, so the wait NST-1 iterations from now covers it
         if (i + NST - 1 < items) issue_dma(i + NST - 1);
-        const GroupRec &m = meta[g % NREC];
-        const int r = wid * 4 + q;
-        if (c == 0) {
-            // the entries of this lane's row go into registers once per group (eight items use them): weights and stage-relative
-            // byte offsets, padded with (weight 0, row 0) up to the longest of the wave's four rows
-            e0r = m.rp[r];
-            cntr = m.rp[r + 1] - e0r;
+        if (c == 0 && (!(AXP_ABL & 8) || g == 0)) {
+            const char *rec = rec_lds + (g % NREC) * REC_BYTES;
+            nj = (__builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(rec)[0]) + 3) >> 2;
+            const float *what = reinterpret_cast<const float *>(rec + 64 + 4 * UMAX) + kq * GR + nt * 16 + m;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k) {
-                const bool ok = k < cntr;
-                const int idx = ok ? e0r + k : 0;
-                const float wv = m.eval[idx];
-                const unsigned ov = m.eoff[idx];
-                rw[k] = ok ? wv : 0.f;
-                ro[k] = (ok ? ov : 0u) + (unsigned)lq * 16u;
-            }
-            int mx = cntr;
-            mx = max(mx, __shfl_xor(mx, 16));
-            mx = max(mx, __shfl_xor(mx, 32));
-            kmax_w = __builtin_amdgcn_readfirstlane(mx);
+            for (int j = 0; j < NJ; ++j) bw[j] = what[j * 4 * GR];
         }
-        const char *sl = smem_raw + (size_t)st * UMAX * CH * 4;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#if AXP_ABL != 1
+        const float *ap = reinterpret_cast<const float *>(smem_raw + st * STAGE_BYTES + a_lane);
+        v4f acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+#if !(AXP_ABL & 1)
+        // two operand buffers of eight k-steps: the reads of the next eight are in flight while the MFMA chain of the current
+        // eight runs (sched_barrier keeps hipcc from sinking every read next to its MFMA, which exposes the LDS latency per pair)
+        float a0[8], a1[8];
 #pragma unroll
-        for (int kb = 0; kb < KMAX; kb += 8) {
-            if (kb < kmax_w) {
-                float4 h[8];
+        for (int u = 0; u < 8; ++u) a0[u] = ap[u * 256];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) h[u] = *reinterpret_cast<const float4 *>(sl + ro[kb + u]);
+        for (int jb = 0; jb < NJ; jb += 16) {
+            if (jb + 8 < nj) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a1[u] = ap[(jb + 8 + u) * 256];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (jb < nj) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    acc.x = fmaf(rw[kb + u], h[u].x, acc.x);
-                    acc.y = fmaf(rw[kb + u], h[u].y, acc.y);
-                    acc.z = fmaf(rw[kb + u], h[u].z, acc.z);
-                    acc.w = fmaf(rw[kb + u], h[u].w, acc.w);
+                    if ((AXP_ABL & 16) && (u & 1)) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bw[jb + u], acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bw[jb + u], acc, 0, 0, 0);
                 }
             }
-        }
-        if (kmax_w > KMAX) {                                     // rare: rows with more than KMAX entries finish from the LDS record
-            for (int e = e0r + KMAX; __any(e < e0r + cntr); ++e) {
-                const bool ok = e < e0r + cntr;
-                const float wv = m.eval[ok ? e : 0];
-                const float4 hv = *reinterpret_cast<const float4 *>(sl + (unsigned)m.eoff[ok ? e : 0] + lq * 16);
-                if (ok) {
-                    acc.x = fmaf(wv, hv.x, acc.x);
-                    acc.y = fmaf(wv, hv.y, acc.y);
-                    acc.z = fmaf(wv, hv.z, acc.z);
-                    acc.w = fmaf(wv, hv.w, acc.w);
+            if (jb + 16 < NJ && jb + 16 < nj) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a0[u] = ap[(jb + 16 + u) * 256];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (jb + 8 < nj) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if ((AXP_ABL & 16) && (u & 1)) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bw[jb + 8 + u], acc2, 0, 0, 0);
+                    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bw[jb + 8 + u], acc, 0, 0, 0);
                 }
             }
         }
 #endif
-#if AXP_ABL != 3
-        typedef float v4f __attribute__((ext_vector_type(4)));
-        const v4f t = {acc.x, acc.y, acc.z, acc.w};
-        __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(out + (size_t)((g_first + g) * 32 + r) * C + c * CH + lq * 4));
+        if (AXP_ABL & 16) acc += acc2;
+#if !(AXP_ABL & 4)
+        __builtin_nontemporal_store(acc, reinterpret_cast<v4f *>(out + (size_t)((g_first + g) * GR + nt * 16 + m) * C + c * CH + ct * 16 + kq * 4));
 #else
         if (acc.x == 1.2345f) out[0] = acc.y;
 #endif
     }
 }
 
+extern "C" int ax_pipe_rec_bytes() { return REC_BYTES; }
+extern "C" int ax_pipe_umax() { return UMAX; }
+extern "C" int ax_pipe_group_rows() { return GR; }
+
 extern "C" int ax_pipe_run(const float *H, const void *recs, float *out, int G, int C, void *stream)
 {
-    const int wgs = 256;
+    const int wgs = AXP_WGS;
     const int groups_per_wg = (G + wgs - 1) / wgs;
-    const size_t lds = (size_t)NST * UMAX * CH * 4 + NREC * sizeof(GroupRec);
+    const size_t lds = (size_t)NST * STAGE_BYTES + NREC * REC_BYTES;
     if (C != 512) return -1;
     static bool once = false;
     if (!once) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ax_pipe<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -2;
         once = true;
     }
-    hipLaunchKernelGGL(k_ax_pipe<512>, dim3(wgs), dim3(512), lds, static_cast<hipStream_t>(stream), H, static_cast<const GroupRec *>(recs), out, G,
+    hipLaunchKernelGGL(k_ax_pipe<512>, dim3(wgs), dim3(NW * 64), lds, static_cast<hipStream_t>(stream), H, static_cast<const char *>(recs), out, G,
                        groups_per_wg);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
