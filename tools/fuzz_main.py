@@ -7,14 +7,15 @@ import cmap_oracle, gcn_oracle
 from mDeepFRI import synthetic
 from mDeepFRI.batch import HotPathEngine, PackedProteins
 from mDeepFRI.predict import Predictor
-rng = np.random.default_rng(7)
+SEED = int(os.environ.get("FUZZ_SEED", 7))
+rng = np.random.default_rng(SEED)
 worst = 0.0
-for it in range(16):
+for it in range(int(os.environ.get("FUZZ_ITERS", 16))):
     n_gc = int(rng.integers(1, 4))
-    w = synthetic.glorot_gcn_weights(seed=it, n_terms=int(rng.integers(1, 2100)), embed=int(rng.choice([7, 64, 1024])),
+    w = synthetic.glorot_gcn_weights(seed=SEED * 100 + it, n_terms=int(rng.integers(1, 2100)), embed=int(rng.choice([7, 64, 1024])),
                                      gc_dims=tuple(int(x) for x in rng.choice([256, 512, 1024], size=n_gc)), fc_dim=int(rng.choice([256, 512, 1024])))
     n = int(rng.integers(1, 40))
-    prots = synthetic.synthetic_proteins(seed=1000 + it, count=n, length=(1, int(rng.choice([40, 300, 700]))), indel_rate=float(rng.choice([0.0, 0.05, 0.3])))
+    prots = synthetic.synthetic_proteins(seed=1000 * SEED + it, count=n, length=(1, int(rng.choice([40, 300, 700]))), indel_rate=float(rng.choice([0.0, 0.05, 0.3])))
     thr, gen = float(rng.choice([4.0, 6.0, 10.0])), int(rng.integers(0, 5))
     eng = HotPathEngine({"m": Predictor("g", weights=w)}, max_rows=int(rng.choice([128, 2048, 65536])), nnz_per_row=int(rng.choice([2, 40])),
                         threshold=thr, generated_contacts=gen)

@@ -6,7 +6,7 @@ import cnn_oracle, lm_oracle, gcn_oracle
 from mDeepFRI import synthetic
 from mDeepFRI.batch import SequenceEngine, HotPathEngine, PackedProteins
 from mDeepFRI.predict import Predictor
-rng = np.random.default_rng(123)
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", 123)))
 worst = 0
 for it in range(25):
     nb = int(rng.integers(1, 6))
