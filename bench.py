@@ -26,7 +26,8 @@ Objects on the line (tier contract):
   cpu_baseline  the oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample: one thread
                 (the configuration the reference ships) and a pool of single-thread worker processes (the reference's own
                 parallelism, pipeline.py:476-481); real onnxruntime-CPU on the exported synthetic weights when ORT is importable
-  by_length / mixed / end_to_end   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix, and the
+  by_length / mixed / helix / end_to_end   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix,
+  protein-like helix-bundle traces (fewer contacts per residue than a random walk), and the
                 PCIe-inclusive host-lists-in / host-arrays-out rate -- never `value`
 """
 import argparse
@@ -129,6 +130,16 @@ def make_fixed_length(seed, count, L):
     v /= np.linalg.norm(v, axis=2, keepdims=True) + 1e-12
     xyz = np.round(np.cumsum(v * 3.8, axis=1), 3).astype(np.float32)
     return seqs, [xyz[i] for i in range(count)], seqs, seqs
+
+
+def make_helix(seed, count, L):
+    """Protein-like C-alpha traces (synthetic.helix_bundle_coords: ~8.6 contacts per residue at 6 A instead of the ~12.6 of a random
+    walk; SURVEY.md section 8d asks for this second generator), otherwise as make_fixed_length."""
+    from mDeepFRI import synthetic
+    rng = np.random.default_rng(seed)
+    letters = np.frombuffer(synthetic.AA20.encode(), dtype=np.uint8)
+    seqs = [bytes(r).decode() for r in letters[rng.integers(0, 20, size=(count, L))]]
+    return seqs, [synthetic.helix_bundle_coords(rng, L) for _ in range(count)], seqs, seqs
 
 
 def make_mixed(seed, count):
@@ -528,6 +539,8 @@ def main():
             # the rest of the north_star's measurement list on the same engine, each a short run of its own (never `value`)
             line["by_length"] = {str(L): mini_run(ctx, eng, make_fixed_length(42 + 2 + L, n_local, L), args.chunk_rows) for L in (256, 1024)}
             line["mixed"] = mini_run(ctx, eng, make_mixed(42 + 4, n_local), args.chunk_rows)
+            line["helix"] = mini_run(ctx, eng, make_helix(42 + 5, n_local, args.length), args.chunk_rows)
+            line["helix"]["note"] = "same shape as the headline run, protein-like C-alpha traces (helix bundles) instead of random walks"
             if args.end_to_end > 0:
                 from mDeepFRI.stream import AlignmentStream
                 items = []

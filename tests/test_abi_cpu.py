@@ -171,6 +171,22 @@ def test_synthetic_generators_are_deterministic_and_pipeline_realistic():
         assert np.allclose(step, 3.8, atol=0.01)
 
 
+def test_helix_bundle_generator_is_protein_like():
+    """a second coordinate generator with ~5-9 contacts per residue at 6 A (a random walk gives ~12.6)."""
+    a = synthetic.synthetic_proteins(seed=7, count=3, length=300, indel_rate=0.05, coords="helix")
+    b = synthetic.synthetic_proteins(seed=7, count=3, length=300, indel_rate=0.05, coords="helix")
+    assert all(np.array_equal(x["coords"], y["coords"]) for x, y in zip(a, b))
+    for p in a:
+        xyz = p["coords"].astype(np.float64)
+        assert p["coords"].dtype == np.float32 and xyz.shape == (len(p["t_aln"].replace("-", "")), 3)
+        assert np.allclose(np.linalg.norm(np.diff(xyz, axis=0), axis=1), 3.8, atol=0.05)
+        per_row = (((xyz[:, None] - xyz[None]) ** 2).sum(-1) < 36.0).sum(1)
+        assert 6.0 < per_row.mean() < 10.5, per_row.mean()
+    def mean_entries(prots):
+        return np.mean([(((x[:, None] - x[None]) ** 2).sum(-1) < 36.0).sum(1).mean() for x in (p["coords"].astype(np.float64) for p in prots)])
+    assert mean_entries(synthetic.synthetic_proteins(seed=7, count=8, length=300)) > mean_entries(a) + 2.0
+
+
 def test_insert_gaps_reference_kats_and_contract():
     # reference mDeepFRI/tests/test_alignment.py:38-45
     from mDeepFRI.alignment import AlignmentResult, insert_gaps

@@ -161,6 +161,30 @@ def test_fused_batch_vs_oracle_and_per_call(mf, cc):
         assert np.array_equal(s_mf[i], pm.forward_pass(p["seq"], cm)), i
 
 
+def test_fused_batch_on_protein_like_traces(mf):
+    """The same chain on helix-bundle traces (~8.6 entries per CSR row instead of ~12.6) with indels: contact
+    maps bit-exact with the oracle's, scores within the budget, batch == per call."""
+    from mDeepFRI.batch import PackedProteins
+    from types import SimpleNamespace
+    from mDeepFRI.bio_utils import build_align_contact_map
+    w, pred = mf
+    prots = synthetic.synthetic_proteins(seed=77, count=20, length=(25, 400), indel_rate=0.08, coords="helix")
+    eng = _engine({"mf": pred}, max_rows=2048)
+    pk = PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots],
+                             [p["t_aln"] for p in prots], max_rows=2048)
+    db = eng.upload(pk)
+    s = eng.forward_alignments(db)["mf"]
+    eng.check(db)
+    s = s.cpu().numpy()
+    for i, p in enumerate(prots):
+        cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
+        assert np.max(np.abs(s[i] - gcn_oracle.gcn_forward(w, p["seq"], cm))) < TOL, i
+        assert np.array_equal(s[i], pred.forward_pass(p["seq"], cm)), i
+        if i < 6:
+            aln = SimpleNamespace(query_name=p["id"], target_name="t", gapped_sequence=p["q_aln"], gapped_target=p["t_aln"], coords=p["coords"])
+            assert np.array_equal(build_align_contact_map(aln)[1], cm), i
+
+
 def test_dense_batch_path_matches_per_call(mf):
     from mDeepFRI.batch import PackedProteins
     w, pred = mf
