@@ -18,10 +18,11 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #ifndef AXP_ABL
 #define AXP_ABL 0   // timing ablations, bit mask: 1 = no accumulation, 2 = no DMA, 4 = no stores, 8 = Ahat operand loaded for the first group only,
-                    // 16 = two MFMA chains (even / odd k-steps) instead of one  (results wrong by construction except 16: other summation order)
+                    // (results wrong by construction)
 #endif
 #ifndef AXP_NST
 #define AXP_NST 3
@@ -119,18 +120,45 @@ __global__ __launch_bounds__(NW * 64) void k_ax_pipe(const float *__restrict__ H
     // MFMA roles: wave = (channel tile ct, row tile nt); lane = (m = lane % 16, kq = lane / 16)
     //   A[i = m][k = kq]  = H_u[slot 4j + kq][channel ct*16 + m]      (ds_read_b32)
     //   B[k = kq][j = m]  = Ahat[row nt*16 + m][slot 4j + kq]         (registers, per group)
-    //   D[i = 4*kq + v][j = m] -> out[row nt*16 + m][channels ct*16 + 4*kq .. +4]
+    //   D[i = 4*kq + v][j = m] -> row nt*16 + m, channels ct*16 + 4*kq .. +4: dropped into an LDS output tile (GR rows x 64 channels,
+    //   two of them) and written out one item later as 256-byte row segments, four rows per wave instruction
     const int ct = wid & 3, nt = wid >> 2, m = lane & 15, kq = lane >> 4;
     const unsigned a_lane = (unsigned)(kq * 256 + (((ct * 4 + (m >> 2)) ^ ((kq & 1) << 2)) * 16) + (m & 3) * 4);
+    float *otile = reinterpret_cast<float *>(smem_raw + NST * STAGE_BYTES + NREC * REC_BYTES);   // [2][GR][CH]
     float bw[NJ];
     int nj = 0;
+    auto product = [&](int st, auto njc) -> v4f {                // one dependent chain of NJC MFMAs, operands read in one batch
+        constexpr int NJC = decltype(njc)::value;
+        const float *ap = reinterpret_cast<const float *>(smem_raw + st * STAGE_BYTES + a_lane);
+        float a[NJC];
+#pragma unroll
+        for (int u = 0; u < NJC; ++u) a[u] = ap[u * 256];
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NJC; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bw[u], acc, 0, 0, 0);
+        return acc;
+    };
+    auto write_out = [&](int item) {                             // rows 4*wid .. 4*wid+3 of the finished item, 256 B each
+        const int g = item / NS, c = item % NS;
+        const int r = wid * 4 + (lane >> 4);
+        if (r < GR) {
+            const v4f t = *reinterpret_cast<const v4f *>(otile + (item & 1) * GR * CH + r * CH + (lane & 15) * 4);
+#if !(AXP_ABL & 4)
+            __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(out + (size_t)((g_first + g) * GR + r) * C + c * CH + (lane & 15) * 4));
+#else
+            if (t.x == 1.2345f) out[0] = t.y;
+#endif
+        }
+    };
     for (int i = 0; i < items; ++i) {
         const int g = i / NS, c = i % NS, st = i % NST;
-        wait_vmcnt_le(loads - mark[st]);
-        wg_barrier();                                            // item i has landed for every wave; the stage of item i-1 is free
+        if (!(AXP_ABL & 64)) wait_vmcnt_le(loads - mark[st]);
+        wg_barrier();                                            // item i has landed for every wave; the stage of item i-1 is free;
+                                                                 // every tile of item i-1 is in its output tile
         if (c == 1 && g + 1 < ng) fetch_rec(g + 1);              // into the slot of group g-1 (finished); older than the DMA issued
                                                                  // next, so the wait NST-1 iterations from now covers it
         if (i + NST - 1 < items) issue_dma(i + NST - 1);
+        if (!(AXP_ABL & 16) && i > 0) write_out(i - 1);
         if (c == 0 && (!(AXP_ABL & 8) || g == 0)) {
             const char *rec = rec_lds + (g % NREC) * REC_BYTES;
             nj = (__builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(rec)[0]) + 3) >> 2;
@@ -138,49 +166,18 @@ __global__ __launch_bounds__(NW * 64) void k_ax_pipe(const float *__restrict__ H
 #pragma unroll
             for (int j = 0; j < NJ; ++j) bw[j] = what[j * 4 * GR];
         }
-        const float *ap = reinterpret_cast<const float *>(smem_raw + st * STAGE_BYTES + a_lane);
-        v4f acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
 #if !(AXP_ABL & 1)
-        // two operand buffers of eight k-steps: the reads of the next eight are in flight while the MFMA chain of the current
-        // eight runs (sched_barrier keeps hipcc from sinking every read next to its MFMA, which exposes the LDS latency per pair)
-        float a0[8], a1[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) a0[u] = ap[u * 256];
-#pragma unroll
-        for (int jb = 0; jb < NJ; jb += 16) {
-            if (jb + 8 < nj) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) a1[u] = ap[(jb + 8 + u) * 256];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (jb < nj) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if ((AXP_ABL & 16) && (u & 1)) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bw[jb + u], acc2, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bw[jb + u], acc, 0, 0, 0);
-                }
-            }
-            if (jb + 16 < NJ && jb + 16 < nj) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) a0[u] = ap[(jb + 16 + u) * 256];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (jb + 8 < nj) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if ((AXP_ABL & 16) && (u & 1)) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bw[jb + 8 + u], acc2, 0, 0, 0);
-                    else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bw[jb + 8 + u], acc, 0, 0, 0);
-                }
-            }
-        }
+        // union size buckets (wave-uniform): the chain is as long as the bucket, zero weights fill the rest
+        if ((AXP_ABL & 32) || nj <= NJ / 2) acc = product(st, std::integral_constant<int, NJ / 2>());
+        else if (nj <= 3 * NJ / 4) acc = product(st, std::integral_constant<int, 3 * NJ / 4>());
+        else acc = product(st, std::integral_constant<int, NJ>());
 #endif
-        if (AXP_ABL & 16) acc += acc2;
-#if !(AXP_ABL & 4)
-        __builtin_nontemporal_store(acc, reinterpret_cast<v4f *>(out + (size_t)((g_first + g) * GR + nt * 16 + m) * C + c * CH + ct * 16 + kq * 4));
-#else
-        if (acc.x == 1.2345f) out[0] = acc.y;
-#endif
+        if (AXP_ABL & 16) __builtin_nontemporal_store(acc, reinterpret_cast<v4f *>(out + (size_t)((g_first + g) * GR + nt * 16 + m) * C + c * CH + ct * 16 + kq * 4));
+        else *reinterpret_cast<v4f *>(otile + (i & 1) * GR * CH + (nt * 16 + m) * CH + ct * 16 + kq * 4) = acc;
     }
+    wg_barrier();
+    if (!(AXP_ABL & 16)) write_out(items - 1);
 }
 
 extern "C" int ax_pipe_rec_bytes() { return REC_BYTES; }
@@ -191,7 +188,7 @@ extern "C" int ax_pipe_run(const float *H, const void *recs, float *out, int G, 
 {
     const int wgs = AXP_WGS;
     const int groups_per_wg = (G + wgs - 1) / wgs;
-    const size_t lds = (size_t)NST * STAGE_BYTES + NREC * REC_BYTES;
+    const size_t lds = (size_t)NST * STAGE_BYTES + NREC * REC_BYTES + 2 * GR * CH * 4;
     if (C != 512) return -1;
     static bool once = false;
     if (!once) {
