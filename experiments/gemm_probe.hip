@@ -2,7 +2,7 @@
 // and checks a sample of outputs against a double-precision host reference.
 //   build:  make -C metagenomic-deepfri_amd/csrc probe      run:  metagenomic-deepfri_amd/lib/gemm_probe [M] [iters]
 #define MDF_PROBE_TIMING 1
-#include "../gcn.hip"
+#include "../metagenomic-deepfri_amd/csrc/gcn.hip"
 
 #include <random>
 

@@ -4,7 +4,7 @@
 #include <random>
 #include <vector>
 
-#include "../gcn.hip"
+#include "../metagenomic-deepfri_amd/csrc/gcn.hip"
 
 #define CK(x)                                                                      \
     do {                                                                           \

@@ -405,6 +405,13 @@ __global__ __launch_bounds__(1024) void k_scan_groups(const int32_t *__restrict_
 // whose column residue is letter a, accumulated in CSR (ascending column) order -- the arithmetic of k_letter_sums (gcn.hip),
 // without re-reading the CSR or a separate launch.
 // ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync_lds()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off, int B,
                                                    const int32_t *__restrict__ counts, const int32_t *__restrict__ group_base,
                                                    const unsigned long long *__restrict__ masks, int W, int32_t *__restrict__ rowptr,
@@ -437,7 +444,9 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
         run += counts[wrow0 + k];
     }
     for (int e = lane; e < 8 * 32; e += 64) s_bins[wid * 8 + (e >> 5)][e & 31] = 0.0f;
-    // (s_start / s_bins are private to this wave's 8 rows: program order within the wave is all the synchronisation needed)
+    // s_start / s_bins are private to this wave's 8 rows, but they are written and read by DIFFERENT lanes of the wave: a
+    // wavefront-scope fence + wave barrier makes that ordering part of the program instead of a property of the code generator
+    wave_sync_lds();
     const int n_items = 8 * Wp;
     for (int t0 = 0; t0 < n_items; t0 += 64) {
         const int t = t0 + lane;
@@ -455,6 +464,9 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
             di = 1.0f / (1e-6f + sqrtf((float)counts[row]));
         }
         for (int ww = 0; ww < Wp; ++ww) {          // ascending word order keeps every (row, letter) sum in column order
+            // the lanes holding the words of one row take turns: the barrier is convergent (Wp is uniform), so the loop cannot be
+            // collapsed into `if (w < Wp)`, and the fence orders one lane's bin updates before the next lane's
+            wave_sync_lds();
             if (w != ww) continue;
             unsigned long long m = word;
             while (m) {
@@ -471,6 +483,7 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
             }
         }
     }
+    wave_sync_lds();
     if (letter_sums) {
         for (int e = lane; e < 8 * 32; e += 64) {
             const int k = e >> 5, a = e & 31;

@@ -61,15 +61,18 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
     }
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool gap_first = tie_rule & 1, horiz_first = tie_rule & 2, ext_first = tie_rule & 4;   // see oracle/nw_oracle.c
-    const bool coop = (int)blockIdx.x < n_long;
-    if (coop)
+    const bool own_block = (int)blockIdx.x < n_long;   // this workgroup holds ONE pair
+    if (own_block)
         for (int e = threadIdx.x; e < NW_MAX_COOP_STRIPS; e += blockDim.x) s_prog[e] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int p = coop ? (int)blockIdx.x : n_long + ((int)blockIdx.x - n_long) * 4 + wid;
+    const int p = own_block ? (int)blockIdx.x : n_long + ((int)blockIdx.x - n_long) * 4 + wid;
     if (p >= P) return;
     const int iq = pair_q[p], it = pair_t[p];
     const int Lq = seq_len[iq], Lt = seq_len[it];
+    // a caller's n_long is not trusted with the size of s_prog: a pair with more strips than it holds is swept by wave 0 alone
+    const bool coop = own_block && ((Lt + 63) >> 6) <= NW_MAX_COOP_STRIPS;
+    if (own_block && !coop && wid != 0) return;
     const uint8_t *q = codes + seq_off[iq], *t = codes + seq_off[it];
     if (Lq == 0 || Lt == 0) {   // degenerate: one all-gap run (or nothing)
         if (lane == 0 && (!coop || wid == 0)) scores[p] = (Lq + Lt == 0) ? 0 : -(go + (Lq + Lt - 1) * ge);
@@ -338,7 +341,10 @@ static int nw_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *
         MDF_REQUIRE(seq_len[s] >= 0 && seq_off[s] >= 0, "nw: negative length/offset at sequence %d", s);
         total = std::max<int64_t>(total, seq_off[s] + seq_len[s]);
     }
-    for (int64_t b = 0; b < total; ++b) MDF_REQUIRE(codes[b] < A, "nw: residue code %d at byte %lld is outside the alphabet (size %d)", (int)codes[b], (long long)b, A);
+    for (int32_t s = 0; s < n_seq; ++s)   // per sequence: bytes between non-contiguous sequences are not the caller's to be judged on
+        for (int64_t b = seq_off[s]; b < seq_off[s] + seq_len[s]; ++b)
+            MDF_REQUIRE(codes[b] < A, "nw: residue code %d at position %lld of sequence %d is outside the alphabet (size %d)", (int)codes[b],
+                        (long long)(b - seq_off[s]), s, A);
     std::vector<int64_t> bo((size_t)P + 1), to((size_t)P + 1), oo((size_t)P + 1);
     if (int rc = mdf_nw_plan(seq_len, pair_q, pair_t, P, bo.data(), to.data(), oo.data())) return rc;
     size_t o = 0;

@@ -166,7 +166,7 @@ class _PairBatch:
             out[order] = sc
         return out
 
-    def align(self, pair_q, pair_t, gap_open, gap_extend, max_trace_bytes: int = 4 << 30, tie_rule: int = 0):
+    def align(self, pair_q, pair_t, gap_open, gap_extend, max_trace_bytes: int = 512 << 20, tie_rule: int = 0):
         """Full alignments -> dict of arrays: ops / q_aln / t_aln (flat uint8), off (P+1, int64: pair p's columns are
         [off[p], off[p+1])), op_len, n_match, score.  Pairs are processed in groups whose direction bytes fit `max_trace_bytes`."""
         L = _hip.lib()

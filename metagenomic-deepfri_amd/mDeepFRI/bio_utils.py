@@ -85,13 +85,41 @@ _THREE_TO_ONE = {"ALA": "A", "ARG": "R", "ASN": "N", "ASP": "D", "CYS": "C", "GL
                  "ASX": "B", "GLX": "Z", "UNK": "X", "SEC": "U", "PYL": "O"}
 
 
+# Modified residues -> the standard residue they derive from: the facts of pdbfixer's table, which the reference embeds as its
+# module-level `substitutions` (reference bio_utils.py:48-193) and always applies at :252.  Kept here grouped by parent residue.
+_MODIFIED_RESIDUES = {
+    "ALA": "AIB ALM AYA BNN CHG CSD DAL DHA DNP FLA HAC MAA PRR TIH TPQ",
+    "ARG": "ACL AGM ARM DAR HAR HMR",
+    "ASN": "MEN",
+    "ASP": "2AS ASA ASB ASK ASL ASQ BHD DAS DSP IAS",
+    "CYS": "BCS BUC C5C C6C CAS CCS CEA CME CSO CSP CSS CSW CSX CY1 CY3 CYG CYM CYQ DCY EFC OCS PEC PR3 PYX SCH SCS SCY SHC SMC SOC",
+    "GLN": "DGN",
+    "GLU": "5HP CGU DGL GGL GMA PCA",
+    "GLY": "GL3 GLZ GSC MPQ MSA NMC SAR",
+    "HIS": "3AH DHI HIC HIP MHS NEM NEP",
+    "ILE": "DIL IIL",
+    "LEU": "BUG CLE DLE MK8 MLE NLE NLN NLP",
+    "LYS": "5OW ALY DLY KCX LLP LLY LYM LYZ SHR TRG",
+    "MET": "CXM FME MSE OMT",
+    "PHE": "DAH DPN HPQ PHI PHL",
+    "PRO": "DPR HYP",
+    "SER": "DSN MIS OAS SAC SEL SEP SET SVA",
+    "THR": "ALO BMT DTH TPO",
+    "TRP": "DTR HTR LTR TPL TRO",
+    "TYR": "DTY IYR PAQ PTR STY TYB TYI TYQ TYS TYY",
+    "VAL": "DIV DVA MVA",
+}
+#: same name and meaning as the reference's module attribute: {modified three-letter name: standard three-letter name}
+substitutions = {mod: std for std, mods in _MODIFIED_RESIDUES.items() for mod in mods.split()}
+
+
 def get_residues_coordinates(structure, chain: str = "A", substitutions=None):
     """reference bio_utils.py:230-255: (one-letter residues, C-alpha coordinates) of one chain -- the C-alpha feed of the hot
     path.  `structure` is a biotite AtomArray or anything with the same per-atom NumPy attributes (chain_id, atom_name, hetero,
     res_name, coord); the selection is one vectorised mask (chain == `chain`, atom "CA", not hetero), no per-atom Python.
-    Non-standard residue names are mapped through `substitutions` ({three-letter: standard three-letter}, e.g. pdbfixer's
-    table the reference embeds at bio_utils.py:49-193) before the one-letter conversion; unknown names raise, as biotite's
-    ProteinSequence does.  Coordinates are returned as the structure stores them (float32 (L, 3) for biotite)."""
+    Non-standard residue names are mapped through `substitutions` ({three-letter: standard three-letter}; default None = the
+    module-level table above, which is what the reference always applies at bio_utils.py:252) before the one-letter
+    conversion; unknown names raise, as biotite's ProteinSequence does.  Coordinates are returned as the structure stores them (float32 (L, 3) for biotite)."""
     chain_id = np.asarray(structure.chain_id)
     if chain not in set(chain_id.tolist()):
         raise ValueError(f"Chain {chain} not found in structure.")
@@ -99,9 +127,10 @@ def get_residues_coordinates(structure, chain: str = "A", substitutions=None):
     names = np.asarray(structure.res_name)[keep]
     uniq, inverse = np.unique(names, return_inverse=True)
     table = dict(_THREE_TO_ONE)
+    subst = globals()["substitutions"] if substitutions is None else substitutions
     letters = []
     for n in uniq.tolist():
-        std = (substitutions or {}).get(n, n)
+        std = subst.get(n, n)
         if std not in table:
             raise ValueError(f"'{n}' is not a known amino acid residue name")
         letters.append(table[std])

@@ -14,19 +14,41 @@ def protein_cost(length: int) -> int:
 
 
 def partition_by_cost(lengths, world_size: int):
-    """Greedy longest-processing-time assignment.  Returns `world_size` index lists (each sorted by length, as the
-    reference sorts its work list, pipeline.py:529-533).  Deterministic."""
+    """Greedy longest-processing-time assignment: proteins by decreasing length (ties by index), each to the rank with the
+    smallest load so far (ties: lowest rank).  Returns `world_size` index lists (each sorted by length, as the reference sorts
+    its work list, pipeline.py:529-533).  Deterministic.  The order is one NumPy lexsort and the deal a binary heap --
+    O(N log world), 0.3 s for the 500 000 proteins of BASELINE configs[4] (it runs on every rank before the first launch)."""
+    import heapq
     lengths = np.asarray(lengths, dtype=np.int64)
-    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
-    loads = [0] * world_size
-    shards = [[] for _ in range(world_size)]
-    for i in order:
-        r = min(range(world_size), key=lambda k: (loads[k], k))
-        shards[r].append(i)
-        loads[r] += protein_cost(lengths[i])
-    for s in shards:
-        s.sort(key=lambda i: (int(lengths[i]), i))
+    n = len(lengths)
+    order = np.lexsort((np.arange(n), -lengths))
+    cost = ((lengths + 31) // 32 * 32)[order].tolist()
+    heap = [(0, r) for r in range(world_size)]          # (load, rank): the heap order IS the tie rule
+    owner = np.empty(n, dtype=np.int64)
+    own = owner.tolist()
+    for k, c in enumerate(cost):
+        load, r = heap[0]
+        own[k] = r
+        heapq.heapreplace(heap, (load + c, r))
+    owner = np.asarray(own, dtype=np.int64)
+    shards = []
+    for r in range(world_size):
+        mine = order[owner == r]
+        shards.append(mine[np.lexsort((mine, lengths[mine]))].tolist())
     return shards
+
+
+def plan_summary(lengths, world_size: int, max_rows: int = 65536):
+    """What `bench.py --dry-plan` prints and tests/test_sharding_cpu.py asserts on: per rank the proteins, padded residue rows
+    (the cost model) and chunks of `max_rows`, plus the predicted imbalance max/mean - 1 of the padded rows.  CPU only."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    pad = (lengths + 31) // 32 * 32
+    shards = partition_by_cost(lengths, world_size)
+    rows = [int(pad[s].sum()) for s in shards]
+    mean = sum(rows) / max(world_size, 1)
+    return {"world": world_size, "proteins": [len(s) for s in shards], "padded_rows": rows,
+            "chunks": [int(-(-r // max_rows)) for r in rows],
+            "imbalance": (max(rows) / mean - 1.0) if mean else 0.0}
 
 
 def gather_scores(local_scores, local_index, total: int, dst: int = 0, group=None):
@@ -115,9 +137,12 @@ class DenseGatherPlan:
 
 class FilteredGatherPlan:
     """The compacted gather (gather_filtered) with its host work hoisted: the first `run` agrees on the sizes (it has to
-    read the survivor counts back once); later runs reuse padded buffers with 25 % headroom and touch the host only if a
-    rank's survivors outgrow them (flagged by the sizes exchanged on the device, re-planned on the next call).
-    Output as gather_filtered: (offsets (total+1) int32, term_idx, kept) in input order on `dst`."""
+    read the survivor counts back once); later runs reuse padded buffers with 25 % headroom.  Every payload carries the
+    rank's true survivor count in a trailer element, so `dst` learns all sizes from ONE read-back of `world` integers.
+    Output as gather_filtered: (offsets (total+1) int32, term_idx, kept) in input order on `dst`.
+
+    Host synchronisations per `run`: sizes_may_change=True -- one on every rank (the size agreement); False -- none on the
+    sending ranks, one on `dst` (the trailer read-back that sizes its output)."""
 
     def __init__(self, local_index, total: int, device, dst: int = 0, group=None, collectives_for_one_rank: bool = False):
         import torch
@@ -129,15 +154,50 @@ class FilteredGatherPlan:
         self.via_host = self.world > 1 and dist.get_backend(group) == "gloo" and torch.device(device).type == "cuda"
         self.dev = torch.device("cpu") if self.via_host else torch.device(device)
         self.local_index = list(local_index)
-        self.z_cap = 0
+        self.z_cap = self.z_cap_last = 0
+        self._overflowed = False      # a rank outgrew the plan in an earlier run(sizes_may_change=False): raised by every rank together
+        self._pending = None          # (host copy of the all-reduced overflow flag, event) of the previous run
         self.dense = DenseGatherPlan(len(self.local_index), 1, self.local_index, total, self.dev, dtype=torch.int64, dst=dst, group=group,
                                      collectives_for_one_rank=collectives_for_one_rank)
 
+    # -- overflow agreement, one step late: all ranks learn it without a synchronisation inside the step ------------------
+    def _post_flag(self, overflow: bool):
+        import torch
+        import torch.distributed as dist
+        flag = torch.full((1,), 1 if overflow else 0, dtype=torch.int32, device=self.dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if self.dev.type == "cuda":
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self._pending = (host, ev, flag)
+        else:
+            self._pending = (flag, None, flag)
+
+    def check(self):
+        """Raise -- on EVERY rank -- if some rank's survivors exceeded the planned payload in the previous
+        run(sizes_may_change=False); that run's result is incomplete.  Called at the start of each run and by the caller
+        after its last one; by then the flag has long arrived, so the wait is not a stall."""
+        if self._pending is not None:
+            host, ev, _ = self._pending
+            self._pending = None
+            if ev is not None:
+                ev.synchronize()
+            if int(host[0]) != 0:
+                self._overflowed = True
+        if self._overflowed:
+            self._overflowed = False
+            self.z_cap = 0        # the next run re-plans
+            raise RuntimeError(f"rank {self.rank}: a rank's survivors exceeded the planned payload of {self.z_cap_last} entries in the previous "
+                               "run; its result is incomplete -- call run(..., sizes_may_change=True)")
+
     def run(self, offsets, term_idx, kept, sizes_may_change: bool = True):
         """sizes_may_change=True (default, always safe): every call agrees on the padded payload size with one tiny all-reduce and
-        one read-back.  False: the caller guarantees that no rank's survivor count exceeds what the first call planned for (e.g.
-        bench.py, which repeats the same workload) -- then a step has no host synchronisation at all; a rank that outgrows the
-        plan raises instead of silently desynchronising the collectives."""
+        one read-back.  False: the caller expects that no rank's survivor count exceeds what the first call planned for (e.g.
+        bench.py, which repeats the same workload) -- then the sending ranks never wait for the device.  A rank that outgrows
+        the plan truncates its payload, COMPLETES the collectives (nobody hangs), and the overflow is raised on every rank by the
+        next run() or check() (the sizes travel with the payload, the flag by an all-reduce read one step late)."""
         import torch
         import torch.distributed as dist
         cnt = (offsets[1:] - offsets[:-1]).to(torch.int64).to(self.dev)
@@ -146,32 +206,40 @@ class FilteredGatherPlan:
             counts = self.dense.run(cnt.reshape(-1, 1)).reshape(-1)
             goff = torch.zeros(self.total + 1, dtype=torch.int64, device=self.dev)
             torch.cumsum(counts, 0, out=goff[1:])
-            return _place_filtered(goff, [(self.dense.order, cnt, term_idx, kept)], self.dev)
+            return _place_filtered(goff, [(self.dense.order, cnt, term_idx, kept)], self.dev, [int(term_idx.numel())])
+        self.check()
         z = int(term_idx.numel())
+        zs_host = None
         if self.z_cap == 0 or sizes_may_change:             # a COLLECTIVE decision: every rank takes this branch together
             zs = torch.zeros(self.world, dtype=torch.long, device=self.dev)
             zs[self.rank] = z
             dist.all_reduce(zs, group=self.group)
-            need = int(zs.max().item())
-        else:
-            need = 0
-            if z > self.z_cap:
-                raise RuntimeError(f"rank {self.rank}: {z} survivors exceed the planned {self.z_cap}; call run(..., sizes_may_change=True)")
-        if self.z_cap == 0 or need > self.z_cap:
-            self.z_cap = max(need * 5 // 4, 1)
-            self.t_pay = torch.zeros(self.z_cap, dtype=torch.int32, device=self.dev)
-            self.s_pay = torch.zeros(self.z_cap, dtype=torch.float32, device=self.dev)
-            if self.rank == self.dst:
-                self.t_recv = [torch.empty_like(self.t_pay) for _ in range(self.world)]
-                self.s_recv = [torch.empty_like(self.s_pay) for _ in range(self.world)]
+            zs_host = [int(v) for v in zs.tolist()]
+            need = max(zs_host)
+            if need > self.z_cap or self.z_cap == 0:
+                self.z_cap = max(need * 5 // 4, 1)
+                self.t_pay = torch.zeros(self.z_cap + 1, dtype=torch.int32, device=self.dev)     # [z_cap] = the rank's true count
+                self.s_pay = torch.zeros(self.z_cap, dtype=torch.float32, device=self.dev)
+                if self.rank == self.dst:
+                    self.t_recv = [torch.empty_like(self.t_pay) for _ in range(self.world)]
+                    self.s_recv = [torch.empty_like(self.s_pay) for _ in range(self.world)]
+        self.z_cap_last = self.z_cap
+        z_send = min(z, self.z_cap)
         counts = self.dense.run(cnt.reshape(-1, 1))          # per-protein survivor counts in input order (dst only)
-        self.t_pay[:z].copy_(term_idx, non_blocking=True)
-        self.s_pay[:z].copy_(kept, non_blocking=True)
+        self.t_pay[:z_send].copy_(term_idx[:z_send], non_blocking=True)
+        self.s_pay[:z_send].copy_(kept[:z_send], non_blocking=True)
+        self.t_pay[self.z_cap] = z
         is_dst = self.rank == self.dst
         dist.gather(self.t_pay, self.t_recv if is_dst else None, dst=self.dst, group=self.group)
         dist.gather(self.s_pay, self.s_recv if is_dst else None, dst=self.dst, group=self.group)
+        if zs_host is None:
+            self._post_flag(z > self.z_cap)
         if not is_dst:
             return None
+        if zs_host is None:                                  # ONE read-back: every rank's true survivor count
+            zs_host = [int(v) for v in torch.stack([t[self.z_cap] for t in self.t_recv]).tolist()]
+            if max(zs_host) > self.z_cap:                    # truncated payloads cannot be placed; every rank raises in check()
+                self.check()
         counts = counts.reshape(-1)
         goff = torch.zeros(self.total + 1, dtype=torch.int64, device=self.dev)
         torch.cumsum(counts, 0, out=goff[1:])
@@ -183,22 +251,22 @@ class FilteredGatherPlan:
             rows = flat_rows[start:start + n_r]
             start += n_r
             blocks.append((rows, counts[rows], self.t_recv[r], self.s_recv[r]))
-        return _place_filtered(goff, blocks, self.dev)
+        return _place_filtered(goff, blocks, self.dev, zs_host)
 
 
-def _place_filtered(goff, blocks, dev):
+def _place_filtered(goff, blocks, dev, sizes):
     """Scatter per-rank compacted payloads into global protein order.  blocks: (global rows of the rank's proteins in payload
-    order, their counts, term payload, score payload); payloads may carry padding behind the rank's survivors."""
+    order, their counts, term payload, score payload); payloads may carry padding behind the rank's survivors.  `sizes`: the
+    survivors of each block as host integers (the caller read them back once), so nothing here waits for the device."""
     import torch
-    n = int(goff[-1].item())
+    n = int(sum(sizes))
     out_t = torch.empty(n, dtype=torch.int32, device=dev)
     out_s = torch.empty(n, dtype=torch.float32, device=dev)
-    for rows, c, t, s in blocks:
-        z = int(c.sum().item())
+    for (rows, c, t, s), z in zip(blocks, sizes):
         if z == 0:
             continue
         lo = torch.cumsum(c, 0) - c                                   # start of each protein inside the rank's payload
-        dest = torch.repeat_interleave(goff[rows] - lo, c) + torch.arange(z, device=dev)
+        dest = torch.repeat_interleave(goff[rows] - lo, c, output_size=z) + torch.arange(z, device=dev)
         out_t[dest] = t[:z]
         out_s[dest] = s[:z]
     return goff.to(torch.int32), out_t, out_s

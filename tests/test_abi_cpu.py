@@ -288,7 +288,11 @@ def test_get_residues_coordinates_selects_calpha_of_one_chain():
                         hetero=np.array([a[2] for a in atoms]), res_name=np.array([a[3] for a in atoms]),
                         coord=rng.random((len(atoms), 3)).astype(np.float32))
     with pytest.raises(ValueError, match="is not a known amino acid"):
-        get_residues_coordinates(s)
+        get_residues_coordinates(s, substitutions={})
+    # the default call applies the module-level table, as the reference always does (bio_utils.py:48-193, :252)
+    from mDeepFRI import bio_utils
+    assert len(bio_utils.substitutions) == 144 and bio_utils.substitutions["MSE"] == "MET" and bio_utils.substitutions["SEP"] == "SER"
+    assert get_residues_coordinates(s)[0] == "MLLSAMG"
     seq, xyz = get_residues_coordinates(s, substitutions={"MSE": "MET"})
     assert seq == "MLLSAMG" and xyz.shape == (7, 3) and xyz.dtype == np.float32
     assert np.array_equal(xyz, s.coord[[1 + 4 * k for k in range(7)]])

@@ -25,6 +25,17 @@ def test_partition_covers_everything_and_balances():
     assert sharding.partition_by_cost([5, 5], 4) == [[0], [1], [], []]
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dry_plan_of_the_sharded_baseline_configs_is_balanced(world):
+    """BASELINE configs[3] (100 000 proteins, L ~ U{128..1024}, seed 4) and configs[4] (500 000, length histogram): predicted
+    imbalance of the padded rows below 1 % at every rank count the driver will launch (`bench.py --gpus N --dry-plan`)."""
+    from mDeepFRI import synthetic
+    for lengths in (np.random.default_rng(4).integers(128, 1025, size=100_000), synthetic.histogram_lengths(46, 500_000)):
+        plan = sharding.plan_summary(lengths, world)
+        assert sum(plan["proteins"]) == len(lengths) and plan["world"] == world
+        assert plan["imbalance"] < 0.01, plan
+
+
 def test_gather_single_process_restores_order():
     scores = torch.arange(12, dtype=torch.float32).reshape(4, 3)
     out = sharding.gather_scores(scores, [2, 0, 3, 1], total=4)
@@ -105,6 +116,29 @@ def _worker_csr(rank, world, port, n, T, q):
             assert (again is None) == (rank != 0)
             if rank == 0:
                 assert all(torch.equal(a, b) for a, b in zip(again, out))
+        # the steady-state form bench.py uses: sizes fixed by the first run, no size agreement afterwards
+        for _ in range(2):
+            again = plan.run(torch.tensor(off, dtype=torch.int32), torch.tensor(terms, dtype=torch.int32), torch.tensor(scores, dtype=torch.float32),
+                             sizes_may_change=False)
+            assert (again is None) == (rank != 0)
+            if rank == 0:
+                assert all(torch.equal(a, b) for a, b in zip(again, out))
+        plan.check()
+        if n >= 9:
+            # rank 1 outgrows the plan: nobody may hang in a collective, and EVERY rank raises (at the latest in check())
+            grow = 40 if rank == 1 else 1
+            big_t = torch.tensor(terms * grow, dtype=torch.int32)
+            big_s = torch.tensor(scores * grow, dtype=torch.float32)
+            big_off = torch.tensor([o * grow for o in off], dtype=torch.int32)
+            with pytest.raises(RuntimeError, match="exceeded the planned payload"):
+                plan.run(big_off, big_t, big_s, sizes_may_change=False)
+                plan.check()
+            # the plan recovers: the next run re-agrees on the sizes
+            again = plan.run(torch.tensor(off, dtype=torch.int32), torch.tensor(terms, dtype=torch.int32), torch.tensor(scores, dtype=torch.float32),
+                             sizes_may_change=False)
+            if rank == 0:
+                assert all(torch.equal(a, b) for a, b in zip(again, out))
+            plan.check()
         if rank == 0:
             q.put([x.numpy() for x in out])
         else:
