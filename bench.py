@@ -75,6 +75,9 @@ def parse(argv=None):
     ap.add_argument("--end-to-end", type=int, default=2, metavar="N", help="batches of the end_to_end mini-run (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-device", type=int, default=None, help="testing aid: put every rank on this device ordinal")
+    ap.add_argument("--dry-plan", action="store_true",
+                    help="CPU only: print, as one JSON line, how configs3 / configs4 would be dealt to --gpus ranks (proteins, padded rows, "
+                         "chunks and predicted imbalance per rank) and exit")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)   # internal: one single-thread worker of the all-core leg
     return ap.parse_args(argv)
 
@@ -82,9 +85,19 @@ def parse(argv=None):
 # ---------------------------------------------------------------------------------------------------------------------
 # self-launch: a parent that has made no GPU call starts the N rank processes (never a re-exec of a process that touched HIP)
 # ---------------------------------------------------------------------------------------------------------------------
+def visible_devices() -> int:
+    """HIP devices visible to a rank, counted in a THROW-AWAY child process: the parent that starts the ranks must never open
+    the GPU driver itself (on some ROCm wheels torch.cuda.device_count() falls through to hipGetDeviceCount), and the child
+    sees exactly the HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES filtering the ranks will see."""
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        return int(out.stdout.strip().splitlines()[-1])
+    except Exception:
+        return 0
+
+
 def launch_ranks(args) -> int:
-    import torch
-    visible = torch.cuda.device_count()     # counts devices without initialising the GPU
+    visible = args.gpus if args.force_device is not None else visible_devices()
     if args.force_device is None and visible < args.gpus:
         print(f"bench.py: --gpus {args.gpus} requested but only {visible} HIP device(s) are visible", file=sys.stderr)
         return 2
@@ -188,9 +201,11 @@ def cpu_worker(spec):
     print(json.dumps({"n": n, "t": t}), flush=True)
 
 
-def make_weights(lm):
+def make_weights(lm, sparse_scores=False):
+    """sparse_scores: the operating point of trained heads (1-4 % of the terms pass score >= 0.1; synthetic.glorot_gcn_weights) --
+    used by the workloads whose step ends in the FILTERED gather, so that they measure a compacted payload."""
     from mDeepFRI import synthetic
-    weights = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=synthetic.GO_TERMS[m]) for i, m in enumerate(MODES)}
+    weights = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=synthetic.GO_TERMS[m], sparse_scores=sparse_scores) for i, m in enumerate(MODES)}
     if lm:
         lmw = synthetic.glorot_lm_weights(seed=1000)
         for i, m in enumerate(MODES):
@@ -394,10 +409,28 @@ def mini_run(ctx, eng, cols, chunk_rows, steps=2, warmup=1, lm=False):
             "roofline_ax": {k: roof_ax[k] for k in ("achieved", "unit", "frac")} if roof_ax else None}
 
 
+def dry_plan(args):
+    """`--dry-plan`: the deal of the strong-scaling workloads without a GPU -- what every rank would compute for itself."""
+    from mDeepFRI import sharding, synthetic
+    out = {}
+    for name in ([args.workload] if args.workload in STRONG else list(STRONG)):
+        total, seed = STRONG[name]
+        total = args.proteins or total
+        lengths = synthetic.uniform_lengths(seed, total) if name == "configs3" else synthetic.histogram_lengths(seed, total)
+        t0 = time.perf_counter()
+        plan = sharding.plan_summary(lengths, args.gpus, args.chunk_rows)
+        plan["plan_seconds"] = round(time.perf_counter() - t0, 3)
+        plan["imbalance"] = round(plan["imbalance"], 6)
+        out[name] = plan
+    print(json.dumps({"dry_plan": out, "gpus": args.gpus, "chunk_rows": args.chunk_rows}), flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_worker:
         return cpu_worker(args.cpu_worker)
+    if args.dry_plan:
+        return dry_plan(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
 
@@ -441,7 +474,7 @@ def main():
     if args.workload == "cnn":
         return bench_cnn(args, ctx, local_rank)
 
-    weights = make_weights(args.lm)
+    weights = make_weights(args.lm, sparse_scores=args.workload in STRONG)
     preds = {m: Predictor(f"synthetic-{m}", weights=weights[m], device=local_rank) for m in MODES}
     T_total = sum(p.n_terms for p in preds.values())
     eng = batch.HotPathEngine(preds, device=local_rank, max_rows=args.chunk_rows)
@@ -453,7 +486,7 @@ def main():
         total = args.proteins or total
         lengths = synthetic.uniform_lengths(seed, total) if args.workload == "configs3" else synthetic.histogram_lengths(seed, total)
         mine = sharding.partition_by_cost(lengths, ctx.world)[ctx.rank]    # sorted by length inside the shard (pipeline.py:529)
-        cols = synthetic.bulk_proteins(seed, lengths, mine, indel_rate=0.05)
+        cols = synthetic.bulk_proteins(seed, lengths, mine, indel_rate=0.05, workers=min(32, max(1, (os.cpu_count() or 1) // ctx.world)))
         n_local, n_job = len(mine), total
         plans = {m: sharding.FilteredGatherPlan(mine, total, dev, dst=0) for m in MODES}
         gathered = {}
@@ -480,9 +513,21 @@ def main():
     pk = batch.PackedProteins.pack(seqs, coords, q_alns, t_alns, max_rows=args.chunk_rows)
     db = eng.upload(pk)
 
+    # who is in the job: device name per rank and the world size as the backend reports it
+    me = f"rank {ctx.rank}: {torch.cuda.get_device_name(dev)} (cuda:{local_rank})"
+    if ctx.world > 1:
+        names = [None] * ctx.world
+        dist.all_gather_object(names, me)
+        rank_info = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": names}
+    else:
+        rank_info = {"world_size": 1, "backend": None, "devices": [me]}
+
     timing_period = 0 if args.no_kernel_timing else args.timing_period
     elapsed, out = timed_run(ctx, eng, db, args.steps, args.warmup, after=after, timing_period=timing_period)
 
+    if strong:
+        for m in MODES:
+            plans[m].check()      # a rank that outgrew the planned payload in the last step is raised on every rank here
     if ctx.rank == 0:
         kernels = read_kernels(ctx, ("gemm", "gemm1", "ax", "cmap", "head") + (("lstm", "lstm2", "embed") if args.lm else ())) if timing_period else {}
         roof, roof_ax = rooflines(ctx, eng, pk, kernels, args.lm)
@@ -519,7 +564,15 @@ def main():
             "kernels": kernels,
         }
         if strong:
-            line["gathered_survivors"] = {m: int(gathered[m][1].numel()) for m in MODES}
+            surv = {m: int(gathered[m][1].numel()) for m in MODES}
+            line["gathered_survivors"] = surv
+            line["gathered_survivors_per_protein"] = {m: round(surv[m] / n_job, 2) for m in MODES}
+            line["survivor_fraction"] = {m: round(surv[m] / (n_job * preds[m].n_terms), 4) for m in MODES}
+            # what the step's gathers move into rank 0: 8 B per surviving (term, score) pair + 8 B per protein of counts
+            line["gather_bytes_per_step"] = {"filtered": int(8 * sum(surv.values()) + 8 * n_job * len(MODES)), "dense_equivalent": int(4 * n_job * T_total)}
+        elif ctx.world > 1:
+            line["gather_bytes_per_step"] = {"dense": int(4 * n_job * T_total)}
+        line["ranks"] = rank_info
         if args.verify > 0:
             line["verify"] = verify(seqs, coords, q_alns, t_alns, weights, out, args.verify, args.lm)
             if strong:   # and what rank 0 holds after the gather == filtering rank 0's own scores (its proteins sit at `mine`)

@@ -80,13 +80,21 @@ def glorot_uniform(rng: np.random.Generator, fan_in: int, fan_out: int) -> np.nd
 
 
 def glorot_gcn_weights(seed: int = 0, n_terms: int = 489, embed: int = 1024, gc_dims=(512, 512, 512),
-                       fc_dim: int = 1024, fc_gain: float = 0.1) -> dict:
+                       fc_dim: int = 1024, fc_gain: float = 0.1, sparse_scores: bool = False) -> dict:
     """Random-init DeepFRI GCN weights (fp32).  Keys are the ones mDeepFRI.weights reads and writes.
 
     `fc_gain` scales the Glorot draw of W_fc: the sum-pooled features grow linearly with the protein
     length, and with untrained unit-gain weights the pair-softmax saturates to exactly 0/1 beyond
     L~256, which would make an absolute 1e-4 score check vacuous.  0.1 keeps |logit| ~ 2-8 for
-    L = 256-1024, the regime trained heads operate in."""
+    L = 256-1024, the regime trained heads operate in.
+
+    `sparse_scores`: give the output layer the operating point of a TRAINED head -- most GO terms are off for most proteins.
+    The score of term t is sigmoid(z[2t] - z[2t+1]); with Glorot weights and +-0.05 biases the difference is centred on 0
+    (std ~ 0.0022 L), so 84-100 % of all terms pass the results.tsv filter `score >= 0.1` (reference pipeline.py:696-705)
+    and a "filtered" gather carries MORE bytes than the dense one.  The switch adds a per-term prior N(9, 3^2) to the bias of
+    channel 1 (drawn from its own generator: every other weight is unchanged): the pass rate becomes
+    Phi(-(9 - 2.197) / sqrt(9 + (0.0022 L)^2)) = 1.2 % at L = 128, 1.7 % at L = 512, 3.5 % at L = 1024 -- a few dozen terms
+    per protein, different ones per protein.  Used by bench.py's configs3 / configs4 and tools/pipeline_example.py."""
     rng = np.random.default_rng(seed)
     w = {"W_aa": glorot_uniform(rng, 26, embed)}
     prev = embed
@@ -97,6 +105,9 @@ def glorot_gcn_weights(seed: int = 0, n_terms: int = 489, embed: int = 1024, gc_
     w["b_fc"] = rng.uniform(-0.05, 0.05, size=(fc_dim,)).astype(np.float32)
     w["W_out"] = glorot_uniform(rng, fc_dim, 2 * n_terms)
     w["b_out"] = rng.uniform(-0.05, 0.05, size=(2 * n_terms,)).astype(np.float32)
+    if sparse_scores:
+        prior = np.random.default_rng([int(seed), 0x5A]).normal(9.0, 3.0, size=n_terms).astype(np.float32)
+        w["b_out"][1::2] += prior
     return w
 
 
@@ -214,9 +225,27 @@ def bulk_protein(seed: int, index: int, length: int, indel_rate: float = 0.0):
     return seq, coords, q_aln, t_aln
 
 
-def bulk_proteins(seed: int, lengths, indices, indel_rate: float = 0.0):
-    """Columns (seqs, coords, q_alns, t_alns) for the proteins `indices` of a workload whose lengths are `lengths`."""
+def _bulk_slice(job):
+    seed, idx, lens, indel_rate = job
+    return [bulk_protein(seed, i, l, indel_rate) for i, l in zip(idx, lens)]
+
+
+def bulk_proteins(seed: int, lengths, indices, indel_rate: float = 0.0, workers: int = 0):
+    """Columns (seqs, coords, q_alns, t_alns) for the proteins `indices` of a workload whose lengths are `lengths`.
+    workers > 1: generated by that many SPAWNED worker processes (every protein has its own seeded generator, so the result
+    does not depend on it); to be called before the calling process needs its cores for anything else."""
+    indices = list(indices)
     cols = ([], [], [], [])
+    if workers > 1 and len(indices) >= 4096:
+        import multiprocessing as mp
+        step = 2048
+        jobs = [(seed, indices[k:k + step], [int(lengths[i]) for i in indices[k:k + step]], indel_rate) for k in range(0, len(indices), step)]
+        with mp.get_context("spawn").Pool(workers) as pool:
+            for part in pool.imap(_bulk_slice, jobs):
+                for prot in part:
+                    for c, x in zip(cols, prot):
+                        c.append(x)
+        return cols
     for i in indices:
         for c, x in zip(cols, bulk_protein(seed, i, lengths[i], indel_rate)):
             c.append(x)

@@ -26,3 +26,15 @@ def test_cpu_worker_runs_the_oracle_chain():
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["n"] >= 2 and out["t"] > 0
+
+
+def test_dry_plan_prints_the_deal_of_the_strong_workloads():
+    """`bench.py --gpus 8 --dry-plan`: CPU only, one JSON line, predicted imbalance of the padded rows below 1 % for both
+    BASELINE configs (the same lengths and seeds the timed run uses)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--dry-plan"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    plan = json.loads(r.stdout.strip().splitlines()[-1])["dry_plan"]
+    assert set(plan) == {"configs3", "configs4"}
+    assert sum(plan["configs3"]["proteins"]) == 100_000 and sum(plan["configs4"]["proteins"]) == 500_000
+    for p in plan.values():
+        assert p["world"] == 8 and p["imbalance"] < 0.01 and p["plan_seconds"] < 30

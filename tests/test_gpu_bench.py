@@ -48,6 +48,25 @@ def test_bare_python_launches_two_ranks_strong_filtered(workload, count):
     assert all(v > 0 for v in line["gathered_survivors"].values())
 
 
+@pytest.mark.parametrize("workload,count,floor", [("configs3", 100_000, 15_000), ("configs4", 500_000, 25_000)])
+def test_strong_workloads_at_full_size_one_gpu(workload, count, floor):
+    """BASELINE.json configs[3] (100 000 mixed-length proteins) and configs[4] (500 000, proteome length histogram) at their STATED
+    size on one GPU: contact-map alignment + three GO heads + GPU filter + the filtered gather plan (degenerate at N = 1), one
+    timed step.  Heads at the operating point of trained ones (sparse_scores): the survivors are a few per cent of the terms,
+    so the gathered payload is what the workload advertises -- far below the dense one.  The floors are ~1/3 of the rates
+    measured in round 3 (profiles/r03_bench_configs{3,4}_n1.json)."""
+    line = _run("--workload", workload, "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--verify", "6", timeout=1500)
+    assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["proteins_total"] == count
+    assert line["metric"] == f"proteins/sec (GCN+cmap), {workload}"
+    assert line["verify"]["max_abs_err_vs_oracle"] < 1e-4 and line["verify"]["gather_restores_input_order"] is True
+    assert line["value"] > floor, line["value"]
+    for m, frac in line["survivor_fraction"].items():
+        assert 0.002 < frac < 0.08, (m, frac)                 # compacted: a few per cent of the terms, not 90 %
+    g = line["gather_bytes_per_step"]
+    assert g["filtered"] < 0.25 * g["dense_equivalent"], g
+    assert line["ranks"]["world_size"] == 1 and "cuda:0" in line["ranks"]["devices"][0]
+
+
 def test_too_many_ranks_for_the_devices_is_refused():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run([sys.executable, BENCH, "--gpus", "64", "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=300)

@@ -161,6 +161,61 @@ def test_fused_batch_vs_oracle_and_per_call(mf, cc):
         assert np.array_equal(s_mf[i], pm.forward_pass(p["seq"], cm)), i
 
 
+@pytest.fixture(scope="module")
+def bp():
+    from mDeepFRI.predict import Predictor
+    w = synthetic.glorot_gcn_weights(seed=1, n_terms=synthetic.GO_TERMS["bp"])
+    return w, Predictor("synthetic-bp.onnx", weights=w)
+
+
+@pytest.mark.parametrize("threshold,gen", [(10.0, 2), (4.0, 0), (8.0, 5)])
+def test_fused_batch_at_other_thresholds_and_generated_contacts(mf, threshold, gen):
+    """The released GCN files are trained on 10 A maps (`..._ca_10.0_...`, reference mDeepFRI/__init__.py:73,78) while the CLI's
+    default is 6 A / generated_contacts 2 (cli.py:360-371): the fused batched path (k_cmap_rows<COUNT> + k_cmap_fill -> CSR ->
+    GraphConv) at three other (threshold, generated_contacts) settings vs the oracle chain, with indels so that synthetic
+    contacts exist, several chunks, and the CSR capacity retry (10 A gives ~40 entries per row; nnz_per_row starts at 8)."""
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    w, pred = mf
+    prots = synthetic.synthetic_proteins(seed=int(threshold) * 10 + gen, count=18, length=(20, 330), indel_rate=0.12)
+    eng = HotPathEngine({"mf": pred}, device=0, max_rows=1024, nnz_per_row=8, threshold=threshold, generated_contacts=gen)
+    pk = PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots],
+                             [p["t_aln"] for p in prots], max_rows=1024)
+    assert len(pk.chunks) > 2
+    out = eng.run_alignments(pk)["mf"]
+    n_syn = 0
+    for i, p in enumerate(prots):
+        cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], threshold, gen)
+        n_syn += int(cm.sum() - orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], threshold, 0).sum())
+        assert np.max(np.abs(out[i] - gcn_oracle.gcn_forward(w, p["seq"], cm))) < TOL, (i, len(p["seq"]))
+        assert np.array_equal(out[i], pred.forward_pass(p["seq"], cm)), i            # batch == per call, bitwise
+    assert (n_syn > 0) == (gen > 0)
+
+
+@pytest.mark.parametrize("L", [1, 33, 128, 512, 1024])
+def test_bp_sized_head_vs_oracle(bp, L):
+    """The biological-process head: T = 1 943 terms -> 3 886 output columns, padded to 4 096 inside the library (the widest GO head
+    of the v1.0 models, reference mDeepFRI/__init__.py:47-80); per call and inside a fused batch, both vs the oracle."""
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    w, pred = bp
+    assert pred.n_terms == 1943
+    p = synthetic.synthetic_proteins(seed=900 + L, count=1, length=L, indel_rate=0.05 if L > 8 else 0.0)[0]
+    cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
+    ref = gcn_oracle.gcn_forward(w, p["seq"], cm)
+    y = pred.forward_pass(p["seq"], cm)
+    assert y.shape == (1943,) and y.dtype == np.float32
+    assert np.max(np.abs(y - ref)) < TOL
+    eng = HotPathEngine({"bp": pred}, device=0, max_rows=4096)
+    others = synthetic.synthetic_proteins(seed=901 + L, count=5, length=(10, 200))
+    prots = others[:2] + [p] + others[2:]
+    pk = PackedProteins.pack([q["seq"] for q in prots], [q["coords"] for q in prots], [q["q_aln"] for q in prots], [q["t_aln"] for q in prots],
+                             max_rows=4096)
+    out = eng.run_alignments(pk)["bp"]
+    assert np.array_equal(out[2], y)                                                    # company-invariant, bitwise
+    for i, q in enumerate(prots):
+        cmq = orc.build_align_contact_map(q["coords"], q["q_aln"], q["t_aln"], 6.0, 2)
+        assert np.max(np.abs(out[i] - gcn_oracle.gcn_forward(w, q["seq"], cmq))) < TOL, i
+
+
 def test_fused_batch_on_protein_like_traces(mf):
     """The same chain on helix-bundle traces (~8.6 entries per CSR row instead of ~12.6) with indels: contact
     maps bit-exact with the oracle's, scores within the budget, batch == per call."""

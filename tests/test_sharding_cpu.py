@@ -27,10 +27,10 @@ def test_partition_covers_everything_and_balances():
 
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_dry_plan_of_the_sharded_baseline_configs_is_balanced(world):
-    """BASELINE configs[3] (100 000 proteins, L ~ U{128..1024}, seed 4) and configs[4] (500 000, length histogram): predicted
+    """BASELINE configs[3] (100 000 proteins, L ~ U{128..1024}) and configs[4] (500 000, length histogram): predicted
     imbalance of the padded rows below 1 % at every rank count the driver will launch (`bench.py --gpus N --dry-plan`)."""
     from mDeepFRI import synthetic
-    for lengths in (np.random.default_rng(4).integers(128, 1025, size=100_000), synthetic.histogram_lengths(46, 500_000)):
+    for lengths in (synthetic.uniform_lengths(46, 100_000), synthetic.histogram_lengths(47, 500_000)):   # bench.py's seeds
         plan = sharding.plan_summary(lengths, world)
         assert sum(plan["proteins"]) == len(lengths) and plan["world"] == world
         assert plan["imbalance"] < 0.01, plan
