@@ -363,8 +363,7 @@ def rooflines(ctx, eng, pk, kernels, lm):
     if a.get("launches"):
         # read Z (rows x 512 f32) once + write (rows x 512 f32) once per layer; CSR adjacency (4 B colidx
         # + 4 B val per entry + 4 B rowptr per row) added and stated
-        rp = eng._bufs["rowptr"]
-        nnz_per_row = float(rp[pk.chunks[-1].rows].item()) / float(pk.chunks[-1].rows)
+        nnz_per_row = float(eng.last_chunk_nnz()) / float(pk.chunks[-1].rows)
         bytes_row = 2 * 4 * C + 4 + 8 * nnz_per_row
         gbs = bytes_row * rows_launch / (a["avg_us"] * 1e-6) / 1e9
         roof_ax = {"kernel": "k_aggregate<512> (A.X, CSR gather, one wave per residue row)", "bound": "hbm", "achieved": round(gbs, 1),

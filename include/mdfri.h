@@ -130,6 +130,7 @@ int mdf_model_num_terms(const mdf_model *m);
 int mdf_model_feature_dim(const mdf_model *m); /* sum(gc_dims): width of the pooled feature vector */
 int mdf_model_device(const mdf_model *m);
 int mdf_model_lm_dim(const mdf_model *m);      /* 0: no language-model branch */
+struct mdf_lm *mdf_model_lm(const mdf_model *m); /* the attached language model (mdf_model_attach_lm), or NULL */
 
 /* ------------------------------------------------------------------------------------------------
  * LSTM language model feeding the GCN embedding of the released DeepFRI models.  The reference has no
@@ -292,6 +293,108 @@ int mdf_gcn_pool_dev(mdf_model *m, const float *partial, const int32_t *grp_off,
 size_t mdf_head_workspace_bytes(const mdf_model *m, int32_t B);
 int mdf_gcn_head_dev(mdf_model *m, const float *pooled, int32_t B, float *scores, float *logits,
                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Batch engine: the whole batched hot path behind ONE call (`mdf_cmap_batch` /
+ * `mdf_gcn_forward_batch`) -- the counterpart of pipeline.py:476-481 Pool.map(build_align_contact_map) followed by
+ * pipeline.py:292-319 _run_prediction_loop, for B proteins and several GO heads at once.  The planner that cuts a batch
+ * into chunks of residue rows, the per-chunk launch sequence (encode -> fused contact map/CSR -> GraphConv stack per head ->
+ * pooling) and the GO heads run inside the library; a consumer of this header needs no other entry point.
+ * An engine serialises its work on the stream it is called with and owns its device workspaces (grown on demand,
+ * never shrunk); use one engine per stream / thread.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* --- planner (host only; needs no GPU) ---
+ * Proteins stay in input order.  A CHUNK is a run of consecutive proteins whose padded rows (32 per protein, see the
+ * residue-row layout above) fit `max_rows`; a SEGMENT is a run of chunks whose per-32-row pool partials share one array
+ * (at most max_segment_groups 32-row groups).  An immutable plan may be shared by any number of batches of the same
+ * lengths. */
+typedef struct mdf_plan mdf_plan;
+int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, int32_t max_segment_groups, mdf_plan **out);
+void mdf_plan_free(mdf_plan *plan);
+int32_t mdf_plan_num_proteins(const mdf_plan *plan);
+int32_t mdf_plan_num_chunks(const mdf_plan *plan);
+int32_t mdf_plan_num_segments(const mdf_plan *plan);
+int64_t mdf_plan_max_chunk_rows(const mdf_plan *plan);
+/* chunk table, n_chunks x 6 int64: p0, p1 (proteins [p0, p1)), rows (R of the chunk), row_off_pos (start of the chunk's
+ * p1-p0+1 row offsets in the row-offset array), segment, group_base (first 32-row group of the chunk in its segment) */
+int mdf_plan_chunks(const mdf_plan *plan, int64_t *out);
+/* segment table, n_segments x 4 int64: p0, p1, groups, grp_off_pos */
+int mdf_plan_segments(const mdf_plan *plan, int64_t *out);
+/* host arrays owned by the plan: row offsets of all chunks (B + n_chunks entries), group offsets of all segments
+ * (B + n_segments entries); *count receives the length */
+const int32_t *mdf_plan_chunk_row_off(const mdf_plan *plan, int64_t *count);
+const int32_t *mdf_plan_grp_off(const mdf_plan *plan, int64_t *count);
+
+/* --- engine --- */
+typedef struct mdf_engine mdf_engine;
+typedef struct {
+    int32_t max_rows;            /* residue rows per fused chunk; 0 = 65536 (multiples of 32768 are whole rounds of GEMM tiles) */
+    int32_t nnz_per_row;         /* initial CSR capacity per residue row; 0 = 40 (6 A maps hold ~13, 10 A maps ~40) */
+    double threshold;            /* contact threshold in Angstrom (cli.py:360-371 default 6.0) */
+    int32_t generated_contacts;  /* contact_map_utils.pyx:44 generated_contacts (default 2) */
+    int32_t max_segment_groups;  /* 0 = 1 << 19 */
+    int32_t lm_batch;            /* proteins per LSTM group for heads with a language model; 0 = 8192 */
+    double lm_workspace_gib;     /* LSTM time-major workspace budget; 0 = 48 */
+    int32_t graph_max_chunks;    /* batches of at most this many chunks replay their launch sequence as ONE hipGraph from the
+                                    third identical call on (same plan, buffers and outputs); 0 = 8, negative = never */
+} mdf_engine_config;
+/* models: n GO heads (GCN models of one device; heads with a language model must have it attached, mdf_model_attach_lm).
+ * The models are not owned and must outlive the engine.  cfg may be NULL (all defaults, threshold 6.0, 2 generated contacts). */
+int mdf_engine_create(mdf_model *const *models, int32_t n_models, int device, const mdf_engine_config *cfg, mdf_engine **out);
+void mdf_engine_free(mdf_engine *e);
+/* Raise the CSR capacity per row (after MDF_ECAPACITY from mdf_engine_check). */
+int mdf_engine_set_nnz_per_row(mdf_engine *e, int32_t nnz_per_row);
+int64_t mdf_engine_nnz_capacity(const mdf_engine *e);   /* CSR entries the current buffers hold (0 before the first call) */
+
+/* One batch resident on the device (all pointers DEVICE memory owned by the caller, int32 descriptors as in the
+ * residue-row layout above; the plan's own arrays are uploaded by the engine).  coords .. aln_off may be NULL for
+ * batches that only ever take the dense-map path. */
+typedef struct {
+    int32_t B;
+    const char *seqs;            /* packed query sequences */
+    const int32_t *seq_off;      /* (B+1) */
+    const int32_t *Lq;           /* (B) */
+    const float *coords;         /* packed (sum Lt, 3) */
+    const int32_t *coord_off;    /* (B+1) */
+    const char *q_aln, *t_aln;   /* packed gapped strings */
+    const int32_t *aln_off;      /* (B+1) */
+    int32_t *status;             /* (n_chunks, 4) zero-initialised by the caller: see mdf_cmap_csr_dev */
+    int64_t *bad;                /* (n_chunks) initialised to -1 by the caller: see mdf_seq_encode_dev */
+} mdf_batch_dev;
+
+/* The fused path: C-alpha coordinates + gapped alignments + sequences -> GO scores of every head.
+ * scores[k]: DEVICE (B, T_k) f32 of head k (order of mdf_engine_create); logits: NULL, or per head NULL / DEVICE (B, 2 T_k).
+ * Asynchronous on `stream`; call mdf_engine_check before trusting the result. */
+int mdf_engine_forward_alignments(mdf_engine *e, const mdf_plan *plan, const mdf_batch_dev *batch, float *const *scores,
+                                  float *const *logits, void *stream);
+/* The reference-format path: one dense (Lq,Lq) contact map per protein (what build_align_contact_map returns) in HOST
+ * memory, all of cmap_dtype (MDF_DT_I32 or MDF_DT_F32), uploaded chunk by chunk.  Synchronises `stream` before returning. */
+int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *plan, const mdf_batch_dev *batch, const void *const *cmaps_host,
+                             int cmap_dtype, float *const *scores, float *const *logits, void *stream);
+/* Synchronise `stream` and report what the asynchronous stages flagged, in the order the per-call API would raise it:
+ * MDF_EBADCHAR  -- info[0] = protein, info[1] = position of the FIRST invalid residue of the batch (predict.pyx:36-46);
+ * MDF_EINVAL    -- a query longer than the contact stage was sized for (info[2] = its length);
+ * MDF_ECAPACITY -- CSR overflow, info[3] = entries the fullest chunk needs (raise mdf_engine_set_nnz_per_row and re-run with
+ *                  re-initialised flags).  info may be NULL. */
+int mdf_engine_check(mdf_engine *e, const mdf_plan *plan, const mdf_batch_dev *batch, void *stream, int64_t info[4]);
+/* Language-model features (LSTM2 output) of every protein, packed (sum Lq, H) f32 in HOST memory, for LM `which` of the
+ * engine's distinct language models -- inspection and tests. */
+int mdf_engine_lm_features_host(mdf_engine *e, const mdf_plan *plan, const mdf_batch_dev *batch, int32_t which, float *out,
+                                void *stream);
+int32_t mdf_engine_num_lms(const mdf_engine *e);
+/* Diagnostic: forward calls replayed as a hipGraph / issued launch by launch since the engine was made. */
+int mdf_engine_graph_stats(const mdf_engine *e, int64_t *graph_launches, int64_t *eager_runs);
+/* Diagnostic: synchronise `stream` and return the CSR entries of the chunk processed last (rowptr[R]); negative = error. */
+int64_t mdf_engine_last_chunk_nnz(mdf_engine *e, void *stream);
+
+/* Everything in one call with HOST buffers: plan, upload, fused forward, validation (one automatic retry with a larger
+ * CSR capacity), download.  seqs / q_aln / t_aln are packed byte strings with per-protein lengths Lq / La / La; coords is
+ * packed (sum Lt, 3) f32.  scores_host[k]: (B, T_k) f32.  Errors as mdf_engine_check (info may be NULL).
+ * This is the single-call batched entry SURVEY.md section 8b lists (mdf_cmap_batch + mdf_gcn_forward_batch). */
+int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords,
+                                   const int32_t *Lt, const char *q_aln, const char *t_aln, const int32_t *La,
+                                   float *const *scores_host, int64_t info[4]);
 
 /* Output stage next to the path (mDeepFRI/pipeline.py:696-705, 733-740: results.tsv keeps, per protein, the terms with
  * float(score) >= 0.1 sorted by score descending; Python's sort is stable, so equal scores keep term order).

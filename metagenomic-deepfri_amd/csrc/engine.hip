@@ -1,0 +1,1009 @@
+// engine.hip -- the batch engine behind the C ABI (include/mdfri.h, "Batch engine"): planner + per-chunk launch sequence + GO
+// heads for B proteins and several heads at once.  The counterpart of reference pipeline.py:476-481
+// (Pool.map(build_align_contact_map)) followed by pipeline.py:292-319 (_run_prediction_loop); SURVEY.md section 8b's
+// `mdf_cmap_batch` / `mdf_gcn_forward_batch`.  No kernels here: the stages are the device entry points of cmap.hip / gcn.hip,
+// strung together in C++ so that a consumer of the header needs nothing else, and so that a short launch sequence can be
+// replayed as one hipGraph.
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <functional>
+#include <numeric>
+#include <vector>
+
+#include "common.h"
+
+using namespace mdf;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------------------------------
+struct PlanChunk {
+    int32_t p0, p1;
+    int64_t rows, row_off_pos;
+    int32_t segment;
+    int64_t group_base;
+    int32_t max_len;   // longest query of the chunk: sizes the contact-bit words of ITS rows
+};
+struct PlanSegment {
+    int32_t p0, p1;
+    int64_t groups, grp_off_pos;
+};
+// proteins of consecutive chunks [c0, c1) that run through the LSTM together (heads with a language model)
+struct LmGroup {
+    int32_t c0, c1;
+    std::vector<int64_t> bases;      // first row of each chunk inside the group's row space, + total
+    std::vector<int32_t> lens_host;  // lengths in non-increasing order
+    int32_t B, Lmax;
+    size_t rows_pos, lens_pos;       // element offsets of this group's arrays in the plan's device mirror
+};
+
+struct mdf_plan {
+    uint64_t serial = 0;
+    int32_t B = 0, max_rows = 0, max_segment_groups = 0, max_len = 0;
+    int64_t max_chunk_rows = 0, max_groups = 0;
+    std::vector<int32_t> Lq, chunk_row_off, grp_off;
+    std::vector<PlanChunk> chunks;
+    std::vector<PlanSegment> segments;
+    // device mirror (created by the first engine call that uses the plan; one device per plan)
+    mutable std::mutex mu;
+    mutable int device = -1;
+    mutable int32_t *d_chunk_row_off = nullptr, *d_grp_off = nullptr;
+    // LSTM grouping, keyed by the engine parameters it depends on
+    mutable int64_t lm_key[3] = {-1, -1, -1};
+    mutable std::vector<LmGroup> lm_groups;
+    mutable int64_t *d_lm_rows = nullptr;
+    mutable int32_t *d_lm_lens = nullptr;
+};
+
+static std::atomic<uint64_t> g_plan_serial{1};
+
+static void close_segment(mdf_plan *pl, const std::vector<int> &ids, int64_t groups)
+{
+    const PlanChunk &first = pl->chunks[ids.front()], &last = pl->chunks[ids.back()];
+    PlanSegment sg{first.p0, last.p1, groups, (int64_t)pl->grp_off.size()};
+    const size_t base = pl->grp_off.size();
+    pl->grp_off.resize(base + (size_t)(last.p1 - first.p0) + 1);
+    for (int ci : ids) {
+        const PlanChunk &ch = pl->chunks[ci];
+        const int32_t *ro = pl->chunk_row_off.data() + ch.row_off_pos;
+        for (int32_t p = ch.p0; p < ch.p1; ++p) pl->grp_off[base + (size_t)(p - first.p0)] = (int32_t)(ch.group_base + ro[p - ch.p0] / 32);
+    }
+    pl->grp_off[base + (size_t)(last.p1 - first.p0)] = (int32_t)groups;
+    pl->segments.push_back(sg);
+}
+
+extern "C" int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, int32_t max_segment_groups, mdf_plan **out)
+{
+    MDF_REQUIRE(Lq && out, "plan_create: NULL argument");
+    MDF_REQUIRE(B > 0, "plan_create: empty batch");
+    if (max_rows <= 0) max_rows = 65536;
+    if (max_segment_groups <= 0) max_segment_groups = 1 << 19;
+    for (int32_t p = 0; p < B; ++p) MDF_REQUIRE(Lq[p] > 0, "plan_create: empty sequence in batch (protein %d)", p);
+    auto *pl = new mdf_plan();
+    pl->serial = g_plan_serial.fetch_add(1);
+    pl->B = B;
+    pl->max_rows = max_rows;
+    pl->max_segment_groups = max_segment_groups;
+    pl->Lq.assign(Lq, Lq + B);
+    int32_t p0 = 0;
+    while (p0 < B) {
+        int32_t p1 = p0, ml = 0;
+        int64_t rows = 0;
+        while (p1 < B) {
+            const int64_t pad = ((int64_t)Lq[p1] + 31) / 32 * 32;
+            if (p1 != p0 && rows + pad > max_rows) break;
+            rows += pad;
+            ml = std::max(ml, Lq[p1]);
+            ++p1;
+        }
+        PlanChunk ch{};
+        ch.p0 = p0;
+        ch.p1 = p1;
+        ch.row_off_pos = (int64_t)pl->chunk_row_off.size();
+        ch.max_len = ml;
+        pl->chunk_row_off.resize(pl->chunk_row_off.size() + (size_t)(p1 - p0) + 1);
+        const int64_t R = mdf_layout_rows(Lq + p0, p1 - p0, pl->chunk_row_off.data() + ch.row_off_pos);
+        if (R < 0) {
+            delete pl;
+            return (int)R;
+        }
+        ch.rows = R;
+        pl->chunks.push_back(ch);
+        pl->max_chunk_rows = std::max(pl->max_chunk_rows, R);
+        pl->max_len = std::max(pl->max_len, ml);
+        p0 = p1;
+    }
+    // pooling segments: protein p's 32-row groups are [grp_off[p], grp_off[p+1]) inside its segment's partial array
+    std::vector<int> cur;
+    int64_t seg_groups = 0;
+    for (int ci = 0; ci < (int)pl->chunks.size(); ++ci) {
+        PlanChunk &ch = pl->chunks[ci];
+        const int64_t g = ch.rows / 32;
+        if (!cur.empty() && seg_groups + g > max_segment_groups) {
+            close_segment(pl, cur, seg_groups);
+            pl->max_groups = std::max(pl->max_groups, seg_groups);
+            cur.clear();
+            seg_groups = 0;
+        }
+        ch.segment = (int32_t)pl->segments.size();
+        ch.group_base = seg_groups;
+        cur.push_back(ci);
+        seg_groups += g;
+    }
+    close_segment(pl, cur, seg_groups);
+    pl->max_groups = std::max(pl->max_groups, seg_groups);
+    if (pl->max_groups >= 0x7fffffffLL) {
+        delete pl;
+        return fail(MDF_EINVAL, "plan_create: a pooling segment of %lld groups does not fit int32", (long long)seg_groups);
+    }
+    *out = pl;
+    return MDF_OK;
+}
+
+extern "C" void mdf_plan_free(mdf_plan *pl)
+{
+    if (!pl) return;
+    if (pl->d_chunk_row_off || pl->d_lm_rows) {
+        DeviceGuard g(pl->device);
+        (void)hipFree(pl->d_chunk_row_off);   // one allocation holds both mirrors
+        (void)hipFree(pl->d_lm_rows);
+    }
+    delete pl;
+}
+
+extern "C" int32_t mdf_plan_num_proteins(const mdf_plan *pl) { return pl ? pl->B : 0; }
+extern "C" int32_t mdf_plan_num_chunks(const mdf_plan *pl) { return pl ? (int32_t)pl->chunks.size() : 0; }
+extern "C" int32_t mdf_plan_num_segments(const mdf_plan *pl) { return pl ? (int32_t)pl->segments.size() : 0; }
+extern "C" int64_t mdf_plan_max_chunk_rows(const mdf_plan *pl) { return pl ? pl->max_chunk_rows : 0; }
+
+extern "C" int mdf_plan_chunks(const mdf_plan *pl, int64_t *out)
+{
+    MDF_REQUIRE(pl && out, "plan_chunks: NULL argument");
+    for (size_t c = 0; c < pl->chunks.size(); ++c) {
+        const PlanChunk &ch = pl->chunks[c];
+        int64_t *o = out + 6 * c;
+        o[0] = ch.p0, o[1] = ch.p1, o[2] = ch.rows, o[3] = ch.row_off_pos, o[4] = ch.segment, o[5] = ch.group_base;
+    }
+    return MDF_OK;
+}
+
+extern "C" int mdf_plan_segments(const mdf_plan *pl, int64_t *out)
+{
+    MDF_REQUIRE(pl && out, "plan_segments: NULL argument");
+    for (size_t s = 0; s < pl->segments.size(); ++s) {
+        const PlanSegment &sg = pl->segments[s];
+        int64_t *o = out + 4 * s;
+        o[0] = sg.p0, o[1] = sg.p1, o[2] = sg.groups, o[3] = sg.grp_off_pos;
+    }
+    return MDF_OK;
+}
+
+extern "C" const int32_t *mdf_plan_chunk_row_off(const mdf_plan *pl, int64_t *count)
+{
+    if (!pl) return nullptr;
+    if (count) *count = (int64_t)pl->chunk_row_off.size();
+    return pl->chunk_row_off.data();
+}
+
+extern "C" const int32_t *mdf_plan_grp_off(const mdf_plan *pl, int64_t *count)
+{
+    if (!pl) return nullptr;
+    if (count) *count = (int64_t)pl->grp_off.size();
+    return pl->grp_off.data();
+}
+
+// the plan's two descriptor arrays on `device` (uploaded once, synchronously: a plan is made once per batch shape)
+static int plan_mirror(const mdf_plan *pl, int device)
+{
+    std::lock_guard<std::mutex> lk(pl->mu);
+    if (pl->d_chunk_row_off && pl->device == device) return MDF_OK;
+    if (pl->d_chunk_row_off || pl->d_lm_rows) {   // the plan moves to another device: drop the old mirror
+        DeviceGuard g(pl->device);
+        (void)hipFree(pl->d_chunk_row_off);
+        (void)hipFree(pl->d_lm_rows);
+        pl->d_chunk_row_off = nullptr;
+        pl->d_lm_rows = nullptr;
+        pl->lm_key[0] = -1;
+    }
+    const size_t n1 = pl->chunk_row_off.size(), n2 = pl->grp_off.size();
+    int32_t *d = nullptr;
+    MDF_HIP(hipMalloc(reinterpret_cast<void **>(&d), (n1 + n2) * 4 + 256));
+    if (hipMemcpy(d, pl->chunk_row_off.data(), n1 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + n1, pl->grp_off.data(), n2 * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return fail(MDF_ENODEVICE, "plan: upload of the descriptor arrays failed");
+    }
+    pl->d_chunk_row_off = d;
+    pl->d_grp_off = d + n1;
+    pl->device = device;
+    return MDF_OK;
+}
+
+// Consecutive chunk ranges whose proteins run through the LSTM together: at most `cap` proteins and a time-major workspace
+// (2 x (Lmax+1) x B x H floats) within `ws_bytes`.  The proteins are dealt evenly over the fewest such groups: an LSTM time
+// step costs whole rounds of 256x256 tiles, so a small trailing group would cost as much as a full one.
+static int plan_lm_groups(const mdf_plan *pl, int64_t lm_batch, int64_t ws_bytes, int64_t H)
+{
+    std::lock_guard<std::mutex> lk(pl->mu);
+    if (pl->lm_key[0] == lm_batch && pl->lm_key[1] == ws_bytes && pl->lm_key[2] == H && pl->d_lm_rows) return MDF_OK;
+    const int64_t cap = std::min<int64_t>(lm_batch, 65535);
+    const int nC = (int)pl->chunks.size();
+    int64_t n_groups = std::max<int64_t>(1, (pl->B + cap - 1) / cap);
+    std::vector<std::pair<int, int>> ranges;
+    for (;;) {
+        const int64_t target = (pl->B + n_groups - 1) / n_groups;
+        ranges.clear();
+        int c0 = 0;
+        int64_t nb = 0, lmax = 0;
+        for (int ci = 0; ci < nC; ++ci) {
+            const PlanChunk &ch = pl->chunks[ci];
+            const int64_t n = ch.p1 - ch.p0, l = ch.max_len;
+            if (ci > c0 && (nb + n > cap || nb >= target || 8 * (std::max(lmax, l) + 1) * (nb + n) * H > ws_bytes)) {
+                ranges.push_back({c0, ci});
+                c0 = ci, nb = 0, lmax = 0;
+            }
+            nb += n;
+            lmax = std::max(lmax, l);
+        }
+        ranges.push_back({c0, nC});
+        if ((int64_t)ranges.size() <= n_groups || n_groups >= nC) break;
+        n_groups = (int64_t)ranges.size();   // memory or chunk granularity forced more groups: re-balance for that count
+    }
+    pl->lm_groups.clear();
+    std::vector<int64_t> all_rows;
+    std::vector<int32_t> all_lens;
+    for (auto &rg : ranges) {
+        LmGroup g;
+        g.c0 = rg.first, g.c1 = rg.second;
+        g.bases.push_back(0);
+        for (int ci = g.c0; ci < g.c1; ++ci) g.bases.push_back(g.bases.back() + pl->chunks[ci].rows);
+        const int32_t P0 = pl->chunks[g.c0].p0, P1 = pl->chunks[g.c1 - 1].p1;
+        std::vector<int64_t> prot_row((size_t)(P1 - P0));
+        for (int ci = g.c0; ci < g.c1; ++ci) {
+            const PlanChunk &ch = pl->chunks[ci];
+            const int32_t *ro = pl->chunk_row_off.data() + ch.row_off_pos;
+            for (int32_t p = ch.p0; p < ch.p1; ++p) prot_row[(size_t)(p - P0)] = g.bases[(size_t)(ci - g.c0)] + ro[p - ch.p0];
+        }
+        std::vector<int32_t> order((size_t)(P1 - P0));
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return pl->Lq[(size_t)(P0 + a)] > pl->Lq[(size_t)(P0 + b)]; });
+        g.B = P1 - P0;
+        g.rows_pos = all_rows.size();
+        g.lens_pos = all_lens.size();
+        for (int32_t k : order) {
+            all_rows.push_back(prot_row[(size_t)k]);
+            all_lens.push_back(pl->Lq[(size_t)(P0 + k)]);
+            g.lens_host.push_back(pl->Lq[(size_t)(P0 + k)]);
+        }
+        g.Lmax = g.lens_host[0];
+        pl->lm_groups.push_back(std::move(g));
+    }
+    if (pl->d_lm_rows) (void)hipFree(pl->d_lm_rows);
+    pl->d_lm_rows = nullptr;
+    char *d = nullptr;
+    const size_t rb = align_up(all_rows.size() * 8, 256);
+    MDF_HIP(hipMalloc(reinterpret_cast<void **>(&d), rb + all_lens.size() * 4 + 256));
+    if (hipMemcpy(d, all_rows.data(), all_rows.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d + rb, all_lens.data(), all_lens.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return fail(MDF_ENODEVICE, "plan: upload of the LSTM group arrays failed");
+    }
+    pl->d_lm_rows = reinterpret_cast<int64_t *>(d);
+    pl->d_lm_lens = reinterpret_cast<int32_t *>(d + rb);
+    pl->lm_key[0] = lm_batch, pl->lm_key[1] = ws_bytes, pl->lm_key[2] = H;
+    return MDF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    // grow-only; a reallocation frees the old block (hipFree waits for the device, so nothing in flight reads it)
+    int grow(size_t need, uint64_t *generation, bool zero = false)
+    {
+        if (bytes >= need && p) return MDF_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        need = align_up(std::max<size_t>(need, 256), 256);
+        MDF_HIP(hipMalloc(&p, need));
+        if (zero) MDF_HIP(hipMemset(p, 0, need));
+        bytes = need;
+        if (generation) ++*generation;
+        return MDF_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T>
+    T *as() const { return static_cast<T *>(p); }
+};
+
+struct GraphEntry {
+    std::vector<uint64_t> key;
+    int seen = 0;            // calls with this key so far
+    bool disabled = false;   // capture failed once: stay eager
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t last_use = 0;
+};
+
+struct mdf_engine {
+    int device = 0;
+    std::vector<mdf_model *> models;
+    std::vector<mdf_lm *> lms;        // distinct attached language models
+    std::vector<int> model_lm;        // per model: index into lms, or -1
+    mdf_engine_config cfg{};
+    bool want_lsum = false;           // some head has no language model: it takes the folded layer-1 operand
+    int64_t lm_hidden_max = 0;
+    // workspaces
+    DevBuf rowptr, colidx, val, seq_idx, lsum, cws, gws, hws, seq_all, lm_ws, host_in, host_scores, map_dev[2], flags;
+    std::vector<DevBuf> partial, pooled, lm_h;
+    int64_t rows_alloc = 0, nnz_cap = 0;
+    int32_t len_alloc = 0;
+    uint64_t generation = 0;          // bumped by every reallocation: captured graphs refer to old addresses
+    std::mutex mu;
+    // pinned staging + events of the dense-map path
+    char *map_pin[2] = {nullptr, nullptr};
+    size_t map_pin_bytes[2] = {0, 0};
+    hipEvent_t map_ev[2] = {nullptr, nullptr};
+    // hipGraph cache (short launch sequences); captured on an engine-owned stream (the caller's may be the legacy default
+    // stream, which cannot be captured), replayed on the caller's
+    hipStream_t cap_stream = nullptr;
+    std::vector<GraphEntry> graphs;
+    uint64_t tick = 0;
+    int64_t graph_launches = 0, eager_runs = 0;
+    int64_t last_rows = 0;            // rows of the chunk whose CSR is in the buffers now
+};
+
+extern "C" int mdf_engine_create(mdf_model *const *models, int32_t n_models, int device, const mdf_engine_config *cfg, mdf_engine **out)
+{
+    MDF_REQUIRE(models && out && n_models > 0, "engine_create: at least one model is required");
+    if (int rc = require_device()) return rc;
+    auto *e = new mdf_engine();
+    e->device = device;
+    if (cfg) e->cfg = *cfg;
+    mdf_engine_config &c = e->cfg;
+    if (c.max_rows <= 0) c.max_rows = 65536;
+    if (c.nnz_per_row <= 0) c.nnz_per_row = 40;
+    if (!cfg) c.threshold = 6.0, c.generated_contacts = 2;
+    if (c.max_segment_groups <= 0) c.max_segment_groups = 1 << 19;
+    if (c.lm_batch <= 0) c.lm_batch = 8192;
+    if (c.lm_workspace_gib <= 0) c.lm_workspace_gib = 48.0;
+    if (c.graph_max_chunks == 0) c.graph_max_chunks = 8;
+    if (const char *g = getenv("MDFRI_ENGINE_GRAPH")) {   // developer knob: 0 = never replay graphs
+        if (atoi(g) == 0) c.graph_max_chunks = -1;
+    }
+    for (int32_t k = 0; k < n_models; ++k) {
+        mdf_model *m = models[k];
+        if (!m || mdf_model_device(m) != device) {
+            delete e;
+            return fail(MDF_EINVAL, "engine_create: model %d is NULL or lives on another device", k);
+        }
+        e->models.push_back(m);
+        int li = -1;
+        if (mdf_model_lm_dim(m) > 0) {
+            mdf_lm *lm = mdf_model_lm(m);
+            if (!lm) {
+                delete e;
+                return fail(MDF_EINVAL, "engine_create: model %d has a language-model branch but no language model attached", k);
+            }
+            for (size_t i = 0; i < e->lms.size(); ++i)
+                if (e->lms[i] == lm) li = (int)i;
+            if (li < 0) {
+                li = (int)e->lms.size();
+                e->lms.push_back(lm);
+                e->lm_hidden_max = std::max<int64_t>(e->lm_hidden_max, mdf_lm_hidden(lm));
+            }
+        } else {
+            e->want_lsum = true;
+        }
+        e->model_lm.push_back(li);
+    }
+    e->partial.resize(e->models.size());
+    e->pooled.resize(e->models.size());
+    e->lm_h.resize(e->lms.size());
+    *out = e;
+    return MDF_OK;
+}
+
+static void drop_graphs(mdf_engine *e)
+{
+    for (auto &g : e->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    e->graphs.clear();
+}
+
+extern "C" void mdf_engine_free(mdf_engine *e)
+{
+    if (!e) return;
+    DeviceGuard g(e->device);
+    (void)hipDeviceSynchronize();
+    drop_graphs(e);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    for (DevBuf *b : {&e->rowptr, &e->colidx, &e->val, &e->seq_idx, &e->lsum, &e->cws, &e->gws, &e->hws, &e->seq_all, &e->lm_ws, &e->host_in,
+                      &e->host_scores, &e->map_dev[0], &e->map_dev[1], &e->flags})
+        b->release();
+    for (auto &b : e->partial) b.release();
+    for (auto &b : e->pooled) b.release();
+    for (auto &b : e->lm_h) b.release();
+    for (int i = 0; i < 2; ++i) {
+        if (e->map_pin[i]) (void)hipHostFree(e->map_pin[i]);
+        if (e->map_ev[i]) (void)hipEventDestroy(e->map_ev[i]);
+    }
+    delete e;
+}
+
+extern "C" int mdf_engine_set_nnz_per_row(mdf_engine *e, int32_t nnz_per_row)
+{
+    MDF_REQUIRE(e && nnz_per_row > 0, "engine_set_nnz_per_row: bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    e->cfg.nnz_per_row = nnz_per_row;
+    e->rows_alloc = 0;   // the next call re-sizes the CSR arrays
+    return MDF_OK;
+}
+
+extern "C" int64_t mdf_engine_nnz_capacity(const mdf_engine *e) { return e ? e->nnz_cap : 0; }
+extern "C" int32_t mdf_engine_num_lms(const mdf_engine *e) { return e ? (int32_t)e->lms.size() : 0; }
+
+// workspaces for chunks of up to `rows` rows, queries up to `max_len`, B proteins, segments of up to `groups` groups
+static int ensure(mdf_engine *e, int64_t rows, int32_t B, int32_t max_len, int64_t groups)
+{
+    max_len = (max_len + 63) / 64 * 64;
+    uint64_t *gen = &e->generation;
+    if (rows > e->rows_alloc || max_len > e->len_alloc) {
+        rows = std::max(rows, e->rows_alloc);
+        max_len = std::max(max_len, e->len_alloc);
+        const int64_t cap = std::max<int64_t>(rows * e->cfg.nnz_per_row, e->rows_alloc ? e->nnz_cap : 0);
+        MDF_REQUIRE(cap < 0x7fffffffLL, "engine: %lld rows x %d entries per row exceed the int32 CSR; lower max_rows", (long long)rows, e->cfg.nnz_per_row);
+        size_t gws = 0;
+        for (mdf_model *m : e->models) gws = std::max(gws, mdf_gcn_workspace_bytes(m, rows));
+        if (int rc = e->rowptr.grow((size_t)(rows + 1) * 4, gen)) return rc;
+        if (int rc = e->colidx.grow((size_t)cap * 4, gen)) return rc;
+        if (int rc = e->val.grow((size_t)cap * 4, gen)) return rc;
+        if (int rc = e->seq_idx.grow((size_t)rows, gen)) return rc;
+        if (int rc = e->lsum.grow((size_t)rows * 32 * 4, gen)) return rc;
+        if (int rc = e->cws.grow(mdf_cmap_workspace_bytes(1 << 20, rows, max_len), gen)) return rc;
+        if (int rc = e->gws.grow(gws, gen)) return rc;
+        e->rows_alloc = rows;
+        e->nnz_cap = cap;
+        e->len_alloc = max_len;
+    }
+    size_t hws = 0;
+    for (mdf_model *m : e->models) hws = std::max(hws, mdf_head_workspace_bytes(m, B));
+    if (int rc = e->hws.grow(hws, gen)) return rc;
+    for (size_t k = 0; k < e->models.size(); ++k) {
+        const size_t feat = (size_t)mdf_model_feature_dim(e->models[k]);
+        if (int rc = e->partial[k].grow((size_t)groups * feat * 4, gen)) return rc;
+        if (int rc = e->pooled[k].grow((size_t)B * feat * 4, gen)) return rc;
+    }
+    return MDF_OK;
+}
+
+static int check_batch(const mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, bool need_coords)
+{
+    MDF_REQUIRE(e && pl && b, "engine: NULL argument");
+    MDF_REQUIRE(b->B == pl->B, "engine: the batch holds %d proteins but the plan was made for %d", b->B, pl->B);
+    MDF_REQUIRE(b->seqs && b->seq_off && b->Lq && b->status && b->bad, "engine: NULL pointer in the batch descriptor");
+    if (need_coords)
+        MDF_REQUIRE(b->coords && b->coord_off && b->q_aln && b->t_aln && b->aln_off, "engine: batch was packed without coordinates/alignments");
+    return MDF_OK;
+}
+
+// per-chunk stages ---------------------------------------------------------------------------------------------------
+static int encode_chunk(mdf_engine *, const mdf_plan *pl, const mdf_batch_dev *b, int ci, uint8_t *seq_ptr, hipStream_t st)
+{
+    const PlanChunk &ch = pl->chunks[(size_t)ci];
+    return mdf_seq_encode_dev(b->seqs, b->seq_off + ch.p0, b->Lq + ch.p0, pl->d_chunk_row_off + ch.row_off_pos, ch.p1 - ch.p0, ch.rows, seq_ptr,
+                              b->bad + ci, st);
+}
+
+// letter sums once per chunk (shared by every head without a language model), then the GraphConv stack of each head; the
+// per-group partial sums land in the head's segment array
+static int gcn_chunk(mdf_engine *e, const PlanChunk &ch, const uint8_t *seq_ptr, const std::vector<const float *> &lm_h, bool have_lsum,
+                     hipStream_t st)
+{
+    if (!have_lsum && e->want_lsum)
+        if (int rc = mdf_letter_sums_dev(seq_ptr, e->rowptr.as<int32_t>(), e->colidx.as<int32_t>(), e->val.as<float>(), ch.rows, e->lsum.as<float>(), st))
+            return rc;
+    for (size_t k = 0; k < e->models.size(); ++k) {
+        mdf_model *m = e->models[k];
+        float *part = e->partial[k].as<float>() + (size_t)ch.group_base * (size_t)mdf_model_feature_dim(m);
+        int rc;
+        if (e->model_lm[k] < 0)
+            rc = mdf_gcn_embed_dev(m, e->lsum.as<float>(), e->rowptr.as<int32_t>(), e->colidx.as<int32_t>(), e->val.as<float>(), ch.rows, part,
+                                   e->gws.p, e->gws.bytes, st);
+        else
+            rc = mdf_gcn_embed_lm_dev(m, seq_ptr, lm_h[(size_t)e->model_lm[k]], e->rowptr.as<int32_t>(), e->colidx.as<int32_t>(), e->val.as<float>(),
+                                      ch.rows, part, e->gws.p, e->gws.bytes, st);
+        if (rc) return rc;
+    }
+    return MDF_OK;
+}
+
+static int pool_segment(mdf_engine *e, const mdf_plan *pl, const PlanSegment &sg, hipStream_t st)
+{
+    for (size_t k = 0; k < e->models.size(); ++k) {
+        mdf_model *m = e->models[k];
+        if (int rc = mdf_gcn_pool_dev(m, e->partial[k].as<float>(), pl->d_grp_off + sg.grp_off_pos, sg.p1 - sg.p0,
+                                      e->pooled[k].as<float>() + (size_t)sg.p0 * (size_t)mdf_model_feature_dim(m), st))
+            return rc;
+    }
+    return MDF_OK;
+}
+
+using BuildCsr = std::function<int(int ci, const PlanChunk &ch, const uint8_t *seq_ptr, bool *have_lsum)>;
+
+// Common driver: per chunk the residue indices are encoded, `build_csr` writes the adjacency (saying whether it also produced
+// the layer-1 letter sums), then the GCN stack runs; segments are pooled as soon as their last chunk has been issued.  With a
+// language model the chunks are taken a group of proteins at a time: all of them are encoded first, the LSTM runs over the
+// whole group, then the per-chunk stages follow.
+static int run_chunks(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, const BuildCsr &build_csr, hipStream_t st)
+{
+    const int nC = (int)pl->chunks.size();
+    std::vector<const float *> lm_ptr(e->lms.size(), nullptr);
+    auto tail = [&](int ci, const uint8_t *seq_ptr) -> int {
+        const PlanChunk &ch = pl->chunks[(size_t)ci];
+        e->last_rows = ch.rows;
+        bool have_lsum = false;
+        if (int rc = build_csr(ci, ch, seq_ptr, &have_lsum)) return rc;
+        if (int rc = gcn_chunk(e, ch, seq_ptr, lm_ptr, have_lsum, st)) return rc;
+        if (ci + 1 == nC || pl->chunks[(size_t)ci + 1].segment != ch.segment) return pool_segment(e, pl, pl->segments[(size_t)ch.segment], st);
+        return MDF_OK;
+    };
+    if (e->lms.empty()) {
+        for (int ci = 0; ci < nC; ++ci) {
+            if (int rc = encode_chunk(e, pl, b, ci, e->seq_idx.as<uint8_t>(), st)) return rc;
+            if (int rc = tail(ci, e->seq_idx.as<uint8_t>())) return rc;
+        }
+        return MDF_OK;
+    }
+    if (int rc = plan_lm_groups(pl, e->cfg.lm_batch, (int64_t)(e->cfg.lm_workspace_gib * 1073741824.0), e->lm_hidden_max)) return rc;
+    // size the group-level buffers once, for the largest group (growing them between groups would stall the device)
+    int64_t rows_max = 0;
+    size_t ws_max = 0;
+    for (const LmGroup &g : pl->lm_groups) {
+        rows_max = std::max(rows_max, g.bases.back());
+        for (mdf_lm *lm : e->lms) ws_max = std::max(ws_max, mdf_lm_workspace_bytes(lm, g.B, g.Lmax));
+    }
+    if (int rc = e->seq_all.grow((size_t)rows_max, &e->generation)) return rc;
+    if (int rc = e->lm_ws.grow(ws_max, &e->generation)) return rc;
+    for (size_t i = 0; i < e->lms.size(); ++i)
+        if (int rc = e->lm_h[i].grow((size_t)rows_max * (size_t)mdf_lm_hidden(e->lms[i]) * 4, &e->generation, /*zero=*/true)) return rc;
+    for (const LmGroup &g : pl->lm_groups) {
+        uint8_t *seq_all = e->seq_all.as<uint8_t>();
+        for (int ci = g.c0; ci < g.c1; ++ci)
+            if (int rc = encode_chunk(e, pl, b, ci, seq_all + g.bases[(size_t)(ci - g.c0)], st)) return rc;
+        for (size_t i = 0; i < e->lms.size(); ++i)
+            if (int rc = mdf_lm_forward_dev(e->lms[i], seq_all, pl->d_lm_rows + g.rows_pos, pl->d_lm_lens + g.lens_pos, g.lens_host.data(), g.B,
+                                            e->lm_h[i].as<float>(), e->lm_ws.p, e->lm_ws.bytes, st))
+                return rc;
+        for (int ci = g.c0; ci < g.c1; ++ci) {
+            const int64_t base = g.bases[(size_t)(ci - g.c0)];
+            for (size_t i = 0; i < e->lms.size(); ++i) lm_ptr[i] = e->lm_h[i].as<float>() + (size_t)base * (size_t)mdf_lm_hidden(e->lms[i]);
+            if (int rc = tail(ci, seq_all + base)) return rc;
+        }
+    }
+    return MDF_OK;
+}
+
+static int run_heads(mdf_engine *e, int32_t B, float *const *scores, float *const *logits, hipStream_t st)
+{
+    for (size_t k = 0; k < e->models.size(); ++k) {
+        MDF_REQUIRE(scores[k], "engine: scores[%zu] is NULL", k);
+        if (int rc = mdf_gcn_head_dev(e->models[k], e->pooled[k].as<float>(), B, scores[k], logits ? logits[k] : nullptr, e->hws.p, e->hws.bytes, st))
+            return rc;
+    }
+    return MDF_OK;
+}
+
+static int forward_alignments_eager(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, float *const *scores, float *const *logits,
+                                    hipStream_t st)
+{
+    BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *seq_ptr, bool *have_lsum) -> int {
+        // contact stage: coordinates read once; the CSR fill also writes the layer-1 letter sums of the chunk
+        *have_lsum = e->want_lsum;
+        return mdf_cmap_csr_dev(b->coords, b->coord_off + ch.p0, b->q_aln, b->t_aln, b->aln_off + ch.p0, b->Lq + ch.p0,
+                                pl->d_chunk_row_off + ch.row_off_pos, ch.p1 - ch.p0, ch.rows, ch.max_len, e->cfg.threshold, e->cfg.generated_contacts,
+                                e->rowptr.as<int32_t>(), e->colidx.as<int32_t>(), e->val.as<float>(), e->nnz_cap, b->status + 4 * ci,
+                                e->want_lsum ? seq_ptr : nullptr, e->want_lsum ? e->lsum.as<float>() : nullptr, e->cws.p, e->cws.bytes, st);
+    };
+    if (int rc = run_chunks(e, pl, b, build, st)) return rc;
+    return run_heads(e, pl->B, scores, logits, st);
+}
+
+// ---- hipGraph replay of short launch sequences ------------------------------------------------------------------------
+// A batch below one chunk is launch-bound: ~12 launches per head plus the contact stage, each a few microseconds of kernel
+// behind a host-side dispatch.  The sequence is a pure function of (plan, input/flag/output pointers, engine buffers,
+// engine parameters), so the third identical call captures it into a graph and later calls replay it with one launch.
+static std::vector<uint64_t> graph_key(const mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, float *const *scores,
+                                       float *const *logits, hipStream_t st)
+{
+    std::vector<uint64_t> k = {pl->serial, (uint64_t)(uintptr_t)b->seqs, (uint64_t)(uintptr_t)b->seq_off, (uint64_t)(uintptr_t)b->Lq,
+                               (uint64_t)(uintptr_t)b->coords, (uint64_t)(uintptr_t)b->coord_off, (uint64_t)(uintptr_t)b->q_aln,
+                               (uint64_t)(uintptr_t)b->t_aln, (uint64_t)(uintptr_t)b->aln_off, (uint64_t)(uintptr_t)b->status,
+                               (uint64_t)(uintptr_t)b->bad, e->generation, (uint64_t)e->nnz_cap, (uint64_t)(uintptr_t)st};
+    uint64_t thr;
+    memcpy(&thr, &e->cfg.threshold, 8);
+    k.push_back(thr);
+    k.push_back((uint64_t)e->cfg.generated_contacts);
+    for (size_t i = 0; i < e->models.size(); ++i) {
+        k.push_back((uint64_t)(uintptr_t)scores[i]);
+        k.push_back((uint64_t)(uintptr_t)(logits ? logits[i] : nullptr));
+    }
+    return k;
+}
+
+static int forward_alignments_locked(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, float *const *scores, float *const *logits,
+                                     hipStream_t st)
+{
+    if (int rc = plan_mirror(pl, e->device)) return rc;
+    if (int rc = ensure(e, pl->max_chunk_rows, pl->B, pl->max_len, pl->max_groups)) return rc;
+    const bool graphable = e->cfg.graph_max_chunks > 0 && (int)pl->chunks.size() <= e->cfg.graph_max_chunks && e->lms.empty() && !timing_on();
+    if (!graphable) {
+        ++e->eager_runs;
+        return forward_alignments_eager(e, pl, b, scores, logits, st);
+    }
+    const std::vector<uint64_t> key = graph_key(e, pl, b, scores, logits, st);
+    GraphEntry *ge = nullptr;
+    for (auto &g : e->graphs)
+        if (g.key == key) ge = &g;
+    if (!ge) {
+        if (e->graphs.size() >= 16) {   // evict the least recently used entry
+            size_t victim = 0;
+            for (size_t i = 1; i < e->graphs.size(); ++i)
+                if (e->graphs[i].last_use < e->graphs[victim].last_use) victim = i;
+            if (e->graphs[victim].exec) (void)hipGraphExecDestroy(e->graphs[victim].exec);
+            if (e->graphs[victim].graph) (void)hipGraphDestroy(e->graphs[victim].graph);
+            e->graphs.erase(e->graphs.begin() + (long)victim);
+        }
+        e->graphs.push_back(GraphEntry());
+        ge = &e->graphs.back();
+        ge->key = key;
+    }
+    ge->last_use = ++e->tick;
+    ++ge->seen;
+    if (ge->exec) {
+        if (hipGraphLaunch(ge->exec, st) == hipSuccess) {
+            ++e->graph_launches;
+            return MDF_OK;
+        }
+        (void)hipGetLastError();
+        ge->disabled = true;   // fall through to the eager path, for good
+        (void)hipGraphExecDestroy(ge->exec);
+        ge->exec = nullptr;
+    }
+    if (ge->disabled || ge->seen < 3) {   // calls 1 and 2 run eagerly (lazy one-time initialisation happens outside any capture)
+        ++e->eager_runs;
+        return forward_alignments_eager(e, pl, b, scores, logits, st);
+    }
+    // third call: capture (nothing executes), instantiate, launch on the caller's stream
+    if ((!e->cap_stream && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) ||
+        hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        ge->disabled = true;
+        ++e->eager_runs;
+        return forward_alignments_eager(e, pl, b, scores, logits, st);
+    }
+    const int rc = forward_alignments_eager(e, pl, b, scores, logits, e->cap_stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
+    if (rc != MDF_OK || ce != hipSuccess || !graph) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        ge->disabled = true;
+        if (rc != MDF_OK) return rc;   // an argument error is an argument error, captured or not
+        ++e->eager_runs;
+        return forward_alignments_eager(e, pl, b, scores, logits, st);
+    }
+    hipGraphExec_t exec = nullptr;
+    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || hipGraphLaunch(exec, st) != hipSuccess) {
+        (void)hipGetLastError();
+        if (exec) (void)hipGraphExecDestroy(exec);
+        (void)hipGraphDestroy(graph);
+        ge->disabled = true;
+        ++e->eager_runs;
+        return forward_alignments_eager(e, pl, b, scores, logits, st);
+    }
+    ge->graph = graph;
+    ge->exec = exec;
+    ++e->graph_launches;
+    return MDF_OK;
+}
+
+extern "C" int mdf_engine_forward_alignments(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, float *const *scores,
+                                             float *const *logits, void *stream)
+{
+    if (int rc = check_batch(e, pl, b, true)) return rc;
+    MDF_REQUIRE(scores, "engine_forward_alignments: scores is NULL");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    MDF_HIP(g.err);
+    return forward_alignments_locked(e, pl, b, scores, logits, static_cast<hipStream_t>(stream));
+}
+
+// Diagnostic: forward calls replayed as graphs / issued eagerly since the engine was made.
+extern "C" int mdf_engine_graph_stats(const mdf_engine *e, int64_t *graph_launches, int64_t *eager_runs)
+{
+    MDF_REQUIRE(e, "engine_graph_stats: NULL engine");
+    if (graph_launches) *graph_launches = e->graph_launches;
+    if (eager_runs) *eager_runs = e->eager_runs;
+    return MDF_OK;
+}
+
+extern "C" int64_t mdf_engine_last_chunk_nnz(mdf_engine *e, void *stream)
+{
+    MDF_REQUIRE(e, "engine_last_chunk_nnz: NULL engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    MDF_REQUIRE(e->last_rows > 0 && e->rowptr.p, "engine_last_chunk_nnz: nothing has run yet");
+    DeviceGuard g(e->device);
+    MDF_HIP(g.err);
+    int32_t nnz = 0;
+    MDF_HIP(hipMemcpyAsync(&nnz, e->rowptr.as<int32_t>() + e->last_rows, 4, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    MDF_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return nnz;
+}
+
+// ---- dense-map path ------------------------------------------------------------------------------------------------
+extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, const void *const *cmaps_host, int cmap_dtype,
+                                        float *const *scores, float *const *logits, void *stream)
+{
+    if (int rc = check_batch(e, pl, b, false)) return rc;
+    MDF_REQUIRE(cmaps_host && scores, "engine_forward_dense: NULL argument");
+    MDF_REQUIRE(cmap_dtype == MDF_DT_I32 || cmap_dtype == MDF_DT_F32, "engine_forward_dense: maps must be int32 or float32 (dtype code %d)", cmap_dtype);
+    for (int32_t p = 0; p < pl->B; ++p) MDF_REQUIRE(cmaps_host[p], "engine_forward_dense: contact map of protein %d is NULL", p);
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    MDF_HIP(g.err);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = plan_mirror(pl, e->device)) return rc;
+    if (int rc = ensure(e, pl->max_chunk_rows, pl->B, 0, pl->max_groups)) return rc;
+    for (int i = 0; i < 2; ++i)
+        if (!e->map_ev[i]) MDF_HIP(hipEventCreateWithFlags(&e->map_ev[i], hipEventDisableTiming));
+    int parity = 0;
+    bool used[2] = {false, false};
+    BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *, bool *have_lsum) -> int {
+        *have_lsum = false;
+        const int32_t Bc = ch.p1 - ch.p0;
+        // pack the chunk's maps + their element offsets into pinned memory: [offsets (Bc x int64) | maps]
+        size_t elems = 0;
+        for (int32_t p = ch.p0; p < ch.p1; ++p) elems += (size_t)pl->Lq[(size_t)p] * (size_t)pl->Lq[(size_t)p];
+        const size_t o_maps = align_up((size_t)Bc * 8, 256), total = o_maps + elems * 4;
+        const int s = parity;
+        parity ^= 1;
+        if (used[s]) MDF_HIP(hipEventSynchronize(e->map_ev[s]));   // the kernels that read this slot two chunks ago are done
+        if (e->map_pin_bytes[s] < total) {
+            if (e->map_pin[s]) (void)hipHostFree(e->map_pin[s]);
+            e->map_pin[s] = nullptr;
+            e->map_pin_bytes[s] = 0;
+            MDF_HIP(hipHostMalloc(reinterpret_cast<void **>(&e->map_pin[s]), total + total / 4, hipHostMallocDefault));
+            e->map_pin_bytes[s] = total + total / 4;
+        }
+        if (int rc = e->map_dev[s].grow(total + total / 4, &e->generation)) return rc;
+        int64_t *offs = reinterpret_cast<int64_t *>(e->map_pin[s]);
+        char *dst = e->map_pin[s] + o_maps;
+        int64_t nnz_needed = ch.rows, off = 0;
+        for (int32_t p = ch.p0; p < ch.p1; ++p) {
+            const size_t n = (size_t)pl->Lq[(size_t)p] * (size_t)pl->Lq[(size_t)p];
+            offs[p - ch.p0] = off;
+            memcpy(dst + (size_t)off * 4, cmaps_host[p], n * 4);
+            const uint32_t *w = reinterpret_cast<const uint32_t *>(dst + (size_t)off * 4);
+            int64_t nz = 0;
+            if (cmap_dtype == MDF_DT_I32) {
+                for (size_t i = 0; i < n; ++i) nz += w[i] != 0;
+            } else {
+                for (size_t i = 0; i < n; ++i) nz += (w[i] << 1) != 0;   // +0.0 and -0.0 are zeros
+            }
+            nnz_needed += nz;
+            off += (int64_t)n;
+        }
+        if (nnz_needed > e->nnz_cap) {   // a denser chunk than the CSR arrays hold: grow them (hipFree waits for the device)
+            MDF_REQUIRE(nnz_needed < 0x7fffffffLL, "engine_forward_dense: a chunk needs %lld CSR entries; lower max_rows", (long long)nnz_needed);
+            if (int rc = e->colidx.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
+            if (int rc = e->val.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
+            e->nnz_cap = nnz_needed;
+        }
+        char *d = e->map_dev[s].as<char>();
+        MDF_HIP(hipMemcpyAsync(d, e->map_pin[s], total, hipMemcpyHostToDevice, st));
+        const int rc = mdf_dense_to_csr_dev(d + o_maps, cmap_dtype, reinterpret_cast<const int64_t *>(d), b->Lq + ch.p0, pl->d_chunk_row_off + ch.row_off_pos,
+                                            Bc, ch.rows, e->rowptr.as<int32_t>(), e->colidx.as<int32_t>(), e->val.as<float>(), e->nnz_cap,
+                                            b->status + 4 * ci, e->cws.p, e->cws.bytes, st);
+        if (rc) return rc;
+        MDF_HIP(hipEventRecord(e->map_ev[s], st));
+        used[s] = true;
+        return MDF_OK;
+    };
+    ++e->eager_runs;
+    if (int rc = run_chunks(e, pl, b, build, st)) return rc;
+    if (int rc = run_heads(e, pl->B, scores, logits, st)) return rc;
+    MDF_HIP(hipStreamSynchronize(st));
+    return MDF_OK;
+}
+
+// ---- validation ------------------------------------------------------------------------------------------------------
+static int check_locked(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, hipStream_t st, int64_t *info)
+{
+    const size_t nC = pl->chunks.size();
+    std::vector<int64_t> bad(nC);
+    std::vector<int32_t> status(nC * 4);
+    MDF_HIP(hipMemcpyAsync(bad.data(), b->bad, nC * 8, hipMemcpyDeviceToHost, st));
+    MDF_HIP(hipMemcpyAsync(status.data(), b->status, nC * 16, hipMemcpyDeviceToHost, st));
+    MDF_HIP(hipStreamSynchronize(st));
+    if (info) info[0] = info[1] = info[2] = info[3] = -1;
+    // chunks hold consecutive proteins, so the first flagged chunk carries the first invalid byte of the whole batch: what the
+    // reference's serial loop would have hit first (predict.pyx:36-46)
+    for (size_t ci = 0; ci < nC; ++ci) {
+        if (bad[ci] != -1) {
+            const int64_t p = pl->chunks[ci].p0 + (bad[ci] >> 32), pos = bad[ci] & 0xffffffffLL;
+            if (info) info[0] = p, info[1] = pos;
+            return fail(MDF_EBADCHAR, "Invalid character in sequence: protein %lld, position %lld", (long long)p, (long long)pos);
+        }
+    }
+    int32_t too_long = 0, need = 0;
+    bool overflow = false;
+    for (size_t ci = 0; ci < nC; ++ci) {
+        too_long = std::max(too_long, status[ci * 4 + 2]);
+        if (status[ci * 4]) overflow = true, need = std::max(need, status[ci * 4 + 1]);
+    }
+    if (too_long) {
+        if (info) info[2] = too_long;
+        return fail(MDF_EINVAL, "a query of length %d exceeds the max_len the contact stage was given", too_long);
+    }
+    if (overflow) {
+        if (info) info[3] = need;
+        return fail(MDF_ECAPACITY, "CSR capacity %lld too small (a chunk needs %d); raise nnz_per_row", (long long)e->nnz_cap, need);
+    }
+    return MDF_OK;
+}
+
+extern "C" int mdf_engine_check(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, void *stream, int64_t info[4])
+{
+    if (int rc = check_batch(e, pl, b, false)) return rc;
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    MDF_HIP(g.err);
+    return check_locked(e, pl, b, static_cast<hipStream_t>(stream), info);
+}
+
+// ---- language-model features (inspection) ------------------------------------------------------------------------------
+extern "C" int mdf_engine_lm_features_host(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, int32_t which, float *out, void *stream)
+{
+    if (int rc = check_batch(e, pl, b, false)) return rc;
+    MDF_REQUIRE(out && which >= 0 && which < (int32_t)e->lms.size(), "engine_lm_features_host: no language model %d", which);
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    MDF_HIP(g.err);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = plan_mirror(pl, e->device)) return rc;
+    if (int rc = plan_lm_groups(pl, e->cfg.lm_batch, (int64_t)(e->cfg.lm_workspace_gib * 1073741824.0), e->lm_hidden_max)) return rc;
+    mdf_lm *lm = e->lms[(size_t)which];
+    const size_t H = (size_t)mdf_lm_hidden(lm);
+    std::vector<float> host;
+    std::vector<size_t> out_pos((size_t)pl->B + 1, 0);
+    for (int32_t p = 0; p < pl->B; ++p) out_pos[(size_t)p + 1] = out_pos[(size_t)p] + (size_t)pl->Lq[(size_t)p] * H;
+    for (const LmGroup &grp : pl->lm_groups) {
+        const int64_t rows = grp.bases.back();
+        if (int rc = e->seq_all.grow((size_t)rows, &e->generation)) return rc;
+        if (int rc = e->lm_ws.grow(mdf_lm_workspace_bytes(lm, grp.B, grp.Lmax), &e->generation)) return rc;
+        if (int rc = e->lm_h[(size_t)which].grow((size_t)rows * H * 4, &e->generation, true)) return rc;
+        uint8_t *seq_all = e->seq_all.as<uint8_t>();
+        for (int ci = grp.c0; ci < grp.c1; ++ci)
+            if (int rc = encode_chunk(e, pl, b, ci, seq_all + grp.bases[(size_t)(ci - grp.c0)], st)) return rc;
+        if (int rc = mdf_lm_forward_dev(lm, seq_all, pl->d_lm_rows + grp.rows_pos, pl->d_lm_lens + grp.lens_pos, grp.lens_host.data(), grp.B,
+                                        e->lm_h[(size_t)which].as<float>(), e->lm_ws.p, e->lm_ws.bytes, st))
+            return rc;
+        host.resize((size_t)rows * H);
+        MDF_HIP(hipMemcpyAsync(host.data(), e->lm_h[(size_t)which].p, (size_t)rows * H * 4, hipMemcpyDeviceToHost, st));
+        MDF_HIP(hipStreamSynchronize(st));
+        for (int ci = grp.c0; ci < grp.c1; ++ci) {
+            const PlanChunk &ch = pl->chunks[(size_t)ci];
+            const int32_t *ro = pl->chunk_row_off.data() + ch.row_off_pos;
+            for (int32_t p = ch.p0; p < ch.p1; ++p) {
+                const size_t r0 = (size_t)(grp.bases[(size_t)(ci - grp.c0)] + ro[p - ch.p0]);
+                memcpy(out + out_pos[(size_t)p], host.data() + r0 * H, (size_t)pl->Lq[(size_t)p] * H * 4);
+            }
+        }
+    }
+    return MDF_OK;
+}
+
+// ---- everything in one call, host buffers -------------------------------------------------------------------------------
+extern "C" int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords, const int32_t *Lt,
+                                              const char *q_aln, const char *t_aln, const int32_t *La, float *const *scores_host, int64_t info[4])
+{
+    MDF_REQUIRE(e && seqs && Lq && coords && Lt && q_aln && t_aln && La && scores_host, "engine_run_alignments_host: NULL argument");
+    MDF_REQUIRE(B > 0, "engine_run_alignments_host: empty batch");
+    // offsets + the consistency the Python packer checks (a gapped query must spell its sequence)
+    std::vector<int32_t> seq_off((size_t)B + 1, 0), coord_off((size_t)B + 1, 0), aln_off((size_t)B + 1, 0);
+    int64_t so = 0, co = 0, ao = 0;
+    for (int32_t p = 0; p < B; ++p) {
+        MDF_REQUIRE(Lq[p] > 0 && Lt[p] >= 0 && La[p] >= 0, "engine_run_alignments_host: bad length at protein %d", p);
+        seq_off[(size_t)p] = (int32_t)so, coord_off[(size_t)p] = (int32_t)co, aln_off[(size_t)p] = (int32_t)ao;
+        int64_t nongap = 0;
+        for (int32_t i = 0; i < La[p]; ++i) nongap += q_aln[ao + i] != '-';
+        MDF_REQUIRE(nongap == Lq[p], "protein %d: gapped query does not spell a sequence of length %d", p, Lq[p]);
+        so += Lq[p], co += Lt[p], ao += La[p];
+        MDF_REQUIRE(so < 0x7fffffffLL && co < 0x7fffffffLL / 3 && ao < 0x7fffffffLL, "batch too large for int32 offsets; split it");
+    }
+    seq_off[(size_t)B] = (int32_t)so, coord_off[(size_t)B] = (int32_t)co, aln_off[(size_t)B] = (int32_t)ao;
+    mdf_plan *pl = nullptr;
+    if (int rc = mdf_plan_create(Lq, B, e->cfg.max_rows, e->cfg.max_segment_groups, &pl)) return rc;
+    struct PlanGuard {
+        mdf_plan *p;
+        ~PlanGuard() { mdf_plan_free(p); }
+    } pg{pl};
+    const size_t nC = pl->chunks.size();
+    int rc = MDF_OK;
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        DeviceGuard g(e->device);
+        MDF_HIP(g.err);
+        hipStream_t st = nullptr;
+        // one device slab for the inputs: [seqs | seq_off | Lq | coords | coord_off | q_aln | t_aln | aln_off | status | bad]
+        size_t o = 0;
+        auto take = [&](size_t bytes) { const size_t r = o; o = align_up(o + std::max<size_t>(bytes, 4), 256); return r; };
+        const size_t o_seq = take((size_t)so), o_soff = take(((size_t)B + 1) * 4), o_lq = take((size_t)B * 4), o_xyz = take((size_t)co * 12),
+                     o_coff = take(((size_t)B + 1) * 4), o_q = take((size_t)ao), o_t = take((size_t)ao), o_aoff = take(((size_t)B + 1) * 4),
+                     o_status = take(nC * 16), o_bad = take(nC * 8);
+        if ((rc = e->host_in.grow(o, nullptr))) return rc;
+        char *d = e->host_in.as<char>();
+        MDF_HIP(hipMemcpyAsync(d + o_seq, seqs, (size_t)so, hipMemcpyHostToDevice, st));
+        MDF_HIP(hipMemcpyAsync(d + o_soff, seq_off.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice, st));
+        MDF_HIP(hipMemcpyAsync(d + o_lq, Lq, (size_t)B * 4, hipMemcpyHostToDevice, st));
+        if (co) MDF_HIP(hipMemcpyAsync(d + o_xyz, coords, (size_t)co * 12, hipMemcpyHostToDevice, st));
+        MDF_HIP(hipMemcpyAsync(d + o_coff, coord_off.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice, st));
+        if (ao) {
+            MDF_HIP(hipMemcpyAsync(d + o_q, q_aln, (size_t)ao, hipMemcpyHostToDevice, st));
+            MDF_HIP(hipMemcpyAsync(d + o_t, t_aln, (size_t)ao, hipMemcpyHostToDevice, st));
+        }
+        MDF_HIP(hipMemcpyAsync(d + o_aoff, aln_off.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice, st));
+        mdf_batch_dev b{};
+        b.B = B;
+        b.seqs = d + o_seq;
+        b.seq_off = reinterpret_cast<const int32_t *>(d + o_soff);
+        b.Lq = reinterpret_cast<const int32_t *>(d + o_lq);
+        b.coords = reinterpret_cast<const float *>(d + o_xyz);
+        b.coord_off = reinterpret_cast<const int32_t *>(d + o_coff);
+        b.q_aln = d + o_q;
+        b.t_aln = d + o_t;
+        b.aln_off = reinterpret_cast<const int32_t *>(d + o_aoff);
+        b.status = reinterpret_cast<int32_t *>(d + o_status);
+        b.bad = reinterpret_cast<int64_t *>(d + o_bad);
+        // device score blocks
+        std::vector<size_t> s_off(e->models.size());
+        size_t s_total = 0;
+        for (size_t k = 0; k < e->models.size(); ++k) {
+            MDF_REQUIRE(scores_host[k], "engine_run_alignments_host: scores_host[%zu] is NULL", k);
+            s_off[k] = s_total;
+            s_total = align_up(s_total + (size_t)B * (size_t)mdf_model_num_terms(e->models[k]) * 4, 256);
+        }
+        if ((rc = e->host_scores.grow(s_total, nullptr))) return rc;
+        std::vector<float *> d_scores(e->models.size());
+        for (size_t k = 0; k < e->models.size(); ++k) d_scores[k] = reinterpret_cast<float *>(e->host_scores.as<char>() + s_off[k]);
+        int64_t inf[4] = {-1, -1, -1, -1};
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            MDF_HIP(hipMemsetAsync(d + o_status, 0, nC * 16, st));
+            MDF_HIP(hipMemsetAsync(d + o_bad, 0xff, nC * 8, st));
+            if ((rc = forward_alignments_locked(e, pl, &b, d_scores.data(), nullptr, st))) return rc;
+            rc = check_locked(e, pl, &b, st, inf);
+            if (rc != MDF_ECAPACITY || attempt == 1) break;
+            // a denser batch than the CSR arrays planned for: raise the capacity once and re-run
+            e->cfg.nnz_per_row = (int32_t)(inf[3] / std::max<int64_t>(pl->max_chunk_rows, 1) + 8);
+            e->rows_alloc = 0;
+        }
+        if (info) memcpy(info, inf, sizeof(inf));
+        if (rc) return rc;
+        for (size_t k = 0; k < e->models.size(); ++k)
+            MDF_HIP(hipMemcpyAsync(scores_host[k], d_scores[k], (size_t)B * (size_t)mdf_model_num_terms(e->models[k]) * 4, hipMemcpyDeviceToHost, st));
+        MDF_HIP(hipStreamSynchronize(st));
+    }
+    return MDF_OK;
+}

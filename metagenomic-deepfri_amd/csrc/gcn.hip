@@ -1559,6 +1559,8 @@ int mdf_model_load(const char *path, int device, mdf_model **out)
     return mdf_model_create(&w, device, out);
 }
 
+mdf_lm *mdf_model_lm(const mdf_model *m) { return m ? m->lm : nullptr; }
+
 size_t mdf_gcn_workspace_bytes(const mdf_model *m, int64_t R) { return m ? gcn_ws_bytes(m, R) : 0; }
 
 int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,

@@ -53,6 +53,22 @@ class CnnWeights(ctypes.Structure):
     ]
 
 
+class EngineConfig(ctypes.Structure):
+    """mdf_engine_config (include/mdfri.h)"""
+    _fields_ = [
+        ("max_rows", c_int32), ("nnz_per_row", c_int32), ("threshold", c_double), ("generated_contacts", c_int32),
+        ("max_segment_groups", c_int32), ("lm_batch", c_int32), ("lm_workspace_gib", c_double), ("graph_max_chunks", c_int32),
+    ]
+
+
+class BatchDev(ctypes.Structure):
+    """mdf_batch_dev (include/mdfri.h): device pointers of one uploaded batch"""
+    _fields_ = [
+        ("B", c_int32), ("seqs", c_void_p), ("seq_off", c_void_p), ("Lq", c_void_p), ("coords", c_void_p), ("coord_off", c_void_p),
+        ("q_aln", c_void_p), ("t_aln", c_void_p), ("aln_off", c_void_p), ("status", c_void_p), ("bad", c_void_p),
+    ]
+
+
 _f32p, _i32p, _i64p, _u8p = POINTER(c_float), POINTER(c_int32), POINTER(c_int64), POINTER(c_uint8)
 
 # name -> (restype, argtypes); every symbol include/mdfri.h declares
@@ -76,6 +92,7 @@ SIGNATURES = {
     "mdf_model_feature_dim": (c_int, [c_void_p]),
     "mdf_model_device": (c_int, [c_void_p]),
     "mdf_model_lm_dim": (c_int, [c_void_p]),
+    "mdf_model_lm": (c_void_p, [c_void_p]),
     "mdf_lm_create": (c_int, [POINTER(LmWeights), c_int, POINTER(c_void_p)]),
     "mdf_lm_free": (None, [c_void_p]),
     "mdf_lm_hidden": (c_int, [c_void_p]),
@@ -111,6 +128,30 @@ SIGNATURES = {
     "mdf_gcn_pool_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "mdf_head_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
     "mdf_gcn_head_dev": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_plan_create": (c_int, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "mdf_plan_free": (None, [c_void_p]),
+    "mdf_plan_num_proteins": (c_int32, [c_void_p]),
+    "mdf_plan_num_chunks": (c_int32, [c_void_p]),
+    "mdf_plan_num_segments": (c_int32, [c_void_p]),
+    "mdf_plan_max_chunk_rows": (c_int64, [c_void_p]),
+    "mdf_plan_chunks": (c_int, [c_void_p, c_void_p]),
+    "mdf_plan_segments": (c_int, [c_void_p, c_void_p]),
+    "mdf_plan_chunk_row_off": (POINTER(c_int32), [c_void_p, _i64p]),
+    "mdf_plan_grp_off": (POINTER(c_int32), [c_void_p, _i64p]),
+    "mdf_engine_create": (c_int, [POINTER(c_void_p), c_int32, c_int, POINTER(EngineConfig), POINTER(c_void_p)]),
+    "mdf_engine_free": (None, [c_void_p]),
+    "mdf_engine_set_nnz_per_row": (c_int, [c_void_p, c_int32]),
+    "mdf_engine_nnz_capacity": (c_int64, [c_void_p]),
+    "mdf_engine_forward_alignments": (c_int, [c_void_p, c_void_p, POINTER(BatchDev), POINTER(c_void_p), POINTER(c_void_p), c_void_p]),
+    "mdf_engine_forward_dense": (c_int, [c_void_p, c_void_p, POINTER(BatchDev), POINTER(c_void_p), c_int, POINTER(c_void_p), POINTER(c_void_p),
+                                         c_void_p]),
+    "mdf_engine_check": (c_int, [c_void_p, c_void_p, POINTER(BatchDev), c_void_p, _i64p]),
+    "mdf_engine_lm_features_host": (c_int, [c_void_p, c_void_p, POINTER(BatchDev), c_int32, c_void_p, c_void_p]),
+    "mdf_engine_num_lms": (c_int32, [c_void_p]),
+    "mdf_engine_graph_stats": (c_int, [c_void_p, _i64p, _i64p]),
+    "mdf_engine_last_chunk_nnz": (c_int64, [c_void_p, c_void_p]),
+    "mdf_engine_run_alignments_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               POINTER(c_void_p), _i64p]),
     "mdf_filter_workspace_bytes": (c_size_t, [c_int32]),
     "mdf_filter_scores_dev": (c_int, [c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),

@@ -157,48 +157,26 @@ class PackedProteins:
         return pk, keep
 
     def _plan(self, max_rows: int, max_segment_groups: int = 1 << 19):
+        """Chunks and pooling segments from the library's planner (mdf_plan_create, csrc/engine.hip): the Python objects below
+        are a read-only view of its tables; the handle itself is what the engine entry points take."""
+        import weakref
         L = _hip.lib()
-        self.chunks, offs = [], []
-        p0, B = 0, self.B
-        pad = (self.Lq.astype(np.int64) + 31) // 32 * 32
-        while p0 < B:
-            p1, rows = p0, 0
-            while p1 < B and (p1 == p0 or rows + pad[p1] <= max_rows):
-                rows += pad[p1]
-                p1 += 1
-            ro = np.zeros(p1 - p0 + 1, dtype=np.int32)
-            lq = np.ascontiguousarray(self.Lq[p0:p1])
-            R = L.mdf_layout_rows(_hip.ptr(lq), p1 - p0, _hip.ptr(ro))
-            if R < 0:
-                _hip.check(int(R))
-            self.chunks.append(Chunk(p0, p1, int(R), sum(len(o) for o in offs)))
-            offs.append(ro)
-            p0 = p1
-        self.chunk_row_off = np.concatenate(offs)
-        # pooling segments: protein p's 32-row groups are [grp_off[p], grp_off[p+1]) inside its segment's partial array
-        self.segments, goffs = [], []
-        cur, seg_groups, seg_first = [], 0, 0
-        for ci, ch in enumerate(self.chunks):
-            g = ch.rows // 32
-            if cur and seg_groups + g > max_segment_groups:
-                self._close_segment(cur, seg_groups, goffs)
-                cur, seg_groups = [], 0
-            ch.segment, ch.group_base = len(self.segments), seg_groups
-            cur.append(ci)
-            seg_groups += g
-        self._close_segment(cur, seg_groups, goffs)
-        self.grp_off = np.concatenate(goffs)
-
-    def _close_segment(self, chunk_ids, groups, goffs):
-        first, last = self.chunks[chunk_ids[0]], self.chunks[chunk_ids[-1]]
-        off = np.empty(last.p1 - first.p0 + 1, dtype=np.int32)
-        for ci in chunk_ids:
-            ch = self.chunks[ci]
-            ro = self.chunk_row_off[ch.row_off_pos:ch.row_off_pos + (ch.p1 - ch.p0) + 1]
-            off[ch.p0 - first.p0:ch.p1 - first.p0] = ch.group_base + ro[:-1] // 32
-        off[-1] = groups
-        self.segments.append(Segment(first.p0, last.p1, int(groups), sum(len(o) for o in goffs)))
-        goffs.append(off)
+        lq = np.ascontiguousarray(self.Lq, dtype=np.int32)
+        h = ctypes.c_void_p()
+        _hip.check(L.mdf_plan_create(_hip.ptr(lq), len(lq), int(max_rows), int(max_segment_groups), ctypes.byref(h)))
+        self.plan = h
+        weakref.finalize(self, L.mdf_plan_free, h)
+        nc, ns = L.mdf_plan_num_chunks(h), L.mdf_plan_num_segments(h)
+        ct, stab = np.empty((nc, 6), dtype=np.int64), np.empty((ns, 4), dtype=np.int64)
+        _hip.check(L.mdf_plan_chunks(h, _hip.ptr(ct)))
+        _hip.check(L.mdf_plan_segments(h, _hip.ptr(stab)))
+        self.chunks = [Chunk(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5])) for r in ct]
+        self.segments = [Segment(int(r[0]), int(r[1]), int(r[2]), int(r[3])) for r in stab]
+        n = _hip.c_int64(0)
+        ptr = L.mdf_plan_chunk_row_off(h, n)
+        self.chunk_row_off = np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+        ptr = L.mdf_plan_grp_off(h, n)
+        self.grp_off = np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
 
     @property
     def max_chunk_rows(self) -> int:
@@ -213,7 +191,7 @@ def _p(t, elem_offset: int = 0):
 
 
 class DeviceBatch:
-    """PackedProteins uploaded to one GPU (torch tensors)."""
+    """PackedProteins uploaded to one GPU (torch tensors own the memory; `desc` is the mdf_batch_dev the engine takes)."""
 
     def __init__(self, packed: PackedProteins, device):
         torch = _torch()
@@ -232,6 +210,9 @@ class DeviceBatch:
         n = len(packed.chunks)
         self.status = torch.zeros((n, 4), dtype=torch.int32, device=device)
         self.bad = torch.full((n,), -1, dtype=torch.int64, device=device)   # per chunk: (protein << 32 | position) of the first invalid byte
+        a = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+        self.desc = _hip.BatchDev(packed.B, a(self.seq_bytes), a(self.seq_off), a(self.Lq), a(self.coords), a(self.coord_off), a(self.q_aln),
+                                  a(self.t_aln), a(self.aln_off), a(self.status), a(self.bad))
 
     @property
     def B(self):
@@ -249,54 +230,44 @@ def first_invalid_residue(packed: PackedProteins, bad) -> None:
 
 class HotPathEngine:
     """contact map + GCN forward for batches of proteins on one GPU, for one or several GO heads
-    (`predictors`: {mode: mDeepFRI.predict.Predictor}; all heads share the contact-map stage)."""
+    (`predictors`: {mode: mDeepFRI.predict.Predictor}; all heads share the contact-map stage).
+
+    A thin caller of the library's batch engine (include/mdfri.h `mdf_engine_*`, csrc/engine.hip): the planner, the per-chunk
+    launch sequence, the language-model grouping, the GO heads and the hipGraph replay of short batches all run in C++; this
+    class owns the torch tensors (inputs, flags, outputs) and turns return codes into the exceptions of the per-call API."""
 
     def __init__(self, predictors: dict, device: int = 0, max_rows: int = 32768, nnz_per_row: int = 40,
-                 threshold: float = 6.0, generated_contacts: int = 2, lm_batch: int = 8192, lm_workspace_gib: float = 48.0):
+                 threshold: float = 6.0, generated_contacts: int = 2, lm_batch: int = 8192, lm_workspace_gib: float = 48.0,
+                 graph_max_chunks: int = 0):
+        import weakref
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("HotPathEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
         self.L = _hip.lib()
         self.predictors = dict(predictors)
+        self.modes = list(self.predictors)
         self.device = torch.device(f"cuda:{device}")
         self.max_rows = int(max_rows)
         self.nnz_per_row = int(nnz_per_row)
         self.threshold = float(threshold)
         self.generated_contacts = int(generated_contacts)
-        self._rows_alloc = self._len_alloc = 0
-        self._bufs = {}
-        # heads with a language-model branch, grouped by the (shared) LanguageModel they are attached to; the LSTM runs
-        # once per group over `lm_batch` proteins at a time (every time step is one GEMM over all of them)
+        for m, p in self.predictors.items():
+            if p.session.kind != "gcn":
+                raise ValueError(f"predictor {m!r} is not a GCN model (sequence-only models run on SequenceEngine)")
+        # distinct language models, in the engine's order (inspection: lm_features(which=...))
         self.lms = []
         for p in self.predictors.values():
             lm = getattr(p.session, "lm", None)
             if lm is not None and all(lm is not x for x in self.lms):
                 self.lms.append(lm)
-        self.lm_batch = int(lm_batch)
-        self.lm_workspace_bytes = int(lm_workspace_gib * 2**30)
-
-    # -- memory ------------------------------------------------------------------------------------------------------
-    def _ensure(self, rows: int, n_proteins: int, max_len: int = 0):
-        torch = _torch()
-        max_len = (int(max_len) + 63) // 64 * 64
-        if rows > self._rows_alloc or max_len > self._len_alloc:
-            rows, max_len = max(rows, self._rows_alloc), max(max_len, self._len_alloc)
-            dev = self.device
-            cap = rows * self.nnz_per_row
-            gws = max(self.L.mdf_gcn_workspace_bytes(p.session.handle, rows) for p in self.predictors.values())
-            self._bufs = {
-                "rowptr": torch.empty(rows + 1, dtype=torch.int32, device=dev),
-                "colidx": torch.empty(cap, dtype=torch.int32, device=dev),
-                "val": torch.empty(cap, dtype=torch.float32, device=dev),
-                "seq_idx": torch.empty(rows, dtype=torch.uint8, device=dev),
-                "lsum": torch.empty(rows * 32, dtype=torch.float32, device=dev),
-                "cws": torch.empty(self.L.mdf_cmap_workspace_bytes(1 << 20, rows, max_len), dtype=torch.uint8, device=dev),
-                "gws": torch.empty(gws, dtype=torch.uint8, device=dev),
-            }
-            self._rows_alloc, self._nnz_cap, self._len_alloc = rows, cap, max_len
-        hws = max(self.L.mdf_head_workspace_bytes(p.session.handle, n_proteins) for p in self.predictors.values())
-        if self._bufs.get("hws") is None or self._bufs["hws"].numel() < hws:
-            self._bufs["hws"] = torch.empty(hws, dtype=torch.uint8, device=self.device)
+        cfg = _hip.EngineConfig(self.max_rows, self.nnz_per_row, self.threshold, self.generated_contacts, 0, int(lm_batch), float(lm_workspace_gib),
+                                int(graph_max_chunks))
+        handles = (ctypes.c_void_p * len(self.modes))(*[self.predictors[m].session.handle for m in self.modes])
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _hip.check(self.L.mdf_engine_create(handles, len(self.modes), int(device), ctypes.byref(cfg), ctypes.byref(h)))
+        self.handle = h
+        weakref.finalize(self, self.L.mdf_engine_free, h)
 
     def upload(self, packed: PackedProteins) -> DeviceBatch:
         return DeviceBatch(packed, self.device)
@@ -304,94 +275,52 @@ class HotPathEngine:
     def _stream(self):
         return ctypes.c_void_p(_torch().cuda.current_stream(self.device).cuda_stream)
 
-    # -- stages ------------------------------------------------------------------------------------------------------
-    def _gcn_chunk(self, db: DeviceBatch, ch: Chunk, partial: dict, st, seq_ptr, lm_h=None, have_lsum: bool = False):
-        """letter sums once per chunk (shared by every head without a language model), then the GraphConv stack of each
-        head; the per-group partial sums land in the head's segment array.  `lm_h`: {LanguageModel: pointer to this
-        chunk's (rows, H) language-model features}."""
-        b = self._bufs
-        if not have_lsum and any(getattr(p.session, "lm", None) is None for p in self.predictors.values()):
-            _hip.check(self.L.mdf_letter_sums_dev(seq_ptr, _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]), ch.rows, _p(b["lsum"]), st))
-        for mode, pred in self.predictors.items():
-            feat = pred.session.topology["feature_dim"]
-            lm = getattr(pred.session, "lm", None)
-            if lm is None:
-                _hip.check(self.L.mdf_gcn_embed_dev(pred.session.handle, _p(b["lsum"]), _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]),
-                                                    ch.rows, _p(partial[mode], ch.group_base * feat), _p(b["gws"]), b["gws"].numel(), st))
-            else:
-                _hip.check(self.L.mdf_gcn_embed_lm_dev(pred.session.handle, seq_ptr, lm_h[id(lm)], _p(b["rowptr"]), _p(b["colidx"]),
-                                                       _p(b["val"]), ch.rows, _p(partial[mode], ch.group_base * feat), _p(b["gws"]),
-                                                       b["gws"].numel(), st))
-
-    # -- language model ------------------------------------------------------------------------------------------------
-    def _lm_batches(self, packed: PackedProteins):
-        """Consecutive chunk ranges [c0, c1) whose proteins run through the LSTM together: at most `lm_batch` proteins and
-        a time-major workspace (2 x (Lmax+1) x B x H floats) within `lm_workspace_bytes`.  The proteins are dealt evenly
-        over the fewest such groups: an LSTM time step costs whole rounds of 256x256 tiles, so a small trailing group
-        would cost as much as a full one."""
-        H = max(lm.hidden for lm in self.lms)
-        cap = min(self.lm_batch, 65535)
-        n_groups = max(1, -(-packed.B // cap))
-        while True:
-            target = -(-packed.B // n_groups)
-            out, c0, nb, lmax, ok = [], 0, 0, 0, True
-            for ci, ch in enumerate(packed.chunks):
-                n = ch.p1 - ch.p0
-                l = int(packed.Lq[ch.p0:ch.p1].max())
-                if ci > c0 and (nb + n > cap or nb >= target or 8 * (max(lmax, l) + 1) * (nb + n) * H > self.lm_workspace_bytes):
-                    out.append((c0, ci))
-                    c0, nb, lmax = ci, 0, 0
-                nb, lmax = nb + n, max(lmax, l)
-            out.append((c0, len(packed.chunks)))
-            if len(out) <= n_groups or n_groups >= len(packed.chunks):
-                return out
-            n_groups = len(out)   # memory or chunk granularity forced more groups: re-balance for that count
-
-    def _lm_forward(self, db: DeviceBatch, c0: int, c1: int, bases, seq_all, st):
-        """LSTM features of every protein in chunks [c0, c1) -> {id(lm): (rows_total, H) tensor} in residue-row layout."""
+    def _outputs(self, db: DeviceBatch, want_logits: bool):
         torch = _torch()
-        pk = db.packed
-        chunks = pk.chunks[c0:c1]
-        rows_total = bases[-1]
-        prot_row = np.concatenate([bases[k] + pk.chunk_row_off[ch.row_off_pos:ch.row_off_pos + (ch.p1 - ch.p0)].astype(np.int64)
-                                   for k, ch in enumerate(chunks)])
-        lens = pk.Lq[chunks[0].p0:chunks[-1].p1]
-        order = np.argsort(-lens.astype(np.int64), kind="stable")
-        lens_h = np.ascontiguousarray(lens[order], dtype=np.int32)
-        d_rows = torch.from_numpy(np.ascontiguousarray(prot_row[order])).to(self.device)
-        d_lens = torch.from_numpy(lens_h).to(self.device)
-        B, Lmax = len(lens_h), int(lens_h[0])
-        out = {}
-        for lm in self.lms:
-            need = self.L.mdf_lm_workspace_bytes(lm.handle, B, Lmax)
-            if self._bufs.get("lm_ws") is None or self._bufs["lm_ws"].numel() < need:
-                self._bufs["lm_ws"] = None
-                self._bufs["lm_ws"] = torch.empty(need, dtype=torch.uint8, device=self.device)
-            key = ("lm_h", id(lm))
-            if self._bufs.get(key) is None or self._bufs[key].numel() < rows_total * lm.hidden:
-                self._bufs[key] = None
-                self._bufs[key] = torch.zeros(rows_total * lm.hidden, dtype=torch.float32, device=self.device)
-            _hip.check(self.L.mdf_lm_forward_dev(lm.handle, _p(seq_all), _p(d_rows), _p(d_lens), _hip.ptr(lens_h), B, _p(self._bufs[key]),
-                                                 _p(self._bufs["lm_ws"]), self._bufs["lm_ws"].numel(), st))
-            out[id(lm)] = self._bufs[key]
-        self._keep = (d_rows, d_lens, lens_h)  # outlive the asynchronous launches
-        return out
+        scores = {m: torch.empty((db.B, p.n_terms), dtype=torch.float32, device=self.device) for m, p in self.predictors.items()}
+        logits = {m: torch.empty((db.B, 2 * p.n_terms), dtype=torch.float32, device=self.device) for m, p in self.predictors.items()} if want_logits else None
+        sp = (ctypes.c_void_p * len(self.modes))(*[scores[m].data_ptr() for m in self.modes])
+        lp = (ctypes.c_void_p * len(self.modes))(*[logits[m].data_ptr() for m in self.modes]) if want_logits else None
+        return scores, logits, sp, lp
 
-    def _pool_segment(self, db: DeviceBatch, seg: Segment, partial: dict, pooled: dict, st):
-        for mode, pred in self.predictors.items():
-            feat = pred.session.topology["feature_dim"]
-            _hip.check(self.L.mdf_gcn_pool_dev(pred.session.handle, _p(partial[mode]), _p(db.grp_off, seg.grp_off_pos), seg.p1 - seg.p0,
-                                               _p(pooled[mode], seg.p0 * feat), st))
-
-    def _alloc_partial(self, db):
+    def forward_alignments(self, db: DeviceBatch, want_logits: bool = False, out=None):
+        """Fused path: coords + alignments + sequences -> {mode: (B,T) float32 scores on the device}.  Asynchronous
+        on the current stream; call `check(db)` (one sync) before trusting the result.  `out`: the tuple a previous call with
+        the same `db` returned through `outputs_for(db)` -- re-using the output tensors lets the engine replay a short batch
+        as one hipGraph."""
+        if db.coords is None:
+            raise ValueError("batch was packed without coordinates/alignments")
         torch = _torch()
-        g = max(sg.groups for sg in db.packed.segments)
-        key = ("partial", g)
-        if self._bufs.get("partial_key") != key:
-            self._bufs["partial"] = {m: torch.empty(g * p.session.topology["feature_dim"], dtype=torch.float32, device=self.device)
-                                     for m, p in self.predictors.items()}
-            self._bufs["partial_key"] = key
-        return self._bufs["partial"]
+        with torch.cuda.device(self.device):
+            scores, logits, sp, lp = out if out is not None else self._outputs(db, want_logits)
+            _hip.check(self.L.mdf_engine_forward_alignments(self.handle, db.packed.plan, ctypes.byref(db.desc), sp, lp, self._stream()))
+        return (scores, logits) if logits is not None else scores
+
+    def outputs_for(self, db: DeviceBatch, want_logits: bool = False):
+        """Pre-allocated outputs for repeated forward_alignments(db, out=...) calls (steady-state serving of one batch shape)."""
+        return self._outputs(db, want_logits)
+
+    def forward_dense(self, db: DeviceBatch, cmaps, want_logits: bool = False):
+        """Reference-format path: one dense (L,L) contact map per protein (what build_align_contact_map returns,
+        int32) -> scores.  Maps are uploaded chunk by chunk (inside the library); synchronises before returning."""
+        torch = _torch()
+        if len(cmaps) != db.B:
+            raise ValueError("one contact map per protein expected")
+        flat = []
+        for p, A in enumerate(cmaps):
+            A = np.asarray(A)
+            Lp = int(db.packed.Lq[p])
+            if A.shape != (Lp, Lp):
+                raise ValueError(f"protein {p}: cmap shape {A.shape} != ({Lp},{Lp})")
+            flat.append(np.ascontiguousarray(A, dtype=np.float32 if A.dtype.kind == "f" else np.int32))
+        if len({a.dtype for a in flat}) > 1:
+            flat = [a.astype(np.float32) for a in flat]
+        dt = _hip.DT_F32 if flat[0].dtype == np.float32 else _hip.DT_I32
+        ptrs = (ctypes.c_void_p * db.B)(*[a.ctypes.data for a in flat])
+        with torch.cuda.device(self.device):
+            scores, logits, sp, lp = self._outputs(db, want_logits)
+            _hip.check(self.L.mdf_engine_forward_dense(self.handle, db.packed.plan, ctypes.byref(db.desc), ptrs, dt, sp, lp, self._stream()))
+        return (scores, logits) if want_logits else scores
 
     def lm_features(self, packed: PackedProteins, which: int = 0):
         """Language-model features (LSTM2 output) of every protein of `packed`: list of (L_p, H) float32 arrays.  For
@@ -399,188 +328,51 @@ class HotPathEngine:
         torch = _torch()
         lm = self.lms[which]
         db = self.upload(packed)
-        res = []
+        out = np.empty((int(packed.Lq.astype(np.int64).sum()), lm.hidden), dtype=np.float32)
         with torch.cuda.device(self.device):
-            st = self._stream()
-            keep_lms, self.lms = self.lms, [lm]
-            try:
-                for c0, c1 in self._lm_batches(packed):
-                    chunks = packed.chunks[c0:c1]
-                    bases = [0]
-                    for ch in chunks:
-                        bases.append(bases[-1] + ch.rows)
-                    seq_all = torch.empty(bases[-1], dtype=torch.uint8, device=self.device)
-                    for k, ch in enumerate(chunks):
-                        _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0),
-                                                             _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows,
-                                                             _p(seq_all, bases[k]), _p(db.bad, c0 + k), st))
-                    feats = self._lm_forward(db, c0, c1, bases, seq_all, st)[id(lm)]
-                    torch.cuda.current_stream(self.device).synchronize()
-                    host = feats[:bases[-1] * lm.hidden].view(bases[-1], lm.hidden).cpu().numpy()
-                    for k, ch in enumerate(chunks):
-                        ro = packed.chunk_row_off[ch.row_off_pos:ch.row_off_pos + (ch.p1 - ch.p0)]
-                        for j, p in enumerate(range(ch.p0, ch.p1)):
-                            r0 = bases[k] + int(ro[j])
-                            res.append(host[r0:r0 + int(packed.Lq[p])].copy())
-            finally:
-                self.lms = keep_lms
-        return res
+            _hip.check(self.L.mdf_engine_lm_features_host(self.handle, packed.plan, ctypes.byref(db.desc), int(which), _hip.ptr(out), self._stream()))
+        first_invalid_residue(packed, db.bad.cpu().numpy())
+        off = np.concatenate(([0], np.cumsum(packed.Lq.astype(np.int64))))
+        return [out[off[p]:off[p + 1]].copy() for p in range(packed.B)]
 
-    def _run_chunks(self, db: DeviceBatch, encode, build_csr, st):
-        """Common driver: per chunk `encode(ci, ch, seq_ptr)` writes the residue indices and `build_csr(ci, ch, seq_ptr)` the
-        adjacency (returning True when it also produced the layer-1 letter sums), then the GCN stack runs; segments are pooled as soon as their last chunk has been issued.  With a
-        language model the chunks are taken `lm_batch` proteins at a time: all of them are encoded first, the LSTM runs
-        over the whole group, then the per-chunk stages follow."""
-        torch = _torch()
-        pooled, partial = self._alloc_pooled(db), self._alloc_partial(db)
-        chunks, segs = db.packed.chunks, db.packed.segments
-        b = self._bufs
+    @property
+    def nnz_capacity(self) -> int:
+        return int(self.L.mdf_engine_nnz_capacity(self.handle))
 
-        def tail(ci, ch, seq_ptr, lm_h):
-            have_lsum = bool(build_csr(ci, ch, seq_ptr))
-            self._gcn_chunk(db, ch, partial, st, seq_ptr, lm_h, have_lsum)
-            if ci + 1 == len(chunks) or chunks[ci + 1].segment != ch.segment:
-                self._pool_segment(db, segs[ch.segment], partial, pooled, st)
-
-        if not self.lms:
-            for ci, ch in enumerate(chunks):
-                encode(ci, ch, _p(b["seq_idx"]))
-                tail(ci, ch, _p(b["seq_idx"]), None)
-            return pooled
-        for c0, c1 in self._lm_batches(db.packed):
-            bases = [0]
-            for ch in chunks[c0:c1]:
-                bases.append(bases[-1] + ch.rows)
-            if b.get("seq_all") is None or b["seq_all"].numel() < bases[-1]:
-                b["seq_all"] = torch.empty(bases[-1], dtype=torch.uint8, device=self.device)
-            for k, ci in enumerate(range(c0, c1)):
-                encode(ci, chunks[ci], _p(b["seq_all"], bases[k]))
-            feats = self._lm_forward(db, c0, c1, bases, b["seq_all"], st)
-            hid = {id(lm): lm.hidden for lm in self.lms}
-            for k, ci in enumerate(range(c0, c1)):
-                lm_h = {key: _p(t, bases[k] * hid[key]) for key, t in feats.items()}
-                tail(ci, chunks[ci], _p(b["seq_all"], bases[k]), lm_h)
-        return pooled
-
-    def _heads(self, db: DeviceBatch, pooled: dict, want_logits: bool, st):
-        torch = _torch()
-        scores, logits = {}, {}
-        for mode, pred in self.predictors.items():
-            T = pred.n_terms
-            scores[mode] = torch.empty((db.B, T), dtype=torch.float32, device=self.device)
-            lg = torch.empty((db.B, 2 * T), dtype=torch.float32, device=self.device) if want_logits else None
-            _hip.check(self.L.mdf_gcn_head_dev(pred.session.handle, _p(pooled[mode]), db.B, _p(scores[mode]),
-                                               _p(lg) if lg is not None else None, _p(self._bufs["hws"]),
-                                               self._bufs["hws"].numel(), st))
-            if want_logits:
-                logits[mode] = lg
-        return (scores, logits) if want_logits else scores
-
-    def _alloc_pooled(self, db):
-        torch = _torch()
-        return {m: torch.empty((db.B, p.session.topology["feature_dim"]), dtype=torch.float32, device=self.device)
-                for m, p in self.predictors.items()}
-
-    def forward_alignments(self, db: DeviceBatch, want_logits: bool = False):
-        """Fused path: coords + alignments + sequences -> {mode: (B,T) float32 scores on the device}.  Asynchronous
-        on the current stream; call `check(db)` (one sync) before trusting the result."""
-        if db.coords is None:
-            raise ValueError("batch was packed without coordinates/alignments")
+    def last_chunk_nnz(self) -> int:
+        """CSR entries of the chunk processed last (diagnostic for the A.X roofline of bench.py; synchronises)."""
         torch = _torch()
         with torch.cuda.device(self.device):
-            max_len = int(db.packed.Lq.max())
-            self._ensure(db.packed.max_chunk_rows, db.B, max_len)
-            b, st = self._bufs, self._stream()
-            want_lsum = any(getattr(p.session, "lm", None) is None for p in self.predictors.values())
+            return int(self.L.mdf_engine_last_chunk_nnz(self.handle, self._stream()))
 
-            def encode(ci, ch, seq_ptr):
-                _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0),
-                                                     _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows, seq_ptr,
-                                                     _p(db.bad, ci), st))
-
-            def build_csr(ci, ch, seq_ptr):
-                # contact stage: coordinates read once; the CSR fill also writes the layer-1 letter sums of the chunk
-                Bc = ch.p1 - ch.p0
-                ro = _p(db.chunk_row_off, ch.row_off_pos)
-                _hip.check(self.L.mdf_cmap_csr_dev(
-                    _p(db.coords), _p(db.coord_off, ch.p0), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off, ch.p0), _p(db.Lq, ch.p0), ro,
-                    Bc, ch.rows, max_len, self.threshold, self.generated_contacts, _p(b["rowptr"]), _p(b["colidx"]), _p(b["val"]),
-                    self._nnz_cap, _p(db.status, ci * 4), seq_ptr if want_lsum else None, _p(b["lsum"]) if want_lsum else None,
-                    _p(b["cws"]), b["cws"].numel(), st))
-                return want_lsum
-
-            pooled = self._run_chunks(db, encode, build_csr, st)
-            return self._heads(db, pooled, want_logits, st)
-
-    def forward_dense(self, db: DeviceBatch, cmaps, want_logits: bool = False):
-        """Reference-format path: one dense (L,L) contact map per protein (what build_align_contact_map returns,
-        int32) -> scores.  Maps are uploaded chunk by chunk."""
-        torch = _torch()
-        if len(cmaps) != db.B:
-            raise ValueError("one contact map per protein expected")
-        with torch.cuda.device(self.device):
-            self._ensure(db.packed.max_chunk_rows, db.B)
-            b, st = self._bufs, self._stream()
-            keep = []  # device copies of the maps must outlive the asynchronous kernels that read them
-
-            def encode(ci, ch, seq_ptr):
-                _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0),
-                                                     _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows, seq_ptr,
-                                                     _p(db.bad, ci), st))
-
-            def build_csr(ci, ch, seq_ptr):
-                Bc = ch.p1 - ch.p0
-                ro = _p(db.chunk_row_off, ch.row_off_pos)
-                flat, offs = [], [0]
-                for p in range(ch.p0, ch.p1):
-                    A = np.asarray(cmaps[p])
-                    Lp = int(db.packed.Lq[p])
-                    if A.shape != (Lp, Lp):
-                        raise ValueError(f"protein {p}: cmap shape {A.shape} != ({Lp},{Lp})")
-                    flat.append(np.ascontiguousarray(A, dtype=np.float32 if A.dtype.kind == "f" else np.int32).reshape(-1))
-                    offs.append(offs[-1] + Lp * Lp)
-                if len({a.dtype for a in flat}) > 1:
-                    flat = [a.astype(np.float32) for a in flat]
-                host = np.concatenate(flat)
-                d_maps = torch.from_numpy(host).to(self.device)
-                d_off = torch.from_numpy(np.asarray(offs[:-1], dtype=np.int64)).to(self.device)
-                keep.append((d_maps, d_off))
-                nnz_needed = int(sum(int(np.count_nonzero(a)) for a in flat)) + ch.rows
-                if nnz_needed > self._nnz_cap:
-                    torch.cuda.current_stream(self.device).synchronize()
-                    b["colidx"] = torch.empty(nnz_needed, dtype=torch.int32, device=self.device)
-                    b["val"] = torch.empty(nnz_needed, dtype=torch.float32, device=self.device)
-                    self._nnz_cap = nnz_needed
-                dt = _hip.DT_F32 if host.dtype == np.float32 else _hip.DT_I32
-                _hip.check(self.L.mdf_dense_to_csr_dev(_p(d_maps), dt, _p(d_off), _p(db.Lq, ch.p0), ro, Bc, ch.rows, _p(b["rowptr"]),
-                                                       _p(b["colidx"]), _p(b["val"]), self._nnz_cap, _p(db.status, ci * 4),
-                                                       _p(b["cws"]), b["cws"].numel(), st))
-                if len(keep) > 2:  # bound the device memory held by uploaded maps
-                    torch.cuda.current_stream(self.device).synchronize()
-                    del keep[:-1]
-
-            pooled = self._run_chunks(db, encode, build_csr, st)
-            out = self._heads(db, pooled, want_logits, st)
-            torch.cuda.current_stream(self.device).synchronize()
-            return out
+    def graph_stats(self):
+        """(forward calls replayed as one hipGraph, forward calls issued launch by launch)"""
+        g, e = _hip.c_int64(0), _hip.c_int64(0)
+        _hip.check(self.L.mdf_engine_graph_stats(self.handle, g, e))
+        return int(g.value), int(e.value)
 
     def check(self, db: DeviceBatch):
         """Synchronise and raise what the asynchronous stages flagged (invalid residue, CSR overflow)."""
         torch = _torch()
-        torch.cuda.current_stream(self.device).synchronize()
-        self.raise_flags(db.packed, db.bad.cpu().numpy(), db.status.cpu().numpy())
+        info = (ctypes.c_int64 * 4)()
+        with torch.cuda.device(self.device):
+            rc = self.L.mdf_engine_check(self.handle, db.packed.plan, ctypes.byref(db.desc), self._stream(), info)
+        if rc == _hip.MDF_EBADCHAR:
+            raise ValueError(f"Invalid character in sequence: {db.packed.seqs[info[0]][info[1]]}")
+        _hip.check(rc)
 
     def raise_flags(self, packed: PackedProteins, bad, st):
         """Turn the per-chunk device flags (host copies: bad (n_chunks,) int64, status (n_chunks, 4)) into the exceptions the
-        per-call API raises.  Chunks hold consecutive proteins, so the first flagged chunk carries the first invalid byte of
-        the whole batch: what the reference's serial loop would have hit first (predict.pyx:36-46)."""
+        per-call API raises -- for callers that copied the flags themselves (mDeepFRI.stream).  Chunks hold consecutive
+        proteins, so the first flagged chunk carries the first invalid byte of the whole batch: what the reference's serial loop
+        would have hit first (predict.pyx:36-46)."""
         first_invalid_residue(packed, bad)
         if (st[:, 2] != 0).any():
             raise ValueError(f"a query of length {int(st[:, 2].max())} exceeds the max_len the contact stage was given")
         if (st[:, 0] != 0).any():
             need = int(st[:, 1].max())
             raise _hip.CapacityError(_hip.MDF_ECAPACITY,
-                                     f"CSR capacity {self._nnz_cap} too small (a chunk needs {need}); raise nnz_per_row")
+                                     f"CSR capacity {self.nnz_capacity} too small (a chunk needs {need}); raise nnz_per_row")
 
     def run_alignments(self, packed: PackedProteins) -> dict:
         """Convenience: upload, run the fused path, validate, return {mode: np.ndarray (B,T)}.  On a CSR overflow the
@@ -592,7 +384,7 @@ class HotPathEngine:
         except _hip.CapacityError:
             need = int(db.status.cpu().numpy()[:, 1].max())
             self.nnz_per_row = need // max(packed.max_chunk_rows, 1) + 8
-            self._rows_alloc = 0
+            _hip.check(self.L.mdf_engine_set_nnz_per_row(self.handle, self.nnz_per_row))
             db = self.upload(packed)
             out = self.forward_alignments(db)
             self.check(db)

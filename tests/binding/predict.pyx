@@ -68,9 +68,25 @@ cdef extern from "mdfri.h":
     void mdf_cnn_free(mdf_cnn *m)
     int mdf_cnn_num_terms(const mdf_cnn *m)
     int mdf_cnn_forward_host(mdf_cnn *m, const char *seq, int64_t L, float *scores, int64_t *bad_idx) nogil
+    ctypedef struct mdf_engine
+    ctypedef struct mdf_engine_config:
+        int32_t max_rows
+        int32_t nnz_per_row
+        double threshold
+        int32_t generated_contacts
+        int32_t max_segment_groups
+        int32_t lm_batch
+        double lm_workspace_gib
+        int32_t graph_max_chunks
+    int mdf_engine_create(mdf_model *const *models, int32_t n_models, int device, const mdf_engine_config *cfg, mdf_engine **out)
+    void mdf_engine_free(mdf_engine *e)
+    int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords,
+                                       const int32_t *Lt, const char *q_aln, const char *t_aln, const int32_t *La,
+                                       float *const *scores_host, int64_t *info) nogil
 
 DEF MDF_EBADCHAR = -4
 DEF MDF_DT_F32 = 1
+DEF MAX_HEADS = 8
 
 
 cdef int _check(int rc) except -1:
@@ -217,3 +233,59 @@ cdef class Predictor(object):
             mdf_lm_free(self._lm)
         if self._cnn != NULL:
             mdf_cnn_free(self._cnn)
+
+
+def predict_batch(list predictors, list seqs, list coords, list q_alns, list t_alns, double threshold = 6.0, int generated_contacts = 2,
+                  int max_rows = 65536):
+    """The batched counterpart of the reference's two loops -- Pool.map(build_align_contact_map) (pipeline.py:476-481) followed by
+    _run_prediction_loop (pipeline.py:292-319) -- as ONE call into the library (mdf_engine_run_alignments_host): C-alpha
+    coordinates + gapped alignments + sequences of B proteins in, one (B, T) float32 array per GCN Predictor out.  The arrays
+    cross the boundary as packed bytes / floats with per-protein lengths; planning, upload, the fused launch sequence,
+    validation (with the CSR-capacity retry) and the download happen inside."""
+    cdef int n = len(predictors), B = len(seqs), k
+    cdef mdf_model *models[MAX_HEADS]
+    cdef float *outs[MAX_HEADS]
+    cdef mdf_engine *eng = NULL
+    cdef mdf_engine_config cfg
+    cdef int64_t info[4]
+    cdef int rc
+    cdef Predictor pr
+    if n == 0 or n > MAX_HEADS:
+        raise ValueError(f"1..{MAX_HEADS} predictors expected")
+    if not (len(coords) == len(q_alns) == len(t_alns) == B) or B == 0:
+        raise ValueError("seqs, coords, q_alns and t_alns must be non-empty lists of one length")
+    for k in range(n):
+        pr = predictors[k]
+        if pr._gcn == NULL:
+            raise ValueError("predict_batch takes GCN predictors")
+        models[k] = pr._gcn
+    cdef bytes sb = "".join(seqs).encode("ascii"), qb = "".join(q_alns).encode("ascii"), tb = "".join(t_alns).encode("ascii")
+    cdef cnp.ndarray[int32_t, ndim=1, mode="c"] Lq = np.array([len(x) for x in seqs], dtype=np.int32)
+    cdef cnp.ndarray[int32_t, ndim=1, mode="c"] La = np.array([len(x) for x in q_alns], dtype=np.int32)
+    if [len(x) for x in t_alns] != La.tolist():
+        raise ValueError("gapped query and target differ in length")
+    cs = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1, 3) for c in coords]
+    cdef cnp.ndarray[int32_t, ndim=1, mode="c"] Lt = np.array([c.shape[0] for c in cs], dtype=np.int32)
+    cdef cnp.ndarray[float, ndim=2, mode="c"] xyz = np.ascontiguousarray(np.concatenate(cs, axis=0)) if int(Lt.sum()) else np.zeros((1, 3), np.float32)
+    results = [np.empty((B, (<Predictor>predictors[k])._T), dtype=np.float32) for k in range(n)]
+    for k in range(n):
+        outs[k] = <float *>cnp.PyArray_DATA(results[k])
+    cfg.max_rows, cfg.nnz_per_row, cfg.threshold, cfg.generated_contacts = max_rows, 0, threshold, generated_contacts
+    cfg.max_segment_groups, cfg.lm_batch, cfg.lm_workspace_gib, cfg.graph_max_chunks = 0, 0, 0.0, 0
+    _check(mdf_engine_create(models, n, 0, &cfg, &eng))
+    cdef const char *sp = sb
+    cdef const char *qp = qb
+    cdef const char *tp = tb
+    cdef const int32_t *lqp = <const int32_t *>Lq.data
+    cdef const int32_t *ltp = <const int32_t *>Lt.data
+    cdef const int32_t *lap = <const int32_t *>La.data
+    cdef const float *xp = <const float *>xyz.data
+    try:
+        with nogil:
+            rc = mdf_engine_run_alignments_host(eng, sp, lqp, B, xp, ltp, qp, tp, lap, outs, info)
+        if rc == MDF_EBADCHAR:
+            raise ValueError(f"Invalid character in sequence: {seqs[info[0]][info[1]]}")
+        _check(rc)
+    finally:
+        mdf_engine_free(eng)
+    return results

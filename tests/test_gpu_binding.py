@@ -93,6 +93,36 @@ def test_predictor_gcn_lm_and_cnn_through_the_compiled_class(compiled, tmp_path)
     assert np.max(np.abs(pc.forward_pass(seq) - cnn_oracle.cnn_forward(wc, seq))) < 1e-4
 
 
+def test_predict_batch_10k_l512_through_the_compiled_binding(compiled, tmp_path):
+    """BASELINE configs[2]'s batch -- 10 000 synthetic L=512 proteins, MF + CC heads -- through the COMPILED binding alone:
+    `predict_batch` is one cdef-extern call into mdf_engine_run_alignments_host (no torch, no ctypes, no Python loop over chunks).
+    Bitwise equal to the ctypes/torch engine on the same inputs; a sample is checked against the per-call compiled
+    `Predictor.forward_pass` (bitwise) and the oracle (1e-4)."""
+    _, pr = compiled
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.predict import Predictor as CtypesPredictor
+    seqs, coords, q_alns, t_alns = bench.make_fixed_length(42 + 2, 10_000, 512)
+    ws = {"mf": synthetic.glorot_gcn_weights(seed=0, n_terms=synthetic.GO_TERMS["mf"]), "cc": synthetic.glorot_gcn_weights(seed=2, n_terms=synthetic.GO_TERMS["cc"])}
+    preds = []
+    for m, w in ws.items():
+        weights.save_mdfw(str(tmp_path / f"{m}.mdfw"), w)
+        preds.append(pr.Predictor(str(tmp_path / f"{m}.mdfw")))
+    got = pr.predict_batch(preds, seqs, coords, q_alns, t_alns)
+    assert [g.shape for g in got] == [(10_000, 489), (10_000, 320)] and all(g.dtype == np.float32 for g in got)
+    eng = HotPathEngine({m: CtypesPredictor(m, weights=w) for m, w in ws.items()}, device=0, max_rows=65536)
+    ref = eng.run_alignments(PackedProteins.pack(seqs, coords, q_alns, t_alns, max_rows=65536))
+    assert np.array_equal(got[0], ref["mf"]) and np.array_equal(got[1], ref["cc"])
+    for i in (0, 4999, 9999):
+        cm = orc.build_align_contact_map(coords[i], q_alns[i], t_alns[i], 6.0, 2)
+        assert np.array_equal(got[0][i], preds[0].forward_pass(seqs[i], cm))
+        assert np.max(np.abs(got[0][i] - gcn_oracle.gcn_forward(ws["mf"], seqs[i], cm))) < 1e-4
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        pr.predict_batch(preds, ["ACD", "AJD"], [coords[0][:3], coords[1][:3]], ["ACD", "AJD"], ["ACD", "AJD"])
+
+
 def test_forked_pool_map_build_align_contact_map():
     """reference pipeline.py:476-481 from a parent that has not touched the GPU (a fresh interpreter: this pytest process has)."""
     env = dict(os.environ)

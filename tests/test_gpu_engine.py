@@ -1,0 +1,133 @@
+"""The batch engine behind the C ABI (include/mdfri.h `mdf_engine_*`, csrc/engine.hip) on the GPU: the single-call host entry,
+the hipGraph replay of short batches, and the validation codes -- against the oracle chain and against the launch-by-launch form
+(bitwise)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import cmap_oracle as orc
+import gcn_oracle
+from mDeepFRI import _hip, synthetic
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def heads():
+    from mDeepFRI.predict import Predictor
+    ws = {"mf": synthetic.glorot_gcn_weights(seed=0, n_terms=synthetic.GO_TERMS["mf"]),
+          "cc": synthetic.glorot_gcn_weights(seed=2, n_terms=synthetic.GO_TERMS["cc"])}
+    return ws, {m: Predictor(f"synthetic-{m}", weights=w) for m, w in ws.items()}
+
+
+def _pack(prots, **kw):
+    from mDeepFRI.batch import PackedProteins
+    return PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots], [p["t_aln"] for p in prots], **kw)
+
+
+def _run_host(L, handle, prots, n_terms):
+    seqs = "".join(p["seq"] for p in prots).encode()
+    q = "".join(p["q_aln"] for p in prots).encode()
+    t = "".join(p["t_aln"] for p in prots).encode()
+    Lq = np.array([len(p["seq"]) for p in prots], dtype=np.int32)
+    Lt = np.array([p["coords"].shape[0] for p in prots], dtype=np.int32)
+    La = np.array([len(p["q_aln"]) for p in prots], dtype=np.int32)
+    xyz = np.ascontiguousarray(np.concatenate([p["coords"] for p in prots], axis=0), dtype=np.float32)
+    outs = [np.empty((len(prots), T), dtype=np.float32) for T in n_terms]
+    ptrs = (ctypes.c_void_p * len(outs))(*[o.ctypes.data for o in outs])
+    info = (ctypes.c_int64 * 4)()
+    rc = L.mdf_engine_run_alignments_host(handle, seqs, _hip.ptr(Lq), len(prots), _hip.ptr(xyz), _hip.ptr(Lt), q, t, _hip.ptr(La), ptrs, info)
+    return rc, outs, list(info)
+
+
+def test_single_call_host_entry_vs_oracle_and_engine(heads):
+    """mdf_engine_run_alignments_host: packed host arrays in, (B, T) host arrays out, nothing else -- SURVEY.md section 8b's
+    `mdf_cmap_batch` + `mdf_gcn_forward_batch`.  Several chunks, indels, two heads; vs the oracle chain and bitwise vs the
+    device-pointer form the Python engine uses."""
+    from mDeepFRI.batch import HotPathEngine
+    ws, preds = heads
+    prots = synthetic.synthetic_proteins(seed=61, count=40, length=(20, 420), indel_rate=0.07)
+    eng = HotPathEngine(preds, device=0, max_rows=2048)
+    ref = eng.run_alignments(_pack(prots, max_rows=2048))
+    rc, outs, info = _run_host(eng.L, eng.handle, prots, [preds[m].n_terms for m in eng.modes])
+    assert rc == 0, _hip.last_error()
+    for m, got in zip(eng.modes, outs):
+        assert np.array_equal(got, ref[m]), m
+    for i in (0, 7, 39):
+        p = prots[i]
+        cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
+        for m, got in zip(eng.modes, outs):
+            assert np.max(np.abs(got[i] - gcn_oracle.gcn_forward(ws[m], p["seq"], cm))) < TOL, (m, i)
+
+
+def test_single_call_host_entry_reports_what_the_loop_would_raise(heads):
+    from mDeepFRI.batch import HotPathEngine
+    ws, preds = heads
+    prots = synthetic.synthetic_proteins(seed=62, count=12, length=(30, 150))
+    eng = HotPathEngine(preds, device=0, max_rows=256)
+    # first invalid residue of the batch: protein 3 before protein 7, lowest position first (reference predict.pyx:36-46)
+    bad = [dict(p) for p in prots]
+    for i, pos in ((7, 2), (3, 11), (3, 20)):
+        s = bad[i]["seq"]
+        bad[i]["seq"] = bad[i]["q_aln"] = bad[i]["t_aln"] = s[:pos] + "J" + s[pos + 1:]
+    rc, _, info = _run_host(eng.L, eng.handle, bad, [preds[m].n_terms for m in eng.modes])
+    assert rc == _hip.MDF_EBADCHAR and info[:2] == [3, 11]
+    # a gapped query that does not spell its sequence is refused before anything is uploaded
+    broken = [dict(p) for p in prots]
+    broken[5]["q_aln"] = broken[5]["q_aln"][:-1] + "-"
+    rc, _, _ = _run_host(eng.L, eng.handle, broken, [preds[m].n_terms for m in eng.modes])
+    assert rc == _hip.MDF_EINVAL and "protein 5" in _hip.last_error()
+    # CSR capacity far too small: one automatic retry inside the call
+    tight = HotPathEngine(preds, device=0, max_rows=256, nnz_per_row=2)
+    rc, outs, _ = _run_host(tight.L, tight.handle, prots, [preds[m].n_terms for m in tight.modes])
+    assert rc == 0, _hip.last_error()
+    ref = eng.run_alignments(_pack(prots, max_rows=256))
+    assert all(np.array_equal(o, ref[m]) for m, o in zip(tight.modes, outs))
+
+
+@pytest.mark.parametrize("B,L", [(8, 512), (3, 77), (64, 200)])
+def test_short_batches_replay_as_one_graph_bitwise(heads, B, L):
+    """A batch of at most graph_max_chunks chunks: from the third identical call on the launch sequence is ONE hipGraphLaunch.
+    Replayed results == launch-by-launch results, bit for bit; flags still work under replay."""
+    import torch
+    from mDeepFRI.batch import HotPathEngine
+    ws, preds = heads
+    prots = synthetic.synthetic_proteins(seed=B * 1000 + L, count=B, length=L, indel_rate=0.05)
+    pk = _pack(prots, max_rows=65536)
+    eager = HotPathEngine(preds, device=0, max_rows=65536, graph_max_chunks=-1)
+    ref = eager.run_alignments(pk)
+    assert eager.graph_stats()[0] == 0
+    eng = HotPathEngine(preds, device=0, max_rows=65536)
+    db = eng.upload(pk)
+    out = eng.outputs_for(db)
+    for k in range(6):
+        for t in out[0].values():
+            t.zero_()
+        scores = eng.forward_alignments(db, out=out)
+        eng.check(db)
+        for m in eng.modes:
+            assert np.array_equal(scores[m].cpu().numpy(), ref[m]), (k, m)
+    g, e = eng.graph_stats()
+    assert g == 4 and e == 2, (g, e)          # calls 1-2 launch by launch, call 3 captures + replays, calls 4-6 replay
+    # a different batch of the same shape through the same engine: its own key, its own results
+    other = synthetic.synthetic_proteins(seed=B * 1000 + L + 1, count=B, length=L, indel_rate=0.05)
+    assert np.array_equal(eng.run_alignments(_pack(other))["mf"], eager.run_alignments(_pack(other))["mf"])
+    torch.cuda.synchronize()
+
+
+def test_graph_replay_keeps_reporting_invalid_residues(heads):
+    from mDeepFRI.batch import HotPathEngine
+    ws, preds = heads
+    prots = synthetic.synthetic_proteins(seed=5, count=6, length=90)
+    s = prots[4]["seq"]
+    prots[4]["seq"] = prots[4]["q_aln"] = prots[4]["t_aln"] = s[:17] + "*" + s[18:]
+    eng = HotPathEngine(preds, device=0)
+    db = eng.upload(_pack(prots))
+    out = eng.outputs_for(db)
+    for _ in range(5):
+        eng.forward_alignments(db, out=out)
+        with pytest.raises(ValueError, match=r"Invalid character in sequence: \*"):
+            eng.check(db)
+    assert eng.graph_stats()[0] >= 2

@@ -37,7 +37,7 @@ for name, prots in (("L512 x 512", synthetic.synthetic_proteins(3, 512, 512)),
     n, ms = _hip.c_int64(0), _hip.ctypes.c_double(0.0)
     lib.mdf_timing_read(b"ax", n, ms)
     rows = sum(c.rows for c in pk.chunks) / len(pk.chunks)
-    nnz = float(eng._bufs["rowptr"][pk.chunks[-1].rows].item()) / pk.chunks[-1].rows
+    nnz = float(eng.last_chunk_nnz()) / pk.chunks[-1].rows
     us = 1e3 * ms.value / max(n.value, 1)
     gbs = rows * (2 * 4 * 512 + 4 + 8 * nnz) / (us * 1e-6) / 1e9
     h.update(out["mf"].cpu().numpy().tobytes())
