@@ -1,7 +1,7 @@
-"""Developer fuzz (not in the test suite): random GCN head shapes, chunk sizes, CSR capacities and workloads against the oracle."""
+"""Developer fuzz (run by hand from the repository root: python tests/fuzz/<name>.py; a seeded slice of it is in tests/test_gpu_gcn.py): random GCN head shapes, chunk sizes, CSR capacities and workloads against the oracle."""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "metagenomic-deepfri_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "oracle"))
 import numpy as np
 import cmap_oracle, gcn_oracle
 from mDeepFRI import synthetic

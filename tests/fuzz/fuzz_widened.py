@@ -1,4 +1,4 @@
-"""Developer fuzz (not in the test suite): random CNN topologies and random LM-model shapes / batch splits against the oracles."""
+"""Developer fuzz (run by hand from the repository root: python tests/fuzz/<name>.py; a seeded slice of it is in tests/test_gpu_gcn.py): random CNN topologies and random LM-model shapes / batch splits against the oracles."""
 import os, sys
 sys.path.insert(0, "metagenomic-deepfri_amd"); sys.path.insert(0, "oracle")
 import numpy as np

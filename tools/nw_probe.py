@@ -7,7 +7,6 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
 import torch  # noqa: E402
 from mDeepFRI import _hip, synthetic  # noqa: E402
 from mDeepFRI.alignment import ScoringMatrix, _PairBatch, align_queries_arrays  # noqa: E402
