@@ -428,9 +428,13 @@ int mdf_nw_plan(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pa
                 int64_t *ops_off);
 
 /* Host helper: length of the leading run of LARGE pairs (>= 512 x 512 cells) of a pair list ordered by decreasing size -- the
- * n_long argument below.  Large pairs get a whole workgroup each (their 64-column strips run as a four-wave pipeline); with a
- * single wave a 2 000 x 2 000 pair would outlive the rest of the launch by milliseconds.  0 is always valid. */
+ * n_long argument of mdf_nw_score_dev.  Large pairs get a whole workgroup each (their 64-column strips run as a pipeline sixteen
+ * waves deep, the column between two strips handed over through LDS); with a single wave a 2 000 x 2 000 pair would outlive the
+ * rest of the launch by milliseconds.  0 is always valid. */
 int32_t mdf_nw_count_long(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P);
+/* The same for mdf_nw_align_dev: full alignments are asked for far fewer pairs (one winner per query), so the launch lasts as
+ * long as its longest serial chain and the workgroup form pays from 256 x 256 cells on. */
+int32_t mdf_nw_count_long_align(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P);
 
 /* Scores of P pairs (device pointers; bnd: int32 workspace of bnd_off[P] elements).  Pairs [0, n_long): one workgroup per pair;
  * the others: one wave per pair. */

@@ -26,8 +26,12 @@ namespace mdf {
 
 constexpr int NW_NEG = INT32_MIN / 2;
 constexpr int NW_LDA = 32;   // row pitch of the substitution matrix in LDS; alphabet size <= 32
+constexpr int NW_WG_WAVES = 16;                 // waves per workgroup: the depth of the strip pipeline of a long pair
+constexpr int NW_THREADS = NW_WG_WAVES * 64;
 constexpr int NW_MAX_COOP_STRIPS = 2048;   // a cooperatively swept pair has at most this many 64-column strips (Lt <= 131 072)
-constexpr int64_t NW_COOP_MIN_CELLS = 512 * 512;   // pairs at least this large get a workgroup of their own
+constexpr int NW_LDS_ROWS = 4096;          // ... and keeps the column between two strips in LDS when its query is at most this long
+constexpr int64_t NW_COOP_MIN_CELLS = 512 * 512;         // score mode: pairs at least this large get a workgroup of their own
+constexpr int64_t NW_COOP_MIN_CELLS_ALIGN = 256 * 256;   // full alignments (far fewer pairs, launch = its longest chains): earlier
 
 // lane l <- value of lane l-1 (previous lane of the wave); lane 0 <- fill.  DPP wave_shr:1 (gfx9 family: one VALU op).
 __device__ __forceinline__ int wave_shr1(int v, int fill)
@@ -38,23 +42,29 @@ __device__ __forceinline__ int wave_shr1(int v, int fill)
 __device__ __forceinline__ int ld_coherent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coherent(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// steps of one strip, padded: rows Lq skewed over 64 lanes
-__host__ __device__ __forceinline__ int64_t nw_strip_steps(int Lq) { return (int64_t)Lq + 64; }
+// steps of one strip: rows Lq skewed over 64 lanes, padded to whole groups of four (four direction bytes make one stored word)
+__host__ __device__ __forceinline__ int64_t nw_strip_steps(int Lq) { return ((int64_t)Lq + 63 + 3) / 4 * 4; }
 
+// Direction bytes of a full alignment (k_nw<true> writes, k_nw_traceback reads): strip k occupies nw_strip_steps(Lq) * 64 bytes;
+// inside it, the four steps 4g .. 4g+3 of lane l share the 32-bit word (g * 64 + l), step s in byte (s & 3) -- one coalesced
+// 256-byte store per wave and four steps.  Byte: bits 0-1 source of H (0 diagonal, 1 vertical gap 'D', 2 horizontal gap 'I'),
+// bit 2 E extended, bit 3 F extended, bit 4 the two residues are equal ('M' instead of 'X').
 template <bool TRACE>
-__global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
-                                            const int32_t *__restrict__ seq_len, const int32_t *__restrict__ pair_q,
-                                            const int32_t *__restrict__ pair_t, int P, const int32_t *__restrict__ matrix, int A,
-                                            int go, int ge, const int64_t *__restrict__ bnd_off, int32_t *bnd,
-                                            const int64_t *__restrict__ trace_off, uint8_t *__restrict__ trace,
-                                            int32_t *__restrict__ scores, int n_long, int tie_rule)
+__global__ __launch_bounds__(NW_THREADS) void k_nw(const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
+                                                   const int32_t *__restrict__ seq_len, const int32_t *__restrict__ pair_q,
+                                                   const int32_t *__restrict__ pair_t, int P, const int32_t *__restrict__ matrix, int A,
+                                                   int go, int ge, const int64_t *__restrict__ bnd_off, int32_t *bnd,
+                                                   const int64_t *__restrict__ trace_off, uint8_t *__restrict__ trace,
+                                                   int32_t *__restrict__ scores, int n_long, int tie_rule)
 {
-    // Pairs [0, n_long) are LONG: one whole workgroup per pair, wave w sweeps strips w, w+4, ... and may enter a 64-row chunk of
-    // strip k as soon as strip k-1 has published the boundary values of those rows (s_prog, LDS) -- the strips of one matrix
-    // run as a pipeline four waves deep.  Without it a single 2 000 x 2 000 pair is a serial chain of ~67 000 steps on one wave
-    // that outlives everything else in the launch by milliseconds.  Pairs >= n_long: one wave per pair, four pairs per workgroup.
+    // Pairs [0, n_long) are LONG: one whole workgroup per pair, wave w sweeps strips w, w+16, ... and may enter a 64-row chunk of
+    // strip k as soon as strip k-1 has published the boundary values of those rows (s_prog, LDS) -- the strips of one matrix run
+    // as a pipeline sixteen waves deep, the column between two strips handed over through LDS (s_bnd) when the query fits.
+    // Without it a single 2 000 x 2 000 pair is a serial chain of ~67 000 steps on one wave that outlives everything else in the
+    // launch by milliseconds.  Pairs >= n_long: one wave per pair, sixteen pairs per workgroup, boundary column through L2.
     __shared__ int s_S[NW_LDA * NW_LDA];
     __shared__ int s_prog[NW_MAX_COOP_STRIPS];
+    extern __shared__ int s_bnd[];   // [2][NW_LDS_ROWS] when the launch has long pairs (dynamic)
     for (int e = threadIdx.x; e < NW_LDA * NW_LDA; e += blockDim.x) {
         const int r = e / NW_LDA, c = e % NW_LDA;
         s_S[e] = (r < A && c < A) ? matrix[r * A + c] : 0;
@@ -66,30 +76,33 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
         for (int e = threadIdx.x; e < NW_MAX_COOP_STRIPS; e += blockDim.x) s_prog[e] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int p = own_block ? (int)blockIdx.x : n_long + ((int)blockIdx.x - n_long) * 4 + wid;
+    const int p = own_block ? (int)blockIdx.x : n_long + ((int)blockIdx.x - n_long) * NW_WG_WAVES + wid;
     if (p >= P) return;
     const int iq = pair_q[p], it = pair_t[p];
     const int Lq = seq_len[iq], Lt = seq_len[it];
     // a caller's n_long is not trusted with the size of s_prog: a pair with more strips than it holds is swept by wave 0 alone
     const bool coop = own_block && ((Lt + 63) >> 6) <= NW_MAX_COOP_STRIPS;
     if (own_block && !coop && wid != 0) return;
+    const bool lds_bnd = coop && Lq <= NW_LDS_ROWS;
     const uint8_t *q = codes + seq_off[iq], *t = codes + seq_off[it];
     if (Lq == 0 || Lt == 0) {   // degenerate: one all-gap run (or nothing)
         if (lane == 0 && (!coop || wid == 0)) scores[p] = (Lq + Lt == 0) ? 0 : -(go + (Lq + Lt - 1) * ge);
         return;
     }
-    int32_t *Hb = bnd + bnd_off[p], *Eb = Hb + Lq;   // H / E of the column left of the current strip, rows 1..Lq
+    int32_t *Hb = bnd + bnd_off[p], *Eb = Hb + Lq;   // H / E of the column left of the current strip, rows 1..Lq (when not in LDS)
+    volatile int *Hl = s_bnd, *El = s_bnd + NW_LDS_ROWS;
     uint8_t *tr = TRACE ? trace + trace_off[p] : nullptr;
     const int n_strips = (Lt + 63) >> 6;
-    const int n_steps = Lq + 63;
-    for (int k = coop ? wid : 0; k < n_strips; k += coop ? 4 : 1) {
+    const int n_steps = (int)nw_strip_steps(Lq);        // >= Lq + 63; the padding steps are inactive everywhere
+    for (int k = coop ? wid : 0; k < n_strips; k += coop ? NW_WG_WAVES : 1) {
         const int j = (k << 6) + lane;                 // my column: target residue j, DP column j + 1
         const int tc = j < Lt ? min((int)t[j], NW_LDA - 1) : 0;   // (codes are validated by the host entry points; clamped so that a bad one cannot index outside the table)
         int up = -(go + j * ge);                       // H[0][j+1]
         int fup = NW_NEG;                              // F[0][j+1]
         int diag = j == 0 ? 0 : -(go + (j - 1) * ge);  // H[0][j]
         int h_out = NW_NEG, e_out = NW_NEG, qc = 0;
-        uint8_t *trk = TRACE ? tr + (int64_t)k * nw_strip_steps(Lq) * 64 : nullptr;
+        uint32_t *trk = TRACE ? reinterpret_cast<uint32_t *>(tr + (int64_t)k * nw_strip_steps(Lq) * 64) : nullptr;
+        uint32_t dir_word = 0;
         const bool pass_right = k + 1 < n_strips;
         // the substitution score of the NEXT step is looked up one step ahead (its query residue is known as soon as the shift
         // register has moved), so that the LDS latency is off the step-to-step dependency chain
@@ -105,17 +118,22 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
             } else {
                 if (coop) {   // rows [s0, s0 + 64) of the left neighbour strip must have been published
                     const int need = min(Lq, s0 + 64);
-                    while (__hip_atomic_load(&s_prog[k - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
+                    while (__hip_atomic_load(&s_prog[k - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
                 }
-                hbchunk = r < Lq ? ld_coherent(Hb + r) : NW_NEG;
-                ebchunk = r < Lq ? ld_coherent(Eb + r) : NW_NEG;
+                if (lds_bnd) {
+                    hbchunk = r < Lq ? Hl[r] : NW_NEG;
+                    ebchunk = r < Lq ? El[r] : NW_NEG;
+                } else {
+                    hbchunk = r < Lq ? ld_coherent(Hb + r) : NW_NEG;
+                    ebchunk = r < Lq ? ld_coherent(Eb + r) : NW_NEG;
+                }
             }
             if (s0 == 0) {
                 qc_next = wave_shr1(0, __builtin_amdgcn_readlane(qchunk, 0));
                 sc_cur = s_S[qc_next * NW_LDA + tc];
             }
             int hb_keep = 0, eb_keep = 0;              // lane u keeps what lane 63 produced at step s0 + u (row s0 + u - 63)
-            const int u_end = min(64, n_steps - s0);
+            const int u_end = min(64, n_steps - s0);   // a multiple of four
             for (int u = 0; u < u_end; ++u) {
                 const int s = s0 + u;
                 // what lane l-1 produced one step ago is this row's left neighbour; lane 0 takes the boundary column
@@ -143,7 +161,7 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
                     const int g1 = horiz_first ? e : f, g2 = horiz_first ? f : e;
                     if (g1 > h || (gap_first && g1 == h)) { h = g1; src = horiz_first ? 2 : 1; }
                     if (g2 > h || (gap_first && g2 == h && src == 0)) { h = g2; src = horiz_first ? 1 : 2; }
-                    code |= src;
+                    code |= src | (qc == tc ? 16 : 0);
                 } else {
                     e = max(e_open, e_ext);
                     f = max(f_open, f_ext);
@@ -161,86 +179,147 @@ __global__ __launch_bounds__(256) void k_nw(const uint8_t *__restrict__ codes, c
                     eb_keep = lane == u ? e63 : eb_keep;
                 }
                 if (active && i == Lq - 1 && j == Lt - 1) scores[p] = h;
-                if (TRACE) trk[(int64_t)s * 64 + lane] = (uint8_t)(active ? code : 0);   // 64 contiguous bytes per step
+                if (TRACE) {   // four steps make one word: a 256-byte coalesced store per wave
+                    dir_word |= (uint32_t)(active ? code : 0) << ((u & 3) * 8);
+                    if ((u & 3) == 3) {
+                        trk[(int64_t)(s >> 2) * 64 + lane] = dir_word;
+                        dir_word = 0;
+                    }
+                }
             }
             if (pass_right) {
                 // lane 63 worked on row s0 + u - 63 at step s0 + u: one coalesced store of the chunk's boundary values
                 const int row = s0 + lane - 63;
-                if (lane < u_end && row >= 0 && row < Lq) {
-                    st_coherent(Hb + row, hb_keep);
-                    st_coherent(Eb + row, eb_keep);
-                }
-                if (coop) {   // publish: rows [0, s0 + u_end - 63) of this strip's right boundary are in memory
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (lane == 0)
-                        __hip_atomic_store(&s_prog[k], max(0, min(Lq, s0 + u_end - 63)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const bool mine = lane < u_end && row >= 0 && row < Lq;
+                if (lds_bnd) {
+                    if (mine) {
+                        Hl[row] = hb_keep;
+                        El[row] = eb_keep;
+                    }
+                    // LDS executes a wave's accesses in order: once these are counted out, the progress word may follow (the trace
+                    // stores still in flight to HBM are nobody's business here -- a release fence would wait for them too)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&s_prog[k], max(0, min(Lq, s0 + u_end - 63)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    if (mine) {
+                        st_coherent(Hb + row, hb_keep);
+                        st_coherent(Eb + row, eb_keep);
+                    }
+                    if (coop) {   // publish: rows [0, s0 + u_end - 63) of this strip's right boundary are in memory
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0)
+                            __hip_atomic_store(&s_prog[k], max(0, min(Lq, s0 + u_end - 63)), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the boundary column is complete before the next strip reads it
+        if (!lds_bnd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the boundary column is complete before the next strip reads it
     }
 }
 
-// One thread per pair: walk the direction bytes back from (Lq, Lt).  Operations (and, optionally, the gapped strings) are
-// written back to front into [ops_off[p+1] - n, ops_off[p+1]); op_len[p] = n, n_match[p] = number of 'M'.
-__global__ __launch_bounds__(64) void k_nw_traceback(const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
-                                                     const int32_t *__restrict__ seq_len, const int32_t *__restrict__ pair_q,
-                                                     const int32_t *__restrict__ pair_t, int P, const int64_t *__restrict__ trace_off,
-                                                     const uint8_t *__restrict__ trace, const int64_t *__restrict__ ops_off,
-                                                     const char *__restrict__ alphabet, char *__restrict__ ops,
-                                                     char *__restrict__ q_aln, char *__restrict__ t_aln,
-                                                     int32_t *__restrict__ op_len, int32_t *__restrict__ n_match)
+// One WAVE per pair: walk the direction bytes back from (Lq, Lt).  Every lane executes the same walk (the position is
+// wave-uniform); the bytes come from a 64-step window of the current strip staged in LDS by wave-wide loads (4 KiB, refilled
+// about every 32-64 moves), so a move costs an LDS read instead of an L2 round trip.  Operations are written back to front
+// into [ops_off[p+1] - n, ops_off[p+1]); op_len[p] = n, n_match[p] = number of 'M' (the "residues are equal" bit travels with
+// the direction byte, so no residue is read here).
+__global__ __launch_bounds__(256) void k_nw_traceback(const int32_t *__restrict__ seq_len, const int32_t *__restrict__ pair_q,
+                                                      const int32_t *__restrict__ pair_t, int P, const int64_t *__restrict__ trace_off,
+                                                      const uint8_t *__restrict__ trace, const int64_t *__restrict__ ops_off,
+                                                      char *__restrict__ ops, int32_t *__restrict__ op_len, int32_t *__restrict__ n_match)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_win[4][1024];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wid;
     if (p >= P) return;
-    const int iq = pair_q[p], it = pair_t[p];
-    const int Lq = seq_len[iq], Lt = seq_len[it];
-    const uint8_t *q = codes + seq_off[iq], *t = codes + seq_off[it];
+    const int Lq = __builtin_amdgcn_readfirstlane(seq_len[pair_q[p]]), Lt = __builtin_amdgcn_readfirstlane(seq_len[pair_t[p]]);
     const uint8_t *tr = trace + trace_off[p];
-    const int64_t strip = nw_strip_steps(Lq) * 64;
+    const int64_t strip_bytes = nw_strip_steps(Lq) * 64;
+    uint32_t *win = s_win[wid];
+    int win_strip = -1, win_chunk = -1;
     auto code_at = [&](int i, int j) -> int {   // DP cell (i, j), both >= 1
-        const int jj = j - 1, ln = jj & 63;
-        return tr[(int64_t)(jj >> 6) * strip + (int64_t)(i - 1 + ln) * 64 + ln];
+        const int jj = j - 1, ln = jj & 63, strip = jj >> 6, s = i - 1 + ln, chunk = s >> 6;
+        if (strip != win_strip || chunk != win_chunk) {
+            const int64_t off = (int64_t)strip * strip_bytes + (int64_t)chunk * 4096;
+            const int n16 = (int)min((int64_t)256, (strip_bytes - (int64_t)chunk * 4096) / 16);
+            const uint4 *src = reinterpret_cast<const uint4 *>(tr + off);
+            __builtin_amdgcn_wave_barrier();
+            for (int e = lane; e < n16; e += 64) reinterpret_cast<uint4 *>(win)[e] = src[e];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            win_strip = strip;
+            win_chunk = chunk;
+        }
+        const int so = s & 63;
+        return (int)((win[(so >> 2) * 64 + ln] >> ((so & 3) * 8)) & 0xffu);
     };
     int64_t w = ops_off[p + 1];
     int i = Lq, j = Lt, n = 0, matches = 0, state = 0;   // state 0: H, 1: vertical gap ('D'), 2: horizontal gap ('I')
     while (i > 0 || j > 0) {
-        char op, qa, ta;
+        i = __builtin_amdgcn_readfirstlane(i);
+        j = __builtin_amdgcn_readfirstlane(j);
+        state = __builtin_amdgcn_readfirstlane(state);
+        char op;
         if (state == 0) {
             if (i == 0) { state = 2; continue; }
             if (j == 0) { state = 1; continue; }
-            const int src = code_at(i, j) & 3;
+            const int c = __builtin_amdgcn_readfirstlane(code_at(i, j));
+            const int src = c & 3;
             if (src != 0) { state = src; continue; }
-            const bool same = q[i - 1] == t[j - 1];
+            const int same = (c >> 4) & 1;
             op = same ? 'M' : 'X';
             matches += same;
-            qa = alphabet[q[i - 1]];
-            ta = alphabet[t[j - 1]];
             --i;
             --j;
         } else if (state == 1) {
-            const int ext = (j == 0) ? (i > 1) : ((code_at(i, j) >> 3) & 1);
+            const int ext = (j == 0) ? (i > 1) : ((__builtin_amdgcn_readfirstlane(code_at(i, j)) >> 3) & 1);
             op = 'D';
-            qa = alphabet[q[i - 1]];
-            ta = '-';
             --i;
             state = ext ? 1 : 0;
         } else {
-            const int ext = (i == 0) ? (j > 1) : ((code_at(i, j) >> 2) & 1);
+            const int ext = (i == 0) ? (j > 1) : ((__builtin_amdgcn_readfirstlane(code_at(i, j)) >> 2) & 1);
             op = 'I';
-            qa = '-';
-            ta = alphabet[t[j - 1]];
             --j;
             state = ext ? 2 : 0;
         }
         --w;
-        ops[w] = op;
-        if (q_aln) q_aln[w] = qa;
-        if (t_aln) t_aln[w] = ta;
+        if (lane == 0) ops[w] = op;
         ++n;
     }
-    op_len[p] = n;
-    n_match[p] = matches;
+    if (lane == 0) {
+        op_len[p] = n;
+        n_match[p] = matches;
+    }
+}
+
+// Gapped strings from the operations (what reference insert_gaps builds, alignment.py:38-62): one wave per pair, 64 columns per
+// round; the residue index of a column is a prefix count of the operations that consume a residue (ballot + popcount).
+__global__ __launch_bounds__(256) void k_nw_gapped(const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
+                                                   const int32_t *__restrict__ pair_q, const int32_t *__restrict__ pair_t, int P,
+                                                   const int64_t *__restrict__ ops_off, const char *__restrict__ ops,
+                                                   const int32_t *__restrict__ op_len, const char *__restrict__ alphabet,
+                                                   char *__restrict__ q_aln, char *__restrict__ t_aln)
+{
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wid;
+    if (p >= P) return;
+    const uint8_t *q = codes + seq_off[pair_q[p]], *t = codes + seq_off[pair_t[p]];
+    const int n = op_len[p];
+    const int64_t base = ops_off[p + 1] - n;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int qi = 0, ti = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int c = c0 + lane;
+        const char op = c < n ? ops[base + c] : 0;
+        const bool uq = op == 'M' || op == 'X' || op == 'D', ut = op == 'M' || op == 'X' || op == 'I';
+        const unsigned long long bq = __ballot(uq), bt = __ballot(ut);
+        if (c < n) {
+            if (q_aln) q_aln[base + c] = uq ? alphabet[q[qi + __popcll(bq & below)]] : '-';
+            if (t_aln) t_aln[base + c] = ut ? alphabet[t[ti + __popcll(bt & below)]] : '-';
+        }
+        qi += __popcll(bq);
+        ti += __popcll(bt);
+    }
 }
 
 static int nw_check(const void *codes, const void *seq_off, const void *seq_len, const void *pq, const void *pt, int32_t P,
@@ -259,10 +338,9 @@ using namespace mdf;
 
 extern "C" {
 
-int32_t mdf_nw_count_long(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P)
+static int32_t count_long(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P, int64_t min_cells)
 {
     if (!seq_len || !pair_q || !pair_t || P < 0) return fail(MDF_EINVAL, "nw_count_long: bad arguments");
-    static const int64_t min_cells = getenv("MDFRI_NW_COOP_MIN_CELLS") ? atoll(getenv("MDFRI_NW_COOP_MIN_CELLS")) : NW_COOP_MIN_CELLS;   // developer knob
     int32_t n = 0;
     while (n < P) {
         const int64_t Lq = seq_len[pair_q[n]], Lt = seq_len[pair_t[n]];
@@ -270,6 +348,18 @@ int32_t mdf_nw_count_long(const int32_t *seq_len, const int32_t *pair_q, const i
         ++n;
     }
     return n;
+}
+
+int32_t mdf_nw_count_long(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P)
+{
+    static const int64_t min_cells = getenv("MDFRI_NW_COOP_MIN_CELLS") ? atoll(getenv("MDFRI_NW_COOP_MIN_CELLS")) : NW_COOP_MIN_CELLS;   // developer knob
+    return count_long(seq_len, pair_q, pair_t, P, min_cells);
+}
+
+int32_t mdf_nw_count_long_align(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P)
+{
+    static const int64_t min_cells = getenv("MDFRI_NW_COOP_MIN_CELLS_ALIGN") ? atoll(getenv("MDFRI_NW_COOP_MIN_CELLS_ALIGN")) : NW_COOP_MIN_CELLS_ALIGN;
+    return count_long(seq_len, pair_q, pair_t, P, min_cells);
 }
 
 int mdf_nw_plan(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P, int64_t *bnd_off, int64_t *trace_off,
@@ -300,9 +390,9 @@ int mdf_nw_score_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t
     if (int rc = nw_check(codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend)) return rc;
     MDF_REQUIRE(bnd_off && bnd && scores, "nw_score_dev: NULL argument");
     MDF_REQUIRE(n_long >= 0 && n_long <= P, "nw_score_dev: n_long=%d not in 0..P", n_long);
-    hipLaunchKernelGGL(k_nw<false>, dim3((unsigned)(n_long + (P - n_long + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), codes, seq_off,
-                       seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, bnd_off, bnd, (const int64_t *)nullptr, (uint8_t *)nullptr,
-                       scores, n_long, 0);
+    hipLaunchKernelGGL(k_nw<false>, dim3((unsigned)(n_long + (P - n_long + NW_WG_WAVES - 1) / NW_WG_WAVES)), dim3(NW_THREADS),
+                       n_long ? 2 * NW_LDS_ROWS * sizeof(int) : 0, static_cast<hipStream_t>(stream), codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A,
+                       gap_open, gap_extend, bnd_off, bnd, (const int64_t *)nullptr, (uint8_t *)nullptr, scores, n_long, 0);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -317,10 +407,14 @@ int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t
     MDF_REQUIRE(alphabet && bnd_off && bnd && trace_off && trace && ops_off && ops && op_len && n_match && scores, "nw_align_dev: NULL argument");
     MDF_REQUIRE(n_long >= 0 && n_long <= P, "nw_align_dev: n_long=%d not in 0..P", n_long);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_nw<true>, dim3((unsigned)(n_long + (P - n_long + 3) / 4)), dim3(256), 0, st, codes, seq_off, seq_len, pair_q, pair_t, P,
-                       matrix, A, gap_open, gap_extend, bnd_off, bnd, trace_off, trace, scores, n_long, tie_rule);
-    hipLaunchKernelGGL(k_nw_traceback, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, st, codes, seq_off, seq_len, pair_q, pair_t, P, trace_off,
-                       (const uint8_t *)trace, ops_off, alphabet, ops, q_aln, t_aln, op_len, n_match);
+    hipLaunchKernelGGL(k_nw<true>, dim3((unsigned)(n_long + (P - n_long + NW_WG_WAVES - 1) / NW_WG_WAVES)), dim3(NW_THREADS),
+                       n_long ? 2 * NW_LDS_ROWS * sizeof(int) : 0, st, codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, bnd_off,
+                       bnd, trace_off, trace, scores, n_long, tie_rule);
+    hipLaunchKernelGGL(k_nw_traceback, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, seq_len, pair_q, pair_t, P, trace_off, (const uint8_t *)trace,
+                       ops_off, ops, op_len, n_match);
+    if (q_aln || t_aln)
+        hipLaunchKernelGGL(k_nw_gapped, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, codes, seq_off, pair_q, pair_t, P, ops_off, (const char *)ops,
+                           (const int32_t *)op_len, alphabet, q_aln, t_aln);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -375,7 +469,8 @@ static int nw_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *
     MDF_HIP(hipMemcpy(b + o_mat, matrix, (size_t)A * A * 4, hipMemcpyHostToDevice));
     MDF_HIP(hipMemcpy(b + o_bo, bo.data(), ((size_t)P + 1) * 8, hipMemcpyHostToDevice));
     auto D = [&](size_t off) { return b + off; };
-    const int32_t n_long = mdf_nw_count_long(seq_len, pair_q, pair_t, P);   // leading run of large pairs (callers order by decreasing size)
+    // leading run of large pairs (callers order by decreasing size)
+    const int32_t n_long = full ? mdf_nw_count_long_align(seq_len, pair_q, pair_t, P) : mdf_nw_count_long(seq_len, pair_q, pair_t, P);
     int rc;
     if (!full) {
         rc = mdf_nw_score_dev((const uint8_t *)D(o_codes), (const int64_t *)D(o_soff), (const int32_t *)D(o_slen), (const int32_t *)D(o_pq),

@@ -157,6 +157,7 @@ SIGNATURES = {
                                       c_size_t, c_void_p]),
     "mdf_nw_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
     "mdf_nw_count_long": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32]),
+    "mdf_nw_count_long_align": (c_int32, [c_void_p, c_void_p, c_void_p, c_int32]),
     "mdf_nw_score_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int, c_int, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
     "mdf_nw_align_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int, c_int, c_int, c_void_p, c_void_p,

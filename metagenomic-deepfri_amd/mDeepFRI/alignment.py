@@ -175,7 +175,7 @@ class _PairBatch:
         order = self._by_cost(pq0, pt0) if P else np.zeros(0, np.int64)
         pq, pt = np.ascontiguousarray(pq0[order]), np.ascontiguousarray(pt0[order])
         parts = []
-        cost = (self.seq_len[pt].astype(np.int64) + 63) // 64 * (self.seq_len[pq].astype(np.int64) + 64) * 64
+        cost = (self.seq_len[pt].astype(np.int64) + 63) // 64 * ((self.seq_len[pq].astype(np.int64) + 66) // 4 * 4) * 64   # = mdf_nw_plan's trace bytes
         p0 = 0
         while p0 < P:
             p1, acc = p0, 0
