@@ -427,7 +427,7 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
 int mdf_nw_plan(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P, int64_t *bnd_off, int64_t *trace_off,
                 int64_t *ops_off);
 
-/* Host helper: length of the leading run of LARGE pairs (>= 512 x 512 cells) of a pair list ordered by decreasing size -- the
+/* Host helper: length of the leading run of LARGE pairs (>= 768 x 768 cells) of a pair list ordered by decreasing size -- the
  * n_long argument of mdf_nw_score_dev.  Large pairs get a whole workgroup each (their 64-column strips run as a pipeline sixteen
  * waves deep, the column between two strips handed over through LDS); with a single wave a 2 000 x 2 000 pair would outlive the
  * rest of the launch by milliseconds.  0 is always valid. */

@@ -28,9 +28,10 @@ constexpr int NW_NEG = INT32_MIN / 2;
 constexpr int NW_LDA = 32;   // row pitch of the substitution matrix in LDS; alphabet size <= 32
 constexpr int NW_WG_WAVES = 16;                 // waves per workgroup: the depth of the strip pipeline of a long pair
 constexpr int NW_THREADS = NW_WG_WAVES * 64;
-constexpr int NW_MAX_COOP_STRIPS = 2048;   // a cooperatively swept pair has at most this many 64-column strips (Lt <= 131 072)
-constexpr int NW_LDS_ROWS = 4096;          // ... and keeps the column between two strips in LDS when its query is at most this long
-constexpr int64_t NW_COOP_MIN_CELLS = 512 * 512;         // score mode: pairs at least this large get a workgroup of their own
+constexpr int NW_MAX_COOP_STRIPS = 512;    // a cooperatively swept pair has at most this many 64-column strips (Lt <= 32 768)
+constexpr int NW_LDS_INTS_ALIGN = 8192;    // ... and keeps the column between two strips in LDS when it fits this many words (full
+constexpr int NW_LDS_INTS_SCORE = 2048;    // alignments: 2 workgroups of 16 waves per CU anyway; score mode: LDS must not cost occupancy)
+constexpr int64_t NW_COOP_MIN_CELLS = 768 * 768;         // score mode: pairs at least this large get a workgroup of their own (swept: flat from 600 x 600 to 1 000 x 1 000)
 constexpr int64_t NW_COOP_MIN_CELLS_ALIGN = 256 * 256;   // full alignments (far fewer pairs, launch = its longest chains): earlier
 
 // lane l <- value of lane l-1 (previous lane of the wave); lane 0 <- fill.  DPP wave_shr:1 (gfx9 family: one VALU op).
@@ -42,21 +43,64 @@ __device__ __forceinline__ int wave_shr1(int v, int fill)
 __device__ __forceinline__ int ld_coherent(const int32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coherent(int32_t *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+constexpr int NW_FMT_BYTES = -32, NW_FMT_NIBBLES = -16;   // which kernel wrote a pair's directions (travels in n_match[p] until k_nw_finish)
+
+// Substitution matrix -> LDS (row pitch NW_LDA, zero outside the alphabet) plus its extreme values (the 16-bit kernel's range test).
+__device__ __forceinline__ void stage_matrix(const int32_t *__restrict__ matrix, int A, int *s_S, int *s_mm)
+{
+    if (threadIdx.x == 0) {
+        s_mm[0] = INT32_MAX;
+        s_mm[1] = INT32_MIN;
+    }
+    __syncthreads();
+    int lo = INT32_MAX, hi = INT32_MIN;
+    for (int e = threadIdx.x; e < NW_LDA * NW_LDA; e += blockDim.x) {
+        const int r = e / NW_LDA, c = e % NW_LDA;
+        const bool in = r < A && c < A;
+        const int v = in ? matrix[r * A + c] : 0;
+        s_S[e] = v;
+        if (in) lo = min(lo, v), hi = max(hi, v);
+    }
+    atomicMin(&s_mm[0], lo);
+    atomicMax(&s_mm[1], hi);
+}
+
+// May this pair run in packed 16-bit arithmetic with results IDENTICAL to the 32-bit kernel?  Decided from the lengths, the gap
+// penalties and the extreme matrix entries alone (Opal sorts pairs into 8/16/32-bit "buckets" by watching for overflow,
+// reference alignment.py:184 overflow="buckets"; here the bucket is known before the sweep, so nothing is ever re-run):
+//   every real H is at most min(Lq, Lt) * smax                                   -> must stay below 2^15
+//   every real H / E / F is at least -(2 go + (Lq + Lt) ge)                      -> must stay above the "minus infinity" band,
+//   which starts at -16384 and reaches up by at most 130 matrix entries (the 128 virtual rows above the matrix)
+//   row 0 is produced by the recurrence itself, which equals the analytic -(go + (j-1) ge) only for ge <= go.
+__host__ __device__ __forceinline__ bool nw16_eligible(int Lq, int Lt, int go, int ge, int smin, int smax)
+{
+    if (Lq <= 0 || Lt <= 0 || ge > go || go > 100) return false;
+    const int amax = max(max(smax, -smin), 1);
+    if (amax > 64) return false;
+    if ((int64_t)min(Lq, Lt) * max(smax, 0) > 30000) return false;
+    return 2 * (int64_t)go + ((int64_t)Lq + Lt) * ge + 130 * (int64_t)amax + 64 <= 16000;
+}
+
 // steps of one strip: rows Lq skewed over 64 lanes, padded to whole groups of four (four direction bytes make one stored word)
 __host__ __device__ __forceinline__ int64_t nw_strip_steps(int Lq) { return ((int64_t)Lq + 63 + 3) / 4 * 4; }
+// ... and of one PAIR of strips in k_nw16: rows 0..Lq (row 0 is swept too) skewed over 128 columns, plus the step that hands
+// the last row to the boundary column
+__host__ __device__ __forceinline__ int64_t nw_strip_steps16(int Lq) { return ((int64_t)Lq + 129 + 3) / 4 * 4; }
 
 // Direction bytes of a full alignment (k_nw<true> writes, k_nw_traceback reads): strip k occupies nw_strip_steps(Lq) * 64 bytes;
 // inside it, the four steps 4g .. 4g+3 of lane l share the 32-bit word (g * 64 + l), step s in byte (s & 3) -- one coalesced
 // 256-byte store per wave and four steps.  Byte: bits 0-1 source of H (0 diagonal, 1 vertical gap 'D', 2 horizontal gap 'I'),
-// bit 2 E extended, bit 3 F extended, bit 4 the two residues are equal ('M' instead of 'X').
+// bit 2 E extended, bit 3 F extended.  (k_nw16 stores the same four bits as a nibble, two cells per byte.)
 template <bool TRACE>
 __global__ __launch_bounds__(NW_THREADS) void k_nw(const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
                                                    const int32_t *__restrict__ seq_len, const int32_t *__restrict__ pair_q,
                                                    const int32_t *__restrict__ pair_t, int P, const int32_t *__restrict__ matrix, int A,
                                                    int go, int ge, const int64_t *__restrict__ bnd_off, int32_t *bnd,
                                                    const int64_t *__restrict__ trace_off, uint8_t *__restrict__ trace,
-                                                   int32_t *__restrict__ scores, int n_long, int tie_rule)
+                                                   int32_t *__restrict__ scores, int n_long, int tie_rule, int allow16,
+                                                   int32_t *__restrict__ fmt_out, int lds_ints)
 {
+    // (pairs that qualify for the packed 16-bit kernel k_nw16 below are left to it when allow16 is set)
     // Pairs [0, n_long) are LONG: one whole workgroup per pair, wave w sweeps strips w, w+16, ... and may enter a 64-row chunk of
     // strip k as soon as strip k-1 has published the boundary values of those rows (s_prog, LDS) -- the strips of one matrix run
     // as a pipeline sixteen waves deep, the column between two strips handed over through LDS (s_bnd) when the query fits.
@@ -64,11 +108,10 @@ __global__ __launch_bounds__(NW_THREADS) void k_nw(const uint8_t *__restrict__ c
     // launch by milliseconds.  Pairs >= n_long: one wave per pair, sixteen pairs per workgroup, boundary column through L2.
     __shared__ int s_S[NW_LDA * NW_LDA];
     __shared__ int s_prog[NW_MAX_COOP_STRIPS];
-    extern __shared__ int s_bnd[];   // [2][NW_LDS_ROWS] when the launch has long pairs (dynamic)
-    for (int e = threadIdx.x; e < NW_LDA * NW_LDA; e += blockDim.x) {
-        const int r = e / NW_LDA, c = e % NW_LDA;
-        s_S[e] = (r < A && c < A) ? matrix[r * A + c] : 0;
-    }
+    __shared__ int s_mm[2];
+    extern __shared__ int s_bnd[];   // lds_ints words (H rows, then E rows) when the launch has long pairs (dynamic)
+    stage_matrix(matrix, A, s_S, s_mm);
+    const int wg_waves = blockDim.x >> 6;   // depth of the strip pipeline of a long pair = pairs per workgroup otherwise
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool gap_first = tie_rule & 1, horiz_first = tie_rule & 2, ext_first = tie_rule & 4;   // see oracle/nw_oracle.c
     const bool own_block = (int)blockIdx.x < n_long;   // this workgroup holds ONE pair
@@ -76,25 +119,27 @@ __global__ __launch_bounds__(NW_THREADS) void k_nw(const uint8_t *__restrict__ c
         for (int e = threadIdx.x; e < NW_MAX_COOP_STRIPS; e += blockDim.x) s_prog[e] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int p = own_block ? (int)blockIdx.x : n_long + ((int)blockIdx.x - n_long) * NW_WG_WAVES + wid;
+    const int p = own_block ? (int)blockIdx.x : n_long + ((int)blockIdx.x - n_long) * wg_waves + wid;
     if (p >= P) return;
     const int iq = pair_q[p], it = pair_t[p];
     const int Lq = seq_len[iq], Lt = seq_len[it];
+    if (allow16 && nw16_eligible(Lq, Lt, go, ge, s_mm[0], s_mm[1])) return;   // k_nw16 takes this pair
     // a caller's n_long is not trusted with the size of s_prog: a pair with more strips than it holds is swept by wave 0 alone
     const bool coop = own_block && ((Lt + 63) >> 6) <= NW_MAX_COOP_STRIPS;
     if (own_block && !coop && wid != 0) return;
-    const bool lds_bnd = coop && Lq <= NW_LDS_ROWS;
+    const bool lds_bnd = coop && 2 * Lq <= lds_ints;
+    if (TRACE && lane == 0 && (!coop || wid == 0)) fmt_out[p] = NW_FMT_BYTES;
     const uint8_t *q = codes + seq_off[iq], *t = codes + seq_off[it];
     if (Lq == 0 || Lt == 0) {   // degenerate: one all-gap run (or nothing)
         if (lane == 0 && (!coop || wid == 0)) scores[p] = (Lq + Lt == 0) ? 0 : -(go + (Lq + Lt - 1) * ge);
         return;
     }
     int32_t *Hb = bnd + bnd_off[p], *Eb = Hb + Lq;   // H / E of the column left of the current strip, rows 1..Lq (when not in LDS)
-    volatile int *Hl = s_bnd, *El = s_bnd + NW_LDS_ROWS;
+    volatile int *Hl = s_bnd, *El = s_bnd + (lds_ints >> 1);
     uint8_t *tr = TRACE ? trace + trace_off[p] : nullptr;
     const int n_strips = (Lt + 63) >> 6;
     const int n_steps = (int)nw_strip_steps(Lq);        // >= Lq + 63; the padding steps are inactive everywhere
-    for (int k = coop ? wid : 0; k < n_strips; k += coop ? NW_WG_WAVES : 1) {
+    for (int k = coop ? wid : 0; k < n_strips; k += coop ? wg_waves : 1) {
         const int j = (k << 6) + lane;                 // my column: target residue j, DP column j + 1
         const int tc = j < Lt ? min((int)t[j], NW_LDA - 1) : 0;   // (codes are validated by the host entry points; clamped so that a bad one cannot index outside the table)
         int up = -(go + j * ge);                       // H[0][j+1]
@@ -161,7 +206,7 @@ __global__ __launch_bounds__(NW_THREADS) void k_nw(const uint8_t *__restrict__ c
                     const int g1 = horiz_first ? e : f, g2 = horiz_first ? f : e;
                     if (g1 > h || (gap_first && g1 == h)) { h = g1; src = horiz_first ? 2 : 1; }
                     if (g2 > h || (gap_first && g2 == h && src == 0)) { h = g2; src = horiz_first ? 1 : 2; }
-                    code |= src | (qc == tc ? 16 : 0);
+                    code |= src;
                 } else {
                     e = max(e_open, e_ext);
                     f = max(f_open, f_ext);
@@ -217,15 +262,186 @@ __global__ __launch_bounds__(NW_THREADS) void k_nw(const uint8_t *__restrict__ c
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same sweep in packed 16-bit arithmetic: two 64-column strips at once.  A lane holds column l of strip 2m in the low half
+// and column l of strip 2m+1 in the high half of every 32-bit register; the wave is then a systolic array 128 columns wide
+// (element e = half * 64 + lane works on row s - e at step s), and one v_pk_*_i16 instruction advances 128 cells.  The shift
+// between neighbours is still one DPP move per register: lane 0's low half takes the boundary column, its high half takes
+// what lane 63's low half produced one step earlier.  Two more things make a step cheap:
+//   * no "inside the matrix" selects: the 128 virtual rows above the matrix hold minus infinity (-16384, never beaten by a real
+//     value, see nw16_eligible), row 0 -- the gap-only row -- is produced by the recurrence itself, and whatever is computed
+//     below row Lq or right of column Lt is never read by a real cell;
+//   * directions (TRACE) come from the sign bits of saturating packed subtractions -- no compares, no per-half unpacking --
+//     and are kept as one nibble per cell (bits as in k_nw), four steps to a stored word.
+// Values are exactly those of the 32-bit kernel for every pair nw16_eligible admits; k_nw sweeps the others.
+// ------------------------------------------------------------------------------------------------------------------
+typedef short nw_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_bits(nw_s16x2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ nw_s16x2 pk_vec(uint32_t v) { return __builtin_bit_cast(nw_s16x2, v); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return pk_bits(pk_vec(a) + pk_vec(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return pk_bits(pk_vec(a) - pk_vec(b)); }
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return pk_bits(__builtin_elementwise_max(pk_vec(a), pk_vec(b))); }
+// sign bit of each half set  <=>  a > b   (saturating: the difference of two 16-bit values does not fit 16 bits)
+__device__ __forceinline__ uint32_t pk_gt(uint32_t a, uint32_t b) { return pk_bits(__builtin_elementwise_sub_sat(pk_vec(b), pk_vec(a))); }
+// sign bit set  <=>  a >= b  (= not b > a)
+__device__ __forceinline__ uint32_t pk_ge(uint32_t a, uint32_t b) { return ~pk_gt(b, a); }
+
+__device__ __forceinline__ uint32_t nw16_lookup(const short *tab, uint32_t qres, uint32_t tcaddr)
+{
+    const uint32_t a = qres + tcaddr;   // byte offsets {q * 64 + tc * 2} of both halves; each stays below 2^16, so no carry crosses
+    const char *base = reinterpret_cast<const char *>(tab);
+    nw_s16x2 v;
+    v.x = *reinterpret_cast<const short *>(base + (a & 0xffffu));
+    v.y = *reinterpret_cast<const short *>(base + (a >> 16));
+    return pk_bits(v);
+}
+
+template <bool TRACE, int RULE>
+__global__ __launch_bounds__(NW_THREADS) void k_nw16(const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
+                                                     const int32_t *__restrict__ seq_len, const int32_t *__restrict__ pair_q,
+                                                     const int32_t *__restrict__ pair_t, int P, const int32_t *__restrict__ matrix, int A,
+                                                     int go, int ge, const int64_t *__restrict__ bnd_off, int32_t *bnd,
+                                                     const int64_t *__restrict__ trace_off, uint8_t *__restrict__ trace,
+                                                     int32_t *__restrict__ scores, int n_long, int32_t *__restrict__ fmt_out, int lds_ints)
+{
+    constexpr bool GAP = RULE & 1, HORIZ = RULE & 2, EXT = RULE & 4;   // tie rule bits, see oracle/nw_oracle.c
+    constexpr uint32_t NEG2 = 0xC000C000u;                             // -16384 in both halves
+    __shared__ int s_S[NW_LDA * NW_LDA];
+    __shared__ short s_S16[NW_LDA * NW_LDA];
+    __shared__ int s_prog[NW_MAX_COOP_STRIPS];
+    __shared__ int s_mm[2];
+    extern __shared__ int s_bnd[];   // packed {H, E} of the column between two strip pairs, rows 0..Lq, for long pairs (dynamic)
+    stage_matrix(matrix, A, s_S, s_mm);
+    const int wg_waves = blockDim.x >> 6;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool own_block = (int)blockIdx.x < n_long;
+    if (own_block)
+        for (int e = threadIdx.x; e < NW_MAX_COOP_STRIPS; e += blockDim.x) s_prog[e] = 0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < NW_LDA * NW_LDA; e += blockDim.x) s_S16[e] = (short)max(-32768, min(32767, s_S[e]));
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int p = own_block ? (int)blockIdx.x : n_long + ((int)blockIdx.x - n_long) * wg_waves + wid;
+    if (p >= P) return;
+    const int iq = pair_q[p], it = pair_t[p];
+    const int Lq = seq_len[iq], Lt = seq_len[it];
+    if (!nw16_eligible(Lq, Lt, go, ge, s_mm[0], s_mm[1])) return;   // k_nw takes this pair
+    const int n_sp = (Lt + 127) >> 7;                  // strip pairs
+    const bool coop = own_block && n_sp <= NW_MAX_COOP_STRIPS;
+    if (own_block && !coop && wid != 0) return;
+    const bool lds_bnd = coop && Lq + 1 <= lds_ints;
+    if (TRACE && lane == 0 && (!coop || wid == 0)) fmt_out[p] = NW_FMT_NIBBLES;
+    const uint8_t *q = codes + seq_off[iq], *t = codes + seq_off[it];
+    int32_t *Bg = bnd + bnd_off[p];                    // (Lq + 1) packed words fit the 2 * Lq the plan reserves (Lq >= 1)
+    volatile int *Bl = s_bnd;
+    uint8_t *tr = TRACE ? trace + trace_off[p] : nullptr;
+    const int n_steps = (int)nw_strip_steps16(Lq);
+    const uint32_t GO2 = (uint32_t)(go & 0xffff) * 0x10001u, GE2 = (uint32_t)(ge & 0xffff) * 0x10001u;
+    const int e_last = (Lt - 1) & 127, m_last = (Lt - 1) >> 7, s_star = Lq + e_last;   // H[Lq][Lt] leaves element e_last at step s_star
+    for (int m = coop ? wid : 0; m < n_sp; m += coop ? wg_waves : 1) {
+        const int jlo = (m << 7) + lane, jhi = jlo + 64;
+        const uint32_t tcaddr = (uint32_t)((jlo < Lt ? min((int)t[jlo], NW_LDA - 1) : 0) * 2) | ((uint32_t)((jhi < Lt ? min((int)t[jhi], NW_LDA - 1) : 0) * 2) << 16);
+        uint32_t up = NEG2, fup = NEG2, diag = NEG2, h_out = NEG2, e_out = NEG2;
+        uint32_t qres = 0, qres_next = 0, sc_cur = 0, dir_acc = 0;
+        const bool pass_right = m + 1 < n_sp, last = m == m_last;
+        uint32_t *trk = TRACE ? reinterpret_cast<uint32_t *>(tr + (int64_t)m * n_steps * 64) : nullptr;
+        for (int s0 = 0; s0 < n_steps; s0 += 64) {
+            // what element 0 is fed at step s0 + lane (its row r = s0 + lane): query residue (pre-scaled to a table row offset) and
+            // the packed {H, E} of the column left of this strip pair
+            const int r = s0 + lane;
+            const uint32_t qrow = (r >= 1 && r <= Lq) ? (uint32_t)min((int)q[r - 1], NW_LDA - 1) * 64u : 0u;
+            uint32_t b;
+            if (m == 0) {
+                const int hb = r == 0 ? 0 : (r <= Lq ? -(go + (r - 1) * ge) : -16384);   // H[r][0];  E[r][0] = minus infinity
+                b = ((uint32_t)hb & 0xffffu) | 0xC0000000u;
+            } else {
+                if (coop) {
+                    const int need = min(Lq + 1, s0 + 64);
+                    while (__hip_atomic_load(&s_prog[m - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                }
+                b = r <= Lq ? (lds_bnd ? (uint32_t)Bl[r] : (uint32_t)ld_coherent(Bg + r)) : NEG2;
+            }
+            if (s0 == 0) {   // step 0: every element still sits above the matrix; row 0 has no residue
+                qres_next = 0;
+                sc_cur = nw16_lookup(s_S16, qres_next, tcaddr);
+            }
+            uint32_t keep = 0;                           // lane u keeps element 127's {H, E} of step s0 + u - 1 (row s0 + u - 128)
+            const int u_end = min(64, n_steps - s0);     // a multiple of four
+            for (int u = 0; u < u_end; ++u) {
+                const int s = s0 + u;
+                const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)b, u);
+                const uint32_t h63 = (uint32_t)__builtin_amdgcn_readlane((int)h_out, 63), e63 = (uint32_t)__builtin_amdgcn_readlane((int)e_out, 63);
+                const uint32_t left = (uint32_t)wave_shr1((int)h_out, (int)((h63 << 16) | (bs & 0xffffu)));
+                const uint32_t eleft = (uint32_t)wave_shr1((int)e_out, (int)((e63 << 16) | (bs >> 16)));
+                if (pass_right) keep = lane == u ? ((h63 >> 16) | (e63 & 0xffff0000u)) : keep;
+                qres = qres_next;
+                const uint32_t sc = sc_cur;
+                // shift the residues for the next step and start its score lookup one step ahead
+                const uint32_t q63 = (uint32_t)__builtin_amdgcn_readlane((int)qres, 63);
+                const uint32_t q_in = (u + 1 < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)qrow, (u + 1) & 63)
+                                                   : ((s + 1 <= Lq) ? (uint32_t)min((int)q[s], NW_LDA - 1) * 64u : 0u);
+                qres_next = (uint32_t)wave_shr1((int)qres, (int)((q63 << 16) | q_in));
+                sc_cur = nw16_lookup(s_S16, qres_next, tcaddr);
+                const uint32_t e_open = pk_sub(left, GO2), e_ext = pk_sub(eleft, GE2);
+                const uint32_t f_open = pk_sub(up, GO2), f_ext = pk_sub(fup, GE2);
+                const uint32_t e = pk_max(e_open, e_ext), f = pk_max(f_open, f_ext);
+                const uint32_t d = pk_add(diag, sc);
+                const uint32_t g1 = HORIZ ? e : f, g2 = HORIZ ? f : e;
+                const uint32_t m1 = pk_max(d, g1), h = pk_max(m1, g2);
+                if (TRACE) {
+                    // sign bits (15 and 31) carry the four decisions of k_nw's tie logic, for both halves at once
+                    const uint32_t xe = EXT ? pk_ge(e_ext, e_open) : pk_gt(e_ext, e_open);
+                    const uint32_t xf = EXT ? pk_ge(f_ext, f_open) : pk_gt(f_ext, f_open);
+                    const uint32_t c1 = GAP ? pk_ge(g1, d) : pk_gt(g1, d);                     // H takes g1 over the diagonal
+                    uint32_t c2 = pk_gt(g2, m1);                                              // ... and g2 over both
+                    if (GAP) c2 |= pk_ge(g2, m1) & ~c1;
+                    const uint32_t first = c1 & ~c2;                                          // H came from g1
+                    const uint32_t from_f = HORIZ ? c2 : first, from_e = HORIZ ? first : c2;  // code 1 = 'D' (F), 2 = 'I' (E)
+                    const uint32_t w = ((from_f >> 3) & 0x10001000u) | ((from_e >> 2) & 0x20002000u) | ((xe >> 1) & 0x40004000u) | (xf & 0x80008000u);
+                    dir_acc = ((dir_acc >> 4) & 0x0FFF0FFFu) | w;                              // nibble k of a half = step 4g + k
+                    if ((u & 3) == 3) trk[(int64_t)(s >> 2) * 64 + lane] = dir_acc;
+                }
+                diag = left;
+                up = h;
+                fup = f;
+                h_out = h;
+                e_out = e;
+                if (last && s == s_star) {
+                    const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)h_out, e_last & 63);
+                    if (lane == 0) scores[p] = (e_last & 64) ? ((int)v >> 16) : (int)(short)(v & 0xffffu);
+                }
+            }
+            if (pass_right) {
+                const int row = s0 + lane - 128;
+                const bool mine = lane < u_end && row >= 0 && row <= Lq;
+                const int done = max(0, min(Lq + 1, s0 + u_end - 127));   // rows 0 .. done-1 of the right boundary are out
+                if (lds_bnd) {
+                    if (mine) Bl[row] = (int)keep;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) __hip_atomic_store(&s_prog[m], done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    if (mine) st_coherent(Bg + row, (int)keep);
+                    if (coop) {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(&s_prog[m], done, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        if (!lds_bnd) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 // One WAVE per pair: walk the direction bytes back from (Lq, Lt).  Every lane executes the same walk (the position is
 // wave-uniform); the bytes come from a 64-step window of the current strip staged in LDS by wave-wide loads (4 KiB, refilled
 // about every 32-64 moves), so a move costs an LDS read instead of an L2 round trip.  Operations are written back to front
-// into [ops_off[p+1] - n, ops_off[p+1]); op_len[p] = n, n_match[p] = number of 'M' (the "residues are equal" bit travels with
-// the direction byte, so no residue is read here).
+// into [ops_off[p+1] - n, ops_off[p+1]); op_len[p] = n.  No residue is read here: a diagonal move is written as 'M' and
+// k_nw_finish decides between 'M' and 'X'.
 __global__ __launch_bounds__(256) void k_nw_traceback(const int32_t *__restrict__ seq_len, const int32_t *__restrict__ pair_q,
                                                       const int32_t *__restrict__ pair_t, int P, const int64_t *__restrict__ trace_off,
                                                       const uint8_t *__restrict__ trace, const int64_t *__restrict__ ops_off,
-                                                      char *__restrict__ ops, int32_t *__restrict__ op_len, int32_t *__restrict__ n_match)
+                                                      char *__restrict__ ops, int32_t *__restrict__ op_len, const int32_t *__restrict__ n_match)
 {
     __shared__ uint32_t s_win[4][1024];
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -233,11 +449,14 @@ __global__ __launch_bounds__(256) void k_nw_traceback(const int32_t *__restrict_
     if (p >= P) return;
     const int Lq = __builtin_amdgcn_readfirstlane(seq_len[pair_q[p]]), Lt = __builtin_amdgcn_readfirstlane(seq_len[pair_t[p]]);
     const uint8_t *tr = trace + trace_off[p];
-    const int64_t strip_bytes = nw_strip_steps(Lq) * 64;
+    const bool nib = __builtin_amdgcn_readfirstlane(n_match[p]) == NW_FMT_NIBBLES;   // which kernel swept this pair (left here by it)
+    const int64_t strip_bytes = (nib ? nw_strip_steps16(Lq) : nw_strip_steps(Lq)) * 64;
     uint32_t *win = s_win[wid];
     int win_strip = -1, win_chunk = -1;
-    auto code_at = [&](int i, int j) -> int {   // DP cell (i, j), both >= 1
-        const int jj = j - 1, ln = jj & 63, strip = jj >> 6, s = i - 1 + ln, chunk = s >> 6;
+    auto code_at = [&](int i, int j) -> int {   // DP cell (i, j), both >= 1 -> its four direction bits
+        const int jj = j - 1, ln = jj & 63;
+        const int strip = nib ? jj >> 7 : jj >> 6;               // k_nw16: a strip PAIR, element (jj & 127) works on row i at step i + element
+        const int s = nib ? i + (jj & 127) : i - 1 + ln, chunk = s >> 6;
         if (strip != win_strip || chunk != win_chunk) {
             const int64_t off = (int64_t)strip * strip_bytes + (int64_t)chunk * 4096;
             const int n16 = (int)min((int64_t)256, (strip_bytes - (int64_t)chunk * 4096) / 16);
@@ -251,10 +470,11 @@ __global__ __launch_bounds__(256) void k_nw_traceback(const int32_t *__restrict_
             win_chunk = chunk;
         }
         const int so = s & 63;
-        return (int)((win[(so >> 2) * 64 + ln] >> ((so & 3) * 8)) & 0xffu);
+        const uint32_t word = win[(so >> 2) * 64 + ln];
+        return nib ? (int)((word >> ((jj & 64 ? 16 : 0) + (so & 3) * 4)) & 0xfu) : (int)((word >> ((so & 3) * 8)) & 0xfu);
     };
     int64_t w = ops_off[p + 1];
-    int i = Lq, j = Lt, n = 0, matches = 0, state = 0;   // state 0: H, 1: vertical gap ('D'), 2: horizontal gap ('I')
+    int i = Lq, j = Lt, n = 0, state = 0;   // state 0: H, 1: vertical gap ('D'), 2: horizontal gap ('I')
     while (i > 0 || j > 0) {
         i = __builtin_amdgcn_readfirstlane(i);
         j = __builtin_amdgcn_readfirstlane(j);
@@ -266,9 +486,7 @@ __global__ __launch_bounds__(256) void k_nw_traceback(const int32_t *__restrict_
             const int c = __builtin_amdgcn_readfirstlane(code_at(i, j));
             const int src = c & 3;
             if (src != 0) { state = src; continue; }
-            const int same = (c >> 4) & 1;
-            op = same ? 'M' : 'X';
-            matches += same;
+            op = 'M';     // k_nw_finish turns it into 'X' where the residues differ
             --i;
             --j;
         } else if (state == 1) {
@@ -286,19 +504,18 @@ __global__ __launch_bounds__(256) void k_nw_traceback(const int32_t *__restrict_
         if (lane == 0) ops[w] = op;
         ++n;
     }
-    if (lane == 0) {
-        op_len[p] = n;
-        n_match[p] = matches;
-    }
+    if (lane == 0) op_len[p] = n;
 }
 
-// Gapped strings from the operations (what reference insert_gaps builds, alignment.py:38-62): one wave per pair, 64 columns per
-// round; the residue index of a column is a prefix count of the operations that consume a residue (ballot + popcount).
-__global__ __launch_bounds__(256) void k_nw_gapped(const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
+// Last pass over the operations, one wave per pair, 64 columns per round; the residue index of a column is a prefix count of
+// the operations that consume a residue (ballot + popcount).  A diagonal move becomes 'M' or 'X' by comparing its two residues,
+// n_match[p] = number of 'M', and -- when asked for -- the gapped strings are spelled (what reference insert_gaps builds,
+// alignment.py:38-62).
+__global__ __launch_bounds__(256) void k_nw_finish(const uint8_t *__restrict__ codes, const int64_t *__restrict__ seq_off,
                                                    const int32_t *__restrict__ pair_q, const int32_t *__restrict__ pair_t, int P,
-                                                   const int64_t *__restrict__ ops_off, const char *__restrict__ ops,
+                                                   const int64_t *__restrict__ ops_off, char *__restrict__ ops,
                                                    const int32_t *__restrict__ op_len, const char *__restrict__ alphabet,
-                                                   char *__restrict__ q_aln, char *__restrict__ t_aln)
+                                                   char *__restrict__ q_aln, char *__restrict__ t_aln, int32_t *__restrict__ n_match)
 {
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + wid;
@@ -307,19 +524,31 @@ __global__ __launch_bounds__(256) void k_nw_gapped(const uint8_t *__restrict__ c
     const int n = op_len[p];
     const int64_t base = ops_off[p + 1] - n;
     const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    int qi = 0, ti = 0;
+    int qi = 0, ti = 0, matches = 0;
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int c = c0 + lane;
-        const char op = c < n ? ops[base + c] : 0;
-        const bool uq = op == 'M' || op == 'X' || op == 'D', ut = op == 'M' || op == 'X' || op == 'I';
+        char op = c < n ? ops[base + c] : 0;
+        const bool uq = op == 'M' || op == 'D', ut = op == 'M' || op == 'I';
         const unsigned long long bq = __ballot(uq), bt = __ballot(ut);
+        const int qc = uq ? q[qi + __popcll(bq & below)] : 0, tc = ut ? t[ti + __popcll(bt & below)] : 0;
+        const bool same = op == 'M' && qc == tc;
         if (c < n) {
-            if (q_aln) q_aln[base + c] = uq ? alphabet[q[qi + __popcll(bq & below)]] : '-';
-            if (t_aln) t_aln[base + c] = ut ? alphabet[t[ti + __popcll(bt & below)]] : '-';
+            if (op == 'M' && !same) ops[base + c] = 'X';
+            if (q_aln) q_aln[base + c] = uq ? alphabet[qc] : '-';
+            if (t_aln) t_aln[base + c] = ut ? alphabet[tc] : '-';
         }
+        matches += __popcll(__ballot(same));
         qi += __popcll(bq);
         ti += __popcll(bt);
     }
+    if (lane == 0) n_match[p] = matches;
+}
+
+// developer knob: MDFRI_NW_INT16=0 sweeps every pair in 32-bit arithmetic
+static int nw_allow16()
+{
+    static const int v = getenv("MDFRI_NW_INT16") ? atoi(getenv("MDFRI_NW_INT16")) != 0 : 1;
+    return v;
 }
 
 static int nw_check(const void *codes, const void *seq_off, const void *seq_len, const void *pq, const void *pt, int32_t P,
@@ -374,7 +603,7 @@ int mdf_nw_plan(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pa
         if (trace_off) trace_off[p] = tr;
         if (ops_off) ops_off[p] = o;
         b += 2 * Lq;
-        tr += ((Lt + 63) / 64) * nw_strip_steps((int)Lq) * 64;
+        tr += std::max(((Lt + 63) / 64) * nw_strip_steps((int)Lq), ((Lt + 127) / 128) * nw_strip_steps16((int)Lq)) * 64;   // either kernel's format fits
         o += Lq + Lt;
     }
     if (bnd_off) bnd_off[P] = b;
@@ -390,9 +619,19 @@ int mdf_nw_score_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t
     if (int rc = nw_check(codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend)) return rc;
     MDF_REQUIRE(bnd_off && bnd && scores, "nw_score_dev: NULL argument");
     MDF_REQUIRE(n_long >= 0 && n_long <= P, "nw_score_dev: n_long=%d not in 0..P", n_long);
-    hipLaunchKernelGGL(k_nw<false>, dim3((unsigned)(n_long + (P - n_long + NW_WG_WAVES - 1) / NW_WG_WAVES)), dim3(NW_THREADS),
-                       n_long ? 2 * NW_LDS_ROWS * sizeof(int) : 0, static_cast<hipStream_t>(stream), codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A,
-                       gap_open, gap_extend, bnd_off, bnd, (const int64_t *)nullptr, (uint8_t *)nullptr, scores, n_long, 0);
+    // score mode is throughput-bound: four-wave workgroups (a long pair's strips run four deep), every pair to the kernel whose
+    // arithmetic width it qualifies for (decided per pair on the device, nw16_eligible)
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static const int waves_env = getenv("MDFRI_NW_SCORE_WAVES") ? atoi(getenv("MDFRI_NW_SCORE_WAVES")) : 4;   // developer knob
+    const int waves = std::min(std::max(waves_env, 1), NW_WG_WAVES), a16 = nw_allow16();
+    const dim3 grid((unsigned)(n_long + (P - n_long + waves - 1) / waves));
+    const int lds_ints = n_long ? NW_LDS_INTS_SCORE : 0;
+    const size_t lds = (size_t)lds_ints * sizeof(int);
+    if (a16)
+        hipLaunchKernelGGL((k_nw16<false, 0>), grid, dim3(waves * 64), lds, st, codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend,
+                           bnd_off, bnd, (const int64_t *)nullptr, (uint8_t *)nullptr, scores, n_long, (int32_t *)nullptr, lds_ints);
+    hipLaunchKernelGGL(k_nw<false>, grid, dim3(waves * 64), lds, st, codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, bnd_off,
+                       bnd, (const int64_t *)nullptr, (uint8_t *)nullptr, scores, n_long, 0, a16, (int32_t *)nullptr, lds_ints);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -407,14 +646,28 @@ int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t
     MDF_REQUIRE(alphabet && bnd_off && bnd && trace_off && trace && ops_off && ops && op_len && n_match && scores, "nw_align_dev: NULL argument");
     MDF_REQUIRE(n_long >= 0 && n_long <= P, "nw_align_dev: n_long=%d not in 0..P", n_long);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_nw<true>, dim3((unsigned)(n_long + (P - n_long + NW_WG_WAVES - 1) / NW_WG_WAVES)), dim3(NW_THREADS),
-                       n_long ? 2 * NW_LDS_ROWS * sizeof(int) : 0, st, codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, bnd_off,
-                       bnd, trace_off, trace, scores, n_long, tie_rule);
+    // full alignments are few and the launch lasts as long as its longest chain: sixteen-wave workgroups
+    const int a16 = nw_allow16();
+    const dim3 grid((unsigned)(n_long + (P - n_long + NW_WG_WAVES - 1) / NW_WG_WAVES));
+    const int lds_ints = n_long ? NW_LDS_INTS_ALIGN : 0;
+    const size_t lds = (size_t)lds_ints * sizeof(int);
+    if (a16) {
+#define MDF_NW16(R)                                                                                                                              \
+    case R:                                                                                                                                      \
+        hipLaunchKernelGGL((k_nw16<true, R>), grid, dim3(NW_THREADS), lds, st, codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, \
+                           bnd_off, bnd, trace_off, trace, scores, n_long, n_match, lds_ints);                                                     \
+        break;
+        switch (tie_rule) {
+            MDF_NW16(0) MDF_NW16(1) MDF_NW16(2) MDF_NW16(3) MDF_NW16(4) MDF_NW16(5) MDF_NW16(6) MDF_NW16(7)
+        }
+#undef MDF_NW16
+    }
+    hipLaunchKernelGGL(k_nw<true>, grid, dim3(NW_THREADS), lds, st, codes, seq_off, seq_len, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, bnd_off, bnd,
+                       trace_off, trace, scores, n_long, tie_rule, a16, n_match, lds_ints);
     hipLaunchKernelGGL(k_nw_traceback, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, seq_len, pair_q, pair_t, P, trace_off, (const uint8_t *)trace,
-                       ops_off, ops, op_len, n_match);
-    if (q_aln || t_aln)
-        hipLaunchKernelGGL(k_nw_gapped, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, codes, seq_off, pair_q, pair_t, P, ops_off, (const char *)ops,
-                           (const int32_t *)op_len, alphabet, q_aln, t_aln);
+                       ops_off, ops, op_len, (const int32_t *)n_match);
+    hipLaunchKernelGGL(k_nw_finish, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, st, codes, seq_off, pair_q, pair_t, P, ops_off, ops,
+                       (const int32_t *)op_len, alphabet, q_aln, t_aln, n_match);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }

@@ -2,10 +2,13 @@
 work, so scores, operation strings, gapped strings and match counts must be IDENTICAL.  Also the reference's own known answers
 for the alignment step (mDeepFRI/tests/test_alignment.py:9-48) through the drop-in functions, and the hand-over of the
 aligner's arrays to the fused contact-map + GCN path."""
+import os
+
 import numpy as np
 import pytest
 
 import nw_oracle as nwo
+from conftest import ROOT
 from mDeepFRI import synthetic
 from mDeepFRI.alignment import (AlignmentResult, ScoringMatrix, align_pairwise, align_queries, align_queries_arrays, best_hit_database,
                                 insert_gaps, pairwise_against_database)
@@ -183,6 +186,74 @@ def test_size_independent_properties_at_scale():
         assert int(full["n_match"][k]) == ops.count("M")
     selfaln = pb.align(idx[:200], idx[:200], 10, 1)
     assert all(bytes(selfaln["ops"][int(selfaln["off"][k]):int(selfaln["off"][k + 1])]) == b"M" * len(seqs[k]) for k in range(200))
+
+
+@pytest.mark.parametrize("case", ["extend_above_open", "huge_open", "large_entries", "long_scores", "long_gaps"])
+def test_pairs_outside_the_16_bit_bucket_take_the_32_bit_kernel(case):
+    """Which arithmetic width sweeps a pair is decided per pair on the device (nw16_eligible, csrc/nw.hip -- Opal's "buckets",
+    reference alignment.py:184): gap models the 16-bit recurrence cannot express, matrices with large entries, and pairs whose
+    scores or gap runs leave the 16-bit range go to the 32-bit kernel -- in the SAME launch as pairs that qualify.  All of
+    them: scores and operation strings identical to the oracle."""
+    from mDeepFRI.alignment import _PairBatch
+    rng = np.random.default_rng(hash(case) % 1000)
+    sm, go, ge, sizes = _matrix(), 10, 1, [(40, 50), (300, 310), (129, 64)]
+    if case == "extend_above_open":
+        go, ge = 2, 5
+    elif case == "huge_open":
+        go, ge = 150, 3
+    elif case == "large_entries":
+        sm = ScoringMatrix(ALPHA, _matrix().matrix * 20, "scaled")
+    elif case == "long_scores":
+        sizes = [(40, 50), (2700, 2650), (300, 310)]          # 2 650 x 12 > 30 000: the middle pair alone leaves the bucket
+    elif case == "long_gaps":
+        go, ge, sizes = 10, 2, [(40, 50), (4000, 3900), (300, 310)]   # 2 go + (Lq + Lt) ge > 16 000
+    seqs, pq, pt = [], [], []
+    for lq, lt in sizes:
+        q = _seq(rng, lq)
+        t = (_mutate(rng, q, 0.1) + _seq(rng, lt))[:lt]
+        pq.append(len(seqs))
+        pt.append(len(seqs) + 1)
+        seqs += [q, t]
+    pb = _PairBatch(seqs, sm)
+    pq, pt = np.array(pq, np.int32), np.array(pt, np.int32)
+    sc = pb.scores(pq, pt, go, ge)
+    full = pb.align(pq, pt, go, ge)
+    for k in range(len(sizes)):
+        q, t = seqs[pq[k]], seqs[pt[k]]
+        e_ops, _, _, _, e_score = nwo.align_pairwise(q, t, sm.matrix, sm.alphabet, go, ge)
+        assert int(sc[k]) == e_score == int(full["score"][k]), (case, sizes[k])
+        assert bytes(full["ops"][int(full["off"][k]):int(full["off"][k + 1])]).decode() == e_ops, (case, sizes[k])
+        assert int(full["n_match"][k]) == e_ops.count("M")
+
+
+def test_16_bit_and_32_bit_kernels_agree_at_scale():
+    """The developer knob MDFRI_NW_INT16=0 sweeps everything in 32-bit arithmetic: 3 000 histogram-length pairs, scores and
+    operation strings identical to the default (packed 16-bit where a pair qualifies) -- in a fresh process each."""
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import sys, json, hashlib, numpy as np\n"
+        "sys.path[:0] = [%r, %r]\n"
+        "from mDeepFRI import synthetic\n"
+        "from mDeepFRI.alignment import ScoringMatrix, _PairBatch\n"
+        "rng = np.random.default_rng(3)\n"
+        "A = 'ARNDCQEGHILKMFPSTWYVBZX*'\n"
+        "m = rng.integers(-6, 4, size=(24, 24)); m = (m + m.T) // 2; np.fill_diagonal(m, rng.integers(5, 13, size=24))\n"
+        "lens = synthetic.histogram_lengths(9, 1500)\n"
+        "seqs = [''.join(rng.choice(list(A[:20]), size=int(L))) for L in lens]\n"
+        "pb = _PairBatch(seqs, ScoringMatrix(A, m))\n"
+        "a = rng.integers(0, 1500, size=3000).astype(np.int32); b = rng.integers(0, 1500, size=3000).astype(np.int32)\n"
+        "s = pb.scores(a, b, 10, 1); f = pb.align(a[::10], b[::10], 10, 1)\n"
+        "print(json.dumps({'scores': hashlib.sha256(s.tobytes()).hexdigest(), 'ops': hashlib.sha256(f['ops'].tobytes()).hexdigest(),\n"
+        "                  'off': hashlib.sha256(f['off'].tobytes()).hexdigest(), 'nm': int(f['n_match'].sum()), 'same': bool((f['score'] == s[::10]).all())}))\n"
+    ) % (os.path.join(ROOT, "metagenomic-deepfri_amd"), os.path.join(ROOT, "oracle"))
+    outs = []
+    for knob in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MDFRI_NW_INT16=knob), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1] and outs[0]["same"]
 
 
 @pytest.mark.parametrize("tie_rule", range(8))
