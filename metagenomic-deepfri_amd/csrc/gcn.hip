@@ -313,6 +313,16 @@ __device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr
                  : "v"(gsrc), "s"(lds_byte_addr)
                  : "memory");
 }
+// The same with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset: the eight
+// source addresses a wave keeps per pipeline position cost 8 VGPRs instead of 16.
+__device__ __forceinline__ void glds16s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr_of(const float *p)
 {
     return __builtin_amdgcn_readfirstlane((unsigned)(size_t)((lds_void_t *)p));
@@ -370,29 +380,29 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) fkg[kg] = ((kg * 2 + (lane >> 5)) ^ fswz) << 2;
 
-    // per-lane DMA source pointers of the position the prefetch cursor points at; recomputed (pure VALU/SALU work) in
-    // the last k-group of every position for the DMA issued at the head of the next one.  Rows past M clamp to M-1.
-    const float *sa0, *sa1, *sa2, *sa3, *sb0, *sb1, *sb2, *sb3;
+    // DMA sources of the position the prefetch cursor points at, as a wave-uniform base (SGPRs) + per-lane 32-bit byte offsets:
+    // the B offsets never change (only the base moves with the cursor), the A offsets carry the row clamp (rows past M read
+    // row M-1) and are recomputed -- pure VALU/SALU work -- in the last k-group of every position for the DMA issued at the head
+    // of the next one.  (Offsets fit 32 bits: an operand is at most M * lda * 4 B < 4 GiB, host-checked.)
+    const float *baseA, *baseB;
+    unsigned oa0, oa1, oa2, oa3;
+    const unsigned ob0 = (unsigned)((drow + 0) * ldb + dcol[0]) * 4u, ob1 = (unsigned)((drow + 8) * ldb + dcol[1]) * 4u,
+                   ob2 = (unsigned)((drow + 16) * ldb + dcol[2]) * 4u, ob3 = (unsigned)((drow + 24) * ldb + dcol[3]) * 4u;
 #define MDF_DMA_SETUP(cur_)                                                                                         \
     {                                                                                                               \
-        const float *gA_ = (EPI == EPI_LSTM_BIAS && (cur_).kt >= aux.ksplit)                                        \
-                               ? aux.A2 + (size_t)((cur_).kt - aux.ksplit) * BK                                     \
-                               : A + (size_t)(cur_).kt * BK;                                                        \
-        const float *gB_ = Bt + (size_t)((cur_).nt * BN + wid * 32 + drow) * ldb + (size_t)(cur_).kt * BK;          \
+        baseA = (EPI == EPI_LSTM_BIAS && (cur_).kt >= aux.ksplit) ? aux.A2 + (size_t)((cur_).kt - aux.ksplit) * BK    \
+                                                                   : A + (size_t)(cur_).kt * BK;                      \
+        baseB = Bt + (size_t)((cur_).nt * BN + wid * 32) * ldb + (size_t)(cur_).kt * BK;                              \
         const int rA_ = (cur_).mt * BM + wid * 32 + drow;                                                           \
-        sa0 = gA_ + (size_t)min(rA_, M - 1) * lda + dcol[0];                                                        \
-        sa1 = gA_ + (size_t)min(rA_ + 8, M - 1) * lda + dcol[1];                                                    \
-        sa2 = gA_ + (size_t)min(rA_ + 16, M - 1) * lda + dcol[2];                                                   \
-        sa3 = gA_ + (size_t)min(rA_ + 24, M - 1) * lda + dcol[3];                                                   \
-        sb0 = gB_ + dcol[0];                                                                                        \
-        sb1 = gB_ + (size_t)8 * ldb + dcol[1];                                                                      \
-        sb2 = gB_ + (size_t)16 * ldb + dcol[2];                                                                     \
-        sb3 = gB_ + (size_t)24 * ldb + dcol[3];                                                                     \
+        oa0 = (unsigned)(min(rA_, M - 1) * lda + dcol[0]) * 4u;                                                     \
+        oa1 = (unsigned)(min(rA_ + 8, M - 1) * lda + dcol[1]) * 4u;                                                 \
+        oa2 = (unsigned)(min(rA_ + 16, M - 1) * lda + dcol[2]) * 4u;                                                \
+        oa3 = (unsigned)(min(rA_ + 24, M - 1) * lda + dcol[3]) * 4u;                                                \
     }
 #define MDF_DMA_PIECE(i, ldsA_, ldsB_)                                       \
     if (ABL == 0) {                                                            \
-        glds16(sa##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024));           \
-        glds16(sb##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024));           \
+        glds16s(baseA, oa##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024));   \
+        glds16s(baseB, ob##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024));   \
     }
 #define MDF_SB __builtin_amdgcn_sched_barrier(0);
 #define MDF_MF(tm, tn, a, b) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tm][tn], 0, 0, 0);
@@ -966,6 +976,9 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
                        const GemmAux &aux = GemmAux())
 {
     MDF_REQUIRE(N % BN == 0 && K % BK == 0 && lda % 4 == 0 && ldb % 4 == 0, "gemm: unsupported shape M=%d N=%d K=%d", M, N, K);
+    // the LDS-DMA addresses a tile row as a 64-bit base + a 32-bit byte offset
+    MDF_REQUIRE((size_t)std::max(M, 1) * (size_t)lda * 4 < ((size_t)1 << 32) && (size_t)N * (size_t)ldb * 4 < ((size_t)1 << 32),
+                "gemm: operand larger than 4 GiB (M=%d lda=%d N=%d ldb=%d); split the batch", M, lda, N, ldb);
     if (int rc = set_gemm_attr_once()) return rc;
     const int MT = (M + BM - 1) / BM, NT = N / BN;
     const bool plain = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
