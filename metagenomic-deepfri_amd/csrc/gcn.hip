@@ -405,7 +405,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
         glds16s(baseB, ob##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024));   \
     }
 #define MDF_SB __builtin_amdgcn_sched_barrier(0);
+#ifdef MDF_PROBE_VALU_PAD   // experiments/gemm_probe.hip only: N independent packed fp32 FMAs behind every MFMA (how much VALU issue is free?)
+#define MDF_MF(tm, tn, a, b)                                                           \
+    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tm][tn], 0, 0, 0);    \
+    _Pragma("unroll") for (int pad_i_ = 0; pad_i_ < MDF_PROBE_VALU_PAD; ++pad_i_)      \
+        asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(probe_pad[pad_i_ & 3]) : "v"(probe_src));
+#else
 #define MDF_MF(tm, tn, a, b) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tm][tn], 0, 0, 0);
+#endif
     // fragments of one k-group: A tiles 0..3 (F##a0..a3), B tiles 0..1 (F##b0, F##b1)
 #define MDF_FRAG_DECL(F) float4 F##a0, F##a1, F##a2, F##a3, F##b0, F##b1;
 #define MDF_RDA(F, t, kg, base) if (ABL < 2) F##a##t = *reinterpret_cast<const float4 *>((base) + (t) * 1024 + fkg[kg]);
@@ -420,6 +427,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
     MDF_MF(0, 0, F##a0.e, F##b0.e) MDF_MF(0, 1, F##a0.e, F##b1.e) MDF_MF(1, 0, F##a1.e, F##b0.e) MDF_MF(1, 1, F##a1.e, F##b1.e) \
     MDF_MF(2, 0, F##a2.e, F##b0.e) MDF_MF(2, 1, F##a2.e, F##b1.e) MDF_MF(3, 0, F##a3.e, F##b0.e) MDF_MF(3, 1, F##a3.e, F##b1.e)
 
+#ifdef MDF_PROBE_VALU_PAD
+    typedef float probe_f2 __attribute__((ext_vector_type(2)));
+    probe_f2 probe_pad[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, probe_src = {1.0f + threadIdx.x * 1e-9f, 0.5f};
+#endif
     f32x16 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
