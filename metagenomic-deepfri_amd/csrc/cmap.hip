@@ -153,7 +153,7 @@ __global__ __launch_bounds__(1024) void k_scan_i32_to_i64(const int32_t *__restr
         const int64_t carry = carry_s;
         if (idx < n) base[idx] = carry + woff + inc - v;
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        if (threadIdx.x == blockDim.x - 1) carry_s = carry + woff + inc;
         __syncthreads();
     }
     if (threadIdx.x == 0) base[n] = carry_s;
@@ -359,8 +359,9 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
     }
 }
 
-// Exclusive scan of the per-group nnz (int32) with one 1024-thread block; writes rowptr[R] = total and the
-// overflow status.
+// Exclusive scan of the per-group nnz (int32) with one block of up to 1024 threads (launched with 256: four waves of 36 VGPRs
+// fit next to a resident GEMM workgroup, which matters when the contact stage of the next chunk runs under the GEMMs of the
+// current one); writes rowptr[R] = total and the overflow status.
 __global__ __launch_bounds__(1024) void k_scan_groups(const int32_t *__restrict__ group_sum, int G,
                                                       int32_t *__restrict__ group_base, int32_t *__restrict__ rowptr_end,
                                                       int64_t nnz_cap, int32_t *__restrict__ status)
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(1024) void k_scan_groups(const int32_t *__restrict_
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    for (int c0 = 0; c0 < G; c0 += 1024) {
+    for (int c0 = 0; c0 < G; c0 += (int)blockDim.x) {
         const int idx = c0 + threadIdx.x;
         const long long v = idx < G ? group_sum[idx] : 0;
         long long inc = v;
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(1024) void k_scan_groups(const int32_t *__restrict_
         const long long carry = carry_s;
         if (idx < G) group_base[idx] = (int32_t)(carry + woff + inc - v);
         __syncthreads();
-        if (threadIdx.x == 1023) carry_s = carry + woff + inc;
+        if (threadIdx.x == blockDim.x - 1) carry_s = carry + woff + inc;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -923,7 +924,7 @@ int mdf_cmap_csr_dev(const float *coords, const int32_t *coord_off, const char *
     // ONE pass over the coordinates: row counts + the contact bits themselves ...
     hipLaunchKernelGGL(k_cmap_rows<CM_COUNT>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t, t2,
                        generated_contacts, w.counts, w.group_sum, w.masks, W, (int32_t *)nullptr, (const int64_t *)nullptr);
-    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
     // ... then the CSR (and the layer-1 letter sums) from the bits
     hipLaunchKernelGGL(k_cmap_fill, dim3(G), dim3(256), 0, st, Lq, row_off, B, (const int32_t *)w.counts, (const int32_t *)w.group_base,
                        (const unsigned long long *)w.masks, W, rowptr, colidx, val, nnz_cap, seq_idx, letter_sums, status);
@@ -1009,7 +1010,7 @@ int mdf_dense_to_csr_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_
     hipLaunchKernelGGL(k_dense_rows<false>, dim3(G), dim3(256), 0, st, cmaps, cmap_dtype, cmap_off, Lq, row_off, B, w.counts,
                        w.rowsum, w.group_sum, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr,
                        (int64_t)0);
-    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(1024), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
     hipLaunchKernelGGL(k_dense_rows<true>, dim3(G), dim3(256), 0, st, cmaps, cmap_dtype, cmap_off, Lq, row_off, B, w.counts,
                        w.rowsum, (int32_t *)nullptr, (const int32_t *)w.group_base, rowptr, colidx, val, nnz_cap);
     MDF_HIP(hipGetLastError());

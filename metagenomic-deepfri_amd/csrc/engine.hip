@@ -343,7 +343,17 @@ struct mdf_engine {
     bool want_lsum = false;           // some head has no language model: it takes the folded layer-1 operand
     int64_t lm_hidden_max = 0;
     // workspaces
-    DevBuf rowptr, colidx, val, seq_idx, lsum, cws, gws, hws, seq_all, lm_ws, host_in, host_scores, map_dev[2], flags;
+    // the contact stage's outputs exist twice: while the GraphConv stacks of chunk c read one set, the contact stage of chunk
+    // c+1 fills the other on a second stream (pipelined fused path); everything else uses set 0
+    struct ContactSet {
+        DevBuf rowptr, colidx, val, seq_idx, lsum, cws;
+        hipEvent_t ready = nullptr, free = nullptr;
+    } cs[2];
+    hipStream_t aux = nullptr;        // low-priority stream of the pipelined contact stage
+    hipEvent_t ev_fork = nullptr;
+    bool pipeline_contact = false;
+    int last_set = 0;
+    DevBuf gws, hws, seq_all, lm_ws, host_in, host_scores, map_dev[2], flags;
     std::vector<DevBuf> partial, pooled, lm_h;
     int64_t rows_alloc = 0, nnz_cap = 0;
     int32_t len_alloc = 0;
@@ -406,6 +416,22 @@ extern "C" int mdf_engine_create(mdf_model *const *models, int32_t n_models, int
         }
         e->model_lm.push_back(li);
     }
+    // the pipelined contact stage: engines without a language model (those encode whole LSTM groups ahead of the contact stage)
+    {
+        static const int knob = getenv("MDFRI_CONTACT_PIPELINE") ? atoi(getenv("MDFRI_CONTACT_PIPELINE")) : 1;   // developer knob: 0 = one stream
+        if (knob != 0 && e->lms.empty() && e->cfg.pipeline_contact >= 0) {
+            DeviceGuard g(device);
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            bool ok = hipStreamCreateWithPriority(&e->aux, hipStreamNonBlocking, lo) == hipSuccess &&
+                      hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
+            for (auto &c : e->cs)
+                ok = ok && hipEventCreateWithFlags(&c.ready, hipEventDisableTiming) == hipSuccess &&
+                     hipEventCreateWithFlags(&c.free, hipEventDisableTiming) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+            e->pipeline_contact = ok;
+        }
+    }
     e->partial.resize(e->models.size());
     e->pooled.resize(e->models.size());
     e->lm_h.resize(e->lms.size());
@@ -429,9 +455,14 @@ extern "C" void mdf_engine_free(mdf_engine *e)
     (void)hipDeviceSynchronize();
     drop_graphs(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-    for (DevBuf *b : {&e->rowptr, &e->colidx, &e->val, &e->seq_idx, &e->lsum, &e->cws, &e->gws, &e->hws, &e->seq_all, &e->lm_ws, &e->host_in,
-                      &e->host_scores, &e->map_dev[0], &e->map_dev[1], &e->flags})
-        b->release();
+    for (auto &c : e->cs) {
+        for (DevBuf *b : {&c.rowptr, &c.colidx, &c.val, &c.seq_idx, &c.lsum, &c.cws}) b->release();
+        if (c.ready) (void)hipEventDestroy(c.ready);
+        if (c.free) (void)hipEventDestroy(c.free);
+    }
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
+    for (DevBuf *b : {&e->gws, &e->hws, &e->seq_all, &e->lm_ws, &e->host_in, &e->host_scores, &e->map_dev[0], &e->map_dev[1], &e->flags}) b->release();
     for (auto &b : e->partial) b.release();
     for (auto &b : e->pooled) b.release();
     for (auto &b : e->lm_h) b.release();
@@ -466,12 +497,15 @@ static int ensure(mdf_engine *e, int64_t rows, int32_t B, int32_t max_len, int64
         MDF_REQUIRE(cap < 0x7fffffffLL, "engine: %lld rows x %d entries per row exceed the int32 CSR; lower max_rows", (long long)rows, e->cfg.nnz_per_row);
         size_t gws = 0;
         for (mdf_model *m : e->models) gws = std::max(gws, mdf_gcn_workspace_bytes(m, rows));
-        if (int rc = e->rowptr.grow((size_t)(rows + 1) * 4, gen)) return rc;
-        if (int rc = e->colidx.grow((size_t)cap * 4, gen)) return rc;
-        if (int rc = e->val.grow((size_t)cap * 4, gen)) return rc;
-        if (int rc = e->seq_idx.grow((size_t)rows, gen)) return rc;
-        if (int rc = e->lsum.grow((size_t)rows * 32 * 4, gen)) return rc;
-        if (int rc = e->cws.grow(mdf_cmap_workspace_bytes(1 << 20, rows, max_len), gen)) return rc;
+        for (int k = 0; k < (e->pipeline_contact ? 2 : 1); ++k) {
+            mdf_engine::ContactSet &c = e->cs[k];
+            if (int rc = c.rowptr.grow((size_t)(rows + 1) * 4, gen)) return rc;
+            if (int rc = c.colidx.grow((size_t)cap * 4, gen)) return rc;
+            if (int rc = c.val.grow((size_t)cap * 4, gen)) return rc;
+            if (int rc = c.seq_idx.grow((size_t)rows, gen)) return rc;
+            if (int rc = c.lsum.grow((size_t)rows * 32 * 4, gen)) return rc;
+            if (int rc = c.cws.grow(mdf_cmap_workspace_bytes(1 << 20, rows, max_len), gen)) return rc;
+        }
         if (int rc = e->gws.grow(gws, gen)) return rc;
         e->rows_alloc = rows;
         e->nnz_cap = cap;
@@ -508,22 +542,22 @@ static int encode_chunk(mdf_engine *, const mdf_plan *pl, const mdf_batch_dev *b
 
 // letter sums once per chunk (shared by every head without a language model), then the GraphConv stack of each head; the
 // per-group partial sums land in the head's segment array
-static int gcn_chunk(mdf_engine *e, const PlanChunk &ch, const uint8_t *seq_ptr, const std::vector<const float *> &lm_h, bool have_lsum,
-                     hipStream_t st)
+static int gcn_chunk(mdf_engine *e, mdf_engine::ContactSet &c, const PlanChunk &ch, const uint8_t *seq_ptr, const std::vector<const float *> &lm_h,
+                     bool have_lsum, hipStream_t st)
 {
     if (!have_lsum && e->want_lsum)
-        if (int rc = mdf_letter_sums_dev(seq_ptr, e->rowptr.as<int32_t>(), e->colidx.as<int32_t>(), e->val.as<float>(), ch.rows, e->lsum.as<float>(), st))
+        if (int rc = mdf_letter_sums_dev(seq_ptr, c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), ch.rows, c.lsum.as<float>(), st))
             return rc;
     for (size_t k = 0; k < e->models.size(); ++k) {
         mdf_model *m = e->models[k];
         float *part = e->partial[k].as<float>() + (size_t)ch.group_base * (size_t)mdf_model_feature_dim(m);
         int rc;
         if (e->model_lm[k] < 0)
-            rc = mdf_gcn_embed_dev(m, e->lsum.as<float>(), e->rowptr.as<int32_t>(), e->colidx.as<int32_t>(), e->val.as<float>(), ch.rows, part,
-                                   e->gws.p, e->gws.bytes, st);
+            rc = mdf_gcn_embed_dev(m, c.lsum.as<float>(), c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), ch.rows, part, e->gws.p,
+                                   e->gws.bytes, st);
         else
-            rc = mdf_gcn_embed_lm_dev(m, seq_ptr, lm_h[(size_t)e->model_lm[k]], e->rowptr.as<int32_t>(), e->colidx.as<int32_t>(), e->val.as<float>(),
-                                      ch.rows, part, e->gws.p, e->gws.bytes, st);
+            rc = mdf_gcn_embed_lm_dev(m, seq_ptr, lm_h[(size_t)e->model_lm[k]], c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), ch.rows,
+                                      part, e->gws.p, e->gws.bytes, st);
         if (rc) return rc;
     }
     return MDF_OK;
@@ -553,16 +587,17 @@ static int run_chunks(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b,
     auto tail = [&](int ci, const uint8_t *seq_ptr) -> int {
         const PlanChunk &ch = pl->chunks[(size_t)ci];
         e->last_rows = ch.rows;
+        e->last_set = 0;
         bool have_lsum = false;
         if (int rc = build_csr(ci, ch, seq_ptr, &have_lsum)) return rc;
-        if (int rc = gcn_chunk(e, ch, seq_ptr, lm_ptr, have_lsum, st)) return rc;
+        if (int rc = gcn_chunk(e, e->cs[0], ch, seq_ptr, lm_ptr, have_lsum, st)) return rc;
         if (ci + 1 == nC || pl->chunks[(size_t)ci + 1].segment != ch.segment) return pool_segment(e, pl, pl->segments[(size_t)ch.segment], st);
         return MDF_OK;
     };
     if (e->lms.empty()) {
         for (int ci = 0; ci < nC; ++ci) {
-            if (int rc = encode_chunk(e, pl, b, ci, e->seq_idx.as<uint8_t>(), st)) return rc;
-            if (int rc = tail(ci, e->seq_idx.as<uint8_t>())) return rc;
+            if (int rc = encode_chunk(e, pl, b, ci, e->cs[0].seq_idx.as<uint8_t>(), st)) return rc;
+            if (int rc = tail(ci, e->cs[0].seq_idx.as<uint8_t>())) return rc;
         }
         return MDF_OK;
     }
@@ -605,18 +640,63 @@ static int run_heads(mdf_engine *e, int32_t B, float *const *scores, float *cons
     return MDF_OK;
 }
 
+// contact stage of chunk ci into contact set c: residue indices, then coordinates + alignment -> normalised CSR (+ the layer-1
+// letter sums when some head takes the folded embedding)
+static int contact_chunk(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, int ci, mdf_engine::ContactSet &c, hipStream_t st)
+{
+    const PlanChunk &ch = pl->chunks[(size_t)ci];
+    if (int rc = encode_chunk(e, pl, b, ci, c.seq_idx.as<uint8_t>(), st)) return rc;
+    return mdf_cmap_csr_dev(b->coords, b->coord_off + ch.p0, b->q_aln, b->t_aln, b->aln_off + ch.p0, b->Lq + ch.p0, pl->d_chunk_row_off + ch.row_off_pos,
+                            ch.p1 - ch.p0, ch.rows, ch.max_len, e->cfg.threshold, e->cfg.generated_contacts, c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(),
+                            c.val.as<float>(), e->nnz_cap, b->status + 4 * ci, e->want_lsum ? c.seq_idx.as<uint8_t>() : nullptr,
+                            e->want_lsum ? c.lsum.as<float>() : nullptr, c.cws.p, c.cws.bytes, st);
+}
+
 static int forward_alignments_eager(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, float *const *scores, float *const *logits,
                                     hipStream_t st)
 {
-    BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *seq_ptr, bool *have_lsum) -> int {
-        // contact stage: coordinates read once; the CSR fill also writes the layer-1 letter sums of the chunk
-        *have_lsum = e->want_lsum;
-        return mdf_cmap_csr_dev(b->coords, b->coord_off + ch.p0, b->q_aln, b->t_aln, b->aln_off + ch.p0, b->Lq + ch.p0,
-                                pl->d_chunk_row_off + ch.row_off_pos, ch.p1 - ch.p0, ch.rows, ch.max_len, e->cfg.threshold, e->cfg.generated_contacts,
-                                e->rowptr.as<int32_t>(), e->colidx.as<int32_t>(), e->val.as<float>(), e->nnz_cap, b->status + 4 * ci,
-                                e->want_lsum ? seq_ptr : nullptr, e->want_lsum ? e->lsum.as<float>() : nullptr, e->cws.p, e->cws.bytes, st);
-    };
-    if (int rc = run_chunks(e, pl, b, build, st)) return rc;
+    if (!e->pipeline_contact) {
+        BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *seq_ptr, bool *have_lsum) -> int {
+            // contact stage: coordinates read once; the CSR fill also writes the layer-1 letter sums of the chunk
+            *have_lsum = e->want_lsum;
+            mdf_engine::ContactSet &c = e->cs[0];
+            return mdf_cmap_csr_dev(b->coords, b->coord_off + ch.p0, b->q_aln, b->t_aln, b->aln_off + ch.p0, b->Lq + ch.p0,
+                                    pl->d_chunk_row_off + ch.row_off_pos, ch.p1 - ch.p0, ch.rows, ch.max_len, e->cfg.threshold, e->cfg.generated_contacts,
+                                    c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), e->nnz_cap, b->status + 4 * ci,
+                                    e->want_lsum ? seq_ptr : nullptr, e->want_lsum ? c.lsum.as<float>() : nullptr, c.cws.p, c.cws.bytes, st);
+        };
+        if (int rc = run_chunks(e, pl, b, build, st)) return rc;
+        return run_heads(e, pl->B, scores, logits, st);
+    }
+    // Pipelined form (no language model): the contact stage of chunk c+1 runs on a second, low-priority stream while the GraphConv
+    // stacks of chunk c hold the matrix pipe.  Its kernels are small and compute/latency-bound (27-60 VGPRs, next to nothing in
+    // LDS, a few MB of traffic): they fit on the SIMDs NEXT to a resident GEMM workgroup (216 of 512 VGPRs per wave, two waves)
+    // and, unlike the aggregation, do not compete for L2.  Two sets of contact outputs alternate; events order producer and
+    // consumer; every piece of second-stream work is joined back into `st` before the call's last launch.
+    const int nC = (int)pl->chunks.size();
+    hipStream_t sc = e->aux;
+    const std::vector<const float *> no_lm;
+    MDF_HIP(hipEventRecord(e->ev_fork, st));          // whatever precedes this call on st (uploads, the previous batch) comes first
+    MDF_HIP(hipStreamWaitEvent(sc, e->ev_fork, 0));
+    if (int rc = contact_chunk(e, pl, b, 0, e->cs[0], sc)) return rc;
+    MDF_HIP(hipEventRecord(e->cs[0].ready, sc));
+    for (int ci = 0; ci < nC; ++ci) {
+        mdf_engine::ContactSet &cur = e->cs[ci & 1];
+        if (ci + 1 < nC) {
+            mdf_engine::ContactSet &nxt = e->cs[(ci + 1) & 1];
+            if (ci >= 1) MDF_HIP(hipStreamWaitEvent(sc, nxt.free, 0));   // chunk ci-1 has finished reading that set
+            if (int rc = contact_chunk(e, pl, b, ci + 1, nxt, sc)) return rc;
+            MDF_HIP(hipEventRecord(nxt.ready, sc));
+        }
+        const PlanChunk &ch = pl->chunks[(size_t)ci];
+        MDF_HIP(hipStreamWaitEvent(st, cur.ready, 0));
+        e->last_rows = ch.rows;
+        e->last_set = ci & 1;
+        if (int rc = gcn_chunk(e, cur, ch, cur.seq_idx.as<uint8_t>(), no_lm, /*have_lsum=*/e->want_lsum, st)) return rc;
+        if (ci + 1 == nC || pl->chunks[(size_t)ci + 1].segment != ch.segment)
+            if (int rc = pool_segment(e, pl, pl->segments[(size_t)ch.segment], st)) return rc;
+        MDF_HIP(hipEventRecord(cur.free, st));
+    }
     return run_heads(e, pl->B, scores, logits, st);
 }
 
@@ -743,11 +823,11 @@ extern "C" int64_t mdf_engine_last_chunk_nnz(mdf_engine *e, void *stream)
 {
     MDF_REQUIRE(e, "engine_last_chunk_nnz: NULL engine");
     std::lock_guard<std::mutex> lk(e->mu);
-    MDF_REQUIRE(e->last_rows > 0 && e->rowptr.p, "engine_last_chunk_nnz: nothing has run yet");
+    MDF_REQUIRE(e->last_rows > 0 && e->cs[e->last_set].rowptr.p, "engine_last_chunk_nnz: nothing has run yet");
     DeviceGuard g(e->device);
     MDF_HIP(g.err);
     int32_t nnz = 0;
-    MDF_HIP(hipMemcpyAsync(&nnz, e->rowptr.as<int32_t>() + e->last_rows, 4, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    MDF_HIP(hipMemcpyAsync(&nnz, e->cs[e->last_set].rowptr.as<int32_t>() + e->last_rows, 4, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
     MDF_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return nnz;
 }
@@ -807,15 +887,15 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         }
         if (nnz_needed > e->nnz_cap) {   // a denser chunk than the CSR arrays hold: grow them (hipFree waits for the device)
             MDF_REQUIRE(nnz_needed < 0x7fffffffLL, "engine_forward_dense: a chunk needs %lld CSR entries; lower max_rows", (long long)nnz_needed);
-            if (int rc = e->colidx.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
-            if (int rc = e->val.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
+            if (int rc = e->cs[0].colidx.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
+            if (int rc = e->cs[0].val.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
             e->nnz_cap = nnz_needed;
         }
         char *d = e->map_dev[s].as<char>();
         MDF_HIP(hipMemcpyAsync(d, e->map_pin[s], total, hipMemcpyHostToDevice, st));
         const int rc = mdf_dense_to_csr_dev(d + o_maps, cmap_dtype, reinterpret_cast<const int64_t *>(d), b->Lq + ch.p0, pl->d_chunk_row_off + ch.row_off_pos,
-                                            Bc, ch.rows, e->rowptr.as<int32_t>(), e->colidx.as<int32_t>(), e->val.as<float>(), e->nnz_cap,
-                                            b->status + 4 * ci, e->cws.p, e->cws.bytes, st);
+                                            Bc, ch.rows, e->cs[0].rowptr.as<int32_t>(), e->cs[0].colidx.as<int32_t>(), e->cs[0].val.as<float>(), e->nnz_cap,
+                                            b->status + 4 * ci, e->cs[0].cws.p, e->cs[0].cws.bytes, st);
         if (rc) return rc;
         MDF_HIP(hipEventRecord(e->map_ev[s], st));
         used[s] = true;

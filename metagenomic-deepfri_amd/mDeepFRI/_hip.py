@@ -58,6 +58,7 @@ class EngineConfig(ctypes.Structure):
     _fields_ = [
         ("max_rows", c_int32), ("nnz_per_row", c_int32), ("threshold", c_double), ("generated_contacts", c_int32),
         ("max_segment_groups", c_int32), ("lm_batch", c_int32), ("lm_workspace_gib", c_double), ("graph_max_chunks", c_int32),
+        ("pipeline_contact", c_int32),
     ]
 
 

@@ -238,7 +238,7 @@ class HotPathEngine:
 
     def __init__(self, predictors: dict, device: int = 0, max_rows: int = 32768, nnz_per_row: int = 40,
                  threshold: float = 6.0, generated_contacts: int = 2, lm_batch: int = 8192, lm_workspace_gib: float = 48.0,
-                 graph_max_chunks: int = 0):
+                 graph_max_chunks: int = 0, pipeline_contact: int = 0):
         import weakref
         torch = _torch()
         if not torch.cuda.is_available():
@@ -261,7 +261,7 @@ class HotPathEngine:
             if lm is not None and all(lm is not x for x in self.lms):
                 self.lms.append(lm)
         cfg = _hip.EngineConfig(self.max_rows, self.nnz_per_row, self.threshold, self.generated_contacts, 0, int(lm_batch), float(lm_workspace_gib),
-                                int(graph_max_chunks))
+                                int(graph_max_chunks), int(pipeline_contact))
         handles = (ctypes.c_void_p * len(self.modes))(*[self.predictors[m].session.handle for m in self.modes])
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):

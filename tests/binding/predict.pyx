@@ -78,6 +78,7 @@ cdef extern from "mdfri.h":
         int32_t lm_batch
         double lm_workspace_gib
         int32_t graph_max_chunks
+        int32_t pipeline_contact
     int mdf_engine_create(mdf_model *const *models, int32_t n_models, int device, const mdf_engine_config *cfg, mdf_engine **out)
     void mdf_engine_free(mdf_engine *e)
     int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords,
@@ -271,7 +272,7 @@ def predict_batch(list predictors, list seqs, list coords, list q_alns, list t_a
     for k in range(n):
         outs[k] = <float *>cnp.PyArray_DATA(results[k])
     cfg.max_rows, cfg.nnz_per_row, cfg.threshold, cfg.generated_contacts = max_rows, 0, threshold, generated_contacts
-    cfg.max_segment_groups, cfg.lm_batch, cfg.lm_workspace_gib, cfg.graph_max_chunks = 0, 0, 0.0, 0
+    cfg.max_segment_groups, cfg.lm_batch, cfg.lm_workspace_gib, cfg.graph_max_chunks, cfg.pipeline_contact = 0, 0, 0.0, 0, 0
     _check(mdf_engine_create(models, n, 0, &cfg, &eng))
     cdef const char *sp = sb
     cdef const char *qp = qb
