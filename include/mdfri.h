@@ -390,6 +390,14 @@ int mdf_engine_graph_stats(const mdf_engine *e, int64_t *graph_launches, int64_t
 /* Diagnostic: synchronise `stream` and return the CSR entries of the chunk processed last (rowptr[R]); negative = error. */
 int64_t mdf_engine_last_chunk_nnz(mdf_engine *e, void *stream);
 
+/* The same for sequence-only CNN models (mdf_cnn): the batched counterpart of the reference's CNN loop over the proteins without
+ * a structural hit (pipeline.py:600-648).  batch: seqs / seq_off / Lq / status / bad are used.  scores[k]: DEVICE (B, T_k). */
+typedef struct mdf_seq_engine mdf_seq_engine;
+int mdf_seq_engine_create(mdf_cnn *const *models, int32_t n_models, int device, mdf_seq_engine **out);
+void mdf_seq_engine_free(mdf_seq_engine *e);
+int mdf_seq_engine_forward(mdf_seq_engine *e, const mdf_plan *plan, const mdf_batch_dev *batch, float *const *scores, void *stream);
+int mdf_seq_engine_check(mdf_seq_engine *e, const mdf_plan *plan, const mdf_batch_dev *batch, void *stream, int64_t info[4]);
+
 /* Everything in one call with HOST buffers: plan, upload, fused forward, validation (one automatic retry with a larger
  * CSR capacity), download.  seqs / q_aln / t_aln are packed byte strings with per-protein lengths Lq / La / La; coords is
  * packed (sum Lt, 3) f32.  scores_host[k]: (B, T_k) f32.  Errors as mdf_engine_check (info may be NULL).

@@ -909,7 +909,7 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
 }
 
 // ---- validation ------------------------------------------------------------------------------------------------------
-static int check_locked(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, hipStream_t st, int64_t *info)
+static int check_locked(const mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, hipStream_t st, int64_t *info)
 {
     const size_t nC = pl->chunks.size();
     std::vector<int64_t> bad(nC);
@@ -939,7 +939,7 @@ static int check_locked(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *
     }
     if (overflow) {
         if (info) info[3] = need;
-        return fail(MDF_ECAPACITY, "CSR capacity %lld too small (a chunk needs %d); raise nnz_per_row", (long long)e->nnz_cap, need);
+        return fail(MDF_ECAPACITY, "CSR capacity %lld too small (a chunk needs %d); raise nnz_per_row", (long long)(e ? e->nnz_cap : 0), need);
     }
     return MDF_OK;
 }
@@ -951,6 +951,91 @@ extern "C" int mdf_engine_check(mdf_engine *e, const mdf_plan *pl, const mdf_bat
     DeviceGuard g(e->device);
     MDF_HIP(g.err);
     return check_locked(e, pl, b, static_cast<hipStream_t>(stream), info);
+}
+
+// ---- sequence-only CNN models: the batched counterpart of the reference's CNN loop over the unaligned queries --------------
+// (pipeline.py:600-648, `_run_prediction_loop(predictor=cnn, ...)`): residue indices chunk by chunk, conv + max pool per head
+// into one (B, C) array, then the output layer ONCE per head over all proteins (a 2 048-protein chunk is too few rows to fill
+// the GEMM's 256-row tiles on 256 CUs).
+struct mdf_seq_engine {
+    int device = 0;
+    std::vector<mdf_cnn *> models;
+    DevBuf seq_idx, ws;
+    std::vector<DevBuf> pooled;
+    std::mutex mu;
+};
+
+extern "C" int mdf_seq_engine_create(mdf_cnn *const *models, int32_t n_models, int device, mdf_seq_engine **out)
+{
+    MDF_REQUIRE(models && out && n_models > 0, "seq_engine_create: at least one model is required");
+    if (int rc = require_device()) return rc;
+    auto *e = new mdf_seq_engine();
+    e->device = device;
+    for (int32_t k = 0; k < n_models; ++k) {
+        if (!models[k]) {
+            delete e;
+            return fail(MDF_EINVAL, "seq_engine_create: model %d is NULL", k);
+        }
+        e->models.push_back(models[k]);
+    }
+    e->pooled.resize(e->models.size());
+    *out = e;
+    return MDF_OK;
+}
+
+extern "C" void mdf_seq_engine_free(mdf_seq_engine *e)
+{
+    if (!e) return;
+    DeviceGuard g(e->device);
+    (void)hipDeviceSynchronize();
+    e->seq_idx.release();
+    e->ws.release();
+    for (auto &b : e->pooled) b.release();
+    delete e;
+}
+
+extern "C" int mdf_seq_engine_forward(mdf_seq_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, float *const *scores, void *stream)
+{
+    MDF_REQUIRE(e && pl && b && scores, "seq_engine_forward: NULL argument");
+    MDF_REQUIRE(b->B == pl->B, "seq_engine_forward: the batch holds %d proteins but the plan was made for %d", b->B, pl->B);
+    MDF_REQUIRE(b->seqs && b->seq_off && b->Lq && b->bad, "seq_engine_forward: NULL pointer in the batch descriptor");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    MDF_HIP(g.err);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = plan_mirror(pl, e->device)) return rc;
+    const int64_t rows = pl->max_chunk_rows;
+    if (int rc = e->seq_idx.grow((size_t)rows, nullptr)) return rc;
+    if (int rc = e->ws.grow((size_t)(rows / 32 + 1) * 4 + 512, nullptr)) return rc;
+    std::vector<int> cpad(e->models.size());
+    for (size_t k = 0; k < e->models.size(); ++k) {
+        cpad[k] = mdf_cnn_padded_channels(e->models[k]);
+        if (int rc = e->pooled[k].grow((size_t)pl->B * (size_t)cpad[k] * 4, nullptr)) return rc;
+    }
+    for (size_t ci = 0; ci < pl->chunks.size(); ++ci) {
+        const PlanChunk &ch = pl->chunks[ci];
+        const int32_t *ro = pl->d_chunk_row_off + ch.row_off_pos;
+        if (int rc = mdf_seq_encode_dev(b->seqs, b->seq_off + ch.p0, b->Lq + ch.p0, ro, ch.p1 - ch.p0, ch.rows, e->seq_idx.as<uint8_t>(), b->bad + ci, st))
+            return rc;
+        for (size_t k = 0; k < e->models.size(); ++k)
+            if (int rc = mdf_cnn_pool_dev(e->models[k], e->seq_idx.as<uint8_t>(), b->Lq + ch.p0, ro, ch.p1 - ch.p0, ch.rows,
+                                          e->pooled[k].as<float>() + (size_t)ch.p0 * (size_t)cpad[k], e->ws.p, e->ws.bytes, st))
+                return rc;
+    }
+    for (size_t k = 0; k < e->models.size(); ++k) {
+        MDF_REQUIRE(scores[k], "seq_engine_forward: scores[%zu] is NULL", k);
+        if (int rc = mdf_cnn_head_dev(e->models[k], e->pooled[k].as<float>(), pl->B, scores[k], st)) return rc;
+    }
+    return MDF_OK;
+}
+
+extern "C" int mdf_seq_engine_check(mdf_seq_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, void *stream, int64_t info[4])
+{
+    MDF_REQUIRE(e && pl && b && b->bad && b->status, "seq_engine_check: NULL argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    MDF_HIP(g.err);
+    return check_locked(nullptr, pl, b, static_cast<hipStream_t>(stream), info);
 }
 
 // ---- language-model features (inspection) ------------------------------------------------------------------------------

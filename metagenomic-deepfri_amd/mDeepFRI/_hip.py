@@ -151,6 +151,10 @@ SIGNATURES = {
     "mdf_engine_num_lms": (c_int32, [c_void_p]),
     "mdf_engine_graph_stats": (c_int, [c_void_p, _i64p, _i64p]),
     "mdf_engine_last_chunk_nnz": (c_int64, [c_void_p, c_void_p]),
+    "mdf_seq_engine_create": (c_int, [POINTER(c_void_p), c_int32, c_int, POINTER(c_void_p)]),
+    "mdf_seq_engine_free": (None, [c_void_p]),
+    "mdf_seq_engine_forward": (c_int, [c_void_p, c_void_p, POINTER(BatchDev), POINTER(c_void_p), c_void_p]),
+    "mdf_seq_engine_check": (c_int, [c_void_p, c_void_p, POINTER(BatchDev), c_void_p, _i64p]),
     "mdf_engine_run_alignments_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                POINTER(c_void_p), _i64p]),
     "mdf_filter_workspace_bytes": (c_size_t, [c_int32]),

@@ -77,37 +77,42 @@ class PackedProteins:
 
     @classmethod
     def pack(cls, seqs, coords=None, q_alns=None, t_alns=None, max_rows: int = 32768, max_segment_groups: int = 1 << 19):
+        """Host-side packing, vectorised: one join + one encode per column (a non-ASCII letter fails there, as `str.encode("ascii")`
+        per sequence did), lengths by `map(len, ...)`, the "gapped query spells its sequence" check by one reduceat over the packed
+        bytes -- no per-protein Python work besides `len` (the producer thread of mDeepFRI.stream packs batches while the GPU
+        computes: at 22 us per protein the old loop, not the GPU, bounded the host-to-host rate)."""
         seqs = list(seqs)
         if not seqs:
             raise ValueError("empty batch")
-        enc = [s.encode("ascii") for s in seqs]
-        Lq = np.array([len(b) for b in enc], dtype=np.int32)
+        Lq = np.fromiter(map(len, seqs), dtype=np.int64, count=len(seqs))
         if (Lq <= 0).any():
             raise ValueError("empty sequence in batch")
-        pk = cls(seqs=seqs, Lq=Lq, seq_bytes=np.frombuffer(b"".join(enc), dtype=np.uint8).copy(), seq_off=_offsets(Lq))
+        seq_bytes = np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8).copy()
+        pk = cls(seqs=seqs, Lq=Lq.astype(np.int32), seq_bytes=seq_bytes, seq_off=_offsets(Lq))
         if coords is not None:
             if q_alns is None or t_alns is None or not (len(coords) == len(q_alns) == len(t_alns) == len(seqs)):
                 raise ValueError("coords, q_alns and t_alns must all be given, one per sequence")
-            cs = []
-            for c in coords:
-                c = np.asarray(c)
+            cs = [c if type(c) is np.ndarray else np.asarray(c) for c in coords]
+            for c in cs:
                 if c.dtype != np.float32 or c.ndim != 2 or c.shape[1] != 3:
                     raise ValueError("coordinates must be float32 (Lt,3)")
-                cs.append(np.ascontiguousarray(c))
-            pk.coords = np.concatenate(cs, axis=0) if cs else np.zeros((0, 3), np.float32)
+            pk.coords = np.ascontiguousarray(np.concatenate(cs, axis=0)) if cs else np.zeros((0, 3), np.float32)
             if pk.coords.shape[0] == 0:
                 pk.coords = np.zeros((1, 3), np.float32)
             pk.coord_off = _offsets([c.shape[0] for c in cs])
-            qb = [q.encode("ascii") for q in q_alns]
-            tb = [t.encode("ascii") for t in t_alns]
-            for i, (q, t, s) in enumerate(zip(qb, tb, enc)):
-                if len(q) != len(t):
-                    raise ValueError(f"protein {i}: gapped query and target differ in length")
-                if len(q) - q.count(b"-") != len(s):
-                    raise ValueError(f"protein {i}: gapped query does not spell a sequence of length {len(s)}")
-            pk.q_aln = np.frombuffer(b"".join(qb), dtype=np.uint8).copy()
-            pk.t_aln = np.frombuffer(b"".join(tb), dtype=np.uint8).copy()
-            pk.aln_off = _offsets([len(q) for q in qb])
+            La = np.fromiter(map(len, q_alns), dtype=np.int64, count=len(seqs))
+            Lt_aln = np.fromiter(map(len, t_alns), dtype=np.int64, count=len(seqs))
+            if not np.array_equal(La, Lt_aln):
+                i = int(np.argmax(La != Lt_aln))
+                raise ValueError(f"protein {i}: gapped query and target differ in length")
+            pk.q_aln = np.frombuffer("".join(q_alns).encode("ascii"), dtype=np.uint8).copy()
+            pk.t_aln = np.frombuffer("".join(t_alns).encode("ascii"), dtype=np.uint8).copy()
+            pk.aln_off = _offsets(La)
+            gaps = np.flatnonzero(pk.q_aln == 45)                        # gap columns are few: count them per protein by bisection
+            nongap = La - (np.searchsorted(gaps, pk.aln_off[1:]) - np.searchsorted(gaps, pk.aln_off[:-1]))
+            if not np.array_equal(nongap, Lq):
+                i = int(np.argmax(nongap != Lq))
+                raise ValueError(f"protein {i}: gapped query does not spell a sequence of length {int(Lq[i])}")
         pk._plan(max_rows, max_segment_groups)
         return pk
 
@@ -394,9 +399,10 @@ class HotPathEngine:
 class SequenceEngine:
     """Sequence-only CNN models for batches of proteins on one GPU: the batched counterpart of the reference's CNN loop
     over the unaligned queries (pipeline.py:600-648, `_run_prediction_loop(predictor=cnn, ...)`).
-    `predictors`: {mode: Predictor built from a DeepCNN model}."""
+    `predictors`: {mode: Predictor built from a DeepCNN model}.  A thin caller of the library's `mdf_seq_engine_*`."""
 
     def __init__(self, predictors: dict, device: int = 0, max_rows: int = 1 << 20):
+        import weakref
         torch = _torch()
         if not torch.cuda.is_available():
             raise RuntimeError("SequenceEngine needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -405,40 +411,35 @@ class SequenceEngine:
                 raise ValueError(f"predictor {m!r} is not a sequence-only (CNN) model")
         self.L = _hip.lib()
         self.predictors = dict(predictors)
+        self.modes = list(self.predictors)
         self.device = torch.device(f"cuda:{device}")
         self.max_rows = int(max_rows)
+        handles = (ctypes.c_void_p * len(self.modes))(*[self.predictors[m].session.handle for m in self.modes])
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _hip.check(self.L.mdf_seq_engine_create(handles, len(self.modes), int(device), ctypes.byref(h)))
+        self.handle = h
+        weakref.finalize(self, self.L.mdf_seq_engine_free, h)
 
     def forward(self, db: DeviceBatch) -> dict:
         """{mode: (B, T) float32 scores on the device}; asynchronous on the current stream (`check(db)` syncs)."""
         torch = _torch()
-        pk = db.packed
         with torch.cuda.device(self.device):
             st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            rows = pk.max_chunk_rows
-            seq_idx = torch.empty(rows, dtype=torch.uint8, device=self.device)
-            ws = torch.empty((rows // 32 + 1) * 4 + 512, dtype=torch.uint8, device=self.device)
             out = {m: torch.empty((db.B, p.n_terms), dtype=torch.float32, device=self.device) for m, p in self.predictors.items()}
-            # conv + max pool chunk by chunk into one (B, C) array per head; the output layer then runs ONCE per head over all
-            # proteins (a 2 048-protein chunk is too few rows to fill the GEMM's 256-row tiles on 256 CUs)
-            cpad = {m: int(self.L.mdf_cnn_padded_channels(p.session.handle)) for m, p in self.predictors.items()}
-            pooled = {m: torch.empty((db.B, cpad[m]), dtype=torch.float32, device=self.device) for m in self.predictors}
-            for ci, ch in enumerate(pk.chunks):
-                Bc = ch.p1 - ch.p0
-                ro = _p(db.chunk_row_off, ch.row_off_pos)
-                _hip.check(self.L.mdf_seq_encode_dev(_p(db.seq_bytes), _p(db.seq_off, ch.p0), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
-                                                     _p(seq_idx), _p(db.bad, ci), st))
-                for m, p in self.predictors.items():
-                    _hip.check(self.L.mdf_cnn_pool_dev(p.session.handle, _p(seq_idx), _p(db.Lq, ch.p0), ro, Bc, ch.rows,
-                                                       _p(pooled[m], ch.p0 * cpad[m]), _p(ws), ws.numel(), st))
-            for m, p in self.predictors.items():
-                _hip.check(self.L.mdf_cnn_head_dev(p.session.handle, _p(pooled[m]), db.B, _p(out[m]), st))
-            self._keep = (seq_idx, ws, pooled)
+            sp = (ctypes.c_void_p * len(self.modes))(*[out[m].data_ptr() for m in self.modes])
+            _hip.check(self.L.mdf_seq_engine_forward(self.handle, db.packed.plan, ctypes.byref(db.desc), sp, st))
             return out
 
     def check(self, db: DeviceBatch):
         torch = _torch()
-        torch.cuda.current_stream(self.device).synchronize()
-        first_invalid_residue(db.packed, db.bad.cpu().numpy())
+        info = (ctypes.c_int64 * 4)()
+        with torch.cuda.device(self.device):
+            st = ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            rc = self.L.mdf_seq_engine_check(self.handle, db.packed.plan, ctypes.byref(db.desc), st, info)
+        if rc == _hip.MDF_EBADCHAR:
+            raise ValueError(f"Invalid character in sequence: {db.packed.seqs[info[0]][info[1]]}")
+        _hip.check(rc)
 
     def run(self, seqs) -> dict:
         """Convenience: pack, upload, run, validate -> {mode: np.ndarray (B, T)}."""
