@@ -338,8 +338,9 @@ typedef struct {
     double lm_workspace_gib;     /* LSTM time-major workspace budget; 0 = 48 */
     int32_t graph_max_chunks;    /* batches of at most this many chunks replay their launch sequence as ONE hipGraph from the
                                     third identical call on (same plan, buffers and outputs); 0 = 8, negative = never */
-    int32_t pipeline_contact;    /* 0 = automatic: engines without a language model build the contact maps of chunk c+1 on a second
-                                    (library-owned, low-priority) stream under the GraphConv stacks of chunk c; negative = never */
+    int32_t pipeline_contact;    /* > 0 (engines without a language model): build the contact maps of chunk c+1 on a second,
+                                    library-owned low-priority stream under the GraphConv stacks of chunk c (+0.8 % on the step; the
+                                    aggregation kernel next to it runs 15 % slower); 0 = everything on the caller's stream (default) */
 } mdf_engine_config;
 /* models: n GO heads (GCN models of one device; heads with a language model must have it attached, mdf_model_attach_lm).
  * The models are not owned and must outlive the engine.  cfg may be NULL (all defaults, threshold 6.0, 2 generated contacts). */

@@ -131,3 +131,31 @@ def test_graph_replay_keeps_reporting_invalid_residues(heads):
         with pytest.raises(ValueError, match=r"Invalid character in sequence: \*"):
             eng.check(db)
     assert eng.graph_stats()[0] >= 2
+
+
+def test_pipelined_contact_stage_is_bitwise_the_same(heads):
+    """cfg.pipeline_contact = 1: the contact stage of chunk c+1 on the engine's second stream under the GraphConv stacks of chunk c,
+    two alternating contact sets ordered by events -- same kernels, same inputs: bit-identical scores, flags still reported, and
+    the form survives repeated calls (graph replay included) and odd / even chunk counts."""
+    from mDeepFRI.batch import HotPathEngine
+    ws, preds = heads
+    for count, max_rows in ((37, 1024), (6, 65536), (50, 2048)):
+        prots = synthetic.synthetic_proteins(seed=300 + count, count=count, length=(20, 400), indel_rate=0.06)
+        pk = _pack(prots, max_rows=max_rows)
+        ref = HotPathEngine(preds, device=0, max_rows=max_rows).run_alignments(pk)
+        eng = HotPathEngine(preds, device=0, max_rows=max_rows, pipeline_contact=1)
+        db = eng.upload(pk)
+        out = eng.outputs_for(db)
+        for _ in range(4):
+            scores = eng.forward_alignments(db, out=out)
+            eng.check(db)
+            for m in eng.modes:
+                assert np.array_equal(scores[m].cpu().numpy(), ref[m]), (count, m)
+    bad = [dict(p) for p in prots]
+    s = bad[31]["seq"]
+    bad[31]["seq"] = bad[31]["q_aln"] = bad[31]["t_aln"] = s[:5] + "J" + s[6:]
+    eng = HotPathEngine(preds, device=0, max_rows=2048, pipeline_contact=1)
+    db = eng.upload(_pack(bad, max_rows=2048))
+    eng.forward_alignments(db)
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        eng.check(db)
