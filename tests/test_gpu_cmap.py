@@ -1,6 +1,7 @@
 """GPU parity: contact-map kernels (through the C ABI / the drop-in Python API) vs the golden vectors of the
 compiled reference and vs the C oracle.  Bit-exact everywhere (integer / index work and f32 bit patterns)."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -236,6 +237,63 @@ def test_batched_build_align_contact_maps_matches_per_call():
         if a.coords is not None:
             assert cm.dtype == np.int32
             assert np.array_equal(cm, orc.build_align_contact_map(a.coords, a.gapped_sequence, a.gapped_target, 6.0, 2))
+
+
+def test_other_thresholds_against_the_compiled_reference_goldens():
+    """(10 A, 2) -- the operating point of the released `..._ca_10.0_...` models --, (4, 0), (8, 5), (10, 0), (7.5, 1): the per-call
+    drop-in functions, the fused per-call build and the batched dense build, bit for bit against outputs of the COMPILED REFERENCE
+    (tests/golden/cmap_thr_golden.npz, made by tests/golden/make_thr_golden.py); and the CSR the fused GCN path consumes holds
+    exactly the reference's contacts (column indices per row)."""
+    import ctypes
+    import hashlib
+    import torch
+    from conftest import GOLDEN
+    from mDeepFRI import _hip
+    from mDeepFRI.batch import DeviceBatch, PackedProteins, _p, build_align_contact_maps
+    from mDeepFRI.bio_utils import build_align_contact_map, calculate_contact_map
+    from mDeepFRI.contact_map_utils import align_contact_map
+    z = np.load(os.path.join(GOLDEN, "cmap_thr_golden.npz"))
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()  # noqa: E731
+    by_setting = {}
+    for n in (str(x) for x in z["index"]):
+        coords, q, t = z[n + "/coords"], gstr(z[n + "/q"]), gstr(z[n + "/t"])
+        thr, gen = float(z[n + "/thr"]), int(z[n + "/gen"])
+        sparse = calculate_contact_map(coords, thr, mode="sparse")
+        assert sparse.dtype == np.int32 and sha(sparse) == gstr(z[n + "/sha_sparse"]), n
+        out = align_contact_map(q, t, sparse, gen)
+        assert sha(out) == gstr(z[n + "/sha_out"]), n
+        assert np.array_equal(build_align_contact_map(Aln(coords, q, t), thr, gen)[1], out), n
+        by_setting.setdefault((thr, gen), []).append((n, coords, q, t, out))
+    L = _hip.lib()
+    dev = torch.device("cuda:0")
+    for (thr, gen), cases in by_setting.items():
+        res = build_align_contact_maps([Aln(c, q, t) for _, c, q, t, _ in cases], thr, gen, max_rows=1024)
+        for (n, _, _, _, out), (_, cm) in zip(cases, res):
+            assert np.array_equal(cm, out), n
+        # the CSR of the fused path: every row's column set == the reference map's row
+        pk = PackedProteins.pack([q.replace("-", "") for _, _, q, _, _ in cases], [c for _, c, _, _, _ in cases], [q for _, _, q, _, _ in cases],
+                                 [t for _, _, _, t, _ in cases], max_rows=65536)
+        assert len(pk.chunks) == 1
+        db, R = DeviceBatch(pk, dev), pk.chunks[0].rows
+        max_len, cap = int(pk.Lq.max()), R * 128
+        ws = torch.empty(L.mdf_cmap_workspace_bytes(pk.B, R, max_len), dtype=torch.uint8, device=dev)
+        rowptr = torch.empty(R + 1, dtype=torch.int32, device=dev)
+        colidx = torch.empty(cap, dtype=torch.int32, device=dev)
+        val = torch.empty(cap, dtype=torch.float32, device=dev)
+        status = torch.zeros(4, dtype=torch.int32, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _hip.check(L.mdf_cmap_csr_dev(_p(db.coords), _p(db.coord_off), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off), _p(db.Lq), _p(db.chunk_row_off), pk.B, R,
+                                      max_len, thr, gen, _p(rowptr), _p(colidx), _p(val), cap, _p(status), None, None, _p(ws), ws.numel(), st))
+        torch.cuda.synchronize()
+        assert status.tolist() == [0, 0, 0, 0]
+        rp, ci = rowptr.cpu().numpy(), colidx.cpu().numpy()
+        ro = pk.chunk_row_off
+        for k, (n, _, _, _, out) in enumerate(cases):
+            r0 = int(ro[k])
+            for i in range(out.shape[0]):
+                cols = ci[rp[r0 + i]:rp[r0 + i + 1]] - r0
+                exp = np.flatnonzero(out[i] | (np.arange(out.shape[0]) == i))          # GraphConv adds the self loop
+                assert np.array_equal(cols, exp), (n, i)
 
 
 def test_csr_stage_flags_a_query_longer_than_max_len():

@@ -8,7 +8,7 @@ import pytest
 
 import cmap_oracle as orc
 import gcn_oracle
-from conftest import gstr
+from conftest import GOLDEN, gstr
 from mDeepFRI import synthetic
 
 
@@ -79,6 +79,24 @@ def test_chain_cases_bit_exact(cmap_golden):
         assert np.array_equal(fused, out), n
         if n + "/out" in cmap_golden.files:
             assert np.array_equal(out, cmap_golden[n + "/out"]), n
+
+
+def test_chain_cases_at_other_thresholds_bit_exact():
+    """The same chain at (10 A, 2) -- the operating point of the released `..._ca_10.0_...` GCN files -- (4, 0), (8, 5), (10, 0),
+    (7.5, 1): goldens made by the compiled reference (tests/golden/make_thr_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, "cmap_thr_golden.npz"))
+    names = [str(n) for n in z["index"]]
+    assert len(names) == 20
+    for n in names:
+        coords, q, t = z[n + "/coords"], gstr(z[n + "/q"]), gstr(z[n + "/t"])
+        thr, gen = float(z[n + "/thr"]), int(z[n + "/gen"])
+        sparse = orc.calculate_contact_map(coords, thr, mode="sparse")
+        assert sparse.shape[0] == int(z[n + "/nnz_target"]) and sha(sparse) == gstr(z[n + "/sha_sparse"]), n
+        out = orc.align_contact_map(q, t, sparse, gen)
+        assert sha(out) == gstr(z[n + "/sha_out"]), n
+        assert np.array_equal(orc.build_align_contact_map(coords, q, t, thr, gen), out), n
+        if n + "/out_bits" in z.files:
+            assert np.array_equal(np.packbits(out.astype(np.uint8), axis=1), z[n + "/out_bits"]), n
 
 
 def test_oracle_against_live_reference_when_present():
