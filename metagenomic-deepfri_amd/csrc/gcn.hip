@@ -551,32 +551,62 @@ __global__ __launch_bounds__(256) void k_gemm_f32_small(const float *__restrict_
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     const int nkg = K >> 3;                     // k-groups of 8 (host-checked: K % 32 == 0, so nkg % 4 == 0)
-    float4 a[4], b[4], an[4], bn[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        a[u] = *reinterpret_cast<const float4 *>(pa + u * 8);
-        b[u] = *reinterpret_cast<const float4 *>(pb + u * 8);
+    // Operands are fetched FOUR blocks of four k-groups ahead through a ring of four register buffers (an L2 round trip under load
+    // is 1-2 us, a block of 16 MFMAs 0.4 us: with one block ahead the chain waited on every block -- 48 us for a 512 x 512 x 512
+    // layer whose MFMA chain is 7 us).  Ordinary loads, so that hipcc keeps counting them (vmcnt(24) in front of each block) and
+    // never copies a register whose data has not landed; the empty asm with a memory clobber behind each group of loads keeps the
+    // compiler from sinking them down to their use (which it does for `const __restrict__` data, turning the ring into no
+    // prefetch at all).  Inline-asm loads with hand-counted waits were tried and are unsafe: the register allocator may copy an
+    // asm "output" before its data has arrived.
+    const int nblk = nkg >> 2;
+#define MDF_LOAD_BLK(BA, BB, blk_)                                                      \
+    {                                                                                   \
+        const int kb_ = min((blk_), nblk - 1) * 4;   /* past the end: re-read the last block (harmless) */ \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                   \
+        {                                                                               \
+            BA[u] = *reinterpret_cast<const float4 *>(pa + (size_t)(kb_ + u) * 8);      \
+            BB[u] = *reinterpret_cast<const float4 *>(pb + (size_t)(kb_ + u) * 8);      \
+        }                                                                               \
+        asm volatile("" ::: "memory");                                                  \
     }
-    for (int kg = 0; kg < nkg; kg += 4) {
-        const int kn = min(kg + 4, nkg - 4);    // the last iteration re-reads its own block (harmless)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            an[u] = *reinterpret_cast<const float4 *>(pa + (size_t)(kn + u) * 8);
-            bn[u] = *reinterpret_cast<const float4 *>(pb + (size_t)(kn + u) * 8);
+#define MDF_MFMA_BLK(BA, BB)                                                            \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u)                                       \
+    {                                                                                   \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(BA[u].x, BB[u].x, acc, 0, 0, 0);     \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(BA[u].y, BB[u].y, acc, 0, 0, 0);     \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(BA[u].z, BB[u].z, acc, 0, 0, 0);     \
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(BA[u].w, BB[u].w, acc, 0, 0, 0);     \
+    }
+    float4 a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
+    if ((nblk & 3) == 0) {   // K a multiple of 128 (every layer but the K = 32 one): four unconditional phases per round
+        MDF_LOAD_BLK(a0, b0, 0)
+        MDF_LOAD_BLK(a1, b1, 1)
+        MDF_LOAD_BLK(a2, b2, 2)
+        MDF_LOAD_BLK(a3, b3, 3)
+        for (int blk = 0; blk < nblk; blk += 4) {
+            MDF_MFMA_BLK(a0, b0)
+            MDF_LOAD_BLK(a0, b0, blk + 4)
+            MDF_MFMA_BLK(a1, b1)
+            MDF_LOAD_BLK(a1, b1, blk + 5)
+            MDF_MFMA_BLK(a2, b2)
+            MDF_LOAD_BLK(a2, b2, blk + 6)
+            MDF_MFMA_BLK(a3, b3)
+            MDF_LOAD_BLK(a3, b3, blk + 7)
         }
+    } else {                 // short K: one block ahead
+        MDF_LOAD_BLK(a0, b0, 0)
+        for (int blk = 0; blk < nblk; ++blk) {
+            MDF_LOAD_BLK(a1, b1, blk + 1)
+            MDF_MFMA_BLK(a0, b0)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a[u] = an[u];
-            b[u] = bn[u];
+            for (int u = 0; u < 4; ++u) {
+                a0[u] = a1[u];
+                b0[u] = b1[u];
+            }
         }
     }
+#undef MDF_LOAD_BLK
+#undef MDF_MFMA_BLK
     // epilogue: the arithmetic of gemm_epilogue<EPI> on one 32 x 32 MFMA tile (lane l, register r -> col l&31, row (r&3)+8*(r>>2)+4*(l>>5))
     const int lcol = lane & 31, lrow = 4 * (lane >> 5);
     const int rbase = mt * 32, col = nt * 32 + lcol;
@@ -621,6 +651,60 @@ __global__ __launch_bounds__(256) void k_gemm_f32_small(const float *__restrict_
                     const float e0 = expf(z - mx), e1 = expf(zo - mx);
                     C[(size_t)row * ldc + (col >> 1)] = e0 / (e0 + e1);
                 }
+            }
+        }
+    }
+}
+
+// ---- the GO head for a handful of pooled vectors (M <= 8: one protein through the per-call API, a tiny batch) ----------------
+// A 32 x 32 MFMA tile of k_gemm_f32_small is one wave walking K/2 DEPENDENT matrix instructions (64 cycles each): 1 x 1536 x 1024
+// takes 75 us on 32 waves however little data it touches.  Here a LANE owns an output column and runs the same accumulation as a
+// scalar FMA chain: v_mfma_f32_32x32x2_f32 is, per output element, fma(a[k+4], b[k+4], fma(a[k], b[k], c)), so the chain
+// (k, k+4), (k+1, k+5), ... in ascending k-group order reproduces k_gemm_f32 / k_gemm_f32_small BIT FOR BIT (asserted on the
+// GPU: a protein scores the same alone and inside a batch).  The row of A is wave-uniform (scalar loads), a lane streams its own
+// row of Bt ([N][K], K contiguous) as float4 loads, eight k-groups in flight.
+template <int EPI>
+__global__ __launch_bounds__(64) void k_gemv_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M, int N, int K,
+                                                 float *__restrict__ C, int ldc, const float *__restrict__ bias, float *__restrict__ logits,
+                                                 int n_real)
+{
+    const int lane = threadIdx.x, n = blockIdx.x * 64 + lane, m = blockIdx.y;
+    const float4 *pa = reinterpret_cast<const float4 *>(A + (size_t)m * lda);
+    const float4 *pb = reinterpret_cast<const float4 *>(Bt + (size_t)n * ldb);
+    float acc = 0.0f;
+    const int nkg = K >> 3;   // k-groups of 8; K % 32 == 0 (host-checked), so nkg % 4 == 0
+    for (int kg = 0; kg < nkg; kg += 4) {
+        float4 a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = pa[kg * 2 + u];
+            b[u] = pb[kg * 2 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {   // k-group kg + u: (k, k+4) pairs in ascending k, as the MFMA kernels feed them
+            const float4 a0 = a[2 * u], a1 = a[2 * u + 1], b0 = b[2 * u], b1 = b[2 * u + 1];
+            acc = __builtin_fmaf(a0.x, b0.x, acc);
+            acc = __builtin_fmaf(a1.x, b1.x, acc);
+            acc = __builtin_fmaf(a0.y, b0.y, acc);
+            acc = __builtin_fmaf(a1.y, b1.y, acc);
+            acc = __builtin_fmaf(a0.z, b0.z, acc);
+            acc = __builtin_fmaf(a1.z, b1.z, acc);
+            acc = __builtin_fmaf(a0.w, b0.w, acc);
+            acc = __builtin_fmaf(a1.w, b1.w, acc);
+        }
+    }
+    const float bv = bias[n];
+    if (EPI == EPI_BIAS_RELU) {
+        C[(size_t)m * ldc + n] = fmaxf(acc + bv, 0.0f);
+    } else {   // EPI_BIAS_SOFTMAX2: columns (2t, 2t+1) are the two channels of term t; keep channel 0
+        const float z = acc + bv;
+        const float zo = __shfl_xor(z, 1, 64);
+        if (n < n_real) {
+            if (logits) logits[(size_t)m * n_real + n] = z;
+            if ((n & 1) == 0) {
+                const float mx = fmaxf(z, zo);
+                const float e0 = expf(z - mx), e1 = expf(zo - mx);
+                C[(size_t)m * ldc + (n >> 1)] = e0 / (e0 + e1);
             }
         }
     }
@@ -991,6 +1075,15 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     MDF_REQUIRE((size_t)std::max(M, 1) * (size_t)lda * 4 < ((size_t)1 << 32) && (size_t)N * (size_t)ldb * 4 < ((size_t)1 << 32),
                 "gemm: operand larger than 4 GiB (M=%d lda=%d N=%d ldb=%d); split the batch", M, lda, N, ldb);
     if (int rc = set_gemm_attr_once()) return rc;
+    if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_SOFTMAX2) {
+        // a handful of pooled vectors through the GO head: one lane per output column, bit-identical FMA chain (k_gemv_f32)
+        static const int gemv_max = getenv("MDFRI_GEMV_MAX_M") ? atoi(getenv("MDFRI_GEMV_MAX_M")) : 8;   // developer knob: 0 = never
+        if (M <= gemv_max) {
+            hipLaunchKernelGGL(k_gemv_f32<EPI>, dim3(N / 64, M), dim3(64), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias, logits, n_real);
+            MDF_HIP(hipGetLastError());
+            return MDF_OK;
+        }
+    }
     const int MT = (M + BM - 1) / BM, NT = N / BN;
     const bool plain = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
     if constexpr (EPI != EPI_LSTM_TAB && EPI != EPI_LSTM_BIAS) {
