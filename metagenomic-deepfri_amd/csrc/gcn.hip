@@ -1087,9 +1087,11 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     const int MT = (M + BM - 1) / BM, NT = N / BN;
     const bool plain = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
     if constexpr (EPI != EPI_LSTM_TAB && EPI != EPI_LSTM_BIAS) {
-        // small problems (fewer 256 x 256 tiles than a quarter of the CUs): one wave per 32 x 32 tile, bit-identical results
+        // small problems (fewer 256 x 256 tiles than 3/8 of the CUs -- measured crossover with the four-block prefetch ring: 8 192
+        // rows x 512 columns = 64 tiles 0.91 vs 1.17 ms per 3-head forward, 16 384 rows = 128 tiles 1.49 vs 1.28 ms): one wave per 32 x 32
+        // tile, bit-identical results
         static const int small_env = getenv("MDFRI_GEMM_SMALL") ? atoi(getenv("MDFRI_GEMM_SMALL")) : -1;   // developer knob: 0 never, 1 always
-        const bool small = small_env >= 0 ? small_env != 0 : MT * NT * 4 < gemm_resident_blocks();
+        const bool small = small_env >= 0 ? small_env != 0 : MT * NT * 8 < 3 * gemm_resident_blocks();
         if (small) {
             const int tiles = ((M + 31) / 32) * (N / 32);
             hipLaunchKernelGGL(k_gemm_f32_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias, pool_partial, ldp,
