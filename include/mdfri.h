@@ -119,6 +119,11 @@ typedef struct {
     int32_t lm_dim;       /* width of the language-model features (512) */
     const float *W_lm;    /* (lm_dim, embed) */
     const float *b_lm;    /* (embed) */
+    /* Activation of the embedding: 0 = relu (the topology SURVEY.md section 3.3 states), 1 = none.  Upstream DeepFRI's model
+     * builder is not in the reference tree and no released file exists offline; whether the no-language-model branch applies an
+     * activation to `AA_embedding` is exactly the kind of detail only a released file settles, so it is DATA here: the ONNX reader
+     * sets it from the graph (is there a Relu between the embedding and the first GraphConv?). */
+    int32_t embed_linear;
 } mdf_gcn_weights;
 
 /* Upload weights to `device` and pre-pack them (transposed GEMM operands, folded embedding table). */

@@ -39,6 +39,7 @@ struct mdf_model {
     float *bout = nullptr;        // (n_out_pad)
     // language-model branch (lm_dim > 0): X0 = relu(lm_h . W_lm + b_lm + W_aa[letter]); layer 1 is then not foldable
     int lm_dim = 0;
+    bool embed_linear = false;    // the embedding has no activation (mdf_gcn_weights.embed_linear)
     float *Wlm_t = nullptr;       // (embed, lm_dim)  W_lm^T
     float *T0 = nullptr;          // (32, embed)      rows < 26: W_aa[a] + b_lm, rows 26..31 zero
     float *Wgc1_t = nullptr;      // (gc0, embed)     W_gc1^T
@@ -73,6 +74,7 @@ struct GemmAux {
     int ksplit = 0;
     const float *table = nullptr;      // EPI_LSTM_TAB / EPI_EMBED: (32, N) additive rows, selected per output row by letters[row]
     const uint8_t *letters = nullptr;  // (M) residue indices 0..25 (anything larger reads the zero rows 26..31)
+    float floor = 0.0f;                // EPI_EMBED: X0 = max(acc + table, floor): 0 = relu, -FLT_MAX = no activation
     float *cstate = nullptr;           // EPI_LSTM_*: (M, N/4) cell state, updated in place
 };
 
@@ -205,7 +207,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n
                 for (int r = 0; r < 16; ++r) tv[r] = aux.table[lt[r] + col];
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    C[(size_t)(rbase + (r & 3) + 8 * (r >> 2) + lrow) * ldc + col] = fmaxf(acc[tm][tn][r] + tv[r], 0.0f);
+                    C[(size_t)(rbase + (r & 3) + 8 * (r >> 2) + lrow) * ldc + col] = fmaxf(acc[tm][tn][r] + tv[r], aux.floor);
             }
         }
         return;
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_small(const float *__restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
-            if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[r] + aux.table[lt[r] + col], 0.0f);
+            if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[r] + aux.table[lt[r] + col], aux.floor);
         }
     } else if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_L1_STORE || EPI == EPI_L1) {
         float sum = 0.0f;
@@ -1261,15 +1263,16 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
     m->T = w->n_terms;
     m->feat = feat;
     m->n_out_pad = (2 * w->n_terms + BN - 1) / BN * BN;  // output layer padded to whole GEMM column tiles
+    m->embed_linear = w->embed_linear != 0;
     int rc = MDF_OK;
     {
-        // T1 = relu(W_aa) @ W_gc1 in double, rounded once to f32
+        // T1 = act(W_aa) @ W_gc1 in double, rounded once to f32 (act = relu, or nothing when embed_linear)
         const int E = w->embed, C0 = w->gc_dims[0];
         std::vector<double> acc((size_t)26 * C0, 0.0);
         for (int a = 0; a < 26; ++a)
             for (int e = 0; e < E; ++e) {
                 const double x = w->W_aa[(size_t)a * E + e];
-                if (x <= 0.0) continue;
+                if (x <= 0.0 && !m->embed_linear) continue;
                 const float *wr = w->W_gc[0] + (size_t)e * C0;
                 double *ar = acc.data() + (size_t)a * C0;
                 for (int c = 0; c < C0; ++c) ar[c] += x * (double)wr[c];
@@ -1571,6 +1574,7 @@ int mdf_gcn_embed_lm_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h
         GemmAux a;
         a.table = m->T0;
         a.letters = seq_idx;
+        a.floor = m->embed_linear ? -3.402823466e38f : 0.0f;
         if (int rc = launch_gemm<EPI_EMBED>(lm_h, m->lm_dim, m->Wlm_t, m->lm_dim, Ri, E, m->lm_dim, X0, E, nullptr, nullptr, 0, nullptr, E, st, a))
             return rc;
     }
@@ -1668,6 +1672,16 @@ int mdf_model_load(const char *path, int device, mdf_model **out)
     w.W_out = reinterpret_cast<const float *>(buf.data() + e.offset);
     if (!find("b_out", e) || (int)e.dims[0] != 2 * w.n_terms) return fail(MDF_EIO, "model_load: b_out missing or wrong shape");
     w.b_out = reinterpret_cast<const float *>(buf.data() + e.offset);
+    if (find("embed_linear", e)) w.embed_linear = *reinterpret_cast<const float *>(buf.data() + e.offset) != 0.0f;
+    std::vector<float> waa_biased;   // a bias on AA_embedding: one-hot rows select W_aa[a] + b_aa (mDeepFRI/predict.py does the same fold)
+    if (find("b_aa", e)) {
+        if (e.ndim != 1 || (int)e.dims[0] != w.embed) return fail(MDF_EIO, "model_load: b_aa has the wrong shape");
+        const float *ba = reinterpret_cast<const float *>(buf.data() + e.offset);
+        waa_biased.assign(w.W_aa, w.W_aa + (size_t)26 * w.embed);
+        for (int a = 0; a < 26; ++a)
+            for (int c = 0; c < w.embed; ++c) waa_biased[(size_t)a * w.embed + c] += ba[c];
+        w.W_aa = waa_biased.data();
+    }
     if (find("W_lm", e)) {  // language-model branch of the released models (optional)
         if (e.ndim != 2 || (int)e.dims[1] != w.embed) return fail(MDF_EIO, "model_load: W_lm has the wrong shape");
         w.lm_dim = (int32_t)e.dims[0];

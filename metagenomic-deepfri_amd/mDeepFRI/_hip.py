@@ -33,6 +33,7 @@ class GcnWeights(ctypes.Structure):
         ("W_aa", POINTER(c_float)), ("W_gc", POINTER(c_float) * 3), ("W_fc", POINTER(c_float)),
         ("b_fc", POINTER(c_float)), ("W_out", POINTER(c_float)), ("b_out", POINTER(c_float)),
         ("lm_dim", c_int32), ("W_lm", POINTER(c_float)), ("b_lm", POINTER(c_float)),
+        ("embed_linear", c_int32),
     ]
 
 

@@ -358,13 +358,33 @@ def extract_gcn_weights(g: Graph) -> dict:
                 return W, b
         fail(f"no layer matches {what}")
 
-    w["W_aa"], b = take(lambda W, b: W.shape[0] == 26 and b is None, "AA_embedding (26, E) without bias")
+    # AA_embedding: the first constant (26, E) product, with or without a bias
+    aa_i = next((i for i, (W, b_, _) in enumerate(dense) if W.shape[0] == 26), None)
+    if aa_i is None:
+        fail("no layer matches AA_embedding (26, E)")
+    producers = {o: nd for nd in g.nodes for o in nd.outputs}
+    src = dense[aa_i][2].inputs[0]
+    while src in producers and producers[src].op_type in _PASS_THROUGH:
+        src = producers[src].inputs[0]
+    no_embedding = src in producers and producers[src].op_type == "MatMul" and all(i not in const for i in producers[src].inputs)
+    if no_embedding:
+        # the (26, C) product sits BEHIND a batch product with the adjacency: it is GraphConv 1 itself and the graph has no
+        # embedding layer (the one-hot rows go straight into the stack).  Expressed in the topology the kernels implement as an
+        # identity embedding without activation: onehot . I = onehot, exactly.
+        w["W_aa"], aa_node = np.eye(26, dtype=np.float32), None
+        w["embed_linear"] = np.ones(1, np.float32)
+    else:
+        used.add(aa_i)
+        w["W_aa"], b_aa, aa_node = dense[aa_i]
+        if b_aa is not None:
+            w["b_aa"] = b_aa
     E = w["W_aa"].shape[1]
     if lstm:
         H = w["lm_U2"].shape[0]
         if w["lm_W1"].shape[0] != 26 or w["lm_W2"].shape[0] != w["lm_U1"].shape[0]:
             fail(f"LSTM shapes {w['lm_W1'].shape} {w['lm_W2'].shape} do not form a 26 -> H -> H stack")
-        w["W_lm"], w["b_lm"] = take(lambda W, b: W.shape == (H, E) and b is not None, f"LM_embedding ({H}, {E}) with bias")
+        w["W_lm"], b_lm = take(lambda W, b: W.shape == (H, E), f"LM_embedding ({H}, {E})")
+        w["b_lm"] = b_lm if b_lm is not None else np.zeros(E, np.float32)      # upstream puts the bias on one of the two embeddings
     prev, k = E, 0
     while k < 3:
         cand = [i for i, (W, b, _) in enumerate(dense) if i not in used and b is None and W.shape[0] == prev]
@@ -384,6 +404,28 @@ def extract_gcn_weights(g: Graph) -> dict:
     left = [shapes[i] for i in range(len(dense)) if i not in used]
     if left:
         fail(f"unrecognised extra layers {left} (more than one fully connected layer is not supported)")
+    # activation of the embedding: is there a Relu on the way from the AA_embedding product to the first batch product with the
+    # adjacency (a MatMul whose other operand is not a constant)?  No Relu -> the `embed_linear` variant.
+    consumers = {}
+    for nd in g.nodes:
+        for i in nd.inputs:
+            consumers.setdefault(i, []).append(nd)
+    frontier, seen, relu = (list(aa_node.outputs) if aa_node is not None else []), set(), aa_node is None and False
+    while frontier and not relu:
+        name = frontier.pop()
+        for nd in consumers.get(name, []):
+            if id(nd) in seen:
+                continue
+            seen.add(id(nd))
+            if nd.op_type == "Relu":
+                relu = True
+                break
+            if nd.op_type == "MatMul" and all(i not in const for i in nd.inputs):
+                continue                                   # reached GraphConv's batch_dot(Ahat, X): stop along this path
+            if nd.op_type in ("Add", "Identity", "Cast", "Reshape", "Squeeze", "Unsqueeze", "Transpose", "Dropout"):
+                frontier += nd.outputs
+    if aa_node is not None and not relu:
+        w["embed_linear"] = np.ones(1, np.float32)
     return {k_: np.ascontiguousarray(v, dtype=np.float32) for k_, v in w.items()}
 
 

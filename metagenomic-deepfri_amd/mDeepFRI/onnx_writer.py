@@ -159,7 +159,12 @@ def deepfri_gcn_model(w: dict, raw=True, use_gemm_head=False) -> bytes:
     AA/LM embeddings, GraphConv layers with adjacency normalisation, sum pooling, dense head, pair softmax)."""
     b = GraphBuilder()
     cmap, seq = b.input("cmap", [1, "L", "L"]), b.input("seq", [1, "L", 26])   # the two feeds of predict.pyx:82-90
-    x_aa = b.node("MatMul", [seq, b.const(w["W_aa"], "AA_embedding/kernel", raw)])
+    if "W_aa" not in w:      # topology variant: no embedding layer at all, GraphConv 1 takes the one-hot rows (W_gc1 is (26, C))
+        x_aa = seq
+    else:
+        x_aa = b.node("MatMul", [seq, b.const(w["W_aa"], "AA_embedding/kernel", raw)])
+    if "b_aa" in w:
+        x_aa = b.node("Add", [x_aa, b.const(w["b_aa"], "AA_embedding/bias", raw)])
     if "lm_W1" in w:
         h = b.node("Transpose", [seq], perm=[1, 0, 2])
         for k in (1, 2):
@@ -170,7 +175,8 @@ def deepfri_gcn_model(w: dict, raw=True, use_gemm_head=False) -> bytes:
         h = b.node("Transpose", [h], perm=[1, 0, 2])
         x_lm = b.node("Add", [b.node("MatMul", [h, b.const(w["W_lm"], "LM_embedding/kernel", raw)]), b.const(w["b_lm"], "LM_embedding/bias", raw)])
         x_aa = b.node("Add", [x_lm, x_aa])
-    x = b.node("Relu", [x_aa])
+    linear = "W_aa" not in w or ("embed_linear" in w and float(np.asarray(w["embed_linear"]).reshape(-1)[0]) != 0.0)
+    x = x_aa if linear else b.node("Relu", [x_aa])
     # adjacency normalisation of GraphConv, arithmetically complete (constants that are NOT weights -- eps, one, axes -- must be
     # ignored by the reader):  A' = A - A*I + I;  d = 1 / (sqrt(rowsum A') + 1e-6);  Ahat = diag(d) A' diag(d)
     a2 = b.node("Squeeze", [cmap, b.const(np.array([0], np.int64), "axes", raw)])                   # (L, L): EyeLike wants rank 2

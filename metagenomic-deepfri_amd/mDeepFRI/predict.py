@@ -103,7 +103,10 @@ def create_model_handle(weights: dict, device: int = 0):
     """weights dict (see mDeepFRI.weights) -> (mdf_model* as c_void_p, topology)."""
     topo = _weights.validate(weights)
     w = {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weights.items()}
+    if "b_aa" in w:   # a bias on AA_embedding: the input rows are one-hot, so onehot.W_aa + b_aa IS the row W_aa[a] + b_aa (one rounding, as in the graph)
+        w["W_aa"] = np.ascontiguousarray(w["W_aa"] + w["b_aa"][None, :], dtype=np.float32)
     s = _hip.GcnWeights()
+    s.embed_linear = int(topo["embed_linear"])
     s.embed, s.n_gc, s.fc_dim, s.n_terms = topo["embed"], len(topo["gc_dims"]), topo["fc_dim"], topo["n_terms"]
     fp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))  # noqa: E731
     for k, c in enumerate(topo["gc_dims"]):

@@ -80,7 +80,8 @@ def glorot_uniform(rng: np.random.Generator, fan_in: int, fan_out: int) -> np.nd
 
 
 def glorot_gcn_weights(seed: int = 0, n_terms: int = 489, embed: int = 1024, gc_dims=(512, 512, 512),
-                       fc_dim: int = 1024, fc_gain: float = 0.1, sparse_scores: bool = False) -> dict:
+                       fc_dim: int = 1024, fc_gain: float = 0.1, sparse_scores: bool = False, embed_linear: bool = False,
+                       embed_bias: bool = False) -> dict:
     """Random-init DeepFRI GCN weights (fp32).  Keys are the ones mDeepFRI.weights reads and writes.
 
     `fc_gain` scales the Glorot draw of W_fc: the sum-pooled features grow linearly with the protein
@@ -105,6 +106,10 @@ def glorot_gcn_weights(seed: int = 0, n_terms: int = 489, embed: int = 1024, gc_
     w["b_fc"] = rng.uniform(-0.05, 0.05, size=(fc_dim,)).astype(np.float32)
     w["W_out"] = glorot_uniform(rng, fc_dim, 2 * n_terms)
     w["b_out"] = rng.uniform(-0.05, 0.05, size=(2 * n_terms,)).astype(np.float32)
+    if embed_linear:   # topology variant: AA_embedding without activation (weights.validate: "embed_linear")
+        w["embed_linear"] = np.ones(1, dtype=np.float32)
+    if embed_bias:     # topology variant: AA_embedding with a bias
+        w["b_aa"] = np.random.default_rng([int(seed), 0xB1]).uniform(-0.05, 0.05, size=(embed,)).astype(np.float32)
     if sparse_scores:
         prior = np.random.default_rng([int(seed), 0x5A]).normal(9.0, 3.0, size=n_terms).astype(np.float32)
         w["b_out"][1::2] += prior

@@ -147,8 +147,12 @@ def validate(weights: dict) -> dict:
         for k, shp in want.items():
             if tuple(w[k].shape) != shp:
                 raise ValueError(f"weights: {k} has shape {tuple(w[k].shape)}, expected {shp}")
+    if "b_aa" in w and tuple(w["b_aa"].shape) != (int(w["W_aa"].shape[1]),):
+        raise ValueError("weights: b_aa must be (E,)")
+    # optional 1-element tensor: the embedding has NO activation (a topology detail the model file decides, see include/mdfri.h)
+    embed_linear = bool("embed_linear" in w and float(np.asarray(w["embed_linear"]).reshape(-1)[0]) != 0.0)
     return {"embed": int(w["W_aa"].shape[1]), "gc_dims": gc, "fc_dim": int(w["W_fc"].shape[1]),
-            "n_terms": int(w["W_out"].shape[1] // 2), "lm_dim": lm_dim}
+            "n_terms": int(w["W_out"].shape[1] // 2), "lm_dim": lm_dim, "embed_linear": embed_linear}
 
 
 def resolve_model_path(model_path: str) -> str:

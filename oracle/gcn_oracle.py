@@ -20,6 +20,8 @@ Scope follows BASELINE.json north_star: one-hot embed -> 3x GraphConv -> sum poo
 
 Op order (fp32 unless dtype=float64 is requested for tolerance studies):
     X0   = relu(S @ W_aa)                                   Dense(use_bias=False) + Activation('relu')
+           (topology variants a released file may turn out to have, carried as DATA: `embed_linear` -- no activation;
+            `b_aa` -- a bias on AA_embedding; mDeepFRI.onnx_reader sets them from the graph)
     A'   = A - diag(diag(A)) + I ;  d = 1/(1e-6 + sqrt(rowsum(A')))
     Ahat = (diag(d) @ A') @ diag(d)                         GraphConv._normalize
     H_k  = elu((Ahat @ H_{k-1}) @ W_k)      k=1..3          batch_dot then dot, use_bias=False, elu
@@ -64,10 +66,14 @@ def gcn_forward(weights: dict, seq: str, cmap: np.ndarray, dtype=np.float32, ret
     """weights: W_aa (26,E), W_gc1 (E,C1), W_gc2 (C1,C2), W_gc3 (C2,C3), W_fc (C1+C2+C3,F), b_fc (F,),
     W_out (F,2T), b_out (2T,).  cmap: (L,L) any numeric dtype (cast to f32 first, predict.pyx:88)."""
     dt = np.dtype(dtype)
-    w = {k: np.asarray(v, dtype=dt) for k, v in weights.items()}
+    w = {k: np.asarray(v, dtype=dt) for k, v in weights.items() if not isinstance(v, str)}
     S = onehot(seq, dt)
     A = np.asarray(cmap).reshape(len(seq), len(seq)).astype(np.float32).astype(dt)
-    X = np.maximum(S @ w["W_aa"], 0)
+    X = S @ w["W_aa"]
+    if "b_aa" in w:                                                        # topology variant: AA_embedding with a bias
+        X = X + w["b_aa"]
+    if not ("embed_linear" in w and float(np.asarray(w["embed_linear"]).reshape(-1)[0]) != 0.0):
+        X = np.maximum(X, 0)                                               # Activation('relu'); absent in the `embed_linear` variant
     A_hat = normalize_adjacency(A)
     feats = []
     k = 1

@@ -69,7 +69,11 @@ def gcn_lm_forward(weights: dict, seq: str, cmap: np.ndarray, dtype=np.float32, 
     S = gcn_oracle.onehot(seq, dt)
     h2 = lm_forward(weights, seq, dt)
     A = np.asarray(cmap).reshape(len(seq), len(seq)).astype(np.float32).astype(dt)
-    X = np.maximum(S @ w["W_aa"] + (h2 @ w["W_lm"] + w["b_lm"]), 0)
+    X = S @ w["W_aa"] + (h2 @ w["W_lm"] + w["b_lm"])
+    if "b_aa" in w:
+        X = X + w["b_aa"]
+    if not ("embed_linear" in w and float(np.asarray(w["embed_linear"]).reshape(-1)[0]) != 0.0):
+        X = np.maximum(X, 0)
     A_hat = gcn_oracle.normalize_adjacency(A)
     feats = []
     k = 1

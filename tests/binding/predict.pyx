@@ -31,6 +31,7 @@ cdef extern from "mdfri.h":
         int32_t lm_dim
         const float *W_lm
         const float *b_lm
+        int32_t embed_linear
     ctypedef struct mdf_lm_weights:
         int32_t hidden
         const float *W1
@@ -156,6 +157,10 @@ cdef class Predictor(object):
             g.gc_dims[k] = topo["gc_dims"][k] if k < g.n_gc else 0
             g.W_gc[k] = _fp(a[f"W_gc{k + 1}"]) if k < g.n_gc else NULL
         g.W_aa, g.W_fc, g.b_fc, g.W_out, g.b_out = _fp(a["W_aa"]), _fp(a["W_fc"]), _fp(a["b_fc"]), _fp(a["W_out"]), _fp(a["b_out"])
+        if "b_aa" in a:    # one-hot rows: onehot.W_aa + b_aa is the row W_aa[letter] + b_aa
+            a["W_aa"] = np.ascontiguousarray(a["W_aa"] + a["b_aa"][None, :], dtype=np.float32)
+            g.W_aa = _fp(a["W_aa"])
+        g.embed_linear = 1 if topo["embed_linear"] else 0
         g.lm_dim = topo["lm_dim"]
         g.W_lm = _fp(a["W_lm"]) if g.lm_dim else NULL
         g.b_lm = _fp(a["b_lm"]) if g.lm_dim else NULL

@@ -104,7 +104,7 @@ def test_weight_container_round_trip(tmp_path):
     weights.save_mdfw(str(p), w)
     r = weights.load_mdfw(str(p))
     assert sorted(r) == sorted(w) and all(np.array_equal(r[k], w[k]) for k in w)
-    assert weights.validate(r) == {"embed": 64, "gc_dims": [256, 256, 256], "fc_dim": 128, "n_terms": 17, "lm_dim": 0}
+    assert weights.validate(r) == {"embed": 64, "gc_dims": [256, 256, 256], "fc_dim": 128, "n_terms": 17, "lm_dim": 0, "embed_linear": False}
     assert weights.resolve_model_path(str(tmp_path / "m.onnx")) == str(p)
     with pytest.raises(FileNotFoundError, match="no such model file"):
         weights.resolve_model_path(str(tmp_path / "other.onnx"))

@@ -191,6 +191,57 @@ def test_fused_batch_at_other_thresholds_and_generated_contacts(mf, threshold, g
     assert (n_syn > 0) == (gen > 0)
 
 
+@pytest.mark.parametrize("variant", ["embed_linear", "embed_bias", "linear_and_bias", "no_embedding"])
+def test_embedding_topology_variants_vs_oracle(variant, tmp_path):
+    """The embedding's activation / bias / existence is data the model file decides (include/mdfri.h `embed_linear`, weights `b_aa`,
+    identity embedding for a graph without one): per call, batched, through a .mdfw container loaded by the C loader, and through an
+    exported .onnx read back -- all vs the oracle, batch == per call bitwise."""
+    import ctypes
+    from mDeepFRI import _hip, onnx_writer, weights
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.predict import Predictor
+    kw = {"embed_linear": dict(embed_linear=True), "embed_bias": dict(embed_bias=True), "linear_and_bias": dict(embed_linear=True, embed_bias=True),
+          "no_embedding": {}}[variant]
+    w = synthetic.glorot_gcn_weights(seed=12, n_terms=57, **kw)
+    if variant == "no_embedding":
+        del w["W_aa"]
+        w["W_gc1"] = synthetic.glorot_uniform(np.random.default_rng(3), 26, 512)
+        path = tmp_path / "noembed_mf.onnx"
+        path.write_bytes(onnx_writer.deepfri_gcn_model(w))
+        pred = Predictor(str(path))                       # the reader expresses it as an identity embedding without activation
+        w = dict(w, W_aa=np.eye(26, dtype=np.float32), embed_linear=np.ones(1, np.float32))
+    else:
+        path = tmp_path / "variant_mf.onnx"
+        path.write_bytes(onnx_writer.deepfri_gcn_model(w))
+        pred = Predictor(str(path))
+        assert weights.validate(weights.load_weights(str(path)))["embed_linear"] == ("linear" in variant)
+    prots = synthetic.synthetic_proteins(seed=70, count=9, length=(15, 300), indel_rate=0.05)
+    out = HotPathEngine({"m": pred}, device=0, max_rows=1024).run_alignments(
+        PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots], [p["t_aln"] for p in prots], max_rows=1024))["m"]
+    for i, p in enumerate(prots):
+        cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
+        ref = gcn_oracle.gcn_forward(w, p["seq"], cm)
+        assert np.max(np.abs(out[i] - ref)) < TOL, (variant, i)
+        assert np.array_equal(out[i], pred.forward_pass(p["seq"], cm)), (variant, i)
+    # the flag matters: the default topology scores differently on the same tensors
+    plain = {k: v for k, v in w.items() if k not in ("embed_linear", "b_aa")}
+    cm0 = orc.build_align_contact_map(prots[0]["coords"], prots[0]["q_aln"], prots[0]["t_aln"], 6.0, 2)
+    if variant != "no_embedding":      # (an identity embedding is non-negative: relu changes nothing there)
+        assert np.max(np.abs(gcn_oracle.gcn_forward(plain, prots[0]["seq"], cm0) - out[0])) > 1e-5
+    # the C loader (mdf_model_load) reads the same container
+    weights.save_mdfw(str(tmp_path / "v.mdfw"), w)
+    h = ctypes.c_void_p()
+    _hip.check(_hip.lib().mdf_model_load(str(tmp_path / "v.mdfw").encode(), 0, ctypes.byref(h)))
+    try:
+        y = np.empty(57, dtype=np.float32)
+        bad = _hip.c_int64(-1)
+        seq = prots[0]["seq"].encode()
+        _hip.check(_hip.lib().mdf_gcn_forward_host(h, seq, len(seq), _hip.ptr(np.ascontiguousarray(cm0)), _hip.DT_I32, _hip.ptr(y), bad))
+        assert np.array_equal(y, out[0])
+    finally:
+        _hip.lib().mdf_model_free(h)
+
+
 @pytest.mark.parametrize("L", [1, 33, 128, 512, 1024])
 def test_bp_sized_head_vs_oracle(bp, L):
     """The biological-process head: T = 1 943 terms -> 3 886 output columns, padded to 4 096 inside the library (the widest GO head

@@ -114,6 +114,29 @@ def test_engine_scores_with_language_model_full_size():
             assert np.abs(out[m][p] - ref).max() < 1e-4, (m, p)
 
 
+def test_language_model_head_with_linear_embedding_and_aa_bias():
+    """Topology variants of the embedding in a head WITH the language model: no activation on the sum (`embed_linear`), bias on the
+    AA branch (`b_aa`) -- vs the oracle, per call and batched."""
+    import cmap_oracle
+    import lm_oracle
+    from mDeepFRI import synthetic
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.predict import Predictor
+    w = synthetic.glorot_gcn_weights(seed=31, n_terms=41, embed=256, gc_dims=(256, 256), fc_dim=256, embed_linear=True, embed_bias=True)
+    w.update(synthetic.glorot_lm_weights(seed=1000, hidden=64, embed=256))
+    pred = Predictor("synthetic", weights=w)
+    prot = synthetic.synthetic_proteins(seed=5, count=5, length=(20, 150), indel_rate=0.05)
+    out = HotPathEngine({"m": pred}, max_rows=256).run_alignments(
+        PackedProteins.pack([d["seq"] for d in prot], [d["coords"] for d in prot], [d["q_aln"] for d in prot], [d["t_aln"] for d in prot], max_rows=256))["m"]
+    for p, d in enumerate(prot):
+        A = cmap_oracle.build_align_contact_map(d["coords"], d["q_aln"], d["t_aln"], 6.0, 2)
+        ref = lm_oracle.gcn_lm_forward(w, d["seq"], A)
+        assert np.abs(out[p] - ref).max() < 1e-4, p
+        assert np.abs(pred.forward_pass(d["seq"], A) - ref).max() < 1e-4, p
+    plain = {k: v for k, v in w.items() if k not in ("embed_linear", "b_aa")}
+    assert np.abs(lm_oracle.gcn_lm_forward(plain, prot[0]["seq"], cmap_oracle.build_align_contact_map(prot[0]["coords"], prot[0]["q_aln"], prot[0]["t_aln"], 6.0, 2)) - out[0]).max() > 1e-5
+
+
 def test_mdfw_roundtrip_with_language_model(tmp_path):
     from mDeepFRI import weights as W
     from mDeepFRI.predict import Predictor

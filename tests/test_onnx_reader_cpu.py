@@ -152,3 +152,42 @@ def test_exported_cnn_graph_computes_what_the_oracle_states(conv2d_form, explici
     y = onnx_numpy_runtime.run(g, {"seq": _one_hot(seq).reshape(1, len(seq), 26)})[0][:, :, 0].reshape(-1)
     ref = cnn_oracle.cnn_forward(w, seq, dtype=np.float64) if "dtype" in cnn_oracle.cnn_forward.__code__.co_varnames else cnn_oracle.cnn_forward(w, seq)
     assert np.max(np.abs(y - ref)) < 1e-6
+
+
+@pytest.mark.parametrize("variant", ["embed_linear", "embed_bias", "linear_and_bias", "lm_linear", "no_embedding"])
+def test_embedding_topology_variants_are_read_from_the_graph(variant):
+    """What a released file's embedding really looks like (activation or not, bias or not, a layer at all or not) cannot be known
+    offline, so it is DATA: the reader decides from the graph, the weight dict carries `embed_linear` / `b_aa`, and the file's own
+    graph executed under ONNX semantics agrees with the oracle on the extracted tensors."""
+    import onnx_numpy_runtime as rt
+    import gcn_oracle
+    import lm_oracle
+    from mDeepFRI import onnx_reader, synthetic, weights
+    kw = {"embed_linear": dict(embed_linear=True), "embed_bias": dict(embed_bias=True), "linear_and_bias": dict(embed_linear=True, embed_bias=True),
+          "lm_linear": dict(embed_linear=True, embed_bias=True), "no_embedding": {}}[variant]
+    w = synthetic.glorot_gcn_weights(seed=8, n_terms=13, embed=256, gc_dims=(256, 256), fc_dim=256, **kw)
+    if variant == "lm_linear":
+        w.update(synthetic.glorot_lm_weights(seed=5, hidden=64, embed=256))
+    if variant == "no_embedding":
+        del w["W_aa"]
+        w["W_gc1"] = synthetic.glorot_uniform(np.random.default_rng(1), 26, 256)
+    g = onnx_reader.parse_model(onnx_writer.deepfri_gcn_model(w))
+    got = onnx_reader.extract_gcn_weights(g)
+    topo = weights.validate(got)
+    assert topo["embed_linear"] == (variant != "embed_bias")
+    assert ("b_aa" in got) == ("bias" in variant or variant == "lm_linear")
+    if variant == "no_embedding":
+        assert np.array_equal(got["W_aa"], np.eye(26, dtype=np.float32)) and got["W_gc1"].shape == (26, 256) and topo["embed"] == 26
+    else:
+        for k in w:
+            np.testing.assert_array_equal(got[k], w[k], err_msg=k)
+    rng = np.random.default_rng(2)
+    seq = synthetic.random_sequence(rng, 50)
+    cm = rng.integers(0, 2, size=(50, 50)).astype(np.int32)
+    y_graph = rt.run(g, {"cmap": cm.reshape(1, 50, 50).astype(np.float32), "seq": gcn_oracle.onehot(seq).reshape(1, 50, 26)})[0][:, :, 0].reshape(-1)
+    fwd = lm_oracle.gcn_lm_forward if variant == "lm_linear" else gcn_oracle.gcn_forward
+    assert np.max(np.abs(fwd(got, seq, cm, dtype=np.float64) - y_graph)) < 1e-9
+    if variant == "embed_linear":   # and the default graph, executed, differs from it: the flag is not a no-op
+        w2 = dict(w)
+        del w2["embed_linear"]
+        assert np.max(np.abs(gcn_oracle.gcn_forward(w2, seq, cm, dtype=np.float64) - y_graph)) > 1e-6
