@@ -30,3 +30,53 @@ def test_pipeline_example_matches_the_oracle_chain():
         gq, gt = insert_gaps(qseqs[i], tseq, ops)
         cm = cmap_oracle.build_align_contact_map(db_xyz[key], gq, gt, 6.0, 2)
         assert np.max(np.abs(s_mf[i] - gcn_oracle.gcn_forward(weights["mf"], qseqs[i], cm))) < 1e-4, i
+
+
+def test_reference_query_fixture_through_aligner_cnn_and_gcn():
+    """tests/golden/small_query.faa is the query FASTA the reference's own regression test feeds the pipeline
+    (mDeepFRI/tests/data/small_query.faa, tests/test_pipeline_regression.py:14-23; a data file, three real proteins of 298-350
+    residues and a 120-residue selenocysteine record that the reference drops before alignment, mmseqs.py:645-665): real residue composition through the stages next to the path -- every query against the three as a database
+    (best hit = itself, all 'M'), the sequence-only CNN and, on a synthetic C-alpha trace per target, the fused contact map + GCN --
+    each against its oracle."""
+    import cmap_oracle
+    import cnn_oracle
+    import gcn_oracle
+    import nw_oracle
+    from conftest import GOLDEN
+    from mDeepFRI import synthetic
+    from mDeepFRI.alignment import ScoringMatrix, align_queries_arrays
+    from mDeepFRI.batch import HotPathEngine, PackedProteins, SequenceEngine
+    from mDeepFRI.predict import Predictor
+    names, seqs = [], []
+    for line in open(os.path.join(GOLDEN, "small_query.faa")):
+        if line.startswith(">"):
+            names.append(line[1:].strip())
+            seqs.append("")
+        else:
+            seqs[-1] += line.strip()
+    assert [len(s) for s in seqs] == [298, 350, 315, 120] and "U" in seqs[3]
+    allseqs, names, seqs = seqs, names[:3], seqs[:3]
+    sm = ScoringMatrix.simple()
+    db = dict(zip(names, seqs))
+    batch = align_queries_arrays(names, seqs, [db] * 3, scoring_matrix=sm)
+    assert list(batch.target_keys) == names
+    for i, s in enumerate(seqs):
+        lo, hi = int(batch.aln_off[i]), int(batch.aln_off[i + 1])
+        assert bytes(batch.q_aln[lo:hi]).decode() == s == bytes(batch.t_aln[lo:hi]).decode()
+        assert int(batch.score[i]) == nw_oracle.nw_score(s, s, sm.matrix, sm.alphabet) == 5 * len(s)
+        assert bytes(batch.ops[lo:hi]).decode() == "M" * len(s) and float(batch.identity[i]) == 1.0
+    with pytest.raises(ValueError, match="'U' is not in the scoring matrix alphabet"):     # PyOpal refuses it the same way: encode error
+        align_queries_arrays(["s"], [allseqs[3]], [db], scoring_matrix=sm)
+    wc = synthetic.glorot_cnn_weights(seed=3, n_terms=40)
+    y = SequenceEngine({"c": Predictor("synthetic-cnn", weights=wc)}).run(allseqs)["c"]
+    for i, s in enumerate(allseqs):
+        assert np.max(np.abs(y[i] - cnn_oracle.cnn_forward(wc, s))) < 1e-4
+    rng = np.random.default_rng(0)
+    coords = [synthetic.random_walk_coords(rng, len(s)) for s in seqs]
+    wg = synthetic.glorot_gcn_weights(seed=0, n_terms=50)
+    pk, kept = PackedProteins.from_aligned_batch(batch, coords)
+    assert kept == [0, 1, 2]
+    out = HotPathEngine({"g": Predictor("synthetic", weights=wg)}).run_alignments(pk)["g"]
+    for i, s in enumerate(seqs):
+        cm = cmap_oracle.build_align_contact_map(coords[i], s, s, 6.0, 2)
+        assert np.max(np.abs(out[i] - gcn_oracle.gcn_forward(wg, s, cm))) < 1e-4
