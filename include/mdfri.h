@@ -422,6 +422,18 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
                           float *kept_scores, int64_t capacity, int32_t *status, void *workspace, size_t workspace_bytes,
                           void *stream);
 
+/* The text of results.tsv for one GO head from the filter's arrays (host buffers), one line per kept (protein, term) as
+ * mDeepFRI/pipeline.py:713-716 / 745-748 writes it:
+ *     query_id \t <middle> \t term \t f"{score:.4f}" \t go_name \t <tail> \n
+ * middle = "net_type\tmode label" (NUL-terminated); qid / term / name: concatenated strings with (count + 1) offsets; tail = the six
+ * alignment fields of the protein joined by tabs -- per protein with tail_off (B + 1 offsets), or ONE NUL-terminated string for all
+ * (tail_off == NULL: the reference's six "nan" when the query has no alignment record).  The score is printed as Python prints
+ * float(np.float32) with ".4f" (correctly rounded, ties to even).  *bytes = size of the text, *lines = number of lines; MDF_ECAPACITY
+ * when it exceeds `capacity` (call with out = NULL, capacity = 0 to size the buffer).  Host code: no device is touched. */
+int mdf_results_format_host(const char *qid, const int64_t *qid_off, const char *middle, const char *term, const int64_t *term_off, const char *name,
+                            const int64_t *name_off, const char *tail, const int64_t *tail_off, const int32_t *offsets, const int32_t *term_idx,
+                            const float *kept, int32_t B, int32_t T, char *out, int64_t capacity, int64_t *bytes, int64_t *lines);
+
 /* ------------------------------------------------------------------------------------------------
  * Alignment step in front of the path: global Needleman-Wunsch with affine gaps, the
  * arithmetic the reference obtains from PyOpal at mDeepFRI/alignment.py:164-250
@@ -474,6 +486,24 @@ int mdf_nw_score_host(const uint8_t *codes, const int64_t *seq_off, const int32_
 int mdf_nw_align_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,
                       const int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int tie_rule,
                       const char *alphabet, char *ops, char *q_aln, char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores);
+
+/* Best hit of every query and its alignment in ONE call: the batched counterpart of the reference's per-query pool task
+ * (alignment.py:223-250 `pairwise_against_database` = `best_hit_database` :164-196 + `align_pairwise` :198-221, mapped over the
+ * queries by the pool of :266-320).  Host buffers in, host buffers out; everything between (launch order, the arg-max over a query's
+ * candidates, the plans of the winners' alignments, packing in query order) happens inside.
+ *   sequences: n_seq byte strings text[seq_off[s] .. seq_off[s] + seq_len[s]), offsets ascending.  lut != NULL: the bytes are residue
+ *     LETTERS, translated on the device through the 256-entry table (255 = not in the alphabet: MDF_EBADCHAR, info[0] = sequence,
+ *     info[1] = position of the first offender in sequence order); lut == NULL: they are residue codes < A.
+ *   queries are sequences 0 .. nq-1; the candidates of query q are the sequences cand[first[q] .. first[q+1]) (at least one each).
+ *   out, per query: best = position of the winner inside q's candidate list (the FIRST maximum, Python's max()), score, op_len (columns),
+ *     n_match, aln_off (nq + 1); ops / q_aln / t_aln packed in query order, query q's columns at [aln_off[q], aln_off[q+1]).
+ *     capacity = bytes available in each of ops / q_aln / t_aln (sum over q of Lq + the longest candidate always suffices); too small:
+ *     MDF_ECAPACITY with info[2] = bytes needed.  cand_scores (optional, P = first[nq] ints): every candidate's score.
+ *   max_trace_bytes: device memory the direction words of one alignment launch may take (the winners are aligned in groups). */
+int mdf_nw_best_hits_host(const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut, int32_t nq,
+                          const int32_t *cand, const int64_t *first, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int tie_rule,
+                          const char *alphabet, int64_t max_trace_bytes, int32_t *best, int32_t *score, int32_t *op_len, int32_t *n_match,
+                          int64_t *aln_off, char *ops, char *q_aln, char *t_aln, int64_t capacity, int32_t *cand_scores, int64_t *info);
 
 /* Timing hook for bench.py: mdf_timing_enable(n), n = 0 off, n >= 1: the library brackets every n-th launch of each
  * kernel class with hipEvents on the stream it is launched on and accumulates count and milliseconds of the sampled

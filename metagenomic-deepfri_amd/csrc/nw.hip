@@ -17,6 +17,7 @@
 // vertical >= horizontal, inside a gap opening wins) -- bit-exact integer work.
 // PARITY UNPINNED against PyOpal itself (absent offline), see the oracle's header.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <vector>
 
@@ -561,6 +562,111 @@ static int nw_check(const void *codes, const void *seq_off, const void *seq_len,
     return MDF_OK;
 }
 
+
+// ---- batched best hit + alignment of the winner (mdf_nw_best_hits_host) ---------------------------------------------------------
+// Residue letters -> codes through a 256-entry table, in place; the FIRST byte outside the alphabet is left in *bad (a global byte
+// position; the host maps it to sequence and offset).
+__global__ __launch_bounds__(256) void k_nw_encode(uint8_t *__restrict__ text, int64_t total, const uint8_t *__restrict__ lut,
+                                                   unsigned long long *__restrict__ bad)
+{
+    __shared__ uint8_t s_lut[256];
+    s_lut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (i0 >= total) return;
+    if (i0 + 16 <= total) {
+        uint4 v = *reinterpret_cast<const uint4 *>(text + i0);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        int first_bad = 16;
+#pragma unroll
+        for (int k = 3; k >= 0; --k) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 3; b >= 0; --b) {
+                const uint32_t c = s_lut[(w[k] >> (8 * b)) & 255];
+                if (c == 255) first_bad = 4 * k + b;
+                o |= c << (8 * b);
+            }
+            w[k] = o;
+        }
+        *reinterpret_cast<uint4 *>(text + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+        if (first_bad < 16) atomicMin(bad, (unsigned long long)(i0 + first_bad));
+    } else {
+        for (int64_t i = total - 1; i >= i0; --i) {
+            const uint8_t c = s_lut[text[i]];
+            text[i] = c;
+            if (c == 255) atomicMin(bad, (unsigned long long)i);
+        }
+    }
+}
+
+// Per query: the FIRST candidate that reaches the maximum score (Python's max(), reference alignment.py:189-196).  The scores
+// arrive in launch order (largest matrices first); rank[p] is where candidate slot p of the caller's lists went.
+__global__ __launch_bounds__(256) void k_nw_best(const int32_t *__restrict__ scores, const int32_t *__restrict__ rank,
+                                                 const int64_t *__restrict__ first, int nq, int32_t *__restrict__ best,
+                                                 int32_t *__restrict__ best_score, int32_t *__restrict__ cand_scores)
+{
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const int64_t a = first[q], b = first[q + 1];
+    int bs = INT32_MIN, bi = 0;
+    for (int64_t p = a; p < b; ++p) {
+        const int v = scores[rank[p]];
+        if (cand_scores) cand_scores[p] = v;
+        if (v > bs) bs = v, bi = (int)(p - a);
+    }
+    best[q] = bi;
+    best_score[q] = bs;
+}
+
+// Winners were aligned in launch order (slot); the caller gets them packed in QUERY order: aln_off = exclusive scan of the column
+// counts (one workgroup; nq is at most a few million), per-query scalars gathered on the way.
+__global__ __launch_bounds__(1024) void k_nw_scan_len(const int32_t *__restrict__ slot_of, const int32_t *__restrict__ op_len_s,
+                                                      const int32_t *__restrict__ n_match_s, const int32_t *__restrict__ score_s, int nq,
+                                                      int64_t *__restrict__ aln_off, int32_t *__restrict__ op_len, int32_t *__restrict__ n_match,
+                                                      int32_t *__restrict__ score)
+{
+    __shared__ int64_t s_sum[1024];
+    const int t = threadIdx.x, per = (nq + 1023) / 1024;
+    const int q0 = min(t * per, nq), q1 = min(q0 + per, nq);
+    int64_t acc = 0;
+    for (int q = q0; q < q1; ++q) acc += op_len_s[slot_of[q]];
+    s_sum[t] = acc;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int64_t v = t >= d ? s_sum[t - d] : 0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    int64_t off = s_sum[t] - acc;
+    for (int q = q0; q < q1; ++q) {
+        const int s = slot_of[q], n = op_len_s[s];
+        aln_off[q] = off;
+        op_len[q] = n;
+        n_match[q] = n_match_s[s];
+        score[q] = score_s[s];
+        off += n;
+    }
+    if (t == 1023) aln_off[nq] = s_sum[1023];
+}
+
+// One wave per query: its columns (right-aligned in the slot's capacity [ops_off[s], ops_off[s+1])) -> [aln_off[q], aln_off[q+1]).
+__global__ __launch_bounds__(256) void k_nw_pack(const int32_t *__restrict__ slot_of, const int64_t *__restrict__ ops_off,
+                                                 const int64_t *__restrict__ aln_off, int nq, const char *__restrict__ ops_s,
+                                                 const char *__restrict__ qa_s, const char *__restrict__ ta_s, char *__restrict__ ops,
+                                                 char *__restrict__ qa, char *__restrict__ ta)
+{
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const int64_t dst = aln_off[q], n = aln_off[q + 1] - dst, src = ops_off[slot_of[q] + 1] - n;
+    for (int64_t k = lane; k < n; k += 64) {
+        ops[dst + k] = ops_s[src + k];
+        qa[dst + k] = qa_s[src + k];
+        ta[dst + k] = ta_s[src + k];
+    }
+}
+
 }  // namespace mdf
 
 using namespace mdf;
@@ -769,6 +875,240 @@ int mdf_nw_align_host(const uint8_t *codes, const int64_t *seq_off, const int32_
     MDF_REQUIRE(tie_rule >= 0 && tie_rule < 8, "nw_align_host: tie_rule=%d not in 0..7", tie_rule);
     return nw_host(codes, seq_off, seq_len, n_seq, pair_q, pair_t, P, matrix, A, gap_open, gap_extend, tie_rule, alphabet, ops, q_aln, t_aln, op_len, n_match,
                    scores, true);
+}
+
+// Launch order of a pair list: largest DP matrices first (a pair swept by one wave or one workgroup lasts as long as its matrix is
+// large; started last it would run on alone).  order[k] = index of the k-th pair to launch; stable among equal sizes.
+static void order_by_cells(const int32_t *seq_len, const int32_t *pq, const int32_t *pt, int64_t P, std::vector<int32_t> &order)
+{
+    // LSD radix sort of (descending size key, index): three 11-bit passes over a 32-bit key (cells / 256, saturated), stable
+    std::vector<uint32_t> key((size_t)P), key2((size_t)P);
+    std::vector<int32_t> idx2((size_t)P);
+    order.resize((size_t)P);
+    for (int64_t p = 0; p < P; ++p) {
+        key[(size_t)p] = 0xffffffffu - (uint32_t)std::min<uint64_t>((uint64_t)seq_len[pq[p]] * (uint64_t)seq_len[pt[p]] >> 8, 0xffffffffu);
+        order[(size_t)p] = (int32_t)p;
+    }
+    uint32_t *k0 = key.data(), *k1 = key2.data();
+    int32_t *i0 = order.data(), *i1 = idx2.data();
+    for (int pass = 0; pass < 3; ++pass) {
+        const int sh = 11 * pass;
+        size_t cnt[2049] = {0};
+        for (int64_t p = 0; p < P; ++p) ++cnt[((k0[p] >> sh) & 2047) + 1];
+        for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
+        for (int64_t p = 0; p < P; ++p) {
+            const size_t at = cnt[(k0[p] >> sh) & 2047]++;
+            k1[at] = k0[p];
+            i1[at] = i0[p];
+        }
+        std::swap(k0, k1);
+        std::swap(i0, i1);
+    }
+    if (i0 != order.data()) std::copy(i0, i0 + P, order.data());   // three passes: the result sits in the second buffer
+}
+
+int mdf_nw_best_hits_host(const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut, int32_t nq,
+                          const int32_t *cand, const int64_t *first, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int tie_rule,
+                          const char *alphabet, int64_t max_trace_bytes, int32_t *best, int32_t *score, int32_t *op_len, int32_t *n_match,
+                          int64_t *aln_off, char *ops, char *q_aln, char *t_aln, int64_t capacity, int32_t *cand_scores, int64_t *info)
+{
+    if (info) info[0] = info[1] = info[2] = -1;
+    static const bool tm_on = getenv("MDFRI_NW_TIMING") != nullptr;
+    auto tm_now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tm_last = tm_now();
+    auto tm = [&](const char *what) { if (tm_on) { double t = tm_now(); fprintf(stderr, "[nw_best_hits] %-28s %.2f ms\n", what, t - tm_last); tm_last = t; } };
+    MDF_REQUIRE(text && seq_off && seq_len && cand && first && matrix && alphabet, "nw_best_hits: NULL argument");
+    MDF_REQUIRE(best && score && op_len && n_match && aln_off && ops && q_aln && t_aln, "nw_best_hits: NULL output");
+    MDF_REQUIRE(n_seq > 0 && nq > 0 && nq <= n_seq, "nw_best_hits: nq=%d queries among n_seq=%d sequences", nq, n_seq);
+    MDF_REQUIRE(tie_rule >= 0 && tie_rule < 8, "nw_best_hits: tie_rule=%d not in 0..7", tie_rule);
+    MDF_REQUIRE(capacity >= 0 && max_trace_bytes > 0, "nw_best_hits: bad capacity / trace budget");
+    MDF_REQUIRE(first[0] == 0 && first[nq] > 0 && first[nq] < INT32_MAX, "nw_best_hits: candidate offsets must run from 0 to P < 2^31");
+    const int32_t P = (int32_t)first[nq];
+    if (int rc = nw_check(text, seq_off, seq_len, cand, cand, P, matrix, A, gap_open, gap_extend)) return rc;
+    int64_t total = 0;
+    for (int32_t s = 0; s < n_seq; ++s) {
+        MDF_REQUIRE(seq_len[s] >= 0 && seq_len[s] < (1 << 24) && seq_off[s] >= total, "nw_best_hits: sequence %d: bad length, or offsets not ascending", s);
+        total = seq_off[s] + seq_len[s];
+    }
+    for (int32_t q = 0; q < nq; ++q)
+        MDF_REQUIRE(first[q + 1] > first[q], "nw_best_hits: query %d has no candidate (the reference never builds such a task)", q);
+    for (int32_t p = 0; p < P; ++p) MDF_REQUIRE(cand[p] >= 0 && cand[p] < n_seq, "nw_best_hits: candidate %d refers to a sequence out of range", p);
+    if (!lut)
+        for (int32_t s = 0; s < n_seq; ++s) {
+            uint8_t mx = 0;
+            for (int64_t b = seq_off[s]; b < seq_off[s] + seq_len[s]; ++b) mx = std::max(mx, text[b]);
+            MDF_REQUIRE(mx < A, "nw_best_hits: a residue code of sequence %d is outside the alphabet (size %d)", s, A);
+        }
+    if (int rc = require_device()) return rc;
+    tm("validate");
+
+    // ---- phase 1: score every (query, candidate) pair, largest first; arg-max per query on the device -------------------------------------
+    std::vector<int32_t> pq((size_t)P), order, rank((size_t)P);
+    for (int32_t q = 0; q < nq; ++q)
+        for (int64_t p = first[q]; p < first[q + 1]; ++p) pq[(size_t)p] = q;
+    order_by_cells(seq_len, pq.data(), cand, P, order);
+    tm("order pairs");
+    size_t ho = 0;
+    auto htake = [&](size_t bytes) { size_t r = ho; ho = align_up(ho + bytes, 256); return r; };
+    const size_t h_text = htake((size_t)total + 16), h_soff = htake((size_t)n_seq * 8), h_slen = htake((size_t)n_seq * 4), h_pq = htake((size_t)P * 4),
+                 h_pt = htake((size_t)P * 4), h_rank = htake((size_t)P * 4), h_first = htake(((size_t)nq + 1) * 8), h_mat = htake((size_t)A * A * 4),
+                 h_bo = htake(((size_t)P + 1) * 8), h_lut = htake(256), h_al = htake(64), h_bad = htake(8), h_up = ho;
+    const size_t h_best = htake((size_t)nq * 4), h_bsc = htake((size_t)nq * 4);
+    size_t go_ = 0;   // phase 2's staging (sizes depend on nq alone): behind phase 1's, one pinned block for the call
+    auto gtake = [&](size_t bytes) { size_t r = go_; go_ = align_up(go_ + bytes, 256); return r; };
+    const size_t g_pq = gtake((size_t)nq * 4), g_pt = gtake((size_t)nq * 4), g_slot = gtake((size_t)nq * 4), g_bo = gtake(((size_t)nq + 1) * 8),
+                 g_to = gtake(((size_t)nq + 1) * 8), g_oo = gtake(((size_t)nq + 1) * 8), g_up = go_;
+    const size_t g_meta = gtake(((size_t)nq + 1) * 8 + (size_t)nq * 12);
+    HostStage &hs = host_stage();
+    if (int rc = hs.reserve(ho + go_)) return rc;
+    char *h = hs.ptr;
+    memcpy(h + h_text, text, (size_t)total);
+    if (lut) {   // bytes between two sequences are nobody's residues: make them a letter of the alphabet, so that only real offenders are flagged
+        int ok = 0;
+        while (ok < 256 && lut[ok] == 255) ++ok;
+        MDF_REQUIRE(ok < 256, "nw_best_hits: the letter table maps nothing into the alphabet");
+        int64_t end = 0;
+        for (int32_t s = 0; s < n_seq; ++s) {
+            if (seq_off[s] > end) memset(h + h_text + end, ok, (size_t)(seq_off[s] - end));
+            end = seq_off[s] + seq_len[s];
+        }
+    }
+    memcpy(h + h_soff, seq_off, (size_t)n_seq * 8);
+    memcpy(h + h_slen, seq_len, (size_t)n_seq * 4);
+    memcpy(h + h_first, first, ((size_t)nq + 1) * 8);
+    memcpy(h + h_mat, matrix, (size_t)A * A * 4);
+    if (lut) memcpy(h + h_lut, lut, 256);
+    memset(h + h_al, 0, 64);
+    memcpy(h + h_al, alphabet, std::min<size_t>(strlen(alphabet), 63));
+    *reinterpret_cast<unsigned long long *>(h + h_bad) = ~0ull;
+    {
+        int32_t *spq = reinterpret_cast<int32_t *>(h + h_pq), *spt = reinterpret_cast<int32_t *>(h + h_pt), *rk = reinterpret_cast<int32_t *>(h + h_rank);
+        int64_t *bo = reinterpret_cast<int64_t *>(h + h_bo), b = 0;
+        for (int32_t k = 0; k < P; ++k) {
+            const int32_t p = order[(size_t)k];
+            spq[k] = pq[(size_t)p];
+            spt[k] = cand[p];
+            rk[p] = k;
+            bo[k] = b;
+            b += 2 * (int64_t)seq_len[spq[k]];
+        }
+        bo[P] = b;
+    }
+    const int64_t bnd_ints = reinterpret_cast<int64_t *>(h + h_bo)[P];
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    const size_t d_in = take(h_up), d_bnd = take((size_t)bnd_ints * 4 + 4), d_sc = take((size_t)P * 4), d_best = take((size_t)nq * 4),
+                 d_bsc = take((size_t)nq * 4), d_csc = take(cand_scores ? (size_t)P * 4 : 4);
+    Scratch &s1 = scratch(1);
+    if (int rc = s1.reserve(o)) return rc;
+    char *b1 = static_cast<char *>(s1.ptr);
+    hipStream_t st = nullptr;
+    tm("stage phase 1");
+    MDF_HIP(hipMemcpyAsync(b1 + d_in, h, h_up, hipMemcpyHostToDevice, st));
+    auto I = [&](size_t off) { return b1 + d_in + off; };
+    if (lut) hipLaunchKernelGGL(k_nw_encode, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, (uint8_t *)I(h_text), total, (const uint8_t *)I(h_lut),
+                                (unsigned long long *)I(h_bad));
+    const int32_t *spq = reinterpret_cast<const int32_t *>(h + h_pq), *spt = reinterpret_cast<const int32_t *>(h + h_pt);
+    if (int rc = mdf_nw_score_dev((const uint8_t *)I(h_text), (const int64_t *)I(h_soff), (const int32_t *)I(h_slen), (const int32_t *)I(h_pq),
+                                  (const int32_t *)I(h_pt), P, mdf_nw_count_long(seq_len, spq, spt, P), (const int32_t *)I(h_mat), A, gap_open, gap_extend,
+                                  (const int64_t *)I(h_bo), (int32_t *)(b1 + d_bnd), (int32_t *)(b1 + d_sc), st))
+        return rc;
+    hipLaunchKernelGGL(k_nw_best, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const int32_t *)(b1 + d_sc), (const int32_t *)I(h_rank),
+                       (const int64_t *)I(h_first), nq, (int32_t *)(b1 + d_best), (int32_t *)(b1 + d_bsc), cand_scores ? (int32_t *)(b1 + d_csc) : nullptr);
+    MDF_HIP(hipGetLastError());
+    MDF_HIP(hipMemcpyAsync(h + h_best, b1 + d_best, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    MDF_HIP(hipMemcpyAsync(h + h_bsc, b1 + d_bsc, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    MDF_HIP(hipMemcpyAsync(h + h_bad, I(h_bad), 8, hipMemcpyDeviceToHost, st));
+    MDF_HIP(hipStreamSynchronize(st));
+    tm("upload + score + best");
+    if (lut) {
+        const unsigned long long bad = *reinterpret_cast<unsigned long long *>(h + h_bad);
+        if (bad != ~0ull) {   // the first byte outside the alphabet, in sequence order (offsets ascend)
+            int32_t s = (int32_t)(std::upper_bound(seq_off, seq_off + n_seq, (int64_t)bad) - seq_off) - 1;
+            while (s > 0 && seq_len[s] == 0) --s;
+            if (info) info[0] = s, info[1] = (int64_t)bad - seq_off[s];
+            return fail(MDF_EBADCHAR, "nw_best_hits: character %d at position %lld of sequence %d is not in the scoring matrix alphabet",
+                        (int)text[bad], (long long)((int64_t)bad - seq_off[s]), s);
+        }
+    }
+    if (cand_scores) MDF_HIP(hipMemcpy(cand_scores, b1 + d_csc, (size_t)P * 4, hipMemcpyDeviceToHost));
+    memcpy(best, h + h_best, (size_t)nq * 4);
+    const int32_t *bsc = reinterpret_cast<const int32_t *>(h + h_bsc);
+
+    // ---- phase 2: full alignment of each query with its winner, in groups whose directions fit the trace budget -----------------------------
+    std::vector<int32_t> wq((size_t)nq), wt((size_t)nq);
+    for (int32_t q = 0; q < nq; ++q) wq[(size_t)q] = q, wt[(size_t)q] = cand[first[q] + best[q]];
+    order_by_cells(seq_len, wq.data(), wt.data(), nq, order);
+    h = hs.ptr + ho;
+    int32_t *sq = reinterpret_cast<int32_t *>(h + g_pq), *stt = reinterpret_cast<int32_t *>(h + g_pt), *so = reinterpret_cast<int32_t *>(h + g_slot);
+    for (int32_t k = 0; k < nq; ++k) {
+        const int32_t q = order[(size_t)k];
+        sq[k] = q;
+        stt[k] = wt[(size_t)q];
+        so[q] = k;
+    }
+    int64_t *bo2 = reinterpret_cast<int64_t *>(h + g_bo), *to2 = reinterpret_cast<int64_t *>(h + g_to), *oo2 = reinterpret_cast<int64_t *>(h + g_oo);
+    if (int rc = mdf_nw_plan(seq_len, sq, stt, nq, bo2, to2, oo2)) return rc;
+    int64_t max_group = 0;
+    std::vector<int32_t> cuts{0};
+    for (int32_t p0 = 0; p0 < nq;) {
+        int32_t p1 = p0 + 1;
+        while (p1 < nq && to2[p1 + 1] - to2[p0] <= max_trace_bytes) ++p1;
+        max_group = std::max(max_group, to2[p1] - to2[p0]);
+        cuts.push_back(p1);
+        p0 = p1;
+    }
+    const int64_t cols = oo2[nq];
+    size_t o2 = 0;
+    auto take2 = [&](size_t bytes) { size_t r = o2; o2 = align_up(o2 + bytes, 256); return r; };
+    const size_t e_in = take2(g_up), e_bnd = take2((size_t)bo2[nq] * 4 + 4), e_tr = take2((size_t)max_group + 16), e_ops = take2((size_t)cols + 1),
+                 e_qa = take2((size_t)cols + 1), e_ta = take2((size_t)cols + 1), e_ol = take2((size_t)nq * 4), e_nm = take2((size_t)nq * 4),
+                 e_sc = take2((size_t)nq * 4), e_meta = take2(((size_t)nq + 1) * 8 + (size_t)nq * 12), e_pops = take2((size_t)cols + 1),
+                 e_pqa = take2((size_t)cols + 1), e_pta = take2((size_t)cols + 1);
+    Scratch &s2 = scratch(2);
+    if (int rc = s2.reserve(o2)) return rc;
+    char *b2 = static_cast<char *>(s2.ptr);
+    tm("plan winners");
+    MDF_HIP(hipMemcpyAsync(b2 + e_in, h, g_up, hipMemcpyHostToDevice, st));
+    auto J = [&](size_t off) { return b2 + e_in + off; };
+    for (size_t g = 0; g + 1 < cuts.size(); ++g) {
+        const int32_t p0 = cuts[g], n = cuts[g + 1] - p0;
+        if (int rc = mdf_nw_align_dev((const uint8_t *)I(h_text), (const int64_t *)I(h_soff), (const int32_t *)I(h_slen), (const int32_t *)J(g_pq) + p0,
+                                      (const int32_t *)J(g_pt) + p0, n, mdf_nw_count_long_align(seq_len, sq + p0, stt + p0, n), (const int32_t *)I(h_mat), A,
+                                      gap_open, gap_extend, tie_rule, I(h_al), (const int64_t *)J(g_bo) + p0, (int32_t *)(b2 + e_bnd),
+                                      (const int64_t *)J(g_to) + p0, (uint8_t *)(b2 + e_tr) - to2[p0], (const int64_t *)J(g_oo) + p0, b2 + e_ops, b2 + e_qa,
+                                      b2 + e_ta, (int32_t *)(b2 + e_ol) + p0, (int32_t *)(b2 + e_nm) + p0, (int32_t *)(b2 + e_sc) + p0, st))
+            return rc;
+    }
+    int64_t *m_off = reinterpret_cast<int64_t *>(b2 + e_meta);
+    int32_t *m_ol = reinterpret_cast<int32_t *>(m_off + nq + 1), *m_nm = m_ol + nq, *m_sc = m_nm + nq;
+    hipLaunchKernelGGL(k_nw_scan_len, dim3(1), dim3(1024), 0, st, (const int32_t *)J(g_slot), (const int32_t *)(b2 + e_ol), (const int32_t *)(b2 + e_nm),
+                       (const int32_t *)(b2 + e_sc), nq, m_off, m_ol, m_nm, m_sc);
+    hipLaunchKernelGGL(k_nw_pack, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, (const int32_t *)J(g_slot), (const int64_t *)J(g_oo), (const int64_t *)m_off, nq,
+                       (const char *)(b2 + e_ops), (const char *)(b2 + e_qa), (const char *)(b2 + e_ta), b2 + e_pops, b2 + e_pqa, b2 + e_pta);
+    MDF_HIP(hipGetLastError());
+    MDF_HIP(hipMemcpyAsync(h + g_meta, b2 + e_meta, ((size_t)nq + 1) * 8 + (size_t)nq * 12, hipMemcpyDeviceToHost, st));
+    MDF_HIP(hipStreamSynchronize(st));
+    tm("align + pack");
+    const int64_t *r_off = reinterpret_cast<const int64_t *>(h + g_meta);
+    const int32_t *r_ol = reinterpret_cast<const int32_t *>(r_off + nq + 1), *r_nm = r_ol + nq, *r_sc = r_nm + nq;
+    memcpy(aln_off, r_off, ((size_t)nq + 1) * 8);
+    memcpy(op_len, r_ol, (size_t)nq * 4);
+    memcpy(n_match, r_nm, (size_t)nq * 4);
+    memcpy(score, r_sc, (size_t)nq * 4);
+    for (int32_t q = 0; q < nq; ++q)
+        if (r_sc[q] != bsc[q])
+            return fail(MDF_EINVAL, "nw_best_hits: internal error: the full alignment of query %d scores %d, score mode said %d", q, r_sc[q], bsc[q]);
+    if (info) info[2] = r_off[nq];
+    if (r_off[nq] > capacity)
+        return fail(MDF_ECAPACITY, "nw_best_hits: the alignments have %lld columns, capacity is %lld", (long long)r_off[nq], (long long)capacity);
+    if (r_off[nq] > 0) {
+        MDF_HIP(hipMemcpy(ops, b2 + e_pops, (size_t)r_off[nq], hipMemcpyDeviceToHost));
+        MDF_HIP(hipMemcpy(q_aln, b2 + e_pqa, (size_t)r_off[nq], hipMemcpyDeviceToHost));
+        MDF_HIP(hipMemcpy(t_aln, b2 + e_pta, (size_t)r_off[nq], hipMemcpyDeviceToHost));
+    }
+    tm("download");
+    return MDF_OK;
 }
 
 }  // extern "C"

@@ -6,6 +6,9 @@
 // before anything crosses PCIe or xGMI.  Integer/compare work: no LDS tricks beyond a per-protein candidate list.
 #include <algorithm>
 
+#include <cmath>
+#include <cstring>
+
 #include "common.h"
 
 namespace mdf {
@@ -143,6 +146,90 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
     hipLaunchKernelGGL(k_filter_scan, dim3(1), dim3(1024), 0, st, counts, B, offsets, capacity, status);
     hipLaunchKernelGGL(k_filter_fill, dim3(B), dim3(256), FILTER_MAX_T * 8, st, scores, T, threshold, offsets, term_idx, kept_scores);
     MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+// ---- results.tsv text (host code: a few MB of bytes per head, assembled next to the arrays the filter produced) ----------------------
+// f"{score:.4f}" of a float32 widened to double, correctly rounded (half to even on the exact value), as Python and glibc print it.
+// value * 10000 is exact in double (24 significant bits times 625 * 2^4), so the rounding is decided on an exact number.
+static inline char *format_4f(char *o, float f)
+{
+    double d = (double)f;
+    if (std::isnan(d)) {
+        memcpy(o, "nan", 3);
+        return o + 3;
+    }
+    if (std::signbit(d)) *o++ = '-', d = -d;
+    if (std::isinf(d)) {
+        memcpy(o, "inf", 3);
+        return o + 3;
+    }
+    if (!(d < 1e9)) return o + snprintf(o, 64, "%.4f", d);
+    const double x = d * 10000.0;
+    uint64_t n = (uint64_t)x;
+    const double frac = x - (double)n;
+    if (frac > 0.5 || (frac == 0.5 && (n & 1))) ++n;
+    uint64_t ip = n / 10000;
+    const unsigned fp = (unsigned)(n % 10000);
+    char tmp[24];
+    int k = 0;
+    do {
+        tmp[k++] = (char)('0' + ip % 10);
+        ip /= 10;
+    } while (ip);
+    while (k) *o++ = tmp[--k];
+    *o++ = '.';
+    o[0] = (char)('0' + fp / 1000);
+    o[1] = (char)('0' + fp / 100 % 10);
+    o[2] = (char)('0' + fp / 10 % 10);
+    o[3] = (char)('0' + fp % 10);
+    return o + 4;
+}
+
+int mdf_results_format_host(const char *qid, const int64_t *qid_off, const char *middle, const char *term, const int64_t *term_off, const char *name,
+                            const int64_t *name_off, const char *tail, const int64_t *tail_off, const int32_t *offsets, const int32_t *term_idx,
+                            const float *kept, int32_t B, int32_t T, char *out, int64_t capacity, int64_t *bytes, int64_t *lines)
+{
+    MDF_REQUIRE(qid && qid_off && middle && term && term_off && name && name_off && tail && offsets && bytes, "results_format: NULL argument");
+    MDF_REQUIRE(B >= 0 && T > 0 && capacity >= 0 && (out || capacity == 0), "results_format: bad sizes");
+    MDF_REQUIRE(offsets[0] == 0, "results_format: offsets must start at 0");
+    const size_t mid_len = strlen(middle), tail_all = tail_off ? 0 : strlen(tail);
+    const int64_t N = B ? offsets[B] : 0;
+    MDF_REQUIRE(N == 0 || (term_idx && kept), "results_format: NULL term_idx / kept");
+    // pass 1: exact size (the score's text length depends on its value)
+    int64_t need = 0;
+    char num[72];
+    for (int32_t p = 0; p < B; ++p) {
+        MDF_REQUIRE(offsets[p + 1] >= offsets[p], "results_format: offsets decrease at protein %d", p);
+        const int64_t fixed = (qid_off[p + 1] - qid_off[p]) + 1 + (int64_t)mid_len + 1 + 1 + 1 + (tail_off ? tail_off[p + 1] - tail_off[p] : (int64_t)tail_all) + 1;
+        for (int32_t k = offsets[p]; k < offsets[p + 1]; ++k) {
+            const int32_t t = term_idx[k];
+            MDF_REQUIRE(t >= 0 && t < T, "results_format: term index %d out of range at entry %d", t, k);
+            need += fixed + (term_off[t + 1] - term_off[t]) + 1 + (format_4f(num, kept[k]) - num) + (name_off[t + 1] - name_off[t]);
+        }
+    }
+    *bytes = need;
+    if (lines) *lines = N;
+    if (need > capacity) return fail(MDF_ECAPACITY, "results_format: the lines take %lld bytes, capacity is %lld", (long long)need, (long long)capacity);
+    char *o = out;
+    auto put = [&](const char *src, int64_t n) { memcpy(o, src, (size_t)n); o += n; };
+    for (int32_t p = 0; p < B; ++p)
+        for (int32_t k = offsets[p]; k < offsets[p + 1]; ++k) {
+            const int32_t t = term_idx[k];
+            put(qid + qid_off[p], qid_off[p + 1] - qid_off[p]);
+            *o++ = '\t';
+            put(middle, (int64_t)mid_len);
+            *o++ = '\t';
+            put(term + term_off[t], term_off[t + 1] - term_off[t]);
+            *o++ = '\t';
+            o = format_4f(o, kept[k]);
+            *o++ = '\t';
+            put(name + name_off[t], name_off[t + 1] - name_off[t]);
+            *o++ = '\t';
+            if (tail_off) put(tail + tail_off[p], tail_off[p + 1] - tail_off[p]);
+            else put(tail, (int64_t)tail_all);
+            *o++ = '\n';
+        }
     return MDF_OK;
 }
 

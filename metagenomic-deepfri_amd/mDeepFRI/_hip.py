@@ -171,6 +171,11 @@ SIGNATURES = {
     "mdf_nw_score_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_void_p]),
     "mdf_nw_align_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_int, c_char_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mdf_nw_best_hits_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_int,
+                                      c_char_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                      c_void_p]),
+    "mdf_results_format_host": (c_int, [c_void_p, c_void_p, c_char_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_int32, c_int32, c_void_p, c_int64, _i64p, _i64p]),
     "mdf_timing_enable": (c_int, [c_int]),
     "mdf_timing_read": (c_int, [c_char_p, _i64p, POINTER(c_double)]),
     "mdf_timing_reset": (c_int, []),

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+from itertools import islice
+
 import numpy as np
 
 from . import _hip
@@ -79,6 +81,10 @@ class ScoringMatrix:
         self._lut = np.full(256, 255, dtype=np.uint8)
         for i, c in enumerate(self.alphabet):
             self._lut[ord(c)] = i
+        self._lut_nocase = self._lut.copy()      # the batched entry upper-cases on the device: a lower-case letter is its capital
+        for i, c in enumerate(self.alphabet):
+            if c.isalpha() and self._lut_nocase[ord(c.lower())] == 255:
+                self._lut_nocase[ord(c.lower())] = i
 
     @classmethod
     def simple(cls, alphabet: str = "ARNDCQEGHILKMFPSTWYVBZX*", match: int = 5, mismatch: int = -4):
@@ -233,6 +239,7 @@ def best_hit_database(query, target_sequences, gap_open: int = 10, gap_extend: i
     return keys[best], targets[best]
 
 
+MAX_TRACE_BYTES = 512 << 20   # device memory the direction words of one alignment launch may take (align_queries_arrays)
 TIE_RULE = 0   # which co-optimal alignment is returned (3 bits, see include/mdfri.h / oracle/nw_oracle.c); PyOpal's choice is unpinned
 
 
@@ -290,36 +297,47 @@ def align_queries_arrays(query_ids, query_sequences, target_sequences, gap_open:
     query_ids = list(query_ids)
     seqs = list(query_sequences)
     nq = len(seqs)
-    keys = [list(d) for d in target_sequences]
-    if any(len(k) == 0 for k in keys):
+    if nq == 0:
+        z = np.zeros(0, np.int32)
+        return AlignedBatch([], [], [], [], np.zeros(0, np.int64), {"ops": np.zeros(0, np.uint8), "q_aln": np.zeros(0, np.uint8), "t_aln": np.zeros(0, np.uint8),
+                                                                   "off": np.zeros(1, np.int64), "op_len": z, "n_match": z, "score": z})
+    target_sequences = list(target_sequences)
+    first = np.zeros(nq + 1, dtype=np.int64)
+    np.cumsum(np.fromiter(map(len, target_sequences), dtype=np.int64, count=nq), out=first[1:])
+    if (first[1:] == first[:-1]).any():
         raise ValueError("every query needs at least one candidate target")
-    # unique targets are encoded once (the same database entry is a candidate of many queries)
-    index = {}
-    pair_q, pair_t, first = [], [], np.zeros(nq + 1, dtype=np.int64)
-    for qi, (d, ks) in enumerate(zip(target_sequences, keys)):
-        for k in ks:
-            t = d[k]
-            j = index.get(t)
-            if j is None:
-                j = index[t] = len(seqs)
-                seqs.append(t)
-            pair_q.append(qi)
-            pair_t.append(j)
-        first[qi + 1] = len(pair_q)
-    pb = _PairBatch(seqs, sm)
-    qs = [_upper(s) for s in seqs[:nq]]
-    sc = pb.scores(pair_q, pair_t, gap_open, gap_extend)
-    # per-query arg-max, first maximum wins (Python's max): reduceat the maxima, then the first position that reaches them
-    seg_max = np.maximum.reduceat(sc, first[:-1])
-    is_max = sc == np.repeat(seg_max, np.diff(first))
-    pos = np.where(is_max, np.arange(len(sc)), len(sc))
-    best_pair = np.minimum.reduceat(pos, first[:-1])
-    best = (best_pair - first[:-1]).astype(np.int64)
-    bt = np.asarray(pair_t, dtype=np.int32)[best_pair]
-    res = pb.align(np.arange(nq, dtype=np.int32), bt, gap_open, gap_extend, tie_rule=TIE_RULE)
-    if not np.array_equal(res["score"], seg_max):
-        raise RuntimeError("internal error: full-alignment score differs from the score-mode score")
-    return AlignedBatch(query_ids, qs, [keys[q][int(b)] for q, b in enumerate(best)], [_upper(seqs[int(j)]) for j in bt], best, res)
+    # unique targets travel once (the same database entry is a candidate of many queries): sequence index = nq + first-seen rank
+    flat = [t for d in target_sequences for t in d.values()]
+    uniq = dict.fromkeys(flat)
+    for i, t in enumerate(uniq):
+        uniq[t] = nq + i
+    cand = np.fromiter(map(uniq.__getitem__, flat), dtype=np.int32, count=len(flat))
+    seqs.extend(uniq)
+    seq_len = np.fromiter(map(len, seqs), dtype=np.int32, count=len(seqs))
+    seq_off = np.zeros(len(seqs), dtype=np.int64)
+    np.cumsum(seq_len[:-1], out=seq_off[1:])
+    joined = "".join(seqs)
+    text = np.frombuffer(joined.encode("ascii"), dtype=np.uint8)
+    if text.size == 0:
+        text = np.zeros(1, np.uint8)
+    cap = max(int(seq_len[:nq].sum(dtype=np.int64) + np.maximum.reduceat(seq_len[cand], first[:-1]).sum(dtype=np.int64)), 1)
+    ops, qa, ta = (np.empty(cap, dtype=np.uint8) for _ in range(3))
+    best, score, op_len, n_match = (np.empty(nq, dtype=np.int32) for _ in range(4))
+    off = np.empty(nq + 1, dtype=np.int64)
+    info = np.zeros(4, dtype=np.int64)
+    rc = _hip.lib().mdf_nw_best_hits_host(_hip.ptr(text), _hip.ptr(seq_off), _hip.ptr(seq_len), len(seqs), _hip.ptr(sm._lut_nocase), nq, _hip.ptr(cand),
+                                          _hip.ptr(first), _hip.ptr(sm.matrix), len(sm.alphabet), int(gap_open), int(gap_extend), int(TIE_RULE),
+                                          sm.alphabet.encode("ascii"), int(MAX_TRACE_BYTES), _hip.ptr(best), _hip.ptr(score), _hip.ptr(op_len),
+                                          _hip.ptr(n_match), _hip.ptr(off), _hip.ptr(ops), _hip.ptr(qa), _hip.ptr(ta), cap, None, _hip.ptr(info))
+    if rc == _hip.MDF_EBADCHAR:
+        raise ValueError(f"character {seqs[int(info[0])][int(info[1])]!r} is not in the scoring matrix alphabet")
+    _hip.check(rc)
+    n = int(off[-1])
+    # the reference upper-cases every sequence it aligns (alignment.py:152-161); the usual input already is
+    upper = seqs if joined.isupper() or not joined else "\n".join(seqs).upper().split("\n")
+    bt = cand[first[:-1] + best]
+    res = {"ops": ops[:n], "q_aln": qa[:n], "t_aln": ta[:n], "off": off, "op_len": op_len, "n_match": n_match, "score": score}
+    return AlignedBatch(query_ids, upper[:nq], [next(islice(d, b, None)) for d, b in zip(target_sequences, best.tolist())], [upper[j] for j in bt.tolist()], best.astype(np.int64), res)
 
 
 def align_queries(query_ids, query_sequences, target_sequences, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80"):

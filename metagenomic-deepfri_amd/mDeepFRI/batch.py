@@ -27,6 +27,10 @@ def _torch():
 # ---------------------------------------------------------------------------------------------------------------------
 # host-side packing
 # ---------------------------------------------------------------------------------------------------------------------
+def _is_f32(a) -> bool:
+    return getattr(a, "dtype", None) == np.float32
+
+
 def _offsets(lengths) -> np.ndarray:
     off = np.zeros(len(lengths) + 1, dtype=np.int64)
     np.cumsum(np.asarray(lengths, dtype=np.int64), out=off[1:])
@@ -137,26 +141,34 @@ class PackedProteins:
         if not keep:
             raise ValueError("empty batch")
         off = np.asarray(batch.aln_off, dtype=np.int64)
-        ln = (off[1:] - off[:-1])[keep]
-        sel = np.repeat(off[:-1][keep] - np.concatenate(([0], np.cumsum(ln)[:-1])), ln) + np.arange(int(ln.sum()), dtype=np.int64)
-        q_aln, t_aln = np.ascontiguousarray(batch.q_aln[sel]), np.ascontiguousarray(batch.t_aln[sel])
-        seqs = [batch.query_sequences[i] for i in keep]
-        Lq = np.array([len(s) for s in seqs], dtype=np.int32)
+        ln_all = off[1:] - off[:-1]
+        if len(keep) == len(coords):        # the usual case: every hit has a structure, the aligner's arrays are taken as they are
+            ln, seqs, cs = ln_all, list(batch.query_sequences), list(coords)
+            q_aln, t_aln = np.ascontiguousarray(batch.q_aln[:int(off[-1])]), np.ascontiguousarray(batch.t_aln[:int(off[-1])])
+        else:
+            mask = np.zeros(len(coords), dtype=bool)
+            mask[keep] = True
+            ln = ln_all[mask]
+            cols = np.repeat(mask, ln_all)
+            q_aln, t_aln = batch.q_aln[:int(off[-1])][cols], batch.t_aln[:int(off[-1])][cols]
+            seqs, cs = [batch.query_sequences[i] for i in keep], [coords[i] for i in keep]
+        Lq = np.fromiter(map(len, seqs), dtype=np.int32, count=len(seqs))
         if (Lq <= 0).any():
             raise ValueError("empty sequence in batch")
         starts = np.concatenate(([0], np.cumsum(ln)))
-        nongap = np.add.reduceat((q_aln != 45).astype(np.int64), starts[:-1]) if len(ln) else np.zeros(0, np.int64)
+        nongap = np.add.reduceat(q_aln != 45, starts[:-1], dtype=np.int64) if len(ln) else np.zeros(0, np.int64)
         if not np.array_equal(nongap, Lq):
             raise ValueError("gapped queries do not spell the query sequences")
         pk = cls(seqs=seqs, Lq=Lq, seq_bytes=np.frombuffer("".join(seqs).encode("ascii"), dtype=np.uint8).copy(), seq_off=_offsets(Lq))
-        cs = []
-        for i in keep:
-            c = np.asarray(coords[i])
-            if c.dtype != np.float32 or c.ndim != 2 or c.shape[1] != 3:
-                raise ValueError("coordinates must be float32 (Lt,3)")
-            cs.append(c)
-        pk.coords = np.ascontiguousarray(np.concatenate(cs, axis=0))
-        pk.coord_off = _offsets([c.shape[0] for c in cs])
+        try:                                  # one concatenation checks every trace at once; a wrong one is looked for only on failure
+            xyz = np.concatenate(cs, axis=0)
+            ok = xyz.dtype == np.float32 and xyz.ndim == 2 and xyz.shape[1] == 3 and all(map(_is_f32, cs))
+        except (ValueError, TypeError):
+            ok = False
+        if not ok:
+            raise ValueError("coordinates must be float32 (Lt,3)")
+        pk.coords = np.ascontiguousarray(xyz)
+        pk.coord_off = _offsets(np.fromiter(map(len, cs), dtype=np.int64, count=len(cs)))
         pk.q_aln, pk.t_aln, pk.aln_off = q_aln, t_aln, _offsets(ln)
         pk._plan(max_rows, max_segment_groups)
         return pk, keep

@@ -41,19 +41,48 @@ def filter_scores(scores, threshold: float = 0.1, capacity_per_protein: int = 64
     return offsets, term_idx[:n], kept[:n]
 
 
-def results_rows(query_ids, net_type: str, mode_label: str, terms, gonames, offsets, term_idx, kept, alignment_data=None):
-    """Lines of results.tsv for one GO head, formatted as reference pipeline.py:713-716:
-    query_id, net_type, mode, term, f"{score:.4f}", go_name, then the six alignment fields (nan when unknown)."""
-    off = np.asarray(offsets.cpu() if hasattr(offsets, "cpu") else offsets)
-    ti = np.asarray(term_idx.cpu() if hasattr(term_idx, "cpu") else term_idx)
-    sc = np.asarray(kept.cpu() if hasattr(kept, "cpu") else kept, dtype=np.float32)
+def _concat(strings):
+    """list of str -> (utf-8 bytes, int64 offsets (n + 1))."""
+    enc = [x.encode("utf-8") for x in strings]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum(np.fromiter(map(len, enc), dtype=np.int64, count=len(enc)), out=off[1:])
+    return b"".join(enc) or b"\0", off
+
+
+def results_text(query_ids, net_type: str, mode_label: str, terms, gonames, offsets, term_idx, kept, alignment_data=None) -> bytes:
+    """The text of results.tsv for one GO head (utf-8, the encoding the reference opens the file with), formatted as reference
+    pipeline.py:713-716: query_id, net_type, mode, term, f"{score:.4f}", go_name, then the six alignment fields (nan when
+    unknown) -- assembled by the library (`mdf_results_format_host`) from the filter's arrays, no per-line Python."""
+    L = _hip.lib()
+    off = np.ascontiguousarray(offsets.cpu() if hasattr(offsets, "cpu") else offsets, dtype=np.int32)
+    ti = np.ascontiguousarray(term_idx.cpu() if hasattr(term_idx, "cpu") else term_idx, dtype=np.int32)
+    sc = np.ascontiguousarray(kept.cpu() if hasattr(kept, "cpu") else kept, dtype=np.float32)
+    query_ids = list(query_ids)
+    B = len(query_ids)
+    if len(off) != B + 1:
+        raise ValueError("offsets must hold one entry per query plus one")
+    terms = list(terms)
     names = dict(zip(terms, gonames))
-    lines = []
-    for p, qid in enumerate(query_ids):
-        aln = (alignment_data or {}).get(qid, [np.nan] * 6)
-        aligned, target_id, database, target_identity, query_cov, target_cov = aln
-        for k in range(off[p], off[p + 1]):
-            term = terms[ti[k]]
-            lines.append(f"{qid}\t{net_type}\t{mode_label}\t{term}\t{float(sc[k]):.4f}\t{names.get(term, 'Unknown')}"
-                         f"\t{aligned}\t{target_id}\t{database}\t{target_identity}\t{query_cov}\t{target_cov}\n")
-    return lines
+    qid_b, qid_off = _concat(query_ids)
+    term_b, term_off = _concat(terms)
+    name_b, name_off = _concat([names.get(t, "Unknown") for t in terms])
+    nan6 = "\t".join(["nan"] * 6)
+    if alignment_data:
+        tail_b, tail_off = _concat(["\t".join(map(str, alignment_data[q])) if q in alignment_data else nan6 for q in query_ids])
+        tail_ptr = _hip.ptr(tail_off)
+    else:
+        tail_b, tail_ptr = nan6.encode() + b"\0", None
+    nbytes, nlines = ctypes.c_int64(), ctypes.c_int64()
+    args = (qid_b, _hip.ptr(qid_off), f"{net_type}\t{mode_label}".encode("utf-8"), term_b, _hip.ptr(term_off), name_b, _hip.ptr(name_off), tail_b, tail_ptr,
+            _hip.ptr(off), _hip.ptr(ti), _hip.ptr(sc), B, len(terms))
+    rc = L.mdf_results_format_host(*args, None, 0, ctypes.byref(nbytes), ctypes.byref(nlines))
+    if rc not in (_hip.MDF_OK, _hip.MDF_ECAPACITY):
+        _hip.check(rc)
+    out = np.empty(max(nbytes.value, 1), dtype=np.uint8)
+    _hip.check(L.mdf_results_format_host(*args, _hip.ptr(out), nbytes.value, ctypes.byref(nbytes), ctypes.byref(nlines)))
+    return out[:nbytes.value].tobytes()
+
+
+def results_rows(query_ids, net_type: str, mode_label: str, terms, gonames, offsets, term_idx, kept, alignment_data=None):
+    """The same as a list of lines (str, each ending in a newline)."""
+    return results_text(query_ids, net_type, mode_label, terms, gonames, offsets, term_idx, kept, alignment_data).decode("utf-8").splitlines(keepends=True)

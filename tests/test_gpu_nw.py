@@ -269,3 +269,116 @@ def test_every_tie_rule_matches_the_oracle(tie_rule):
         ops, iden, _, _ = align_pairwise(q, t, 2, 1, sm, tie_rule=tie_rule)
         e_ops, e_iden, _, _, e_score = nwo.align_pairwise(q, t, sm.matrix, sm.alphabet, 2, 1, tie_rule)
         assert ops == e_ops and iden == e_iden, (tie_rule, lq, lt)
+
+
+def _best_hits(sm, seqs, nq, cand, first, lut=True, max_trace=512 << 20, cap=None, tie_rule=0, seq_off=None, text=None, want_cand_scores=True):
+    """mdf_nw_best_hits_host straight through ctypes -> (rc, dict of outputs, info)."""
+    from mDeepFRI import _hip
+    seq_len = np.array([len(s) for s in seqs], dtype=np.int32)
+    if seq_off is None:
+        seq_off = np.concatenate(([0], np.cumsum(seq_len[:-1]))).astype(np.int64)
+        text = np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy()
+    if not lut:
+        text = sm._lut[text]
+    cand, first = np.asarray(cand, dtype=np.int32), np.asarray(first, dtype=np.int64)
+    cap = int(seq_len.sum()) * 2 + 8 if cap is None else cap
+    o = {k: np.zeros(nq, dtype=np.int32) for k in ("best", "score", "op_len", "n_match")}
+    o["off"] = np.zeros(nq + 1, dtype=np.int64)
+    o["ops"], o["qa"], o["ta"] = (np.zeros(max(cap, 1), dtype=np.uint8) for _ in range(3))
+    o["cand_scores"] = np.zeros(len(cand), dtype=np.int32)
+    info = np.zeros(4, dtype=np.int64)
+    rc = _hip.lib().mdf_nw_best_hits_host(_hip.ptr(text), _hip.ptr(seq_off), _hip.ptr(seq_len), len(seqs), _hip.ptr(sm._lut_nocase) if lut else None, nq,
+                                          _hip.ptr(cand), _hip.ptr(first), _hip.ptr(sm.matrix), len(sm.alphabet), 10, 1, tie_rule, sm.alphabet.encode(),
+                                          max_trace, _hip.ptr(o["best"]), _hip.ptr(o["score"]), _hip.ptr(o["op_len"]), _hip.ptr(o["n_match"]),
+                                          _hip.ptr(o["off"]), _hip.ptr(o["ops"]), _hip.ptr(o["qa"]), _hip.ptr(o["ta"]), cap,
+                                          _hip.ptr(o["cand_scores"]) if want_cand_scores else None, _hip.ptr(info))
+    return rc, o, info
+
+
+def _best_hits_case(seed=11, nq=40, ndb=50, lo=20, hi=300):
+    rng = np.random.default_rng(seed)
+    db = [_seq(rng, int(rng.integers(lo, hi))) for _ in range(ndb)]
+    qs = [_mutate(rng, db[int(rng.integers(0, ndb))], 0.2) for _ in range(nq)]
+    cand, first = [], [0]
+    for q in range(nq):
+        ks = rng.choice(ndb, size=int(rng.integers(1, 7)), replace=False)
+        cand += [nq + int(k) for k in ks]
+        first.append(len(cand))
+    return qs + db, cand, first
+
+
+@pytest.mark.parametrize("mode", ["letters", "codes", "small-trace-groups", "tie-rule-5"])
+def test_best_hits_entry_against_the_oracle(mode):
+    """mdf_nw_best_hits_host (one C call: score all candidates, arg-max per query, align the winners, pack in query order): every
+    candidate's score, the first maximum, and the packed alignments are the oracle's -- with letters translated on the device or
+    codes handed in, with the winners split over several alignment launches, and under another tie rule."""
+    from mDeepFRI import _hip
+    sm = _matrix(4)
+    seqs, cand, first = _best_hits_case()
+    nq = len(first) - 1
+    rule = 5 if mode == "tie-rule-5" else 0
+    rc, o, info = _best_hits(sm, seqs, nq, cand, first, lut=mode != "codes", max_trace=(1 << 16) if mode == "small-trace-groups" else 512 << 20, tie_rule=rule)
+    assert rc == 0, _hip.last_error()
+    for q in range(nq):
+        cs = [nwo.nw_score(seqs[q], seqs[t], sm.matrix, sm.alphabet) for t in cand[first[q]:first[q + 1]]]
+        assert o["cand_scores"][first[q]:first[q + 1]].tolist() == cs
+        assert int(o["best"][q]) == int(np.argmax(cs)) and int(o["score"][q]) == max(cs)
+        t = seqs[cand[first[q] + int(o["best"][q])]]
+        ops, iden, _, _, score = nwo.align_pairwise(seqs[q], t, sm.matrix, sm.alphabet, tie_rule=rule)
+        a, b = int(o["off"][q]), int(o["off"][q + 1])
+        assert b - a == int(o["op_len"][q]) == len(ops) and bytes(o["ops"][a:b]).decode() == ops
+        assert (bytes(o["qa"][a:b]).decode(), bytes(o["ta"][a:b]).decode()) == insert_gaps(seqs[q], t, ops)
+        assert int(o["n_match"][q]) == ops.count("M")
+    assert int(info[2]) == int(o["off"][nq])
+
+
+def test_best_hits_entry_errors_lowercase_and_layout():
+    from mDeepFRI import _hip
+    sm = _matrix(4)
+    seqs, cand, first = _best_hits_case(seed=12, nq=6, ndb=8, lo=10, hi=60)
+    nq = 6
+    rc0, ref, _ = _best_hits(sm, seqs, nq, cand, first)
+    assert rc0 == 0
+    # lower-case letters are their capitals (the reference upper-cases what it aligns, alignment.py:152-161)
+    rc, o, _ = _best_hits(sm, [s.lower() if i % 2 else s for i, s in enumerate(seqs)], nq, cand, first)
+    assert rc == 0 and all(np.array_equal(o[k], ref[k]) for k in ("best", "score", "off")) and np.array_equal(o["ops"], ref["ops"])
+    # sequences with bytes between them (an invalid one among those): offsets decide what is a residue
+    seq_len = np.array([len(s) for s in seqs])
+    seq_off = (np.concatenate(([0], np.cumsum(seq_len[:-1]))) + 3 * np.arange(len(seqs))).astype(np.int64)
+    text = np.full(int(seq_off[-1] + seq_len[-1]), ord("#"), dtype=np.uint8)
+    for s, off in zip(seqs, seq_off):
+        text[off:off + len(s)] = np.frombuffer(s.encode(), dtype=np.uint8)
+    rc, o, _ = _best_hits(sm, seqs, nq, cand, first, seq_off=seq_off, text=text)
+    assert rc == 0 and np.array_equal(o["ops"], ref["ops"]) and np.array_equal(o["cand_scores"], ref["cand_scores"])
+    # the FIRST offender in sequence order is reported: sequence 9 position 4 comes before sequence 11 position 0
+    bad = list(seqs)
+    bad[9] = bad[9][:4] + "U" + bad[9][5:]
+    bad[11] = "j" + bad[11][1:]
+    rc, _, info = _best_hits(sm, bad, nq, cand, first)
+    assert rc == _hip.MDF_EBADCHAR and (int(info[0]), int(info[1])) == (9, 4) and "not in the scoring matrix alphabet" in _hip.last_error()
+    rc, _, _ = _best_hits(sm, bad, nq, cand, first, lut=False)            # codes: 255 is outside the alphabet
+    assert rc == _hip.MDF_EINVAL and "outside the alphabet" in _hip.last_error()
+    # capacity: the bytes needed come back
+    rc, _, info = _best_hits(sm, seqs, nq, cand, first, cap=5)
+    assert rc == _hip.MDF_ECAPACITY and int(info[2]) == int(ref["off"][nq])
+    # argument checks
+    assert _best_hits(sm, seqs, nq, cand, [0, 2, 2] + first[3:])[0] == _hip.MDF_EINVAL and "no candidate" in _hip.last_error()
+    assert _best_hits(sm, seqs, nq, [len(seqs)] + cand[1:], first)[0] == _hip.MDF_EINVAL
+    assert _best_hits(sm, seqs, nq, cand, first, tie_rule=8)[0] == _hip.MDF_EINVAL
+    rc, o, _ = _best_hits(sm, seqs, nq, cand, first, want_cand_scores=False)
+    assert rc == 0 and np.array_equal(o["ops"], ref["ops"])
+
+
+def test_batched_queries_empty_and_repeated_calls():
+    sm = _matrix(2)
+    assert len(align_queries_arrays([], [], [], scoring_matrix=sm)) == 0
+    rng = np.random.default_rng(1)
+    db = {f"t{k}": _seq(rng, int(rng.integers(30, 90))) for k in range(5)}
+    qs = [_mutate(rng, db["t2"]).lower(), _mutate(rng, db["t4"])]
+    a = align_queries_arrays(["a", "b"], qs, [db, db], scoring_matrix=sm)
+    b = align_queries_arrays(["a", "b"], qs, [db, db], scoring_matrix=sm)
+    assert a.target_keys == ["t2", "t4"] == b.target_keys and np.array_equal(a.ops, b.ops) and a.query_sequences[0] == qs[0].upper()
+    with pytest.raises(ValueError, match="at least one candidate"):
+        align_queries_arrays(["a"], qs[:1], [{}], scoring_matrix=sm)
+    with pytest.raises(ValueError, match="'u' is not in the scoring matrix alphabet"):
+        align_queries_arrays(["a"], ["acdu"], [db], scoring_matrix=sm)
