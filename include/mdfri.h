@@ -40,6 +40,7 @@ const char *mdf_last_error(void);
 const char *mdf_version(void);
 /* Number of visible HIP devices (0 without a GPU; never fails). */
 int mdf_device_count(void);
+int mdf_current_device(void); /* the calling thread's current HIP device (-1 without a device) */
 
 /* ------------------------------------------------------------------------------------------------
  * Per-call API, host buffers.  Replaces the Cython functions one for one.
@@ -499,8 +500,27 @@ int mdf_nw_align_host(const uint8_t *codes, const int64_t *seq_off, const int32_
  *     n_match, aln_off (nq + 1); ops / q_aln / t_aln packed in query order, query q's columns at [aln_off[q], aln_off[q+1]).
  *     capacity = bytes available in each of ops / q_aln / t_aln (sum over q of Lq + the longest candidate always suffices); too small:
  *     MDF_ECAPACITY with info[2] = bytes needed.  cand_scores (optional, P = first[nq] ints): every candidate's score.
- *   max_trace_bytes: device memory the direction words of one alignment launch may take (the winners are aligned in groups). */
-int mdf_nw_best_hits_host(const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut, int32_t nq,
+ *   max_trace_bytes: device memory the direction words of one alignment launch may take (the winners are aligned in groups).
+ *   ws: what a caller keeps between calls (stream, growable device scratch, pinned staging) on the device it was created for; NULL: the
+ *     calling thread's own on the current device (own stream; kept for the life of the process). */
+typedef struct mdf_nw_workspace mdf_nw_workspace;
+/* stream: the HIP stream the aligner's launches and copies go to (they then sit in THAT stream's order, e.g. between two GCN batches of
+ * the same stream), or NULL for a non-blocking, highest-priority stream owned by the workspace. */
+int mdf_nw_workspace_create(int device, void *stream, mdf_nw_workspace **out);
+void mdf_nw_workspace_free(mdf_nw_workspace *ws);
+/* The same call in three steps, for callers that keep several batches in flight (mDeepFRI.stream.QueryStream): `begin` and `align` only
+ * ENQUEUE (upload + scores + arg-max; alignments of the winners + packing + the copies back into pinned memory), `align` first waits for
+ * the scores of its `begin`, `finish` for the alignments of its `align` -- each for work enqueued one step earlier, so a caller that
+ * interleaves the steps of consecutive batches never waits for the device.  The caller's input buffers are not read after `begin`
+ * returns.  One call in flight per workspace; `abandon` drops it (after an error between the steps).  Arguments as below. */
+int mdf_nw_best_hits_begin(mdf_nw_workspace *ws, const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut,
+                           int32_t nq, const int32_t *cand, const int64_t *first, const int32_t *matrix, int32_t A, int gap_open, int gap_extend,
+                           int tie_rule, const char *alphabet, int64_t max_trace_bytes, int want_cand_scores);
+int mdf_nw_best_hits_align(mdf_nw_workspace *ws, int64_t *info);
+int mdf_nw_best_hits_finish(mdf_nw_workspace *ws, int32_t *best, int32_t *score, int32_t *op_len, int32_t *n_match, int64_t *aln_off, char *ops, char *q_aln,
+                            char *t_aln, int64_t capacity, int32_t *cand_scores, int64_t *info);
+int mdf_nw_best_hits_abandon(mdf_nw_workspace *ws);
+int mdf_nw_best_hits_host(mdf_nw_workspace *ws, const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut, int32_t nq,
                           const int32_t *cand, const int64_t *first, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int tie_rule,
                           const char *alphabet, int64_t max_trace_bytes, int32_t *best, int32_t *score, int32_t *op_len, int32_t *n_match,
                           int64_t *aln_off, char *ops, char *q_aln, char *t_aln, int64_t capacity, int32_t *cand_scores, int64_t *info);

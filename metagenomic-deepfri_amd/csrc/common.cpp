@@ -117,6 +117,8 @@ int mdf_device_count(void)
     return n;
 }
 
+int mdf_current_device(void) { return mdf_device_count() > 0 ? current_device() : -1; }
+
 int mdf_timing_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_t.mu);

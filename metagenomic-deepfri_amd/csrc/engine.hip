@@ -54,7 +54,22 @@ struct mdf_plan {
     mutable std::vector<LmGroup> lm_groups;
     mutable int64_t *d_lm_rows = nullptr;
     mutable int32_t *d_lm_lens = nullptr;
+    // the mirrors are stream-ordered allocations, released in the order of the stream that used the plan last: freeing a plan while
+    // the NEXT batch is running must not wait for the device (hipFree does)
+    mutable hipStream_t last_stream = nullptr;
+    mutable std::vector<int64_t> lm_rows_host;   // sources of the asynchronous uploads of the LSTM grouping: they live with the plan
+    mutable std::vector<int32_t> lm_lens_host;
 };
+
+// release in stream order; a stream that is gone by now (or a runtime without the pool) falls back on the blocking free
+static void plan_release(void *p, hipStream_t st)
+{
+    if (!p) return;
+    if (hipFreeAsync(p, st) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+    }
+}
 
 static std::atomic<uint64_t> g_plan_serial{1};
 
@@ -146,8 +161,8 @@ extern "C" void mdf_plan_free(mdf_plan *pl)
     if (!pl) return;
     if (pl->d_chunk_row_off || pl->d_lm_rows) {
         DeviceGuard g(pl->device);
-        (void)hipFree(pl->d_chunk_row_off);   // one allocation holds both mirrors
-        (void)hipFree(pl->d_lm_rows);
+        plan_release(pl->d_chunk_row_off, pl->last_stream);   // one allocation holds both mirrors
+        plan_release(pl->d_lm_rows, pl->last_stream);
     }
     delete pl;
 }
@@ -194,24 +209,28 @@ extern "C" const int32_t *mdf_plan_grp_off(const mdf_plan *pl, int64_t *count)
 }
 
 // the plan's two descriptor arrays on `device` (uploaded once, synchronously: a plan is made once per batch shape)
-static int plan_mirror(const mdf_plan *pl, int device)
+static int plan_mirror(const mdf_plan *pl, int device, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(pl->mu);
+    const hipStream_t prev = pl->last_stream;
+    pl->last_stream = st;
     if (pl->d_chunk_row_off && pl->device == device) return MDF_OK;
     if (pl->d_chunk_row_off || pl->d_lm_rows) {   // the plan moves to another device: drop the old mirror
         DeviceGuard g(pl->device);
-        (void)hipFree(pl->d_chunk_row_off);
-        (void)hipFree(pl->d_lm_rows);
+        plan_release(pl->d_chunk_row_off, prev);
+        plan_release(pl->d_lm_rows, prev);
         pl->d_chunk_row_off = nullptr;
         pl->d_lm_rows = nullptr;
         pl->lm_key[0] = -1;
     }
     const size_t n1 = pl->chunk_row_off.size(), n2 = pl->grp_off.size();
     int32_t *d = nullptr;
-    MDF_HIP(hipMalloc(reinterpret_cast<void **>(&d), (n1 + n2) * 4 + 256));
-    if (hipMemcpy(d, pl->chunk_row_off.data(), n1 * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d + n1, pl->grp_off.data(), n2 * 4, hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(d);
+    MDF_HIP(hipMallocAsync(reinterpret_cast<void **>(&d), (n1 + n2) * 4 + 256, st));
+    // the sources are the plan's own vectors (pageable: the runtime stages them before it returns); the copies sit in the stream in
+    // front of the kernels that read the mirror
+    if (hipMemcpyAsync(d, pl->chunk_row_off.data(), n1 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d + n1, pl->grp_off.data(), n2 * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
+        plan_release(d, st);
         return fail(MDF_ENODEVICE, "plan: upload of the descriptor arrays failed");
     }
     pl->d_chunk_row_off = d;
@@ -223,7 +242,7 @@ static int plan_mirror(const mdf_plan *pl, int device)
 // Consecutive chunk ranges whose proteins run through the LSTM together: at most `cap` proteins and a time-major workspace
 // (2 x (Lmax+1) x B x H floats) within `ws_bytes`.  The proteins are dealt evenly over the fewest such groups: an LSTM time
 // step costs whole rounds of 256x256 tiles, so a small trailing group would cost as much as a full one.
-static int plan_lm_groups(const mdf_plan *pl, int64_t lm_batch, int64_t ws_bytes, int64_t H)
+static int plan_lm_groups(const mdf_plan *pl, int64_t lm_batch, int64_t ws_bytes, int64_t H, hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(pl->mu);
     if (pl->lm_key[0] == lm_batch && pl->lm_key[1] == ws_bytes && pl->lm_key[2] == H && pl->d_lm_rows) return MDF_OK;
@@ -279,14 +298,18 @@ static int plan_lm_groups(const mdf_plan *pl, int64_t lm_batch, int64_t ws_bytes
         g.Lmax = g.lens_host[0];
         pl->lm_groups.push_back(std::move(g));
     }
-    if (pl->d_lm_rows) (void)hipFree(pl->d_lm_rows);
+    plan_release(pl->d_lm_rows, st);
     pl->d_lm_rows = nullptr;
     char *d = nullptr;
     const size_t rb = align_up(all_rows.size() * 8, 256);
-    MDF_HIP(hipMalloc(reinterpret_cast<void **>(&d), rb + all_lens.size() * 4 + 256));
-    if (hipMemcpy(d, all_rows.data(), all_rows.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d + rb, all_lens.data(), all_lens.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-        (void)hipFree(d);
+    MDF_HIP(hipMallocAsync(reinterpret_cast<void **>(&d), rb + all_lens.size() * 4 + 256, st));
+    if (!pl->lm_rows_host.empty() && hipStreamSynchronize(st) != hipSuccess)   // a re-grouping: the previous upload may still be reading them
+        return fail(MDF_ENODEVICE, "plan: stream synchronisation failed");
+    pl->lm_rows_host.swap(all_rows);
+    pl->lm_lens_host.swap(all_lens);
+    if (hipMemcpyAsync(d, pl->lm_rows_host.data(), pl->lm_rows_host.size() * 8, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d + rb, pl->lm_lens_host.data(), pl->lm_lens_host.size() * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
+        plan_release(d, st);
         return fail(MDF_ENODEVICE, "plan: upload of the LSTM group arrays failed");
     }
     pl->d_lm_rows = reinterpret_cast<int64_t *>(d);
@@ -604,7 +627,7 @@ static int run_chunks(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b,
         }
         return MDF_OK;
     }
-    if (int rc = plan_lm_groups(pl, e->cfg.lm_batch, (int64_t)(e->cfg.lm_workspace_gib * 1073741824.0), e->lm_hidden_max)) return rc;
+    if (int rc = plan_lm_groups(pl, e->cfg.lm_batch, (int64_t)(e->cfg.lm_workspace_gib * 1073741824.0), e->lm_hidden_max, st)) return rc;
     // size the group-level buffers once, for the largest group (growing them between groups would stall the device)
     int64_t rows_max = 0;
     size_t ws_max = 0;
@@ -728,7 +751,7 @@ static std::vector<uint64_t> graph_key(const mdf_engine *e, const mdf_plan *pl, 
 static int forward_alignments_locked(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, float *const *scores, float *const *logits,
                                      hipStream_t st)
 {
-    if (int rc = plan_mirror(pl, e->device)) return rc;
+    if (int rc = plan_mirror(pl, e->device, st)) return rc;
     if (int rc = ensure(e, pl->max_chunk_rows, pl->B, pl->max_len, pl->max_groups)) return rc;
     const bool graphable = e->cfg.graph_max_chunks > 0 && (int)pl->chunks.size() <= e->cfg.graph_max_chunks && e->lms.empty() && !timing_on();
     if (!graphable) {
@@ -847,7 +870,7 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
     DeviceGuard g(e->device);
     MDF_HIP(g.err);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (int rc = plan_mirror(pl, e->device)) return rc;
+    if (int rc = plan_mirror(pl, e->device, st)) return rc;
     if (int rc = ensure(e, pl->max_chunk_rows, pl->B, 0, pl->max_groups)) return rc;
     for (int i = 0; i < 2; ++i)
         if (!e->map_ev[i]) MDF_HIP(hipEventCreateWithFlags(&e->map_ev[i], hipEventDisableTiming));
@@ -1006,7 +1029,7 @@ extern "C" int mdf_seq_engine_forward(mdf_seq_engine *e, const mdf_plan *pl, con
     DeviceGuard g(e->device);
     MDF_HIP(g.err);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (int rc = plan_mirror(pl, e->device)) return rc;
+    if (int rc = plan_mirror(pl, e->device, st)) return rc;
     const int64_t rows = pl->max_chunk_rows;
     if (int rc = e->seq_idx.grow((size_t)rows, nullptr)) return rc;
     if (int rc = e->ws.grow((size_t)(rows / 32 + 1) * 4 + 512, nullptr)) return rc;
@@ -1050,8 +1073,8 @@ extern "C" int mdf_engine_lm_features_host(mdf_engine *e, const mdf_plan *pl, co
     DeviceGuard g(e->device);
     MDF_HIP(g.err);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (int rc = plan_mirror(pl, e->device)) return rc;
-    if (int rc = plan_lm_groups(pl, e->cfg.lm_batch, (int64_t)(e->cfg.lm_workspace_gib * 1073741824.0), e->lm_hidden_max)) return rc;
+    if (int rc = plan_mirror(pl, e->device, st)) return rc;
+    if (int rc = plan_lm_groups(pl, e->cfg.lm_batch, (int64_t)(e->cfg.lm_workspace_gib * 1073741824.0), e->lm_hidden_max, st)) return rc;
     mdf_lm *lm = e->lms[(size_t)which];
     const size_t H = (size_t)mdf_lm_hidden(lm);
     std::vector<float> host;

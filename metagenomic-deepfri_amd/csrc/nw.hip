@@ -879,7 +879,62 @@ int mdf_nw_align_host(const uint8_t *codes, const int64_t *seq_off, const int32_
 
 // Launch order of a pair list: largest DP matrices first (a pair swept by one wave or one workgroup lasts as long as its matrix is
 // large; started last it would run on alone).  order[k] = index of the k-th pair to launch; stable among equal sizes.
-static void order_by_cells(const int32_t *seq_len, const int32_t *pq, const int32_t *pt, int64_t P, std::vector<int32_t> &order)
+}  // extern "C" (the workspace type is C++)
+
+// What one caller of the batched best-hit entry keeps between calls, and the state of its call in flight: a stream (its own --
+// non-blocking, highest priority: next to, not behind, whatever occupies the caller's other streams -- or one the caller names: then
+// the aligner's launches sit in THAT stream's order), growable device scratch for the two phases, pinned staging for what crosses
+// PCIe, two events.  A call is three steps (begin -> align -> finish); only the last two wait, each for work enqueued a step earlier.
+struct mdf_nw_workspace {
+    int device = 0;
+    hipStream_t st = nullptr;
+    bool own_stream = false;
+    Scratch s1, s2;
+    HostStage hs, hs2;
+    hipEvent_t ev1 = nullptr, ev2 = nullptr;
+    int stage = 0;   // 0 idle, 1 scores in flight, 2 alignments in flight
+    // ---- the call in flight
+    int32_t n_seq = 0, nq = 0, P = 0, A = 0;
+    int go = 0, ge = 0, tie_rule = 0;
+    int64_t max_trace = 0, total = 0, cols = 0;
+    bool lut = false, want_cs = false;
+    std::vector<int32_t> seq_len, cand;
+    std::vector<int64_t> seq_off, first;
+    size_t h_text = 0, h_soff = 0, h_slen = 0, h_pq = 0, h_pt = 0, h_rank = 0, h_first = 0, h_mat = 0, h_bo = 0, h_lut = 0, h_al = 0, h_bad = 0, h_up = 0,
+           h_best = 0, h_bsc = 0, h_csc = 0, d_in = 0;
+    size_t g_pq = 0, g_pt = 0, g_slot = 0, g_bo = 0, g_to = 0, g_oo = 0, g_up = 0, g_meta = 0, g_ops = 0, g_qa = 0, g_ta = 0;
+};
+
+namespace {
+
+int nw_workspace_new(int device, hipStream_t stream, mdf_nw_workspace **out)
+{
+    mdf_nw_workspace *w = new (std::nothrow) mdf_nw_workspace();
+    if (!w) return fail(MDF_ENOMEM, "nw_workspace_create: out of memory");
+    w->device = device;
+    hipError_t e = hipSuccess;
+    if (stream) {
+        w->st = stream;
+    } else {
+        int lo = 0, hi = 0;
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        static const char *pr = getenv("MDFRI_NW_STREAM_PRIORITY");   // developer knob: "low" / "normal" (default: highest)
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&w->st, hipStreamNonBlocking, pr && pr[0] == 'l' ? lo : pr && pr[0] == 'n' ? (lo + hi) / 2 : hi);
+        w->own_stream = e == hipSuccess;
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev1, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev2, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        mdf_nw_workspace_free(w);
+        MDF_HIP(e);
+    }
+    *out = w;
+    return MDF_OK;
+}
+
+// Launch order of a pair list: largest DP matrices first (a pair swept by one wave or one workgroup lasts as long as its matrix is
+// large; started last it would run on alone).  order[k] = index of the k-th pair to launch; stable among equal sizes.
+void order_by_cells(const int32_t *seq_len, const int32_t *pq, const int32_t *pt, int64_t P, std::vector<int32_t> &order)
 {
     // LSD radix sort of (descending size key, index): three 11-bit passes over a 32-bit key (cells / 256, saturated), stable
     std::vector<uint32_t> key((size_t)P), key2((size_t)P);
@@ -907,21 +962,75 @@ static void order_by_cells(const int32_t *seq_len, const int32_t *pq, const int3
     if (i0 != order.data()) std::copy(i0, i0 + P, order.data());   // three passes: the result sits in the second buffer
 }
 
-int mdf_nw_best_hits_host(const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut, int32_t nq,
-                          const int32_t *cand, const int64_t *first, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int tie_rule,
-                          const char *alphabet, int64_t max_trace_bytes, int32_t *best, int32_t *score, int32_t *op_len, int32_t *n_match,
-                          int64_t *aln_off, char *ops, char *q_aln, char *t_aln, int64_t capacity, int32_t *cand_scores, int64_t *info)
+struct StageTimer {   // MDFRI_NW_TIMING=1: host milliseconds per step of the batched entry, on stderr (developer knob)
+    bool on;
+    double last;
+    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    StageTimer() : on(getenv("MDFRI_NW_TIMING") != nullptr), last(now()) {}
+    void operator()(const char *what)
+    {
+        if (!on) return;
+        const double t = now();
+        fprintf(stderr, "[nw_best_hits] %-28s %.2f ms\n", what, t - last);
+        last = t;
+    }
+};
+
+// the workspace of a thread that did not bring one: created on first use, per device, kept for the life of the process
+int nw_thread_workspace(mdf_nw_workspace **out)
 {
-    if (info) info[0] = info[1] = info[2] = -1;
-    static const bool tm_on = getenv("MDFRI_NW_TIMING") != nullptr;
-    auto tm_now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double tm_last = tm_now();
-    auto tm = [&](const char *what) { if (tm_on) { double t = tm_now(); fprintf(stderr, "[nw_best_hits] %-28s %.2f ms\n", what, t - tm_last); tm_last = t; } };
+    static thread_local mdf_nw_workspace *tl[MDF_MAX_DEVICES] = {};
+    const int d = current_device();
+    if (!tl[d])
+        if (int rc = nw_workspace_new(d, nullptr, &tl[d])) return rc;
+    *out = tl[d];
+    return MDF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mdf_nw_workspace_create(int device, void *stream, mdf_nw_workspace **out)
+{
+    MDF_REQUIRE(out, "nw_workspace_create: NULL argument");
+    *out = nullptr;
+    if (int rc = require_device()) return rc;
+    int n = 0;
+    MDF_HIP(hipGetDeviceCount(&n));
+    MDF_REQUIRE(device >= 0 && device < n, "nw_workspace_create: device %d not in 0..%d", device, n - 1);
+    DeviceGuard guard(device);
+    MDF_HIP(guard.err);
+    return nw_workspace_new(device, static_cast<hipStream_t>(stream), out);
+}
+
+void mdf_nw_workspace_free(mdf_nw_workspace *w)
+{
+    if (!w) return;
+    DeviceGuard guard(w->device);
+    if (w->st) (void)hipStreamSynchronize(w->st);
+    if (w->st && w->own_stream) (void)hipStreamDestroy(w->st);
+    if (w->ev1) (void)hipEventDestroy(w->ev1);
+    if (w->ev2) (void)hipEventDestroy(w->ev2);
+    if (w->s1.ptr) (void)hipFree(w->s1.ptr);
+    if (w->s2.ptr) (void)hipFree(w->s2.ptr);
+    if (w->hs.ptr) (void)hipHostFree(w->hs.ptr);
+    if (w->hs2.ptr) (void)hipHostFree(w->hs2.ptr);
+    delete w;
+}
+
+// Step 1 (asynchronous): stage and upload the sequences, translate letters, score every (query, candidate) pair -- largest matrices
+// first --, arg-max per query, start the small results on their way back.  The caller's buffers are not read after the return.
+int mdf_nw_best_hits_begin(mdf_nw_workspace *w, const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut,
+                           int32_t nq, const int32_t *cand, const int64_t *first, const int32_t *matrix, int32_t A, int gap_open, int gap_extend,
+                           int tie_rule, const char *alphabet, int64_t max_trace_bytes, int want_cand_scores)
+{
+    MDF_REQUIRE(w, "nw_best_hits_begin: NULL workspace");
+    MDF_REQUIRE(w->stage == 0, "nw_best_hits_begin: the workspace still holds a call in flight (finish it first)");
     MDF_REQUIRE(text && seq_off && seq_len && cand && first && matrix && alphabet, "nw_best_hits: NULL argument");
-    MDF_REQUIRE(best && score && op_len && n_match && aln_off && ops && q_aln && t_aln, "nw_best_hits: NULL output");
     MDF_REQUIRE(n_seq > 0 && nq > 0 && nq <= n_seq, "nw_best_hits: nq=%d queries among n_seq=%d sequences", nq, n_seq);
     MDF_REQUIRE(tie_rule >= 0 && tie_rule < 8, "nw_best_hits: tie_rule=%d not in 0..7", tie_rule);
-    MDF_REQUIRE(capacity >= 0 && max_trace_bytes > 0, "nw_best_hits: bad capacity / trace budget");
+    MDF_REQUIRE(max_trace_bytes > 0, "nw_best_hits: bad trace budget");
     MDF_REQUIRE(first[0] == 0 && first[nq] > 0 && first[nq] < INT32_MAX, "nw_best_hits: candidate offsets must run from 0 to P < 2^31");
     const int32_t P = (int32_t)first[nq];
     if (int rc = nw_check(text, seq_off, seq_len, cand, cand, P, matrix, A, gap_open, gap_extend)) return rc;
@@ -940,175 +1049,254 @@ int mdf_nw_best_hits_host(const uint8_t *text, const int64_t *seq_off, const int
             MDF_REQUIRE(mx < A, "nw_best_hits: a residue code of sequence %d is outside the alphabet (size %d)", s, A);
         }
     if (int rc = require_device()) return rc;
-    tm("validate");
+    DeviceGuard guard(w->device);
+    MDF_HIP(guard.err);
+    StageTimer tm;
+    w->n_seq = n_seq, w->nq = nq, w->P = P, w->A = A, w->go = gap_open, w->ge = gap_extend, w->tie_rule = tie_rule, w->max_trace = max_trace_bytes;
+    w->total = total, w->lut = lut != nullptr, w->want_cs = want_cand_scores != 0;
+    w->seq_len.assign(seq_len, seq_len + n_seq);
+    w->seq_off.assign(seq_off, seq_off + n_seq);
+    w->cand.assign(cand, cand + P);
+    w->first.assign(first, first + nq + 1);
 
-    // ---- phase 1: score every (query, candidate) pair, largest first; arg-max per query on the device -------------------------------------
-    std::vector<int32_t> pq((size_t)P), order, rank((size_t)P);
+    std::vector<int32_t> pq((size_t)P), order;
     for (int32_t q = 0; q < nq; ++q)
         for (int64_t p = first[q]; p < first[q + 1]; ++p) pq[(size_t)p] = q;
     order_by_cells(seq_len, pq.data(), cand, P, order);
     tm("order pairs");
     size_t ho = 0;
     auto htake = [&](size_t bytes) { size_t r = ho; ho = align_up(ho + bytes, 256); return r; };
-    const size_t h_text = htake((size_t)total + 16), h_soff = htake((size_t)n_seq * 8), h_slen = htake((size_t)n_seq * 4), h_pq = htake((size_t)P * 4),
-                 h_pt = htake((size_t)P * 4), h_rank = htake((size_t)P * 4), h_first = htake(((size_t)nq + 1) * 8), h_mat = htake((size_t)A * A * 4),
-                 h_bo = htake(((size_t)P + 1) * 8), h_lut = htake(256), h_al = htake(64), h_bad = htake(8), h_up = ho;
-    const size_t h_best = htake((size_t)nq * 4), h_bsc = htake((size_t)nq * 4);
-    size_t go_ = 0;   // phase 2's staging (sizes depend on nq alone): behind phase 1's, one pinned block for the call
-    auto gtake = [&](size_t bytes) { size_t r = go_; go_ = align_up(go_ + bytes, 256); return r; };
-    const size_t g_pq = gtake((size_t)nq * 4), g_pt = gtake((size_t)nq * 4), g_slot = gtake((size_t)nq * 4), g_bo = gtake(((size_t)nq + 1) * 8),
-                 g_to = gtake(((size_t)nq + 1) * 8), g_oo = gtake(((size_t)nq + 1) * 8), g_up = go_;
-    const size_t g_meta = gtake(((size_t)nq + 1) * 8 + (size_t)nq * 12);
-    HostStage &hs = host_stage();
-    if (int rc = hs.reserve(ho + go_)) return rc;
-    char *h = hs.ptr;
-    memcpy(h + h_text, text, (size_t)total);
+    w->h_text = htake((size_t)total + 16), w->h_soff = htake((size_t)n_seq * 8), w->h_slen = htake((size_t)n_seq * 4), w->h_pq = htake((size_t)P * 4);
+    w->h_pt = htake((size_t)P * 4), w->h_rank = htake((size_t)P * 4), w->h_first = htake(((size_t)nq + 1) * 8), w->h_mat = htake((size_t)A * A * 4);
+    w->h_bo = htake(((size_t)P + 1) * 8), w->h_lut = htake(256), w->h_al = htake(64), w->h_bad = htake(8), w->h_up = ho;
+    w->h_best = htake((size_t)nq * 4), w->h_bsc = htake((size_t)nq * 4), w->h_csc = htake(w->want_cs ? (size_t)P * 4 : 4);
+    if (int rc = w->hs.reserve(ho)) return rc;
+    char *h = w->hs.ptr;
+    memcpy(h + w->h_text, text, (size_t)total);
     if (lut) {   // bytes between two sequences are nobody's residues: make them a letter of the alphabet, so that only real offenders are flagged
         int ok = 0;
         while (ok < 256 && lut[ok] == 255) ++ok;
         MDF_REQUIRE(ok < 256, "nw_best_hits: the letter table maps nothing into the alphabet");
         int64_t end = 0;
         for (int32_t s = 0; s < n_seq; ++s) {
-            if (seq_off[s] > end) memset(h + h_text + end, ok, (size_t)(seq_off[s] - end));
+            if (seq_off[s] > end) memset(h + w->h_text + end, ok, (size_t)(seq_off[s] - end));
             end = seq_off[s] + seq_len[s];
         }
+        memcpy(h + w->h_lut, lut, 256);
     }
-    memcpy(h + h_soff, seq_off, (size_t)n_seq * 8);
-    memcpy(h + h_slen, seq_len, (size_t)n_seq * 4);
-    memcpy(h + h_first, first, ((size_t)nq + 1) * 8);
-    memcpy(h + h_mat, matrix, (size_t)A * A * 4);
-    if (lut) memcpy(h + h_lut, lut, 256);
-    memset(h + h_al, 0, 64);
-    memcpy(h + h_al, alphabet, std::min<size_t>(strlen(alphabet), 63));
-    *reinterpret_cast<unsigned long long *>(h + h_bad) = ~0ull;
-    {
-        int32_t *spq = reinterpret_cast<int32_t *>(h + h_pq), *spt = reinterpret_cast<int32_t *>(h + h_pt), *rk = reinterpret_cast<int32_t *>(h + h_rank);
-        int64_t *bo = reinterpret_cast<int64_t *>(h + h_bo), b = 0;
-        for (int32_t k = 0; k < P; ++k) {
-            const int32_t p = order[(size_t)k];
-            spq[k] = pq[(size_t)p];
-            spt[k] = cand[p];
-            rk[p] = k;
-            bo[k] = b;
-            b += 2 * (int64_t)seq_len[spq[k]];
-        }
-        bo[P] = b;
+    memcpy(h + w->h_soff, seq_off, (size_t)n_seq * 8);
+    memcpy(h + w->h_slen, seq_len, (size_t)n_seq * 4);
+    memcpy(h + w->h_first, first, ((size_t)nq + 1) * 8);
+    memcpy(h + w->h_mat, matrix, (size_t)A * A * 4);
+    memset(h + w->h_al, 0, 64);
+    memcpy(h + w->h_al, alphabet, std::min<size_t>(strlen(alphabet), 63));
+    *reinterpret_cast<unsigned long long *>(h + w->h_bad) = ~0ull;
+    int32_t *spq = reinterpret_cast<int32_t *>(h + w->h_pq), *spt = reinterpret_cast<int32_t *>(h + w->h_pt), *rk = reinterpret_cast<int32_t *>(h + w->h_rank);
+    int64_t *bo = reinterpret_cast<int64_t *>(h + w->h_bo), bnd_ints = 0;
+    for (int32_t k = 0; k < P; ++k) {
+        const int32_t p = order[(size_t)k];
+        spq[k] = pq[(size_t)p];
+        spt[k] = cand[p];
+        rk[p] = k;
+        bo[k] = bnd_ints;
+        bnd_ints += 2 * (int64_t)seq_len[spq[k]];
     }
-    const int64_t bnd_ints = reinterpret_cast<int64_t *>(h + h_bo)[P];
+    bo[P] = bnd_ints;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
-    const size_t d_in = take(h_up), d_bnd = take((size_t)bnd_ints * 4 + 4), d_sc = take((size_t)P * 4), d_best = take((size_t)nq * 4),
-                 d_bsc = take((size_t)nq * 4), d_csc = take(cand_scores ? (size_t)P * 4 : 4);
-    Scratch &s1 = scratch(1);
-    if (int rc = s1.reserve(o)) return rc;
-    char *b1 = static_cast<char *>(s1.ptr);
-    hipStream_t st = nullptr;
+    w->d_in = take(w->h_up);
+    const size_t d_bnd = take((size_t)bnd_ints * 4 + 4), d_sc = take((size_t)P * 4), d_best = take((size_t)nq * 4), d_bsc = take((size_t)nq * 4),
+                 d_csc = take(w->want_cs ? (size_t)P * 4 : 4);
+    if (int rc = w->s1.reserve(o)) return rc;
+    char *b1 = static_cast<char *>(w->s1.ptr);
+    hipStream_t st = w->st;
     tm("stage phase 1");
-    MDF_HIP(hipMemcpyAsync(b1 + d_in, h, h_up, hipMemcpyHostToDevice, st));
-    auto I = [&](size_t off) { return b1 + d_in + off; };
-    if (lut) hipLaunchKernelGGL(k_nw_encode, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, (uint8_t *)I(h_text), total, (const uint8_t *)I(h_lut),
-                                (unsigned long long *)I(h_bad));
-    const int32_t *spq = reinterpret_cast<const int32_t *>(h + h_pq), *spt = reinterpret_cast<const int32_t *>(h + h_pt);
-    if (int rc = mdf_nw_score_dev((const uint8_t *)I(h_text), (const int64_t *)I(h_soff), (const int32_t *)I(h_slen), (const int32_t *)I(h_pq),
-                                  (const int32_t *)I(h_pt), P, mdf_nw_count_long(seq_len, spq, spt, P), (const int32_t *)I(h_mat), A, gap_open, gap_extend,
-                                  (const int64_t *)I(h_bo), (int32_t *)(b1 + d_bnd), (int32_t *)(b1 + d_sc), st))
+    MDF_HIP(hipMemcpyAsync(b1 + w->d_in, h, w->h_up, hipMemcpyHostToDevice, st));
+    auto I = [&](size_t off) { return b1 + w->d_in + off; };
+    if (lut) hipLaunchKernelGGL(k_nw_encode, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, (uint8_t *)I(w->h_text), total, (const uint8_t *)I(w->h_lut),
+                                (unsigned long long *)I(w->h_bad));
+    if (int rc = mdf_nw_score_dev((const uint8_t *)I(w->h_text), (const int64_t *)I(w->h_soff), (const int32_t *)I(w->h_slen), (const int32_t *)I(w->h_pq),
+                                  (const int32_t *)I(w->h_pt), P, mdf_nw_count_long(seq_len, spq, spt, P), (const int32_t *)I(w->h_mat), A, gap_open, gap_extend,
+                                  (const int64_t *)I(w->h_bo), (int32_t *)(b1 + d_bnd), (int32_t *)(b1 + d_sc), st))
         return rc;
-    hipLaunchKernelGGL(k_nw_best, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const int32_t *)(b1 + d_sc), (const int32_t *)I(h_rank),
-                       (const int64_t *)I(h_first), nq, (int32_t *)(b1 + d_best), (int32_t *)(b1 + d_bsc), cand_scores ? (int32_t *)(b1 + d_csc) : nullptr);
+    hipLaunchKernelGGL(k_nw_best, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, st, (const int32_t *)(b1 + d_sc), (const int32_t *)I(w->h_rank),
+                       (const int64_t *)I(w->h_first), nq, (int32_t *)(b1 + d_best), (int32_t *)(b1 + d_bsc), w->want_cs ? (int32_t *)(b1 + d_csc) : nullptr);
     MDF_HIP(hipGetLastError());
-    MDF_HIP(hipMemcpyAsync(h + h_best, b1 + d_best, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    MDF_HIP(hipMemcpyAsync(h + h_bsc, b1 + d_bsc, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
-    MDF_HIP(hipMemcpyAsync(h + h_bad, I(h_bad), 8, hipMemcpyDeviceToHost, st));
-    MDF_HIP(hipStreamSynchronize(st));
-    tm("upload + score + best");
-    if (lut) {
-        const unsigned long long bad = *reinterpret_cast<unsigned long long *>(h + h_bad);
+    MDF_HIP(hipMemcpyAsync(h + w->h_best, b1 + d_best, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    MDF_HIP(hipMemcpyAsync(h + w->h_bsc, b1 + d_bsc, (size_t)nq * 4, hipMemcpyDeviceToHost, st));
+    MDF_HIP(hipMemcpyAsync(h + w->h_bad, I(w->h_bad), 8, hipMemcpyDeviceToHost, st));
+    if (w->want_cs) MDF_HIP(hipMemcpyAsync(h + w->h_csc, b1 + d_csc, (size_t)P * 4, hipMemcpyDeviceToHost, st));
+    MDF_HIP(hipEventRecord(w->ev1, st));
+    w->stage = 1;
+    tm("enqueue phase 1");
+    return MDF_OK;
+}
+
+// Step 2: wait for the scores, then (asynchronous again) align every query with its winner -- in groups whose direction words fit the
+// trace budget --, pack the alignments in query order and start them on their way back.
+int mdf_nw_best_hits_align(mdf_nw_workspace *w, int64_t *info)
+{
+    if (info) info[0] = info[1] = info[2] = -1;
+    MDF_REQUIRE(w && w->stage == 1, "nw_best_hits_align: no scored call in flight on this workspace");
+    DeviceGuard guard(w->device);
+    MDF_HIP(guard.err);
+    StageTimer tm;
+    w->stage = 0;   // any failure below abandons the call
+    MDF_HIP(hipEventSynchronize(w->ev1));
+    tm("wait for scores");
+    char *h = w->hs.ptr;
+    const int32_t nq = w->nq, n_seq = w->n_seq;
+    const int32_t *seq_len = w->seq_len.data();
+    if (w->lut) {
+        const unsigned long long bad = *reinterpret_cast<unsigned long long *>(h + w->h_bad);
         if (bad != ~0ull) {   // the first byte outside the alphabet, in sequence order (offsets ascend)
-            int32_t s = (int32_t)(std::upper_bound(seq_off, seq_off + n_seq, (int64_t)bad) - seq_off) - 1;
+            const int64_t *so = w->seq_off.data();
+            int32_t s = (int32_t)(std::upper_bound(so, so + n_seq, (int64_t)bad) - so) - 1;
             while (s > 0 && seq_len[s] == 0) --s;
-            if (info) info[0] = s, info[1] = (int64_t)bad - seq_off[s];
+            if (info) info[0] = s, info[1] = (int64_t)bad - so[s];
             return fail(MDF_EBADCHAR, "nw_best_hits: character %d at position %lld of sequence %d is not in the scoring matrix alphabet",
-                        (int)text[bad], (long long)((int64_t)bad - seq_off[s]), s);
+                        (int)(uint8_t)h[w->h_text + bad], (long long)((int64_t)bad - so[s]), s);
         }
     }
-    if (cand_scores) MDF_HIP(hipMemcpy(cand_scores, b1 + d_csc, (size_t)P * 4, hipMemcpyDeviceToHost));
-    memcpy(best, h + h_best, (size_t)nq * 4);
-    const int32_t *bsc = reinterpret_cast<const int32_t *>(h + h_bsc);
-
-    // ---- phase 2: full alignment of each query with its winner, in groups whose directions fit the trace budget -----------------------------
-    std::vector<int32_t> wq((size_t)nq), wt((size_t)nq);
-    for (int32_t q = 0; q < nq; ++q) wq[(size_t)q] = q, wt[(size_t)q] = cand[first[q] + best[q]];
+    const int32_t *best = reinterpret_cast<const int32_t *>(h + w->h_best);
+    std::vector<int32_t> wq((size_t)nq), wt((size_t)nq), order;
+    for (int32_t q = 0; q < nq; ++q) wq[(size_t)q] = q, wt[(size_t)q] = w->cand[(size_t)(w->first[(size_t)q] + best[q])];
     order_by_cells(seq_len, wq.data(), wt.data(), nq, order);
-    h = hs.ptr + ho;
-    int32_t *sq = reinterpret_cast<int32_t *>(h + g_pq), *stt = reinterpret_cast<int32_t *>(h + g_pt), *so = reinterpret_cast<int32_t *>(h + g_slot);
+    int64_t cols = 0;
+    for (int32_t q = 0; q < nq; ++q) cols += (int64_t)seq_len[q] + seq_len[wt[(size_t)q]];
+    w->cols = cols;
+    size_t go_ = 0;
+    auto gtake = [&](size_t bytes) { size_t r = go_; go_ = align_up(go_ + bytes, 256); return r; };
+    w->g_pq = gtake((size_t)nq * 4), w->g_pt = gtake((size_t)nq * 4), w->g_slot = gtake((size_t)nq * 4), w->g_bo = gtake(((size_t)nq + 1) * 8);
+    w->g_to = gtake(((size_t)nq + 1) * 8), w->g_oo = gtake(((size_t)nq + 1) * 8), w->g_up = go_;
+    w->g_meta = gtake(((size_t)nq + 1) * 8 + (size_t)nq * 12);
+    w->g_ops = gtake((size_t)cols + 1), w->g_qa = gtake((size_t)cols + 1), w->g_ta = gtake((size_t)cols + 1);
+    if (int rc = w->hs2.reserve(go_)) return rc;
+    char *g = w->hs2.ptr;
+    int32_t *sq = reinterpret_cast<int32_t *>(g + w->g_pq), *stt = reinterpret_cast<int32_t *>(g + w->g_pt), *so = reinterpret_cast<int32_t *>(g + w->g_slot);
     for (int32_t k = 0; k < nq; ++k) {
         const int32_t q = order[(size_t)k];
         sq[k] = q;
         stt[k] = wt[(size_t)q];
         so[q] = k;
     }
-    int64_t *bo2 = reinterpret_cast<int64_t *>(h + g_bo), *to2 = reinterpret_cast<int64_t *>(h + g_to), *oo2 = reinterpret_cast<int64_t *>(h + g_oo);
+    int64_t *bo2 = reinterpret_cast<int64_t *>(g + w->g_bo), *to2 = reinterpret_cast<int64_t *>(g + w->g_to), *oo2 = reinterpret_cast<int64_t *>(g + w->g_oo);
     if (int rc = mdf_nw_plan(seq_len, sq, stt, nq, bo2, to2, oo2)) return rc;
     int64_t max_group = 0;
     std::vector<int32_t> cuts{0};
     for (int32_t p0 = 0; p0 < nq;) {
         int32_t p1 = p0 + 1;
-        while (p1 < nq && to2[p1 + 1] - to2[p0] <= max_trace_bytes) ++p1;
+        while (p1 < nq && to2[p1 + 1] - to2[p0] <= w->max_trace) ++p1;
         max_group = std::max(max_group, to2[p1] - to2[p0]);
         cuts.push_back(p1);
         p0 = p1;
     }
-    const int64_t cols = oo2[nq];
     size_t o2 = 0;
     auto take2 = [&](size_t bytes) { size_t r = o2; o2 = align_up(o2 + bytes, 256); return r; };
-    const size_t e_in = take2(g_up), e_bnd = take2((size_t)bo2[nq] * 4 + 4), e_tr = take2((size_t)max_group + 16), e_ops = take2((size_t)cols + 1),
+    const size_t e_in = take2(w->g_up), e_bnd = take2((size_t)bo2[nq] * 4 + 4), e_tr = take2((size_t)max_group + 16), e_ops = take2((size_t)cols + 1),
                  e_qa = take2((size_t)cols + 1), e_ta = take2((size_t)cols + 1), e_ol = take2((size_t)nq * 4), e_nm = take2((size_t)nq * 4),
                  e_sc = take2((size_t)nq * 4), e_meta = take2(((size_t)nq + 1) * 8 + (size_t)nq * 12), e_pops = take2((size_t)cols + 1),
                  e_pqa = take2((size_t)cols + 1), e_pta = take2((size_t)cols + 1);
-    Scratch &s2 = scratch(2);
-    if (int rc = s2.reserve(o2)) return rc;
-    char *b2 = static_cast<char *>(s2.ptr);
+    if (int rc = w->s2.reserve(o2)) return rc;
+    char *b1 = static_cast<char *>(w->s1.ptr), *b2 = static_cast<char *>(w->s2.ptr);
+    hipStream_t st = w->st;
     tm("plan winners");
-    MDF_HIP(hipMemcpyAsync(b2 + e_in, h, g_up, hipMemcpyHostToDevice, st));
+    MDF_HIP(hipMemcpyAsync(b2 + e_in, g, w->g_up, hipMemcpyHostToDevice, st));
+    auto I = [&](size_t off) { return b1 + w->d_in + off; };
     auto J = [&](size_t off) { return b2 + e_in + off; };
-    for (size_t g = 0; g + 1 < cuts.size(); ++g) {
-        const int32_t p0 = cuts[g], n = cuts[g + 1] - p0;
-        if (int rc = mdf_nw_align_dev((const uint8_t *)I(h_text), (const int64_t *)I(h_soff), (const int32_t *)I(h_slen), (const int32_t *)J(g_pq) + p0,
-                                      (const int32_t *)J(g_pt) + p0, n, mdf_nw_count_long_align(seq_len, sq + p0, stt + p0, n), (const int32_t *)I(h_mat), A,
-                                      gap_open, gap_extend, tie_rule, I(h_al), (const int64_t *)J(g_bo) + p0, (int32_t *)(b2 + e_bnd),
-                                      (const int64_t *)J(g_to) + p0, (uint8_t *)(b2 + e_tr) - to2[p0], (const int64_t *)J(g_oo) + p0, b2 + e_ops, b2 + e_qa,
-                                      b2 + e_ta, (int32_t *)(b2 + e_ol) + p0, (int32_t *)(b2 + e_nm) + p0, (int32_t *)(b2 + e_sc) + p0, st))
+    for (size_t k = 0; k + 1 < cuts.size(); ++k) {
+        const int32_t p0 = cuts[k], n = cuts[k + 1] - p0;
+        if (int rc = mdf_nw_align_dev((const uint8_t *)I(w->h_text), (const int64_t *)I(w->h_soff), (const int32_t *)I(w->h_slen), (const int32_t *)J(w->g_pq) + p0,
+                                      (const int32_t *)J(w->g_pt) + p0, n, mdf_nw_count_long_align(seq_len, sq + p0, stt + p0, n), (const int32_t *)I(w->h_mat),
+                                      w->A, w->go, w->ge, w->tie_rule, I(w->h_al), (const int64_t *)J(w->g_bo) + p0, (int32_t *)(b2 + e_bnd),
+                                      (const int64_t *)J(w->g_to) + p0, (uint8_t *)(b2 + e_tr) - to2[p0], (const int64_t *)J(w->g_oo) + p0, b2 + e_ops,
+                                      b2 + e_qa, b2 + e_ta, (int32_t *)(b2 + e_ol) + p0, (int32_t *)(b2 + e_nm) + p0, (int32_t *)(b2 + e_sc) + p0, st))
             return rc;
     }
     int64_t *m_off = reinterpret_cast<int64_t *>(b2 + e_meta);
     int32_t *m_ol = reinterpret_cast<int32_t *>(m_off + nq + 1), *m_nm = m_ol + nq, *m_sc = m_nm + nq;
-    hipLaunchKernelGGL(k_nw_scan_len, dim3(1), dim3(1024), 0, st, (const int32_t *)J(g_slot), (const int32_t *)(b2 + e_ol), (const int32_t *)(b2 + e_nm),
+    hipLaunchKernelGGL(k_nw_scan_len, dim3(1), dim3(1024), 0, st, (const int32_t *)J(w->g_slot), (const int32_t *)(b2 + e_ol), (const int32_t *)(b2 + e_nm),
                        (const int32_t *)(b2 + e_sc), nq, m_off, m_ol, m_nm, m_sc);
-    hipLaunchKernelGGL(k_nw_pack, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, (const int32_t *)J(g_slot), (const int64_t *)J(g_oo), (const int64_t *)m_off, nq,
+    hipLaunchKernelGGL(k_nw_pack, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, st, (const int32_t *)J(w->g_slot), (const int64_t *)J(w->g_oo), (const int64_t *)m_off, nq,
                        (const char *)(b2 + e_ops), (const char *)(b2 + e_qa), (const char *)(b2 + e_ta), b2 + e_pops, b2 + e_pqa, b2 + e_pta);
     MDF_HIP(hipGetLastError());
-    MDF_HIP(hipMemcpyAsync(h + g_meta, b2 + e_meta, ((size_t)nq + 1) * 8 + (size_t)nq * 12, hipMemcpyDeviceToHost, st));
-    MDF_HIP(hipStreamSynchronize(st));
-    tm("align + pack");
-    const int64_t *r_off = reinterpret_cast<const int64_t *>(h + g_meta);
+    // the packed length is known on the device only: the capacity bound travels (a global alignment has at most Lq + Lt columns)
+    MDF_HIP(hipMemcpyAsync(g + w->g_meta, b2 + e_meta, ((size_t)nq + 1) * 8 + (size_t)nq * 12, hipMemcpyDeviceToHost, st));
+    if (cols > 0) {
+        MDF_HIP(hipMemcpyAsync(g + w->g_ops, b2 + e_pops, (size_t)cols, hipMemcpyDeviceToHost, st));
+        MDF_HIP(hipMemcpyAsync(g + w->g_qa, b2 + e_pqa, (size_t)cols, hipMemcpyDeviceToHost, st));
+        MDF_HIP(hipMemcpyAsync(g + w->g_ta, b2 + e_pta, (size_t)cols, hipMemcpyDeviceToHost, st));
+    }
+    MDF_HIP(hipEventRecord(w->ev2, st));
+    w->stage = 2;
+    tm("enqueue phase 2");
+    return MDF_OK;
+}
+
+// Step 3: wait for the alignments and hand everything out.
+int mdf_nw_best_hits_finish(mdf_nw_workspace *w, int32_t *best, int32_t *score, int32_t *op_len, int32_t *n_match, int64_t *aln_off, char *ops, char *q_aln,
+                            char *t_aln, int64_t capacity, int32_t *cand_scores, int64_t *info)
+{
+    if (info) info[0] = info[1] = info[2] = -1;
+    MDF_REQUIRE(w && w->stage == 2, "nw_best_hits_finish: no aligned call in flight on this workspace");
+    MDF_REQUIRE(best && score && op_len && n_match && aln_off && ops && q_aln && t_aln && capacity >= 0, "nw_best_hits: NULL output");
+    MDF_REQUIRE(!cand_scores || w->want_cs, "nw_best_hits_finish: candidate scores were not asked for at begin");
+    DeviceGuard guard(w->device);
+    MDF_HIP(guard.err);
+    StageTimer tm;
+    w->stage = 0;
+    MDF_HIP(hipEventSynchronize(w->ev2));
+    tm("wait for alignments");
+    const int32_t nq = w->nq;
+    const char *h = w->hs.ptr, *g = w->hs2.ptr;
+    const int64_t *r_off = reinterpret_cast<const int64_t *>(g + w->g_meta);
     const int32_t *r_ol = reinterpret_cast<const int32_t *>(r_off + nq + 1), *r_nm = r_ol + nq, *r_sc = r_nm + nq;
+    const int32_t *bsc = reinterpret_cast<const int32_t *>(h + w->h_bsc);
+    memcpy(best, h + w->h_best, (size_t)nq * 4);
     memcpy(aln_off, r_off, ((size_t)nq + 1) * 8);
     memcpy(op_len, r_ol, (size_t)nq * 4);
     memcpy(n_match, r_nm, (size_t)nq * 4);
     memcpy(score, r_sc, (size_t)nq * 4);
+    if (cand_scores) memcpy(cand_scores, h + w->h_csc, (size_t)w->P * 4);
     for (int32_t q = 0; q < nq; ++q)
         if (r_sc[q] != bsc[q])
             return fail(MDF_EINVAL, "nw_best_hits: internal error: the full alignment of query %d scores %d, score mode said %d", q, r_sc[q], bsc[q]);
     if (info) info[2] = r_off[nq];
     if (r_off[nq] > capacity)
         return fail(MDF_ECAPACITY, "nw_best_hits: the alignments have %lld columns, capacity is %lld", (long long)r_off[nq], (long long)capacity);
-    if (r_off[nq] > 0) {
-        MDF_HIP(hipMemcpy(ops, b2 + e_pops, (size_t)r_off[nq], hipMemcpyDeviceToHost));
-        MDF_HIP(hipMemcpy(q_aln, b2 + e_pqa, (size_t)r_off[nq], hipMemcpyDeviceToHost));
-        MDF_HIP(hipMemcpy(t_aln, b2 + e_pta, (size_t)r_off[nq], hipMemcpyDeviceToHost));
-    }
-    tm("download");
+    if (r_off[nq] > w->cols) return fail(MDF_EINVAL, "nw_best_hits: internal error: %lld columns exceed the bound %lld", (long long)r_off[nq], (long long)w->cols);
+    memcpy(ops, g + w->g_ops, (size_t)r_off[nq]);
+    memcpy(q_aln, g + w->g_qa, (size_t)r_off[nq]);
+    memcpy(t_aln, g + w->g_ta, (size_t)r_off[nq]);
+    tm("hand out");
     return MDF_OK;
+}
+
+int mdf_nw_best_hits_abandon(mdf_nw_workspace *w)
+{
+    MDF_REQUIRE(w, "nw_best_hits_abandon: NULL workspace");
+    DeviceGuard guard(w->device);
+    if (w->stage) (void)hipStreamSynchronize(w->st);   // the copies in flight write into the workspace's own staging: let them land
+    w->stage = 0;
+    return MDF_OK;
+}
+
+int mdf_nw_best_hits_host(mdf_nw_workspace *ws, const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut, int32_t nq,
+                          const int32_t *cand, const int64_t *first, const int32_t *matrix, int32_t A, int gap_open, int gap_extend, int tie_rule,
+                          const char *alphabet, int64_t max_trace_bytes, int32_t *best, int32_t *score, int32_t *op_len, int32_t *n_match,
+                          int64_t *aln_off, char *ops, char *q_aln, char *t_aln, int64_t capacity, int32_t *cand_scores, int64_t *info)
+{
+    if (info) info[0] = info[1] = info[2] = -1;
+    MDF_REQUIRE(best && score && op_len && n_match && aln_off && ops && q_aln && t_aln && capacity >= 0, "nw_best_hits: NULL output");
+    if (!ws) {
+        if (int rc = require_device()) return rc;
+        if (int rc = nw_thread_workspace(&ws)) return rc;
+    }
+    if (int rc = mdf_nw_best_hits_begin(ws, text, seq_off, seq_len, n_seq, lut, nq, cand, first, matrix, A, gap_open, gap_extend, tie_rule, alphabet,
+                                        max_trace_bytes, cand_scores != nullptr))
+        return rc;
+    if (int rc = mdf_nw_best_hits_align(ws, info)) return rc;
+    return mdf_nw_best_hits_finish(ws, best, score, op_len, n_match, aln_off, ops, q_aln, t_aln, capacity, cand_scores, info);
 }
 
 }  // extern "C"

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mdf_last_error": (c_char_p, []),
     "mdf_version": (c_char_p, []),
     "mdf_device_count": (c_int, []),
+    "mdf_current_device": (c_int, []),
     "mdf_pairwise_sqeuclidean_f32": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int]),
     "mdf_threshold_lt_i32": (c_int, [c_void_p, c_int64, c_float, c_void_p]),
     "mdf_threshold_lt_f64_i32": (c_int, [c_void_p, c_int64, c_double, c_void_p]),
@@ -171,7 +172,14 @@ SIGNATURES = {
     "mdf_nw_score_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_void_p]),
     "mdf_nw_align_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int, c_int, c_int, c_char_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "mdf_nw_best_hits_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_int,
+    "mdf_nw_workspace_create": (c_int, [c_int, c_void_p, POINTER(c_void_p)]),
+    "mdf_nw_best_hits_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int,
+                                       c_int, c_char_p, c_int64, c_int]),
+    "mdf_nw_best_hits_align": (c_int, [c_void_p, c_void_p]),
+    "mdf_nw_best_hits_finish": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "mdf_nw_best_hits_abandon": (c_int, [c_void_p]),
+    "mdf_nw_workspace_free": (None, [c_void_p]),
+    "mdf_nw_best_hits_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_int,
                                       c_char_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p]),
     "mdf_results_format_host": (c_int, [c_void_p, c_void_p, c_char_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -251,3 +259,7 @@ def ptr(a):
 
 def device_count() -> int:
     return int(lib().mdf_device_count())
+
+
+def current_device() -> int:
+    return int(lib().mdf_current_device())

@@ -13,6 +13,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import ctypes
+import threading
 from itertools import islice
 
 import numpy as np
@@ -289,18 +291,101 @@ class AlignedBatch:
         return out
 
 
-def align_queries_arrays(query_ids, query_sequences, target_sequences, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80") -> AlignedBatch:
-    """Batched `pairwise_against_database` over many queries (reference alignment.py:266-320: one pool task per query).
-    target_sequences: one {key: sequence} dict per query (its candidate set).  One score launch over all candidates, one
-    alignment launch over the winners; queries with an empty candidate set are not allowed (the reference never builds them)."""
+class AlignerWorkspace:
+    """What a long-lived caller of the batched aligner keeps between calls (`mdf_nw_workspace`: a stream, device scratch, pinned
+    staging, the state of one call in flight) on one device; freed with the object.  `stream`: a HIP stream handle (int) the aligner's
+    launches go to -- they then sit in that stream's order --, None for a stream of the workspace's own.  Without a workspace a
+    call uses the calling thread's own, which lives as long as the process."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        import weakref
+        L = _hip.lib()
+        h = ctypes.c_void_p()
+        _hip.check(L.mdf_nw_workspace_create(int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h)))
+        self.handle, self.device = h, int(device)
+        weakref.finalize(self, L.mdf_nw_workspace_free, h)
+
+
+class PendingAlignment:
+    """A batch of queries on its way through the aligner (`mdf_nw_best_hits_begin` / `_align` / `_finish`): built by
+    `align_queries_begin` (scores enqueued), `launch_alignments()` waits for the scores and enqueues the winners' alignments,
+    `result()` waits for those and returns the AlignedBatch.  Each wait is for work enqueued one step earlier."""
+
+    def __init__(self, workspace, query_ids, seqs, nq, target_sequences, first, cand, cap, joined):
+        self.workspace, self.query_ids, self.seqs, self.nq = workspace, query_ids, seqs, nq
+        self.target_sequences, self.first, self.cand, self.cap, self.joined = target_sequences, first, cand, cap, joined
+        self.stage = 1
+
+    def _fail(self, rc, info):
+        self.stage = 0
+        if rc == _hip.MDF_EBADCHAR:
+            raise ValueError(f"character {self.seqs[int(info[0])][int(info[1])]!r} is not in the scoring matrix alphabet")
+        _hip.check(rc)
+
+    def launch_alignments(self):
+        if self.stage != 1:
+            raise RuntimeError("launch_alignments: the scores of this batch are not in flight")
+        info = np.zeros(4, dtype=np.int64)
+        rc = _hip.lib().mdf_nw_best_hits_align(self.workspace.handle, _hip.ptr(info))
+        if rc:
+            self._fail(rc, info)
+        self.stage = 2
+        return self
+
+    def result(self) -> "AlignedBatch":
+        if self.stage == 1:
+            self.launch_alignments()
+        if self.stage != 2:
+            raise RuntimeError("result: no alignments in flight for this batch")
+        nq, cap = self.nq, self.cap
+        ops, qa, ta = (np.empty(cap, dtype=np.uint8) for _ in range(3))
+        best, score, op_len, n_match = (np.empty(nq, dtype=np.int32) for _ in range(4))
+        off = np.empty(nq + 1, dtype=np.int64)
+        info = np.zeros(4, dtype=np.int64)
+        rc = _hip.lib().mdf_nw_best_hits_finish(self.workspace.handle, _hip.ptr(best), _hip.ptr(score), _hip.ptr(op_len), _hip.ptr(n_match), _hip.ptr(off),
+                                                _hip.ptr(ops), _hip.ptr(qa), _hip.ptr(ta), cap, None, _hip.ptr(info))
+        if rc:
+            self._fail(rc, info)
+        self.stage = 0
+        n = int(off[-1])
+        seqs, joined = self.seqs, self.joined
+        # the reference upper-cases every sequence it aligns (alignment.py:152-161); the usual input already is
+        upper = seqs if joined.isupper() or not joined else "\n".join(seqs).upper().split("\n")
+        bt = self.cand[self.first[:-1] + best]
+        res = {"ops": ops[:n], "q_aln": qa[:n], "t_aln": ta[:n], "off": off, "op_len": op_len, "n_match": n_match, "score": score}
+        return AlignedBatch(self.query_ids, upper[:nq], [next(islice(d, b, None)) for d, b in zip(self.target_sequences, best.tolist())],
+                            [upper[j] for j in bt.tolist()], best.astype(np.int64), res)
+
+    def abandon(self):
+        if self.stage:
+            _hip.lib().mdf_nw_best_hits_abandon(self.workspace.handle)
+            self.stage = 0
+
+
+_thread_state = threading.local()
+
+
+def _thread_workspace() -> AlignerWorkspace:
+    """The calling thread's own workspace on its current device (freed when the thread ends)."""
+    dev = _hip.current_device()
+    if dev < 0:
+        raise _hip.MdfriError(_hip.MDF_ENODEVICE, "no HIP device: the aligner has no CPU fallback")
+    table = _thread_state.__dict__.setdefault("workspaces", {})
+    if dev not in table:
+        table[dev] = AlignerWorkspace(dev)
+    return table[dev]
+
+
+def align_queries_begin(query_ids, query_sequences, target_sequences, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80",
+                        workspace: Optional[AlignerWorkspace] = None) -> Optional[PendingAlignment]:
+    """First step of `align_queries_arrays`: stage the sequences and ENQUEUE the score launch over every (query, candidate) pair and
+    the arg-max per query.  Returns a PendingAlignment (None for an empty batch); one batch in flight per workspace."""
     sm = _matrix(scoring_matrix)
     query_ids = list(query_ids)
     seqs = list(query_sequences)
     nq = len(seqs)
     if nq == 0:
-        z = np.zeros(0, np.int32)
-        return AlignedBatch([], [], [], [], np.zeros(0, np.int64), {"ops": np.zeros(0, np.uint8), "q_aln": np.zeros(0, np.uint8), "t_aln": np.zeros(0, np.uint8),
-                                                                   "off": np.zeros(1, np.int64), "op_len": z, "n_match": z, "score": z})
+        return None
     target_sequences = list(target_sequences)
     first = np.zeros(nq + 1, dtype=np.int64)
     np.cumsum(np.fromiter(map(len, target_sequences), dtype=np.int64, count=nq), out=first[1:])
@@ -321,23 +406,29 @@ def align_queries_arrays(query_ids, query_sequences, target_sequences, gap_open:
     if text.size == 0:
         text = np.zeros(1, np.uint8)
     cap = max(int(seq_len[:nq].sum(dtype=np.int64) + np.maximum.reduceat(seq_len[cand], first[:-1]).sum(dtype=np.int64)), 1)
-    ops, qa, ta = (np.empty(cap, dtype=np.uint8) for _ in range(3))
-    best, score, op_len, n_match = (np.empty(nq, dtype=np.int32) for _ in range(4))
-    off = np.empty(nq + 1, dtype=np.int64)
-    info = np.zeros(4, dtype=np.int64)
-    rc = _hip.lib().mdf_nw_best_hits_host(_hip.ptr(text), _hip.ptr(seq_off), _hip.ptr(seq_len), len(seqs), _hip.ptr(sm._lut_nocase), nq, _hip.ptr(cand),
-                                          _hip.ptr(first), _hip.ptr(sm.matrix), len(sm.alphabet), int(gap_open), int(gap_extend), int(TIE_RULE),
-                                          sm.alphabet.encode("ascii"), int(MAX_TRACE_BYTES), _hip.ptr(best), _hip.ptr(score), _hip.ptr(op_len),
-                                          _hip.ptr(n_match), _hip.ptr(off), _hip.ptr(ops), _hip.ptr(qa), _hip.ptr(ta), cap, None, _hip.ptr(info))
-    if rc == _hip.MDF_EBADCHAR:
-        raise ValueError(f"character {seqs[int(info[0])][int(info[1])]!r} is not in the scoring matrix alphabet")
-    _hip.check(rc)
-    n = int(off[-1])
-    # the reference upper-cases every sequence it aligns (alignment.py:152-161); the usual input already is
-    upper = seqs if joined.isupper() or not joined else "\n".join(seqs).upper().split("\n")
-    bt = cand[first[:-1] + best]
-    res = {"ops": ops[:n], "q_aln": qa[:n], "t_aln": ta[:n], "off": off, "op_len": op_len, "n_match": n_match, "score": score}
-    return AlignedBatch(query_ids, upper[:nq], [next(islice(d, b, None)) for d, b in zip(target_sequences, best.tolist())], [upper[j] for j in bt.tolist()], best.astype(np.int64), res)
+    ws = workspace if workspace is not None else _thread_workspace()
+    _hip.check(_hip.lib().mdf_nw_best_hits_begin(ws.handle, _hip.ptr(text), _hip.ptr(seq_off), _hip.ptr(seq_len), len(seqs), _hip.ptr(sm._lut_nocase), nq,
+                                                _hip.ptr(cand), _hip.ptr(first), _hip.ptr(sm.matrix), len(sm.alphabet), int(gap_open), int(gap_extend),
+                                                int(TIE_RULE), sm.alphabet.encode("ascii"), int(MAX_TRACE_BYTES), 0))
+    return PendingAlignment(ws, query_ids, seqs, nq, target_sequences, first, cand, cap, joined)
+
+
+def align_queries_arrays(query_ids, query_sequences, target_sequences, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80",
+                         workspace: Optional[AlignerWorkspace] = None) -> AlignedBatch:
+    """Batched `pairwise_against_database` over many queries (reference alignment.py:266-320: one pool task per query).
+    target_sequences: one {key: sequence} dict per query (its candidate set).  Everything between the host lists and the host arrays
+    happens in the library (`mdf_nw_best_hits_*`): a score launch over all candidates, the arg-max per query, alignment launches over
+    the winners, packing in query order; queries with an empty candidate set are not allowed (the reference never builds them)."""
+    pending = align_queries_begin(query_ids, query_sequences, target_sequences, gap_open, gap_extend, scoring_matrix, workspace)
+    if pending is None:
+        z = np.zeros(0, np.int32)
+        return AlignedBatch([], [], [], [], np.zeros(0, np.int64), {"ops": np.zeros(0, np.uint8), "q_aln": np.zeros(0, np.uint8), "t_aln": np.zeros(0, np.uint8),
+                                                                   "off": np.zeros(1, np.int64), "op_len": z, "n_match": z, "score": z})
+    try:
+        return pending.result()
+    except BaseException:
+        pending.abandon()
+        raise
 
 
 def align_queries(query_ids, query_sequences, target_sequences, gap_open: int = 10, gap_extend: int = 1, scoring_matrix="VTML80"):

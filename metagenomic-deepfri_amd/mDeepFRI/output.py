@@ -12,31 +12,40 @@ from . import _hip
 FINAL_OUTPUT_COLUMNS = 12  # query, net_type, mode, term, score, name + 6 alignment fields (pipeline.py:713-716)
 
 
-def filter_scores(scores, threshold: float = 0.1, capacity_per_protein: int = 64):
-    """scores: torch float32 CUDA tensor (B, T).  Returns (offsets int32 (B+1), term_idx int32 (N), kept float32 (N)) as
-    torch tensors on the same device: protein p keeps term_idx[offsets[p]:offsets[p+1]], ordered by descending score
-    with ties in term order (Python's stable `sorted(..., reverse=True)`).  Synchronises once (to size the result)."""
+def filter_scores_async(scores, threshold: float = 0.1, capacity: int = 0):
+    """The filter's launches on the current stream, no synchronisation: -> (offsets (B+1), term_idx (capacity), kept (capacity),
+    status (4)) device tensors.  After a sync: status[0] != 0 means `capacity` was too small (status[1] = entries needed);
+    otherwise the first offsets[-1] entries of term_idx / kept are the result (see filter_scores)."""
     import torch
     if not (scores.is_cuda and scores.dtype == torch.float32 and scores.dim() == 2 and scores.is_contiguous()):
         raise ValueError("scores must be a contiguous float32 CUDA tensor of shape (B, T)")
     L = _hip.lib()
     B, T = scores.shape
     dev = scores.device
-    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    ws = torch.empty(L.mdf_filter_workspace_bytes(B), dtype=torch.uint8, device=dev)
-    offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
-    cap = max(int(B) * int(capacity_per_protein), 1024)
+    cap = max(int(capacity), 1024)
     with torch.cuda.device(dev):
-        while True:
-            status = torch.zeros(4, dtype=torch.int32, device=dev)
-            term_idx = torch.empty(cap, dtype=torch.int32, device=dev)
-            kept = torch.empty(cap, dtype=torch.float32, device=dev)
-            _hip.check(L.mdf_filter_scores_dev(_hip.ptr(scores), B, T, float(threshold), _hip.ptr(offsets), _hip.ptr(term_idx),
-                                               _hip.ptr(kept), cap, _hip.ptr(status), _hip.ptr(ws), ws.numel(), st))
-            s = status.cpu().numpy()
-            if s[0] == 0:
-                break
-            cap = int(s[1]) + 16
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        ws = torch.empty(L.mdf_filter_workspace_bytes(B), dtype=torch.uint8, device=dev)
+        offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        status = torch.zeros(4, dtype=torch.int32, device=dev)
+        term_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+        kept = torch.empty(cap, dtype=torch.float32, device=dev)
+        _hip.check(L.mdf_filter_scores_dev(_hip.ptr(scores), B, T, float(threshold), _hip.ptr(offsets), _hip.ptr(term_idx),
+                                           _hip.ptr(kept), cap, _hip.ptr(status), _hip.ptr(ws), ws.numel(), st))
+    return offsets, term_idx, kept, status
+
+
+def filter_scores(scores, threshold: float = 0.1, capacity_per_protein: int = 64):
+    """scores: torch float32 CUDA tensor (B, T).  Returns (offsets int32 (B+1), term_idx int32 (N), kept float32 (N)) as
+    torch tensors on the same device: protein p keeps term_idx[offsets[p]:offsets[p+1]], ordered by descending score
+    with ties in term order (Python's stable `sorted(..., reverse=True)`).  Synchronises once (to size the result)."""
+    cap = int(scores.shape[0]) * int(capacity_per_protein)
+    while True:
+        offsets, term_idx, kept, status = filter_scores_async(scores, threshold, cap)
+        s = status.cpu().numpy()
+        if s[0] == 0:
+            break
+        cap = int(s[1]) + 16
     n = int(offsets[-1].item())
     return offsets, term_idx[:n], kept[:n]
 

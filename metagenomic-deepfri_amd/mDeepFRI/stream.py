@@ -15,7 +15,7 @@ import threading
 import numpy as np
 
 from . import _hip
-from .batch import HotPathEngine, PackedProteins
+from .batch import HotPathEngine, PackedProteins, DeviceBatch
 
 
 def _fields(item):
@@ -109,3 +109,122 @@ class AlignmentStream:
             for m, a in res.items():
                 parts.setdefault(m, []).append(a)
         return {m: np.concatenate(v, axis=0) for m, v in parts.items()}
+
+
+class QueryStream:
+    """The stages either side of the path as ONE stream over arbitrarily many queries: queries + candidate sets -> best hit and
+    alignment (GPU aligner, reference alignment.py:223-320) -> C-alpha trace of the hit -> fused contact map + GCN (pipeline.py:476-481,
+    292-319) -> the `score >= threshold` filter of results.tsv (pipeline.py:696-705), batch by batch.
+
+    One host thread, one device stream, a software pipeline four batches deep.  Step t ENQUEUES, in this order: the score launch of
+    batch t (`mdf_nw_best_hits_begin`), the winners' alignments of batch t-1 (`_align`: needs the scores of t-1, enqueued a step ago),
+    upload + contact maps + GCN + filter of batch t-2 (needs its alignments, enqueued a step ago) -- and then collects batch t-3.
+    Every wait is for work that sits at least one whole GCN batch further up the stream, so the host never holds the device up, and
+    because everything is in ONE stream the aligner's kernels run between two GCN batches, not among their GEMMs (co-resident they cost
+    the GEMMs five times the aligner's own time).  Uploads and the collection of results go through a second, high-priority stream: a
+    copy must not queue behind the batch in flight (streams of equal priority may share a hardware queue).
+
+    engine: HotPathEngine.  structures: mapping target key -> float32 (Lt, 3) C-alpha trace (`.get`; a hit without one is dropped, as
+    pipeline.py:485 does).  batch_size: queries per device batch."""
+
+    def __init__(self, engine: HotPathEngine, structures, batch_size: int = 4000, max_rows: int = 65536, scoring_matrix="VTML80",
+                 gap_open: int = 10, gap_extend: int = 1, threshold: float = 0.1, capacity_per_protein: int = 64):
+        import torch
+        from .alignment import AlignerWorkspace
+        self.engine, self.structures = engine, structures
+        self.batch_size, self.max_rows = int(batch_size), int(max_rows)
+        self.scoring_matrix, self.gap_open, self.gap_extend = scoring_matrix, int(gap_open), int(gap_extend)
+        self.threshold, self.capacity_per_protein = float(threshold), int(capacity_per_protein)
+        self.main, self.side = torch.cuda.Stream(engine.device), torch.cuda.Stream(engine.device, priority=-1)
+        self.ring = [AlignerWorkspace(engine.device.index or 0, stream=self.main.cuda_stream) for _ in range(3)]
+
+    def run(self, query_ids, query_sequences, target_sequences):
+        """Generator over (first_index, AlignedBatch, kept, {mode: (offsets, term_idx, scores)}) in input order: `kept` = positions
+        inside the batch that had a structure; the arrays (numpy) are the filter's output for those proteins, what
+        mDeepFRI.output.results_text takes."""
+        import torch
+        from .alignment import align_queries_begin
+        query_ids, query_sequences, target_sequences = list(query_ids), list(query_sequences), list(target_sequences)
+        starts = list(range(0, len(query_ids), self.batch_size))
+        nb = len(starts)
+        aligning, running = {}, {}
+        try:
+            with torch.cuda.device(self.engine.device):
+                for t in range(nb + 3):
+                    if t < nb:
+                        a, b = starts[t], min(starts[t] + self.batch_size, len(query_ids))
+                        aligning[t] = align_queries_begin(query_ids[a:b], query_sequences[a:b], target_sequences[a:b], self.gap_open, self.gap_extend,
+                                                          self.scoring_matrix, workspace=self.ring[t % 3])
+                    if 0 <= t - 1 < nb:
+                        aligning[t - 1].launch_alignments()
+                    if 0 <= t - 2 < nb:
+                        running[t - 2] = self._enqueue(starts[t - 2], aligning.pop(t - 2).result())
+                    if 0 <= t - 3 < nb:
+                        yield self._finish(running.pop(t - 3))
+        finally:
+            for p in aligning.values():      # an exception (or an abandoned generator) leaves batches in flight: drop them
+                p.abandon()
+
+    def _enqueue(self, first, batch):
+        import torch
+        from .output import filter_scores_async
+        eng, main, side = self.engine, self.main, self.side
+        coords = [self.structures.get(k) for k in batch.target_keys]
+        if not any(c is not None for c in coords):
+            return first, batch, [], None
+        pk, kept = PackedProteins.from_aligned_batch(batch, coords, max_rows=self.max_rows)
+        with torch.cuda.stream(side):      # the upload does not queue behind the batch in flight
+            db = DeviceBatch(pk, eng.device)
+        main.wait_stream(side)
+        with torch.cuda.stream(main):
+            out = eng.forward_alignments(db)
+            filt = {m: filter_scores_async(t, self.threshold, db.B * self.capacity_per_protein) for m, t in out.items()}
+            small = {m: (torch.empty(f[0].shape, dtype=f[0].dtype, pin_memory=True), torch.empty(4, dtype=torch.int32, pin_memory=True))
+                     for m, f in filt.items()}
+            for m, f in filt.items():
+                small[m][0].copy_(f[0], non_blocking=True)
+                small[m][1].copy_(f[3], non_blocking=True)
+            # the validity flags travel with the results: reading them later must not queue behind the next batch
+            flags = (torch.empty(db.bad.shape, dtype=db.bad.dtype, pin_memory=True), torch.empty(db.status.shape, dtype=db.status.dtype, pin_memory=True))
+            flags[0].copy_(db.bad, non_blocking=True)
+            flags[1].copy_(db.status, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(main)
+        return first, batch, kept, (db, pk, out, filt, small, flags, ev)
+
+    def _finish(self, pending):
+        import torch
+        from .output import filter_scores
+        first, batch, kept, work = pending
+        if work is None:
+            return first, batch, kept, {}
+        db, pk, out, filt, small, flags, ev = work
+        eng, side = self.engine, self.side
+        ev.synchronize()
+        try:
+            eng.raise_flags(pk, flags[0].numpy(), flags[1].numpy())
+        except _hip.CapacityError:   # rare: a denser batch than the CSR capacity planned for; redo it synchronously
+            with torch.cuda.stream(side):
+                res = {}
+                for m, a in eng.run_alignments(pk).items():
+                    o, ti, sc = filter_scores(torch.from_numpy(a).to(eng.device), self.threshold, self.capacity_per_protein)
+                    res[m] = (o.cpu().numpy(), ti.cpu().numpy(), sc.cpu().numpy())
+            return first, batch, kept, res
+        res = {}
+        with torch.cuda.stream(side):      # not behind the next batch, which already occupies the main stream
+            for m, (offsets, term_idx, sc, _) in filt.items():
+                off_h, st_h = small[m][0].numpy(), small[m][1].numpy()
+                if st_h[0] != 0:        # more survivors than capacity_per_protein allowed for: filter this head again, sized exactly
+                    out[m].record_stream(side)
+                    o, ti, s2 = filter_scores(out[m], self.threshold, int(st_h[1]) // max(db.B, 1) + 1)
+                    res[m] = (o.cpu().numpy(), ti.cpu().numpy(), s2.cpu().numpy())
+                    continue
+                n = int(off_h[-1])
+                term_idx.record_stream(side)
+                sc.record_stream(side)
+                ti_h, sc_h = torch.empty(n, dtype=torch.int32, pin_memory=True), torch.empty(n, dtype=torch.float32, pin_memory=True)
+                ti_h.copy_(term_idx[:n], non_blocking=True)
+                sc_h.copy_(sc[:n], non_blocking=True)
+                res[m] = (off_h, ti_h.numpy(), sc_h.numpy())
+            side.synchronize()
+        return first, batch, kept, res

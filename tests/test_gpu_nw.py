@@ -271,7 +271,7 @@ def test_every_tie_rule_matches_the_oracle(tie_rule):
         assert ops == e_ops and iden == e_iden, (tie_rule, lq, lt)
 
 
-def _best_hits(sm, seqs, nq, cand, first, lut=True, max_trace=512 << 20, cap=None, tie_rule=0, seq_off=None, text=None, want_cand_scores=True):
+def _best_hits(sm, seqs, nq, cand, first, lut=True, max_trace=512 << 20, cap=None, tie_rule=0, seq_off=None, text=None, want_cand_scores=True, ws=None):
     """mdf_nw_best_hits_host straight through ctypes -> (rc, dict of outputs, info)."""
     from mDeepFRI import _hip
     seq_len = np.array([len(s) for s in seqs], dtype=np.int32)
@@ -287,7 +287,7 @@ def _best_hits(sm, seqs, nq, cand, first, lut=True, max_trace=512 << 20, cap=Non
     o["ops"], o["qa"], o["ta"] = (np.zeros(max(cap, 1), dtype=np.uint8) for _ in range(3))
     o["cand_scores"] = np.zeros(len(cand), dtype=np.int32)
     info = np.zeros(4, dtype=np.int64)
-    rc = _hip.lib().mdf_nw_best_hits_host(_hip.ptr(text), _hip.ptr(seq_off), _hip.ptr(seq_len), len(seqs), _hip.ptr(sm._lut_nocase) if lut else None, nq,
+    rc = _hip.lib().mdf_nw_best_hits_host(ws, _hip.ptr(text), _hip.ptr(seq_off), _hip.ptr(seq_len), len(seqs), _hip.ptr(sm._lut_nocase) if lut else None, nq,
                                           _hip.ptr(cand), _hip.ptr(first), _hip.ptr(sm.matrix), len(sm.alphabet), 10, 1, tie_rule, sm.alphabet.encode(),
                                           max_trace, _hip.ptr(o["best"]), _hip.ptr(o["score"]), _hip.ptr(o["op_len"]), _hip.ptr(o["n_match"]),
                                           _hip.ptr(o["off"]), _hip.ptr(o["ops"]), _hip.ptr(o["qa"]), _hip.ptr(o["ta"]), cap,
@@ -382,3 +382,67 @@ def test_batched_queries_empty_and_repeated_calls():
         align_queries_arrays(["a"], qs[:1], [{}], scoring_matrix=sm)
     with pytest.raises(ValueError, match="'u' is not in the scoring matrix alphabet"):
         align_queries_arrays(["a"], ["acdu"], [db], scoring_matrix=sm)
+
+
+def test_aligner_workspace_is_the_same_aligner():
+    """An explicit mdf_nw_workspace (own stream, scratch and staging; what mDeepFRI.stream.QueryStream hands its producer thread): the
+    same results as the thread's own, from another thread, repeatedly, with growing and shrinking batches."""
+    import threading
+    from mDeepFRI.alignment import AlignerWorkspace
+    sm = _matrix(4)
+    ws = AlignerWorkspace(0)
+    cases = [_best_hits_case(seed=s, nq=n, ndb=d) for s, n, d in ((1, 10, 12), (2, 60, 50), (3, 5, 6))]
+    ref = [_best_hits(sm, seqs, len(first) - 1, cand, first)[1] for seqs, cand, first in cases]
+    got = []
+
+    def work():
+        for seqs, cand, first in cases + cases:
+            rc, o, _ = _best_hits(sm, seqs, len(first) - 1, cand, first, ws=ws.handle)
+            got.append((rc, o))
+    th = threading.Thread(target=work)
+    th.start()
+    th.join()
+    assert len(got) == 6
+    for k, (rc, o) in enumerate(got):
+        assert rc == 0 and all(np.array_equal(o[f], ref[k % 3][f]) for f in ("best", "score", "off", "ops", "qa", "ta", "cand_scores", "n_match"))
+    db = {f"t{k}": s for k, s in enumerate(cases[0][0][10:])}
+    a = align_queries_arrays(["q"], [cases[0][0][0]], [db], scoring_matrix=sm, workspace=ws)
+    b = align_queries_arrays(["q"], [cases[0][0][0]], [db], scoring_matrix=sm)
+    assert a.target_keys == b.target_keys and np.array_equal(a.ops, b.ops)
+
+
+def test_stepped_aligner_keeps_several_batches_in_flight():
+    """begin / align / finish of consecutive batches interleaved on ONE stream (what QueryStream does): same results as one call each;
+    the one-call-per-workspace rule, an invalid letter surfacing at the second step, and abandon."""
+    import torch
+    from mDeepFRI.alignment import AlignerWorkspace, align_queries_begin
+    sm = _matrix(6)
+    rng = np.random.default_rng(2)
+    db = {f"t{k}": _seq(rng, int(rng.integers(30, 200))) for k in range(30)}
+    batches = []
+    for b in range(4):
+        qs = [_mutate(rng, db[f"t{int(rng.integers(0, 30))}"]) for _ in range(int(rng.integers(5, 25)))]
+        batches.append(([f"b{b}q{i}" for i in range(len(qs))], qs, [{k: db[k] for k in rng.choice(list(db), size=4, replace=False)} for _ in qs]))
+    ref = [align_queries_arrays(*b, scoring_matrix=sm) for b in batches]
+    st = torch.cuda.Stream()
+    ring = [AlignerWorkspace(0, stream=st.cuda_stream) for _ in range(2)]
+    pend, got = {}, {}
+    for t in range(len(batches) + 2):
+        if t < len(batches):
+            pend[t] = align_queries_begin(*batches[t], scoring_matrix=sm, workspace=ring[t % 2])
+        if 0 <= t - 1 < len(batches):
+            pend[t - 1].launch_alignments()
+            got[t - 1] = pend.pop(t - 1).result()
+    for r, g in zip(ref, (got[k] for k in range(len(batches)))):
+        assert g.target_keys == r.target_keys and g.query_ids == r.query_ids
+        assert all(np.array_equal(getattr(g, f), getattr(r, f)) for f in ("ops", "q_aln", "t_aln", "aln_off", "score", "n_match", "op_len"))
+    p = align_queries_begin(*batches[0], scoring_matrix=sm, workspace=ring[0])
+    with pytest.raises(ValueError, match="still holds a call in flight"):
+        align_queries_begin(*batches[1], scoring_matrix=sm, workspace=ring[0])
+    p.abandon()
+    ids, qs, cs = batches[1]
+    p = align_queries_begin(ids, [qs[0], qs[1][:3] + "u" + qs[1][3:]] + qs[2:], cs, scoring_matrix=sm, workspace=ring[0])
+    with pytest.raises(ValueError, match="'u' is not in the scoring matrix alphabet"):
+        p.launch_alignments()
+    again = align_queries_begin(*batches[1], scoring_matrix=sm, workspace=ring[0]).result()      # the workspace is free again
+    assert np.array_equal(again.ops, ref[1].ops)

@@ -7,7 +7,8 @@
     --filter_scores / results_rows-->      results.tsv lines                                           (pipeline.py:684-748)
 
 Synthetic data (no network): a database of random-walk structures, queries = mutated database members, 8 candidates each.
-Prints the stage times and the overall proteins/s."""
+Prints the stage times and the overall proteins/s of ONE batch run stage after stage, then the sustained rate of the same
+chain as a stream over several batches (mDeepFRI.stream.QueryStream: the host stages of batch k+1 run under the GCN of batch k)."""
 import os
 import sys
 import time
@@ -20,7 +21,7 @@ import torch  # noqa: E402
 from mDeepFRI import synthetic  # noqa: E402
 from mDeepFRI.alignment import ScoringMatrix, align_queries_arrays  # noqa: E402
 from mDeepFRI.batch import HotPathEngine, PackedProteins  # noqa: E402
-from mDeepFRI.output import filter_scores, results_rows  # noqa: E402
+from mDeepFRI.output import filter_scores, results_text  # noqa: E402
 from mDeepFRI.predict import Predictor  # noqa: E402
 
 MODES = ("mf", "bp", "cc")
@@ -65,7 +66,7 @@ def main(n_queries=int(os.environ.get("NQ", 4000))):
         for m in MODES:
             off, ti, sc = filter_scores(scores[m], threshold=THRESHOLD, capacity_per_protein=synthetic.GO_TERMS[m])
             if rep and m == "cc":
-                n_lines = len(results_rows([qids[i] for i in kept], "gcn", m, terms[m], terms[m], off, ti, sc))
+                n_lines = results_text([qids[i] for i in kept], "gcn", m, terms[m], terms[m], off, ti, sc).count(b"\n")
         torch.cuda.synchronize()
         t.append(time.perf_counter())
     home_hit = float(np.mean([batch.target_keys[i] == list(cands[i])[0] for i in range(n_queries)]))
@@ -79,5 +80,29 @@ def main(n_queries=int(os.environ.get("NQ", 4000))):
     return batch, scores, kept, (qids, qseqs, cands, db_xyz, weights, sm)
 
 
+def stream_main(n_batches=int(os.environ.get("NB", 6)), batch=int(os.environ.get("NQ", 4000))):
+    """The same chain as a stream: n_batches x batch queries, result text of all three heads."""
+    from mDeepFRI.stream import QueryStream
+    sm = ScoringMatrix.simple()
+    qids, qseqs, cands, db_xyz = make_inputs(n_batches * batch, 1500, seed=1)
+    weights = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=synthetic.GO_TERMS[m], sparse_scores=True) for i, m in enumerate(MODES)}
+    eng = HotPathEngine({m: Predictor(f"syn-{m}", weights=weights[m]) for m in MODES}, max_rows=65536)
+    terms = {m: [f"GO:{k:07d}" for k in range(synthetic.GO_TERMS[m])] for m in MODES}
+    qs = QueryStream(eng, db_xyz, batch_size=batch, scoring_matrix=sm, threshold=THRESHOLD)
+    for rep in range(2):             # first pass warms allocations up
+        t0 = time.perf_counter()
+        n_lines = n_bytes = 0
+        for first, b, kept, res in qs.run(qids, qseqs, cands):
+            for m in MODES:
+                text = results_text([b.query_ids[i] for i in kept], "gcn", m, terms[m], terms[m], *res[m])
+                n_lines += text.count(b"\n")
+                n_bytes += len(text)
+        dt = time.perf_counter() - t0
+    print(f"stream of {n_batches} batches x {batch} queries (8 candidates each), three heads: {dt * 1e3:.1f} ms = {n_batches * batch / dt:.0f} proteins/s sustained "
+          f"(host sequences in -> {n_lines} result lines, {n_bytes / 1e6:.1f} MB of text, out)")
+    return n_batches * batch / dt
+
+
 if __name__ == "__main__":
     main()
+    stream_main()
