@@ -431,6 +431,14 @@ int mdf_filter_scores_dev(const float *scores, int32_t B, int32_t T, float thres
  * (tail_off == NULL: the reference's six "nan" when the query has no alignment record).  The score is printed as Python prints
  * float(np.float32) with ".4f" (correctly rounded, ties to even).  *bytes = size of the text, *lines = number of lines; MDF_ECAPACITY
  * when it exceeds `capacity` (call with out = NULL, capacity = 0 to size the buffer).  Host code: no device is touched. */
+/* Rows of the prediction matrix (mDeepFRI/pipeline.py:318-319: csv.writer(delimiter="\t").writerow([query_id, net_type] + pred.tolist())):
+ * prefix = B strings "query_id\tnet_type" (already csv-quoted where an id needs it) with B + 1 offsets; scores (B, T) f32; every score
+ * printed as repr(float(np.float32(s))) -- the shortest digits that read back as the same double, CPython's layout --, rows end "\r\n"
+ * (csv's default).  *bytes = size of the text; MDF_ECAPACITY when it exceeds `capacity` (out = NULL, capacity = 0 sizes the buffer;
+ * B * (T * 25 + 2) + the prefixes always suffices).  threads: host threads the rows are dealt to (0 = up to 32, as the machine has).
+ * Host code: no device is touched. */
+int mdf_matrix_format_host(const char *prefix, const int64_t *prefix_off, const float *scores, int32_t B, int32_t T, char *out, int64_t capacity,
+                           int threads, int64_t *bytes);
 int mdf_results_format_host(const char *qid, const int64_t *qid_off, const char *middle, const char *term, const int64_t *term_off, const char *name,
                             const int64_t *name_off, const char *tail, const int64_t *tail_off, const int32_t *offsets, const int32_t *term_idx,
                             const float *kept, int32_t B, int32_t T, char *out, int64_t capacity, int64_t *bytes, int64_t *lines);

@@ -6,8 +6,12 @@
 // before anything crosses PCIe or xGMI.  Integer/compare work: no LDS tricks beyond a per-protein candidate list.
 #include <algorithm>
 
+#include <charconv>
 #include <cmath>
 #include <cstring>
+#include <memory>
+#include <thread>
+#include <vector>
 
 #include "common.h"
 
@@ -230,6 +234,134 @@ int mdf_results_format_host(const char *qid, const int64_t *qid_off, const char 
             else put(tail, (int64_t)tail_all);
             *o++ = '\n';
         }
+    return MDF_OK;
+}
+
+// repr(float(np.float32(x))): the text Python's csv writer puts into the prediction matrix for every score (reference pipeline.py:318-319:
+// `[query_id, net_type] + pred_vector.tolist()`): the shortest digit string that reads back as the same double, laid out by CPython's rule
+// (float_repr_style "short", format 'r': exponent form when the decimal point falls outside (-4, 16], at least two exponent digits).
+static inline char *format_repr(char *o, float f)
+{
+    const double d = (double)f;
+    if (std::isnan(d)) {
+        memcpy(o, "nan", 3);
+        return o + 3;
+    }
+    if (std::signbit(d)) *o++ = '-';
+    if (std::isinf(d)) {
+        memcpy(o, "inf", 3);
+        return o + 3;
+    }
+    if (d == 0.0) {
+        memcpy(o, "0.0", 3);
+        return o + 3;
+    }
+    char sci[48];
+    const auto r = std::to_chars(sci, sci + sizeof(sci), std::fabs(d), std::chars_format::scientific);   // "d.ddde-05": shortest round trip
+    char dig[24];
+    int nd = 0;
+    const char *p = sci;
+    for (; p < r.ptr && *p != 'e'; ++p)
+        if (*p != '.') dig[nd++] = *p;
+    int e10 = 0;
+    {
+        ++p;   // 'e'
+        const bool neg = *p == '-';
+        ++p;   // sign
+        for (; p < r.ptr; ++p) e10 = e10 * 10 + (*p - '0');
+        if (neg) e10 = -e10;
+    }
+    const int decpt = e10 + 1;
+    if (decpt <= -4 || decpt > 16) {
+        *o++ = dig[0];
+        if (nd > 1) {
+            *o++ = '.';
+            memcpy(o, dig + 1, (size_t)nd - 1);
+            o += nd - 1;
+        }
+        *o++ = 'e';
+        int e = decpt - 1;
+        *o++ = e < 0 ? '-' : '+';
+        if (e < 0) e = -e;
+        if (e >= 100) *o++ = (char)('0' + e / 100);
+        *o++ = (char)('0' + e / 10 % 10);
+        *o++ = (char)('0' + e % 10);
+        return o;
+    }
+    if (decpt <= 0) {
+        *o++ = '0';
+        *o++ = '.';
+        for (int k = 0; k < -decpt; ++k) *o++ = '0';
+        memcpy(o, dig, (size_t)nd);
+        return o + nd;
+    }
+    if (decpt >= nd) {
+        memcpy(o, dig, (size_t)nd);
+        o += nd;
+        for (int k = nd; k < decpt; ++k) *o++ = '0';
+        *o++ = '.';
+        *o++ = '0';
+        return o;
+    }
+    memcpy(o, dig, (size_t)decpt);
+    o += decpt;
+    *o++ = '.';
+    memcpy(o, dig + decpt, (size_t)(nd - decpt));
+    return o + (nd - decpt);
+}
+
+int mdf_matrix_format_host(const char *prefix, const int64_t *prefix_off, const float *scores, int32_t B, int32_t T, char *out, int64_t capacity,
+                           int threads, int64_t *bytes)
+{
+    MDF_REQUIRE(prefix && prefix_off && bytes && B >= 0 && T >= 0 && capacity >= 0 && (out || capacity == 0), "matrix_format: bad arguments");
+    MDF_REQUIRE(B == 0 || T == 0 || scores, "matrix_format: NULL scores");
+    // Rows are independent and the digit generation (~100 ns per score) is all of the cost: blocks of rows go to host threads, each
+    // formats into a buffer of its own (a score takes at most 24 characters + its tab), then copies it to its place in the output.
+    int nt = threads > 0 ? threads : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 32u);
+    nt = (int)std::max<int64_t>(1, std::min<int64_t>(nt, ((int64_t)B * std::max(T, 1) + 65535) / 65536));
+    const int64_t row_max = (int64_t)T * 25 + 2;
+    std::vector<std::unique_ptr<char[]>> part((size_t)nt);
+    std::vector<int64_t> len((size_t)nt, 0), at((size_t)nt + 1, 0);
+    auto first_row = [&](int k) { return (int32_t)((int64_t)B * k / nt); };
+    auto work = [&](int k) {
+        const int32_t p0 = first_row(k), p1 = first_row(k + 1);
+        if (p1 <= p0) return;
+        part[(size_t)k].reset(new char[(size_t)(prefix_off[p1] - prefix_off[p0]) + (size_t)(p1 - p0) * (size_t)row_max]);
+        char *const begin = part[(size_t)k].get();
+        char *o = begin;
+        for (int32_t p = p0; p < p1; ++p) {
+            const int64_t n = prefix_off[p + 1] - prefix_off[p];
+            memcpy(o, prefix + prefix_off[p], (size_t)n);
+            o += n;
+            const float *row = scores + (size_t)p * T;
+            for (int32_t t = 0; t < T; ++t) {
+                *o++ = '\t';
+                o = format_repr(o, row[t]);
+            }
+            *o++ = '\r';   // csv.writer's default line terminator
+            *o++ = '\n';
+        }
+        len[(size_t)k] = o - begin;
+    };
+    auto place = [&](int k) {
+        if (len[(size_t)k]) memcpy(out + at[(size_t)k], part[(size_t)k].get(), (size_t)len[(size_t)k]);
+    };
+    auto run = [&](auto &&fn) {
+        std::vector<std::thread> pool;
+        for (int k = 1; k < nt; ++k) pool.emplace_back(fn, k);
+        fn(0);
+        for (auto &th : pool) th.join();
+    };
+    try {
+        run(work);
+        for (int k = 0; k < nt; ++k) at[(size_t)k + 1] = at[(size_t)k] + len[(size_t)k];
+        *bytes = at[(size_t)nt];
+        if (at[(size_t)nt] > capacity)
+            return fail(MDF_ECAPACITY, "matrix_format: the rows take %lld bytes, capacity is %lld", (long long)at[(size_t)nt], (long long)capacity);
+        run(place);   // the blocks go end to end, each thread its own
+    } catch (const std::exception &e) {
+        return fail(MDF_ENOMEM, "matrix_format: %s", e.what());
+    }
     return MDF_OK;
 }
 

@@ -182,6 +182,7 @@ SIGNATURES = {
     "mdf_nw_best_hits_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int, c_int, c_int,
                                       c_char_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                       c_void_p]),
+    "mdf_matrix_format_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int64, c_int, _i64p]),
     "mdf_results_format_host": (c_int, [c_void_p, c_void_p, c_char_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                         c_int32, c_int32, c_void_p, c_int64, _i64p, _i64p]),
     "mdf_timing_enable": (c_int, [c_int]),

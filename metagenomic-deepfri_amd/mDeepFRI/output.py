@@ -95,3 +95,55 @@ def results_text(query_ids, net_type: str, mode_label: str, terms, gonames, offs
 def results_rows(query_ids, net_type: str, mode_label: str, terms, gonames, offsets, term_idx, kept, alignment_data=None):
     """The same as a list of lines (str, each ending in a newline)."""
     return results_text(query_ids, net_type, mode_label, terms, gonames, offsets, term_idx, kept, alignment_data).decode("utf-8").splitlines(keepends=True)
+
+
+def _matrix_body(query_ids, scores, net_type, threads):
+    import csv
+    import io
+    s = scores.detach().cpu().numpy() if hasattr(scores, "detach") else np.asarray(scores)
+    s = np.ascontiguousarray(s, dtype=np.float32)
+    query_ids = [str(q) for q in query_ids]
+    if s.ndim != 2 or s.shape[0] != len(query_ids):
+        raise ValueError("scores must be (len(query_ids), T)")
+    special = any(c in q for q in query_ids for c in '\t"\r\n') or any(c in net_type for c in '\t"\r\n') or any(q == "" for q in query_ids)
+    prefixes = [_csv_row([q, net_type]) for q in query_ids] if special else [f"{q}\t{net_type}" for q in query_ids]
+    pre_b, pre_off = _concat(prefixes)
+    B, T = s.shape
+    L = _hip.lib()
+    nbytes = ctypes.c_int64()
+    if B * T <= (1 << 20):       # small: one sizing pass, then a buffer of exactly that size
+        rc = L.mdf_matrix_format_host(pre_b, _hip.ptr(pre_off), _hip.ptr(s), B, T, None, 0, int(threads), ctypes.byref(nbytes))
+        if rc not in (_hip.MDF_OK, _hip.MDF_ECAPACITY):
+            _hip.check(rc)
+        out = np.empty(max(nbytes.value, 1), dtype=np.uint8)
+    else:                        # large: no second pass over the digits, the bound is allocated (untouched pages cost nothing)
+        out = np.empty(int(pre_off[-1]) + B * (T * 25 + 2) + 1, dtype=np.uint8)
+    _hip.check(L.mdf_matrix_format_host(pre_b, _hip.ptr(pre_off), _hip.ptr(s), B, T, _hip.ptr(out), out.size, int(threads), ctypes.byref(nbytes)))
+    return out[:nbytes.value]
+
+
+def _csv_row(fields) -> str:
+    import csv
+    import io
+    buf = io.StringIO()
+    csv.writer(buf, delimiter="\t").writerow(fields)      # the reference's dialect: what gets quoted depends on its line terminator too
+    return buf.getvalue()[:-2]
+
+
+def prediction_matrix_text(query_ids, scores, net_type: str = "gcn", terms=None, threads: int = 0) -> bytes:
+    """The text of the prediction matrix as reference pipeline.py writes it (header :566-571 when `terms` is given, rows :318-319:
+    `csv.writer(delimiter="\t").writerow([query_id, net_type] + pred_vector.tolist())`), utf-8: every score is
+    repr(float(np.float32(s))), rows end "\r\n".  scores: (B, T) float32 (numpy, or a torch tensor: copied to the host).  The rows are
+    assembled by the library (`mdf_matrix_format_host`, rows dealt to `threads` host threads, 0 = as many as the machine has up to 32);
+    only ids that need csv quoting go through the csv module.  `write_prediction_matrix` is the same without the final copies."""
+    head = (_csv_row(["Protein", "Network_type"] + list(terms)) + "\r\n").encode("utf-8") if terms is not None else b""
+    return head + _matrix_body(query_ids, scores, net_type, threads).tobytes()
+
+
+def write_prediction_matrix(fh, query_ids, scores, net_type: str = "gcn", terms=None, threads: int = 0) -> int:
+    """Write header (when `terms` is given) and rows to the binary file object `fh`; returns the bytes written."""
+    head = (_csv_row(["Protein", "Network_type"] + list(terms)) + "\r\n").encode("utf-8") if terms is not None else b""
+    body = _matrix_body(query_ids, scores, net_type, threads)
+    fh.write(head)
+    fh.write(memoryview(body))
+    return len(head) + body.size
