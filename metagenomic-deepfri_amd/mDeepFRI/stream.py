@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import queue
 import threading
+from dataclasses import dataclass, field
 
 import numpy as np
 
@@ -111,6 +112,25 @@ class AlignmentStream:
         return {m: np.concatenate(v, axis=0) for m, v in parts.items()}
 
 
+@dataclass
+class QueryBatchResult:
+    """One slice of the input after QueryStream: `batch` = the AlignedBatch of the queries that had candidates (`aligned`: their positions
+    inside the slice), `kept` = positions inside `batch` whose hit had a structure and `gcn` the filter's arrays for exactly those
+    ({mode: (offsets, term_idx, scores)}); `sequence_only` = positions inside the slice without a structure (no candidate, or a hit
+    without a trace) and `cnn` the filter's arrays of the sequence-only heads for those (empty without a sequence engine)."""
+    first: int
+    count: int
+    batch: object = None
+    aligned: list = field(default_factory=list)
+    kept: list = field(default_factory=list)
+    gcn: dict = field(default_factory=dict)
+    sequence_only: list = field(default_factory=list)
+    cnn: dict = field(default_factory=dict)
+
+    def __iter__(self):      # (first, batch, kept, gcn): the structure branch alone
+        return iter((self.first, self.batch, self.kept, self.gcn))
+
+
 class QueryStream:
     """The stages either side of the path as ONE stream over arbitrarily many queries: queries + candidate sets -> best hit and
     alignment (GPU aligner, reference alignment.py:223-320) -> C-alpha trace of the hit -> fused contact map + GCN (pipeline.py:476-481,
@@ -124,14 +144,15 @@ class QueryStream:
     the GEMMs five times the aligner's own time).  Uploads and the collection of results go through a second, high-priority stream: a
     copy must not queue behind the batch in flight (streams of equal priority may share a hardware queue).
 
-    engine: HotPathEngine.  structures: mapping target key -> float32 (Lt, 3) C-alpha trace (`.get`; a hit without one is dropped, as
-    pipeline.py:485 does).  batch_size: queries per device batch."""
+    engine: HotPathEngine.  structures: mapping target key -> float32 (Lt, 3) C-alpha trace (`.get`; a hit without one makes its query a
+    sequence-only query, as pipeline.py:485 does).  batch_size: queries per device batch.  sequence_engine: a batch.SequenceEngine with
+    the CNN heads for the sequence-only queries (optional)."""
 
     def __init__(self, engine: HotPathEngine, structures, batch_size: int = 4000, max_rows: int = 65536, scoring_matrix="VTML80",
-                 gap_open: int = 10, gap_extend: int = 1, threshold: float = 0.1, capacity_per_protein: int = 64):
+                 gap_open: int = 10, gap_extend: int = 1, threshold: float = 0.1, capacity_per_protein: int = 64, sequence_engine=None):
         import torch
         from .alignment import AlignerWorkspace
-        self.engine, self.structures = engine, structures
+        self.engine, self.structures, self.sequence_engine = engine, structures, sequence_engine
         self.batch_size, self.max_rows = int(batch_size), int(max_rows)
         self.scoring_matrix, self.gap_open, self.gap_extend = scoring_matrix, int(gap_open), int(gap_extend)
         self.threshold, self.capacity_per_protein = float(threshold), int(capacity_per_protein)
@@ -139,45 +160,52 @@ class QueryStream:
         self.ring = [AlignerWorkspace(engine.device.index or 0, stream=self.main.cuda_stream) for _ in range(3)]
 
     def run(self, query_ids, query_sequences, target_sequences):
-        """Generator over (first_index, AlignedBatch, kept, {mode: (offsets, term_idx, scores)}) in input order: `kept` = positions
-        inside the batch that had a structure; the arrays (numpy) are the filter's output for those proteins, what
-        mDeepFRI.output.results_text takes."""
+        """Generator over QueryBatchResult (it also unpacks as (first_index, AlignedBatch, kept, {mode: (offsets, term_idx, scores)})) in
+        input order: `kept` = positions inside the batch that had a structure; the arrays (numpy) are the filter's output for those
+        proteins, what mDeepFRI.output.results_text takes.  A query with an empty candidate set, or whose best hit has no structure,
+        is a sequence-only query: with a `sequence_engine` it runs through the CNN heads in the same step (reference
+        pipeline.py:600-648: `unaligned_queries`), without one it is only listed in `sequence_only`."""
         import torch
         from .alignment import align_queries_begin
         query_ids, query_sequences, target_sequences = list(query_ids), list(query_sequences), list(target_sequences)
         starts = list(range(0, len(query_ids), self.batch_size))
         nb = len(starts)
-        aligning, running = {}, {}
+        aligning, running, slices = {}, {}, {}
         try:
             with torch.cuda.device(self.engine.device):
                 for t in range(nb + 3):
                     if t < nb:
                         a, b = starts[t], min(starts[t] + self.batch_size, len(query_ids))
-                        aligning[t] = align_queries_begin(query_ids[a:b], query_sequences[a:b], target_sequences[a:b], self.gap_open, self.gap_extend,
-                                                          self.scoring_matrix, workspace=self.ring[t % 3])
-                    if 0 <= t - 1 < nb:
+                        pos = [i for i in range(a, b) if len(target_sequences[i]) > 0]
+                        slices[t] = (a, b, pos)
+                        if len(pos) == b - a:
+                            args = (query_ids[a:b], query_sequences[a:b], target_sequences[a:b])
+                        else:
+                            args = ([query_ids[i] for i in pos], [query_sequences[i] for i in pos], [target_sequences[i] for i in pos])
+                        aligning[t] = align_queries_begin(*args, self.gap_open, self.gap_extend, self.scoring_matrix, workspace=self.ring[t % 3]) if pos else None
+                    if 0 <= t - 1 < nb and aligning[t - 1] is not None:
                         aligning[t - 1].launch_alignments()
                     if 0 <= t - 2 < nb:
-                        running[t - 2] = self._enqueue(starts[t - 2], aligning.pop(t - 2).result())
+                        a, b, pos = slices.pop(t - 2)
+                        pend = aligning.pop(t - 2)
+                        running[t - 2] = self._enqueue(a, b, pos, pend.result() if pend is not None else None, query_ids, query_sequences)
                     if 0 <= t - 3 < nb:
                         yield self._finish(running.pop(t - 3))
         finally:
             for p in aligning.values():      # an exception (or an abandoned generator) leaves batches in flight: drop them
-                p.abandon()
+                if p is not None:
+                    p.abandon()
 
-    def _enqueue(self, first, batch):
+    def _launch(self, pk, forward):
+        """Upload (side stream), `forward(db)` + filter (main stream), the small results on their way back.  -> the part's state."""
         import torch
         from .output import filter_scores_async
         eng, main, side = self.engine, self.main, self.side
-        coords = [self.structures.get(k) for k in batch.target_keys]
-        if not any(c is not None for c in coords):
-            return first, batch, [], None
-        pk, kept = PackedProteins.from_aligned_batch(batch, coords, max_rows=self.max_rows)
         with torch.cuda.stream(side):      # the upload does not queue behind the batch in flight
             db = DeviceBatch(pk, eng.device)
         main.wait_stream(side)
         with torch.cuda.stream(main):
-            out = eng.forward_alignments(db)
+            out = forward(db)
             filt = {m: filter_scores_async(t, self.threshold, db.B * self.capacity_per_protein) for m, t in out.items()}
             small = {m: (torch.empty(f[0].shape, dtype=f[0].dtype, pin_memory=True), torch.empty(4, dtype=torch.int32, pin_memory=True))
                      for m, f in filt.items()}
@@ -188,28 +216,48 @@ class QueryStream:
             flags = (torch.empty(db.bad.shape, dtype=db.bad.dtype, pin_memory=True), torch.empty(db.status.shape, dtype=db.status.dtype, pin_memory=True))
             flags[0].copy_(db.bad, non_blocking=True)
             flags[1].copy_(db.status, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(main)
-        return first, batch, kept, (db, pk, out, filt, small, flags, ev)
+        return db, pk, out, filt, small, flags
 
-    def _finish(self, pending):
+    def _enqueue(self, a, b, pos, batch, query_ids, query_sequences):
         import torch
+        res = QueryBatchResult(first=a, count=b - a, batch=batch, aligned=[i - a for i in pos])
+        structured = set()
+        gcn = cnn = None
+        if batch is not None:
+            coords = [self.structures.get(k) for k in batch.target_keys]
+            if any(c is not None for c in coords):
+                pk, res.kept = PackedProteins.from_aligned_batch(batch, coords, max_rows=self.max_rows)
+                structured = {res.aligned[k] for k in res.kept}
+                gcn = self._launch(pk, self.engine.forward_alignments)
+        res.sequence_only = [i for i in range(b - a) if i not in structured]
+        if self.sequence_engine is not None and res.sequence_only:
+            pk = PackedProteins.pack([query_sequences[a + i] for i in res.sequence_only], max_rows=self.sequence_engine.max_rows)
+            cnn = self._launch(pk, self.sequence_engine.forward)
+        ev = None
+        if gcn is not None or cnn is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.main)
+        return res, gcn, cnn, ev
+
+    def _collect(self, part, redo):
+        """Results of one part (after its event): {mode: (offsets, term_idx, scores)} as numpy, through the side stream."""
+        import torch
+        from .batch import first_invalid_residue
         from .output import filter_scores
-        first, batch, kept, work = pending
-        if work is None:
-            return first, batch, kept, {}
-        db, pk, out, filt, small, flags, ev = work
+        db, pk, out, filt, small, flags = part
         eng, side = self.engine, self.side
-        ev.synchronize()
         try:
-            eng.raise_flags(pk, flags[0].numpy(), flags[1].numpy())
+            if redo is None:      # sequence-only models flag invalid residues only
+                first_invalid_residue(pk, flags[0].numpy())
+            else:
+                eng.raise_flags(pk, flags[0].numpy(), flags[1].numpy())
         except _hip.CapacityError:   # rare: a denser batch than the CSR capacity planned for; redo it synchronously
             with torch.cuda.stream(side):
                 res = {}
-                for m, a in eng.run_alignments(pk).items():
-                    o, ti, sc = filter_scores(torch.from_numpy(a).to(eng.device), self.threshold, self.capacity_per_protein)
+                for m, arr in redo(pk).items():
+                    o, ti, sc = filter_scores(torch.from_numpy(arr).to(eng.device), self.threshold, self.capacity_per_protein)
                     res[m] = (o.cpu().numpy(), ti.cpu().numpy(), sc.cpu().numpy())
-            return first, batch, kept, res
+            return res
         res = {}
         with torch.cuda.stream(side):      # not behind the next batch, which already occupies the main stream
             for m, (offsets, term_idx, sc, _) in filt.items():
@@ -227,4 +275,14 @@ class QueryStream:
                 sc_h.copy_(sc[:n], non_blocking=True)
                 res[m] = (off_h, ti_h.numpy(), sc_h.numpy())
             side.synchronize()
-        return first, batch, kept, res
+        return res
+
+    def _finish(self, pending):
+        res, gcn, cnn, ev = pending
+        if ev is not None:
+            ev.synchronize()
+        if gcn is not None:
+            res.gcn = self._collect(gcn, self.engine.run_alignments)
+        if cnn is not None:
+            res.cnn = self._collect(cnn, None)
+        return res

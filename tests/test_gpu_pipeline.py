@@ -83,46 +83,68 @@ def test_reference_query_fixture_through_aligner_cnn_and_gcn():
 
 
 def test_query_stream_equals_the_stage_by_stage_chain():
-    """mDeepFRI.stream.QueryStream (aligner + packing of batch k+1 in a producer thread under the GCN of batch k, filter collected
-    through a side stream) returns, batch by batch, exactly what the stages give when run one after the other -- including a hit
-    without a structure (dropped), a batch in which no hit has one, and a head whose survivors exceed the planned capacity."""
+    """mDeepFRI.stream.QueryStream (one stream, software pipeline four batches deep, results collected through a side stream) returns,
+    batch by batch, exactly what the stages give when run one after the other -- including a hit without a structure and queries
+    without any candidate (both sequence-only: they go through the CNN heads, reference pipeline.py:600-648), a batch in which no hit has
+    a structure, and a head whose survivors exceed the planned capacity."""
     import torch
     from mDeepFRI import synthetic
     from mDeepFRI.alignment import ScoringMatrix, align_queries_arrays
-    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.batch import HotPathEngine, PackedProteins, SequenceEngine
     from mDeepFRI.output import filter_scores, results_text
     from mDeepFRI.predict import Predictor
     from mDeepFRI.stream import QueryStream
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pipeline_example
     qids, qseqs, cands, db_xyz = pipeline_example.make_inputs(230, 60, seed=3, k=4)
+    cands = [dict(c) for c in cands]
+    for i in (3, 57, 58, 120):
+        cands[i] = {}                                                   # no MMseqs hit at all
     sm = ScoringMatrix.simple()
     w = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=t, sparse_scores=(m == "a")) for i, (m, t) in enumerate({"a": 300, "b": 40}.items())}
+    wc = {"a": synthetic.glorot_cnn_weights(seed=5, n_terms=70)}
     eng = HotPathEngine({m: Predictor(f"syn-{m}", weights=w[m]) for m in w}, max_rows=8192)
-    ref_batch = align_queries_arrays(qids, qseqs, cands, scoring_matrix=sm)
+    seq_eng = SequenceEngine({m: Predictor(f"cnn-{m}", weights=wc[m]) for m in wc}, max_rows=4096)
+    has = [i for i in range(230) if cands[i]]
+    ref_batch = align_queries_arrays([qids[i] for i in has], [qseqs[i] for i in has], [cands[i] for i in has], scoring_matrix=sm)
     xyz = dict(db_xyz)
     del xyz[ref_batch.target_keys[7]]                                   # a hit without a structure
-    for i in range(200, 230):                                           # the last batch: no structure at all
-        xyz.pop(ref_batch.target_keys[i], None)
-    stream = QueryStream(eng, xyz, batch_size=50, max_rows=8192, scoring_matrix=sm, threshold=0.1, capacity_per_protein=2)   # head "b" (dense scores) overflows 2 per protein
-    seen = 0
-    for first, b, kept, res in stream.run(qids, qseqs, cands):
-        assert first == seen
-        n = len(b)
-        seen += n
-        one = align_queries_arrays(qids[first:first + n], qseqs[first:first + n], cands[first:first + n], scoring_matrix=sm)
+    for k in range(len(has)):                                           # the last slice: no structure at all
+        if has[k] >= 200:
+            xyz.pop(ref_batch.target_keys[k], None)
+    stream = QueryStream(eng, xyz, batch_size=50, max_rows=8192, scoring_matrix=sm, threshold=0.1, capacity_per_protein=2,   # head "b" (dense scores) overflows 2 per protein
+                         sequence_engine=seq_eng)
+    seen = n_seq_only = 0
+    for r in stream.run(qids, qseqs, cands):
+        first, b, kept, res = r
+        assert first == seen and r.count == min(50, 230 - first)
+        sl = range(first, first + r.count)
+        seen += r.count
+        assert r.aligned == [i - first for i in sl if cands[i]]
+        one = align_queries_arrays([qids[first + i] for i in r.aligned], [qseqs[first + i] for i in r.aligned], [cands[first + i] for i in r.aligned], scoring_matrix=sm)
         assert b.target_keys == one.target_keys and np.array_equal(b.ops, one.ops) and np.array_equal(b.aln_off, one.aln_off)
         coords = [xyz.get(k) for k in one.target_keys]
         assert kept == [i for i, c in enumerate(coords) if c is not None]
+        structured = {r.aligned[k] for k in kept}
+        assert r.sequence_only == [i for i in range(r.count) if i not in structured]
+        n_seq_only += len(r.sequence_only)
         if not kept:
             assert res == {} and first == 200
-            continue
-        pk, _ = PackedProteins.from_aligned_batch(one, coords, max_rows=8192)
-        scores = eng.run_alignments(pk)
-        for m in w:
-            off, ti, sc = filter_scores(torch.from_numpy(scores[m]).cuda(), 0.1, capacity_per_protein=400)
-            assert np.array_equal(res[m][0], off.cpu().numpy()) and np.array_equal(res[m][1], ti.cpu().numpy()) and np.array_equal(res[m][2], sc.cpu().numpy())
-            ids = [b.query_ids[i] for i in kept]
-            assert results_text(ids, "gcn", m, [f"t{k}" for k in range(scores[m].shape[1])], [], *res[m]).count(b"\n") == len(res[m][1])
-    assert seen == 230
-    assert any(ref_batch.target_keys[7] == k for k in ref_batch.target_keys)
+        else:
+            pk, _ = PackedProteins.from_aligned_batch(one, coords, max_rows=8192)
+            scores = eng.run_alignments(pk)
+            for m in w:
+                off, ti, sc = filter_scores(torch.from_numpy(scores[m]).cuda(), 0.1, capacity_per_protein=400)
+                assert np.array_equal(res[m][0], off.cpu().numpy()) and np.array_equal(res[m][1], ti.cpu().numpy()) and np.array_equal(res[m][2], sc.cpu().numpy())
+                ids = [b.query_ids[i] for i in kept]
+                assert results_text(ids, "gcn", m, [f"t{k}" for k in range(scores[m].shape[1])], [], *res[m]).count(b"\n") == len(res[m][1])
+        if r.sequence_only:
+            y = seq_eng.run([qseqs[first + i] for i in r.sequence_only])["a"]
+            off, ti, sc = filter_scores(torch.from_numpy(y).cuda(), 0.1, capacity_per_protein=100)
+            assert np.array_equal(r.cnn["a"][0], off.cpu().numpy()) and np.array_equal(r.cnn["a"][1], ti.cpu().numpy()) and np.array_equal(r.cnn["a"][2], sc.cpu().numpy())
+        else:
+            assert r.cnn == {}
+    assert seen == 230 and n_seq_only >= 4 + 1 + 30
+    # without a sequence engine the sequence-only queries are listed, nothing else
+    r0 = next(iter(QueryStream(eng, xyz, batch_size=50, max_rows=8192, scoring_matrix=sm).run(qids[:50], qseqs[:50], cands[:50])))
+    assert r0.cnn == {} and 3 in r0.sequence_only and len(r0.kept) == 50 - len(r0.sequence_only)
