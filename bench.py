@@ -26,9 +26,10 @@ Objects on the line (tier contract):
   cpu_baseline  the oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample: one thread
                 (the configuration the reference ships) and a pool of single-thread worker processes (the reference's own
                 parallelism, pipeline.py:476-481); real onnxruntime-CPU on the exported synthetic weights when ORT is importable
-  by_length / mixed / helix / end_to_end   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix,
-  protein-like helix-bundle traces (fewer contacts per residue than a random walk), and the
-                PCIe-inclusive host-lists-in / host-arrays-out rate -- never `value`
+  by_length / mixed / helix / end_to_end / query_stream   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix,
+  protein-like helix-bundle traces (fewer contacts per residue than a random walk), the
+                PCIe-inclusive host-lists-in / host-arrays-out rate, and the stages either side of the path as one stream
+                (sequences + candidate sets in -> aligner -> path -> filter -> results.tsv text out) -- never `value`
 """
 import argparse
 import json
@@ -73,6 +74,7 @@ def parse(argv=None):
                          "LM embedding; SURVEY.md section 8f row 1).  Not the BASELINE.json configuration: an extra measurement.")
     ap.add_argument("--no-extras", action="store_true", help="N = 1 default run: skip the by_length / mixed / end_to_end mini-runs")
     ap.add_argument("--end-to-end", type=int, default=2, metavar="N", help="batches of the end_to_end mini-run (0 = skip)")
+    ap.add_argument("--query-stream", type=int, default=6, metavar="N", help="batches of 4 000 queries of the query_stream mini-run (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-device", type=int, default=None, help="testing aid: put every rank on this device ordinal")
     ap.add_argument("--dry-plan", action="store_true",
@@ -161,6 +163,25 @@ def make_mixed(seed, count):
     L = synthetic.uniform_lengths(seed, count)
     order = np.argsort(L, kind="stable")
     return synthetic.bulk_proteins(seed, L, order, indel_rate=0.05)
+
+
+def make_queries(seed, n_queries, n_db=1500, k=8):
+    """Inputs of the stages in front of and behind the path (query_stream leg): a database of histogram-length sequences with random-walk
+    structures, queries = mutated database members (ungapped, as a FASTA record holds them), k candidate targets each."""
+    from mDeepFRI import synthetic
+    rng = np.random.default_rng(seed)
+    lens = synthetic.histogram_lengths(seed + 1, n_db)
+    db_seq = {f"T{j}": synthetic.random_sequence(rng, int(L)) for j, L in enumerate(lens)}
+    db_xyz = {name: synthetic.random_walk_coords(rng, len(s)) for name, s in db_seq.items()}
+    names = list(db_seq)
+    qids, qseqs, cands = [], [], []
+    for i in range(n_queries):
+        home = names[int(rng.integers(0, n_db))]
+        q, _, _ = synthetic.mutate_alignment(rng, db_seq[home], 0.04)
+        qids.append(f"Q{i}")
+        qseqs.append(q.replace("-", "") or "A")
+        cands.append({n: db_seq[n] for n in [home] + [names[int(j)] for j in rng.integers(0, n_db, size=k - 1)]})
+    return qids, qseqs, cands, db_xyz
 
 
 def oracle_paths():
@@ -608,6 +629,36 @@ def main():
                 line["end_to_end"] = {"value": round(len(items) / dt, 1), "unit": "proteins/s", "batches": args.end_to_end,
                                       "note": "PCIe-inclusive: host lists in -> host float32 score arrays out (packing thread + upload + compute + "
                                               "download, batches pipelined; mDeepFRI.stream.AlignmentStream); never `value`"}
+            if args.query_stream > 0:
+                # the stages either side of the path as one stream (SURVEY 8f rows 3 and 4 around the path): host sequences + candidate sets
+                # in, results.tsv text of all three heads out; heads at a trained-like operating point (a few % of the terms pass 0.1)
+                from mDeepFRI.alignment import ScoringMatrix
+                from mDeepFRI.output import results_text
+                from mDeepFRI.stream import QueryStream
+                w_sparse = make_weights(False, sparse_scores=True)
+                eng_q = batch.HotPathEngine({m: Predictor(f"synthetic-sparse-{m}", weights=w_sparse[m], device=local_rank) for m in MODES},
+                                            device=local_rank, max_rows=args.chunk_rows)
+                nq = 4000 * args.query_stream
+                qids, qseqs, cands, db_xyz = make_queries(42 + 6, nq)
+                terms = {m: [f"GO:{k:07d}" for k in range(synthetic.GO_TERMS[m])] for m in MODES}
+                qs = QueryStream(eng_q, db_xyz, batch_size=4000, max_rows=args.chunk_rows, scoring_matrix=ScoringMatrix.simple(), threshold=0.1)
+                for rep in range(2):      # the first pass sizes the buffers
+                    n_lines = n_bytes = 0
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for r in qs.run(qids, qseqs, cands):
+                        ids = [r.batch.query_ids[i] for i in r.kept]
+                        for m in MODES:
+                            text = results_text(ids, "gcn", m, terms[m], terms[m], *r.gcn[m])
+                            n_lines += text.count(b"\n")
+                            n_bytes += len(text)
+                    dt = time.perf_counter() - t0
+                line["query_stream"] = {"value": round(nq / dt, 1), "unit": "proteins/s", "batches": args.query_stream, "queries": nq,
+                                        "candidates_per_query": 8, "mean_query_length": round(float(np.mean([len(q) for q in qseqs])), 1),
+                                        "result_lines": n_lines, "text_mb": round(n_bytes / 1e6, 1),
+                                        "note": "host sequences + candidate sets in -> best hit + alignment (GPU aligner) -> contact maps + GCN, 3 heads -> "
+                                                "score >= 0.1 filter -> results.tsv text out (mDeepFRI.stream.QueryStream: one stream, software pipeline "
+                                                "four batches deep; includes its fill and drain); never `value`"}
         line["cpu_baseline"] = cpu_leg
         if cpu_leg:
             line["gpu_over_cpu_1core"] = round(line["value"] / cpu_leg["value"], 1)

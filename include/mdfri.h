@@ -488,6 +488,12 @@ int mdf_nw_align_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t
                      const char *alphabet, const int64_t *bnd_off, int32_t *bnd, const int64_t *trace_off, uint8_t *trace, const int64_t *ops_off, char *ops, char *q_aln,
                      char *t_aln, int32_t *op_len, int32_t *n_match, int32_t *scores, void *stream);
 
+/* Score mode only: NW(q, t; S) = NW(t, q; S^T), so for a SYMMETRIC matrix a pair may be swept with either sequence as the rows; this turns
+ * every pair of the list to the orientation that takes fewer steps on the device (in place; call it before mdf_nw_plan / mdf_nw_score_dev;
+ * the host entries do it themselves).  Returns the number of pairs turned round (0 for an asymmetric matrix), negative on bad arguments. */
+int32_t mdf_nw_orient_pairs(const int32_t *seq_len, int32_t *pair_q, int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open,
+                            int gap_extend);
+
 /* The same with host buffers (upload, run, download): n_seq sequences, P pairs; ops / q_aln / t_aln hold sum(Lq + Lt) bytes
  * laid out as mdf_nw_plan's ops_off says; alphabet is a NUL-terminated string of A letters. */
 int mdf_nw_score_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const int32_t *pair_q,

@@ -697,6 +697,35 @@ int32_t mdf_nw_count_long_align(const int32_t *seq_len, const int32_t *pair_q, c
     return count_long(seq_len, pair_q, pair_t, P, min_cells);
 }
 
+// Score mode only needs the corner of the matrix, and NW(q, t; S) = NW(t, q; S^T): for a symmetric substitution matrix a pair may be swept
+// with either sequence as the rows.  The sweep costs ceil(columns / 128) strip pairs of (rows + 129) steps each (64-column strips of rows + 63
+// steps outside the 16-bit bucket), so the orientation with fewer steps is taken: a 100-residue query against a 300-residue candidate is one
+// strip pair of 432 steps instead of three of 232.  In place; returns the number of pairs turned round (0 for an asymmetric matrix).
+int32_t mdf_nw_orient_pairs(const int32_t *seq_len, int32_t *pair_q, int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend)
+{
+    if (!seq_len || !pair_q || !pair_t || !matrix || P < 0 || A <= 0) return fail(MDF_EINVAL, "nw_orient_pairs: bad arguments");
+    static const bool off = getenv("MDFRI_NW_ORIENT") && atoi(getenv("MDFRI_NW_ORIENT")) == 0;   // developer knob
+    if (off) return 0;
+    int smin = INT32_MAX, smax = INT32_MIN;
+    for (int32_t r = 0; r < A; ++r)
+        for (int32_t c = 0; c < A; ++c) {
+            if (matrix[r * A + c] != matrix[c * A + r]) return 0;
+            smin = std::min(smin, matrix[r * A + c]), smax = std::max(smax, matrix[r * A + c]);
+        }
+    const bool a16 = nw_allow16();
+    int32_t turned = 0;
+    for (int32_t p = 0; p < P; ++p) {
+        const int Lq = seq_len[pair_q[p]], Lt = seq_len[pair_t[p]];
+        const bool b16 = a16 && nw16_eligible(Lq, Lt, gap_open, gap_extend, smin, smax);   // symmetric in the two lengths
+        auto steps = [&](int rows, int cols) { return b16 ? ((int64_t)cols + 127) / 128 * nw_strip_steps16(rows) : ((int64_t)cols + 63) / 64 * nw_strip_steps(rows); };
+        if (Lq > 0 && Lt > 0 && steps(Lt, Lq) < steps(Lq, Lt)) {
+            std::swap(pair_q[p], pair_t[p]);
+            ++turned;
+        }
+    }
+    return turned;
+}
+
 int mdf_nw_plan(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P, int64_t *bnd_off, int64_t *trace_off,
                 int64_t *ops_off)
 {
@@ -799,6 +828,14 @@ static int nw_host(const uint8_t *codes, const int64_t *seq_off, const int32_t *
             MDF_REQUIRE(codes[b] < A, "nw: residue code %d at position %lld of sequence %d is outside the alphabet (size %d)", (int)codes[b],
                         (long long)(b - seq_off[s]), s, A);
     std::vector<int64_t> bo((size_t)P + 1), to((size_t)P + 1), oo((size_t)P + 1);
+    std::vector<int32_t> oq, ot;
+    if (!full) {   // score mode: every pair swept with the cheaper of its two orientations (mdf_nw_orient_pairs)
+        oq.assign(pair_q, pair_q + P);
+        ot.assign(pair_t, pair_t + P);
+        mdf_nw_orient_pairs(seq_len, oq.data(), ot.data(), P, matrix, A, go, ge);
+        pair_q = oq.data();
+        pair_t = ot.data();
+    }
     if (int rc = mdf_nw_plan(seq_len, pair_q, pair_t, P, bo.data(), to.data(), oo.data())) return rc;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
@@ -1098,6 +1135,9 @@ int mdf_nw_best_hits_begin(mdf_nw_workspace *w, const uint8_t *text, const int64
         spq[k] = pq[(size_t)p];
         spt[k] = cand[p];
         rk[p] = k;
+    }
+    mdf_nw_orient_pairs(seq_len, spq, spt, P, matrix, A, gap_open, gap_extend);   // score mode: rows = whichever sequence gives fewer steps
+    for (int32_t k = 0; k < P; ++k) {
         bo[k] = bnd_ints;
         bnd_ints += 2 * (int64_t)seq_len[spq[k]];
     }

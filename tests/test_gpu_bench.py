@@ -23,11 +23,12 @@ def _run(*argv, timeout=900):
 
 
 def test_default_shape_small():
-    line = _run("--proteins", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--cpu-workers", "2", "--end-to-end", "1")
+    line = _run("--proteins", "256", "--steps", "2", "--warmup", "1", "--cpu-seconds", "1", "--cpu-workers", "2", "--end-to-end", "1", "--query-stream", "2")
     assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["unit"] == "proteins/s" and line["value"] > 0
     assert line["verify"]["max_abs_err_vs_oracle"] < 1e-4
     assert line["roofline"]["bound"] == "mfma" and line["roofline_ax"]["bound"] == "hbm"
     assert set(line["by_length"]) == {"256", "1024"} and line["mixed"]["value"] > 0 and line["end_to_end"]["value"] > 0
+    assert line["query_stream"]["value"] > 0 and line["query_stream"]["queries"] == 8000 and line["query_stream"]["result_lines"] > 8000
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["process_pool"]["cores"] == 2 and "available" in cb["onnxruntime"]
     assert "cmap_stage_reference" in cb and cb["cmap_stage_reference"]["note"].startswith("constant")

@@ -58,6 +58,8 @@ if os.environ.get("NW_SORT", "1") == "1":      # largest DP matrices first (what
     o = pb._by_cost(pq, pt)
     pq, pt = np.ascontiguousarray(pq[o]), np.ascontiguousarray(pt[o])
 P = len(pq)
+if os.environ.get("NW_ORIENT", "1") == "1":    # score mode: rows = whichever sequence takes fewer steps (what the host entries do)
+    print("pairs turned round:", L.mdf_nw_orient_pairs(_hip.ptr(pb.seq_len), _hip.ptr(pq), _hip.ptr(pt), P, _hip.ptr(sm.matrix), 24, 10, 1), "of", P)
 bnd_off = np.zeros(P + 1, np.int64)
 L.mdf_nw_plan(_hip.ptr(pb.seq_len), _hip.ptr(pq), _hip.ptr(pt), P, _hip.ptr(bnd_off), None, None)
 dev = torch.device("cuda:0")
