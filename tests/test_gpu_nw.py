@@ -446,3 +446,27 @@ def test_stepped_aligner_keeps_several_batches_in_flight():
         p.launch_alignments()
     again = align_queries_begin(*batches[1], scoring_matrix=sm, workspace=ring[0]).result()      # the workspace is free again
     assert np.array_equal(again.ops, ref[1].ops)
+
+
+def test_score_mode_turns_pairs_to_the_cheaper_orientation():
+    """NW(q, t; S) = NW(t, q; S^T): with a symmetric matrix the score launch sweeps every pair with whichever sequence as rows takes
+    fewer steps (mdf_nw_orient_pairs); an asymmetric matrix turns nothing.  Scores equal the oracle's either way."""
+    from mDeepFRI import _hip
+    from mDeepFRI.alignment import _PairBatch
+    rng = np.random.default_rng(4)
+    seqs = [_seq(rng, int(n)) for n in (40, 300, 90, 700, 130, 129, 5, 260)]
+    pq = np.array([0, 0, 2, 4, 6, 5, 1, 3, 7], dtype=np.int32)
+    pt = np.array([1, 3, 7, 3, 3, 4, 0, 0, 2], dtype=np.int32)
+    sym = _matrix(5)
+    asym = ScoringMatrix(ALPHA, sym.matrix + np.triu(np.ones((24, 24), dtype=np.int32), 1), "asymmetric")
+    for sm, expect_turned in ((sym, True), (asym, False)):
+        pb = _PairBatch(seqs, sm)
+        a, b = pq.copy(), pt.copy()
+        turned = _hip.lib().mdf_nw_orient_pairs(_hip.ptr(pb.seq_len), _hip.ptr(a), _hip.ptr(b), len(a), _hip.ptr(sm.matrix), 24, 10, 1)
+        assert (turned > 0) == expect_turned
+        if expect_turned:      # exactly the pairs whose query is the shorter sequence by more than the strip quantisation buys back
+            assert [int(x) for x in a[:2]] == [1, 3] and [int(x) for x in b[:2]] == [0, 0] and (int(a[6]), int(b[6])) == (1, 0)
+        else:
+            assert np.array_equal(a, pq) and np.array_equal(b, pt)
+        got = pb.scores(pq, pt, 10, 1)
+        assert got.tolist() == [nwo.nw_score(seqs[i], seqs[j], sm.matrix, sm.alphabet) for i, j in zip(pq, pt)]
