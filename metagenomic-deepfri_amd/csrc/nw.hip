@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -325,8 +326,8 @@ __global__ __launch_bounds__(NW_THREADS) void k_nw16(const uint8_t *__restrict__
     const int lane = threadIdx.x & 63;
     const int p = own_block ? (int)blockIdx.x : n_long + ((int)blockIdx.x - n_long) * wg_waves + wid;
     if (p >= P) return;
-    const int iq = pair_q[p], it = pair_t[p];
-    const int Lq = seq_len[iq], Lt = seq_len[it];
+    const int iq = __builtin_amdgcn_readfirstlane(pair_q[p]), it = __builtin_amdgcn_readfirstlane(pair_t[p]);   // wave-uniform: say so
+    const int Lq = __builtin_amdgcn_readfirstlane(seq_len[iq]), Lt = __builtin_amdgcn_readfirstlane(seq_len[it]);
     if (!nw16_eligible(Lq, Lt, go, ge, s_mm[0], s_mm[1])) return;   // k_nw takes this pair
     const int n_sp = (Lt + 127) >> 7;                  // strip pairs
     const bool coop = own_block && n_sp <= NW_MAX_COOP_STRIPS;
@@ -367,21 +368,28 @@ __global__ __launch_bounds__(NW_THREADS) void k_nw16(const uint8_t *__restrict__
                 qres_next = 0;
                 sc_cur = nw16_lookup(s_S16, qres_next, tcaddr);
             }
-            uint32_t keep = 0;                           // lane u keeps element 127's {H, E} of step s0 + u - 1 (row s0 + u - 128)
+            uint32_t keep = 0;                           // element 127's {H, E} of step s0 + u - 1 (row s0 + u - 128) enters at lane 0 at step u and moves up a lane per step
             const int u_end = min(64, n_steps - s0);     // a multiple of four
-            for (int u = 0; u < u_end; ++u) {
+            // four steps per trip: the loop-carried registers rotate in place, the sub-step is known at compile time; only the chunk in which
+            // H[Lq][Lt] leaves the array looks for it (STAR)
+            auto sweep = [&](auto star_tag, auto pass_tag) {
+            constexpr bool STAR = decltype(star_tag)::value, PASS = decltype(pass_tag)::value;
+            for (int u0 = 0; u0 < u_end; u0 += 4)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const int u = u0 + k4;
                 const int s = s0 + u;
                 const uint32_t bs = (uint32_t)__builtin_amdgcn_readlane((int)b, u);
                 const uint32_t h63 = (uint32_t)__builtin_amdgcn_readlane((int)h_out, 63), e63 = (uint32_t)__builtin_amdgcn_readlane((int)e_out, 63);
                 const uint32_t left = (uint32_t)wave_shr1((int)h_out, (int)((h63 << 16) | (bs & 0xffffu)));
                 const uint32_t eleft = (uint32_t)wave_shr1((int)e_out, (int)((e63 << 16) | (bs >> 16)));
-                if (pass_right) keep = lane == u ? ((h63 >> 16) | (e63 & 0xffff0000u)) : keep;
+                if (PASS) keep = (uint32_t)wave_shr1((int)keep, (int)((h63 >> 16) | (e63 & 0xffff0000u)));   // a shift register: one DPP move per step
                 qres = qres_next;
                 const uint32_t sc = sc_cur;
                 // shift the residues for the next step and start its score lookup one step ahead
                 const uint32_t q63 = (uint32_t)__builtin_amdgcn_readlane((int)qres, 63);
-                const uint32_t q_in = (u + 1 < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)qrow, (u + 1) & 63)
-                                                   : ((s + 1 <= Lq) ? (uint32_t)min((int)q[s], NW_LDA - 1) * 64u : 0u);
+                const uint32_t q_in = (k4 < 3 || u + 1 < 64) ? (uint32_t)__builtin_amdgcn_readlane((int)qrow, (u + 1) & 63)
+                                                             : ((s + 1 <= Lq) ? (uint32_t)min((int)q[s], NW_LDA - 1) * 64u : 0u);
                 qres_next = (uint32_t)wave_shr1((int)qres, (int)((q63 << 16) | q_in));
                 sc_cur = nw16_lookup(s_S16, qres_next, tcaddr);
                 const uint32_t e_open = pk_sub(left, GO2), e_ext = pk_sub(eleft, GE2);
@@ -401,20 +409,29 @@ __global__ __launch_bounds__(NW_THREADS) void k_nw16(const uint8_t *__restrict__
                     const uint32_t from_f = HORIZ ? c2 : first, from_e = HORIZ ? first : c2;  // code 1 = 'D' (F), 2 = 'I' (E)
                     const uint32_t w = ((from_f >> 3) & 0x10001000u) | ((from_e >> 2) & 0x20002000u) | ((xe >> 1) & 0x40004000u) | (xf & 0x80008000u);
                     dir_acc = ((dir_acc >> 4) & 0x0FFF0FFFu) | w;                              // nibble k of a half = step 4g + k
-                    if ((u & 3) == 3) trk[(int64_t)(s >> 2) * 64 + lane] = dir_acc;
+                    if (k4 == 3) trk[(int64_t)(s >> 2) * 64 + lane] = dir_acc;
                 }
                 diag = left;
                 up = h;
                 fup = f;
                 h_out = h;
                 e_out = e;
-                if (last && s == s_star) {
+                if (STAR && s == s_star) {
                     const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)h_out, e_last & 63);
                     if (lane == 0) scores[p] = (e_last & 64) ? ((int)v >> 16) : (int)(short)(v & 0xffffu);
                 }
             }
+            };
+            const bool star = last && s_star >= s0 && s_star < s0 + u_end;
             if (pass_right) {
-                const int row = s0 + lane - 128;
+                if (star) sweep(std::true_type{}, std::true_type{});
+                else sweep(std::false_type{}, std::true_type{});
+            } else {
+                if (star) sweep(std::true_type{}, std::false_type{});
+                else sweep(std::false_type{}, std::false_type{});
+            }
+            if (pass_right) {
+                const int row = s0 + (u_end - 1 - lane) - 128;   // lane L holds what entered at step u_end - 1 - L
                 const bool mine = lane < u_end && row >= 0 && row <= Lq;
                 const int done = max(0, min(Lq + 1, s0 + u_end - 127));   // rows 0 .. done-1 of the right boundary are out
                 if (lds_bnd) {
