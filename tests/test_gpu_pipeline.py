@@ -148,3 +148,33 @@ def test_query_stream_equals_the_stage_by_stage_chain():
     # without a sequence engine the sequence-only queries are listed, nothing else
     r0 = next(iter(QueryStream(eng, xyz, batch_size=50, max_rows=8192, scoring_matrix=sm).run(qids[:50], qseqs[:50], cands[:50])))
     assert r0.cnn == {} and 3 in r0.sequence_only and len(r0.kept) == 50 - len(r0.sequence_only)
+
+
+def test_query_stream_errors_leave_it_usable():
+    """An invalid letter in a middle batch surfaces as the aligner's ValueError at that batch's second step; batches in flight are
+    abandoned and the same stream object (its three aligner workspaces) runs the next job."""
+    from mDeepFRI import synthetic
+    from mDeepFRI.alignment import ScoringMatrix
+    from mDeepFRI.batch import HotPathEngine
+    from mDeepFRI.predict import Predictor
+    from mDeepFRI.stream import QueryStream
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pipeline_example
+    qids, qseqs, cands, db_xyz = pipeline_example.make_inputs(120, 40, seed=5, k=3)
+    eng = HotPathEngine({"a": Predictor("syn", weights=synthetic.glorot_gcn_weights(seed=0, n_terms=50, sparse_scores=True))}, max_rows=8192)
+    stream = QueryStream(eng, db_xyz, batch_size=20, max_rows=8192, scoring_matrix=ScoringMatrix.simple())
+    bad = list(qseqs)
+    bad[65] = bad[65][:7] + "U" + bad[65][8:]
+    seen = []
+    with pytest.raises(ValueError, match="'U' is not in the scoring matrix alphabet"):
+        for r in stream.run(qids, bad, cands):
+            seen.append(r.first)
+    assert seen == [0]                                       # batch 3 (queries 60..79) fails at ITS second step = step 4 of the pipeline, which would have handed out batch 1
+    good = [r for r in stream.run(qids, qseqs, cands)]
+    assert [r.first for r in good] == list(range(0, 120, 20)) and all(len(r.kept) == 20 and r.gcn["a"][0][-1] >= 0 for r in good)
+    half = []
+    for r in stream.run(qids, qseqs, cands):                 # a consumer that stops early: the generator is closed with batches in flight
+        half.append(r.first)
+        if len(half) == 2:
+            break
+    assert [r.first for r in stream.run(qids[:40], qseqs[:40], cands[:40])] == [0, 20]
