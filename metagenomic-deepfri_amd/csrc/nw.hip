@@ -1191,12 +1191,21 @@ int mdf_nw_best_hits_begin(mdf_nw_workspace *w, const uint8_t *text, const int64
 
 // Step 2: wait for the scores, then (asynchronous again) align every query with its winner -- in groups whose direction words fit the
 // trace budget --, pack the alignments in query order and start them on their way back.
+static int nw_best_hits_align_steps(mdf_nw_workspace *w, int64_t *info);
+
 int mdf_nw_best_hits_align(mdf_nw_workspace *w, int64_t *info)
 {
     if (info) info[0] = info[1] = info[2] = -1;
     MDF_REQUIRE(w && w->stage == 1, "nw_best_hits_align: no scored call in flight on this workspace");
     DeviceGuard guard(w->device);
     MDF_HIP(guard.err);
+    const int rc = nw_best_hits_align_steps(w, info);
+    if (rc != MDF_OK) (void)hipStreamSynchronize(w->st);   // whatever was enqueued before the failure writes into the workspace: let it land
+    return rc;
+}
+
+static int nw_best_hits_align_steps(mdf_nw_workspace *w, int64_t *info)
+{
     StageTimer tm;
     w->stage = 0;   // any failure below abandons the call
     MDF_HIP(hipEventSynchronize(w->ev1));

@@ -255,12 +255,9 @@ def align_pairwise(query, target, gap_open: int = 10, gap_extend: int = 1, scori
 
 def pairwise_against_database(query_id, query_sequence, target_sequences, gap_open: int = 10, gap_extend: int = 1,
                               scoring_matrix="VTML80") -> AlignmentResult:
-    """reference alignment.py:223-250."""
-    sm = _matrix(scoring_matrix)
-    query_sequence = _upper(query_sequence)
-    best_idx, best_target = best_hit_database(query_sequence, target_sequences, gap_open, gap_extend, sm)
-    alignment, identity, qc, tc = align_pairwise(query_sequence, best_target, gap_open, gap_extend, sm)
-    return AlignmentResult(query_id, query_sequence, best_idx, best_target, alignment, identity, query_coverage=qc, target_coverage=tc)
+    """reference alignment.py:223-250: best hit of one query among its candidates + the alignment with it -- the batched entry with a
+    batch of one (a single library call instead of a score call and an alignment call)."""
+    return align_queries_arrays([query_id], [query_sequence], [target_sequences], gap_open, gap_extend, scoring_matrix).results()[0]
 
 
 class AlignedBatch:
