@@ -610,11 +610,19 @@ def main():
                 raise SystemExit(f"parity check failed: max |score - oracle| = {line['verify']['max_abs_err_vs_oracle']}")
         if ctx.world == 1 and args.workload == "configs2" and not args.no_extras and not args.lm:
             # the rest of the north_star's measurement list on the same engine, each a short run of its own (never `value`)
-            line["by_length"] = {str(L): mini_run(ctx, eng, make_fixed_length(42 + 2 + L, n_local, L), args.chunk_rows) for L in (256, 1024)}
-            line["mixed"] = mini_run(ctx, eng, make_mixed(42 + 4, n_local), args.chunk_rows)
-            line["helix"] = mini_run(ctx, eng, make_helix(42 + 5, n_local, args.length), args.chunk_rows)
-            line["helix"]["note"] = "same shape as the headline run, protein-like C-alpha traces (helix bundles) instead of random walks"
-            if args.end_to_end > 0:
+            # a leg that fails is reported in its own field and does not take the headline line with it
+            def leg(name, fn):
+                try:
+                    line[name] = fn()
+                except Exception as e:  # noqa: BLE001
+                    line[name] = {"error": f"{type(e).__name__}: {e}"[:500]}
+
+            leg("by_length", lambda: {str(L): mini_run(ctx, eng, make_fixed_length(42 + 2 + L, n_local, L), args.chunk_rows) for L in (256, 1024)})
+            leg("mixed", lambda: mini_run(ctx, eng, make_mixed(42 + 4, n_local), args.chunk_rows))
+            leg("helix", lambda: dict(mini_run(ctx, eng, make_helix(42 + 5, n_local, args.length), args.chunk_rows),
+                                      note="same shape as the headline run, protein-like C-alpha traces (helix bundles) instead of random walks"))
+
+            def end_to_end_leg():
                 from mDeepFRI.stream import AlignmentStream
                 items = []
                 for k in range(args.end_to_end):
@@ -626,10 +634,11 @@ def main():
                 n_out = sum(res[MODES[0]].shape[0] for _, res in stream.run(items))
                 dt = time.perf_counter() - t0
                 assert n_out == len(items)
-                line["end_to_end"] = {"value": round(len(items) / dt, 1), "unit": "proteins/s", "batches": args.end_to_end,
-                                      "note": "PCIe-inclusive: host lists in -> host float32 score arrays out (packing thread + upload + compute + "
-                                              "download, batches pipelined; mDeepFRI.stream.AlignmentStream); never `value`"}
-            if args.query_stream > 0:
+                return {"value": round(len(items) / dt, 1), "unit": "proteins/s", "batches": args.end_to_end,
+                        "note": "PCIe-inclusive: host lists in -> host float32 score arrays out (packing thread + upload + compute + "
+                                "download, batches pipelined; mDeepFRI.stream.AlignmentStream); never `value`"}
+
+            def query_stream_leg():
                 # the stages either side of the path as one stream (SURVEY 8f rows 3 and 4 around the path): host sequences + candidate sets
                 # in, results.tsv text of all three heads out; heads at a trained-like operating point (a few % of the terms pass 0.1)
                 from mDeepFRI.alignment import ScoringMatrix
@@ -653,12 +662,17 @@ def main():
                             n_lines += text.count(b"\n")
                             n_bytes += len(text)
                     dt = time.perf_counter() - t0
-                line["query_stream"] = {"value": round(nq / dt, 1), "unit": "proteins/s", "batches": args.query_stream, "queries": nq,
-                                        "candidates_per_query": 8, "mean_query_length": round(float(np.mean([len(q) for q in qseqs])), 1),
-                                        "result_lines": n_lines, "text_mb": round(n_bytes / 1e6, 1),
-                                        "note": "host sequences + candidate sets in -> best hit + alignment (GPU aligner) -> contact maps + GCN, 3 heads -> "
-                                                "score >= 0.1 filter -> results.tsv text out (mDeepFRI.stream.QueryStream: one stream, software pipeline "
-                                                "four batches deep; includes its fill and drain); never `value`"}
+                return {"value": round(nq / dt, 1), "unit": "proteins/s", "batches": args.query_stream, "queries": nq,
+                        "candidates_per_query": 8, "mean_query_length": round(float(np.mean([len(q) for q in qseqs])), 1),
+                        "result_lines": n_lines, "text_mb": round(n_bytes / 1e6, 1),
+                        "note": "host sequences + candidate sets in -> best hit + alignment (GPU aligner) -> contact maps + GCN, 3 heads -> "
+                                "score >= 0.1 filter -> results.tsv text out (mDeepFRI.stream.QueryStream: one stream, software pipeline "
+                                "four batches deep; includes its fill and drain); never `value`"}
+
+            if args.end_to_end > 0:
+                leg("end_to_end", end_to_end_leg)
+            if args.query_stream > 0:
+                leg("query_stream", query_stream_leg)
         line["cpu_baseline"] = cpu_leg
         if cpu_leg:
             line["gpu_over_cpu_1core"] = round(line["value"] / cpu_leg["value"], 1)
