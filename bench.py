@@ -26,8 +26,8 @@ Objects on the line (tier contract):
   cpu_baseline  the oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample: one thread
                 (the configuration the reference ships) and a pool of single-thread worker processes (the reference's own
                 parallelism, pipeline.py:476-481); real onnxruntime-CPU on the exported synthetic weights when ORT is importable
-  by_length / mixed / helix / end_to_end / query_stream   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix,
-  protein-like helix-bundle traces (fewer contacts per residue than a random walk), the
+  by_length / mixed / helix / gcn_only / end_to_end / query_stream   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix,
+  protein-like helix-bundle traces (fewer contacts per residue than a random walk), the GCN alone on given contact maps, the
                 PCIe-inclusive host-lists-in / host-arrays-out rate, and the stages either side of the path as one stream
                 (sequences + candidate sets in -> aligner -> path -> filter -> results.tsv text out) -- never `value`
 """
@@ -669,6 +669,42 @@ def main():
                                 "score >= 0.1 filter -> results.tsv text out (mDeepFRI.stream.QueryStream: one stream, software pipeline "
                                 "four batches deep; includes its fill and drain); never `value`"}
 
+            def gcn_only_leg():
+                # the other half of SURVEY 8(d)'s metric: the GCN alone, contact maps given.  (i) as the reference's API hands them over --
+                # dense int32 (L, L) arrays in host memory, 1 MiB per protein at L = 512 (Predictor.forward_pass's shape, batched:
+                # HotPathEngine.forward_dense): PCIe-bound; (ii) the fused step without its contact-map kernels (their sampled time
+                # taken off the step): what the GCN kernels alone sustain on maps already in HBM.
+                from mDeepFRI.alignment import AlignmentResult
+                n = min(1024, n_local)
+                alns = []
+                for k in range(n):
+                    a = AlignmentResult(query_name=f"p{k}", query_sequence=seqs[k], target_name=f"t{k}", target_sequence=seqs[k], alignment="M" * len(seqs[k]))
+                    a.gapped_sequence, a.gapped_target, a.coords = q_alns[k], t_alns[k], coords[k]
+                    alns.append(a)
+                maps = [cm for _, cm in batch.build_align_contact_maps(alns, device=local_rank, max_rows=args.chunk_rows)]
+                pk_d = batch.PackedProteins.pack(seqs[:n], max_rows=args.chunk_rows)
+                db_d = eng.upload(pk_d)
+                eng.forward_dense(db_d, maps)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                out_d = eng.forward_dense(db_d, maps)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                err = float(max((out_d[m][:8] - out[m][:8]).abs().max().item() for m in MODES))
+                res = {"value": round(n / dt, 1), "unit": "proteins/s", "proteins": n, "host_map_bytes": int(sum(m_.nbytes for m_ in maps)),
+                       "max_abs_diff_vs_fused_path": err,
+                       "note": "GCN alone on dense int32 (L, L) contact maps handed over from host memory (the reference API's format, batched: "
+                               "forward_dense): PCIe-inclusive, 1 MiB per protein at L = 512; never `value`"}
+                cm = kernels.get("cmap") if isinstance(kernels, dict) else None
+                if cm and cm.get("launches"):
+                    chunks_per_step = len(pk.chunks)
+                    cmap_ms = cm["avg_us"] * chunks_per_step / 1e3
+                    res["maps_in_hbm"] = {"value": round(n_local / ((1e3 * elapsed / args.steps - cmap_ms) / 1e3), 1), "unit": "proteins/s",
+                                          "note": f"the fused step minus its contact-map kernels ({cmap_ms:.2f} ms of {1e3 * elapsed / args.steps:.2f} ms per step, sampled "
+                                                  "launch times): the GCN kernels alone on maps already in HBM"}
+                return res
+
+            leg("gcn_only", gcn_only_leg)
             if args.end_to_end > 0:
                 leg("end_to_end", end_to_end_leg)
             if args.query_stream > 0:

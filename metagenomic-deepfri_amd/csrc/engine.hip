@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <functional>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -385,7 +386,8 @@ struct mdf_engine {
     // pinned staging + events of the dense-map path
     char *map_pin[2] = {nullptr, nullptr};
     size_t map_pin_bytes[2] = {0, 0};
-    hipEvent_t map_ev[2] = {nullptr, nullptr};
+    hipEvent_t map_ev[2] = {nullptr, nullptr}, map_up_ev[2] = {nullptr, nullptr};
+    hipStream_t map_stream = nullptr;   // the maps cross PCIe on a stream of their own (highest priority: its own hardware queue), under the previous chunk's kernels
     // hipGraph cache (short launch sequences); captured on an engine-owned stream (the caller's may be the legacy default
     // stream, which cannot be captured), replayed on the caller's
     hipStream_t cap_stream = nullptr;
@@ -488,6 +490,7 @@ extern "C" void mdf_engine_free(mdf_engine *e)
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->aux) (void)hipStreamDestroy(e->aux);
+    if (e->map_stream) (void)hipStreamDestroy(e->map_stream);
     for (DevBuf *b : {&e->gws, &e->hws, &e->seq_all, &e->lm_ws, &e->host_in, &e->host_scores, &e->map_dev[0], &e->map_dev[1], &e->flags}) b->release();
     for (auto &b : e->partial) b.release();
     for (auto &b : e->pooled) b.release();
@@ -495,6 +498,7 @@ extern "C" void mdf_engine_free(mdf_engine *e)
     for (int i = 0; i < 2; ++i) {
         if (e->map_pin[i]) (void)hipHostFree(e->map_pin[i]);
         if (e->map_ev[i]) (void)hipEventDestroy(e->map_ev[i]);
+        if (e->map_up_ev[i]) (void)hipEventDestroy(e->map_up_ev[i]);
     }
     delete e;
 }
@@ -859,6 +863,17 @@ extern "C" int64_t mdf_engine_last_chunk_nnz(mdf_engine *e, void *stream)
 }
 
 // ---- dense-map path ------------------------------------------------------------------------------------------------
+// host threads that stage dense maps into pinned memory (MDFRI_HOST_COPY_THREADS, default: up to 8)
+static int host_copy_threads()
+{
+    static const int v = [] {
+        const char *e = getenv("MDFRI_HOST_COPY_THREADS");
+        const int n = e ? atoi(e) : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
+        return std::min(std::max(n, 1), 64);
+    }();
+    return v;
+}
+
 extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, const void *const *cmaps_host, int cmap_dtype,
                                         float *const *scores, float *const *logits, void *stream)
 {
@@ -872,8 +887,15 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (int rc = plan_mirror(pl, e->device, st)) return rc;
     if (int rc = ensure(e, pl->max_chunk_rows, pl->B, 0, pl->max_groups)) return rc;
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (!e->map_ev[i]) MDF_HIP(hipEventCreateWithFlags(&e->map_ev[i], hipEventDisableTiming));
+        if (!e->map_up_ev[i]) MDF_HIP(hipEventCreateWithFlags(&e->map_up_ev[i], hipEventDisableTiming));
+    }
+    if (!e->map_stream) {
+        int lo = 0, hi = 0;
+        MDF_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        MDF_HIP(hipStreamCreateWithPriority(&e->map_stream, hipStreamNonBlocking, hi));
+    }
     int parity = 0;
     bool used[2] = {false, false};
     BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *, bool *have_lsum) -> int {
@@ -898,19 +920,35 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         char *dst = e->map_pin[s] + o_maps;
         int64_t nnz_needed = ch.rows, off = 0;
         for (int32_t p = ch.p0; p < ch.p1; ++p) {
-            const size_t n = (size_t)pl->Lq[(size_t)p] * (size_t)pl->Lq[(size_t)p];
             offs[p - ch.p0] = off;
-            memcpy(dst + (size_t)off * 4, cmaps_host[p], n * 4);
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(dst + (size_t)off * 4);
-            int64_t nz = 0;
-            if (cmap_dtype == MDF_DT_I32) {
-                for (size_t i = 0; i < n; ++i) nz += w[i] != 0;
-            } else {
-                for (size_t i = 0; i < n; ++i) nz += (w[i] << 1) != 0;   // +0.0 and -0.0 are zeros
-            }
-            nnz_needed += nz;
-            off += (int64_t)n;
+            off += (int64_t)pl->Lq[(size_t)p] * (int64_t)pl->Lq[(size_t)p];
         }
+        // copy + count the non-zeros of every map: 128 MiB per chunk at L = 512, two passes of one host core would take ten times
+        // as long as the device needs for the chunk -- the proteins are dealt to a few host threads
+        const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)host_copy_threads(), (int64_t)Bc, (int64_t)(elems >> 20) + 1}));
+        std::vector<int64_t> nz_part((size_t)nt, 0);
+        auto work = [&](int k) {
+            int64_t nz = 0;
+            for (int32_t p = ch.p0 + k; p < ch.p1; p += nt) {
+                const size_t n = (size_t)pl->Lq[(size_t)p] * (size_t)pl->Lq[(size_t)p];
+                char *to = dst + (size_t)offs[p - ch.p0] * 4;
+                memcpy(to, cmaps_host[p], n * 4);
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(to);
+                if (cmap_dtype == MDF_DT_I32) {
+                    for (size_t i = 0; i < n; ++i) nz += w[i] != 0;
+                } else {
+                    for (size_t i = 0; i < n; ++i) nz += (w[i] << 1) != 0;   // +0.0 and -0.0 are zeros
+                }
+            }
+            nz_part[(size_t)k] = nz;
+        };
+        {
+            std::vector<std::thread> pool;
+            for (int k = 1; k < nt; ++k) pool.emplace_back(work, k);
+            work(0);
+            for (auto &th : pool) th.join();
+        }
+        for (int k = 0; k < nt; ++k) nnz_needed += nz_part[(size_t)k];
         if (nnz_needed > e->nnz_cap) {   // a denser chunk than the CSR arrays hold: grow them (hipFree waits for the device)
             MDF_REQUIRE(nnz_needed < 0x7fffffffLL, "engine_forward_dense: a chunk needs %lld CSR entries; lower max_rows", (long long)nnz_needed);
             if (int rc = e->cs[0].colidx.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
@@ -918,7 +956,10 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
             e->nnz_cap = nnz_needed;
         }
         char *d = e->map_dev[s].as<char>();
-        MDF_HIP(hipMemcpyAsync(d, e->map_pin[s], total, hipMemcpyHostToDevice, st));
+        // the device slot is free (map_ev[s] was waited for above): the upload overlaps whatever the compute stream is still doing
+        MDF_HIP(hipMemcpyAsync(d, e->map_pin[s], total, hipMemcpyHostToDevice, e->map_stream));
+        MDF_HIP(hipEventRecord(e->map_up_ev[s], e->map_stream));
+        MDF_HIP(hipStreamWaitEvent(st, e->map_up_ev[s], 0));
         const int rc = mdf_dense_to_csr_dev(d + o_maps, cmap_dtype, reinterpret_cast<const int64_t *>(d), b->Lq + ch.p0, pl->d_chunk_row_off + ch.row_off_pos,
                                             Bc, ch.rows, e->cs[0].rowptr.as<int32_t>(), e->cs[0].colidx.as<int32_t>(), e->cs[0].val.as<float>(), e->nnz_cap,
                                             b->status + 4 * ci, e->cs[0].cws.p, e->cs[0].cws.bytes, st);
