@@ -495,23 +495,57 @@ def build_align_contact_maps(alignments, threshold: float = 6, generated_contact
     seqs = [seqs[k] for k in nonempty]
     pk = PackedProteins.pack(seqs, [alignments[i].coords for i in live], [alignments[i].gapped_sequence for i in live],
                              [alignments[i].gapped_target for i in live], max_rows=max_rows)
-    with torch.cuda.device(dev):
+    # Per chunk: one launch builds the dense maps on the device; they cross PCIe into one of two pinned buffers on a second,
+    # high-priority stream while the next chunk is being built, and a few host threads cut the buffer into the freshly allocated
+    # (Lq, Lq) arrays the reference hands out (1 MiB each at L = 512: the copies, not the kernels, are the cost of this format).
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+
+    def cut(host, off, Lp):
+        a = np.empty((Lp, Lp), dtype=np.int32)
+        np.copyto(a, host[off:off + Lp * Lp].reshape(Lp, Lp))
+        return a
+
+    def finish(job, pool):
+        ch, offs, host, ev = job
+        ev.synchronize()
+        lens = [int(pk.Lq[p]) for p in range(ch.p0, ch.p1)]
+        for p, a in zip(range(ch.p0, ch.p1), pool.map(cut, [host] * len(lens), offs.tolist(), lens)):
+            results[live[p]] = (alignments[live[p]], a)
+
+    with torch.cuda.device(dev), ThreadPoolExecutor(max_workers=max(1, min(8, os.cpu_count() or 1))) as pool:
         db = DeviceBatch(pk, dev)
-        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(dev, priority=-1)
+        st = ctypes.c_void_p(main.cuda_stream)
         cws = torch.empty(L.mdf_cmap_workspace_bytes(pk.B, pk.max_chunk_rows, 0), dtype=torch.uint8, device=dev)
-        for ch in pk.chunks:
+        pin, job = [None, None], None
+        for ci, ch in enumerate(pk.chunks):
             sizes = pk.Lq[ch.p0:ch.p1].astype(np.int64)**2
             offs = np.zeros(len(sizes), dtype=np.int64)
             np.cumsum(sizes[:-1], out=offs[1:])
-            out = torch.empty(int(sizes.sum()), dtype=torch.int32, device=dev)
+            n = int(sizes.sum())
+            out = torch.empty(n, dtype=torch.int32, device=dev)
             d_off = torch.from_numpy(offs).to(dev)
             _hip.check(L.mdf_cmap_dense_dev(_p(db.coords), _p(db.coord_off, ch.p0), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off, ch.p0),
                                             _p(db.Lq, ch.p0), _p(db.chunk_row_off, ch.row_off_pos), ch.p1 - ch.p0, ch.rows,
                                             float(threshold), int(generated_contacts), _p(out), _p(d_off), _p(cws), cws.numel(), st))
-            host = out.cpu().numpy()
-            for k, p in enumerate(range(ch.p0, ch.p1)):
-                Lp = int(pk.Lq[p])
-                results[live[p]] = (alignments[live[p]], host[offs[k]:offs[k] + Lp * Lp].reshape(Lp, Lp).copy())
+            built = torch.cuda.Event()
+            built.record(main)
+            s = ci & 1                      # the buffer chunk ci - 2 used: its arrays were cut out before chunk ci - 1 was launched
+            if pin[s] is None or pin[s].numel() < n:
+                pin[s] = torch.empty(n + n // 4, dtype=torch.int32, pin_memory=True)
+            with torch.cuda.stream(side):
+                side.wait_event(built)
+                out.record_stream(side)
+                pin[s][:n].copy_(out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            if job is not None:
+                finish(job, pool)
+            job = (ch, offs, pin[s].numpy(), ev)
+        if job is not None:
+            finish(job, pool)
     return results
 
 

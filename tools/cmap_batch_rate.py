@@ -1,0 +1,21 @@
+"""Rate of the batched dense contact-map builder (`batch.build_align_contact_maps`: the reference's `Pool.map(build_align_contact_map)`,
+pipeline.py:476-481, int32 (Lq, Lq) maps back in host memory)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
+import numpy as np, torch
+from mDeepFRI import synthetic
+from mDeepFRI.alignment import AlignmentResult
+from mDeepFRI.batch import build_align_contact_maps
+n, L = int(os.environ.get("N", 1024)), 512
+alns = []
+for k, d in enumerate(synthetic.synthetic_proteins(3, n, L)):
+    a = AlignmentResult(query_name=f"p{k}", query_sequence=d["seq"], target_name=f"t{k}", target_sequence=d["seq"], alignment="M" * L)
+    a.gapped_sequence, a.gapped_target, a.coords = d["q_aln"], d["t_aln"], d["coords"]
+    alns.append(a)
+build_align_contact_maps(alns[:256], max_rows=65536)
+for rep in range(3):
+    t0 = time.perf_counter()
+    res = build_align_contact_maps(alns, max_rows=65536)
+    dt = time.perf_counter() - t0
+    print(f"build_align_contact_maps: {n} x L={L}: {dt * 1e3:.1f} ms = {n / dt / 1e3:.1f} k proteins/s ({n * L * L * 4 / dt / 1e9:.1f} GB/s of int32 maps)")
+print(res[5][1].shape, res[5][1].dtype, int(res[5][1].sum()), res[5][1].flags["OWNDATA"])
