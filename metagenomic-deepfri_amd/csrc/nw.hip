@@ -501,12 +501,28 @@ __global__ __launch_bounds__(256) void k_nw_traceback(const int32_t *__restrict_
         if (state == 0) {
             if (i == 0) { state = 2; continue; }
             if (j == 0) { state = 1; continue; }
-            const int c = __builtin_amdgcn_readfirstlane(code_at(i, j));
-            const int src = c & 3;
-            if (src != 0) { state = src; continue; }
-            op = 'M';     // k_nw_finish turns it into 'X' where the residues differ
-            --i;
-            --j;
+            // A run of diagonal moves is taken in one round: lane k looks at cell (i - k, j - k).  Those cells sit in the window of
+            // (i, j) as long as the column stays inside the strip (pair) and the step -- two less per diagonal move -- inside the
+            // 64-step chunk; the first cell whose H did not come from the diagonal ends the run.  ('M' here; k_nw_finish turns it
+            // into 'X' where the residues differ.)
+            (void)code_at(i, j);                                    // makes the window hold (i, j)
+            const int jj = j - 1, e0 = nib ? (jj & 127) : (jj & 63), s0 = nib ? i + e0 : i - 1 + e0, so0 = s0 & 63;
+            const int kmax = min(min(min(i, j), 64), min(e0 + 1, (so0 >> 1) + 1));   // >= 1
+            int src = 0;
+            if (lane < kmax) {
+                const int jk = jj - lane, sk = so0 - 2 * lane;
+                const uint32_t word = win[(sk >> 2) * 64 + (jk & 63)];
+                src = nib ? (int)((word >> ((jk & 64 ? 16 : 0) + (sk & 3) * 4)) & 3u) : (int)((word >> ((sk & 3) * 8)) & 3u);
+            }
+            const unsigned long long stop = __ballot(lane < kmax && src != 0);
+            const int k0 = stop ? (int)__builtin_ctzll(stop) : kmax;                 // diagonal moves before the first other source
+            if (lane < k0) ops[w - 1 - lane] = 'M';
+            w -= k0;
+            n += k0;
+            i -= k0;
+            j -= k0;
+            if (k0 < kmax) state = __builtin_amdgcn_readlane(src, k0);              // cell (i, j) now: its H came from a gap state
+            continue;
         } else if (state == 1) {
             const int ext = (j == 0) ? (i > 1) : ((__builtin_amdgcn_readfirstlane(code_at(i, j)) >> 3) & 1);
             op = 'D';
