@@ -1264,6 +1264,20 @@ static int nw_best_hits_align_steps(mdf_nw_workspace *w, int64_t *info)
     }
     int64_t *bo2 = reinterpret_cast<int64_t *>(g + w->g_bo), *to2 = reinterpret_cast<int64_t *>(g + w->g_to), *oo2 = reinterpret_cast<int64_t *>(g + w->g_oo);
     if (int rc = mdf_nw_plan(seq_len, sq, stt, nq, bo2, to2, oo2)) return rc;
+    {   // mdf_nw_plan reserves the larger of the two direction formats; here the matrix and the gap model are known, hence which kernel
+        // sweeps a pair (nw16_eligible, the test the kernels apply): the exact size -- half of it for nibble pairs -- is reserved
+        const int32_t *mat = reinterpret_cast<const int32_t *>(h + w->h_mat);
+        int smin = INT32_MAX, smax = INT32_MIN;
+        for (int32_t e = 0; e < w->A * w->A; ++e) smin = std::min(smin, mat[e]), smax = std::max(smax, mat[e]);
+        const bool a16 = nw_allow16();
+        int64_t tr = 0;
+        for (int32_t k = 0; k < nq; ++k) {
+            const int Lq = seq_len[sq[k]], Lt = seq_len[stt[k]];
+            to2[k] = tr;
+            tr += (a16 && nw16_eligible(Lq, Lt, w->go, w->ge, smin, smax) ? ((int64_t)Lt + 127) / 128 * nw_strip_steps16(Lq) : ((int64_t)Lt + 63) / 64 * nw_strip_steps(Lq)) * 64;
+        }
+        to2[nq] = tr;
+    }
     int64_t max_group = 0;
     std::vector<int32_t> cuts{0};
     for (int32_t p0 = 0; p0 < nq;) {
