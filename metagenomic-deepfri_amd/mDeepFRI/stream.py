@@ -135,6 +135,8 @@ class QueryBatchResult:
     gcn: dict = field(default_factory=dict)
     sequence_only: list = field(default_factory=list)
     cnn: dict = field(default_factory=dict)
+    gcn_scores: dict = field(default_factory=dict)      # with keep_scores: {mode: float32 (len(kept), T)} / (len(sequence_only), T)
+    cnn_scores: dict = field(default_factory=dict)
 
     def __iter__(self):      # (first, batch, kept, gcn): the structure branch alone
         return iter((self.first, self.batch, self.kept, self.gcn))
@@ -155,16 +157,19 @@ class QueryStream:
 
     engine: HotPathEngine.  structures: mapping target key -> float32 (Lt, 3) C-alpha trace (`.get`; a hit without one makes its query a
     sequence-only query, as pipeline.py:485 does).  batch_size: queries per device batch.  sequence_engine: a batch.SequenceEngine with
-    the CNN heads for the sequence-only queries (optional)."""
+    the CNN heads for the sequence-only queries (optional).  keep_scores: also hand out the full score matrices (`gcn_scores` /
+    `cnn_scores`: {mode: float32 (rows, T)}, what `output.write_prediction_matrix` takes) -- 11 KB per protein and three heads more over
+    PCIe, on the side stream."""
 
     def __init__(self, engine: HotPathEngine, structures, batch_size: int = 4000, max_rows: int = 65536, scoring_matrix="VTML80",
-                 gap_open: int = 10, gap_extend: int = 1, threshold: float = 0.1, capacity_per_protein: int = 64, sequence_engine=None):
+                 gap_open: int = 10, gap_extend: int = 1, threshold: float = 0.1, capacity_per_protein: int = 64, sequence_engine=None,
+                 keep_scores: bool = False):
         import torch
         from .alignment import AlignerWorkspace
         self.engine, self.structures, self.sequence_engine = engine, structures, sequence_engine
         self.batch_size, self.max_rows = int(batch_size), int(max_rows)
         self.scoring_matrix, self.gap_open, self.gap_extend = scoring_matrix, int(gap_open), int(gap_extend)
-        self.threshold, self.capacity_per_protein = float(threshold), int(capacity_per_protein)
+        self.threshold, self.capacity_per_protein, self.keep_scores = float(threshold), int(capacity_per_protein), bool(keep_scores)
         self.main, self.side = torch.cuda.Stream(engine.device), torch.cuda.Stream(engine.device, priority=-1)
         self.ring = [AlignerWorkspace(engine.device.index or 0, stream=self.main.cuda_stream) for _ in range(3)]
 
@@ -262,11 +267,11 @@ class QueryStream:
                 eng.raise_flags(pk, flags[0].numpy(), flags[1].numpy())
         except _hip.CapacityError:   # rare: a denser batch than the CSR capacity planned for; redo it synchronously
             with torch.cuda.stream(side):
-                res = {}
-                for m, arr in redo(pk).items():
+                res, redone = {}, redo(pk)
+                for m, arr in redone.items():
                     o, ti, sc = filter_scores(torch.from_numpy(arr).to(eng.device), self.threshold, self.capacity_per_protein)
                     res[m] = (o.cpu().numpy(), ti.cpu().numpy(), sc.cpu().numpy())
-            return res
+            return res, (redone if self.keep_scores else {})
         res = {}
         with torch.cuda.stream(side):      # not behind the next batch, which already occupies the main stream
             for m, (offsets, term_idx, sc, _) in filt.items():
@@ -283,15 +288,21 @@ class QueryStream:
                 ti_h.copy_(term_idx[:n], non_blocking=True)
                 sc_h.copy_(sc[:n], non_blocking=True)
                 res[m] = (off_h, ti_h.numpy(), sc_h.numpy())
+            full = {}
+            if self.keep_scores:
+                for m, t in out.items():
+                    t.record_stream(side)
+                    full[m] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    full[m].copy_(t, non_blocking=True)
             side.synchronize()
-        return res
+        return res, {m: t.numpy() for m, t in full.items()}
 
     def _finish(self, pending):
         res, gcn, cnn, ev = pending
         if ev is not None:
             ev.synchronize()
         if gcn is not None:
-            res.gcn = self._collect(gcn, self.engine.run_alignments)
+            res.gcn, res.gcn_scores = self._collect(gcn, self.engine.run_alignments)
         if cnn is not None:
-            res.cnn = self._collect(cnn, None)
+            res.cnn, res.cnn_scores = self._collect(cnn, None)
         return res

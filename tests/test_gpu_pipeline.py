@@ -113,7 +113,7 @@ def test_query_stream_equals_the_stage_by_stage_chain():
         if has[k] >= 200:
             xyz.pop(ref_batch.target_keys[k], None)
     stream = QueryStream(eng, xyz, batch_size=50, max_rows=8192, scoring_matrix=sm, threshold=0.1, capacity_per_protein=2,   # head "b" (dense scores) overflows 2 per protein
-                         sequence_engine=seq_eng)
+                         sequence_engine=seq_eng, keep_scores=True)
     seen = n_seq_only = 0
     for r in stream.run(qids, qseqs, cands):
         first, b, kept, res = r
@@ -134,12 +134,14 @@ def test_query_stream_equals_the_stage_by_stage_chain():
             pk, _ = PackedProteins.from_aligned_batch(one, coords, max_rows=8192)
             scores = eng.run_alignments(pk)
             for m in w:
+                assert np.array_equal(r.gcn_scores[m], scores[m])
                 off, ti, sc = filter_scores(torch.from_numpy(scores[m]).cuda(), 0.1, capacity_per_protein=400)
                 assert np.array_equal(res[m][0], off.cpu().numpy()) and np.array_equal(res[m][1], ti.cpu().numpy()) and np.array_equal(res[m][2], sc.cpu().numpy())
                 ids = [b.query_ids[i] for i in kept]
                 assert results_text(ids, "gcn", m, [f"t{k}" for k in range(scores[m].shape[1])], [], *res[m]).count(b"\n") == len(res[m][1])
         if r.sequence_only:
             y = seq_eng.run([qseqs[first + i] for i in r.sequence_only])["a"]
+            assert np.array_equal(r.cnn_scores["a"], y)
             off, ti, sc = filter_scores(torch.from_numpy(y).cuda(), 0.1, capacity_per_protein=100)
             assert np.array_equal(r.cnn["a"][0], off.cpu().numpy()) and np.array_equal(r.cnn["a"][1], ti.cpu().numpy()) and np.array_equal(r.cnn["a"][2], sc.cpu().numpy())
         else:
@@ -147,7 +149,7 @@ def test_query_stream_equals_the_stage_by_stage_chain():
     assert seen == 230 and n_seq_only >= 4 + 1 + 30
     # without a sequence engine the sequence-only queries are listed, nothing else
     r0 = next(iter(QueryStream(eng, xyz, batch_size=50, max_rows=8192, scoring_matrix=sm).run(qids[:50], qseqs[:50], cands[:50])))
-    assert r0.cnn == {} and 3 in r0.sequence_only and len(r0.kept) == 50 - len(r0.sequence_only)
+    assert r0.cnn == {} and 3 in r0.sequence_only and len(r0.kept) == 50 - len(r0.sequence_only) and r0.gcn_scores == {}
 
 
 def test_query_stream_errors_leave_it_usable():
