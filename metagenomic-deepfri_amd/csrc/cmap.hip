@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_a
 // The contact term is symmetric for coords-derived pairs (argwhere yields (i,j) and (j,i)), so the one-directional
 // write of pyx:115 reproduces exactly this.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int CMAP_COL_TILE = 1024;   // columns of a protein staged in LDS at a time (16 KiB)
 enum CmapMode { CM_COUNT = 0, CM_DENSE = 2 };   // COUNT also stores every row's contact bits (64 columns per word) for k_cmap_fill
 
 __device__ __forceinline__ int find_protein(const int32_t *__restrict__ row_off, int B, int row)
@@ -296,20 +297,37 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
     int32_t *dense_p = nullptr;
     if (MODE == CM_DENSE) dense_p = dense_out + dense_off[p];
 
-    if (i_first < Lq) {
-        for (int j0 = 0; j0 < Lq; j0 += 64) {
+    // The columns' target coordinates go through LDS, a tile of CMAP_COL_TILE columns at a time, loaded once by the whole workgroup:
+    // fetched per 64-column chunk by every wave (an index load and three dependent coordinate loads each time) the kernel spent its
+    // time waiting for eight such round trips in a row.
+    __shared__ float4 s_col[CMAP_COL_TILE];   // x, y, z, bits of the mapped target index (-2 padding, -1 gap, -3 no coordinates)
+    for (int jt = 0; jt < Lq; jt += CMAP_COL_TILE) {
+        const int jt_end = min(jt + CMAP_COL_TILE, Lq);
+        __syncthreads();   // the previous tile has been consumed
+        for (int c = jt + (int)threadIdx.x; c < jt_end; c += 256) {
+            int t = q2t_p[c];
+            if (t >= Lt) t = -3;
+            float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(t));
+            if (t >= 0) {
+                v.x = xyz[t * 3 + 0];
+                v.y = xyz[t * 3 + 1];
+                v.z = xyz[t * 3 + 2];
+            }
+            s_col[c - jt] = v;
+        }
+        __syncthreads();
+        if (i_first >= Lq) continue;   // (wave-uniform; the barriers above are reached by every wave)
+        for (int j0 = jt; j0 < jt_end; j0 += 64) {
             const int j = j0 + lane;
             int tj = -2;
             float xj = 0.f, yj = 0.f, zj = 0.f;
             unsigned long long my_mask = 0;   // COUNT: lane r keeps row r's word of this 64-column chunk
             if (j < Lq) {
-                tj = q2t_p[j];
-                if (tj >= Lt) tj = -3;
-                if (tj >= 0) {
-                    xj = xyz[tj * 3 + 0];
-                    yj = xyz[tj * 3 + 1];
-                    zj = xyz[tj * 3 + 2];
-                }
+                const float4 v = s_col[j - jt];
+                tj = __float_as_int(v.w);
+                xj = v.x;
+                yj = v.y;
+                zj = v.z;
             }
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
@@ -339,6 +357,8 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
             if (MODE == CM_COUNT && lane < 8 && i_first + lane < Lq && (j0 >> 6) < W)   // (a protein longer than max_len is flagged by k_cmap_fill)
                 masks[(int64_t)(row0 + wid * 8 + lane) * W + (j0 >> 6)] = my_mask;
         }
+    }
+    if (i_first < Lq) {
         if (MODE == CM_COUNT && lane == 0) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
