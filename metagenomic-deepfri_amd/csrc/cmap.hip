@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_a
 // The contact term is symmetric for coords-derived pairs (argwhere yields (i,j) and (j,i)), so the one-directional
 // write of pyx:115 reproduces exactly this.
 // ------------------------------------------------------------------------------------------------------------------
+constexpr int CMAP_FILL_COLS = 4096;  // columns of a protein whose degree factor and letter k_cmap_fill keeps in LDS (20 KiB)
 constexpr int CMAP_COL_TILE = 1024;   // columns of a protein staged in LDS at a time (16 KiB)
 enum CmapMode { CM_COUNT = 0, CM_DENSE = 2 };   // COUNT also stores every row's contact bits (64 columns per word) for k_cmap_fill
 
@@ -329,12 +330,30 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
                 yj = v.y;
                 zj = v.z;
             }
+            const unsigned long long col_ok = __ballot(tj >= 0);   // columns of this chunk with coordinates (false beyond Lq)
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int i = i_first + r;
                 if (i >= Lq) continue;  // wave-uniform
                 bool bit = false;
-                if (j < Lq) {
+                if (i + gen < j0 || i - gen > j0 + 63) {
+                    // a chunk away from the diagonal (wave-uniform test): only the distance term can set a bit -- no |i - j| logic, no
+                    // per-lane branches; the same three differences and the same unfused sum of squares as below
+                    if (ti[r] >= 0) {
+                        const float dx = xi[r] - xj, dy = yi[r] - yj, dz = zi[r] - zj;
+                        float d = dx * dx;
+                        d = d + dy * dy;
+                        d = d + dz * dz;
+                        bit = d < thr2;
+                    }
+                    if (MODE != CM_DENSE) {   // the columns without coordinates are masked out of the whole word at once
+                        const unsigned long long mask = __ballot(bit) & col_ok;
+                        cnt[r] += __popcll(mask);
+                        if (lane == r) my_mask = mask;
+                        continue;
+                    }
+                    bit = bit && ((col_ok >> lane) & 1ull);
+                } else if (j < Lq) {
                     const int dist = i > j ? i - j : j - i;
                     bit = (dist == 0) || (dist <= gen && (ti[r] == -1 || tj == -1));
                     if (!bit && ti[r] >= 0 && tj >= 0) {
@@ -438,16 +457,26 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
                                                    const unsigned long long *__restrict__ masks, int W, int32_t *__restrict__ rowptr,
                                                    int32_t *__restrict__ colidx, float *__restrict__ val, int64_t nnz_cap,
                                                    const uint8_t *__restrict__ seq_idx, float *__restrict__ letter_sums,
-                                                   int32_t *__restrict__ status)
+                                                   int32_t *__restrict__ status, int cols_cap)
 {
     // Work item = one 64-bit contact word (row, word index): a wave's 8 rows x Wp words are spread over its lanes, so the
     // serial part of a lane is only the handful of set bits of ITS word.  Letter sums go through per-row LDS bins, visited in
     // (word, bit) = ascending-column order: the summation order of the CSR, hence of k_letter_sums.
     __shared__ float s_bins[32][32];
     __shared__ int s_start[32];
+    // what an entry needs of its COLUMN -- 1 / (1e-6 + sqrt(degree)) and the residue letter -- is staged once per workgroup for the first
+    // CMAP_FILL_COLS columns of the protein: a lane walks the set bits of its word one after the other, and two dependent global loads
+    // per bit were the whole run time of this kernel (columns beyond the tile are fetched as before)
+    extern __shared__ float s_dinv[];                                            // cols_cap floats, then cols_cap letters (dynamic: sized
+    uint8_t *s_letter = reinterpret_cast<uint8_t *>(s_dinv + cols_cap);          // for the longest query of the launch, at most CMAP_FILL_COLS)
     const int g = blockIdx.x, row0 = g * 32;
     const int p = find_protein(row_off, B, row0);
     const int r0 = row_off[p], Lq = Lq_arr[p];
+    for (int c = threadIdx.x; c < min(Lq, cols_cap); c += 256) {
+        s_dinv[c] = 1.0f / (1e-6f + sqrtf((float)counts[r0 + c]));
+        s_letter[c] = seq_idx ? (uint8_t)min((int)seq_idx[r0 + c], 31) : (uint8_t)0;
+    }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int Wp = (Lq + 63) >> 6;
     if (Wp > W) {   // the caller's max_len is smaller than this protein: stay inside the bit rows and say so (status[2])
@@ -493,14 +522,15 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
             while (m) {
                 const int j = (w << 6) + __builtin_ctzll(m);
                 m &= m - 1;
-                const float dj = 1.0f / (1e-6f + sqrtf((float)counts[r0 + j]));
+                const bool staged = j < cols_cap;
+                const float dj = staged ? s_dinv[j] : 1.0f / (1e-6f + sqrtf((float)counts[r0 + j]));
                 const float v = (di * 1.0f) * dj;
                 if (pos < nnz_cap) {
                     colidx[pos] = r0 + j;
                     val[pos] = v;
                 }
                 ++pos;
-                if (seq_idx) s_bins[wid * 8 + r][min((int)seq_idx[r0 + j], 31)] += v;
+                if (seq_idx) s_bins[wid * 8 + r][staged ? (int)s_letter[j] : min((int)seq_idx[r0 + j], 31)] += v;
             }
         }
     }
@@ -946,8 +976,9 @@ int mdf_cmap_csr_dev(const float *coords, const int32_t *coord_off, const char *
                        generated_contacts, w.counts, w.group_sum, w.masks, W, (int32_t *)nullptr, (const int64_t *)nullptr);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
     // ... then the CSR (and the layer-1 letter sums) from the bits
-    hipLaunchKernelGGL(k_cmap_fill, dim3(G), dim3(256), 0, st, Lq, row_off, B, (const int32_t *)w.counts, (const int32_t *)w.group_base,
-                       (const unsigned long long *)w.masks, W, rowptr, colidx, val, nnz_cap, seq_idx, letter_sums, status);
+    const int cols_cap = std::min((max_len + 63) / 64 * 64, CMAP_FILL_COLS);
+    hipLaunchKernelGGL(k_cmap_fill, dim3(G), dim3(256), (size_t)cols_cap * 5, st, Lq, row_off, B, (const int32_t *)w.counts, (const int32_t *)w.group_base,
+                       (const unsigned long long *)w.masks, W, rowptr, colidx, val, nnz_cap, seq_idx, letter_sums, status, cols_cap);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
