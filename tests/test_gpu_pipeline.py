@@ -180,3 +180,37 @@ def test_query_stream_errors_leave_it_usable():
         if len(half) == 2:
             break
     assert [r.first for r in stream.run(qids[:40], qseqs[:40], cands[:40])] == [0, 20]
+
+
+def test_query_stream_with_a_language_model_head():
+    """A head with the LSTM language-model branch next to one without, inside QueryStream: the LSTM grouping of every batch's plan is
+    uploaded asynchronously on the stream (plan-owned sources, stream-ordered allocation) while the previous batch is still running --
+    batch by batch the filtered results equal the stage-by-stage run."""
+    import torch
+    from mDeepFRI import synthetic
+    from mDeepFRI.alignment import ScoringMatrix, align_queries_arrays
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.output import filter_scores
+    from mDeepFRI.predict import Predictor
+    from mDeepFRI.stream import QueryStream
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pipeline_example
+    qids, qseqs, cands, db_xyz = pipeline_example.make_inputs(90, 30, seed=8, k=3)
+    sm = ScoringMatrix.simple()
+    w_lm = synthetic.glorot_gcn_weights(seed=1, n_terms=60, embed=256, gc_dims=(256, 256, 256), fc_dim=256, sparse_scores=True)
+    w_lm.update(synthetic.glorot_lm_weights(seed=1000, hidden=64, embed=256))
+    w_plain = synthetic.glorot_gcn_weights(seed=2, n_terms=45, sparse_scores=True)
+    eng = HotPathEngine({"lm": Predictor("syn-lm", weights=w_lm), "plain": Predictor("syn", weights=w_plain)}, max_rows=4096)
+    stream = QueryStream(eng, db_xyz, batch_size=30, max_rows=4096, scoring_matrix=sm, keep_scores=True)
+    n = 0
+    for r in stream.run(qids, qseqs, cands):
+        one = align_queries_arrays(qids[r.first:r.first + r.count], qseqs[r.first:r.first + r.count], cands[r.first:r.first + r.count], scoring_matrix=sm)
+        pk, kept = PackedProteins.from_aligned_batch(one, [db_xyz[k] for k in one.target_keys], max_rows=4096)
+        assert kept == r.kept
+        ref = eng.run_alignments(pk)
+        for m in ("lm", "plain"):
+            assert np.array_equal(r.gcn_scores[m], ref[m])
+            off, ti, sc = filter_scores(torch.from_numpy(ref[m]).cuda(), 0.1, capacity_per_protein=60)
+            assert np.array_equal(r.gcn[m][0], off.cpu().numpy()) and np.array_equal(r.gcn[m][1], ti.cpu().numpy())
+        n += r.count
+    assert n == 90
