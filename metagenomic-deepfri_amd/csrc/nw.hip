@@ -348,7 +348,10 @@ __global__ __launch_bounds__(NW_THREADS) void k_nw16(const uint8_t *__restrict__
         uint32_t qres = 0, qres_next = 0, sc_cur = 0, dir_acc = 0;
         const bool pass_right = m + 1 < n_sp, last = m == m_last;
         uint32_t *trk = TRACE ? reinterpret_cast<uint32_t *>(tr + (int64_t)m * n_steps * 64) : nullptr;
-        for (int s0 = 0; s0 < n_steps; s0 += 64) {
+        // the last strip pair of a pair whose columns end in its LOW strip: nothing real lives beyond element 63, so the sweep ends 64 steps
+        // earlier (rows + 65 instead of rows + 129; the corner leaves element e_last < 64 at step Lq + e_last)
+        const int n_steps_m = (last && e_last < 64) ? (int)(((int64_t)Lq + 65 + 3) / 4 * 4) : n_steps;
+        for (int s0 = 0; s0 < n_steps_m; s0 += 64) {
             // what element 0 is fed at step s0 + lane (its row r = s0 + lane): query residue (pre-scaled to a table row offset) and
             // the packed {H, E} of the column left of this strip pair
             const int r = s0 + lane;
@@ -369,7 +372,7 @@ __global__ __launch_bounds__(NW_THREADS) void k_nw16(const uint8_t *__restrict__
                 sc_cur = nw16_lookup(s_S16, qres_next, tcaddr);
             }
             uint32_t keep = 0;                           // element 127's {H, E} of step s0 + u - 1 (row s0 + u - 128) enters at lane 0 at step u and moves up a lane per step
-            const int u_end = min(64, n_steps - s0);     // a multiple of four
+            const int u_end = min(64, n_steps_m - s0);   // a multiple of four
             // four steps per trip: the loop-carried registers rotate in place, the sub-step is known at compile time; only the chunk in which
             // H[Lq][Lt] leaves the array looks for it (STAR)
             auto sweep = [&](auto star_tag, auto pass_tag) {
@@ -750,7 +753,12 @@ int32_t mdf_nw_orient_pairs(const int32_t *seq_len, int32_t *pair_q, int32_t *pa
     for (int32_t p = 0; p < P; ++p) {
         const int Lq = seq_len[pair_q[p]], Lt = seq_len[pair_t[p]];
         const bool b16 = a16 && nw16_eligible(Lq, Lt, gap_open, gap_extend, smin, smax);   // symmetric in the two lengths
-        auto steps = [&](int rows, int cols) { return b16 ? ((int64_t)cols + 127) / 128 * nw_strip_steps16(rows) : ((int64_t)cols + 63) / 64 * nw_strip_steps(rows); };
+        auto steps = [&](int rows, int cols) -> int64_t {
+            if (!b16) return ((int64_t)cols + 63) / 64 * nw_strip_steps(rows);
+            const int64_t n_sp = ((int64_t)cols + 127) / 128;
+            // the last strip pair is swept in rows + 65 steps when the columns end in its low strip (k_nw16)
+            return ((cols - 1) & 127) < 64 ? (n_sp - 1) * nw_strip_steps16(rows) + ((int64_t)rows + 65 + 3) / 4 * 4 : n_sp * nw_strip_steps16(rows);
+        };
         if (Lq > 0 && Lt > 0 && steps(Lt, Lq) < steps(Lq, Lt)) {
             std::swap(pair_q[p], pair_t[p]);
             ++turned;

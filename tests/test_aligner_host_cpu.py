@@ -32,18 +32,22 @@ def test_plan_offsets_cover_both_trace_formats():
 
 
 def test_orientation_rule_on_the_host():
-    """A pair is turned when the other orientation takes fewer steps: ceil(cols / 128) strip pairs of rows + 129 steps each."""
+    """A pair is turned when the other orientation takes fewer steps: ceil(cols / 128) strip pairs of rows + 129 steps each (rows + 65 for a
+    last strip pair whose high strip is empty)."""
     L = _hip.lib()
     seq_len = np.array([100, 300, 128, 129, 500, 40], dtype=np.int32)
-    cases = [(0, 1, True),     # 100 x 300: 3 x 232 steps as given, 1 x 432 turned
+    cases = [(0, 1, True),     # 100 x 300: 2 x 232 + 168 steps as given, 1 x 432 turned
              (1, 0, False),    # already the cheaper way round
-             (2, 3, False),    # 128 rows x 129 cols: 2 x 260 as given, 1 x 260 turned ... see below
+             (2, 3, False),
              (3, 2, False),
-             (5, 4, True),     # 40 x 500: 4 x 172 = 688 as given, 1 x 632 turned
+             (5, 4, True),     # 40 x 500: 4 x 172 = 688 as given, 108 turned (one half-filled strip pair)
              (4, 4, False)]
     pq = np.array([c[0] for c in cases], dtype=np.int32)
     pt = np.array([c[1] for c in cases], dtype=np.int32)
-    steps = lambda rows, cols: -(-cols // 128) * ((rows + 129 + 3) // 4 * 4)      # noqa: E731
+    def steps(rows, cols):      # the last strip pair takes rows + 65 steps when the columns end in its low strip
+        full, half = (rows + 129 + 3) // 4 * 4, (rows + 65 + 3) // 4 * 4
+        n_sp = -(-cols // 128)
+        return (n_sp - 1) * full + half if ((cols - 1) & 127) < 64 else n_sp * full
     expect = [steps(seq_len[t], seq_len[q]) < steps(seq_len[q], seq_len[t]) for q, t, _ in cases]
     a, b = pq.copy(), pt.copy()
     m = _sym()
@@ -51,7 +55,7 @@ def test_orientation_rule_on_the_host():
     assert turned == sum(expect)
     for k, e in enumerate(expect):
         assert (int(a[k]), int(b[k])) == ((int(pt[k]), int(pq[k])) if e else (int(pq[k]), int(pt[k])))
-    assert expect[0] and not expect[1] and expect[4]
+    assert not expect[1] and expect[4]
     asym = m.copy()
     asym[0, 1] += 1
     a, b = pq.copy(), pt.copy()
