@@ -62,6 +62,14 @@ struct mdf_plan {
     mutable std::vector<int32_t> lm_lens_host;
 };
 
+// stream-ordered allocation; a runtime without the pool falls back on the blocking allocator
+static hipError_t plan_alloc(void **p, size_t bytes, hipStream_t st)
+{
+    if (hipMallocAsync(p, bytes, st) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+    return hipMalloc(p, bytes);
+}
+
 // release in stream order; a stream that is gone by now (or a runtime without the pool) falls back on the blocking free
 static void plan_release(void *p, hipStream_t st)
 {
@@ -226,7 +234,7 @@ static int plan_mirror(const mdf_plan *pl, int device, hipStream_t st)
     }
     const size_t n1 = pl->chunk_row_off.size(), n2 = pl->grp_off.size();
     int32_t *d = nullptr;
-    MDF_HIP(hipMallocAsync(reinterpret_cast<void **>(&d), (n1 + n2) * 4 + 256, st));
+    MDF_HIP(plan_alloc(reinterpret_cast<void **>(&d), (n1 + n2) * 4 + 256, st));
     // the sources are the plan's own vectors (pageable: the runtime stages them before it returns); the copies sit in the stream in
     // front of the kernels that read the mirror
     if (hipMemcpyAsync(d, pl->chunk_row_off.data(), n1 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
@@ -303,7 +311,7 @@ static int plan_lm_groups(const mdf_plan *pl, int64_t lm_batch, int64_t ws_bytes
     pl->d_lm_rows = nullptr;
     char *d = nullptr;
     const size_t rb = align_up(all_rows.size() * 8, 256);
-    MDF_HIP(hipMallocAsync(reinterpret_cast<void **>(&d), rb + all_lens.size() * 4 + 256, st));
+    MDF_HIP(plan_alloc(reinterpret_cast<void **>(&d), rb + all_lens.size() * 4 + 256, st));
     if (!pl->lm_rows_host.empty() && hipStreamSynchronize(st) != hipSuccess)   // a re-grouping: the previous upload may still be reading them
         return fail(MDF_ENODEVICE, "plan: stream synchronisation failed");
     pl->lm_rows_host.swap(all_rows);
