@@ -675,7 +675,7 @@ def main():
                 # HotPathEngine.forward_dense): PCIe-bound; (ii) the fused step without its contact-map kernels (their sampled time
                 # taken off the step): what the GCN kernels alone sustain on maps already in HBM.
                 from mDeepFRI.alignment import AlignmentResult
-                n = min(1024, n_local)
+                n = max(1, min(1024, n_local, (1 << 30) // (4 * args.length * args.length)))      # at most 1 GiB of maps in host memory
                 alns = []
                 for k in range(n):
                     a = AlignmentResult(query_name=f"p{k}", query_sequence=seqs[k], target_name=f"t{k}", target_sequence=seqs[k], alignment="M" * len(seqs[k]))
