@@ -266,7 +266,10 @@ class QueryStream:
             else:
                 eng.raise_flags(pk, flags[0].numpy(), flags[1].numpy())
         except _hip.CapacityError:   # rare: a denser batch than the CSR capacity planned for; redo it synchronously
-            with torch.cuda.stream(side):
+            # the engine's workspaces are ONE set: the batches already enqueued behind this one must have left them before the batch is
+            # run again (with a larger capacity), and the re-run goes into the same stream as everything else
+            self.main.synchronize()
+            with torch.cuda.stream(self.main):
                 res, redone = {}, redo(pk)
                 for m, arr in redone.items():
                     o, ti, sc = filter_scores(torch.from_numpy(arr).to(eng.device), self.threshold, self.capacity_per_protein)

@@ -214,3 +214,28 @@ def test_query_stream_with_a_language_model_head():
             assert np.array_equal(r.gcn[m][0], off.cpu().numpy()) and np.array_equal(r.gcn[m][1], ti.cpu().numpy())
         n += r.count
     assert n == 90
+
+
+def test_query_stream_recovers_from_a_csr_capacity_that_is_too_small():
+    """An engine sized for 3 contacts per residue: the first batches overflow the CSR (flagged on the device, nothing written out of
+    bounds), are run again with the capacity the flag asks for -- after the batches already in flight have left the engine's workspaces
+    -- and the stream hands out exactly what a correctly sized engine computes."""
+    from mDeepFRI import synthetic
+    from mDeepFRI.alignment import ScoringMatrix
+    from mDeepFRI.batch import HotPathEngine
+    from mDeepFRI.predict import Predictor
+    from mDeepFRI.stream import QueryStream
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pipeline_example
+    qids, qseqs, cands, db_xyz = pipeline_example.make_inputs(160, 40, seed=9, k=3)
+    sm = ScoringMatrix.simple()
+    w = synthetic.glorot_gcn_weights(seed=3, n_terms=64, sparse_scores=True)
+    ref_eng = HotPathEngine({"a": Predictor("syn", weights=w)}, max_rows=8192)
+    ref = {r.first: r for r in QueryStream(ref_eng, db_xyz, batch_size=40, max_rows=8192, scoring_matrix=sm, keep_scores=True).run(qids, qseqs, cands)}
+    small = HotPathEngine({"a": Predictor("syn", weights=w)}, max_rows=8192, nnz_per_row=3)
+    cap0 = small.nnz_capacity
+    got = {r.first: r for r in QueryStream(small, db_xyz, batch_size=40, max_rows=8192, scoring_matrix=sm, keep_scores=True).run(qids, qseqs, cands)}
+    assert small.nnz_capacity > cap0 and sorted(got) == sorted(ref) == [0, 40, 80, 120]
+    for f in ref:
+        assert got[f].kept == ref[f].kept and np.array_equal(got[f].gcn_scores["a"], ref[f].gcn_scores["a"])
+        assert all(np.array_equal(x, y) for x, y in zip(got[f].gcn["a"], ref[f].gcn["a"]))
