@@ -209,6 +209,9 @@ class QueryStream:
             for p in aligning.values():      # an exception (or an abandoned generator) leaves batches in flight: drop them
                 if p is not None:
                     p.abandon()
+            if running:                      # ... and let the enqueued GCN batches finish before their buffers go back to the allocator
+                self.main.synchronize()
+                running.clear()
 
     def _launch(self, pk, forward):
         """Upload (side stream), `forward(db)` + filter (main stream), the small results on their way back.  -> the part's state."""
