@@ -159,13 +159,15 @@ class QueryStream:
     sequence-only query, as pipeline.py:485 does).  batch_size: queries per device batch.  sequence_engine: a batch.SequenceEngine with
     the CNN heads for the sequence-only queries (optional).  keep_scores: also hand out the full score matrices (`gcn_scores` /
     `cnn_scores`: {mode: float32 (rows, T)}, what `output.write_prediction_matrix` takes) -- 11 KB per protein and three heads more over
-    PCIe, on the side stream."""
+    PCIe, on the side stream.  batch_chunks > 0: cut the batches by residue rows instead of by count -- as many queries as fill that many
+    chunks of `max_rows` padded rows (a batch of N queries ends in a mostly empty chunk that still costs whole GEMM rounds)."""
 
     def __init__(self, engine: HotPathEngine, structures, batch_size: int = 4000, max_rows: int = 65536, scoring_matrix="VTML80",
                  gap_open: int = 10, gap_extend: int = 1, threshold: float = 0.1, capacity_per_protein: int = 64, sequence_engine=None,
-                 keep_scores: bool = False):
+                 keep_scores: bool = False, batch_chunks: int = 0):
         import torch
         from .alignment import AlignerWorkspace
+        self.batch_chunks = int(batch_chunks)
         self.engine, self.structures, self.sequence_engine = engine, structures, sequence_engine
         self.batch_size, self.max_rows = int(batch_size), int(max_rows)
         self.scoring_matrix, self.gap_open, self.gap_extend = scoring_matrix, int(gap_open), int(gap_extend)
@@ -182,14 +184,27 @@ class QueryStream:
         import torch
         from .alignment import align_queries_begin
         query_ids, query_sequences, target_sequences = list(query_ids), list(query_sequences), list(target_sequences)
-        starts = list(range(0, len(query_ids), self.batch_size))
+        if self.batch_chunks > 0 and query_ids:      # slices of ~batch_chunks full chunks: greedy over the padded rows, as the planner fills chunks
+            rows = (np.fromiter(map(len, query_sequences), dtype=np.int64, count=len(query_sequences)) + 31) // 32 * 32
+            starts, chunk_rows, chunks = [0], 0, 1
+            for i, r in enumerate(rows.tolist()):
+                if chunk_rows and chunk_rows + r > self.max_rows:
+                    chunks, chunk_rows = chunks + 1, 0
+                    if chunks > self.batch_chunks:
+                        starts.append(i)
+                        chunks = 1
+                chunk_rows += r
+            ends = starts[1:] + [len(query_ids)]
+        else:
+            starts = list(range(0, len(query_ids), self.batch_size))
+            ends = [min(a + self.batch_size, len(query_ids)) for a in starts]
         nb = len(starts)
         aligning, running, slices = {}, {}, {}
         try:
             with torch.cuda.device(self.engine.device):
                 for t in range(nb + 3):
                     if t < nb:
-                        a, b = starts[t], min(starts[t] + self.batch_size, len(query_ids))
+                        a, b = starts[t], ends[t]
                         pos = [i for i in range(a, b) if len(target_sequences[i]) > 0]
                         slices[t] = (a, b, pos)
                         if len(pos) == b - a:

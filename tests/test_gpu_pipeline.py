@@ -239,3 +239,33 @@ def test_query_stream_recovers_from_a_csr_capacity_that_is_too_small():
     for f in ref:
         assert got[f].kept == ref[f].kept and np.array_equal(got[f].gcn_scores["a"], ref[f].gcn_scores["a"])
         assert all(np.array_equal(x, y) for x, y in zip(got[f].gcn["a"], ref[f].gcn["a"]))
+
+
+def test_query_stream_batches_cut_by_rows_give_the_same_results():
+    """batch_chunks: slices sized to fill whole chunks of padded residue rows instead of a fixed number of queries -- other slice
+    boundaries, the same per-query results bit for bit."""
+    from mDeepFRI import synthetic
+    from mDeepFRI.alignment import ScoringMatrix
+    from mDeepFRI.batch import HotPathEngine
+    from mDeepFRI.predict import Predictor
+    from mDeepFRI.stream import QueryStream
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pipeline_example
+    qids, qseqs, cands, db_xyz = pipeline_example.make_inputs(150, 40, seed=10, k=3)
+    sm = ScoringMatrix.simple()
+    eng = HotPathEngine({"a": Predictor("syn", weights=synthetic.glorot_gcn_weights(seed=4, n_terms=64, sparse_scores=True))}, max_rows=4096)
+
+    def per_query(stream):
+        out, firsts = {}, []
+        for r in stream.run(qids, qseqs, cands):
+            firsts.append((r.first, r.count))
+            off, ti, sc = r.gcn["a"]
+            for k, i in enumerate(r.kept):
+                out[r.first + i] = (ti[off[k]:off[k + 1]].tobytes(), sc[off[k]:off[k + 1]].tobytes())
+        return out, firsts
+    by_count, f1 = per_query(QueryStream(eng, db_xyz, batch_size=40, max_rows=4096, scoring_matrix=sm))
+    by_rows, f2 = per_query(QueryStream(eng, db_xyz, batch_size=40, max_rows=4096, scoring_matrix=sm, batch_chunks=2))
+    assert by_count == by_rows and len(by_rows) == 150
+    assert f1 != f2 and sum(c for _, c in f2) == 150 and all(a + c == b for (a, c), (b, _) in zip(f2, f2[1:]))
+    rows = lambda a, c: sum((len(q) + 31) // 32 * 32 for q in qseqs[a:a + c])      # noqa: E731
+    assert all(rows(a, c) <= 2 * 4096 for a, c in f2)
