@@ -239,16 +239,9 @@ class QueryStream:
         with torch.cuda.stream(main):
             out = forward(db)
             filt = {m: filter_scores_async(t, self.threshold, db.B * self.capacity_per_protein) for m, t in out.items()}
-            small = {m: (torch.empty(f[0].shape, dtype=f[0].dtype, pin_memory=True), torch.empty(4, dtype=torch.int32, pin_memory=True))
-                     for m, f in filt.items()}
-            for m, f in filt.items():
-                small[m][0].copy_(f[0], non_blocking=True)
-                small[m][1].copy_(f[3], non_blocking=True)
-            # the validity flags travel with the results: reading them later must not queue behind the next batch
-            flags = (torch.empty(db.bad.shape, dtype=db.bad.dtype, pin_memory=True), torch.empty(db.status.shape, dtype=db.status.dtype, pin_memory=True))
-            flags[0].copy_(db.bad, non_blocking=True)
-            flags[1].copy_(db.status, non_blocking=True)
-        return db, pk, out, filt, small, flags
+        # NO copy back is enqueued here: a device-to-host copy waiting in the compute stream behind a whole batch also holds up the
+        # copy engine's queue, and with it every later copy of the side stream (measured: the collection of batch k waited for batch k+1)
+        return db, pk, out, filt
 
     def _enqueue(self, a, b, pos, batch, query_ids, query_sequences):
         import torch
@@ -276,8 +269,20 @@ class QueryStream:
         import torch
         from .batch import first_invalid_residue
         from .output import filter_scores
-        db, pk, out, filt, small, flags = part
+        db, pk, out, filt = part
         eng, side = self.engine, self.side
+        with torch.cuda.stream(side):      # the part's event has been waited for: its small results first (flags, offsets, filter status)
+            flags = (torch.empty(db.bad.shape, dtype=db.bad.dtype, pin_memory=True), torch.empty(db.status.shape, dtype=db.status.dtype, pin_memory=True))
+            flags[0].copy_(db.bad, non_blocking=True)
+            flags[1].copy_(db.status, non_blocking=True)
+            small = {m: (torch.empty(f[0].shape, dtype=f[0].dtype, pin_memory=True), torch.empty(4, dtype=torch.int32, pin_memory=True))
+                     for m, f in filt.items()}
+            for m, f in filt.items():
+                f[0].record_stream(side)
+                f[3].record_stream(side)
+                small[m][0].copy_(f[0], non_blocking=True)
+                small[m][1].copy_(f[3], non_blocking=True)
+            side.synchronize()
         try:
             if redo is None:      # sequence-only models flag invalid residues only
                 first_invalid_residue(pk, flags[0].numpy())
