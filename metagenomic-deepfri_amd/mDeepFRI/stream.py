@@ -76,7 +76,7 @@ class AlignmentStream:
                 first, pk = got
                 with torch.cuda.device(eng.device):
                     main = torch.cuda.current_stream(eng.device)
-                    db = eng.upload(pk)
+                    db = eng.upload(pk)        # in the compute stream: 75 MB per 10 000 proteins next to the GEMMs on another stream cost more than they hide
                     out = eng.forward_alignments(db)
                     done = torch.cuda.Event()
                     done.record(main)
