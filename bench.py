@@ -63,9 +63,11 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="single-thread worker processes of the all-core leg (0 = min(cores, 32))")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--timing-period", type=int, default=8,
+    ap.add_argument("--timing-period", type=int, default=7,
                     help="bracket every n-th launch of each kernel class with HIP events (an event pair costs GPU time between "
-                         "kernels: timing every launch lowers the step rate by ~6 %%)")
+                         "kernels: timing every launch lowers the step rate by ~6 %%).  Every GraphConv layer is a class of its own "
+                         "(ax2 / ax3, gemm2 / gemm3) and the period is prime, so that a sample cannot lock onto one phase of the "
+                         "engine's launch cycle (3 heads x 2 layers per chunk)")
     ap.add_argument("--workload", default="configs2", choices=["configs2", "configs3", "configs4", "mixed", "cnn"])
     ap.add_argument("--verify", type=int, default=4,
                     help="after the timed region, check this many proteins of the step against the oracle (untimed; 0 = skip)")
@@ -311,7 +313,7 @@ class Ctx:
     pass
 
 
-def timed_run(ctx, eng, db, steps, warmup, after=None, timing_period=8):
+def timed_run(ctx, eng, db, steps, warmup, after=None, timing_period=7):
     """W warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns (seconds (max over ranks), last out)."""
     import torch
     import torch.distributed as dist
@@ -373,25 +375,36 @@ def rooflines(ctx, eng, pk, kernels, lm):
     src = "profiles/traffic.json (rocprofv3 --pmc pass of an earlier run of this command; not a counter of this run)"
     C = 512
     g, a = kernels.get("gemm", {}), kernels.get("ax", {})
+    # `achieved` is the mean over ALL sampled launches of the kernel, every GraphConv layer pooled (the classes are sampled at the same
+    # period and launched equally often); `per_layer` shows the layers on their own: layer 2 gathers rows the short K = 32 launch has
+    # just written (Infinity-Cache resident), layer 3 rows written by a launch that streams 2 x 128 MiB
     if g.get("launches"):
         # with --lm the class also holds the unfolded layer-1 launch (K = 1024): mean over the three layers
         flops_launch = 2.0 * rows_launch * C * ((1024 + C + C) / 3.0 if lm else C)
         tf = flops_launch / (g["avg_us"] * 1e-6) / 1e12
+        per_layer = {k: {"avg_us": kernels[k]["avg_us"], "timed_launches": kernels[k]["launches"],
+                         "frac": round(2.0 * rows_launch * C * C / (kernels[k]["avg_us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4)}
+                     for k in ("gemm2", "gemm3") if kernels.get(k, {}).get("launches") and not lm}
         roof = {"kernel": "k_gemm_f32 (H.W, 256x256x32 tiles, v_mfma_f32_32x32x2_f32, LDS-DMA staging, ELU+pool epilogue)",
                 "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
                 "traffic": traffic.get("gemm_mean_bytes"), "traffic_source": src if traffic else None,
-                "per_launch": {"rows": R, "flops": 2.0 * R * C * C, "avg_us": g["avg_us"], "timed_launches": g["launches"]}}
+                "per_launch": {"rows": R, "flops": 2.0 * R * C * C, "avg_us": g["avg_us"], "timed_launches": g["launches"]},
+                "per_layer": per_layer}
     if a.get("launches"):
         # read Z (rows x 512 f32) once + write (rows x 512 f32) once per layer; CSR adjacency (4 B colidx
         # + 4 B val per entry + 4 B rowptr per row) added and stated
         nnz_per_row = float(eng.last_chunk_nnz()) / float(pk.chunks[-1].rows)
         bytes_row = 2 * 4 * C + 4 + 8 * nnz_per_row
         gbs = bytes_row * rows_launch / (a["avg_us"] * 1e-6) / 1e9
+        per_layer = {k: {"avg_us": kernels[k]["avg_us"], "timed_launches": kernels[k]["launches"],
+                         "frac": round(bytes_row * rows_launch / (kernels[k]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                     for k in ("ax2", "ax3") if kernels.get(k, {}).get("launches") and not lm}
         roof_ax = {"kernel": "k_aggregate<512> (A.X, CSR gather, one wave per residue row)", "bound": "hbm", "achieved": round(gbs, 1),
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                    "traffic": (traffic.get("k_aggregate<512>") or {}).get("bytes"), "traffic_source": src if traffic else None,
                    "per_launch": {"rows": R, "bytes": bytes_row * R, "nnz_per_row": round(nnz_per_row, 2), "avg_us": a["avg_us"],
-                                  "timed_launches": a["launches"]}}
+                                  "timed_launches": a["launches"]},
+                   "per_layer": per_layer}
     return roof, roof_ax
 
 
@@ -419,8 +432,8 @@ def mini_run(ctx, eng, cols, chunk_rows, steps=2, warmup=1, lm=False):
     from mDeepFRI import batch
     pk = batch.PackedProteins.pack(*cols, max_rows=chunk_rows)
     db = eng.upload(pk)
-    elapsed, _ = timed_run(ctx, eng, db, steps, warmup, timing_period=4)
-    kernels = read_kernels(ctx, ("gemm", "ax"))
+    elapsed, _ = timed_run(ctx, eng, db, steps, warmup, timing_period=5)
+    kernels = read_kernels(ctx, ("gemm", "gemm2", "gemm3", "ax", "ax2", "ax3"))
     roof, roof_ax = rooflines(ctx, eng, pk, kernels, lm)
     n = len(cols[0])
     return {"value": round(n * steps / elapsed, 1), "unit": "proteins/s", "proteins": n, "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
@@ -549,7 +562,8 @@ def main():
         for m in MODES:
             plans[m].check()      # a rank that outgrew the planned payload in the last step is raised on every rank here
     if ctx.rank == 0:
-        kernels = read_kernels(ctx, ("gemm", "gemm1", "ax", "cmap", "head") + (("lstm", "lstm2", "embed") if args.lm else ())) if timing_period else {}
+        kernels = read_kernels(ctx, ("gemm", "gemm2", "gemm3", "gemm1", "ax", "ax2", "ax3", "cmap", "head") +
+                               (("lstm", "lstm2", "embed") if args.lm else ())) if timing_period else {}
         roof, roof_ax = rooflines(ctx, eng, pk, kernels, args.lm)
         mean_len = float(np.mean([len(s) for s in seqs]))
         what = {

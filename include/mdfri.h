@@ -543,7 +543,9 @@ int mdf_nw_best_hits_host(mdf_nw_workspace *ws, const uint8_t *text, const int64
  * kernel class with hipEvents on the stream it is launched on and accumulates count and milliseconds of the sampled
  * launches (read after a sync).  An event pair costs GPU time between kernels (~6 % of the step when every launch is
  * timed), hence the sampling.
- * kernel: "ax" (A.X aggregation), "gemm" (H.W fp32 MFMA, layers 2..3), "gemm1" (layer-1 S.T1 GEMM, K=32), "cmap" (fused contact map), "head",
+ * kernel: "ax" (A.X aggregation, every GraphConv layer pooled), "ax2" / "ax3" (the launches of layer 2 / of layer 3 and up on their own: the
+ * two layers find their input in different levels of the memory system), "gemm" (H.W fp32 MFMA, layers 2..3 pooled), "gemm2" / "gemm3"
+ * (per layer), "gemm1" (layer-1 S.T1 GEMM, K=32), "cmap" (fused contact map), "head",
  * "lstm" / "lstm2" (one time step of language-model layer 1 / layer 2; the two run concurrently on two streams, so their
  * durations include the contention), "embed" (language-model embedding GEMM), "cnn" (sequence-only CNN: conv + max pool). */
 int mdf_timing_enable(int on);

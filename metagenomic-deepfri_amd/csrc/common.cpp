@@ -142,9 +142,14 @@ int mdf_timing_reset(void)
 int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms)
 {
     if (!kernel) return fail(MDF_EINVAL, "mdf_timing_read: kernel is NULL");
-    int k = -1;
-    if (!strcmp(kernel, "ax")) k = TK_AX;
-    else if (!strcmp(kernel, "gemm")) k = TK_GEMM;
+    // "ax" / "gemm" pool the launches of every GraphConv layer; "ax2", "ax3", "gemm2", "gemm3" are the layers on their own
+    int k = -1, k2 = -1;
+    if (!strcmp(kernel, "ax")) k = TK_AX, k2 = TK_AX3;
+    else if (!strcmp(kernel, "ax2")) k = TK_AX;
+    else if (!strcmp(kernel, "ax3")) k = TK_AX3;
+    else if (!strcmp(kernel, "gemm")) k = TK_GEMM, k2 = TK_GEMM3;
+    else if (!strcmp(kernel, "gemm2")) k = TK_GEMM;
+    else if (!strcmp(kernel, "gemm3")) k = TK_GEMM3;
     else if (!strcmp(kernel, "cmap")) k = TK_CMAP;
     else if (!strcmp(kernel, "head")) k = TK_HEAD;
     else if (!strcmp(kernel, "gemm1")) k = TK_GEMM1;
@@ -155,8 +160,8 @@ int mdf_timing_read(const char *kernel, int64_t *launches, double *total_ms)
     if (k < 0) return fail(MDF_EINVAL, "mdf_timing_read: unknown kernel class '%s'", kernel);
     std::lock_guard<std::mutex> lk(g_t.mu);
     fold_locked();
-    if (launches) *launches = g_t.launches[k];
-    if (total_ms) *total_ms = g_t.ms[k];
+    if (launches) *launches = g_t.launches[k] + (k2 >= 0 ? g_t.launches[k2] : 0);
+    if (total_ms) *total_ms = g_t.ms[k] + (k2 >= 0 ? g_t.ms[k2] : 0.0);
     return MDF_OK;
 }
 

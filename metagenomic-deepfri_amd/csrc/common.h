@@ -37,7 +37,10 @@ int fail(int code, const char *fmt, ...);
 int require_device();
 
 // ---- launch timing (mdf_timing_*) -----------------------------------------------------------------------------
-enum TimedKernel { TK_AX = 0, TK_GEMM = 1, TK_CMAP = 2, TK_HEAD = 3, TK_GEMM1 = 4, TK_LSTM = 5, TK_EMBED = 6, TK_LSTM2 = 7, TK_CNN = 8, TK_COUNT = 9 };
+// TK_AX / TK_GEMM: the A.X and H.W launches of GraphConv layer 2 (and the unfolded layer 1 of a language-model head);
+// TK_AX3 / TK_GEMM3: those of layer 3 and up -- classes of their own, because the two layers find their input in different places
+// (layer 2's was just written by the short K = 32 launch and sits in the Infinity Cache, layer 3's by a launch that streams 256 MiB).
+enum TimedKernel { TK_AX = 0, TK_GEMM = 1, TK_CMAP = 2, TK_HEAD = 3, TK_GEMM1 = 4, TK_LSTM = 5, TK_EMBED = 6, TK_LSTM2 = 7, TK_CNN = 8, TK_AX3 = 9, TK_GEMM3 = 10, TK_COUNT = 11 };
 bool timing_on();
 // Record an event pair around a launch on `stream`; no-ops when timing is disabled.
 void timing_begin(TimedKernel k, hipStream_t stream);

@@ -748,7 +748,9 @@ static std::vector<uint64_t> graph_key(const mdf_engine *e, const mdf_plan *pl, 
     std::vector<uint64_t> k = {pl->serial, (uint64_t)(uintptr_t)b->seqs, (uint64_t)(uintptr_t)b->seq_off, (uint64_t)(uintptr_t)b->Lq,
                                (uint64_t)(uintptr_t)b->coords, (uint64_t)(uintptr_t)b->coord_off, (uint64_t)(uintptr_t)b->q_aln,
                                (uint64_t)(uintptr_t)b->t_aln, (uint64_t)(uintptr_t)b->aln_off, (uint64_t)(uintptr_t)b->status,
-                               (uint64_t)(uintptr_t)b->bad, e->generation, (uint64_t)e->nnz_cap, (uint64_t)(uintptr_t)st};
+                               (uint64_t)(uintptr_t)b->bad, e->generation, (uint64_t)e->nnz_cap, (uint64_t)(uintptr_t)st,
+                               // the plan's device mirror is re-created when the plan moves to another device: a captured graph embeds its address
+                               (uint64_t)(uintptr_t)pl->d_chunk_row_off, (uint64_t)(uintptr_t)pl->d_lm_rows};
     uint64_t thr;
     memcpy(&thr, &e->cfg.threshold, 8);
     k.push_back(thr);
@@ -959,8 +961,11 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         for (int k = 0; k < nt; ++k) nnz_needed += nz_part[(size_t)k];
         if (nnz_needed > e->nnz_cap) {   // a denser chunk than the CSR arrays hold: grow them (hipFree waits for the device)
             MDF_REQUIRE(nnz_needed < 0x7fffffffLL, "engine_forward_dense: a chunk needs %lld CSR entries; lower max_rows", (long long)nnz_needed);
-            if (int rc = e->cs[0].colidx.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
-            if (int rc = e->cs[0].val.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
+            // EVERY live contact set grows with the shared capacity: a later pipelined forward_alignments hands e->nnz_cap to both
+            for (int k = 0; k < (e->pipeline_contact ? 2 : 1); ++k) {
+                if (int rc = e->cs[k].colidx.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
+                if (int rc = e->cs[k].val.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
+            }
             e->nnz_cap = nnz_needed;
         }
         char *d = e->map_dev[s].as<char>();
@@ -1193,7 +1198,7 @@ extern "C" int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, c
         const size_t o_seq = take((size_t)so), o_soff = take(((size_t)B + 1) * 4), o_lq = take((size_t)B * 4), o_xyz = take((size_t)co * 12),
                      o_coff = take(((size_t)B + 1) * 4), o_q = take((size_t)ao), o_t = take((size_t)ao), o_aoff = take(((size_t)B + 1) * 4),
                      o_status = take(nC * 16), o_bad = take(nC * 8);
-        if ((rc = e->host_in.grow(o, nullptr))) return rc;
+        if ((rc = e->host_in.grow(o, &e->generation))) return rc;
         char *d = e->host_in.as<char>();
         MDF_HIP(hipMemcpyAsync(d + o_seq, seqs, (size_t)so, hipMemcpyHostToDevice, st));
         MDF_HIP(hipMemcpyAsync(d + o_soff, seq_off.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice, st));
@@ -1225,14 +1230,19 @@ extern "C" int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, c
             s_off[k] = s_total;
             s_total = align_up(s_total + (size_t)B * (size_t)mdf_model_num_terms(e->models[k]) * 4, 256);
         }
-        if ((rc = e->host_scores.grow(s_total, nullptr))) return rc;
+        if ((rc = e->host_scores.grow(s_total, &e->generation))) return rc;
         std::vector<float *> d_scores(e->models.size());
         for (size_t k = 0; k < e->models.size(); ++k) d_scores[k] = reinterpret_cast<float *>(e->host_scores.as<char>() + s_off[k]);
         int64_t inf[4] = {-1, -1, -1, -1};
         for (int attempt = 0; attempt < 2; ++attempt) {
             MDF_HIP(hipMemsetAsync(d + o_status, 0, nC * 16, st));
             MDF_HIP(hipMemsetAsync(d + o_bad, 0xff, nC * 8, st));
-            if ((rc = forward_alignments_locked(e, pl, &b, d_scores.data(), nullptr, st))) return rc;
+            // a one-shot plan (fresh serial on every call): issued eagerly, never through the graph cache -- its entry could not be
+            // seen again and would only push the captured graphs of the serving callers out of the LRU
+            if ((rc = plan_mirror(pl, e->device, st))) return rc;
+            if ((rc = ensure(e, pl->max_chunk_rows, pl->B, pl->max_len, pl->max_groups))) return rc;
+            ++e->eager_runs;
+            if ((rc = forward_alignments_eager(e, pl, &b, d_scores.data(), nullptr, st))) return rc;
             rc = check_locked(e, pl, &b, st, inf);
             if (rc != MDF_ECAPACITY || attempt == 1) break;
             // a denser batch than the CSR arrays planned for: raise the capacity once and re-run

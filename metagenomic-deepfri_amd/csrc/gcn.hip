@@ -76,6 +76,8 @@ struct GemmAux {
     const uint8_t *letters = nullptr;  // (M) residue indices 0..25 (anything larger reads the zero rows 26..31)
     float floor = 0.0f;                // EPI_EMBED: X0 = max(acc + table, floor): 0 = relu, -FLT_MAX = no activation
     float *cstate = nullptr;           // EPI_LSTM_*: (M, N/4) cell state, updated in place
+    int a_stream = 0;                  // host side only (launch_gemm): the A operand is read with the non-temporal policy
+    int c_nt = 0;                      // EPI_ELU_POOL_STORE / EPI_L1_STORE: the output rows are stored with the non-temporal policy
 };
 
 // sigmoid / tanh on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error < 3e-7.
@@ -228,7 +230,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n
                     const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
                     const float v = elu1(acc[tm][tn][r]);
                     s += v;
-                    if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_L1_STORE) C[(size_t)row * ldc + col] = v;
+                    if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_L1_STORE) {
+                        if (aux.c_nt) __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
+                        else C[(size_t)row * ldc + col] = v;
+                    }
                 }
                 s += __shfl_xor(s, 32, 64);
                 if (lane < 32) pool_partial[(size_t)(rbase >> 5) * ldp + col] = s;
@@ -317,13 +322,22 @@ __device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr
 }
 // The same with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset: the eight
 // source addresses a wave keeps per pipeline position cost 8 VGPRs instead of 16.
+// NT: the load carries the non-temporal policy (streamed once, not to be kept: the A operand of a launch whose OUTPUT the next
+// kernel gathers from the Infinity Cache -- see launch_gemm, `a_stream`).
+template <bool NT = false>
 __device__ __forceinline__ void glds16s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr)
 {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr)
-                 : "memory");
+    if (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr)
+                     : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr)
+                     : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const float *p)
 {
@@ -332,7 +346,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const float *p)
 
 // ABL != 0: timing ablations for tools/gemm_probe.hip only (results are wrong by construction): 1 = no DMA,
 // 2 = + no LDS fragment reads, 3 = + no barrier
-template <int EPI, int ABL = 0>
+template <int EPI, int ABL = 0, bool ANT = false>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt,
                                                               int ldb, int M, int N, int K, float *__restrict__ C, int ldc,
                                                               const float *__restrict__ bias, float *__restrict__ pool_partial,
@@ -403,8 +417,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
     }
 #define MDF_DMA_PIECE(i, ldsA_, ldsB_)                                       \
     if (ABL == 0) {                                                            \
-        glds16s(baseA, oa##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024));   \
-        glds16s(baseB, ob##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024));   \
+        glds16s<ANT>(baseA, oa##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024)); \
+        glds16s<false>(baseB, ob##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024)); \
     }
 #define MDF_SB __builtin_amdgcn_sched_barrier(0);
 #ifdef MDF_PROBE_VALU_PAD   // experiments/gemm_probe.hip only: N independent packed fp32 FMAs behind every MFMA (how much VALU issue is free?)
@@ -725,10 +739,13 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, 
     // its blocks gather are, for the most part, fetched into that XCD's L2 once.
     const int b = blockIdx.x, x = b & 7, q = b >> 3;
     const int per_sb = 1 << (sb_log - 2);                  // blocks (4 rows each) per super-block
-    const int sb = (q / per_sb) * 8 + x;
+    int sb = (q / per_sb) * 8 + x;
+    if (nt_store & 4) sb = ((int)(gridDim.x / (8 * per_sb)) - 1 - q / per_sb) * 8 + x;   // developer probe: last-written rows first, same XCD
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row = (sb << sb_log) + (q % per_sb) * 4 + wid;
     if (row >= R) return;
+    const int sc_var = (nt_store >> 3) & 3;
+    nt_store &= 3;
     const int lane = threadIdx.x & 63;
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
     float4 acc[NV];
@@ -771,7 +788,22 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, 
             acc[v].w = fmaf(w, h.w, acc[v].w);
         }
     }
-    if (nt_store) {  // the aggregated rows are not re-read by this kernel: keep them out of the way of the gathered rows
+    if (nt_store == 3) {   // developer probe (MDFRI_AX_NT=3, variant in MDFRI_AX_SC): write-through / L2-dropping store forms
+        typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const v4f t = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
+            float *p = out + (size_t)row * C + v * 256 + lane * 4;
+            if (sc_var == 0) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+            else if (sc_var == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
+            else if (sc_var == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(t) : "memory");
+            else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(t) : "memory");
+        }
+    } else if (nt_store == 2) {   // developer probe (MDFRI_AX_NT=2): the gather alone -- nothing is stored unless a sum is NaN (results are wrong by construction)
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (acc[v].x != acc[v].x) *reinterpret_cast<float4 *>(out + (size_t)row * C + v * 256 + lane * 4) = acc[v];
+    } else if (nt_store) {  // the aggregated rows are not re-read by this kernel: keep them out of the way of the gathered rows
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             typedef float v4f __attribute__((ext_vector_type(4)));
@@ -1047,6 +1079,8 @@ static int set_gemm_attr_once()
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_LSTM_TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_LSTM_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_ELU_POOL_STORE, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_ELU_POOL, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return MDF_OK;
 }
@@ -1104,6 +1138,14 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     }
     const int total = plain ? MT * NT : 8 * NT * ((MT + 7) / 8);  // tile slots (in XCD-aware order some lie past M)
     const int blocks = std::min(total, gemm_resident_blocks());
+    if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL) {
+        if (aux.a_stream) {
+            hipLaunchKernelGGL((k_gemm_f32<EPI, 0, true>), dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
+                               pool_partial, ldp, logits, n_real, total, aux);
+            MDF_HIP(hipGetLastError());
+            return MDF_OK;
+        }
+    }
     hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
                        pool_partial, ldp, logits, n_real, total, aux);
     MDF_HIP(hipGetLastError());
@@ -1140,14 +1182,19 @@ static size_t gcn_ws_bytes(const mdf_model *m, int64_t R)
 
 // Ahat . H over `Cin` channels (k_aggregate)
 static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, const int32_t *colidx, const float *val, float *AH,
-                            int Ri, hipStream_t st)
+                            int Ri, hipStream_t st, TimedKernel tk = TK_AX)
 {
-    ScopedTiming tm(TK_AX, st);
+    ScopedTiming tm(tk, st);
     // developer knobs; defaults: 512-row super-blocks per XCD, and non-temporal output stores once input + output
     // slabs no longer fit the 256 MiB Infinity Cache together (measured: +12 % at 65536 rows, -2 % at 32768)
     static const int sb_log = getenv("MDFRI_AX_SB_LOG") ? atoi(getenv("MDFRI_AX_SB_LOG")) : 9;
     static const int nt_env = getenv("MDFRI_AX_NT") ? atoi(getenv("MDFRI_AX_NT")) : -1;
-    const int nt_store = nt_env >= 0 ? nt_env : ((size_t)Ri * Cin * 8 > (size_t)200 << 20);
+    static const int rev_env = getenv("MDFRI_AX_REV") ? atoi(getenv("MDFRI_AX_REV")) : 0;   // developer probe: bit 0 = layer 2, bit 1 = layer 3 walk the rows downwards
+    const int rev = (tk == TK_AX3 ? (rev_env >> 1) & 1 : rev_env & 1) ? 4 : 0;
+    static const int sc_env = getenv("MDFRI_AX_SC") ? atoi(getenv("MDFRI_AX_SC")) : 0;      // developer probe: store form of MDFRI_AX_NT=3
+    static const int nt3_env = getenv("MDFRI_AX_NT3") ? atoi(getenv("MDFRI_AX_NT3")) : -1;  // developer probe: MDFRI_AX_NT for layer 3 only
+    const int nt_pick = (tk == TK_AX3 && nt3_env >= 0) ? nt3_env : nt_env;
+    const int nt_store = (nt_pick >= 0 ? nt_pick : ((size_t)Ri * Cin * 8 > (size_t)200 << 20)) | rev | ((sc_env & 3) << 3);
     const int n_sb = (Ri + (1 << sb_log) - 1) >> sb_log;
     const int blocks = 8 * (1 << (sb_log - 2)) * ((n_sb + 7) / 8);
 #define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, Ri, sb_log, nt_store)
@@ -1163,17 +1210,24 @@ static int gcn_upper_layers(mdf_model *m, float *Hin, float *Hout, float *AH, co
 {
     const int feat = m->feat;
     int off = m->gc[0];
+    static const int buf_env = getenv("MDFRI_GCN_BUF") ? atoi(getenv("MDFRI_GCN_BUF")) : 0;   // developer probe: bit 1 = layer 3 aggregates into the dead H1 slab
     for (int k = 1; k < m->n_gc; ++k) {
         const int Cin = m->gc[k - 1], Cout = m->gc[k];
-        if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st)) return rc;
+        if (k >= 2 && (buf_env & 2)) AH = Hout;   // Hout holds H_{k-2} by now: dead
+        if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st, k >= 2 ? TK_AX3 : TK_AX)) return rc;
         {
-            ScopedTiming tm(TK_GEMM, st);
+            ScopedTiming tm(k >= 2 ? TK_GEMM3 : TK_GEMM, st);
             const bool last = k == m->n_gc - 1;
+            static const int a_nt = getenv("MDFRI_GEMM_A_NT") ? atoi(getenv("MDFRI_GEMM_A_NT")) : 0;   // developer knob: bit 0 = storing launches, bit 1 = the last layer
+            static const int c_nt = getenv("MDFRI_GEMM_C_NT") ? atoi(getenv("MDFRI_GEMM_C_NT")) : 0;   // developer knob: bit 0 = layer-1 output, bit 1 = layer-2 output
+            GemmAux ga;
+            ga.a_stream = last ? (a_nt >> 1) & 1 : a_nt & 1;
+            ga.c_nt = (c_nt >> 1) & 1;
             int rc;
             if (last)
-                rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
+                rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st, ga);
             else
-                rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
+                rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st, ga);
             if (rc) return rc;
         }
         off += Cout;
@@ -1719,17 +1773,25 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
     int cmax = 0;
     for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
     float *Ha = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax);
+    {
+        static const int buf_env = getenv("MDFRI_GCN_BUF") ? atoi(getenv("MDFRI_GCN_BUF")) : 0;   // developer probe: bit 0 = H1 / H2 swap slabs, bit 2 = AH in the middle
+        if (buf_env & 1) std::swap(Ha, Hb);
+        if (buf_env & 4) std::swap(Hb, AH);
+    }
     const int Ri = (int)R, feat = m->feat;
     MDF_REQUIRE(m->lm_dim == 0, "gcn_embed_dev: this model has a language-model branch; use mdf_gcn_embed_lm_dev");
     // layer 1 (folded embedding): H1 = elu(S . T1) on the MFMA GEMM (K = 32), S = Ahat . onehot from mdf_letter_sums_dev
     {
         ScopedTiming tm(TK_GEMM1, st);
         const int C0 = m->gc[0];
+        static const int c_nt = getenv("MDFRI_GEMM_C_NT") ? atoi(getenv("MDFRI_GEMM_C_NT")) : 0;
+        GemmAux ga;
+        ga.c_nt = c_nt & 1;
         int rc;
         if (m->n_gc == 1)
             rc = launch_gemm<EPI_L1>(letter_sums, 32, m->T1t, 32, Ri, C0, 32, nullptr, C0, nullptr, partial, feat, nullptr, C0, st);
         else
-            rc = launch_gemm<EPI_L1_STORE>(letter_sums, 32, m->T1t, 32, Ri, C0, 32, Ha, C0, nullptr, partial, feat, nullptr, C0, st);
+            rc = launch_gemm<EPI_L1_STORE>(letter_sums, 32, m->T1t, 32, Ri, C0, 32, Ha, C0, nullptr, partial, feat, nullptr, C0, st, ga);
         if (rc) return rc;
     }
     if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st)) return rc;

@@ -1099,11 +1099,31 @@ void mdf_nw_workspace_free(mdf_nw_workspace *w)
 
 // Step 1 (asynchronous): stage and upload the sequences, translate letters, score every (query, candidate) pair -- largest matrices
 // first --, arg-max per query, start the small results on their way back.  The caller's buffers are not read after the return.
+static int nw_best_hits_begin_steps(mdf_nw_workspace *w, const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut,
+                                    int32_t nq, const int32_t *cand, const int64_t *first, const int32_t *matrix, int32_t A, int gap_open, int gap_extend,
+                                    int tie_rule, const char *alphabet, int64_t max_trace_bytes, int want_cand_scores, bool *enqueued);
+
 int mdf_nw_best_hits_begin(mdf_nw_workspace *w, const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut,
                            int32_t nq, const int32_t *cand, const int64_t *first, const int32_t *matrix, int32_t A, int gap_open, int gap_extend,
                            int tie_rule, const char *alphabet, int64_t max_trace_bytes, int want_cand_scores)
 {
     MDF_REQUIRE(w, "nw_best_hits_begin: NULL workspace");
+    bool enqueued = false;
+    const int rc = nw_best_hits_begin_steps(w, text, seq_off, seq_len, n_seq, lut, nq, cand, first, matrix, A, gap_open, gap_extend, tie_rule, alphabet,
+                                            max_trace_bytes, want_cand_scores, &enqueued);
+    if (rc != MDF_OK && enqueued) {
+        // a late failure (a launch or a copy refused after the upload was enqueued) leaves work in the stream that reads the pinned
+        // staging and writes the device scratch of THIS workspace: let it land before the caller may begin() on it again
+        DeviceGuard guard(w->device);
+        (void)hipStreamSynchronize(w->st);
+    }
+    return rc;
+}
+
+static int nw_best_hits_begin_steps(mdf_nw_workspace *w, const uint8_t *text, const int64_t *seq_off, const int32_t *seq_len, int32_t n_seq, const uint8_t *lut,
+                                    int32_t nq, const int32_t *cand, const int64_t *first, const int32_t *matrix, int32_t A, int gap_open, int gap_extend,
+                                    int tie_rule, const char *alphabet, int64_t max_trace_bytes, int want_cand_scores, bool *enqueued)
+{
     MDF_REQUIRE(w->stage == 0, "nw_best_hits_begin: the workspace still holds a call in flight (finish it first)");
     MDF_REQUIRE(text && seq_off && seq_len && cand && first && matrix && alphabet, "nw_best_hits: NULL argument");
     MDF_REQUIRE(n_seq > 0 && nq > 0 && nq <= n_seq, "nw_best_hits: nq=%d queries among n_seq=%d sequences", nq, n_seq);
@@ -1192,6 +1212,7 @@ int mdf_nw_best_hits_begin(mdf_nw_workspace *w, const uint8_t *text, const int64
     char *b1 = static_cast<char *>(w->s1.ptr);
     hipStream_t st = w->st;
     tm("stage phase 1");
+    *enqueued = true;
     MDF_HIP(hipMemcpyAsync(b1 + w->d_in, h, w->h_up, hipMemcpyHostToDevice, st));
     auto I = [&](size_t off) { return b1 + w->d_in + off; };
     if (lut) hipLaunchKernelGGL(k_nw_encode, dim3((unsigned)((total + 4095) / 4096)), dim3(256), 0, st, (uint8_t *)I(w->h_text), total, (const uint8_t *)I(w->h_lut),

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -323,10 +324,11 @@ int mdf_matrix_format_host(const char *prefix, const int64_t *prefix_off, const 
     std::vector<std::unique_ptr<char[]>> part((size_t)nt);
     std::vector<int64_t> len((size_t)nt, 0), at((size_t)nt + 1, 0);
     auto first_row = [&](int k) { return (int32_t)((int64_t)B * k / nt); };
+    // every block buffer is allocated HERE, on the calling thread, inside the try below: an allocation failure inside a worker thread
+    // would have no handler (std::terminate), and so would a std::thread that fails to start while earlier ones are still joinable
     auto work = [&](int k) {
         const int32_t p0 = first_row(k), p1 = first_row(k + 1);
         if (p1 <= p0) return;
-        part[(size_t)k].reset(new char[(size_t)(prefix_off[p1] - prefix_off[p0]) + (size_t)(p1 - p0) * (size_t)row_max]);
         char *const begin = part[(size_t)k].get();
         char *o = begin;
         for (int32_t p = p0; p < p1; ++p) {
@@ -346,13 +348,30 @@ int mdf_matrix_format_host(const char *prefix, const int64_t *prefix_off, const 
     auto place = [&](int k) {
         if (len[(size_t)k]) memcpy(out + at[(size_t)k], part[(size_t)k].get(), (size_t)len[(size_t)k]);
     };
+    // workers never throw (plain memory writes into pre-sized buffers); the threads that did start are joined whatever happens next
     auto run = [&](auto &&fn) {
-        std::vector<std::thread> pool;
-        for (int k = 1; k < nt; ++k) pool.emplace_back(fn, k);
+        struct Joiner {
+            std::vector<std::thread> pool;
+            ~Joiner()
+            {
+                for (auto &th : pool)
+                    if (th.joinable()) th.join();
+            }
+        } j;
+        j.pool.reserve((size_t)nt);
+        int started = 1;
+        try {
+            for (int k = 1; k < nt; ++k, ++started) j.pool.emplace_back(fn, k);
+        } catch (const std::system_error &) {   // out of threads: the caller's thread does the blocks that got none
+        }
         fn(0);
-        for (auto &th : pool) th.join();
+        for (int k = started; k < nt; ++k) fn(k);
     };
     try {
+        for (int k = 0; k < nt; ++k) {
+            const int32_t p0 = first_row(k), p1 = first_row(k + 1);
+            if (p1 > p0) part[(size_t)k].reset(new char[(size_t)(prefix_off[p1] - prefix_off[p0]) + (size_t)(p1 - p0) * (size_t)row_max]);
+        }
         run(work);
         for (int k = 0; k < nt; ++k) at[(size_t)k + 1] = at[(size_t)k] + len[(size_t)k];
         *bytes = at[(size_t)nt];

@@ -3,6 +3,9 @@
 
   kernel stats :  python profiles/summarize_rocprof.py stats  <dir with *_kernel_stats.csv>   > profiles/rNN_kernel_stats.txt
   counters     :  python profiles/summarize_rocprof.py pmc    <dir with *_counter_collection.csv> ...  > profiles/rNN_pmc.txt
+  per layer    :  python profiles/summarize_rocprof.py layers <dir with *_kernel_trace.csv>   >> profiles/rNN_kernel_stats.txt
+                  (A.X and H.W launches split by GraphConv layer: a k_aggregate launch is layer 2 when the kernel in front of it is the
+                  K = 32 layer-1 GEMM, layer 3 when it is an H.W GEMM; only full-size launches -- the modal grid -- are counted)
 Counters are averaged per kernel name over all dispatches (one rocprofv3 --pmc pass per directory).
 """
 import csv
@@ -46,8 +49,46 @@ def pmc(dirs):
         print(f"{k:62s} {n:6d} " + " ".join(f"{(acc[k][c][0]/acc[k][c][1] if acc[k][c][1] else float('nan')):22.1f}" for c in counters))
 
 
+def layers(d):
+    """Per-layer durations of the two named kernels from the kernel trace (the same split bench.py's `per_layer` reports from HIP events)."""
+    for f in find(d, "*kernel_trace.csv"):
+        rows = [r for r in csv.DictReader(open(f)) if r["Kind"] == "KERNEL_DISPATCH"]
+        rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+        groups = defaultdict(list)
+        prev = ""
+        for r in rows:
+            name = short(r["Kernel_Name"])
+            dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            grid = int(r["Grid_Size_X"])
+            if name.startswith("k_aggregate"):
+                # layer 1's EPI codes are 4 / 5 (EPI_L1_STORE / EPI_L1); an H.W launch in front means the layer above 2
+                layer = "layer 2" if prev.startswith("k_gemm_f32<(Epilogue)4") or prev.startswith("k_gemm_f32<(mdf::Epilogue)4") or "<4," in prev \
+                    else ("layer 3" if prev.startswith("k_gemm_f32") else "other")
+                groups[("k_aggregate (A.X)", layer, name)].append((grid, dur))
+            elif name.startswith("k_gemm_f32<") and not name.startswith("k_gemm_f32_small"):
+                epi = name.split("<", 1)[1]
+                if epi.startswith("(Epilogue)0") or epi.startswith("0"):
+                    groups[("k_gemm_f32 (H.W)", "layer 2 (stores H2)", name)].append((grid, dur))
+                elif epi.startswith("(Epilogue)1") or epi.startswith("1"):
+                    groups[("k_gemm_f32 (H.W)", "layer 3 (pool only)", name)].append((grid, dur))
+            prev = name
+        print(f"# per-layer split from {os.path.relpath(f, d)} (full-size launches = the modal launch grid of each group)")
+        print(f"{'kernel':22s} {'layer':22s} {'launches':>8s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s}")
+        pooled = defaultdict(list)
+        for (kern, layer, _), v in sorted(groups.items()):
+            grids = [g for g, _ in v]
+            mode = max(set(grids), key=grids.count)
+            full = [t for g, t in v if g == mode]
+            pooled[kern] += full
+            print(f"{kern:22s} {layer:22s} {len(full):8d} {sum(full)/len(full):9.2f} {min(full):9.2f} {max(full):9.2f}")
+        for kern, full in sorted(pooled.items()):
+            print(f"{kern:22s} {'all layers pooled':22s} {len(full):8d} {sum(full)/len(full):9.2f} {min(full):9.2f} {max(full):9.2f}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "layers":
+        layers(sys.argv[2])
     else:
         pmc(sys.argv[2:])

@@ -159,3 +159,37 @@ def test_pipelined_contact_stage_is_bitwise_the_same(heads):
     eng.forward_alignments(db)
     with pytest.raises(ValueError, match="Invalid character in sequence: J"):
         eng.check(db)
+
+
+def test_dense_regrow_reaches_both_contact_sets_of_the_pipelined_stage(heads):
+    """ADVICE r3 (engine.hip, forward_dense's mid-batch regrow): with pipeline_contact on, the shared CSR capacity is handed to BOTH
+    contact sets, so a regrow must resize both.  Sequence: (1) a fused call on a capacity far too small reports CapacityError (nothing is
+    written past the arrays), (2) forward_dense with all-ones maps grows the capacity, (3) the same fused call now fits -- on every chunk,
+    odd ones (set 1) included -- and equals the non-pipelined engine bit for bit."""
+    from mDeepFRI.batch import HotPathEngine
+    ws, preds = heads
+    prots = synthetic.synthetic_proteins(seed=411, count=24, length=(60, 200), indel_rate=0.05)
+    pk = _pack(prots, max_rows=512)
+    assert len(pk.chunks) >= 4
+    ref = HotPathEngine(preds, device=0, max_rows=512).run_alignments(pk)
+    eng = HotPathEngine(preds, device=0, max_rows=512, nnz_per_row=2, pipeline_contact=1)
+    db = eng.upload(pk)
+    eng.forward_alignments(db)
+    with pytest.raises(_hip.CapacityError):
+        eng.check(db)
+    cap0 = eng.nnz_capacity
+    maps = [np.ones((len(p["seq"]), len(p["seq"])), dtype=np.int32) for p in prots]
+    db_d = eng.upload(_pack_seq_only(prots, max_rows=512))
+    eng.forward_dense(db_d, maps)
+    assert eng.nnz_capacity > 8 * cap0
+    db2 = eng.upload(pk)
+    for _ in range(3):
+        out = eng.forward_alignments(db2)
+        eng.check(db2)
+        for m in eng.modes:
+            assert np.array_equal(out[m].cpu().numpy(), ref[m]), m
+
+
+def _pack_seq_only(prots, **kw):
+    from mDeepFRI.batch import PackedProteins
+    return PackedProteins.pack([p["seq"] for p in prots], **kw)
