@@ -41,6 +41,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "metagenomic-deepfri_amd"))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)   # mdfri_testkit: synthetic workloads + weights (not part of the product package)
 
 import numpy as np  # noqa: E402
 
@@ -138,7 +140,7 @@ def launch_ranks(args) -> int:
 def make_fixed_length(seed, count, L):
     """configs[2] inputs: uniform 20-letter sequences, 3.8 A random-walk C-alpha traces rounded to 3 decimals, identity
     alignments.  Vectorised over the batch."""
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     rng = np.random.default_rng(seed)
     letters = np.frombuffer(synthetic.AA20.encode(), dtype=np.uint8)
     seq_bytes = letters[rng.integers(0, 20, size=(count, L))]
@@ -152,7 +154,7 @@ def make_fixed_length(seed, count, L):
 def make_helix(seed, count, L):
     """Protein-like C-alpha traces (synthetic.helix_bundle_coords: ~8.6 contacts per residue at 6 A instead of the ~12.6 of a random
     walk; SURVEY.md section 8d asks for this second generator), otherwise as make_fixed_length."""
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     rng = np.random.default_rng(seed)
     letters = np.frombuffer(synthetic.AA20.encode(), dtype=np.uint8)
     seqs = [bytes(r).decode() for r in letters[rng.integers(0, 20, size=(count, L))]]
@@ -161,7 +163,7 @@ def make_helix(seed, count, L):
 
 def make_mixed(seed, count):
     """configs[3]-shaped: L ~ U{128..1024}, 5 % indels, sorted by length as pipeline.py:529 sorts its work list."""
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     L = synthetic.uniform_lengths(seed, count)
     order = np.argsort(L, kind="stable")
     return synthetic.bulk_proteins(seed, L, order, indel_rate=0.05)
@@ -170,7 +172,7 @@ def make_mixed(seed, count):
 def make_queries(seed, n_queries, n_db=1500, k=8):
     """Inputs of the stages in front of and behind the path (query_stream leg): a database of histogram-length sequences with random-walk
     structures, queries = mutated database members (ungapped, as a FASTA record holds them), k candidate targets each."""
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     rng = np.random.default_rng(seed)
     lens = synthetic.histogram_lengths(seed + 1, n_db)
     db_seq = {f"T{j}": synthetic.random_sequence(rng, int(L)) for j, L in enumerate(lens)}
@@ -216,7 +218,7 @@ def _oracle_loop(seqs, coords, weights, budget_s, lm):
 def cpu_worker(spec):
     """One single-thread worker of the all-core leg (a fresh child process: BLAS pinned to one thread by its environment)."""
     seed, length, budget, lm = spec.split(",")
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     weights = make_weights(bool(int(lm)))
     seqs, coords, _, _ = make_fixed_length(int(seed), 8, int(length))
     del synthetic
@@ -227,7 +229,7 @@ def cpu_worker(spec):
 def make_weights(lm, sparse_scores=False):
     """sparse_scores: the operating point of trained heads (1-4 % of the terms pass score >= 0.1; synthetic.glorot_gcn_weights) --
     used by the workloads whose step ends in the FILTERED gather, so that they measure a compacted payload."""
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     weights = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=synthetic.GO_TERMS[m], sparse_scores=sparse_scores) for i, m in enumerate(MODES)}
     if lm:
         lmw = synthetic.glorot_lm_weights(seed=1000)
@@ -239,7 +241,7 @@ def make_weights(lm, sparse_scores=False):
 
 def ort_leg(seqs, coords, weights, budget_s):
     """Real onnxruntime-CPU, single thread, batch 1 -- the reference's shipped configuration (predict.pyx:62-73,98; SURVEY.md
-    section 0.6) -- on the synthetic weights exported by mDeepFRI.onnx_writer.  Only when `import onnxruntime` works here."""
+    section 0.6) -- on the synthetic weights exported by mdfri_testkit.onnx_writer.  Only when `import onnxruntime` works here."""
     try:
         import onnxruntime as rt
     except Exception as e:
@@ -248,7 +250,7 @@ def ort_leg(seqs, coords, weights, budget_s):
         oracle_paths()
         import cmap_oracle
         import gcn_oracle
-        from mDeepFRI import onnx_writer
+        from mdfri_testkit import onnx_writer
         so = rt.SessionOptions()
         so.intra_op_num_threads = so.inter_op_num_threads = 1
         sess = {m: rt.InferenceSession(onnx_writer.deepfri_gcn_model(weights[m]), so, providers=["CPUExecutionProvider"]) for m in MODES}
@@ -314,14 +316,26 @@ class Ctx:
 
 
 def timed_run(ctx, eng, db, steps, warmup, after=None, timing_period=7):
-    """W warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns (seconds (max over ranks), last out)."""
+    """W warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns (seconds (max over ranks), last out,
+    per-rank split).  The split comes from three events per step on the launch stream: forward issued -> forward done (`compute`)
+    -> the step's gather done (`gather`; on a sending rank that includes waiting for the collective to be matched)."""
     import torch
     import torch.distributed as dist
 
-    def step():
+    marks = []
+
+    def step(timed=False):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timed else None
+        if timed:
+            ev[0].record()
         out = eng.forward_alignments(db)
+        if timed:
+            ev[1].record()
         if after is not None:
             after(out)
+        if timed:
+            ev[2].record()
+            marks.append(ev)
         return out
 
     def fence():
@@ -339,16 +353,21 @@ def timed_run(ctx, eng, db, steps, warmup, after=None, timing_period=7):
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-        out = step()
+        out = step(timed=True)
     fence()
     elapsed = time.perf_counter() - t0
     ctx.lib.mdf_timing_enable(0)
+    mine = [sum(e[0].elapsed_time(e[1]) for e in marks) / steps, sum(e[1].elapsed_time(e[2]) for e in marks) / steps, 1e3 * elapsed / steps]
+    split = {"compute_ms": [round(mine[0], 3)], "gather_ms": [round(mine[1], 3)], "step_ms": [round(mine[2], 3)]}
     if ctx.world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        rows = [None] * ctx.world
+        dist.all_gather_object(rows, mine)
+        split = {"compute_ms": [round(r[0], 3) for r in rows], "gather_ms": [round(r[1], 3) for r in rows], "step_ms": [round(r[2], 3) for r in rows]}
     eng.check(db)
-    return elapsed, out
+    return elapsed, out, split
 
 
 def read_kernels(ctx, names):
@@ -366,13 +385,19 @@ def rooflines(ctx, eng, pk, kernels, lm):
     R = pk.chunks[0].rows                        # rows per launch (all chunks but the last are equal)
     rows_launch = sum(c.rows for c in pk.chunks) / len(pk.chunks)
     roof = roof_ax = None
-    try:  # HBM bytes per launch: a CONSTANT from the committed rocprofv3 PMC passes (profiles/traffic.json), valid for the same rows per launch only
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        if traffic.get("rows_per_launch") != R:
-            traffic = {}
-    except OSError:
-        traffic = {}
+    # HBM bytes per launch: a CONSTANT from the committed rocprofv3 PMC passes (profiles/traffic.json), reported only for the same rows
+    # per launch AND the very kernels it was measured on: the file carries the library's mdf_version() (a hash of the GraphConv
+    # kernels' source, csrc/Makefile); with any other build `traffic` is null and `traffic_source` says why
     src = "profiles/traffic.json (rocprofv3 --pmc pass of an earlier run of this command; not a counter of this run)"
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        lib_version = ctx.lib.mdf_version().decode()
+        if traffic.get("rows_per_launch") != R:
+            traffic, src = {}, f"dropped: profiles/traffic.json is for {traffic.get('rows_per_launch')} rows per launch, this run has {R}"
+        elif traffic.get("library") != lib_version:
+            traffic, src = {}, f"dropped: profiles/traffic.json was measured on '{traffic.get('library')}', this library is '{lib_version}' (re-run tools/refresh_profiles.sh)"
+    except OSError:
+        traffic, src = {}, "dropped: profiles/traffic.json not found"
     C = 512
     g, a = kernels.get("gemm", {}), kernels.get("ax", {})
     # `achieved` is the mean over ALL sampled launches of the kernel, every GraphConv layer pooled (the classes are sampled at the same
@@ -387,7 +412,7 @@ def rooflines(ctx, eng, pk, kernels, lm):
                      for k in ("gemm2", "gemm3") if kernels.get(k, {}).get("launches") and not lm}
         roof = {"kernel": "k_gemm_f32 (H.W, 256x256x32 tiles, v_mfma_f32_32x32x2_f32, LDS-DMA staging, ELU+pool epilogue)",
                 "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
-                "traffic": traffic.get("gemm_mean_bytes"), "traffic_source": src if traffic else None,
+                "traffic": traffic.get("gemm_mean_bytes"), "traffic_source": src,
                 "per_launch": {"rows": R, "flops": 2.0 * R * C * C, "avg_us": g["avg_us"], "timed_launches": g["launches"]},
                 "per_layer": per_layer}
     if a.get("launches"):
@@ -401,7 +426,7 @@ def rooflines(ctx, eng, pk, kernels, lm):
                      for k in ("ax2", "ax3") if kernels.get(k, {}).get("launches") and not lm}
         roof_ax = {"kernel": "k_aggregate<512> (A.X, CSR gather, one wave per residue row)", "bound": "hbm", "achieved": round(gbs, 1),
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                   "traffic": (traffic.get("k_aggregate<512>") or {}).get("bytes"), "traffic_source": src if traffic else None,
+                   "traffic": (traffic.get("k_aggregate<512>") or {}).get("bytes"), "traffic_source": src,
                    "per_launch": {"rows": R, "bytes": bytes_row * R, "nnz_per_row": round(nnz_per_row, 2), "avg_us": a["avg_us"],
                                   "timed_launches": a["launches"]},
                    "per_layer": per_layer}
@@ -432,7 +457,7 @@ def mini_run(ctx, eng, cols, chunk_rows, steps=2, warmup=1, lm=False):
     from mDeepFRI import batch
     pk = batch.PackedProteins.pack(*cols, max_rows=chunk_rows)
     db = eng.upload(pk)
-    elapsed, _ = timed_run(ctx, eng, db, steps, warmup, timing_period=5)
+    elapsed, _, _ = timed_run(ctx, eng, db, steps, warmup, timing_period=5)
     kernels = read_kernels(ctx, ("gemm", "gemm2", "gemm3", "ax", "ax2", "ax3"))
     roof, roof_ax = rooflines(ctx, eng, pk, kernels, lm)
     n = len(cols[0])
@@ -444,7 +469,8 @@ def mini_run(ctx, eng, cols, chunk_rows, steps=2, warmup=1, lm=False):
 
 def dry_plan(args):
     """`--dry-plan`: the deal of the strong-scaling workloads without a GPU -- what every rank would compute for itself."""
-    from mDeepFRI import sharding, synthetic
+    from mDeepFRI import sharding
+    from mdfri_testkit import synthetic
     out = {}
     for name in ([args.workload] if args.workload in STRONG else list(STRONG)):
         total, seed = STRONG[name]
@@ -499,7 +525,8 @@ def main():
             dist.init_process_group(args.backend, rank=ctx.rank, world_size=ctx.world)
         ctx.world = dist.get_world_size()     # as the backend (RCCL) saw it
 
-    from mDeepFRI import _hip, batch, sharding, synthetic
+    from mDeepFRI import _hip, batch, sharding
+    from mdfri_testkit import synthetic
     from mDeepFRI.output import filter_scores
     from mDeepFRI.predict import Predictor
     ctx.lib = _hip.lib()
@@ -556,7 +583,7 @@ def main():
         rank_info = {"world_size": 1, "backend": None, "devices": [me]}
 
     timing_period = 0 if args.no_kernel_timing else args.timing_period
-    elapsed, out = timed_run(ctx, eng, db, args.steps, args.warmup, after=after, timing_period=timing_period)
+    elapsed, out, split = timed_run(ctx, eng, db, args.steps, args.warmup, after=after, timing_period=timing_period)
 
     if strong:
         for m in MODES:
@@ -597,6 +624,12 @@ def main():
             "roofline_ax": roof_ax,
             "kernels": kernels,
         }
+        if kernels and not args.lm:
+            # the sampled mean of every kernel class x the launches a step really makes: must add up to the step (nothing skipped, no idle stream)
+            nC, nH = len(pk.chunks), len(MODES)
+            per_step = {"gemm1": nC * nH, "ax2": nC * nH, "gemm2": nC * nH, "ax3": nC * nH, "gemm3": nC * nH, "cmap": nC, "head": nH}
+            line["kernel_sum_ms_per_step"] = round(sum(kernels[k]["avg_us"] * n for k, n in per_step.items() if kernels.get(k, {}).get("launches")) / 1e3, 3)
+            line["launches_per_step"] = per_step
         if strong:
             surv = {m: int(gathered[m][1].numel()) for m in MODES}
             line["gathered_survivors"] = surv
@@ -606,6 +639,9 @@ def main():
             line["gather_bytes_per_step"] = {"filtered": int(8 * sum(surv.values()) + 8 * n_job * len(MODES)), "dense_equivalent": int(4 * n_job * T_total)}
         elif ctx.world > 1:
             line["gather_bytes_per_step"] = {"dense": int(4 * n_job * T_total)}
+        rank_info["per_rank_ms_per_step"] = split     # forward (compute) and gather, per rank: an imbalance or a slow link shows here
+        rank_info["compute_ms_min_max"] = [min(split["compute_ms"]), max(split["compute_ms"])]
+        rank_info["gather_ms_min_max"] = [min(split["gather_ms"]), max(split["gather_ms"])]
         line["ranks"] = rank_info
         if args.verify > 0:
             line["verify"] = verify(seqs, coords, q_alns, t_alns, weights, out, args.verify, args.lm)
@@ -737,7 +773,8 @@ def bench_cnn(args, ctx, local_rank):
     structural hit (pipeline.py:600-648), 3 heads, upstream DeepCNN default topology, same synthetic sequences."""
     import torch
     import torch.distributed as dist
-    from mDeepFRI import _hip, batch, synthetic
+    from mDeepFRI import _hip, batch
+    from mdfri_testkit import synthetic
     from mDeepFRI.predict import Predictor
     rank, world, dev = ctx.rank, ctx.world, ctx.dev
     n_local = args.proteins or 10000

@@ -218,10 +218,13 @@ int mdf_cnn_forward_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, c
  * pipeline.py:292-319 _run_prediction_loop, for B proteins at once).
  *
  * Residue-row layout: protein p owns rows [row_off[p], row_off[p]+Lq[p]) of every per-residue array;
- * row_off[p] is a multiple of 32 and row_off[B] (= R, total rows) a multiple of 128; rows between
+ * row_off[p] is a multiple of MDF_GROUP_ROWS (16) and row_off[B] (= R, total rows) a multiple of 128; rows between
  * Lq[p] and the next protein are padding (kept zero).  Use mdf_layout_rows() to build row_off.
+ * A GROUP is MDF_GROUP_ROWS consecutive rows: the unit of the pooling partial sums (half a 32 x 32 MFMA tile).
  * All descriptor arrays are int32 on the device.
  * ---------------------------------------------------------------------------------------------- */
+#define MDF_GROUP_ROWS 16
+int mdf_group_rows(void);   /* = MDF_GROUP_ROWS, for callers that do not compile against this header */
 
 /* Host helper: row_off[0..B] from Lq[0..B-1] as specified above.  Returns R (total rows) or a negative code. */
 int64_t mdf_layout_rows(const int32_t *Lq, int32_t B, int32_t *row_off);
@@ -275,7 +278,7 @@ int mdf_dense_to_csr_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_
 int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
                         float *letter_sums, void *stream);
 
-/* GraphConv stack for R residue rows.  Output: per-32-row-group partial sums of concat(H1,H2,H3):
+/* GraphConv stack for R residue rows.  Output: per-group (MDF_GROUP_ROWS rows) partial sums of concat(H1,H2,H3):
  * partial (R/32, feature_dim) f32 -- the deterministic first level of the sum pooling (H3 itself never reaches HBM).
  * workspace: mdf_gcn_workspace_bytes(model, R) bytes. */
 size_t mdf_gcn_workspace_bytes(const mdf_model *m, int64_t R);
@@ -289,7 +292,7 @@ int mdf_gcn_embed_lm_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h
                          const float *val, int64_t R, float *partial, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Second level of the sum pooling: pooled[p] = sum of partial[g] over g in [grp_off[p], grp_off[p+1])  -> (B, feature_dim).
- * grp_off (B+1, int32, device) counts 32-row groups (row_off / 32, plus the group base of the protein's chunk when the
+ * grp_off (B+1, int32, device) counts groups (row_off / MDF_GROUP_ROWS, plus the group base of the protein's chunk when the
  * partials of several chunks share one array). */
 int mdf_gcn_pool_dev(mdf_model *m, const float *partial, const int32_t *grp_off, int32_t B, float *pooled, void *stream);
 
@@ -312,8 +315,8 @@ int mdf_gcn_head_dev(mdf_model *m, const float *pooled, int32_t B, float *scores
 
 /* --- planner (host only; needs no GPU) ---
  * Proteins stay in input order.  A CHUNK is a run of consecutive proteins whose padded rows (32 per protein, see the
- * residue-row layout above) fit `max_rows`; a SEGMENT is a run of chunks whose per-32-row pool partials share one array
- * (at most max_segment_groups 32-row groups).  An immutable plan may be shared by any number of batches of the same
+ * residue-row layout above) fit `max_rows`; a SEGMENT is a run of chunks whose per-group pool partials share one array
+ * (at most max_segment_groups groups of MDF_GROUP_ROWS rows).  An immutable plan may be shared by any number of batches of the same
  * lengths. */
 typedef struct mdf_plan mdf_plan;
 int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, int32_t max_segment_groups, mdf_plan **out);
@@ -323,7 +326,7 @@ int32_t mdf_plan_num_chunks(const mdf_plan *plan);
 int32_t mdf_plan_num_segments(const mdf_plan *plan);
 int64_t mdf_plan_max_chunk_rows(const mdf_plan *plan);
 /* chunk table, n_chunks x 6 int64: p0, p1 (proteins [p0, p1)), rows (R of the chunk), row_off_pos (start of the chunk's
- * p1-p0+1 row offsets in the row-offset array), segment, group_base (first 32-row group of the chunk in its segment) */
+ * p1-p0+1 row offsets in the row-offset array), segment, group_base (first group of the chunk in its segment) */
 int mdf_plan_chunks(const mdf_plan *plan, int64_t *out);
 /* segment table, n_segments x 4 int64: p0, p1, groups, grp_off_pos */
 int mdf_plan_segments(const mdf_plan *plan, int64_t *out);
@@ -339,7 +342,7 @@ typedef struct {
     int32_t nnz_per_row;         /* initial CSR capacity per residue row; 0 = 40 (6 A maps hold ~13, 10 A maps ~40) */
     double threshold;            /* contact threshold in Angstrom (cli.py:360-371 default 6.0) */
     int32_t generated_contacts;  /* contact_map_utils.pyx:44 generated_contacts (default 2) */
-    int32_t max_segment_groups;  /* 0 = 1 << 19 */
+    int32_t max_segment_groups;  /* 0 = 1 << 20 */
     int32_t lm_batch;            /* proteins per LSTM group for heads with a language model; 0 = 8192 */
     double lm_workspace_gib;     /* LSTM time-major workspace budget; 0 = 48 */
     int32_t graph_max_chunks;    /* batches of at most this many chunks replay their launch sequence as ONE hipGraph from the

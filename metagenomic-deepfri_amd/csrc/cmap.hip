@@ -222,10 +222,11 @@ __global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_a
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Fused contact rows.  One block per 32-row group (a group never straddles proteins: row_off is 32-aligned);
-// each of the 4 waves owns 8 consecutive rows.  Lane l of a wave owns column j0+l of the current 64-column
-// chunk and keeps that column's target coordinates in registers while the wave's 8 rows stream past as
-// wave-uniform scalars.
+// Fused contact rows.  One block per 32 rows = two groups of GROUP_ROWS = 16 rows; each of the 4 waves owns 8 consecutive rows.
+// A protein starts on a 16-row boundary, so the two halves of a block (waves 0-1, waves 2-3) may belong to DIFFERENT proteins:
+// every wave resolves its own protein, and the column staging below is shared when the halves agree (the common case) and split
+// in two when they do not.  Lane l of a wave owns column j0+l of the current 64-column chunk and keeps that column's target
+// coordinates in registers while the wave's 8 rows stream past as wave-uniform scalars.
 //   bit(i,j) = (i==j) | synthetic(i,j) | (q2t[i]>=0 & q2t[j]>=0 & both < Lt & dist2(coords[q2t[i]],coords[q2t[j]]) < thr2)
 //   synthetic(i,j) = 0<|i-j|<=gen & (q2t[i]<0 | q2t[j]<0)            (pyx:70-76,91-97, both directions)
 // The contact term is symmetric for coords-derived pairs (argwhere yields (i,j) and (j,i)), so the one-directional
@@ -245,23 +246,34 @@ __device__ __forceinline__ int find_protein(const int32_t *__restrict__ row_off,
     return lo;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coords, const int32_t *__restrict__ coord_off,
-                                                   const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off,
-                                                   int B, const int32_t *__restrict__ q2t, float thr2, int gen,
-                                                   int32_t *__restrict__ counts,        // COUNT: out (R)
-                                                   int32_t *__restrict__ group_sum,     // COUNT: out (R/32)
-                                                   unsigned long long *__restrict__ masks, int W,   // COUNT: out (R, W) contact bits
-                                                   int32_t *__restrict__ dense_out, const int64_t *__restrict__ dense_off)
+// Protein of the SECOND 16-row group of the 32-row block at row0, given the first group's: a protein occupies at least one whole group,
+// so it is either the same protein or the next one -- one load instead of a second binary search in the block's prologue.
+__device__ __forceinline__ int next_group_protein(const int32_t *__restrict__ row_off, int B, int p_lo, int row0)
+{
+    return (p_lo + 1 < B && row_off[p_lo + 1] <= row0 + GROUP_ROWS) ? p_lo + 1 : p_lo;
+}
+
+// SAME: both 16-row groups of the block belong to one protein (block-uniform; every block of a fixed-length batch, all but a few of
+// a mixed one): the staging geometry is then a compile-time constant and the code is the one-protein-per-block kernel it always was.
+template <int MODE, bool SAME>
+__device__ __forceinline__ void cmap_rows_body(const float *__restrict__ coords, const int32_t *__restrict__ coord_off,
+                                               const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off,
+                                               const int32_t *__restrict__ q2t, float thr2, int gen, int32_t *__restrict__ counts,
+                                               int32_t *__restrict__ group_sum, unsigned long long *__restrict__ masks, int W,
+                                               int32_t *__restrict__ dense_out, const int64_t *__restrict__ dense_off, int p_lo, int p_hi,
+                                               float4 *s_col_all, int *s_cnt)
 {
     const int g = blockIdx.x;
     const int row0 = g * 32;
-    const int p = find_protein(row_off, B, row0);
+    // (wid stays a plain per-lane value on purpose: told that it is wave-uniform, the compiler moves the 8 rows' coordinates, target
+    // indices and counters into scalar registers, runs out of them and spills through v_writelane / v_readlane: +22 % on the kernel)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int half = wid >> 1;                                     // which 16-row group of the block this wave works on
+    const int p = (SAME || !half) ? p_lo : p_hi;
     const int r0 = row_off[p];
     const int Lq = Lq_arr[p];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int Lq_blk = SAME ? Lq : max(Lq_arr[p_lo], Lq_arr[p_hi]);   // block-uniform trip count of the staging loop
     const int i_first = row0 - r0 + wid * 8;  // first local row of this wave
-    __shared__ int s_cnt[32];
 
     if (MODE == CM_COUNT && i_first >= Lq) {
         // padding rows: zero neighbours
@@ -301,11 +313,16 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
     // The columns' target coordinates go through LDS, a tile of CMAP_COL_TILE columns at a time, loaded once by the whole workgroup:
     // fetched per 64-column chunk by every wave (an index load and three dependent coordinate loads each time) the kernel spent its
     // time waiting for eight such round trips in a row.
-    __shared__ float4 s_col[CMAP_COL_TILE];   // x, y, z, bits of the mapped target index (-2 padding, -1 gap, -3 no coordinates)
-    for (int jt = 0; jt < Lq; jt += CMAP_COL_TILE) {
-        const int jt_end = min(jt + CMAP_COL_TILE, Lq);
+    // One protein in the block: the whole tile, staged by all 256 threads.  Two proteins: each half stages ITS protein's columns
+    // into its half of the tile with its 128 threads.
+    constexpr int tile = SAME ? CMAP_COL_TILE : CMAP_COL_TILE / 2;
+    float4 *const s_col = SAME ? s_col_all : s_col_all + half * (CMAP_COL_TILE / 2);
+    const int st_tid = SAME ? (int)threadIdx.x : (int)(threadIdx.x & 127);
+    constexpr int st_n = SAME ? 256 : 128;
+    for (int jt = 0; jt < Lq_blk; jt += tile) {
+        const int jt_end = min(jt + tile, Lq);
         __syncthreads();   // the previous tile has been consumed
-        for (int c = jt + (int)threadIdx.x; c < jt_end; c += 256) {
+        for (int c = jt + st_tid; c < jt_end; c += st_n) {
             int t = q2t_p[c];
             if (t >= Lt) t = -3;
             float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(t));
@@ -398,6 +415,25 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coords, const int32_t *__restrict__ coord_off,
+                                                   const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off,
+                                                   int B, const int32_t *__restrict__ q2t, float thr2, int gen,
+                                                   int32_t *__restrict__ counts,        // COUNT: out (R)
+                                                   int32_t *__restrict__ group_sum,     // COUNT: out (R/32)
+                                                   unsigned long long *__restrict__ masks, int W,   // COUNT: out (R, W) contact bits
+                                                   int32_t *__restrict__ dense_out, const int64_t *__restrict__ dense_off)
+{
+    __shared__ float4 s_col_all[CMAP_COL_TILE];   // x, y, z, bits of the mapped target index (-2 padding, -1 gap, -3 no coordinates)
+    __shared__ int s_cnt[32];
+    const int row0 = blockIdx.x * 32;
+    const int p_lo = find_protein(row_off, B, row0), p_hi = next_group_protein(row_off, B, p_lo, row0);
+    if (p_lo == p_hi)
+        cmap_rows_body<MODE, true>(coords, coord_off, Lq_arr, row_off, q2t, thr2, gen, counts, group_sum, masks, W, dense_out, dense_off, p_lo, p_hi, s_col_all, s_cnt);
+    else
+        cmap_rows_body<MODE, false>(coords, coord_off, Lq_arr, row_off, q2t, thr2, gen, counts, group_sum, masks, W, dense_out, dense_off, p_lo, p_hi, s_col_all, s_cnt);
+}
+
 // Exclusive scan of the per-group nnz (int32) with one block of up to 1024 threads (launched with 256: four waves of 36 VGPRs
 // fit next to a resident GEMM workgroup, which matters when the contact stage of the next chunk runs under the GEMMs of the
 // current one); writes rowptr[R] = total and the overflow status.
@@ -469,18 +505,24 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
     // per bit were the whole run time of this kernel (columns beyond the tile are fetched as before)
     extern __shared__ float s_dinv[];                                            // cols_cap floats, then cols_cap letters (dynamic: sized
     uint8_t *s_letter = reinterpret_cast<uint8_t *>(s_dinv + cols_cap);          // for the longest query of the launch, at most CMAP_FILL_COLS)
+    // block = 32 rows = two 16-row groups, which may belong to two proteins (see k_cmap_rows): then each half stages the first
+    // cols_cap / 2 columns of ITS protein with its 128 threads (the columns beyond take the global-memory path below)
     const int g = blockIdx.x, row0 = g * 32;
-    const int p = find_protein(row_off, B, row0);
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int half = wid >> 1;
+    const int p_lo = find_protein(row_off, B, row0), p_hi = next_group_protein(row_off, B, p_lo, row0);
+    const bool same = p_lo == p_hi;
+    const int p = half ? p_hi : p_lo;
     const int r0 = row_off[p], Lq = Lq_arr[p];
-    for (int c = threadIdx.x; c < min(Lq, cols_cap); c += 256) {
-        s_dinv[c] = 1.0f / (1e-6f + sqrtf((float)counts[r0 + c]));
-        s_letter[c] = seq_idx ? (uint8_t)min((int)seq_idx[r0 + c], 31) : (uint8_t)0;
+    const int cap = same ? cols_cap : cols_cap / 2, cbase = same ? 0 : half * cap;   // this wave's slice of the staged columns
+    for (int c = same ? (int)threadIdx.x : (int)(threadIdx.x & 127); c < min(Lq, cap); c += same ? 256 : 128) {
+        s_dinv[cbase + c] = 1.0f / (1e-6f + sqrtf((float)counts[r0 + c]));
+        s_letter[cbase + c] = seq_idx ? (uint8_t)min((int)seq_idx[r0 + c], 31) : (uint8_t)0;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int Wp = (Lq + 63) >> 6;
     if (Wp > W) {   // the caller's max_len is smaller than this protein: stay inside the bit rows and say so (status[2])
-        if (threadIdx.x == 0) status[2] = Lq;
+        if (lane == 0) status[2] = Lq;   // (per wave: the two halves of a block may belong to different proteins)
         Wp = W;
     }
     const int wrow0 = row0 + wid * 8;
@@ -522,15 +564,15 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
             while (m) {
                 const int j = (w << 6) + __builtin_ctzll(m);
                 m &= m - 1;
-                const bool staged = j < cols_cap;
-                const float dj = staged ? s_dinv[j] : 1.0f / (1e-6f + sqrtf((float)counts[r0 + j]));
+                const bool staged = j < cap;
+                const float dj = staged ? s_dinv[cbase + j] : 1.0f / (1e-6f + sqrtf((float)counts[r0 + j]));
                 const float v = (di * 1.0f) * dj;
                 if (pos < nnz_cap) {
                     colidx[pos] = r0 + j;
                     val[pos] = v;
                 }
                 ++pos;
-                if (seq_idx) s_bins[wid * 8 + r][staged ? (int)s_letter[j] : min((int)seq_idx[r0 + j], 31)] += v;
+                if (seq_idx) s_bins[wid * 8 + r][staged ? (int)s_letter[cbase + j] : min((int)seq_idx[r0 + j], 31)] += v;
             }
         }
     }
@@ -575,16 +617,17 @@ __global__ __launch_bounds__(256) void k_dense_rows(const void *__restrict__ cma
                                                     const int32_t *__restrict__ group_base, int32_t *__restrict__ rowptr,
                                                     int32_t *__restrict__ colidx, float *__restrict__ val, int64_t nnz_cap)
 {
-    // block = 32-row group, wave = 8 rows (sequentially)
+    // block = 32 rows (two 16-row groups, possibly of two proteins), wave = 8 rows (sequentially)
     const int g = blockIdx.x, row0 = g * 32;
-    const int p = find_protein(row_off, B, row0);
-    const int r0 = row_off[p], Lq = Lq_arr[p];
+    const int p_lo = find_protein(row_off, B, row0), p_hi = next_group_protein(row_off, B, p_lo, row0);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const char *A = static_cast<const char *>(cmaps) + cmap_off[p] * dtype_size(dtype);
     __shared__ int s_cnt[32];
     int run = 0;
     if (FILL) run = group_base[g];
     for (int r = 0; r < 32; ++r) {
+        const int p = r < GROUP_ROWS ? p_lo : p_hi;
+        const int r0 = row_off[p], Lq = Lq_arr[p];
+        const char *A = static_cast<const char *>(cmaps) + cmap_off[p] * dtype_size(dtype);
         const int row = row0 + r, i = row - r0;
         const bool mine = (r >> 3) == wid;
         if (FILL) {
@@ -890,7 +933,7 @@ int64_t mdf_layout_rows(const int32_t *Lq, int32_t B, int32_t *row_off)
     for (int32_t p = 0; p < B; ++p) {
         if (Lq[p] < 0) return fail(MDF_EINVAL, "layout_rows: negative length at %d", p);
         row_off[p] = (int32_t)r;
-        r += ((int64_t)Lq[p] + 31) / 32 * 32;
+        r += ((int64_t)Lq[p] + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
         if (r >= 0x7fffff00LL) return fail(MDF_EINVAL, "layout_rows: batch exceeds 2^31 rows");
     }
     r = (r + 127) / 128 * 128;

@@ -72,8 +72,9 @@ __global__ __launch_bounds__(256) void k_cnn_conv_pool(const uint8_t *__restrict
 }
 
 // The same computation with the tile's table staged in LDS: (k, 27, 64) floats (row 26 = zeros for positions outside the
-// sequence), loaded once per workgroup of 16 waves, which then walks work items.  A work item is one 32-row group of the
-// residue-row layout (row_off is 32-aligned, so a group belongs to one protein: k_cnn_group_owner): lane i holds the byte
+// sequence), loaded once per workgroup of 16 waves, which then walks work items.  A work item is one 32-row block of the
+// residue-row layout when both of its 16-row groups belong to one protein, otherwise each owned group on its own (a protein starts
+// on a GROUP_ROWS = 16 boundary; k_cnn_group_owner maps groups to proteins): lane i holds the byte
 // offset of the table row of the letter at window position i (32 + k - 1 <= 64 letters); a tap's offset reaches the scalar
 // unit through v_readlane and selects one conflict-free 256-byte LDS row.  The running max of a group is merged into
 // pooled with an integer atomicMax (the values are >= 0, where float order = int order; max is order-independent, so the
@@ -86,7 +87,7 @@ __global__ void k_cnn_group_owner(const int32_t *__restrict__ Lq, const int32_t 
 {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= B) return;
-    const int g0 = row_off[p] >> 5, g1 = (row_off[p] + Lq[p] + 31) >> 5;
+    const int g0 = row_off[p] / GROUP_ROWS, g1 = (row_off[p] + Lq[p] + GROUP_ROWS - 1) / GROUP_ROWS;
     for (int g = g0; g < g1; ++g) owner[g] = p;
 }
 
@@ -110,15 +111,20 @@ __global__ __launch_bounds__(CNN_LDS_THREADS) void k_cnn_conv_pool_lds(const uin
     const float b = bias[cc], sc = scale[cc], sh = shift[cc];
     const char *tl = reinterpret_cast<const char *>(tab + lane);
     constexpr int WAVES = CNN_LDS_THREADS / 64;
-    for (int g = blockIdx.x * WAVES + w; g < n_groups; g += gridDim.x * WAVES) {
-        const int p = owner[g];
+    // n_groups counts 32-row blocks; owner[] is per 16-row group
+    for (int g = blockIdx.x * WAVES + w; g < n_groups; g += gridDim.x * WAVES)
+    for (int h = 0; h < 2; ++h) {
+        const int p_lo = owner[2 * g], p_hi = owner[2 * g + 1];
+        const bool whole = p_lo == p_hi;                           // one protein owns the block: ONE item of up to 32 rows
+        if (whole && h) break;
+        const int p = h ? p_hi : p_lo;
         if (p < 0) continue;
-        const int r0 = row_off[p], L = Lq[p], q0 = g * 32 - r0;
+        const int r0 = row_off[p], L = Lq[p], q0 = g * 32 + h * GROUP_ROWS - r0;
         const uint8_t *s = seq_idx + r0;
         const int qi = q0 - t.left + lane;
         int aoff = 26 * 256;                                      // byte offset of the letter's row inside a tap's 27 rows
         if (qi >= 0 && qi < L) aoff = min((int)s[qi], 26) * 256;
-        const int np = min(32, L - q0);
+        const int np = min(whole ? 32 : GROUP_ROWS, L - q0);
         float best = 0.0f;
         // four residues at a time, four taps at a time: 16 independent LDS reads in flight per wave
 #define MDF_TAP(P, J) (*reinterpret_cast<const float *>(tl + (J) * (27 * 256) + __builtin_amdgcn_readlane(aoff, (P) + (J))))
@@ -264,7 +270,7 @@ int mdf_cnn_channels(const mdf_cnn *m) { return m ? m->C : fail(MDF_EINVAL, "cnn
 
 size_t mdf_cnn_workspace_bytes(const mdf_cnn *m, int32_t B, int64_t R)
 {
-    return m && B > 0 && R > 0 ? align_up((size_t)B * m->Cpad * 4, 256) + 2 * align_up((size_t)(R / 32 + 1) * 4, 256) + 256 : 0;
+    return m && B > 0 && R > 0 ? align_up((size_t)B * m->Cpad * 4, 256) + 2 * align_up((size_t)(R / GROUP_ROWS + 2) * 4, 256) + 256 : 0;
 }
 
 int mdf_cnn_padded_channels(const mdf_cnn *m) { return m ? m->Cpad : fail(MDF_EINVAL, "cnn is NULL"); }
@@ -274,7 +280,7 @@ int mdf_cnn_pool_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, cons
 {
     MDF_REQUIRE(m && seq_idx && Lq && row_off && pooled && workspace, "cnn_pool_dev: NULL argument");
     MDF_REQUIRE(B > 0 && R > 0 && R % 32 == 0 && R < 0x7fffffff, "cnn_pool_dev: B=%d R=%lld", B, (long long)R);
-    if (workspace_bytes < align_up((size_t)(R / 32 + 1) * 4, 256)) return fail(MDF_ECAPACITY, "cnn_pool_dev: workspace too small");
+    if (workspace_bytes < align_up((size_t)(R / GROUP_ROWS + 2) * 4, 256)) return fail(MDF_ECAPACITY, "cnn_pool_dev: workspace too small");
     hipStream_t st = static_cast<hipStream_t>(stream);
     int32_t *owner = static_cast<int32_t *>(workspace);
     const int n_groups = (int)(R / 32);
@@ -293,7 +299,7 @@ int mdf_cnn_pool_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, cons
                 attr_done = true;
             }
         }
-        MDF_HIP(hipMemsetAsync(owner, 0xff, (size_t)n_groups * 4, st));   // -1: group belongs to no protein
+        MDF_HIP(hipMemsetAsync(owner, 0xff, (size_t)n_groups * 2 * 4, st));   // per 16-row group; -1: belongs to no protein
         hipLaunchKernelGGL(k_cnn_group_owner, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, Lq, row_off, B, owner);
         // workgroups per tile: each keeps the table in LDS and walks 32-row groups, 16 at a time
         const int wgs = std::max(1, std::min((n_groups + 63) / 64, 256));
@@ -325,8 +331,8 @@ int mdf_cnn_forward_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, c
     if (workspace_bytes < mdf_cnn_workspace_bytes(m, B, R)) return fail(MDF_ECAPACITY, "cnn_forward_dev: workspace too small");
     Carver cv(workspace, workspace_bytes);
     float *pooled = cv.take<float>((size_t)B * m->Cpad);
-    int32_t *owner = cv.take<int32_t>((size_t)(R / 32 + 1));
-    if (int rc = mdf_cnn_pool_dev(m, seq_idx, Lq, row_off, B, R, pooled, owner, align_up((size_t)(R / 32 + 1) * 4, 256), stream)) return rc;
+    int32_t *owner = cv.take<int32_t>((size_t)(R / GROUP_ROWS + 2));
+    if (int rc = mdf_cnn_pool_dev(m, seq_idx, Lq, row_off, B, R, pooled, owner, align_up((size_t)(R / GROUP_ROWS + 2) * 4, 256), stream)) return rc;
     return mdf_cnn_head_dev(m, pooled, B, scores, stream);
 }
 

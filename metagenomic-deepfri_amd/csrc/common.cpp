@@ -105,7 +105,14 @@ using namespace mdf;
 extern "C" {
 
 const char *mdf_last_error(void) { return g_err; }
-const char *mdf_version(void) { return "mdfri-hip 0.1.0 (gfx950)"; }
+#ifndef MDF_GCN_SRC_HASH
+#define MDF_GCN_SRC_HASH "unstamped"
+#endif
+// "... gcn:<hash>": the first 16 hex digits of sha256(csrc/gcn.hip + csrc/common.h) at build time (csrc/Makefile) -- the identity of
+// the GraphConv kernels that measured per-launch figures (profiles/traffic.json) are tied to
+const char *mdf_version(void) { return "mdfri-hip 0.2.0 (gfx950) gcn:" MDF_GCN_SRC_HASH; }
+
+int mdf_group_rows(void) { return MDF_GROUP_ROWS; }
 
 int mdf_device_count(void)
 {

@@ -14,6 +14,11 @@
 
 namespace mdf {
 
+// Rows of a pooling group = alignment of every protein's first residue row (mdfri.h "Residue-row layout", MDF_GROUP_ROWS).  16: half a
+// 32 x 32 MFMA tile -- the GEMM epilogues write two partial sums per tile (C registers 0..7 hold tile rows 0..15, registers 8..15 rows
+// 16..31) --, so a mixed-length batch carries 7.5 padding rows per protein on average instead of 15.5.
+constexpr int GROUP_ROWS = MDF_GROUP_ROWS;
+
 // ---- thread-local error message -------------------------------------------------------------------------------
 void set_error(const char *fmt, ...);
 int fail(int code, const char *fmt, ...);

@@ -91,7 +91,7 @@ static void close_segment(mdf_plan *pl, const std::vector<int> &ids, int64_t gro
     for (int ci : ids) {
         const PlanChunk &ch = pl->chunks[ci];
         const int32_t *ro = pl->chunk_row_off.data() + ch.row_off_pos;
-        for (int32_t p = ch.p0; p < ch.p1; ++p) pl->grp_off[base + (size_t)(p - first.p0)] = (int32_t)(ch.group_base + ro[p - ch.p0] / 32);
+        for (int32_t p = ch.p0; p < ch.p1; ++p) pl->grp_off[base + (size_t)(p - first.p0)] = (int32_t)(ch.group_base + ro[p - ch.p0] / GROUP_ROWS);
     }
     pl->grp_off[base + (size_t)(last.p1 - first.p0)] = (int32_t)groups;
     pl->segments.push_back(sg);
@@ -102,7 +102,7 @@ extern "C" int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, i
     MDF_REQUIRE(Lq && out, "plan_create: NULL argument");
     MDF_REQUIRE(B > 0, "plan_create: empty batch");
     if (max_rows <= 0) max_rows = 65536;
-    if (max_segment_groups <= 0) max_segment_groups = 1 << 19;
+    if (max_segment_groups <= 0) max_segment_groups = 1 << 20;
     for (int32_t p = 0; p < B; ++p) MDF_REQUIRE(Lq[p] > 0, "plan_create: empty sequence in batch (protein %d)", p);
     auto *pl = new mdf_plan();
     pl->serial = g_plan_serial.fetch_add(1);
@@ -115,7 +115,7 @@ extern "C" int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, i
         int32_t p1 = p0, ml = 0;
         int64_t rows = 0;
         while (p1 < B) {
-            const int64_t pad = ((int64_t)Lq[p1] + 31) / 32 * 32;
+            const int64_t pad = ((int64_t)Lq[p1] + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
             if (p1 != p0 && rows + pad > max_rows) break;
             rows += pad;
             ml = std::max(ml, Lq[p1]);
@@ -138,12 +138,12 @@ extern "C" int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, i
         pl->max_len = std::max(pl->max_len, ml);
         p0 = p1;
     }
-    // pooling segments: protein p's 32-row groups are [grp_off[p], grp_off[p+1]) inside its segment's partial array
+    // pooling segments: protein p's groups (GROUP_ROWS rows each) are [grp_off[p], grp_off[p+1]) inside its segment's partial array
     std::vector<int> cur;
     int64_t seg_groups = 0;
     for (int ci = 0; ci < (int)pl->chunks.size(); ++ci) {
         PlanChunk &ch = pl->chunks[ci];
-        const int64_t g = ch.rows / 32;
+        const int64_t g = ch.rows / GROUP_ROWS;
         if (!cur.empty() && seg_groups + g > max_segment_groups) {
             close_segment(pl, cur, seg_groups);
             pl->max_groups = std::max(pl->max_groups, seg_groups);
@@ -416,7 +416,7 @@ extern "C" int mdf_engine_create(mdf_model *const *models, int32_t n_models, int
     if (c.max_rows <= 0) c.max_rows = 65536;
     if (c.nnz_per_row <= 0) c.nnz_per_row = 40;
     if (!cfg) c.threshold = 6.0, c.generated_contacts = 2;
-    if (c.max_segment_groups <= 0) c.max_segment_groups = 1 << 19;
+    if (c.max_segment_groups <= 0) c.max_segment_groups = 1 << 20;
     if (c.lm_batch <= 0) c.lm_batch = 8192;
     if (c.lm_workspace_gib <= 0) c.lm_workspace_gib = 48.0;
     if (c.graph_max_chunks == 0) c.graph_max_chunks = 8;
@@ -1086,7 +1086,7 @@ extern "C" int mdf_seq_engine_forward(mdf_seq_engine *e, const mdf_plan *pl, con
     if (int rc = plan_mirror(pl, e->device, st)) return rc;
     const int64_t rows = pl->max_chunk_rows;
     if (int rc = e->seq_idx.grow((size_t)rows, nullptr)) return rc;
-    if (int rc = e->ws.grow((size_t)(rows / 32 + 1) * 4 + 512, nullptr)) return rc;
+    if (int rc = e->ws.grow((size_t)(rows / GROUP_ROWS + 2) * 4 + 512, nullptr)) return rc;
     std::vector<int> cpad(e->models.size());
     for (size_t k = 0; k < e->models.size(); ++k) {
         cpad[k] = mdf_cnn_padded_channels(e->models[k]);

@@ -6,7 +6,7 @@
 //                                                            S (k_letter_sums, shared by all GO heads):
 //                                                            H1 = elu(S . T1), a K = 32 launch of the MFMA GEMM
 //   layer k   H_k = elu( (Ahat . H_{k-1}) . W_k )          -- k_aggregate (A.X, HBM/L2-bound) then k_gemm_f32 (fp32 MFMA)
-//   pooling   g   = sum_rows concat(H1,H2,H3)              -- per-32-row partial sums written by the producing GEMM
+//   pooling   g   = sum_rows concat(H1,H2,H3)              -- per-16-row partial sums written by the producing GEMM
 //                                                            epilogue (deterministic, no atomics; H3 never reaches
 //                                                            HBM), folded per protein by k_pool_reduce
 //   head      y   = softmax2( relu(g W_fc + b_fc) W_out + b_out )[:,0]   -- the same GEMM kernel, other epilogues
@@ -31,7 +31,7 @@ struct mdf_model {
     int device = 0;
     int embed = 0, n_gc = 0, gc[3] = {0, 0, 0}, fc = 0, T = 0, feat = 0;
     int n_out_pad = 0;            // 2T rounded up to the GEMM's BN
-    float *T1t = nullptr;         // (gc0, 32)      (relu(W_aa) @ W_gc1)^T, letters padded 26 -> 32; computed in double on the host
+    float *T1 = nullptr;          // (32, gc0)      relu(W_aa) @ W_gc1, letters padded 26 -> 32 (zero rows); computed in double on the host
     float *Wt[3] = {nullptr, nullptr, nullptr};  // k>=1: (gc_k, gc_{k-1}) = W_gc{k+1}^T  ([N][K], K contiguous)
     float *Wfc_t = nullptr;       // (fc, feat)
     float *bfc = nullptr;         // (fc)
@@ -76,8 +76,6 @@ struct GemmAux {
     const uint8_t *letters = nullptr;  // (M) residue indices 0..25 (anything larger reads the zero rows 26..31)
     float floor = 0.0f;                // EPI_EMBED: X0 = max(acc + table, floor): 0 = relu, -FLT_MAX = no activation
     float *cstate = nullptr;           // EPI_LSTM_*: (M, N/4) cell state, updated in place
-    int a_stream = 0;                  // host side only (launch_gemm): the A operand is read with the non-temporal policy
-    int c_nt = 0;                      // EPI_ELU_POOL_STORE / EPI_L1_STORE: the output rows are stored with the non-temporal policy
 };
 
 // sigmoid / tanh on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error < 3e-7.
@@ -224,19 +222,20 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n
                 // M is a multiple of 32 here (residue rows) but not of the 256-row tile: 32-row blocks past M are
                 // neither stored nor pooled (wave-uniform test)
                 if (rbase >= M) continue;
-                float s = 0.0f;
+                // two pooling groups per MFMA tile (GROUP_ROWS = 16): registers 0..7 hold tile rows 0..15 (this lane half's rows
+                // 0-3 / 8-11, the other half's 4-7 / 12-15), registers 8..15 rows 16..31 -- a protein may start in the middle of a tile
+                float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
                     const float v = elu1(acc[tm][tn][r]);
-                    s += v;
-                    if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_L1_STORE) {
-                        if (aux.c_nt) __builtin_nontemporal_store(v, &C[(size_t)row * ldc + col]);
-                        else C[(size_t)row * ldc + col] = v;
-                    }
+                    if (r < 8) s0 += v; else s1 += v;
+                    if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_L1_STORE) C[(size_t)row * ldc + col] = v;
                 }
-                s += __shfl_xor(s, 32, 64);
-                if (lane < 32) pool_partial[(size_t)(rbase >> 5) * ldp + col] = s;
+                // lanes 0..31 finish and write the first group of the tile, lanes 32..63 the second: ONE exchange -- every lane sends the
+                // half-sum its partner needs (own + partner's, the order a two-way xor-add would use)
+                const float mine = lane < 32 ? s0 : s1, send = lane < 32 ? s1 : s0;
+                pool_partial[(size_t)((rbase >> 4) + (lane >> 5)) * ldp + col] = mine + __shfl_xor(send, 32, 64);
             } else if (EPI == EPI_BIAS_RELU) {
                 const float bv = bias[col];
 #pragma unroll
@@ -322,22 +321,13 @@ __device__ __forceinline__ void glds16(const float *gsrc, unsigned lds_byte_addr
 }
 // The same with the address split into a wave-uniform 64-bit base (SGPR pair) and a per-lane 32-bit byte offset: the eight
 // source addresses a wave keeps per pipeline position cost 8 VGPRs instead of 16.
-// NT: the load carries the non-temporal policy (streamed once, not to be kept: the A operand of a launch whose OUTPUT the next
-// kernel gathers from the Infinity Cache -- see launch_gemm, `a_stream`).
-template <bool NT = false>
 __device__ __forceinline__ void glds16s(const float *sbase, unsigned voff_bytes, unsigned lds_byte_addr)
 {
     unsigned keep;
-    if (NT)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr)
-                     : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr)
-                     : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff_bytes), "s"(sbase), "s"(lds_byte_addr)
+                 : "memory");
 }
 __device__ __forceinline__ unsigned lds_addr_of(const float *p)
 {
@@ -346,7 +336,7 @@ __device__ __forceinline__ unsigned lds_addr_of(const float *p)
 
 // ABL != 0: timing ablations for tools/gemm_probe.hip only (results are wrong by construction): 1 = no DMA,
 // 2 = + no LDS fragment reads, 3 = + no barrier
-template <int EPI, int ABL = 0, bool ANT = false>
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__restrict__ A, int lda, const float *__restrict__ Bt,
                                                               int ldb, int M, int N, int K, float *__restrict__ C, int ldc,
                                                               const float *__restrict__ bias, float *__restrict__ pool_partial,
@@ -417,8 +407,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
     }
 #define MDF_DMA_PIECE(i, ldsA_, ldsB_)                                       \
     if (ABL == 0) {                                                            \
-        glds16s<ANT>(baseA, oa##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024)); \
-        glds16s<false>(baseB, ob##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024)); \
+        glds16s(baseA, oa##i, (ldsA_) + (unsigned)((wid * 4 + (i)) * 1024));   \
+        glds16s(baseB, ob##i, (ldsB_) + (unsigned)((wid * 4 + (i)) * 1024));   \
     }
 #define MDF_SB __builtin_amdgcn_sched_barrier(0);
 #ifdef MDF_PROBE_VALU_PAD   // experiments/gemm_probe.hip only: N independent packed fp32 FMAs behind every MFMA (how much VALU issue is free?)
@@ -636,16 +626,16 @@ __global__ __launch_bounds__(256) void k_gemm_f32_small(const float *__restrict_
             if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[r] + aux.table[lt[r] + col], aux.floor);
         }
     } else if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_L1_STORE || EPI == EPI_L1) {
-        float sum = 0.0f;
+        float s0 = 0.0f, s1 = 0.0f;   // the two 16-row pooling groups of the tile, as in gemm_epilogue (bit-identical)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
             const float v = elu1(acc[r]);
-            sum += v;
+            if (r < 8) s0 += v; else s1 += v;
             if (EPI == EPI_ELU_POOL_STORE || EPI == EPI_L1_STORE) C[(size_t)row * ldc + col] = v;
         }
-        sum += __shfl_xor(sum, 32, 64);
-        if (lane < 32) pool_partial[(size_t)(rbase >> 5) * ldp + col] = sum;
+        const float mine = lane < 32 ? s0 : s1, send = lane < 32 ? s1 : s0;
+        pool_partial[(size_t)((rbase >> 4) + (lane >> 5)) * ldp + col] = mine + __shfl_xor(send, 32, 64);
     } else if (EPI == EPI_BIAS_RELU) {
         const float bv = bias[col];
 #pragma unroll
@@ -739,13 +729,10 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, 
     // its blocks gather are, for the most part, fetched into that XCD's L2 once.
     const int b = blockIdx.x, x = b & 7, q = b >> 3;
     const int per_sb = 1 << (sb_log - 2);                  // blocks (4 rows each) per super-block
-    int sb = (q / per_sb) * 8 + x;
-    if (nt_store & 4) sb = ((int)(gridDim.x / (8 * per_sb)) - 1 - q / per_sb) * 8 + x;   // developer probe: last-written rows first, same XCD
+    const int sb = (q / per_sb) * 8 + x;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row = (sb << sb_log) + (q % per_sb) * 4 + wid;
     if (row >= R) return;
-    const int sc_var = (nt_store >> 3) & 3;
-    nt_store &= 3;
     const int lane = threadIdx.x & 63;
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
     float4 acc[NV];
@@ -788,22 +775,7 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, 
             acc[v].w = fmaf(w, h.w, acc[v].w);
         }
     }
-    if (nt_store == 3) {   // developer probe (MDFRI_AX_NT=3, variant in MDFRI_AX_SC): write-through / L2-dropping store forms
-        typedef float v4f __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int v = 0; v < NV; ++v) {
-            const v4f t = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
-            float *p = out + (size_t)row * C + v * 256 + lane * 4;
-            if (sc_var == 0) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
-            else if (sc_var == 1) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(t) : "memory");
-            else if (sc_var == 2) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(t) : "memory");
-            else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(t) : "memory");
-        }
-    } else if (nt_store == 2) {   // developer probe (MDFRI_AX_NT=2): the gather alone -- nothing is stored unless a sum is NaN (results are wrong by construction)
-#pragma unroll
-        for (int v = 0; v < NV; ++v)
-            if (acc[v].x != acc[v].x) *reinterpret_cast<float4 *>(out + (size_t)row * C + v * 256 + lane * 4) = acc[v];
-    } else if (nt_store) {  // the aggregated rows are not re-read by this kernel: keep them out of the way of the gathered rows
+    if (nt_store) {  // the aggregated rows are not re-read by this kernel: keep them out of the way of the gathered rows
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             typedef float v4f __attribute__((ext_vector_type(4)));
@@ -813,6 +785,61 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, 
     } else {
 #pragma unroll
         for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(out + (size_t)row * C + v * 256 + lane * 4) = acc[v];
+    }
+}
+
+// ---- layer 1 (folded embedding): H1[i, :] = elu(S[i, :26] . T1), S = Ahat . onehot, T1 = relu(W_aa) . W_gc1 (26 x C).  A contraction
+// over 26 letters whose OUTPUT is 2 KiB per row: as a K = 32 launch of the MFMA GEMM it spent its time in that kernel's epilogue (one
+// 4-byte store per lane and element, 256 B per wave instruction: 3.3 TB/s, 40 us per 65 536 rows).  Here a wave owns `gpw` consecutive
+// pooling groups (GROUP_ROWS rows each) x one 256-column slab: its 26 x 4 slice of T1 stays in registers, the letter sums of the
+// workgroup's rows are staged in LDS once (one coalesced load) and read back as broadcasts -- a row's 26 factors as scalar loads were a
+// dependent ~0.5 us round trip per row --, every row leaves as one 1 KiB wave store and the group's pool partial is a running sum in
+// registers.  fp32 FMA chain in ascending letter order, the same for a protein alone and inside a batch.
+template <bool STORE>
+__global__ __launch_bounds__(256) void k_layer1(const float *__restrict__ S, const float *__restrict__ T1, int C, int R,
+                                                float *__restrict__ H, float *__restrict__ pool_partial, int ldp, int gpw)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_rows[];   // [sets * gpw * GROUP_ROWS][32]
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wi = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int slabs = C >> 8;                       // 256-column slabs of a row: 1, 2 or 4
+    const int sets = 4 / slabs;                     // group sets of the workgroup (4 waves = sets x slabs)
+    const int set = wi / slabs, cs = wi - set * slabs;
+    const int n_groups = R / GROUP_ROWS;
+    const int g_blk = blockIdx.x * sets * gpw;      // first group of the workgroup
+    const int rows_blk = min(sets * gpw, n_groups - g_blk) * GROUP_ROWS;
+    {   // stage the letter sums of the workgroup's rows: contiguous in S
+        const v4f *src = reinterpret_cast<const v4f *>(S + (size_t)g_blk * GROUP_ROWS * 32);
+        v4f *dst = reinterpret_cast<v4f *>(s_rows);
+        for (int i = threadIdx.x; i < rows_blk * 8; i += 256) dst[i] = src[i];
+    }
+    const int col = cs * 256 + lane * 4;
+    v4f t[26];                                      // this lane's 26 x 4 slice of T1: loaded once, used for gpw x GROUP_ROWS rows
+#pragma unroll
+    for (int a = 0; a < 26; ++a) t[a] = *reinterpret_cast<const v4f *>(T1 + (size_t)a * C + col);
+    __syncthreads();
+    for (int k = 0; k < gpw; ++k) {
+        const int g = g_blk + set * gpw + k;
+        if (g >= n_groups) break;
+        const float *sg = s_rows + (size_t)(set * gpw + k) * GROUP_ROWS * 32;
+        v4f pool = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int r = 0; r < GROUP_ROWS; ++r) {
+            const int row = g * GROUP_ROWS + r;
+            v4f s4[7];                              // the row's 26 (+2) letter sums: LDS broadcasts
+#pragma unroll
+            for (int q = 0; q < 7; ++q) s4[q] = *reinterpret_cast<const v4f *>(sg + r * 32 + q * 4);
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 26; ++a) {
+                const float sa = s4[a >> 2][a & 3];
+                acc = __builtin_elementwise_fma((v4f){sa, sa, sa, sa}, t[a], acc);
+            }
+            const v4f v = {elu1(acc.x), elu1(acc.y), elu1(acc.z), elu1(acc.w)};
+            pool += v;
+            if (STORE) *reinterpret_cast<v4f *>(H + (size_t)row * C + col) = v;
+        }
+        *reinterpret_cast<v4f *>(pool_partial + (size_t)g * ldp + col) = pool;
     }
 }
 
@@ -846,17 +873,33 @@ __global__ __launch_bounds__(256) void k_letter_sums(const uint8_t *__restrict__
     if (lane < 32) S[(size_t)row * 32 + lane] = (lane < 26) ? c : 0.0f;
 }
 
-// pooled[p, c] = sum over the 32-row groups [grp_off[p], grp_off[p+1]) of partial[g, c]   (c over all GraphConv layers);
+// pooled[p, c] = sum over the groups (GROUP_ROWS rows each) [grp_off[p], grp_off[p+1]) of partial[g, c]   (c over all GraphConv layers);
 // fixed summation order -> deterministic.
-__global__ void k_pool_reduce(const float *__restrict__ partial, const int32_t *__restrict__ grp_off, float *__restrict__ pooled, int feat)
+__global__ __launch_bounds__(128) void k_pool_reduce(const float *__restrict__ partial, const int32_t *__restrict__ grp_off, float *__restrict__ pooled, int feat)
 {
+    // a lane owns 4 consecutive features (feat is a multiple of 256): 16-byte loads, eight groups in flight; the sum over a protein's
+    // groups runs in ascending group order per feature, whatever the unrolling (a left fold)
+    typedef float v4f __attribute__((ext_vector_type(4)));
     const int p = blockIdx.x;
     const int g0 = grp_off[p], g1 = grp_off[p + 1];
-    for (int c = blockIdx.y * blockDim.x + threadIdx.x; c < feat; c += gridDim.y * blockDim.x) {
-        float s = 0.0f;
-        for (int g = g0; g < g1; ++g) s += partial[(size_t)g * feat + c];
-        pooled[(size_t)p * feat + c] = s;
+    const int c = (blockIdx.y * blockDim.x + threadIdx.x) * 4;
+    if (c >= feat) return;
+    const float *src = partial + (size_t)g0 * feat + c;
+    v4f s = {0.f, 0.f, 0.f, 0.f};
+    int g = g0;
+    for (; g + 8 <= g1; g += 8) {
+        v4f v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const v4f *>(src + (size_t)u * feat);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+        src += (size_t)8 * feat;
     }
+    for (; g < g1; ++g) {
+        s += *reinterpret_cast<const v4f *>(src);
+        src += feat;
+    }
+    *reinterpret_cast<v4f *>(pooled + (size_t)p * feat + c) = s;
 }
 
 // ---- LSTM language model: layout helpers -------------------------------------------------------------------------------
@@ -1074,13 +1117,9 @@ static int set_gemm_attr_once()
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_ELU_POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_BIAS_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_BIAS_SOFTMAX2>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_L1_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_L1>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_LSTM_TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_LSTM_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_ELU_POOL_STORE, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_ELU_POOL, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return MDF_OK;
 }
@@ -1138,14 +1177,6 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     }
     const int total = plain ? MT * NT : 8 * NT * ((MT + 7) / 8);  // tile slots (in XCD-aware order some lie past M)
     const int blocks = std::min(total, gemm_resident_blocks());
-    if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL) {
-        if (aux.a_stream) {
-            hipLaunchKernelGGL((k_gemm_f32<EPI, 0, true>), dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
-                               pool_partial, ldp, logits, n_real, total, aux);
-            MDF_HIP(hipGetLastError());
-            return MDF_OK;
-        }
-    }
     hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3(blocks), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias,
                        pool_partial, ldp, logits, n_real, total, aux);
     MDF_HIP(hipGetLastError());
@@ -1189,12 +1220,7 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
     // slabs no longer fit the 256 MiB Infinity Cache together (measured: +12 % at 65536 rows, -2 % at 32768)
     static const int sb_log = getenv("MDFRI_AX_SB_LOG") ? atoi(getenv("MDFRI_AX_SB_LOG")) : 9;
     static const int nt_env = getenv("MDFRI_AX_NT") ? atoi(getenv("MDFRI_AX_NT")) : -1;
-    static const int rev_env = getenv("MDFRI_AX_REV") ? atoi(getenv("MDFRI_AX_REV")) : 0;   // developer probe: bit 0 = layer 2, bit 1 = layer 3 walk the rows downwards
-    const int rev = (tk == TK_AX3 ? (rev_env >> 1) & 1 : rev_env & 1) ? 4 : 0;
-    static const int sc_env = getenv("MDFRI_AX_SC") ? atoi(getenv("MDFRI_AX_SC")) : 0;      // developer probe: store form of MDFRI_AX_NT=3
-    static const int nt3_env = getenv("MDFRI_AX_NT3") ? atoi(getenv("MDFRI_AX_NT3")) : -1;  // developer probe: MDFRI_AX_NT for layer 3 only
-    const int nt_pick = (tk == TK_AX3 && nt3_env >= 0) ? nt3_env : nt_env;
-    const int nt_store = (nt_pick >= 0 ? nt_pick : ((size_t)Ri * Cin * 8 > (size_t)200 << 20)) | rev | ((sc_env & 3) << 3);
+    const int nt_store = nt_env >= 0 ? nt_env : ((size_t)Ri * Cin * 8 > (size_t)200 << 20);
     const int n_sb = (Ri + (1 << sb_log) - 1) >> sb_log;
     const int blocks = 8 * (1 << (sb_log - 2)) * ((n_sb + 7) / 8);
 #define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, Ri, sb_log, nt_store)
@@ -1210,24 +1236,21 @@ static int gcn_upper_layers(mdf_model *m, float *Hin, float *Hout, float *AH, co
 {
     const int feat = m->feat;
     int off = m->gc[0];
-    static const int buf_env = getenv("MDFRI_GCN_BUF") ? atoi(getenv("MDFRI_GCN_BUF")) : 0;   // developer probe: bit 1 = layer 3 aggregates into the dead H1 slab
     for (int k = 1; k < m->n_gc; ++k) {
         const int Cin = m->gc[k - 1], Cout = m->gc[k];
-        if (k >= 2 && (buf_env & 2)) AH = Hout;   // Hout holds H_{k-2} by now: dead
+        // from layer 3 on the aggregate goes into the slab that holds H_{k-2} (dead by now, and the last one the previous A.X launch
+        // touched) instead of the AH slab: measured -2 % on both A.X launches of a head (profiles/r04_cache_policy_probes.txt, "mid_dead")
+        // (only for a launch whose GEMM stores nothing -- the last layer --, or the GEMM would write the slab it reads)
+        if (k >= 2 && k == m->n_gc - 1) AH = Hout;
         if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st, k >= 2 ? TK_AX3 : TK_AX)) return rc;
         {
             ScopedTiming tm(k >= 2 ? TK_GEMM3 : TK_GEMM, st);
             const bool last = k == m->n_gc - 1;
-            static const int a_nt = getenv("MDFRI_GEMM_A_NT") ? atoi(getenv("MDFRI_GEMM_A_NT")) : 0;   // developer knob: bit 0 = storing launches, bit 1 = the last layer
-            static const int c_nt = getenv("MDFRI_GEMM_C_NT") ? atoi(getenv("MDFRI_GEMM_C_NT")) : 0;   // developer knob: bit 0 = layer-1 output, bit 1 = layer-2 output
-            GemmAux ga;
-            ga.a_stream = last ? (a_nt >> 1) & 1 : a_nt & 1;
-            ga.c_nt = (c_nt >> 1) & 1;
             int rc;
             if (last)
-                rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st, ga);
+                rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
             else
-                rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st, ga);
+                rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
             if (rc) return rc;
         }
         off += Cout;
@@ -1331,10 +1354,10 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
                 double *ar = acc.data() + (size_t)a * C0;
                 for (int c = 0; c < C0; ++c) ar[c] += x * (double)wr[c];
             }
-        std::vector<float> t1t((size_t)C0 * 32, 0.0f);
+        std::vector<float> t1((size_t)32 * C0, 0.0f);
         for (int a = 0; a < 26; ++a)
-            for (int c = 0; c < C0; ++c) t1t[(size_t)c * 32 + a] = (float)acc[(size_t)a * C0 + c];
-        rc = upload(&m->T1t, t1t.data(), t1t.size());
+            for (int c = 0; c < C0; ++c) t1[(size_t)a * C0 + c] = (float)acc[(size_t)a * C0 + c];
+        rc = upload(&m->T1, t1.data(), t1.size());
     }
     for (int k = 1; k < w->n_gc && rc == MDF_OK; ++k) {
         auto t = transpose(w->W_gc[k], w->gc_dims[k - 1], w->gc_dims[k], w->gc_dims[k]);
@@ -1382,7 +1405,7 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
 void mdf_model_free(mdf_model *m)
 {
     if (!m) return;
-    (void)hipFree(m->T1t);
+    (void)hipFree(m->T1);
     for (int k = 0; k < 3; ++k) (void)hipFree(m->Wt[k]);
     (void)hipFree(m->Wfc_t);
     (void)hipFree(m->bfc);
@@ -1619,7 +1642,8 @@ int mdf_gcn_embed_lm_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h
     Carver cv(workspace, workspace_bytes);
     int cmax = 0;
     for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
-    float *Ha = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax);
+    // slab order H1 | AH | H2 (layer 3 aggregates into the H1 slab, see gcn_upper_layers)
+    float *Ha = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax);
     float *X0 = cv.take<float>((size_t)R * m->embed), *AX = cv.take<float>((size_t)R * m->embed);
     const int Ri = (int)R, E = m->embed, C0 = m->gc[0], feat = m->feat;
     {
@@ -1772,27 +1796,26 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
     Carver cv(workspace, workspace_bytes);
     int cmax = 0;
     for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
-    float *Ha = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax);
-    {
-        static const int buf_env = getenv("MDFRI_GCN_BUF") ? atoi(getenv("MDFRI_GCN_BUF")) : 0;   // developer probe: bit 0 = H1 / H2 swap slabs, bit 2 = AH in the middle
-        if (buf_env & 1) std::swap(Ha, Hb);
-        if (buf_env & 4) std::swap(Hb, AH);
-    }
+    // slab order H1 | AH | H2 (layer 3 aggregates into the H1 slab, see gcn_upper_layers)
+    float *Ha = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax);
     const int Ri = (int)R, feat = m->feat;
     MDF_REQUIRE(m->lm_dim == 0, "gcn_embed_dev: this model has a language-model branch; use mdf_gcn_embed_lm_dev");
     // layer 1 (folded embedding): H1 = elu(S . T1) on the MFMA GEMM (K = 32), S = Ahat . onehot from mdf_letter_sums_dev
     {
         ScopedTiming tm(TK_GEMM1, st);
         const int C0 = m->gc[0];
-        static const int c_nt = getenv("MDFRI_GEMM_C_NT") ? atoi(getenv("MDFRI_GEMM_C_NT")) : 0;
-        GemmAux ga;
-        ga.c_nt = c_nt & 1;
-        int rc;
+        // groups per wave: the wave's slice of T1 (26 KiB per 256-column slab) is fetched once per wave -- with one group per wave a launch
+        // reads more table bytes from L2 than it writes output rows
+        static const int gpw_env = getenv("MDFRI_L1_GPW") ? atoi(getenv("MDFRI_L1_GPW")) : 0;   // developer knob
+        const int n_groups = Ri / GROUP_ROWS, slabs = C0 / 256, sets = 4 / slabs;
+        const int gpw = std::min(8, gpw_env > 0 ? gpw_env : (n_groups >= 2048 ? 2 : 1));
+        const int blocks = (n_groups + sets * gpw - 1) / (sets * gpw);
+        const size_t lds = (size_t)sets * gpw * GROUP_ROWS * 32 * 4;
         if (m->n_gc == 1)
-            rc = launch_gemm<EPI_L1>(letter_sums, 32, m->T1t, 32, Ri, C0, 32, nullptr, C0, nullptr, partial, feat, nullptr, C0, st);
+            hipLaunchKernelGGL(k_layer1<false>, dim3((unsigned)blocks), dim3(256), lds, st, letter_sums, m->T1, C0, Ri, (float *)nullptr, partial, feat, gpw);
         else
-            rc = launch_gemm<EPI_L1_STORE>(letter_sums, 32, m->T1t, 32, Ri, C0, 32, Ha, C0, nullptr, partial, feat, nullptr, C0, st, ga);
-        if (rc) return rc;
+            hipLaunchKernelGGL(k_layer1<true>, dim3((unsigned)blocks), dim3(256), lds, st, letter_sums, m->T1, C0, Ri, Ha, partial, feat, gpw);
+        MDF_HIP(hipGetLastError());
     }
     if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st)) return rc;
     MDF_HIP(hipGetLastError());
@@ -1802,7 +1825,7 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
 int mdf_gcn_pool_dev(mdf_model *m, const float *partial, const int32_t *grp_off, int32_t B, float *pooled, void *stream)
 {
     MDF_REQUIRE(m && partial && grp_off && pooled && B > 0, "gcn_pool_dev: bad argument");
-    hipLaunchKernelGGL(k_pool_reduce, dim3(B, 2), dim3(256), 0, static_cast<hipStream_t>(stream), partial, grp_off, pooled, m->feat);
+    hipLaunchKernelGGL(k_pool_reduce, dim3(B, (unsigned)((m->feat / 4 + 127) / 128)), dim3(128), 0, static_cast<hipStream_t>(stream), partial, grp_off, pooled, m->feat);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -1846,7 +1869,7 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     const size_t o_desc = take(256), o_seq = take((size_t)L), o_idx = take((size_t)R), o_cm = take((size_t)L * L * es),
                  o_rp = take((size_t)(R + 1) * 4), o_ci = take((size_t)nnz_cap * 4), o_va = take((size_t)nnz_cap * 4),
                  o_cws = take(cws), o_gws = take(gws), o_hws = take(hws), o_pool = take((size_t)m->feat * 4),
-                 o_sc = take((size_t)m->T * 4), o_S = take((size_t)R * 32 * 4), o_part = take((size_t)(R / 32) * m->feat * 4),
+                 o_sc = take((size_t)m->T * 4), o_S = take((size_t)R * 32 * 4), o_part = take((size_t)(R / GROUP_ROWS) * m->feat * 4),
                  o_lws = take(lws), o_lmh = take(m->lm_dim ? (size_t)R * m->lm_dim * 4 : 0);
     if (m->host_ws_bytes < o) {
         (void)hipFree(m->host_ws);
@@ -1865,7 +1888,7 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     d.Lq[0] = (int32_t)L;
     d.row_off[0] = row_off[0];
     d.row_off[1] = row_off[1];
-    d.grp_off[1] = (int32_t)(R / 32);
+    d.grp_off[1] = (int32_t)(R / GROUP_ROWS);
     // descriptors + sequence: one upload from pinned staging (o_desc = 0 and o_seq follow each other); the map goes up from the
     // caller's array as it is
     HostStage &hs = host_stage();

@@ -46,7 +46,7 @@ class Chunk:
     rows: int              # R of this chunk (multiple of 128)
     row_off_pos: int       # start of this chunk's row_off (p1-p0+1 entries) in PackedProteins.chunk_row_off
     segment: int = 0       # pooling segment this chunk belongs to
-    group_base: int = 0    # first 32-row group of this chunk inside its segment's partial-sum array
+    group_base: int = 0    # first pooling group (MDF_GROUP_ROWS = 16 rows) of this chunk inside its segment's partial-sum array
 
 
 @dataclass
@@ -54,7 +54,7 @@ class Segment:
     """Consecutive chunks whose per-group partial sums share one array and are pooled by one launch per GO head."""
     p0: int
     p1: int
-    groups: int            # 32-row groups in the segment
+    groups: int            # pooling groups (16 rows each) in the segment
     grp_off_pos: int       # start of the segment's grp_off (p1-p0+1 entries) in PackedProteins.grp_off
 
 
@@ -80,7 +80,7 @@ class PackedProteins:
         return len(self.seqs)
 
     @classmethod
-    def pack(cls, seqs, coords=None, q_alns=None, t_alns=None, max_rows: int = 32768, max_segment_groups: int = 1 << 19):
+    def pack(cls, seqs, coords=None, q_alns=None, t_alns=None, max_rows: int = 32768, max_segment_groups: int = 1 << 20):
         """Host-side packing, vectorised: one join + one encode per column (a non-ASCII letter fails there, as `str.encode("ascii")`
         per sequence did), lengths by `map(len, ...)`, the "gapped query spells its sequence" check by one reduceat over the packed
         bytes -- no per-protein Python work besides `len` (the producer thread of mDeepFRI.stream packs batches while the GPU
@@ -121,7 +121,7 @@ class PackedProteins:
         return pk
 
     @classmethod
-    def from_alignments(cls, alignments, max_rows: int = 32768, max_segment_groups: int = 1 << 19):
+    def from_alignments(cls, alignments, max_rows: int = 32768, max_segment_groups: int = 1 << 20):
         """Pack objects carrying the AlignmentResult attributes the reference's path reads (query_sequence, coords,
         gapped_sequence, gapped_target; reference alignment.py:106-150).  Entries without coordinates are skipped, as
         pipeline.py:485 filters them; returns (packed, kept_indices)."""
@@ -132,7 +132,7 @@ class PackedProteins:
         return pk, keep
 
     @classmethod
-    def from_aligned_batch(cls, batch, coords, max_rows: int = 32768, max_segment_groups: int = 1 << 19):
+    def from_aligned_batch(cls, batch, coords, max_rows: int = 32768, max_segment_groups: int = 1 << 20):
         """Pack the struct-of-arrays output of mDeepFRI.alignment.align_queries_arrays (the GPU aligner) together with the
         targets' C-alpha coordinates -- no AlignmentResult objects, no per-protein string handling: the gapped strings are
         taken as the flat byte arrays the aligner produced.  coords: one float32 (Lt, 3) array per query (its best target's
@@ -173,7 +173,7 @@ class PackedProteins:
         pk._plan(max_rows, max_segment_groups)
         return pk, keep
 
-    def _plan(self, max_rows: int, max_segment_groups: int = 1 << 19):
+    def _plan(self, max_rows: int, max_segment_groups: int = 1 << 20):
         """Chunks and pooling segments from the library's planner (mdf_plan_create, csrc/engine.hip): the Python objects below
         are a read-only view of its tables; the handle itself is what the engine entry points take."""
         import weakref

@@ -8,9 +8,12 @@ from __future__ import annotations
 import numpy as np
 
 
+GROUP_ROWS = 16    # = MDF_GROUP_ROWS of include/mdfri.h (mdf_group_rows()): a protein's residue rows are padded to a multiple of it
+
+
 def protein_cost(length: int) -> int:
     """Work of one protein ~ its padded residue rows (the H.W GEMMs dominate and are linear in rows)."""
-    return (int(length) + 31) // 32 * 32
+    return (int(length) + GROUP_ROWS - 1) // GROUP_ROWS * GROUP_ROWS
 
 
 def partition_by_cost(lengths, world_size: int):
@@ -22,7 +25,7 @@ def partition_by_cost(lengths, world_size: int):
     lengths = np.asarray(lengths, dtype=np.int64)
     n = len(lengths)
     order = np.lexsort((np.arange(n), -lengths))
-    cost = ((lengths + 31) // 32 * 32)[order].tolist()
+    cost = ((lengths + GROUP_ROWS - 1) // GROUP_ROWS * GROUP_ROWS)[order].tolist()
     heap = [(0, r) for r in range(world_size)]          # (load, rank): the heap order IS the tie rule
     owner = np.empty(n, dtype=np.int64)
     own = owner.tolist()
@@ -42,7 +45,7 @@ def plan_summary(lengths, world_size: int, max_rows: int = 65536):
     """What `bench.py --dry-plan` prints and tests/test_sharding_cpu.py asserts on: per rank the proteins, padded residue rows
     (the cost model) and chunks of `max_rows`, plus the predicted imbalance max/mean - 1 of the padded rows.  CPU only."""
     lengths = np.asarray(lengths, dtype=np.int64)
-    pad = (lengths + 31) // 32 * 32
+    pad = (lengths + GROUP_ROWS - 1) // GROUP_ROWS * GROUP_ROWS
     shards = partition_by_cost(lengths, world_size)
     rows = [int(pad[s].sum()) for s in shards]
     mean = sum(rows) / max(world_size, 1)

@@ -185,7 +185,7 @@ class QueryStream:
         from .alignment import align_queries_begin
         query_ids, query_sequences, target_sequences = list(query_ids), list(query_sequences), list(target_sequences)
         if self.batch_chunks > 0 and query_ids:      # slices of ~batch_chunks full chunks: greedy over the padded rows, as the planner fills chunks
-            rows = (np.fromiter(map(len, query_sequences), dtype=np.int64, count=len(query_sequences)) + 31) // 32 * 32
+            rows = (np.fromiter(map(len, query_sequences), dtype=np.int64, count=len(query_sequences)) + 15) // 16 * 16   # padded residue rows (MDF_GROUP_ROWS)
             starts, chunk_rows, chunks = [0], 0, 1
             for i, r in enumerate(rows.tolist()):
                 if chunk_rows and chunk_rows + r > self.max_rows:

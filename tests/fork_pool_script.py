@@ -13,8 +13,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "metagenomic-deepfri_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)   # mdfri_testkit
 
-from mDeepFRI import synthetic  # noqa: E402
+from mdfri_testkit import synthetic
 from mDeepFRI.alignment import AlignmentResult  # noqa: E402
 from mDeepFRI.bio_utils import build_align_contact_map  # noqa: E402
 

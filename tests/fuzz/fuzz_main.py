@@ -2,9 +2,10 @@
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "metagenomic-deepfri_amd"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "oracle"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))   # mdfri_testkit
 import numpy as np
 import cmap_oracle, gcn_oracle
-from mDeepFRI import synthetic
+from mdfri_testkit import synthetic
 from mDeepFRI.batch import HotPathEngine, PackedProteins
 from mDeepFRI.predict import Predictor
 SEED = int(os.environ.get("FUZZ_SEED", 7))

@@ -1,9 +1,9 @@
 """Developer fuzz (run by hand from the repository root: python tests/fuzz/<name>.py; a seeded slice of it is in tests/test_gpu_gcn.py): random CNN topologies and random LM-model shapes / batch splits against the oracles."""
 import os, sys
-sys.path.insert(0, "metagenomic-deepfri_amd"); sys.path.insert(0, "oracle")
+sys.path.insert(0, "metagenomic-deepfri_amd"); sys.path.insert(0, "oracle"); sys.path.insert(0, ".")
 import numpy as np
 import cnn_oracle, lm_oracle, gcn_oracle
-from mDeepFRI import synthetic
+from mdfri_testkit import synthetic
 from mDeepFRI.batch import SequenceEngine, HotPathEngine, PackedProteins
 from mDeepFRI.predict import Predictor
 rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", 123)))

@@ -16,9 +16,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "metagenomic-deepfri_amd"))
+sys.path.insert(0, ROOT)   # mdfri_testkit
 
 import build_ref  # noqa: E402
-from mDeepFRI import synthetic  # noqa: E402
+from mdfri_testkit import synthetic
 
 
 def sha(a):

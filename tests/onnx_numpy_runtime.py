@@ -2,7 +2,7 @@
 semantics of the ONNX specification (opset 13-15, with the attribute forms of older opsets accepted) -- NOT the oracle's
 formulation of the network.  It stands in for onnxruntime, which this image lacks: `run(graph, feeds)` is what
 `InferenceSession.run(None, feeds)` would compute (reference predict.pyx:98), in float64 so that it can referee between a graph
-and oracle/*.py.  Covered: everything mDeepFRI.onnx_writer emits, plus the operators a tf2onnx (opset 15) conversion of the
+and oracle/*.py.  Covered: everything mdfri_testkit.onnx_writer emits, plus the operators a tf2onnx (opset 15) conversion of the
 Keras DeepFRI models may leave in a released file -- shape plumbing (Shape / Gather / Slice / Concat / Cast / Expand /
 ConstantOfShape / Range / Tile), elementwise and comparison ops, Where, Einsum, reductions, LSTM with optional initial state.
 Control flow (Loop / If / Scan) is not: a graph that needs it raises NotImplementedError naming the operator

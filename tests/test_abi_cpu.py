@@ -8,7 +8,8 @@ import numpy as np
 import pytest
 
 from conftest import ROOT
-from mDeepFRI import _hip, synthetic, weights
+from mDeepFRI import _hip, weights
+from mdfri_testkit import synthetic
 
 HEADER = os.path.join(ROOT, "include", "mdfri.h")
 PKG = os.path.join(ROOT, "metagenomic-deepfri_amd")
@@ -76,7 +77,9 @@ def test_align_len_and_layout_rows_host_helpers():
     L = np.array([1, 32, 33, 512, 100], dtype=np.int32)
     ro = np.zeros(6, dtype=np.int32)
     R = lib.mdf_layout_rows(_hip.ptr(L), 5, _hip.ptr(ro))
-    assert list(ro[:5]) == [0, 32, 64, 128, 640] and R == ro[5] == 768 and R % 128 == 0
+    # every protein starts on a MDF_GROUP_ROWS = 16 boundary, the total is a multiple of 128
+    assert lib.mdf_group_rows() == 16
+    assert list(ro[:5]) == [0, 16, 48, 96, 608] and R == ro[5] == 768 and R % 128 == 0
     assert lib.mdf_layout_rows(_hip.ptr(np.array([-1], dtype=np.int32)), 1, _hip.ptr(ro)) < 0
     assert "negative" in _hip.last_error()
 
@@ -124,7 +127,7 @@ def test_packing_and_chunk_plan():
     covered = []
     for ch in pk.chunks:
         ro = pk.chunk_row_off[ch.row_off_pos:ch.row_off_pos + (ch.p1 - ch.p0) + 1]
-        assert ro[0] == 0 and ro[-1] == ch.rows and ch.rows % 128 == 0 and np.all(ro[:-1] % 32 == 0)
+        assert ro[0] == 0 and ro[-1] == ch.rows and ch.rows % 128 == 0 and np.all(ro[:-1] % 16 == 0)
         assert np.all(np.diff(ro)[:-1] >= pk.Lq[ch.p0:ch.p1 - 1])
         assert ch.rows <= 1024 + 128 or ch.p1 - ch.p0 == 1
         covered += list(range(ch.p0, ch.p1))
@@ -135,8 +138,8 @@ def test_packing_and_chunk_plan():
     for sg in pk2.segments:
         off = pk2.grp_off[sg.grp_off_pos:sg.grp_off_pos + (sg.p1 - sg.p0) + 1]
         assert off[0] == 0 and off[-1] == sg.groups and np.all(np.diff(off) > 0) and sg.groups <= 64
-        assert np.all(np.diff(off)[:-1] * 32 >= pk2.Lq[sg.p0:sg.p1 - 1])
-    assert sum(c.rows // 32 for c in pk2.chunks) == sum(s.groups for s in pk2.segments)
+        assert np.all(np.diff(off)[:-1] * 16 >= pk2.Lq[sg.p0:sg.p1 - 1])
+    assert sum(c.rows // 16 for c in pk2.chunks) == sum(s.groups for s in pk2.segments)
     with pytest.raises(ValueError, match="does not spell"):
         PackedProteins.pack(["ACD"], [prots[0]["coords"]], ["AC-"], ["ACD"])
 
@@ -151,7 +154,9 @@ def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under the package may import, include, link or dlopen it
     (mentions in comments/docstrings that say what a kernel is checked against are fine)."""
     forbidden = [r"^\s*(from|import)\s+(oracle|cmap_oracle|gcn_oracle|build_ref)\b", r"#\s*include\s*[\"<][^\">]*oracle",
-                 r"libcmap_oracle", r"CDLL\([^)]*oracle", r"dlopen\([^)]*oracle", r"sys\.path[^\n]*oracle"]
+                 r"libcmap_oracle", r"CDLL\([^)]*oracle", r"dlopen\([^)]*oracle", r"sys\.path[^\n]*oracle",
+                 # nor the test / benchmark support package (synthetic workloads, the ONNX exporter): it lives outside the product
+                 r"^\s*(from|import)\s+mdfri_testkit\b", r"^\s*from\s+\.\s+import\s+[^\n]*\b(synthetic|onnx_writer)\b"]
     for dirpath, _, files in os.walk(PKG):
         for f in files:
             if f.endswith((".py", ".hip", ".cpp", ".h")) or f == "Makefile":

@@ -1,5 +1,5 @@
 """The library's batch planner (mdf_plan_create, csrc/engine.hip) needs no GPU: chunks of consecutive proteins within max_rows,
-32-row padding per protein, chunk totals rounded to 128, pooling segments within max_segment_groups -- checked here against a
+16-row padding per protein (MDF_GROUP_ROWS), chunk totals rounded to 128, pooling segments within max_segment_groups -- checked here against a
 straightforward Python restatement of the layout rules of include/mdfri.h ("Residue-row layout")."""
 import numpy as np
 import pytest
@@ -9,7 +9,7 @@ from mDeepFRI.batch import PackedProteins
 
 
 def _reference_plan(Lq, max_rows, max_segment_groups):
-    pad = (np.asarray(Lq, dtype=np.int64) + 31) // 32 * 32
+    pad = (np.asarray(Lq, dtype=np.int64) + 15) // 16 * 16
     B = len(Lq)
     chunks, row_off, p0 = [], [], 0
     while p0 < B:
@@ -29,12 +29,12 @@ def _reference_plan(Lq, max_rows, max_segment_groups):
         off = []
         for ci in cur:
             ch = chunks[ci]
-            off += list(ch[5] + row_off[ci][:-1] // 32)
+            off += list(ch[5] + row_off[ci][:-1] // 16)
         segments.append([first[0], last[1], groups, sum(len(g) for g in grp_off)])
         grp_off.append(np.asarray(off + [groups]))
 
     for ci, ch in enumerate(chunks):
-        g = ch[2] // 32
+        g = ch[2] // 16
         if cur and groups + g > max_segment_groups:
             close()
             cur, groups = [], 0
@@ -51,7 +51,7 @@ def test_planner_matches_the_layout_rules(seed):
     n = int(rng.integers(1, 400))
     Lq = rng.integers(1, int(rng.choice([40, 300, 1100])), size=n)
     max_rows = int(rng.choice([128, 1024, 4096, 65536]))
-    max_groups = int(rng.choice([8, 64, 1 << 19]))
+    max_groups = int(rng.choice([8, 64, 1 << 20]))
     pk = PackedProteins.pack(["A" * int(l) for l in Lq], max_rows=max_rows, max_segment_groups=max_groups)
     chunks, segments, row_off, grp_off = _reference_plan(Lq, max_rows, max_groups)
     assert [[c.p0, c.p1, c.rows, c.row_off_pos, c.segment, c.group_base] for c in pk.chunks] == chunks
@@ -61,7 +61,7 @@ def test_planner_matches_the_layout_rules(seed):
     # layout invariants of include/mdfri.h
     for c in pk.chunks:
         ro = pk.chunk_row_off[c.row_off_pos:c.row_off_pos + c.p1 - c.p0 + 1]
-        assert (ro[:-1] % 32 == 0).all() and ro[-1] % 128 == 0 and ro[-1] == c.rows
+        assert (ro[:-1] % 16 == 0).all() and ro[-1] % 128 == 0 and ro[-1] == c.rows
         assert c.p1 - c.p0 == 1 or c.rows <= max(max_rows, 128) + 96
 
 

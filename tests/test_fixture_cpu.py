@@ -39,7 +39,7 @@ def test_reference_query_fixture_oracles():
         assert ops.count("M") + ops.count("X") + ops.count("I") == len(q) or ops.count("M") + ops.count("X") + ops.count("D") == len(q)
         oh = cmap_oracle.seq2onehot(q)
         assert oh.shape == (len(q), 26) and np.array_equal(oh.sum(axis=1), np.ones(len(q)))
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     w = synthetic.glorot_cnn_weights(seed=3, n_terms=12)
     y = np.stack([cnn_oracle.cnn_forward(w, s) for s in allseqs])
     assert y.shape == (4, 12) and np.all((y > 0) & (y < 1)) and len({tuple(r) for r in y.round(6)}) == 4

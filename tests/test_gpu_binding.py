@@ -12,7 +12,8 @@ import pytest
 import cmap_oracle as orc
 import gcn_oracle
 from conftest import ROOT, gstr
-from mDeepFRI import synthetic, weights
+from mDeepFRI import weights
+from mdfri_testkit import synthetic
 
 pytestmark = pytest.mark.gpu
 

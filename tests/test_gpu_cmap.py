@@ -8,7 +8,7 @@ import pytest
 
 import cmap_oracle as orc
 from conftest import gstr
-from mDeepFRI import synthetic
+from mdfri_testkit import synthetic
 
 pytestmark = pytest.mark.gpu
 

@@ -7,14 +7,14 @@ pytestmark = pytest.mark.gpu
 
 
 def _seqs(seed, lengths):
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     rng = np.random.default_rng(seed)
     return [synthetic.random_sequence(rng, L) for L in lengths]
 
 
 def test_forward_pass_sequence_only_matches_oracle():
     import cnn_oracle
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.predict import Predictor
     w = synthetic.glorot_cnn_weights(seed=1, n_terms=489)
     pred = Predictor("synthetic-cnn", weights=w)
@@ -31,7 +31,7 @@ def test_forward_pass_sequence_only_matches_oracle():
 
 
 def test_gcn_model_without_cmap_is_refused():
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.predict import Predictor
     pred = Predictor("synthetic", weights=synthetic.glorot_gcn_weights(seed=0, n_terms=5, embed=64, gc_dims=(256,), fc_dim=256))
     with pytest.raises(ValueError, match="pass the contact map"):
@@ -41,7 +41,7 @@ def test_gcn_model_without_cmap_is_refused():
 @pytest.mark.parametrize("filters,kernel_lens", [((120, 100, 80, 60), (5, 10, 15, 20)), ((64, 130), (1, 128)), ((512,) * 3, (8, 16, 24))])
 def test_sequence_engine_matches_oracle(filters, kernel_lens):
     import cnn_oracle
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.batch import SequenceEngine
     from mDeepFRI.predict import Predictor
     heads = {"mf": synthetic.glorot_cnn_weights(seed=5, n_terms=77, filters=filters, kernel_lens=kernel_lens),
@@ -56,7 +56,8 @@ def test_sequence_engine_matches_oracle(filters, kernel_lens):
 
 
 def test_cnn_container_round_trip(tmp_path):
-    from mDeepFRI import synthetic, weights as W
+    from mDeepFRI import weights as W
+    from mdfri_testkit import synthetic
     from mDeepFRI.predict import Predictor
     w = synthetic.glorot_cnn_weights(seed=2, n_terms=12)
     w["cnn_pad2"] = np.array([3], dtype=np.float32)          # explicit (non-default) left padding survives the container
@@ -71,7 +72,7 @@ def test_cnn_container_round_trip(tmp_path):
 
 
 def test_sequence_engine_flags_invalid_residue():
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.batch import SequenceEngine
     from mDeepFRI.predict import Predictor
     eng = SequenceEngine({"mf": Predictor("synthetic-cnn", weights=synthetic.glorot_cnn_weights(seed=1, n_terms=7))}, max_rows=256)

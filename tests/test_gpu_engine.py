@@ -8,7 +8,8 @@ import pytest
 
 import cmap_oracle as orc
 import gcn_oracle
-from mDeepFRI import _hip, synthetic
+from mDeepFRI import _hip
+from mdfri_testkit import synthetic
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4

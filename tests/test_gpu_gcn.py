@@ -9,7 +9,7 @@ import pytest
 import cmap_oracle as orc
 import gcn_oracle
 from conftest import gstr
-from mDeepFRI import synthetic
+from mdfri_testkit import synthetic
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -197,7 +197,8 @@ def test_embedding_topology_variants_vs_oracle(variant, tmp_path):
     identity embedding for a graph without one): per call, batched, through a .mdfw container loaded by the C loader, and through an
     exported .onnx read back -- all vs the oracle, batch == per call bitwise."""
     import ctypes
-    from mDeepFRI import _hip, onnx_writer, weights
+    from mDeepFRI import _hip, weights
+    from mdfri_testkit import onnx_writer
     from mDeepFRI.batch import HotPathEngine, PackedProteins
     from mDeepFRI.predict import Predictor
     kw = {"embed_linear": dict(embed_linear=True), "embed_bias": dict(embed_bias=True), "linear_and_bias": dict(embed_linear=True, embed_bias=True),
@@ -262,6 +263,31 @@ def test_bp_sized_head_vs_oracle(bp, L):
                              max_rows=4096)
     out = eng.run_alignments(pk)["bp"]
     assert np.array_equal(out[2], y)                                                    # company-invariant, bitwise
+    for i, q in enumerate(prots):
+        cmq = orc.build_align_contact_map(q["coords"], q["q_aln"], q["t_aln"], 6.0, 2)
+        assert np.max(np.abs(out[i] - gcn_oracle.gcn_forward(w, q["seq"], cmq))) < TOL, i
+
+
+@pytest.mark.parametrize("L", [17, 300, 777])
+def test_ec_sized_head_vs_oracle(L):
+    """The enzyme-commission head of the v1.0 models (reference mDeepFRI/__init__.py:73-80, mode `ec`): T = 538 terms -> 1 076 output
+    columns, padded to 1 280 inside the library.  T is data, so the path is the one the GO heads take; this runs it once at that size:
+    per call and inside a fused batch of mixed lengths (16-row groups: proteins start in the middle of an MFMA tile), vs the oracle."""
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.predict import Predictor
+    w = synthetic.glorot_gcn_weights(seed=4, n_terms=synthetic.GO_TERMS["ec"])
+    pred = Predictor("synthetic-ec.onnx", weights=w)
+    assert pred.n_terms == 538
+    p = synthetic.synthetic_proteins(seed=950 + L, count=1, length=L, indel_rate=0.05)[0]
+    cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
+    y = pred.forward_pass(p["seq"], cm)
+    assert y.shape == (538,) and np.max(np.abs(y - gcn_oracle.gcn_forward(w, p["seq"], cm))) < TOL
+    others = synthetic.synthetic_proteins(seed=951 + L, count=6, length=(5, 150))
+    prots = others[:3] + [p] + others[3:]
+    pk = PackedProteins.pack([q["seq"] for q in prots], [q["coords"] for q in prots], [q["q_aln"] for q in prots], [q["t_aln"] for q in prots],
+                             max_rows=2048)
+    out = HotPathEngine({"ec": pred}, device=0, max_rows=2048).run_alignments(pk)["ec"]
+    assert np.array_equal(out[3], y)
     for i, q in enumerate(prots):
         cmq = orc.build_align_contact_map(q["coords"], q["q_aln"], q["t_aln"], 6.0, 2)
         assert np.max(np.abs(out[i] - gcn_oracle.gcn_forward(w, q["seq"], cmq))) < TOL, i
@@ -427,22 +453,22 @@ def test_rows_not_multiple_of_gemm_tile_do_not_write_out_of_bounds(mf):
     ws_bytes = L.mdf_gcn_workspace_bytes(h, R)
     pad = 1 << 16
     ws = torch.full((ws_bytes + 2 * pad,), 0x5A, dtype=torch.uint8, device=dev)
-    part = torch.full((R // 32 * feat + 2 * pad,), 777.0, dtype=torch.float32, device=dev)
+    part = torch.full((R // 16 * feat + 2 * pad,), 777.0, dtype=torch.float32, device=dev)
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     _hip.check(L.mdf_gcn_embed_dev(h, _hip.ptr(S), _hip.ptr(grp), _hip.ptr(col), _hip.ptr(val), R,
                                    ctypes.c_void_p(part.data_ptr() + pad * 4), ctypes.c_void_p(ws.data_ptr() + pad), ws_bytes, st))
     torch.cuda.synchronize()
     assert bool((ws[:pad] == 0x5A).all()) and bool((ws[pad + ws_bytes:] == 0x5A).all())
-    assert bool((part[:pad] == 777.0).all()) and bool((part[pad + R // 32 * feat:] == 777.0).all())
-    assert bool(torch.isfinite(part[pad:pad + R // 32 * feat]).all())
+    assert bool((part[:pad] == 777.0).all()) and bool((part[pad + R // 16 * feat:] == 777.0).all())
+    assert bool(torch.isfinite(part[pad:pad + R // 16 * feat]).all())
 
 
 def _library_first_script(then_torch: bool) -> str:
     from conftest import ROOT
     code = (
-        "import sys, os; sys.path.insert(0, os.path.join(%r, 'metagenomic-deepfri_amd'))\n"
+        "import sys, os; ROOT = %r; sys.path.insert(0, os.path.join(ROOT, 'metagenomic-deepfri_amd')); sys.path.insert(0, ROOT)\n"
         "import numpy as np\n"
-        "from mDeepFRI import synthetic\n"
+        "from mdfri_testkit import synthetic\n"
         "from mDeepFRI.predict import Predictor\n"
         "p = Predictor('syn', weights=synthetic.glorot_gcn_weights(0, 16))\n"
         "y = p.forward_pass('ACDEFGHIKL', np.eye(10, dtype=np.int32))\n"

@@ -19,14 +19,14 @@ def lstm_form(request, monkeypatch):
 
 
 def _weights(seed, hidden, embed, gc, fc, T):
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     w = synthetic.glorot_gcn_weights(seed=seed, n_terms=T, embed=embed, gc_dims=gc, fc_dim=fc)
     w.update(synthetic.glorot_lm_weights(seed=1000, hidden=hidden, embed=embed))
     return w
 
 
 def _proteins(seed, lengths):
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     rng = np.random.default_rng(seed)
     seqs = [synthetic.random_sequence(rng, L) for L in lengths]
     coords = [synthetic.random_walk_coords(rng, L) for L in lengths]
@@ -89,7 +89,7 @@ def test_engine_scores_with_language_model_full_size():
     import cmap_oracle
     import gcn_oracle
     import lm_oracle
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.batch import HotPathEngine, PackedProteins
     from mDeepFRI.predict import Predictor
     lm = synthetic.glorot_lm_weights(seed=1000, hidden=512, embed=1024)
@@ -119,7 +119,7 @@ def test_language_model_head_with_linear_embedding_and_aa_bias():
     AA branch (`b_aa`) -- vs the oracle, per call and batched."""
     import cmap_oracle
     import lm_oracle
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.batch import HotPathEngine, PackedProteins
     from mDeepFRI.predict import Predictor
     w = synthetic.glorot_gcn_weights(seed=31, n_terms=41, embed=256, gc_dims=(256, 256), fc_dim=256, embed_linear=True, embed_bias=True)
@@ -152,7 +152,7 @@ def test_mdfw_roundtrip_with_language_model(tmp_path):
 
 def test_predictor_loads_an_onnx_file(tmp_path):
     """The path the reference's pipeline passes (an .onnx file, pipeline.py:549-584) is read directly by mDeepFRI.onnx_reader."""
-    from mDeepFRI import onnx_writer
+    from mdfri_testkit import onnx_writer
     from mDeepFRI.predict import Predictor
     w = _weights(13, 64, 256, (256, 256), 256, 21)
     path = tmp_path / "DeepFRI-MERGED_GraphConv_gcd_512-512-512_fcd_1024_ca_10.0_mf.onnx"

@@ -9,7 +9,7 @@ import pytest
 
 import nw_oracle as nwo
 from conftest import ROOT
-from mDeepFRI import synthetic
+from mdfri_testkit import synthetic
 from mDeepFRI.alignment import (AlignmentResult, ScoringMatrix, align_pairwise, align_queries, align_queries_arrays, best_hit_database,
                                 insert_gaps, pairwise_against_database)
 
@@ -234,8 +234,8 @@ def test_16_bit_and_32_bit_kernels_agree_at_scale():
     import sys
     code = (
         "import sys, json, hashlib, numpy as np\n"
-        "sys.path[:0] = [%r, %r]\n"
-        "from mDeepFRI import synthetic\n"
+        "sys.path[:0] = [%r, %r, %r]\n"
+        "from mdfri_testkit import synthetic\n"
         "from mDeepFRI.alignment import ScoringMatrix, _PairBatch\n"
         "rng = np.random.default_rng(3)\n"
         "A = 'ARNDCQEGHILKMFPSTWYVBZX*'\n"
@@ -247,7 +247,7 @@ def test_16_bit_and_32_bit_kernels_agree_at_scale():
         "s = pb.scores(a, b, 10, 1); f = pb.align(a[::10], b[::10], 10, 1)\n"
         "print(json.dumps({'scores': hashlib.sha256(s.tobytes()).hexdigest(), 'ops': hashlib.sha256(f['ops'].tobytes()).hexdigest(),\n"
         "                  'off': hashlib.sha256(f['off'].tobytes()).hexdigest(), 'nm': int(f['n_match'].sum()), 'same': bool((f['score'] == s[::10]).all())}))\n"
-    ) % (os.path.join(ROOT, "metagenomic-deepfri_amd"), os.path.join(ROOT, "oracle"))
+    ) % (os.path.join(ROOT, "metagenomic-deepfri_amd"), os.path.join(ROOT, "oracle"), ROOT)
     outs = []
     for knob in ("1", "0"):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MDFRI_NW_INT16=knob), capture_output=True, text=True, timeout=600)

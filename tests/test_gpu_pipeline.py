@@ -43,7 +43,7 @@ def test_reference_query_fixture_through_aligner_cnn_and_gcn():
     import gcn_oracle
     import nw_oracle
     from conftest import GOLDEN
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.alignment import ScoringMatrix, align_queries_arrays
     from mDeepFRI.batch import HotPathEngine, PackedProteins, SequenceEngine
     from mDeepFRI.predict import Predictor
@@ -88,7 +88,7 @@ def test_query_stream_equals_the_stage_by_stage_chain():
     without any candidate (both sequence-only: they go through the CNN heads, reference pipeline.py:600-648), a batch in which no hit has
     a structure, and a head whose survivors exceed the planned capacity."""
     import torch
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.alignment import ScoringMatrix, align_queries_arrays
     from mDeepFRI.batch import HotPathEngine, PackedProteins, SequenceEngine
     from mDeepFRI.output import filter_scores, results_text
@@ -155,7 +155,7 @@ def test_query_stream_equals_the_stage_by_stage_chain():
 def test_query_stream_errors_leave_it_usable():
     """An invalid letter in a middle batch surfaces as the aligner's ValueError at that batch's second step; batches in flight are
     abandoned and the same stream object (its three aligner workspaces) runs the next job."""
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.alignment import ScoringMatrix
     from mDeepFRI.batch import HotPathEngine
     from mDeepFRI.predict import Predictor
@@ -187,7 +187,7 @@ def test_query_stream_with_a_language_model_head():
     uploaded asynchronously on the stream (plan-owned sources, stream-ordered allocation) while the previous batch is still running --
     batch by batch the filtered results equal the stage-by-stage run."""
     import torch
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.alignment import ScoringMatrix, align_queries_arrays
     from mDeepFRI.batch import HotPathEngine, PackedProteins
     from mDeepFRI.output import filter_scores
@@ -220,7 +220,7 @@ def test_query_stream_recovers_from_a_csr_capacity_that_is_too_small():
     """An engine sized for 3 contacts per residue: the first batches overflow the CSR (flagged on the device, nothing written out of
     bounds), are run again with the capacity the flag asks for -- after the batches already in flight have left the engine's workspaces
     -- and the stream hands out exactly what a correctly sized engine computes."""
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.alignment import ScoringMatrix
     from mDeepFRI.batch import HotPathEngine
     from mDeepFRI.predict import Predictor
@@ -244,7 +244,7 @@ def test_query_stream_recovers_from_a_csr_capacity_that_is_too_small():
 def test_query_stream_batches_cut_by_rows_give_the_same_results():
     """batch_chunks: slices sized to fill whole chunks of padded residue rows instead of a fixed number of queries -- other slice
     boundaries, the same per-query results bit for bit."""
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     from mDeepFRI.alignment import ScoringMatrix
     from mDeepFRI.batch import HotPathEngine
     from mDeepFRI.predict import Predictor
@@ -267,5 +267,5 @@ def test_query_stream_batches_cut_by_rows_give_the_same_results():
     by_rows, f2 = per_query(QueryStream(eng, db_xyz, batch_size=40, max_rows=4096, scoring_matrix=sm, batch_chunks=2))
     assert by_count == by_rows and len(by_rows) == 150
     assert f1 != f2 and sum(c for _, c in f2) == 150 and all(a + c == b for (a, c), (b, _) in zip(f2, f2[1:]))
-    rows = lambda a, c: sum((len(q) + 31) // 32 * 32 for q in qseqs[a:a + c])      # noqa: E731
+    rows = lambda a, c: sum((len(q) + 15) // 16 * 16 for q in qseqs[a:a + c])      # noqa: E731
     assert all(rows(a, c) <= 2 * 4096 for a, c in f2)

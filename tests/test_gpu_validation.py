@@ -40,11 +40,14 @@ def test_released_model_goldens_if_present():
     if not fixtures or not model_dir:
         pytest.skip("no released-model fixture with onnxruntime scores (tests/validation/validate_release.py MODEL.onnx --ort writes one)")
     from mDeepFRI.predict import Predictor
+    import json
     for f in fixtures:
         z = np.load(f)
-        mode = os.path.basename(f)[len("release_"):-4]
-        cand = glob.glob(os.path.join(model_dir, f"*_{mode}.onnx"))
-        assert cand, f"no *_{mode}.onnx under {model_dir}"
+        rep = json.loads(bytes(z["report"]).decode())          # the fixture remembers which file it was made from and what kind it is
+        name = os.path.basename(rep["file"])
+        cand = glob.glob(os.path.join(model_dir, "**", name), recursive=True)
+        assert cand, f"no {name} under {model_dir}"
         seq, cmap = bytes(z["seq"]).decode(), z["cmap"].astype(np.int32)
-        y = Predictor(cand[0]).forward_pass(seq, cmap) if cmap.size else Predictor(cand[0]).forward_pass(seq)
-        assert np.max(np.abs(y - z["scores_ort"])) < 1e-4, mode
+        is_cnn = (rep.get("mapped") or {}).get("kind") == "cnn"
+        y = Predictor(cand[0]).forward_pass(seq) if is_cnn else Predictor(cand[0]).forward_pass(seq, cmap)
+        assert np.max(np.abs(y - z["scores_ort"])) < 1e-4, name

@@ -1,14 +1,14 @@
 """mDeepFRI.onnx_reader (hand-written protobuf decoding + structural weight extraction) against files written by Google's
-protobuf encoder (mDeepFRI/onnx_writer.py).  CPU only.  No released DeepFRI .onnx file is available offline: what is proven
+protobuf encoder (mdfri_testkit/onnx_writer.py).  CPU only.  No released DeepFRI .onnx file is available offline: what is proven
 here is wire-format decoding and the structural mapping on a graph with tf2onnx's op sequence."""
 import numpy as np
 import pytest
 
-from mDeepFRI import onnx_writer
+from mdfri_testkit import onnx_writer
 
 
 def _weights(lm: bool):
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     w = synthetic.glorot_gcn_weights(seed=3, n_terms=17, embed=256, gc_dims=(256, 512, 256), fc_dim=256)
     if lm:
         w.update(synthetic.glorot_lm_weights(seed=5, hidden=64, embed=256))
@@ -92,7 +92,8 @@ def test_lstm_gate_reorder_matches_oracle_semantics():
 @pytest.mark.parametrize("conv2d_form", [False, True])
 @pytest.mark.parametrize("explicit_pads", [False, True])
 def test_extracts_the_sequence_only_cnn(conv2d_form, explicit_pads):
-    from mDeepFRI import onnx_reader, synthetic, weights
+    from mDeepFRI import onnx_reader, weights
+    from mdfri_testkit import synthetic
     w = synthetic.glorot_cnn_weights(seed=4, n_terms=9)
     if explicit_pads:
         w["cnn_pad3"] = np.array([9], dtype=np.float32)      # a non-default split of the 14 padding zeros of kernel 15
@@ -124,7 +125,8 @@ def test_exported_gcn_graph_computes_what_the_oracle_states(lm, gemm):
     import gcn_oracle
     import lm_oracle
     import onnx_numpy_runtime
-    from mDeepFRI import onnx_reader, synthetic
+    from mDeepFRI import onnx_reader
+    from mdfri_testkit import synthetic
     w = _weights(lm)
     g = onnx_reader.parse_model(onnx_writer.deepfri_gcn_model(w, use_gemm_head=gemm))
     rng = np.random.default_rng(31)
@@ -145,7 +147,8 @@ def test_exported_gcn_graph_computes_what_the_oracle_states(lm, gemm):
 def test_exported_cnn_graph_computes_what_the_oracle_states(conv2d_form, explicit_pads):
     import cnn_oracle
     import onnx_numpy_runtime
-    from mDeepFRI import onnx_reader, synthetic
+    from mDeepFRI import onnx_reader
+    from mdfri_testkit import synthetic
     w = synthetic.glorot_cnn_weights(seed=2, n_terms=13, filters=(24, 16, 8), kernel_lens=(5, 10, 15))
     g = onnx_reader.parse_model(onnx_writer.deepcnn_model(w, conv2d_form=conv2d_form, explicit_pads=explicit_pads))
     seq = synthetic.random_sequence(np.random.default_rng(3), 41)
@@ -162,7 +165,8 @@ def test_embedding_topology_variants_are_read_from_the_graph(variant):
     import onnx_numpy_runtime as rt
     import gcn_oracle
     import lm_oracle
-    from mDeepFRI import onnx_reader, synthetic, weights
+    from mDeepFRI import onnx_reader, weights
+    from mdfri_testkit import synthetic
     kw = {"embed_linear": dict(embed_linear=True), "embed_bias": dict(embed_bias=True), "linear_and_bias": dict(embed_linear=True, embed_bias=True),
           "lm_linear": dict(embed_linear=True, embed_bias=True), "no_embedding": {}}[variant]
     w = synthetic.glorot_gcn_weights(seed=8, n_terms=13, embed=256, gc_dims=(256, 256), fc_dim=256, **kw)

@@ -9,7 +9,7 @@ import pytest
 import cmap_oracle as orc
 import gcn_oracle
 from conftest import GOLDEN, gstr
-from mDeepFRI import synthetic
+from mdfri_testkit import synthetic
 
 
 def sha(a):

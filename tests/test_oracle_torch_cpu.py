@@ -10,7 +10,7 @@ import torch.nn.functional as F
 import cnn_oracle
 import gcn_oracle
 import lm_oracle
-from mDeepFRI import synthetic
+from mdfri_testkit import synthetic
 
 
 def _t(a):

@@ -18,7 +18,7 @@ def test_partition_covers_everything_and_balances():
     flat = sorted(i for s in shards for i in s)
     assert flat == list(range(1000))
     loads = [sum(sharding.protein_cost(L[i]) for i in s) for s in shards]
-    assert max(loads) - min(loads) <= 1024 + 31                     # LPT bound: at most one longest item apart
+    assert max(loads) - min(loads) <= 1024 + 15                     # LPT bound: at most one longest item apart
     for s in shards:
         assert [L[i] for i in s] == sorted(L[i] for i in s)        # each shard sorted by length (pipeline.py:529)
     assert sharding.partition_by_cost(L, 8) == shards               # deterministic
@@ -29,7 +29,7 @@ def test_partition_covers_everything_and_balances():
 def test_dry_plan_of_the_sharded_baseline_configs_is_balanced(world):
     """BASELINE configs[3] (100 000 proteins, L ~ U{128..1024}) and configs[4] (500 000, length histogram): predicted
     imbalance of the padded rows below 1 % at every rank count the driver will launch (`bench.py --gpus N --dry-plan`)."""
-    from mDeepFRI import synthetic
+    from mdfri_testkit import synthetic
     for lengths in (synthetic.uniform_lengths(46, 100_000), synthetic.histogram_lengths(47, 500_000)):   # bench.py's seeds
         plan = sharding.plan_summary(lengths, world)
         assert sum(plan["proteins"]) == len(lengths) and plan["world"] == world
@@ -173,3 +173,10 @@ def test_gather_filtered_single_process():
     s = torch.tensor([0.9, 0.5, 0.3])
     goff, gt, gs = sharding.gather_filtered(off, t, s, [2, 0, 1], total=3)
     assert goff.tolist() == [0, 0, 1, 3] and gt.tolist() == [9, 5, 1] and gs.tolist() == pytest.approx([0.3, 0.9, 0.5])
+
+
+def test_cost_model_uses_the_library_row_alignment():
+    """sharding.GROUP_ROWS mirrors MDF_GROUP_ROWS (include/mdfri.h): the cost of a protein is its padded residue rows."""
+    from mDeepFRI import _hip, sharding
+    assert sharding.GROUP_ROWS == _hip.lib().mdf_group_rows()
+    assert sharding.protein_cost(1) == sharding.GROUP_ROWS and sharding.protein_cost(513) == 528

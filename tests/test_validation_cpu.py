@@ -23,7 +23,7 @@ def test_validate_release_self_test_runs_green_on_cpu(tmp_path):
 
 def test_validate_release_reports_an_unknown_graph_instead_of_guessing(tmp_path):
     """A graph that is not a DeepFRI model: the kit still executes it, says what it could not map, and does not call that a pass."""
-    from mDeepFRI import onnx_writer
+    from mdfri_testkit import onnx_writer
     b = onnx_writer.GraphBuilder()
     x = b.node("MatMul", [b.input("seq"), b.const(np.ones((26, 4), np.float32))])
     b.output(b.node("Relu", [x]))
@@ -44,7 +44,8 @@ def test_numpy_runtime_operators_of_converted_graphs():
     """tf2onnx leaves shape plumbing around Keras layers: Shape / Gather / Unsqueeze / Concat feeding Reshape, Cast, Slice, Where,
     Einsum, ReduceSum with the axes as attribute (opset < 13) or input, Squeeze without axes, LSTM with an initial state."""
     import onnx_numpy_runtime as rt
-    from mDeepFRI import onnx_reader, onnx_writer
+    from mDeepFRI import onnx_reader
+    from mdfri_testkit import onnx_writer
     rng = np.random.default_rng(0)
     X = rng.standard_normal((1, 5, 6)).astype(np.float32)
     b = onnx_writer.GraphBuilder()
@@ -76,3 +77,19 @@ def test_numpy_runtime_operators_of_converted_graphs():
     with pytest.raises(NotImplementedError, match="Loop"):
         from mDeepFRI.onnx_reader import Graph, Node
         rt.run(Graph(nodes=[Node(op_type="Loop", name="l", inputs=[], outputs=["y"])], outputs=["y"]), {})
+
+
+def test_validate_all_one_command_self_test(tmp_path):
+    """tests/validation/validate_all.sh --self-test: the pin-day kit as one command, on this build's own exported graphs -- a GraphConv
+    and a CNN file per {mf, bp, cc, ec} (cc and ec heads at their released sizes, 320 and 538 terms), then the aligner harness
+    (PyOpal absent: skipped cleanly).  Every file PASSes, the table names the embedding variant, goldens are written per (kind, mode)."""
+    r = subprocess.run(["bash", os.path.join(KIT, "validate_all.sh"), "--self-test", "--golden-dir", str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    table = [ln for ln in r.stdout.splitlines() if ln.startswith("selftest-")]
+    assert len(table) == 8 and all(" PASS " in ln for ln in table), table
+    assert sum("embed_relu" in ln for ln in table) == 4 and sum("cnn 4 branches" in ln for ln in table) == 4
+    assert "aligner (PyOpal / VTML80): rc=0" in r.stdout
+    names = sorted(os.listdir(tmp_path))
+    assert names == sorted(f"release_{k}_{m}.npz" for k in ("gcn", "cnn") for m in ("mf", "bp", "cc", "ec")), names
+    z = np.load(tmp_path / "release_gcn_ec.npz")
+    assert z["scores_graph"].shape == (538,) and np.max(np.abs(z["scores_graph"] - z["scores_oracle"])) < 1e-9

@@ -35,7 +35,7 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-for p in (os.path.join(ROOT, "metagenomic-deepfri_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+for p in (os.path.join(ROOT, "metagenomic-deepfri_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -57,7 +57,7 @@ def mode_of(path):
     return m.group(1) if m else os.path.splitext(os.path.basename(path))[0]
 
 
-def validate(path, length=300, seed=0, use_ort=None, device=0, out_dir=None, quiet=False):
+def validate(path, length=300, seed=0, use_ort=None, device=0, out_dir=None, quiet=False, golden_name=None):
     from mDeepFRI import onnx_reader, weights as W
     import onnx_numpy_runtime
     say = (lambda *a: None) if quiet else print
@@ -180,7 +180,7 @@ def validate(path, length=300, seed=0, use_ort=None, device=0, out_dir=None, qui
     say(f"[verdict] {'PASS' if ok else 'FAIL'}: {len(deltas)} comparison(s) among {names}, worst {worst:.3e} against {TOL:g}")
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
-        out = os.path.join(out_dir, f"release_{report['mode']}.npz")
+        out = os.path.join(out_dir, f"release_{golden_name or report['mode']}.npz")
         np.savez_compressed(out, seq=np.frombuffer(seq.encode(), dtype=np.uint8), cmap=cmap.astype(np.uint8),
                             report=np.frombuffer(json.dumps(report).encode(), dtype=np.uint8), **{f"scores_{k}": np.asarray(v) for k, v in results.items()})
         say(f"[golden] wrote {out} (sequence, map, scores of {names})")
@@ -188,10 +188,10 @@ def validate(path, length=300, seed=0, use_ort=None, device=0, out_dir=None, qui
 
 
 def self_test(out_dir=None, quiet=False):
-    """The kit on this build's own exported files (mDeepFRI.onnx_writer): GCN, GCN + language model, sequence-only CNN.  What
+    """The kit on this build's own exported files (mdfri_testkit.onnx_writer): GCN, GCN + language model, sequence-only CNN.  What
     this proves: the kit runs end to end; the exported graphs, executed under ONNX semantics, agree with the oracles and -- on a
     GPU box -- with the HIP path.  What it cannot prove: anything about a released file."""
-    from mDeepFRI import onnx_writer, synthetic
+    from mdfri_testkit import onnx_writer, synthetic
     tmp = tempfile.mkdtemp(prefix="mdfri_validate_")
     w_gcn = synthetic.glorot_gcn_weights(seed=3, n_terms=37, embed=256, gc_dims=(256, 256, 256), fc_dim=256)
     w_lm = dict(synthetic.glorot_gcn_weights(seed=4, n_terms=21, embed=256, gc_dims=(256, 256), fc_dim=256))

@@ -8,8 +8,10 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # mdfri_testkit (synthetic workloads)
 import torch  # noqa: E402
-from mDeepFRI import _hip, synthetic  # noqa: E402
+from mDeepFRI import _hip  # noqa: E402
+from mdfri_testkit import synthetic
 from mDeepFRI.batch import HotPathEngine, PackedProteins  # noqa: E402
 from mDeepFRI.predict import Predictor  # noqa: E402
 

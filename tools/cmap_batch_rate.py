@@ -2,8 +2,9 @@
 pipeline.py:476-481, int32 (Lq, Lq) maps back in host memory)."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # mdfri_testkit (synthetic workloads)
 import numpy as np, torch
-from mDeepFRI import synthetic
+from mdfri_testkit import synthetic
 from mDeepFRI.alignment import AlignmentResult
 from mDeepFRI.batch import build_align_contact_maps
 n, L = int(os.environ.get("N", 1024)), 512

@@ -3,7 +3,8 @@ integer atomicMax is order-independent; the two-stream LSTM form is ordered by e
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
-from mDeepFRI import synthetic
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # mdfri_testkit (synthetic workloads)
+from mdfri_testkit import synthetic
 from mDeepFRI.batch import HotPathEngine, PackedProteins, SequenceEngine
 from mDeepFRI.predict import Predictor
 

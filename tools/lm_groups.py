@@ -2,8 +2,10 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # mdfri_testkit (synthetic workloads)
 import torch
-from mDeepFRI import synthetic, _hip
+from mDeepFRI import _hip
+from mdfri_testkit import synthetic
 lib = _hip.lib()
 from mDeepFRI.batch import HotPathEngine, PackedProteins
 from mDeepFRI.predict import Predictor

@@ -2,7 +2,8 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
-from mDeepFRI import synthetic
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # mdfri_testkit (synthetic workloads)
+from mdfri_testkit import synthetic
 from mDeepFRI.predict import Predictor
 
 w = synthetic.glorot_gcn_weights(seed=0, n_terms=489)

@@ -4,8 +4,9 @@ and while another stream streams 1 GiB copies through the memory system."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # mdfri_testkit (synthetic workloads)
 import torch
-from mDeepFRI import synthetic
+from mdfri_testkit import synthetic
 from mDeepFRI.batch import HotPathEngine, PackedProteins
 from mDeepFRI.predict import Predictor
 

@@ -26,6 +26,6 @@ edges = np.arange(30, 2048 + width + 1, width)
 counts, _ = np.histogram(a, bins=edges)
 out = {"source": "mDeepFRI/tests/data/GCA_000731455.1.proteins.fa.gz (reference v1.1.10)", "proteins": int(len(a)), "clip": [30, 2048],
        "bin_width": width, "first_bin_start": 30, "counts": [int(c) for c in counts], "mean_length": float(a.mean())}
-dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd", "mDeepFRI", "data", "gca_000731455_length_hist.json")
+dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "mdfri_testkit", "data", "gca_000731455_length_hist.json")
 json.dump(out, open(dst, "w"))
 print(len(a), "proteins, mean", a.mean(), "->", dst)

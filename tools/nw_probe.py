@@ -7,8 +7,10 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # mdfri_testkit (synthetic workloads)
 import torch  # noqa: E402
-from mDeepFRI import _hip, synthetic  # noqa: E402
+from mDeepFRI import _hip  # noqa: E402
+from mdfri_testkit import synthetic
 from mDeepFRI.alignment import ScoringMatrix, _PairBatch, align_queries_arrays  # noqa: E402
 
 ALPHA = "ARNDCQEGHILKMFPSTWYVBZX*"

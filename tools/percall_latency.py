@@ -2,7 +2,9 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "metagenomic-deepfri_amd"))
-from mDeepFRI import synthetic, bio_utils
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # mdfri_testkit (synthetic workloads)
+from mDeepFRI import bio_utils
+from mdfri_testkit import synthetic
 from mDeepFRI.contact_map_utils import pairwise_sqeuclidean, align_contact_map
 from mDeepFRI.predict import Predictor, seq2onehot
 

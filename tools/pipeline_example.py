@@ -17,8 +17,9 @@ import numpy as np
 
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "metagenomic-deepfri_amd"))
+sys.path.insert(0, ROOT)   # mdfri_testkit (synthetic workloads)
 import torch  # noqa: E402
-from mDeepFRI import synthetic  # noqa: E402
+from mdfri_testkit import synthetic
 from mDeepFRI.alignment import ScoringMatrix, align_queries_arrays  # noqa: E402
 from mDeepFRI.batch import HotPathEngine, PackedProteins  # noqa: E402
 from mDeepFRI.output import filter_scores, results_text  # noqa: E402

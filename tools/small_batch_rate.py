@@ -14,9 +14,10 @@ ap.add_argument("--reps", type=int, default=200)
 ap.add_argument("--sizes", default="1,8,64,512")
 args = ap.parse_args()
 sys.path.insert(0, os.path.abspath(args.pkg))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))   # mdfri_testkit (synthetic workloads)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
-from mDeepFRI import synthetic  # noqa: E402
+from mdfri_testkit import synthetic
 from mDeepFRI.batch import HotPathEngine, PackedProteins  # noqa: E402
 from mDeepFRI.predict import Predictor  # noqa: E402
 

@@ -3,7 +3,7 @@
 import os, sys, time, hashlib
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import pipeline_example as pe
-from mDeepFRI import synthetic
+from mdfri_testkit import synthetic
 from mDeepFRI.alignment import ScoringMatrix
 from mDeepFRI.batch import HotPathEngine
 from mDeepFRI.predict import Predictor
