@@ -274,6 +274,35 @@ def ort_leg(seqs, coords, weights, budget_s):
         return {"available": True, "error": f"{type(e).__name__}: {str(e)[:300]}"}
 
 
+def reference_cmap_leg(seqs, coords, budget_s):
+    """The contact-map stage on the REAL reference kernels (oracle/_ref: contact_map_utils.pyx compiled by oracle/build_ref.py with
+    the reference's flags), one thread, with the glue of bio_utils.py:196-227,348-385 restated in NumPy: pairwise_sqeuclidean ->
+    D < thr^2 -> argwhere -> align_contact_map.  Falls back on the constant measured in the build container when the compiled
+    reference did not travel to this box."""
+    const = {"kind": "reference", "ms_per_protein": 1.39, "measured": "build container, round 1, 1 thread, L=512",
+             "note": "constant: the compiled reference (oracle/_ref) is not on this box"}
+    try:
+        oracle_paths()
+        import build_ref
+        ref = build_ref.load()
+        if ref is None:
+            return const
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget_s or n < 2:
+            i = n % len(seqs)
+            D = ref.pairwise_sqeuclidean(coords[i])
+            sparse = np.argwhere((D < 6.0 ** 2).astype(np.int32) == 1).astype(np.int32)
+            ref.align_contact_map(seqs[i], seqs[i], sparse, 2)
+            n += 1
+        dt = time.perf_counter() - t0
+        return {"kind": "reference", "value": n / dt, "unit": "proteins/s", "cores": 1, "ms_per_protein": round(1e3 * dt / n, 3),
+                "sample": f"{n} of the step's L={len(seqs[0])} proteins, {dt:.1f} s: pairwise_sqeuclidean + threshold + argwhere + align_contact_map "
+                          "(the reference's own compiled contact_map_utils.pyx, one thread), contact-map stage only",
+                "note": "measured live on this box's host"}
+    except Exception as e:   # noqa: BLE001  -- a baseline leg never takes the headline line with it
+        return dict(const, error=f"{type(e).__name__}: {e}"[:300])
+
+
 def cpu_baseline(seqs, coords, weights, args):
     """Oracle chain (oracle/cmap_oracle.c + oracle/gcn_oracle.py) on this box's host cores."""
     from threadpoolctl import threadpool_limits
@@ -303,8 +332,7 @@ def cpu_baseline(seqs, coords, weights, args):
                       f"(= the configuration the reference ships: ORT intra_op=1, batch 1)",
             "process_pool": pool,
             "onnxruntime": ort_leg(seqs, coords, weights, args.cpu_seconds * 0.5),
-            "cmap_stage_reference": {"kind": "reference", "ms_per_protein": 1.39, "measured": "build container, round 1, 1 thread, L=512",
-                                     "note": "constant: the compiled reference (oracle/_ref) does not travel to the GPU box"},
+            "cmap_stage_reference": reference_cmap_leg(seqs, coords, min(args.cpu_seconds * 0.25, 4.0)),
             "published_anchor": "reference weight_convert/inference_times.csv.gz: 0.13 s/protein/model/core at L~512 (ORT CPU)"}
 
 

@@ -33,7 +33,8 @@ def test_default_shape_small():
     assert line["query_stream"]["value"] > 0 and line["query_stream"]["queries"] == 8000 and line["query_stream"]["result_lines"] > 8000
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["process_pool"]["cores"] == 2 and "available" in cb["onnxruntime"]
-    assert "cmap_stage_reference" in cb and cb["cmap_stage_reference"]["note"].startswith("constant")
+    ref = cb["cmap_stage_reference"]          # the compiled reference travels with the tree: timed live; a constant only where it is absent
+    assert ref["kind"] == "reference" and ref["ms_per_protein"] > 0 and (ref["note"].startswith("constant") or ref["value"] > 0)
 
 
 def test_bare_python_launches_two_ranks_weak():
