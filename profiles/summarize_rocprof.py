@@ -5,7 +5,7 @@
   counters     :  python profiles/summarize_rocprof.py pmc    <dir with *_counter_collection.csv> ...  > profiles/rNN_pmc.txt
   per layer    :  python profiles/summarize_rocprof.py layers <dir with *_kernel_trace.csv>   >> profiles/rNN_kernel_stats.txt
                   (A.X and H.W launches split by GraphConv layer: a k_aggregate launch is layer 2 when the kernel in front of it is the
-                  K = 32 layer-1 GEMM, layer 3 when it is an H.W GEMM; only full-size launches -- the modal grid -- are counted)
+                  layer-1 kernel, layer 3 when it is an H.W GEMM; only full-size launches -- the modal grid -- are counted)
 Counters are averaged per kernel name over all dispatches (one rocprofv3 --pmc pass per directory).
 """
 import csv
@@ -61,9 +61,9 @@ def layers(d):
             dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             grid = int(r["Grid_Size_X"])
             if name.startswith("k_aggregate"):
-                # layer 1's EPI codes are 4 / 5 (EPI_L1_STORE / EPI_L1); an H.W launch in front means the layer above 2
-                layer = "layer 2" if prev.startswith("k_gemm_f32<(Epilogue)4") or prev.startswith("k_gemm_f32<(mdf::Epilogue)4") or "<4," in prev \
-                    else ("layer 3" if prev.startswith("k_gemm_f32") else "other")
+                # the launch in front of a layer-2 aggregation is the layer-1 kernel (k_layer1; the K = 32 GEMM <4, ..> up to round 3), in
+                # front of a layer-3 aggregation an H.W GEMM
+                layer = "layer 2" if prev.startswith("k_layer1") or "<4," in prev else ("layer 3" if prev.startswith("k_gemm_f32") else "other")
                 groups[("k_aggregate (A.X)", layer, name)].append((grid, dur))
             elif name.startswith("k_gemm_f32<") and not name.startswith("k_gemm_f32_small"):
                 epi = name.split("<", 1)[1]
