@@ -194,3 +194,57 @@ def test_dense_regrow_reaches_both_contact_sets_of_the_pipelined_stage(heads):
 def _pack_seq_only(prots, **kw):
     from mDeepFRI.batch import PackedProteins
     return PackedProteins.pack([p["seq"] for p in prots], **kw)
+
+
+def test_proteins_sharing_a_32_row_block_and_an_mfma_tile(heads):
+    """Proteins start on 16-row boundaries (MDF_GROUP_ROWS): with lengths of 1-31 residues two proteins share one 32-row block of the
+    contact stage (k_cmap_rows / k_cmap_fill / k_dense_rows resolve a protein per half) and one 32 x 32 MFMA tile of the GraphConv
+    GEMMs (two pool partials per tile).  Lengths chosen so that every combination occurs -- a protein ending in the first half, one
+    starting in the second, one filling exactly 16 / 32 rows, one-residue proteins, a long one behind them -- through the fused path,
+    the dense-map path and the per-call API: contact maps bit-exact with the oracle, scores within 1e-4, batch == per call bitwise."""
+    from mDeepFRI.batch import HotPathEngine, PackedProteins, build_align_contact_maps
+    from mDeepFRI.alignment import AlignmentResult
+    ws, preds = heads
+    lengths = [5, 9, 16, 17, 3, 40, 1, 64, 31, 1, 15, 33, 2, 300, 16, 7]
+    prots = [synthetic.synthetic_proteins(seed=700 + k, count=1, length=L, indel_rate=0.1 if L > 8 else 0.0)[0] for k, L in enumerate(lengths)]
+    pk = _pack(prots, max_rows=65536)
+    ro = pk.chunk_row_off[:len(prots) + 1]
+    assert np.all(ro[:-1] % 16 == 0) and np.any(ro[:-1] % 32 == 16)           # some proteins do start in the middle of a block
+    eng = HotPathEngine(preds, device=0, max_rows=65536)
+    out = eng.run_alignments(pk)
+    maps = []
+    for i, p in enumerate(prots):
+        cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
+        maps.append(cm)
+        for m in eng.modes:
+            assert np.max(np.abs(out[m][i] - gcn_oracle.gcn_forward(ws[m], p["seq"], cm))) < TOL, (m, i, lengths[i])
+            assert np.array_equal(out[m][i], preds[m].forward_pass(p["seq"], cm)), (m, i, lengths[i])       # per call, bitwise
+    # the batched dense-int32 maps (k_cmap_rows<DENSE>) are the oracle's, bit for bit
+    alns = []
+    for k, p in enumerate(prots):
+        a = AlignmentResult(query_name=f"q{k}", query_sequence=p["seq"], target_name=f"t{k}", target_sequence=p["t_aln"].replace("-", ""), alignment="")
+        a.gapped_sequence, a.gapped_target, a.coords = p["q_aln"], p["t_aln"], p["coords"]
+        alns.append(a)
+    for (_, got), want in zip(build_align_contact_maps(alns, device=0, max_rows=65536), maps):
+        assert got.dtype == np.int32 and np.array_equal(got, want)
+    # the dense-map path (k_dense_rows) on the same maps == the fused path, bitwise
+    db = eng.upload(_pack_seq_only(prots, max_rows=65536))
+    dense = eng.forward_dense(db, maps)
+    for m in eng.modes:
+        assert np.array_equal(dense[m].cpu().numpy(), out[m]), m
+
+
+def test_sequence_models_on_proteins_sharing_a_32_row_block():
+    """The CNN's work items are 32-row blocks owned by one protein or single 16-row groups (k_cnn_conv_pool_lds): the same tiny /
+    straddling lengths, batch == per call and vs the oracle."""
+    import cnn_oracle
+    from mDeepFRI.batch import SequenceEngine
+    from mDeepFRI.predict import Predictor
+    w = synthetic.glorot_cnn_weights(seed=9, n_terms=33)
+    pred = Predictor("synthetic-cnn", weights=w)
+    rng = np.random.default_rng(5)
+    seqs = [synthetic.random_sequence(rng, L) for L in (5, 9, 16, 17, 3, 40, 1, 64, 31, 1, 15, 33, 2, 300, 16, 7)]
+    out = SequenceEngine({"mf": pred}, device=0).run(seqs)["mf"]
+    for i, s in enumerate(seqs):
+        assert np.max(np.abs(out[i] - cnn_oracle.cnn_forward(w, s))) < TOL, (i, len(s))
+        assert np.array_equal(out[i], pred.forward_pass(s)), (i, len(s))
