@@ -97,61 +97,63 @@ __device__ __forceinline__ void split3(float x, unsigned short &hi, unsigned sho
     lo = (unsigned short)(__float_as_uint(r2) >> 16);
 }
 
-// LDS image: Xt[term][channel][row] bf16, a (term, channel) line holds CHUNK rows = CHUNK / 8 slots of 16 bytes; slot s of channel c
-// lives at slot s ^ (c & 15): a fragment read (32 channels x one slot) is conflict-free, the split's writes at most two-way.
+// LDS image: Xt[term][channel][row] bf16, a (term, channel) line holds CHR rows = CHR / 8 slots of 16 bytes; slot s of channel c
+// lives at slot s ^ (c & 15): a fragment read (32 channels x one slot) is conflict-free, the split's writes two-way.
 constexpr int SL = 32;          // channels of a workgroup's slab (one 32 x 32 MFMA tile wide)
-constexpr int CH2 = 256;        // rows of the protein in LDS at a time: 4 waves x 64 rows
-__device__ __forceinline__ int xt_off(int term, int ch, int slot) { return ((term * SL + ch) * (CH2 / 8) + (slot ^ (ch & 15))) * 8; }
+constexpr int CHR = 128;        // rows of the protein in LDS at a time
+constexpr int OPITCH = 40;      // floats per row of the output staging tile (conflict-free writes of the two lane halves)
+__device__ __forceinline__ int xt_off(int term, int ch, int slot) { return ((term * SL + ch) * (CHR / 8) + (slot ^ (ch & 15))) * 8; }
 
-// ROWBLOCKS: 32-row blocks of the protein per wave (L <= 4 waves * ROWBLOCKS * 32)
-template <int ROWBLOCKS>
-__global__ __launch_bounds__(256) void k_ax_mfma(const float *__restrict__ H, const unsigned long long *__restrict__ masks, int W,
-                                                 const float *__restrict__ dinv, const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq,
-                                                 float *__restrict__ out, int abl)
+// One workgroup = (protein, 32-channel slab).  The protein's rows pass through LDS in chunks of CHR rows (split into three bf16 terms,
+// transposed to [term][channel][row]); every wave owns ROWBLOCKS 32-row blocks of the output and multiplies the populated 32 x 16
+// blocks of contact bits with the chunk on the matrix pipe.  ROWBLOCKS: L <= 4 waves * ROWBLOCKS * 32.  WPS: waves per SIMD the
+// register allocation aims at.
+template <int ROWBLOCKS, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_ax_mfma(const float *__restrict__ H, const unsigned long long *__restrict__ masks, int W,
+                                                      const float *__restrict__ dinv, const int32_t *__restrict__ row_off,
+                                                      const int32_t *__restrict__ Lq, const unsigned *__restrict__ blk, float *__restrict__ out, int abl)
 {
-    __shared__ __attribute__((aligned(16))) unsigned short xt[3 * SL * CH2];   // 48 KiB
+    __shared__ __attribute__((aligned(16))) unsigned short xt[3 * SL * CHR];   // 24 KiB; re-used as 4 x 5 KiB output staging at the end
+    __shared__ __attribute__((aligned(16))) unsigned short lut[256 * 8];        // byte of contact bits -> its 8 bf16 (0.0 / 1.0): one ds_read_b128
+    for (int e = threadIdx.x; e < 256 * 8; e += 256) lut[e] = ((e >> 3) >> (e & 7)) & 1 ? 0x3f80 : 0;
     const int p = blockIdx.x / (C / SL), slab = blockIdx.x % (C / SL);
     const int r0 = row_off[p], L = Lq[p];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int frow = lane & 31, half = lane >> 5;
-    const int oct = lane >> 3, quad = lane & 7;   // staging role: rows 8 oct .. 8 oct + 7 of the wave's 64, channels 4 quad .. 4 quad + 3
+    // staging role: rows 8 oct .. 8 oct + 7 of the chunk (16 octets), channels 2 cp, 2 cp + 1
+    const int oct = threadIdx.x >> 4, cp = threadIdx.x & 15;
+    typedef float v2f __attribute__((ext_vector_type(2)));
     f32x16 acc[ROWBLOCKS];
 #pragma unroll
     for (int b = 0; b < ROWBLOCKS; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
     const float *Hs = H + (size_t)r0 * C + slab * SL;
-    v4f x[8];
-    auto fetch = [&](int j0) {
-        const int jb = j0 + wid * 64 + oct * 8;   // first of this lane's 8 rows (L, r0 multiples of 16 in the engine; here any L)
-        v4f d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
-        if (jb + 8 <= L) {
-            d0 = *reinterpret_cast<const v4f *>(dinv + r0 + jb);
-            d1 = *reinterpret_cast<const v4f *>(dinv + r0 + jb + 4);
-        } else {
-            for (int k = 0; k < 8; ++k)
-                if (jb + k < L) (k < 4 ? d0 : d1)[k & 3] = dinv[r0 + jb + k];
-        }
+    for (int j0 = 0; j0 < L; j0 += CHR) {
+        // ---- requests of this chunk: the rows to stage, and the contact bits of its 128 columns for every row block of the wave
+        v2f x[8];
+        {
+            const int jb = j0 + oct * 8;
+            // (dinv is readable up to the padded end of the protein's rows: the engine pads every protein to a multiple of 16 rows)
+            const v4f d0 = *reinterpret_cast<const v4f *>(dinv + r0 + jb), d1 = *reinterpret_cast<const v4f *>(dinv + r0 + jb + 4);
+            const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = jb + k;
-            const v4f h = (j < L && !(abl & 1)) ? *reinterpret_cast<const v4f *>(Hs + (size_t)j * C + quad * 4) : (v4f){0, 0, 0, 0};
-            x[k] = h * (k < 4 ? d0 : d1)[k & 3];
+            for (int k = 0; k < 8; ++k) {
+                const int j = jb + k;
+                const v2f h = (j < L && !(abl & 1)) ? *reinterpret_cast<const v2f *>(Hs + (size_t)j * C + cp * 2) : (v2f){0, 0};
+                x[k] = h * dd[k];
+            }
         }
-    };
-    fetch(0);
-    for (int j0 = 0; j0 < L; j0 += CH2) {
-        // the contact bits of this chunk's columns for every row block of the wave: requested now, used after the barrier
-        unsigned long long mw[ROWBLOCKS][4];
+        unsigned long long mw0[ROWBLOCKS], mw1[ROWBLOCKS];
 #pragma unroll
         for (int b = 0; b < ROWBLOCKS; ++b) {
             const int i = (wid * ROWBLOCKS + b) * 32 + frow;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) mw[b][w] = (i < L && j0 + 64 * w < L) ? masks[(size_t)(r0 + i) * W + (j0 >> 6) + w] : 0ull;
+            mw0[b] = i < L ? masks[(size_t)(r0 + i) * W + (j0 >> 6)] : 0ull;
+            mw1[b] = (i < L && j0 + 64 < L) ? masks[(size_t)(r0 + i) * W + (j0 >> 6) + 1] : 0ull;
         }
         __syncthreads();   // the previous chunk's fragments have been read
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {   // this lane's 4 channels: 8 consecutive rows each = one 16-byte slot per term
+        for (int c = 0; c < 2; ++c) {   // this lane's 2 channels: 8 consecutive rows each = one 16-byte slot per term
             bf16x8 th, tm, tl;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -159,51 +161,70 @@ __global__ __launch_bounds__(256) void k_ax_mfma(const float *__restrict__ H, co
                 split3(x[k][c], a, b, cc);
                 th[k] = (short)a, tm[k] = (short)b, tl[k] = (short)cc;
             }
-            const int slot = wid * 8 + oct, ch = quad * 4 + c;
-            *reinterpret_cast<bf16x8 *>(xt + xt_off(0, ch, slot)) = th;
-            *reinterpret_cast<bf16x8 *>(xt + xt_off(1, ch, slot)) = tm;
-            *reinterpret_cast<bf16x8 *>(xt + xt_off(2, ch, slot)) = tl;
+            const int ch = cp * 2 + c;
+            *reinterpret_cast<bf16x8 *>(xt + xt_off(0, ch, oct)) = th;
+            *reinterpret_cast<bf16x8 *>(xt + xt_off(1, ch, oct)) = tm;
+            *reinterpret_cast<bf16x8 *>(xt + xt_off(2, ch, oct)) = tl;
         }
-        if (j0 + CH2 < L) fetch(j0 + CH2);   // the next chunk's rows travel while this one is multiplied
         __syncthreads();
         if (abl & 2) continue;
-        // ---- every wave: its row blocks x the 16 column blocks (16 rows of X each) of this chunk
+        // ---- every wave: its row blocks x the populated column blocks (16 rows of X each) of this chunk.  Which blocks are populated
+        // is a precomputed bit per (32-row block, 16-column block) -- a scalar load, no per-lane test (as many VALU instructions as the
+        // matrix phase has left: a wave64 VALU instruction costs four cycles, and the per-lane test was the whole phase)
+        const int fbase = (frow * (CHR / 8)) * 16;                          // byte offset of this lane's channel line (term 0) ...
+        const int fx = frow & 15;                                           // ... whose 16-byte slots are XOR-swizzled by this
 #pragma unroll
         for (int b = 0; b < ROWBLOCKS; ++b) {
-#pragma unroll
-            for (int cb = 0; cb < 16; ++cb) {
-                const unsigned bits16 = (unsigned)((mw[b][cb >> 2] >> ((cb & 3) * 16)) & 0xffffu);
-                if (__ballot(bits16 != 0) == 0ull) continue;     // an all-zero 32 x 16 block: nothing to add
-                const unsigned byte = (bits16 >> (8 * half)) & 0xffu;
-                bf16x8 af;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) af[k] = (short)(((byte >> k) & 1u) ? 0x3f80 : 0);
-                const int slot = cb * 2 + half;
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(xt + xt_off(0, frow, slot));
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(xt + xt_off(1, frow, slot));
-                const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(xt + xt_off(2, frow, slot));
+            unsigned nz = (blk[(size_t)p * 16 + wid * ROWBLOCKS + b] >> (j0 >> 4)) & 0xffu;   // (16 row blocks per protein in this probe)
+            const unsigned long long wx = mw0[b] ^ mw1[b];
+            while (nz) {
+                const int cb = __builtin_ctz(nz);
+                nz &= nz - 1;
+                const unsigned long long word = mw0[b] ^ (wx & (0ull - (unsigned long long)((cb >> 2) & 1)));   // a select without an index
+                const unsigned byte = (unsigned)(word >> ((cb & 3) * 16 + 8 * half)) & 0xffu;
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(lut + byte * 8);
+                const char *fp = reinterpret_cast<const char *>(xt) + fbase + (((cb * 2 + half) ^ fx) << 4);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(fp);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(fp + SL * (CHR / 8) * 16);
+                const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(fp + 2 * SL * (CHR / 8) * 16);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the fragment reads first ...
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2, acc[b], 0, 0, 0);   // smallest addends first
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[b], 0, 0, 0);
                 acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[b], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the three matrix instructions
             }
         }
     }
-    // ---- out[i, slab] = d_i * acc: C layout of the 32 x 32 tile: lane -> column l & 31, register r -> row (r&3) + 8 (r>>2) + 4 (l>>5)
+    // ---- out[i, slab] = d_i * acc through a wave-private LDS tile: the 32 x 32 result leaves as 16-byte stores, 8 rows x 128 B per instruction
+    __syncthreads();   // every wave is done with the last chunk's fragments
+    float *ot = reinterpret_cast<float *>(xt) + wid * (32 * OPITCH);
     float *Os = out + (size_t)r0 * C + slab * SL;
+    const int orow = lane >> 3, oq = lane & 7;
 #pragma unroll
     for (int b = 0; b < ROWBLOCKS; ++b) {
-        float di[16];
+        const int ib = (wid * ROWBLOCKS + b) * 32;
+        if (ib >= L) break;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (wid * ROWBLOCKS + b) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            di[r] = i < L ? dinv[r0 + i] : 0.0f;
-        }
+        for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2) + 4 * half) * OPITCH + frow] = acc[b][r];   // C layout: lane -> column, register -> row
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = (wid * ROWBLOCKS + b) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (i < L && !(abl & 4)) __builtin_nontemporal_store(di[r] * acc[b][r], Os + (size_t)i * C + frow);
+        for (int k = 0; k < 4; ++k) {
+            const int i = ib + k * 8 + orow;
+            if (i < L && !(abl & 4)) {
+                const v4f v = *reinterpret_cast<const v4f *>(ot + (k * 8 + orow) * OPITCH + oq * 4) * dinv[r0 + i];
+                __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(Os + (size_t)i * C + oq * 4));
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+}
+
+// streams 256 MiB through the caches: what a GEMM launch between two aggregation launches does to the residency of their operands
+__global__ __launch_bounds__(256) void k_stream(const v4f *__restrict__ a, v4f *__restrict__ b, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i] + 1.0f;
 }
 
 int main(int argc, char **argv)
@@ -239,6 +260,14 @@ int main(int argc, char **argv)
             }
     }
     hro[B] = R;
+    std::vector<unsigned> hblk((size_t)B * 16, 0u);   // bit cb of entry (p, rb): rows [32 rb, 32 rb + 32) have a contact in columns [16 cb, 16 cb + 16)
+    for (int p = 0; p < B; ++p)
+        for (int i = 0; i < L; ++i)
+            for (int w = 0; w < W; ++w) {
+                const unsigned long long m = hm[(size_t)(hro[p] + i) * W + w];
+                for (int q = 0; q < 4; ++q)
+                    if ((m >> (16 * q)) & 0xffffull) hblk[(size_t)p * 16 + i / 32] |= 1u << (w * 4 + q);
+            }
     for (int r = 0; r < R; ++r) hd[r] = nbr[r].empty() ? 0.f : 1.0f / (1e-6f + std::sqrt((float)nbr[r].size()));
     double nnz = 0;
     for (int r = 0; r < R; ++r) {
@@ -254,6 +283,10 @@ int main(int argc, char **argv)
     float *dH, *dd, *dv, *o1, *o2;
     unsigned long long *dm;
     int32_t *dro, *dL, *drp, *dci;
+    unsigned *dblk;
+    v4f *fa, *fb;
+    const size_t fn = (size_t)128 << 20 >> 4;   // 128 MiB in, 128 MiB out
+    CK(hipMalloc(&fa, fn * 16)); CK(hipMalloc(&fb, fn * 16)); CK(hipMemset(fa, 0, fn * 16));
     CK(hipMalloc(&dH, hH.size() * 4)); CK(hipMalloc(&o1, hH.size() * 4)); CK(hipMalloc(&o2, hH.size() * 4));
     CK(hipMalloc(&dd, hd.size() * 4)); CK(hipMalloc(&dm, hm.size() * 8)); CK(hipMalloc(&dro, hro.size() * 4)); CK(hipMalloc(&dL, hL.size() * 4));
     CK(hipMalloc(&drp, rowptr.size() * 4)); CK(hipMalloc(&dci, colidx.size() * 4)); CK(hipMalloc(&dv, val.size() * 4));
@@ -261,41 +294,59 @@ int main(int argc, char **argv)
     CK(hipMemcpy(dm, hm.data(), hm.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dro, hro.data(), hro.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dL, hL.data(), hL.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(drp, rowptr.data(), rowptr.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dci, colidx.data(), colidx.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dv, val.data(), val.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&dblk, hblk.size() * 4)); CK(hipMemcpy(dblk, hblk.data(), hblk.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(o1, 0, hH.size() * 4)); CK(hipMemset(o2, 0, hH.size() * 4));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int n_sb = (R + 511) >> 9, csr_blocks = 8 * 128 * ((n_sb + 7) / 8);
     auto run_csr = [&] { hipLaunchKernelGGL(k_ax_csr, dim3(csr_blocks), dim3(256), 0, nullptr, dH, drp, dci, dv, o1, R); };
-    int abl = 0;
+    int abl = 0, wps = 3;
     auto run_mfma = [&] {
         const int grid = B * (C / SL);
-#define LAUNCH(RB) hipLaunchKernelGGL((k_ax_mfma<RB>), dim3(grid), dim3(256), 0, nullptr, dH, dm, W, dd, dro, dL, o2, abl)
+#define LAUNCH(RB, WPS) hipLaunchKernelGGL((k_ax_mfma<RB, WPS>), dim3(grid), dim3(256), 0, nullptr, dH, dm, W, dd, dro, dL, dblk, o2, abl)
         if (L > 512) { fprintf(stderr, "L > 512 not in this probe\n"); exit(1); }
-        if (L <= 128) LAUNCH(1); else if (L <= 256) LAUNCH(2); else LAUNCH(4);
+        if (wps == 4) { if (L <= 128) LAUNCH(1, 4); else if (L <= 256) LAUNCH(2, 4); else LAUNCH(4, 4); }
+        else if (wps == 3) { if (L <= 128) LAUNCH(1, 3); else if (L <= 256) LAUNCH(2, 3); else LAUNCH(4, 3); }
+        else { if (L <= 128) LAUNCH(1, 2); else if (L <= 256) LAUNCH(2, 2); else LAUNCH(4, 2); }
 #undef LAUNCH
     };
+    bool flush = false;   // a 256 MiB stream between two launches: the operands are then not cache-resident (the layer-3 situation)
     auto timed = [&](auto &&f, const char *name) {
         f();
         CK(hipDeviceSynchronize());
         CK(hipGetLastError());
         const int n = 20;
-        CK(hipEventRecord(e0, nullptr));
-        for (int k = 0; k < n; ++k) f();
-        CK(hipEventRecord(e1, nullptr));
-        CK(hipEventSynchronize(e1));
-        float ms = 0;
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        const double us = ms * 1e3 / n, bytes = 2.0 * 4 * C * (double)B * L;
-        printf("%-28s %8.1f us per launch   %6.0f GB/s of read-once + write-once\n", name, us, bytes / us * 1e-3);
+        double tot = 0;
+        for (int k = 0; k < n; ++k) {
+            if (flush) hipLaunchKernelGGL(k_stream, dim3(2048), dim3(256), 0, nullptr, fa, fb, fn);
+            CK(hipEventRecord(e0, nullptr));
+            f();
+            CK(hipEventRecord(e1, nullptr));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            tot += ms;
+        }
+        const double us = tot * 1e3 / n, bytes = 2.0 * 4 * C * (double)B * L;
+        printf("%-34s %8.1f us per launch   %6.0f GB/s of read-once + write-once\n", name, us, bytes / us * 1e-3);
     };
-    timed(run_csr, "k_ax_csr (gather, CSR)");
-    timed(run_mfma, "k_ax_mfma slab 32, chunk 256");
-    for (abl = 1; abl < 8; ++abl) {
-        char name[64];
-        snprintf(name, sizeof name, "  ablation %d%s%s%s", abl, abl & 1 ? " -loads" : "", abl & 2 ? " -mfma" : "", abl & 4 ? " -stores" : "");
-        timed(run_mfma, name);
+    for (int fl = 0; fl < 2; ++fl) {
+        flush = fl != 0;
+        printf("-- %s\n", flush ? "a 256 MiB stream between launches (operands not cache-resident)" : "back to back (operands cache-resident)");
+        timed(run_csr, "k_ax_csr (gather, CSR)");
+        for (wps = 2; wps <= 4; ++wps) {
+            char name[64];
+            abl = 0;
+            snprintf(name, sizeof name, "k_ax_mfma v5, %d waves/SIMD", wps);
+            timed(run_mfma, name);
+            if (!flush)
+                for (abl = 2; abl <= 7; abl += (abl == 2 ? 2 : 3)) {
+                    snprintf(name, sizeof name, "  ablation %d%s%s%s", abl, abl & 1 ? " -loads" : "", abl & 2 ? " -mfma" : "", abl & 4 ? " -stores" : "");
+                    timed(run_mfma, name);
+                }
+        }
     }
-    abl = 0;
+    abl = 0, wps = 3;
     run_mfma();
     std::vector<float> a(hH.size()), b(hH.size());
     CK(hipMemcpy(a.data(), o1, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), o2, b.size() * 4, hipMemcpyDeviceToHost));
