@@ -221,6 +221,131 @@ __global__ __launch_bounds__(256, WPS) void k_ax_mfma(const float *__restrict__ 
     }
 }
 
+// ---- the same with 8 waves per workgroup (512 threads), 256-row chunks, ROWBLOCKS row blocks per wave: L <= 8 * ROWBLOCKS * 32
+constexpr int CHR8 = 256;       // the 8-wave variant stages 256 rows at a time
+__device__ __forceinline__ int xt_off8(int term, int ch, int slot) { return ((term * SL + ch) * (CHR8 / 8) + (slot ^ (ch & 15))) * 8; }
+
+// One workgroup = (protein, 32-channel slab).  The protein's rows pass through LDS in chunks of CHR rows (split into three bf16 terms,
+// transposed to [term][channel][row]); every wave owns ROWBLOCKS 32-row blocks of the output and multiplies the populated 32 x 16
+// blocks of contact bits with the chunk on the matrix pipe.  ROWBLOCKS: L <= 4 waves * ROWBLOCKS * 32.  WPS: waves per SIMD the
+// register allocation aims at.
+template <int ROWBLOCKS, int WPS>
+__global__ __launch_bounds__(512, WPS) void k_ax_mfma8(const float *__restrict__ H, const unsigned long long *__restrict__ masks, int W,
+                                                      const float *__restrict__ dinv, const int32_t *__restrict__ row_off,
+                                                      const int32_t *__restrict__ Lq, const unsigned *__restrict__ blk, float *__restrict__ out, int abl)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short xt[3 * SL * CHR8];   // 48 KiB; re-used as 8 x 5 KiB output staging at the end
+    __shared__ __attribute__((aligned(16))) unsigned short lut[256 * 8];        // byte of contact bits -> its 8 bf16 (0.0 / 1.0): one ds_read_b128
+    for (int e = threadIdx.x; e < 256 * 8; e += 512) lut[e] = ((e >> 3) >> (e & 7)) & 1 ? 0x3f80 : 0;
+    const int p = blockIdx.x / (C / SL), slab = blockIdx.x % (C / SL);
+    const int r0 = row_off[p], L = Lq[p];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int frow = lane & 31, half = lane >> 5;
+    // staging role: rows 8 oct .. 8 oct + 7 of the chunk (16 octets), channels 2 cp, 2 cp + 1
+    const int oct = threadIdx.x >> 4, cp = threadIdx.x & 15;   // 32 octets = 256 rows
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    f32x16 acc[ROWBLOCKS];
+#pragma unroll
+    for (int b = 0; b < ROWBLOCKS; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+    const float *Hs = H + (size_t)r0 * C + slab * SL;
+    for (int j0 = 0; j0 < L; j0 += CHR8) {
+        // ---- requests of this chunk: the rows to stage, and the contact bits of its 128 columns for every row block of the wave
+        v2f x[8];
+        {
+            const int jb = j0 + oct * 8;
+            // (dinv is readable up to the padded end of the protein's rows: the engine pads every protein to a multiple of 16 rows)
+            const v4f d0 = *reinterpret_cast<const v4f *>(dinv + r0 + jb), d1 = *reinterpret_cast<const v4f *>(dinv + r0 + jb + 4);
+            const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = jb + k;
+                const v2f h = (j < L && !(abl & 1)) ? *reinterpret_cast<const v2f *>(Hs + (size_t)j * C + cp * 2) : (v2f){0, 0};
+                x[k] = h * dd[k];
+            }
+        }
+        unsigned long long mw0[ROWBLOCKS], mw1[ROWBLOCKS], mw2[ROWBLOCKS], mw3[ROWBLOCKS];
+#pragma unroll
+        for (int b = 0; b < ROWBLOCKS; ++b) {
+            const int i = (wid * ROWBLOCKS + b) * 32 + frow;
+            const unsigned long long *mrow = masks + (size_t)(r0 + i) * W + (j0 >> 6);
+            mw0[b] = i < L ? mrow[0] : 0ull;
+            mw1[b] = (i < L && j0 + 64 < L) ? mrow[1] : 0ull;
+            mw2[b] = (i < L && j0 + 128 < L) ? mrow[2] : 0ull;
+            mw3[b] = (i < L && j0 + 192 < L) ? mrow[3] : 0ull;
+        }
+        __syncthreads();   // the previous chunk's fragments have been read
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {   // this lane's 2 channels: 8 consecutive rows each = one 16-byte slot per term
+            bf16x8 th, tm, tl;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                unsigned short a, b, cc;
+                split3(x[k][c], a, b, cc);
+                th[k] = (short)a, tm[k] = (short)b, tl[k] = (short)cc;
+            }
+            const int ch = cp * 2 + c;
+            *reinterpret_cast<bf16x8 *>(xt + xt_off8(0, ch, oct)) = th;
+            *reinterpret_cast<bf16x8 *>(xt + xt_off8(1, ch, oct)) = tm;
+            *reinterpret_cast<bf16x8 *>(xt + xt_off8(2, ch, oct)) = tl;
+        }
+        __syncthreads();
+        if (abl & 2) continue;
+        // ---- every wave: its row blocks x the populated column blocks (16 rows of X each) of this chunk.  Which blocks are populated
+        // is a precomputed bit per (32-row block, 16-column block) -- a scalar load, no per-lane test (as many VALU instructions as the
+        // matrix phase has left: a wave64 VALU instruction costs four cycles, and the per-lane test was the whole phase)
+        const int fbase = (frow * (CHR8 / 8)) * 16;                         // byte offset of this lane's channel line (term 0) ...
+        const int fx = frow & 15;                                           // ... whose 16-byte slots are XOR-swizzled by this
+#pragma unroll
+        for (int b = 0; b < ROWBLOCKS; ++b) {
+            unsigned nz = (blk[(size_t)p * 16 + wid * ROWBLOCKS + b] >> (j0 >> 4)) & 0xffffu;   // (16 row blocks per protein in this probe)
+            while (nz) {
+                const int cb = __builtin_ctz(nz);
+                nz &= nz - 1;
+                const unsigned long long m01 = mw0[b] ^ ((mw0[b] ^ mw1[b]) & (0ull - (unsigned long long)((cb >> 2) & 1)));   // selects without an index
+                const unsigned long long m23 = mw2[b] ^ ((mw2[b] ^ mw3[b]) & (0ull - (unsigned long long)((cb >> 2) & 1)));
+                const unsigned long long word = m01 ^ ((m01 ^ m23) & (0ull - (unsigned long long)((cb >> 3) & 1)));
+                const unsigned byte = (unsigned)(word >> ((cb & 3) * 16 + 8 * half)) & 0xffu;
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(lut + byte * 8);
+                const char *fp = reinterpret_cast<const char *>(xt) + fbase + (((cb * 2 + half) ^ fx) << 4);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(fp);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(fp + SL * (CHR8 / 8) * 16);
+                const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(fp + 2 * SL * (CHR8 / 8) * 16);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the fragment reads first ...
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2, acc[b], 0, 0, 0);   // smallest addends first
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[b], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the three matrix instructions
+            }
+        }
+    }
+    // ---- out[i, slab] = d_i * acc through a wave-private LDS tile: the 32 x 32 result leaves as 16-byte stores, 8 rows x 128 B per instruction
+    __syncthreads();   // every wave is done with the last chunk's fragments
+    float *ot = reinterpret_cast<float *>(xt) + wid * (32 * OPITCH);
+    float *Os = out + (size_t)r0 * C + slab * SL;
+    const int orow = lane >> 3, oq = lane & 7;
+#pragma unroll
+    for (int b = 0; b < ROWBLOCKS; ++b) {
+        const int ib = (wid * ROWBLOCKS + b) * 32;
+        if (ib >= L) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2) + 4 * half) * OPITCH + frow] = acc[b][r];   // C layout: lane -> column, register -> row
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = ib + k * 8 + orow;
+            if (i < L && !(abl & 4)) {
+                const v4f v = *reinterpret_cast<const v4f *>(ot + (k * 8 + orow) * OPITCH + oq * 4) * dinv[r0 + i];
+                __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(Os + (size_t)i * C + oq * 4));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
+
 // streams 256 MiB through the caches: what a GEMM launch between two aggregation launches does to the residency of their operands
 __global__ __launch_bounds__(256) void k_stream(const v4f *__restrict__ a, v4f *__restrict__ b, size_t n)
 {
@@ -310,6 +435,14 @@ int main(int argc, char **argv)
         else { if (L <= 128) LAUNCH(1, 2); else if (L <= 256) LAUNCH(2, 2); else LAUNCH(4, 2); }
 #undef LAUNCH
     };
+    int rb8 = 0;
+    auto run_mfma8 = [&] {
+        const int grid = B * (C / SL);
+#define LAUNCH8(RB, WPS) hipLaunchKernelGGL((k_ax_mfma8<RB, WPS>), dim3(grid), dim3(512), 0, nullptr, dH, dm, W, dd, dro, dL, dblk, o2, abl)
+        if (L <= 256) { if (wps >= 5) LAUNCH8(1, 5); else LAUNCH8(1, 4); } else { if (wps >= 5) LAUNCH8(2, 5); else LAUNCH8(2, 4); }
+#undef LAUNCH8
+        (void)rb8;
+    };
     bool flush = false;   // a 256 MiB stream between two launches: the operands are then not cache-resident (the layer-3 situation)
     auto timed = [&](auto &&f, const char *name) {
         f();
@@ -345,9 +478,16 @@ int main(int argc, char **argv)
                     timed(run_mfma, name);
                 }
         }
+        for (wps = 4; wps <= 5; ++wps) {
+            char name[64];
+            abl = 0;
+            snprintf(name, sizeof name, "k_ax_mfma8 (8 waves), %d waves/SIMD", wps);
+            timed(run_mfma8, name);
+            if (!flush) { abl = 2; timed(run_mfma8, "  ablation 2 -mfma"); }
+        }
     }
-    abl = 0, wps = 3;
-    run_mfma();
+    abl = 0, wps = 4;
+    run_mfma8();
     std::vector<float> a(hH.size()), b(hH.size());
     CK(hipMemcpy(a.data(), o1, a.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), o2, b.size() * 4, hipMemcpyDeviceToHost));
     double worst = 0, ref = 0;
