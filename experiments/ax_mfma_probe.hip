@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void k_stream(const v4f *__restrict__ a, v4f *
 
 int main(int argc, char **argv)
 {
-    const int B = 128, L = argc > 1 ? atoi(argv[1]) : 512;
+    const int L = argc > 1 ? atoi(argv[1]) : 512, B = argc > 2 ? atoi(argv[2]) : 128;
     const int Lpad = (L + 15) / 16 * 16, R = (B * Lpad + 127) / 128 * 128, W = (L + 63) / 64;
     printf("B=%d L=%d R=%d W=%d\n", B, L, R, W);
     std::mt19937 rng(7);

@@ -271,6 +271,12 @@ int mdf_dense_to_csr_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_
                          const int32_t *row_off, int32_t B, int64_t R, int32_t *rowptr, int32_t *colidx,
                          float *val, int64_t nnz_cap, int32_t *status, void *workspace, size_t workspace_bytes,
                          void *stream);
+/* The same, additionally leaving every row's contact BITS (entry != 0) in the workspace (laid out with max_len = the longest query, see
+ * mdf_cmap_ws_view) and telling, per protein, whether its map is binary: binary[p] (int32, device) is left at 1 when every entry off the
+ * diagonal is 0 or 1, cleared to 0 otherwise -- what the matrix-pipe aggregation (mdf_agg_desc) needs of a dense map. */
+int mdf_dense_to_csr_masks_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_off, const int32_t *Lq, const int32_t *row_off,
+                               int32_t B, int64_t R, int32_t max_len, int32_t *rowptr, int32_t *colidx, float *val, int64_t nnz_cap,
+                               int32_t *status, int32_t *binary, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Layer-1 operand, shared by every GO head: letter_sums[i][a] = sum of val over the CSR entries of row i whose column
  * residue is letter a  (= (Ahat . onehot)[i][a]); (R, 32) f32, columns 26..31 zero.  With the embedding folded at model
@@ -278,18 +284,61 @@ int mdf_dense_to_csr_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_
 int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
                         float *letter_sums, void *stream);
 
+/* ---- the matrix-pipe form of the A.X aggregation -----------------------------------------------------------------------------
+ * For a BINARY contact map (the fused path's always are; a dense map handed to forward_pass may hold any values) the aggregation
+ *     out[i] = d_i * sum_j A'[i][j] * (d_j * H[j])
+ * is an exact block-sparse product on the bf16 matrix pipe: A' is 0/1, d_j * H[j] is split into three bf16 terms whose sum is the fp32
+ * value, products 1 * term are exact and the accumulation is fp32 -- the same fp32 sum as the CSR gather's, in another order, with
+ * every H element crossing L1 once instead of once per neighbour.  It serves proteins of at most MDF_AGG_MAX_LEN residues; longer
+ * ones and non-binary maps keep the CSR gather kernel.  Which kernel aggregates a protein depends on that protein alone (its length,
+ * its map), never on the batch around it: batch == per call stays bitwise.
+ * mdf_agg_desc says, for the R rows of one mdf_gcn_embed*_agg_dev call, which proteins go where. */
+#define MDF_AGG_MAX_LEN 512
+typedef struct mdf_agg_desc {
+    const uint64_t *masks;      /* (R, W) device: bit j of word (r0+i, j/64) = A'[i][j] (diagonal set); rows >= Lq of a protein all zero */
+    int32_t W;
+    const float *dinv;          /* (R) device: 1 / (1e-6 + sqrt(degree)), from mdf_agg_prepare_dev */
+    const uint32_t *blk;        /* (B, 16) device: bit c of entry (p, b): rows [32b, 32b+32) of protein p have a contact in columns [16c, 16c+16) */
+    const int32_t *row_off;     /* (B+1) device */
+    const int32_t *Lq;          /* (B) device */
+    const int32_t *plist;       /* (n_mf) device: indices (into row_off / Lq / blk) of the proteins the matrix-pipe kernel aggregates */
+    int32_t n_mf;
+    const int32_t *gate;        /* device, may be NULL: per protein (indexed like Lq), 0 = this protein's map is NOT binary: the matrix-pipe
+                                 * kernel skips it and the CSR gather launch below takes it (per-call path: known on the device only) */
+    const int32_t *csr_seg;     /* HOST: n_seg pairs (first row, row count) left to the CSR gather kernel */
+    int32_t n_seg;
+    int32_t csr_gated;          /* 1: the CSR launches run only where gate[protein 0] == 0 (single-protein calls) */
+    int64_t tail_row0;          /* rows [tail_row0, R) belong to no protein: the aggregate is zeroed there ... */
+    int32_t tail_p;             /* ... by the workgroups of this listed protein (the last one of the rows, when it is on the list), or, < 0, by a
+                                 * memset behind the launches (when the last protein is a long one the gather over its rows covers them) */
+} mdf_agg_desc;
+
+/* dinv (R) and blk (B, 16) from the contact bits and the per-row degrees (counts: int32 (R), the number of set bits of a row) that
+ * the contact stage leaves in its workspace (mdf_cmap_ws_view).  Proteins longer than MDF_AGG_MAX_LEN get no blk entry. */
+int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts, const int32_t *row_off, const int32_t *Lq, int32_t B,
+                        int64_t R, float *dinv, uint32_t *blk, void *stream);
+/* Pointers into a contact-stage workspace (laid out for R rows, max_len) after mdf_cmap_csr_dev / mdf_dense_to_csr_masks_dev ran on it. */
+int mdf_cmap_ws_view(void *workspace, size_t workspace_bytes, int64_t R, int32_t max_len, const uint64_t **masks, int32_t *W,
+                     const int32_t **counts);
+
 /* GraphConv stack for R residue rows.  Output: per-group (MDF_GROUP_ROWS rows) partial sums of concat(H1,H2,H3):
  * partial (R/32, feature_dim) f32 -- the deterministic first level of the sum pooling (H3 itself never reaches HBM).
  * workspace: mdf_gcn_workspace_bytes(model, R) bytes. */
 size_t mdf_gcn_workspace_bytes(const mdf_model *m, int64_t R);
 int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
                       int64_t R, float *partial, void *workspace, size_t workspace_bytes, void *stream);
+/* ... with the aggregation kernels chosen per protein as `agg` says (NULL: the CSR gather for every row, = mdf_gcn_embed_dev) */
+int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
+                          int64_t R, const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, void *stream);
 
 /* The same stage for a model with a language-model branch (lm_dim > 0): X0 = relu(lm_h.W_lm + b_lm + W_aa[seq_idx]) on the
  * MFMA GEMM (table row added in the epilogue), then every GraphConv layer as A.X + H.W (layer 1 over `embed` channels).
  * seq_idx (R) from mdf_seq_encode_dev, lm_h (R, lm_dim) from mdf_lm_forward_dev.  workspace: mdf_gcn_workspace_bytes. */
 int mdf_gcn_embed_lm_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h, const int32_t *rowptr, const int32_t *colidx,
                          const float *val, int64_t R, float *partial, void *workspace, size_t workspace_bytes, void *stream);
+int mdf_gcn_embed_lm_agg_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h, const int32_t *rowptr, const int32_t *colidx,
+                             const float *val, int64_t R, const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes,
+                             void *stream);
 
 /* Second level of the sum pooling: pooled[p] = sum of partial[g] over g in [grp_off[p], grp_off[p+1])  -> (B, feature_dim).
  * grp_off (B+1, int32, device) counts groups (row_off / MDF_GROUP_ROWS, plus the group base of the protein's chunk when the

@@ -615,7 +615,8 @@ __global__ __launch_bounds__(256) void k_dense_rows(const void *__restrict__ cma
                                                     const int32_t *__restrict__ row_off, int B, int32_t *__restrict__ counts,
                                                     float *__restrict__ rowsum, int32_t *__restrict__ group_sum,
                                                     const int32_t *__restrict__ group_base, int32_t *__restrict__ rowptr,
-                                                    int32_t *__restrict__ colidx, float *__restrict__ val, int64_t nnz_cap)
+                                                    int32_t *__restrict__ colidx, float *__restrict__ val, int64_t nnz_cap,
+                                                    unsigned long long *__restrict__ masks, int W, int32_t *__restrict__ binary)
 {
     // block = 32 rows (two 16-row groups, possibly of two proteins), wave = 8 rows (sequentially)
     const int g = blockIdx.x, row0 = g * 32;
@@ -658,14 +659,19 @@ __global__ __launch_bounds__(256) void k_dense_rows(const void *__restrict__ cma
             int c = 0;
             float s = 0.f;
             if (i < Lq) {
+                bool other = false;   // an entry that is neither 0 nor 1: the map is not a contact map in the binary sense
                 for (int j0 = 0; j0 < Lq; j0 += 64) {
                     const int j = j0 + lane;
                     float v = 0.f;
                     if (j < Lq) v = (i == j) ? 1.0f : load_cmap(A, dtype, (int64_t)i * Lq + j);
                     s += v;
-                    c += __popcll(__ballot(v != 0.0f));
+                    const unsigned long long nzm = __ballot(v != 0.0f);
+                    c += __popcll(nzm);
+                    other = other || (v != 0.0f && v != 1.0f);
+                    if (masks && lane == 0 && (j0 >> 6) < W) masks[(int64_t)row * W + (j0 >> 6)] = nzm;   // the row's contact bits, 64 columns per word
                 }
                 for (int d = 32; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);
+                if (binary && __ballot(other) != 0ull && lane == 0) atomicAnd(&binary[p], 0);
             }
             if (lane == 0) {
                 counts[row] = c;
@@ -1103,11 +1109,49 @@ int mdf_dense_to_csr_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_
     const int G = (int)(R / 32);
     hipLaunchKernelGGL(k_dense_rows<false>, dim3(G), dim3(256), 0, st, cmaps, cmap_dtype, cmap_off, Lq, row_off, B, w.counts,
                        w.rowsum, w.group_sum, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr,
-                       (int64_t)0);
+                       (int64_t)0, (unsigned long long *)nullptr, 0, (int32_t *)nullptr);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
     hipLaunchKernelGGL(k_dense_rows<true>, dim3(G), dim3(256), 0, st, cmaps, cmap_dtype, cmap_off, Lq, row_off, B, w.counts,
-                       w.rowsum, (int32_t *)nullptr, (const int32_t *)w.group_base, rowptr, colidx, val, nnz_cap);
+                       w.rowsum, (int32_t *)nullptr, (const int32_t *)w.group_base, rowptr, colidx, val, nnz_cap,
+                       (unsigned long long *)nullptr, 0, (int32_t *)nullptr);
     MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+int mdf_dense_to_csr_masks_dev(const void *cmaps, int cmap_dtype, const int64_t *cmap_off, const int32_t *Lq, const int32_t *row_off,
+                               int32_t B, int64_t R, int32_t max_len, int32_t *rowptr, int32_t *colidx, float *val, int64_t nnz_cap,
+                               int32_t *status, int32_t *binary, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (int rc = check_layout(B, R)) return rc;
+    MDF_REQUIRE(cmaps && cmap_off && Lq && row_off && rowptr && colidx && val && status && binary && workspace, "dense_to_csr_masks_dev: NULL argument");
+    MDF_REQUIRE(cmap_dtype >= MDF_DT_I32 && cmap_dtype <= MDF_DT_U8, "dense_to_csr_masks_dev: unknown dtype %d", cmap_dtype);
+    MDF_REQUIRE(nnz_cap > 0 && nnz_cap < 0x7fffffff && max_len > 0, "dense_to_csr_masks_dev: nnz_cap / max_len out of range");
+    CmapWs w;
+    if (!carve_cmap_ws(workspace, workspace_bytes, R, max_len, w))
+        return fail(MDF_ECAPACITY, "dense_to_csr_masks_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, cmap_ws_bytes(B, R, max_len));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int G = (int)(R / 32);
+    MDF_HIP(hipMemsetAsync(binary, 1, (size_t)B * 4, st));   // every byte 1: non-zero = "binary until an entry says otherwise"
+    hipLaunchKernelGGL(k_dense_rows<false>, dim3(G), dim3(256), 0, st, cmaps, cmap_dtype, cmap_off, Lq, row_off, B, w.counts,
+                       w.rowsum, w.group_sum, (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (float *)nullptr,
+                       (int64_t)0, w.masks, mask_words(max_len), binary);
+    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
+    hipLaunchKernelGGL(k_dense_rows<true>, dim3(G), dim3(256), 0, st, cmaps, cmap_dtype, cmap_off, Lq, row_off, B, w.counts,
+                       w.rowsum, (int32_t *)nullptr, (const int32_t *)w.group_base, rowptr, colidx, val, nnz_cap,
+                       (unsigned long long *)nullptr, 0, (int32_t *)nullptr);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+int mdf_cmap_ws_view(void *workspace, size_t workspace_bytes, int64_t R, int32_t max_len, const uint64_t **masks, int32_t *W,
+                     const int32_t **counts)
+{
+    MDF_REQUIRE(workspace && masks && W && counts && R > 0 && max_len > 0, "cmap_ws_view: bad argument");
+    CmapWs w;
+    if (!carve_cmap_ws(workspace, workspace_bytes, R, max_len, w)) return fail(MDF_ECAPACITY, "cmap_ws_view: the workspace is too small for this layout");
+    *masks = reinterpret_cast<const uint64_t *>(w.masks);
+    *W = mask_words(max_len);
+    *counts = w.counts;
     return MDF_OK;
 }
 

@@ -25,6 +25,11 @@ struct PlanChunk {
     int32_t segment;
     int64_t group_base;
     int32_t max_len;   // longest query of the chunk: sizes the contact-bit words of ITS rows
+    // which aggregation kernel takes which protein of the chunk (mdfri.h mdf_agg_desc): by length alone -- the maps of the fused path are binary
+    int64_t plist_pos;          // position of the chunk's list of matrix-pipe proteins (chunk-local indices) in mdf_plan::agg_plist
+    int32_t n_mf;               // proteins of at most MDF_AGG_MAX_LEN residues
+    int64_t tail_row0;          // first row behind the last protein's padded rows
+    std::vector<int32_t> csr_seg;   // (first row, row count) pairs of the rows of longer proteins: the CSR gather
 };
 struct PlanSegment {
     int32_t p0, p1;
@@ -43,13 +48,13 @@ struct mdf_plan {
     uint64_t serial = 0;
     int32_t B = 0, max_rows = 0, max_segment_groups = 0, max_len = 0;
     int64_t max_chunk_rows = 0, max_groups = 0;
-    std::vector<int32_t> Lq, chunk_row_off, grp_off;
+    std::vector<int32_t> Lq, chunk_row_off, grp_off, agg_plist;
     std::vector<PlanChunk> chunks;
     std::vector<PlanSegment> segments;
     // device mirror (created by the first engine call that uses the plan; one device per plan)
     mutable std::mutex mu;
     mutable int device = -1;
-    mutable int32_t *d_chunk_row_off = nullptr, *d_grp_off = nullptr;
+    mutable int32_t *d_chunk_row_off = nullptr, *d_grp_off = nullptr, *d_agg_plist = nullptr;
     // LSTM grouping, keyed by the engine parameters it depends on
     mutable int64_t lm_key[3] = {-1, -1, -1};
     mutable std::vector<LmGroup> lm_groups;
@@ -133,6 +138,23 @@ extern "C" int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, i
             return (int)R;
         }
         ch.rows = R;
+        {   // aggregation kernels by protein length
+            const int32_t *ro = pl->chunk_row_off.data() + ch.row_off_pos;
+            ch.plist_pos = (int64_t)pl->agg_plist.size();
+            for (int32_t p = p0; p < p1; ++p) {
+                if (Lq[p] <= MDF_AGG_MAX_LEN) {
+                    pl->agg_plist.push_back(p - p0);
+                } else if (!ch.csr_seg.empty() && ch.csr_seg[ch.csr_seg.size() - 2] + ch.csr_seg.back() == ro[p - p0]) {
+                    ch.csr_seg.back() += ro[p - p0 + 1] - ro[p - p0];          // adjacent to the previous long protein: one launch
+                } else {
+                    ch.csr_seg.push_back(ro[p - p0]);
+                    ch.csr_seg.push_back(ro[p - p0 + 1] - ro[p - p0]);
+                }
+            }
+            ch.n_mf = (int32_t)((int64_t)pl->agg_plist.size() - ch.plist_pos);
+            const int32_t last = p1 - 1 - p0;
+            ch.tail_row0 = (int64_t)ro[last] + ((int64_t)Lq[p1 - 1] + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+        }
         pl->chunks.push_back(ch);
         pl->max_chunk_rows = std::max(pl->max_chunk_rows, R);
         pl->max_len = std::max(pl->max_len, ml);
@@ -232,18 +254,20 @@ static int plan_mirror(const mdf_plan *pl, int device, hipStream_t st)
         pl->d_lm_rows = nullptr;
         pl->lm_key[0] = -1;
     }
-    const size_t n1 = pl->chunk_row_off.size(), n2 = pl->grp_off.size();
+    const size_t n1 = pl->chunk_row_off.size(), n2 = pl->grp_off.size(), n3 = pl->agg_plist.size();
     int32_t *d = nullptr;
-    MDF_HIP(plan_alloc(reinterpret_cast<void **>(&d), (n1 + n2) * 4 + 256, st));
+    MDF_HIP(plan_alloc(reinterpret_cast<void **>(&d), (n1 + n2 + n3) * 4 + 256, st));
     // the sources are the plan's own vectors (pageable: the runtime stages them before it returns); the copies sit in the stream in
     // front of the kernels that read the mirror
     if (hipMemcpyAsync(d, pl->chunk_row_off.data(), n1 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(d + n1, pl->grp_off.data(), n2 * 4, hipMemcpyHostToDevice, st) != hipSuccess) {
+        hipMemcpyAsync(d + n1, pl->grp_off.data(), n2 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
+        (n3 && hipMemcpyAsync(d + n1 + n2, pl->agg_plist.data(), n3 * 4, hipMemcpyHostToDevice, st) != hipSuccess)) {
         plan_release(d, st);
         return fail(MDF_ENODEVICE, "plan: upload of the descriptor arrays failed");
     }
     pl->d_chunk_row_off = d;
     pl->d_grp_off = d + n1;
+    pl->d_agg_plist = d + n1 + n2;
     pl->device = device;
     return MDF_OK;
 }
@@ -378,7 +402,7 @@ struct mdf_engine {
     // the contact stage's outputs exist twice: while the GraphConv stacks of chunk c read one set, the contact stage of chunk
     // c+1 fills the other on a second stream (pipelined fused path); everything else uses set 0
     struct ContactSet {
-        DevBuf rowptr, colidx, val, seq_idx, lsum, cws;
+        DevBuf rowptr, colidx, val, seq_idx, lsum, cws, dinv, blk;   // dinv / blk: operands of the matrix-pipe aggregation (mdf_agg_prepare_dev)
         hipEvent_t ready = nullptr, free = nullptr;
     } cs[2];
     hipStream_t aux = nullptr;        // low-priority stream of the pipelined contact stage
@@ -492,7 +516,7 @@ extern "C" void mdf_engine_free(mdf_engine *e)
     drop_graphs(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (auto &c : e->cs) {
-        for (DevBuf *b : {&c.rowptr, &c.colidx, &c.val, &c.seq_idx, &c.lsum, &c.cws}) b->release();
+        for (DevBuf *b : {&c.rowptr, &c.colidx, &c.val, &c.seq_idx, &c.lsum, &c.cws, &c.dinv, &c.blk}) b->release();
         if (c.ready) (void)hipEventDestroy(c.ready);
         if (c.free) (void)hipEventDestroy(c.free);
     }
@@ -543,6 +567,8 @@ static int ensure(mdf_engine *e, int64_t rows, int32_t B, int32_t max_len, int64
             if (int rc = c.seq_idx.grow((size_t)rows, gen)) return rc;
             if (int rc = c.lsum.grow((size_t)rows * 32 * 4, gen)) return rc;
             if (int rc = c.cws.grow(mdf_cmap_workspace_bytes(1 << 20, rows, max_len), gen)) return rc;
+            if (int rc = c.dinv.grow((size_t)rows * 4, gen)) return rc;
+            if (int rc = c.blk.grow((size_t)(rows / GROUP_ROWS + 1) * 16 * 4, gen)) return rc;   // at most rows / 16 proteins in a chunk
         }
         if (int rc = e->gws.grow(gws, gen)) return rc;
         e->rows_alloc = rows;
@@ -580,22 +606,54 @@ static int encode_chunk(mdf_engine *, const mdf_plan *pl, const mdf_batch_dev *b
 
 // letter sums once per chunk (shared by every head without a language model), then the GraphConv stack of each head; the
 // per-group partial sums land in the head's segment array
-static int gcn_chunk(mdf_engine *e, mdf_engine::ContactSet &c, const PlanChunk &ch, const uint8_t *seq_ptr, const std::vector<const float *> &lm_h,
-                     bool have_lsum, hipStream_t st)
+// Which aggregation kernel takes which protein of a chunk when that is not a function of the lengths alone (dense maps: a map that is
+// not binary keeps the CSR gather): replaces the plan's lists for one chunk.
+struct AggOverride {
+    const int32_t *d_plist = nullptr;
+    int32_t n_mf = 0;
+    bool last_listed = false;   // the chunk's last protein is on the list
+    std::vector<int32_t> csr_seg;
+};
+
+// `bits`: the contact set's workspace holds this chunk's contact bits and degrees (the fused contact stage ran on it with (ch.rows,
+// ch.max_len)): proteins of at most MDF_AGG_MAX_LEN residues then aggregate on the matrix pipe, the others through the CSR gather
+static int gcn_chunk(mdf_engine *e, mdf_engine::ContactSet &c, const mdf_plan *pl, const mdf_batch_dev *b, const PlanChunk &ch, const uint8_t *seq_ptr,
+                     const std::vector<const float *> &lm_h, bool have_lsum, bool bits, hipStream_t st, const AggOverride *ov = nullptr)
 {
     if (!have_lsum && e->want_lsum)
         if (int rc = mdf_letter_sums_dev(seq_ptr, c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), ch.rows, c.lsum.as<float>(), st))
             return rc;
+    mdf_agg_desc agg;
+    memset(&agg, 0, sizeof(agg));
+    const mdf_agg_desc *aggp = nullptr;
+    if (bits && (ov ? ov->n_mf : ch.n_mf) > 0) {
+        const uint64_t *masks = nullptr;
+        const int32_t *counts = nullptr;
+        int32_t W = 0;
+        if (int rc = mdf_cmap_ws_view(c.cws.p, c.cws.bytes, ch.rows, ch.max_len, &masks, &W, &counts)) return rc;
+        const int32_t *d_ro = pl->d_chunk_row_off + ch.row_off_pos, *d_lq = b->Lq + ch.p0;
+        if (int rc = mdf_agg_prepare_dev(masks, W, counts, d_ro, d_lq, ch.p1 - ch.p0, ch.rows, c.dinv.as<float>(), c.blk.as<uint32_t>(), st)) return rc;
+        agg.masks = masks, agg.W = W, agg.dinv = c.dinv.as<float>(), agg.blk = c.blk.as<uint32_t>();
+        agg.row_off = d_ro, agg.Lq = d_lq, agg.plist = pl->d_agg_plist + ch.plist_pos, agg.n_mf = ch.n_mf;
+        agg.csr_seg = ch.csr_seg.data(), agg.n_seg = (int32_t)(ch.csr_seg.size() / 2), agg.tail_row0 = ch.tail_row0;
+        if (ov) agg.plist = ov->d_plist, agg.n_mf = ov->n_mf, agg.csr_seg = ov->csr_seg.data(), agg.n_seg = (int32_t)(ov->csr_seg.size() / 2);
+        // the rows behind the last protein: its workgroups zero them when it is on the matrix-pipe list; otherwise the gather segment of that
+        // (long or non-binary) protein runs to the end of the rows and writes zeros there (empty CSR rows)
+        const int32_t last = ch.p1 - ch.p0 - 1;
+        const bool last_listed = ov ? ov->last_listed : pl->Lq[(size_t)ch.p1 - 1] <= MDF_AGG_MAX_LEN;
+        agg.tail_p = last_listed ? last : 0x7fffffff;
+        aggp = &agg;
+    }
     for (size_t k = 0; k < e->models.size(); ++k) {
         mdf_model *m = e->models[k];
         float *part = e->partial[k].as<float>() + (size_t)ch.group_base * (size_t)mdf_model_feature_dim(m);
         int rc;
         if (e->model_lm[k] < 0)
-            rc = mdf_gcn_embed_dev(m, c.lsum.as<float>(), c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), ch.rows, part, e->gws.p,
-                                   e->gws.bytes, st);
+            rc = mdf_gcn_embed_agg_dev(m, c.lsum.as<float>(), c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), ch.rows, aggp, part,
+                                       e->gws.p, e->gws.bytes, st);
         else
-            rc = mdf_gcn_embed_lm_dev(m, seq_ptr, lm_h[(size_t)e->model_lm[k]], c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), ch.rows,
-                                      part, e->gws.p, e->gws.bytes, st);
+            rc = mdf_gcn_embed_lm_agg_dev(m, seq_ptr, lm_h[(size_t)e->model_lm[k]], c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(),
+                                          ch.rows, aggp, part, e->gws.p, e->gws.bytes, st);
         if (rc) return rc;
     }
     return MDF_OK;
@@ -612,7 +670,8 @@ static int pool_segment(mdf_engine *e, const mdf_plan *pl, const PlanSegment &sg
     return MDF_OK;
 }
 
-using BuildCsr = std::function<int(int ci, const PlanChunk &ch, const uint8_t *seq_ptr, bool *have_lsum)>;
+// (have_lsum: the stage also produced the layer-1 letter sums; bits: it left the contact bits + degrees in the set's workspace)
+using BuildCsr = std::function<int(int ci, const PlanChunk &ch, const uint8_t *seq_ptr, bool *have_lsum, bool *bits, const AggOverride **ov)>;
 
 // Common driver: per chunk the residue indices are encoded, `build_csr` writes the adjacency (saying whether it also produced
 // the layer-1 letter sums), then the GCN stack runs; segments are pooled as soon as their last chunk has been issued.  With a
@@ -626,9 +685,10 @@ static int run_chunks(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b,
         const PlanChunk &ch = pl->chunks[(size_t)ci];
         e->last_rows = ch.rows;
         e->last_set = 0;
-        bool have_lsum = false;
-        if (int rc = build_csr(ci, ch, seq_ptr, &have_lsum)) return rc;
-        if (int rc = gcn_chunk(e, e->cs[0], ch, seq_ptr, lm_ptr, have_lsum, st)) return rc;
+        bool have_lsum = false, bits = false;
+        const AggOverride *ov = nullptr;
+        if (int rc = build_csr(ci, ch, seq_ptr, &have_lsum, &bits, &ov)) return rc;
+        if (int rc = gcn_chunk(e, e->cs[0], pl, b, ch, seq_ptr, lm_ptr, have_lsum, bits, st, ov)) return rc;
         if (ci + 1 == nC || pl->chunks[(size_t)ci + 1].segment != ch.segment) return pool_segment(e, pl, pl->segments[(size_t)ch.segment], st);
         return MDF_OK;
     };
@@ -694,9 +754,10 @@ static int forward_alignments_eager(mdf_engine *e, const mdf_plan *pl, const mdf
                                     hipStream_t st)
 {
     if (!e->pipeline_contact) {
-        BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *seq_ptr, bool *have_lsum) -> int {
+        BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *seq_ptr, bool *have_lsum, bool *bits, const AggOverride **) -> int {
             // contact stage: coordinates read once; the CSR fill also writes the layer-1 letter sums of the chunk
             *have_lsum = e->want_lsum;
+            *bits = true;
             mdf_engine::ContactSet &c = e->cs[0];
             return mdf_cmap_csr_dev(b->coords, b->coord_off + ch.p0, b->q_aln, b->t_aln, b->aln_off + ch.p0, b->Lq + ch.p0,
                                     pl->d_chunk_row_off + ch.row_off_pos, ch.p1 - ch.p0, ch.rows, ch.max_len, e->cfg.threshold, e->cfg.generated_contacts,
@@ -730,7 +791,7 @@ static int forward_alignments_eager(mdf_engine *e, const mdf_plan *pl, const mdf
         MDF_HIP(hipStreamWaitEvent(st, cur.ready, 0));
         e->last_rows = ch.rows;
         e->last_set = ci & 1;
-        if (int rc = gcn_chunk(e, cur, ch, cur.seq_idx.as<uint8_t>(), no_lm, /*have_lsum=*/e->want_lsum, st)) return rc;
+        if (int rc = gcn_chunk(e, cur, pl, b, ch, cur.seq_idx.as<uint8_t>(), no_lm, /*have_lsum=*/e->want_lsum, /*bits=*/true, st)) return rc;
         if (ci + 1 == nC || pl->chunks[(size_t)ci + 1].segment != ch.segment)
             if (int rc = pool_segment(e, pl, pl->segments[(size_t)ch.segment], st)) return rc;
         MDF_HIP(hipEventRecord(cur.free, st));
@@ -896,7 +957,7 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
     MDF_HIP(g.err);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (int rc = plan_mirror(pl, e->device, st)) return rc;
-    if (int rc = ensure(e, pl->max_chunk_rows, pl->B, 0, pl->max_groups)) return rc;
+    if (int rc = ensure(e, pl->max_chunk_rows, pl->B, pl->max_len, pl->max_groups)) return rc;   // (max_len: the workspace also takes the contact bits)
     for (int i = 0; i < 2; ++i) {
         if (!e->map_ev[i]) MDF_HIP(hipEventCreateWithFlags(&e->map_ev[i], hipEventDisableTiming));
         if (!e->map_up_ev[i]) MDF_HIP(hipEventCreateWithFlags(&e->map_up_ev[i], hipEventDisableTiming));
@@ -906,15 +967,20 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         MDF_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         MDF_HIP(hipStreamCreateWithPriority(&e->map_stream, hipStreamNonBlocking, hi));
     }
+    if (int rc = e->flags.grow((size_t)pl->B * 4, &e->generation)) return rc;   // per-protein "binary" flags the dense stage writes on the device (the host lists decide here)
     int parity = 0;
     bool used[2] = {false, false};
-    BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *, bool *have_lsum) -> int {
+    AggOverride aov;
+    BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *, bool *have_lsum, bool *bits, const AggOverride **ov) -> int {
         *have_lsum = false;
+        *bits = true;    // the contact bits are left in the workspace; a map that is not binary keeps the CSR gather (decided below, on the host)
+        *ov = &aov;
         const int32_t Bc = ch.p1 - ch.p0;
         // pack the chunk's maps + their element offsets into pinned memory: [offsets (Bc x int64) | maps]
         size_t elems = 0;
         for (int32_t p = ch.p0; p < ch.p1; ++p) elems += (size_t)pl->Lq[(size_t)p] * (size_t)pl->Lq[(size_t)p];
-        const size_t o_maps = align_up((size_t)Bc * 8, 256), total = o_maps + elems * 4;
+        // pinned block: [offsets (Bc x int64) | maps | list of the proteins the matrix-pipe aggregation takes (<= Bc x int32)]
+        const size_t o_maps = align_up((size_t)Bc * 8, 256), o_plist = align_up(o_maps + elems * 4, 256), total = o_plist + (size_t)Bc * 4;
         const int s = parity;
         parity ^= 1;
         if (used[s]) MDF_HIP(hipEventSynchronize(e->map_ev[s]));   // the kernels that read this slot two chunks ago are done
@@ -937,17 +1003,25 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         // as long as the device needs for the chunk -- the proteins are dealt to a few host threads
         const int nt = (int)std::max<int64_t>(1, std::min<int64_t>({(int64_t)host_copy_threads(), (int64_t)Bc, (int64_t)(elems >> 20) + 1}));
         std::vector<int64_t> nz_part((size_t)nt, 0);
+        std::vector<uint8_t> other((size_t)Bc, 0);   // the map holds an entry off the diagonal that is neither 0 nor 1: not a binary contact map
         auto work = [&](int k) {
             int64_t nz = 0;
             for (int32_t p = ch.p0 + k; p < ch.p1; p += nt) {
-                const size_t n = (size_t)pl->Lq[(size_t)p] * (size_t)pl->Lq[(size_t)p];
+                const size_t Lp = (size_t)pl->Lq[(size_t)p], n = Lp * Lp;
                 char *to = dst + (size_t)offs[p - ch.p0] * 4;
                 memcpy(to, cmaps_host[p], n * 4);
                 const uint32_t *w = reinterpret_cast<const uint32_t *>(to);
+                uint32_t odd = 0;
                 if (cmap_dtype == MDF_DT_I32) {
-                    for (size_t i = 0; i < n; ++i) nz += w[i] != 0;
+                    for (size_t i = 0; i < n; ++i) nz += w[i] != 0, odd |= w[i] > 1u;
+                    if (odd)   // (rare) tell an odd diagonal -- the kernels force the diagonal to 1 whatever it holds -- from an odd entry elsewhere
+                        for (size_t i = 0, hits = 0; i < n && !hits; ++i)
+                            if (w[i] > 1u && i % (Lp + 1) != 0) other[(size_t)(p - ch.p0)] = 1, hits = 1;
                 } else {
-                    for (size_t i = 0; i < n; ++i) nz += (w[i] << 1) != 0;   // +0.0 and -0.0 are zeros
+                    for (size_t i = 0; i < n; ++i) nz += (w[i] << 1) != 0, odd |= (uint32_t)((w[i] << 1) != 0 && w[i] != 0x3f800000u);   // +0.0 and -0.0 are zeros
+                    if (odd)
+                        for (size_t i = 0, hits = 0; i < n && !hits; ++i)
+                            if ((w[i] << 1) != 0 && w[i] != 0x3f800000u && i % (Lp + 1) != 0) other[(size_t)(p - ch.p0)] = 1, hits = 1;
                 }
             }
             nz_part[(size_t)k] = nz;
@@ -968,14 +1042,34 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
             }
             e->nnz_cap = nnz_needed;
         }
+        // aggregation kernel per protein: binary map and at most MDF_AGG_MAX_LEN residues -> the matrix pipe; the rest -> CSR gather segments
+        {
+            int32_t *plist = reinterpret_cast<int32_t *>(e->map_pin[s] + o_plist);
+            const int32_t *ro = pl->chunk_row_off.data() + ch.row_off_pos;
+            aov.n_mf = 0;
+            aov.csr_seg.clear();
+            for (int32_t q = 0; q < Bc; ++q) {
+                if (pl->Lq[(size_t)(ch.p0 + q)] <= MDF_AGG_MAX_LEN && !other[(size_t)q]) {
+                    plist[aov.n_mf++] = q;
+                } else if (!aov.csr_seg.empty() && aov.csr_seg[aov.csr_seg.size() - 2] + aov.csr_seg.back() == ro[q]) {
+                    aov.csr_seg.back() += ro[q + 1] - ro[q];
+                } else {
+                    aov.csr_seg.push_back(ro[q]);
+                    aov.csr_seg.push_back(ro[q + 1] - ro[q]);
+                }
+            }
+            aov.last_listed = aov.n_mf > 0 && plist[aov.n_mf - 1] == Bc - 1;
+            aov.d_plist = reinterpret_cast<const int32_t *>(e->map_dev[s].as<char>() + o_plist);
+        }
         char *d = e->map_dev[s].as<char>();
         // the device slot is free (map_ev[s] was waited for above): the upload overlaps whatever the compute stream is still doing
         MDF_HIP(hipMemcpyAsync(d, e->map_pin[s], total, hipMemcpyHostToDevice, e->map_stream));
         MDF_HIP(hipEventRecord(e->map_up_ev[s], e->map_stream));
         MDF_HIP(hipStreamWaitEvent(st, e->map_up_ev[s], 0));
-        const int rc = mdf_dense_to_csr_dev(d + o_maps, cmap_dtype, reinterpret_cast<const int64_t *>(d), b->Lq + ch.p0, pl->d_chunk_row_off + ch.row_off_pos,
-                                            Bc, ch.rows, e->cs[0].rowptr.as<int32_t>(), e->cs[0].colidx.as<int32_t>(), e->cs[0].val.as<float>(), e->nnz_cap,
-                                            b->status + 4 * ci, e->cs[0].cws.p, e->cs[0].cws.bytes, st);
+        const int rc = mdf_dense_to_csr_masks_dev(d + o_maps, cmap_dtype, reinterpret_cast<const int64_t *>(d), b->Lq + ch.p0,
+                                                  pl->d_chunk_row_off + ch.row_off_pos, Bc, ch.rows, ch.max_len, e->cs[0].rowptr.as<int32_t>(),
+                                                  e->cs[0].colidx.as<int32_t>(), e->cs[0].val.as<float>(), e->nnz_cap, b->status + 4 * ci,
+                                                  e->flags.as<int32_t>(), e->cs[0].cws.p, e->cs[0].cws.bytes, st);
         if (rc) return rc;
         MDF_HIP(hipEventRecord(e->map_ev[s], st));
         used[s] = true;

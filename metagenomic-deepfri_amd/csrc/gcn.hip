@@ -722,16 +722,18 @@ __global__ __launch_bounds__(64) void k_gemv_f32(const float *__restrict__ A, in
 template <int C>
 __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, const int32_t *__restrict__ rowptr,
                                                    const int32_t *__restrict__ colidx, const float *__restrict__ val,
-                                                   float *__restrict__ out, int R, int sb_log, int nt_store)
+                                                   float *__restrict__ out, int row0, int R, int sb_log, int nt_store,
+                                                   const int32_t *__restrict__ skip_if)
 {
     constexpr int NV = C / 256;
+    if (skip_if && *skip_if != 0) return;   // single-protein calls: the matrix-pipe kernel has this protein (its map is binary)
     // XCD placement (block b runs on XCD b%8): a 2^sb_log-row super-block stays on one XCD, so that the neighbour rows
     // its blocks gather are, for the most part, fetched into that XCD's L2 once.
     const int b = blockIdx.x, x = b & 7, q = b >> 3;
     const int per_sb = 1 << (sb_log - 2);                  // blocks (4 rows each) per super-block
     const int sb = (q / per_sb) * 8 + x;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int row = (sb << sb_log) + (q % per_sb) * 4 + wid;
+    const int row = row0 + (sb << sb_log) + (q % per_sb) * 4 + wid;   // rows [row0, R) of this launch
     if (row >= R) return;
     const int lane = threadIdx.x & 63;
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
@@ -786,6 +788,199 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, 
 #pragma unroll
         for (int v = 0; v < NV; ++v) *reinterpret_cast<float4 *>(out + (size_t)row * C + v * 256 + lane * 4) = acc[v];
     }
+}
+
+// ---- A.X on the matrix pipe (binary contact maps, proteins of at most MDF_AGG_MAX_LEN residues; mdfri.h `mdf_agg_desc`) ------------
+//   out[i, :] = d_i * sum_j A'[i, j] * (d_j * H[j, :])
+// k_aggregate gathers ~12.6 neighbour rows of 2 KiB per output row through L1 (6.7x the algorithmic bytes cross L2 -> L1, and that
+// path, not HBM, bounds it).  Here every H element crosses L1 ONCE: a workgroup owns (protein, 32-channel slab), streams the
+// protein's rows through LDS in chunks of 256 rows, and multiplies by the contact BITS on the bf16 matrix pipe.  Exact: A' is 0/1,
+// hence exact in bf16; x = d_j * h is split into three bf16 terms hi + mid + lo whose sum IS x (8 + 8 + 8 = 24 significand bits),
+// every product 1 * term is exact and the pipe accumulates in fp32 -- the same fp32 sum as the gather's, in another order (and the
+// same for a protein alone and inside a batch: nothing here depends on the protein's place).  All-zero 32 x 16 blocks of A' are skipped
+// through a precomputed bitmap (k_agg_prepare): ~6.5 of 32 column blocks per row block are populated at 6 A.
+// A wave64 VALU instruction costs four cycles: the matrix phase keeps to ~11 of them per populated block (contact byte -> A fragment
+// through a 256-entry LDS table, fragment addresses as one xor); a per-lane "is this block populated" test was 10x that.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int AGG_SL = 32;        // channels of a workgroup's slab (one 32 x 32 MFMA tile wide)
+constexpr int AGG_CHR = 256;      // rows of the protein in LDS at a time (8 waves x 32 rows)
+constexpr int AGG_OPITCH = 40;    // floats per row of a wave's output staging tile (the two lane halves hit disjoint banks)
+constexpr int AGG_THREADS = 512;
+
+// bf16 terms of an fp32 value: hi = x with the low 16 bits cleared, mid = (x - hi) likewise, lo = x - hi - mid (at most 8 significant
+// bits: exact in bf16).  hi + mid + lo == x (barring underflow of the residuals below 2^-126).
+__device__ __forceinline__ void agg_split3(float x, unsigned short &hi, unsigned short &mid, unsigned short &lo)
+{
+    const unsigned xb = __float_as_uint(x);
+    const float r1 = x - __uint_as_float(xb & 0xffff0000u);
+    const unsigned rb = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(rb & 0xffff0000u);
+    hi = (unsigned short)(xb >> 16);
+    mid = (unsigned short)(rb >> 16);
+    lo = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+// LDS image Xt[term][channel][row] bf16: a (term, channel) line holds AGG_CHR rows = 32 slots of 16 bytes; slot s of channel c lives at
+// slot s ^ (c & 15): a fragment read (32 channels x one slot) is conflict-free, the split's writes two-way.
+__device__ __forceinline__ int agg_xt_off(int term, int ch, int slot) { return ((term * AGG_SL + ch) * (AGG_CHR / 8) + (slot ^ (ch & 15))) * 8; }
+
+// ROWBLOCKS: 32-row blocks of a protein per wave, dealt round robin (block b of wave w = rows [32 (8 b + w), +32)): L <= 256 ROWBLOCKS
+template <int ROWBLOCKS>
+__global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const unsigned long long *__restrict__ masks,
+                                                                   int W, const float *__restrict__ dinv, const uint32_t *__restrict__ blk,
+                                                                   const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq,
+                                                                   const int32_t *__restrict__ plist, const int32_t *__restrict__ gate,
+                                                                   float *__restrict__ out, int tail_p, int tail_row0, int R)
+{
+    __shared__ __attribute__((aligned(16))) unsigned short xt[3 * AGG_SL * AGG_CHR];   // 48 KiB; re-used as 8 x 5 KiB output staging at the end
+    __shared__ __attribute__((aligned(16))) unsigned short lut[256 * 8];                // contact byte -> its 8 bf16 (0.0 / 1.0): one ds_read_b128
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const int slabs = C / AGG_SL;
+    const int p = plist[blockIdx.x / slabs], slab = blockIdx.x % slabs;
+    if (gate && gate[p] == 0) return;                            // not a binary map: the CSR gather launch takes this protein
+    const int r0 = row_off[p], L = Lq[p];
+    for (int e = threadIdx.x; e < 256 * 8; e += AGG_THREADS) lut[e] = ((e >> 3) >> (e & 7)) & 1 ? 0x3f80 : 0;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int frow = lane & 31, half = lane >> 5;
+    const int oct = threadIdx.x >> 4, cp = threadIdx.x & 15;     // staging role: rows 8 oct .. 8 oct + 7 of the chunk, channels 2 cp, 2 cp + 1
+    f32x16 acc[ROWBLOCKS];
+#pragma unroll
+    for (int b = 0; b < ROWBLOCKS; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+    const float *Hs = H + (size_t)r0 * C + slab * AGG_SL;
+    for (int j0 = 0; j0 < L; j0 += AGG_CHR) {
+        // ---- requests of this chunk: the rows to stage (scaled by d_j), and the contact bits of its 256 columns for the wave's row blocks
+        v2f x[8];
+        {
+            const int jb = j0 + oct * 8;
+            v4f d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+            if (jb < L) {   // (a protein's rows are padded to a multiple of 16: dinv is readable up to jb + 7)
+                d0 = *reinterpret_cast<const v4f *>(dinv + r0 + jb);
+                d1 = *reinterpret_cast<const v4f *>(dinv + r0 + jb + 4);
+            }
+            const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = jb + k;
+                const v2f h = j < L ? *reinterpret_cast<const v2f *>(Hs + (size_t)j * C + cp * 2) : (v2f){0, 0};
+                x[k] = h * dd[k];
+            }
+        }
+        unsigned long long mw0[ROWBLOCKS], mw1[ROWBLOCKS], mw2[ROWBLOCKS], mw3[ROWBLOCKS];
+#pragma unroll
+        for (int b = 0; b < ROWBLOCKS; ++b) {
+            const int i = (b * 8 + wid) * 32 + frow;
+            const unsigned long long *mrow = masks + (size_t)(r0 + i) * W + (j0 >> 6);
+            mw0[b] = i < L ? mrow[0] : 0ull;
+            mw1[b] = (i < L && j0 + 64 < L) ? mrow[1] : 0ull;
+            mw2[b] = (i < L && j0 + 128 < L) ? mrow[2] : 0ull;
+            mw3[b] = (i < L && j0 + 192 < L) ? mrow[3] : 0ull;
+        }
+        __syncthreads();   // the previous chunk's fragments have been read (first chunk: the table is complete)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {   // this lane's 2 channels: 8 consecutive rows each = one 16-byte slot per term
+            bf16x8 th, tm, tl;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                unsigned short a, b, cc;
+                agg_split3(x[k][c], a, b, cc);
+                th[k] = (short)a, tm[k] = (short)b, tl[k] = (short)cc;
+            }
+            const int ch = cp * 2 + c;
+            *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(0, ch, oct)) = th;
+            *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(1, ch, oct)) = tm;
+            *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(2, ch, oct)) = tl;
+        }
+        __syncthreads();
+        // ---- every wave: its row blocks x the populated column blocks (16 rows of X each) of this chunk
+        const int fbase = (frow * (AGG_CHR / 8)) * 16;   // byte offset of this lane's channel line (term 0) ...
+        const int fx = frow & 15;                          // ... whose 16-byte slots are XOR-swizzled by this
+#pragma unroll
+        for (int b = 0; b < ROWBLOCKS; ++b) {
+            const int rb = b * 8 + wid;
+            if (rb * 32 >= L) break;   // (wave-uniform)
+            unsigned nz = (blk[(size_t)p * 16 + rb] >> (j0 >> 4)) & 0xffffu;
+            while (nz) {
+                const int cb = __builtin_ctz(nz);
+                nz &= nz - 1;
+                // the word holding column block cb, selected without an index (an indexed select of registers goes through scratch)
+                const unsigned long long s1 = 0ull - (unsigned long long)((cb >> 2) & 1), s2 = 0ull - (unsigned long long)((cb >> 3) & 1);
+                const unsigned long long m01 = mw0[b] ^ ((mw0[b] ^ mw1[b]) & s1), m23 = mw2[b] ^ ((mw2[b] ^ mw3[b]) & s1);
+                const unsigned long long word = m01 ^ ((m01 ^ m23) & s2);
+                const unsigned byte = (unsigned)(word >> ((cb & 3) * 16 + 8 * half)) & 0xffu;
+                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(lut + byte * 8);
+                const char *fp = reinterpret_cast<const char *>(xt) + fbase + (((cb * 2 + half) ^ fx) << 4);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(fp);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(fp + AGG_SL * (AGG_CHR / 8) * 16);
+                const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(fp + 2 * AGG_SL * (AGG_CHR / 8) * 16);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the fragment reads first ...
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2, acc[b], 0, 0, 0);   // smallest addends first
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[b], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the three matrix instructions
+            }
+        }
+    }
+    // ---- out[i, slab] = d_i * acc through a wave-private LDS tile: a 32 x 32 result leaves as 16-byte stores, 8 rows x 128 B per
+    // instruction.  Rows [L, padded L) are written too (zeros): the H.W GEMM reads every row up to the next protein.
+    __syncthreads();   // every wave is done with the last chunk's fragments
+    float *ot = reinterpret_cast<float *>(xt) + wid * (32 * AGG_OPITCH);
+    float *Os = out + (size_t)r0 * C + slab * AGG_SL;
+    const int Lpad = (L + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+    const int orow = lane >> 3, oq = lane & 7;
+#pragma unroll
+    for (int b = 0; b < ROWBLOCKS; ++b) {
+        const int ib = (b * 8 + wid) * 32;
+        if (ib >= Lpad) break;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[((r & 3) + 8 * (r >> 2) + 4 * half) * AGG_OPITCH + frow] = acc[b][r];   // C layout: lane -> column, register -> row
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = ib + k * 8 + orow;
+            if (i < Lpad) {
+                const v4f v = *reinterpret_cast<const v4f *>(ot + (k * 8 + orow) * AGG_OPITCH + oq * 4) * (i < L ? dinv[r0 + i] : 0.0f);
+                __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(Os + (size_t)i * C + oq * 4));
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    // the rows behind the last protein of the launch (the chunk's rows are rounded up to 128) belong to nobody: zeroed by that protein's
+    // workgroups -- when the last protein is a long one, the gather over its rows covers them
+    if (p == tail_p) {
+        float *Ot = out + (size_t)slab * AGG_SL;
+        for (int e = threadIdx.x; e < (R - tail_row0) * (AGG_SL / 4); e += AGG_THREADS)
+            *reinterpret_cast<v4f *>(Ot + (size_t)(tail_row0 + e / (AGG_SL / 4)) * C + (e % (AGG_SL / 4)) * 4) = (v4f){0, 0, 0, 0};
+    }
+}
+
+// dinv[row] = 1 / (1e-6 + sqrt(degree)) for every row, and blk[p][b] = which 16-column blocks hold a contact of rows [32 b, 32 b + 32)
+// of protein p (proteins of at most MDF_AGG_MAX_LEN residues).  One wave per (protein, row block); grid.y = 16.
+__global__ __launch_bounds__(64) void k_agg_prepare(const unsigned long long *__restrict__ masks, int W, const int32_t *__restrict__ counts,
+                                                    const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq, float *__restrict__ dinv,
+                                                    uint32_t *__restrict__ blk)
+{
+    const int p = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int r0 = row_off[p], L = Lq[p], rows_end = row_off[p + 1] - r0;   // rows up to the next protein: padding included
+    // degrees -> factors, 64 rows per (p, b): the 16 blocks of a protein cover 1 024 rows, longer proteins loop
+    for (int i = b * 64 + lane; i < rows_end; i += 16 * 64) dinv[r0 + i] = i < L ? 1.0f / (1e-6f + sqrtf((float)counts[r0 + i])) : 0.0f;
+    if (L > MDF_AGG_MAX_LEN) return;
+    unsigned bits = 0;
+    const int i = b * 32 + (lane & 31);
+    if (i < L && lane < 32) {
+        const unsigned long long *mrow = masks + (size_t)(r0 + i) * W;
+        for (int w = 0; w * 64 < L; ++w) {
+            const unsigned long long m = mrow[w];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((m >> (16 * q)) & 0xffffull) bits |= 1u << (w * 4 + q);
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) bits |= __shfl_xor(bits, d, 64);
+    if (lane == 0) blk[(size_t)p * 16 + b] = bits;
 }
 
 // ---- layer 1 (folded embedding): H1[i, :] = elu(S[i, :26] . T1), S = Ahat . onehot, T1 = relu(W_aa) . W_gc1 (26 x C).  A contraction
@@ -1213,26 +1408,48 @@ static size_t gcn_ws_bytes(const mdf_model *m, int64_t R)
 
 // Ahat . H over `Cin` channels (k_aggregate)
 static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, const int32_t *colidx, const float *val, float *AH,
-                            int Ri, hipStream_t st, TimedKernel tk = TK_AX)
+                            int Ri, hipStream_t st, TimedKernel tk = TK_AX, const mdf_agg_desc *agg = nullptr)
 {
     ScopedTiming tm(tk, st);
+    static const int mfma_env = getenv("MDFRI_AX_MFMA") ? atoi(getenv("MDFRI_AX_MFMA")) : 1;   // developer knob: 0 = the CSR gather for every row
+    if (agg && !mfma_env) agg = nullptr;
     // developer knobs; defaults: 512-row super-blocks per XCD, and non-temporal output stores once input + output
     // slabs no longer fit the 256 MiB Infinity Cache together (measured: +12 % at 65536 rows, -2 % at 32768)
     static const int sb_log = getenv("MDFRI_AX_SB_LOG") ? atoi(getenv("MDFRI_AX_SB_LOG")) : 9;
     static const int nt_env = getenv("MDFRI_AX_NT") ? atoi(getenv("MDFRI_AX_NT")) : -1;
     const int nt_store = nt_env >= 0 ? nt_env : ((size_t)Ri * Cin * 8 > (size_t)200 << 20);
-    const int n_sb = (Ri + (1 << sb_log) - 1) >> sb_log;
-    const int blocks = 8 * (1 << (sb_log - 2)) * ((n_sb + 7) / 8);
-#define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, Ri, sb_log, nt_store)
-    if (Cin == 256) MDF_AX(256); else if (Cin == 512) MDF_AX(512); else MDF_AX(1024);
+    auto gather = [&](int row0, int row_end, const int32_t *skip_if) {   // the CSR gather over rows [row0, row_end)
+        const int n_sb = (row_end - row0 + (1 << sb_log) - 1) >> sb_log;
+        const int blocks = 8 * (1 << (sb_log - 2)) * ((n_sb + 7) / 8);
+#define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, row0, row_end, sb_log, nt_store, skip_if)
+        if (Cin == 256) MDF_AX(256); else if (Cin == 512) MDF_AX(512); else MDF_AX(1024);
 #undef MDF_AX
+    };
+    if (!agg) {
+        gather(0, Ri, nullptr);
+        MDF_HIP(hipGetLastError());
+        return MDF_OK;
+    }
+    // per protein: the matrix-pipe kernel for the listed ones (binary map, at most MDF_AGG_MAX_LEN residues), the gather for the row
+    // segments left over; rows behind the last protein are zeroed (the H.W GEMM reads every row)
+    if (agg->n_mf > 0) {
+        hipLaunchKernelGGL(k_aggregate_mfma<2>, dim3((unsigned)agg->n_mf * (unsigned)(Cin / AGG_SL)), dim3(AGG_THREADS), 0, st, Hin, Cin,
+                           reinterpret_cast<const unsigned long long *>(agg->masks), agg->W, agg->dinv, agg->blk, agg->row_off, agg->Lq, agg->plist,
+                           agg->gate, AH, agg->tail_p, (int)agg->tail_row0, Ri);
+    }
+    for (int k = 0; k < agg->n_seg; ++k) {
+        const int row0 = agg->csr_seg[2 * k], cnt = agg->csr_seg[2 * k + 1];
+        if (cnt > 0) gather(row0, row0 + cnt, agg->csr_gated ? agg->gate : nullptr);
+    }
+    // (tail_p < 0: nobody's workgroups zero the rows behind the last protein -- a gated single-protein call -- : done here)
+    if (agg->tail_p < 0 && agg->tail_row0 < Ri) MDF_HIP(hipMemsetAsync(AH + (size_t)agg->tail_row0 * Cin, 0, (size_t)(Ri - agg->tail_row0) * Cin * 4, st));
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
 
 // GraphConv layers 2..n_gc on top of H1 (in Hin): H_k = elu((Ahat . H_{k-1}) . W_k), pooled partial sums at `partial + off`
 static int gcn_upper_layers(mdf_model *m, float *Hin, float *Hout, float *AH, const int32_t *rowptr, const int32_t *colidx,
-                            const float *val, int Ri, float *partial, hipStream_t st)
+                            const float *val, int Ri, float *partial, hipStream_t st, const mdf_agg_desc *agg = nullptr)
 {
     const int feat = m->feat;
     int off = m->gc[0];
@@ -1242,7 +1459,7 @@ static int gcn_upper_layers(mdf_model *m, float *Hin, float *Hout, float *AH, co
         // touched) instead of the AH slab: measured -2 % on both A.X launches of a head (profiles/r04_cache_policy_probes.txt, "mid_dead")
         // (only for a launch whose GEMM stores nothing -- the last layer --, or the GEMM would write the slab it reads)
         if (k >= 2 && k == m->n_gc - 1) AH = Hout;
-        if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st, k >= 2 ? TK_AX3 : TK_AX)) return rc;
+        if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st, k >= 2 ? TK_AX3 : TK_AX, agg)) return rc;
         {
             ScopedTiming tm(k >= 2 ? TK_GEMM3 : TK_GEMM, st);
             const bool last = k == m->n_gc - 1;
@@ -1633,6 +1850,13 @@ int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_r
 int mdf_gcn_embed_lm_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h, const int32_t *rowptr, const int32_t *colidx,
                          const float *val, int64_t R, float *partial, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return mdf_gcn_embed_lm_agg_dev(m, seq_idx, lm_h, rowptr, colidx, val, R, nullptr, partial, workspace, workspace_bytes, stream);
+}
+
+int mdf_gcn_embed_lm_agg_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h, const int32_t *rowptr, const int32_t *colidx,
+                             const float *val, int64_t R, const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes,
+                             void *stream)
+{
     MDF_REQUIRE(m && seq_idx && lm_h && rowptr && colidx && val && partial && workspace, "gcn_embed_lm_dev: NULL argument");
     MDF_REQUIRE(m->lm_dim > 0, "gcn_embed_lm_dev: this model has no language-model branch; use mdf_gcn_embed_dev");
     MDF_REQUIRE(R > 0 && R % 128 == 0 && R < 0x7fffffff, "gcn_embed_lm_dev: bad row count %lld", (long long)R);
@@ -1656,7 +1880,7 @@ int mdf_gcn_embed_lm_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h
         if (int rc = launch_gemm<EPI_EMBED>(lm_h, m->lm_dim, m->Wlm_t, m->lm_dim, Ri, E, m->lm_dim, X0, E, nullptr, nullptr, 0, nullptr, E, st, a))
             return rc;
     }
-    if (int rc = launch_aggregate(X0, E, rowptr, colidx, val, AX, Ri, st)) return rc;
+    if (int rc = launch_aggregate(X0, E, rowptr, colidx, val, AX, Ri, st, TK_AX, agg)) return rc;
     {
         ScopedTiming tm(TK_GEMM, st);
         int rc;
@@ -1666,7 +1890,7 @@ int mdf_gcn_embed_lm_dev(mdf_model *m, const uint8_t *seq_idx, const float *lm_h
             rc = launch_gemm<EPI_ELU_POOL_STORE>(AX, E, m->Wgc1_t, E, Ri, C0, E, Ha, C0, nullptr, partial, feat, nullptr, C0, st);
         if (rc) return rc;
     }
-    return gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st);
+    return gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg);
 }
 
 /* .mdfw container: "MDFW0001" | u32 n | n x { char name[32]; u32 ndim; u64 dims[4]; u64 offset } | raw f32 data */
@@ -1788,6 +2012,22 @@ int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int
 int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
                       int64_t R, float *partial, void *workspace, size_t workspace_bytes, void *stream)
 {
+    return mdf_gcn_embed_agg_dev(m, letter_sums, rowptr, colidx, val, R, nullptr, partial, workspace, workspace_bytes, stream);
+}
+
+int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts, const int32_t *row_off, const int32_t *Lq, int32_t B,
+                        int64_t R, float *dinv, uint32_t *blk, void *stream)
+{
+    MDF_REQUIRE(masks && counts && row_off && Lq && dinv && blk && B > 0 && W > 0 && R > 0, "agg_prepare_dev: bad argument");
+    hipLaunchKernelGGL(k_agg_prepare, dim3((unsigned)B, 16), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned long long *>(masks), W, counts, row_off, Lq, dinv, blk);
+    MDF_HIP(hipGetLastError());
+    return MDF_OK;
+}
+
+int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
+                          int64_t R, const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, void *stream)
+{
     MDF_REQUIRE(m && letter_sums && rowptr && colidx && val && partial && workspace, "gcn_embed_dev: NULL argument");
     MDF_REQUIRE(R > 0 && R % 128 == 0 && R < 0x7fffffff, "gcn_embed_dev: bad row count %lld", (long long)R);
     if (workspace_bytes < gcn_ws_bytes(m, R))
@@ -1817,7 +2057,7 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
             hipLaunchKernelGGL(k_layer1<true>, dim3((unsigned)blocks), dim3(256), lds, st, letter_sums, m->T1, C0, Ri, Ha, partial, feat, gpw);
         MDF_HIP(hipGetLastError());
     }
-    if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st)) return rc;
+    if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg)) return rc;
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -1861,7 +2101,10 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     const int64_t R = mdf_layout_rows(Lq, 1, row_off);
     const int64_t nnz_cap = std::min<int64_t>(L * L, 0x7ffffff0);
     MDF_REQUIRE(m->lm_dim == 0 || m->lm, "gcn_forward_host: the model has a language-model branch but no mdf_lm is attached (mdf_model_attach_lm)");
-    const size_t cws = mdf_cmap_workspace_bytes(1, R, 0), gws = gcn_ws_bytes(m, R), hws = mdf_head_workspace_bytes(m, 1);
+    // a protein of at most MDF_AGG_MAX_LEN residues takes the matrix-pipe aggregation when its map turns out binary (decided on the
+    // device: the flag gates the two aggregation kernels, no extra synchronisation) -- the same choice the batched paths make for it
+    const bool agg_ok = L <= MDF_AGG_MAX_LEN;
+    const size_t cws = mdf_cmap_workspace_bytes(1, R, agg_ok ? (int32_t)L : 0), gws = gcn_ws_bytes(m, R), hws = mdf_head_workspace_bytes(m, 1);
     const size_t lws = m->lm_dim ? lm_ws_bytes(m->lm, 1, L) : 0;
     // layout of the session scratch
     size_t o = 0;
@@ -1870,7 +2113,8 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
                  o_rp = take((size_t)(R + 1) * 4), o_ci = take((size_t)nnz_cap * 4), o_va = take((size_t)nnz_cap * 4),
                  o_cws = take(cws), o_gws = take(gws), o_hws = take(hws), o_pool = take((size_t)m->feat * 4),
                  o_sc = take((size_t)m->T * 4), o_S = take((size_t)R * 32 * 4), o_part = take((size_t)(R / GROUP_ROWS) * m->feat * 4),
-                 o_lws = take(lws), o_lmh = take(m->lm_dim ? (size_t)R * m->lm_dim * 4 : 0);
+                 o_lws = take(lws), o_lmh = take(m->lm_dim ? (size_t)R * m->lm_dim * 4 : 0), o_dinv = take((size_t)R * 4), o_blk = take(16 * 4),
+                 o_flag = take(256);   // [binary flag | plist = {0}]
     if (m->host_ws_bytes < o) {
         (void)hipFree(m->host_ws);
         m->host_ws = nullptr;
@@ -1903,17 +2147,40 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     float *d_va = reinterpret_cast<float *>(b + o_va), *d_pool = reinterpret_cast<float *>(b + o_pool),
           *d_sc = reinterpret_cast<float *>(b + o_sc);
     if (int rc = mdf_seq_encode_dev(b + o_seq, dd->seq_off, dd->Lq, dd->row_off, 1, R, d_idx, dd->bad, nullptr)) return rc;
-    if (int rc = mdf_dense_to_csr_dev(b + o_cm, cmap_dtype, dd->cmap_off, dd->Lq, dd->row_off, 1, R, d_rp, d_ci, d_va, nnz_cap,
-                                      dd->status, b + o_cws, cws, nullptr))
+    mdf_agg_desc agg;
+    memset(&agg, 0, sizeof(agg));
+    const int32_t seg_all[2] = {0, (int32_t)R};
+    if (agg_ok) {
+        int32_t *d_flag = reinterpret_cast<int32_t *>(b + o_flag);
+        MDF_HIP(hipMemsetAsync(d_flag + 1, 0, 4, nullptr));   // plist[0] = 0 (the flag itself is set by the call below)
+        if (int rc = mdf_dense_to_csr_masks_dev(b + o_cm, cmap_dtype, dd->cmap_off, dd->Lq, dd->row_off, 1, R, (int32_t)L, d_rp, d_ci, d_va, nnz_cap,
+                                                dd->status, d_flag, b + o_cws, cws, nullptr))
+            return rc;
+        const uint64_t *d_masks = nullptr;
+        const int32_t *d_counts = nullptr;
+        int32_t W = 0;
+        if (int rc = mdf_cmap_ws_view(b + o_cws, cws, R, (int32_t)L, &d_masks, &W, &d_counts)) return rc;
+        if (int rc = mdf_agg_prepare_dev(d_masks, W, d_counts, dd->row_off, dd->Lq, 1, R, reinterpret_cast<float *>(b + o_dinv),
+                                         reinterpret_cast<uint32_t *>(b + o_blk), nullptr))
+            return rc;
+        agg.masks = d_masks, agg.W = W, agg.dinv = reinterpret_cast<const float *>(b + o_dinv), agg.blk = reinterpret_cast<const uint32_t *>(b + o_blk);
+        agg.row_off = dd->row_off, agg.Lq = dd->Lq, agg.plist = d_flag + 1, agg.n_mf = 1, agg.gate = d_flag;
+        agg.csr_seg = seg_all, agg.n_seg = 1, agg.csr_gated = 1;     // the gather runs (over all rows) only if the map is not binary
+        // the rows behind the protein's padded length: zeroed by a memset (harmless after a gather, which covers every row: they are padding)
+        agg.tail_row0 = (L + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+        agg.tail_p = -1;
+    } else if (int rc = mdf_dense_to_csr_dev(b + o_cm, cmap_dtype, dd->cmap_off, dd->Lq, dd->row_off, 1, R, d_rp, d_ci, d_va, nnz_cap,
+                                             dd->status, b + o_cws, cws, nullptr))
         return rc;
+    const mdf_agg_desc *aggp = agg_ok ? &agg : nullptr;
     float *d_S = reinterpret_cast<float *>(b + o_S), *d_part = reinterpret_cast<float *>(b + o_part);
     if (m->lm_dim) {
         float *d_lmh = reinterpret_cast<float *>(b + o_lmh);
         if (int rc = mdf_lm_forward_dev(m->lm, d_idx, dd->prot_row, dd->Lq, Lq, 1, d_lmh, b + o_lws, lws, nullptr)) return rc;
-        if (int rc = mdf_gcn_embed_lm_dev(m, d_idx, d_lmh, d_rp, d_ci, d_va, R, d_part, b + o_gws, gws, nullptr)) return rc;
+        if (int rc = mdf_gcn_embed_lm_agg_dev(m, d_idx, d_lmh, d_rp, d_ci, d_va, R, aggp, d_part, b + o_gws, gws, nullptr)) return rc;
     } else {
         if (int rc = mdf_letter_sums_dev(d_idx, d_rp, d_ci, d_va, R, d_S, nullptr)) return rc;
-        if (int rc = mdf_gcn_embed_dev(m, d_S, d_rp, d_ci, d_va, R, d_part, b + o_gws, gws, nullptr)) return rc;
+        if (int rc = mdf_gcn_embed_agg_dev(m, d_S, d_rp, d_ci, d_va, R, aggp, d_part, b + o_gws, gws, nullptr)) return rc;
     }
     if (int rc = mdf_gcn_pool_dev(m, d_part, dd->grp_off, 1, d_pool, nullptr)) return rc;
     if (int rc = mdf_gcn_head_dev(m, d_pool, 1, d_sc, nullptr, b + o_hws, hws, nullptr)) return rc;

@@ -129,6 +129,14 @@ SIGNATURES = {
     "mdf_gcn_workspace_bytes": (c_size_t, [c_void_p, c_int64]),
     "mdf_letter_sums_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "mdf_gcn_embed_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    # the matrix-pipe aggregation (mdf_agg_desc is passed by pointer: opaque here, the batch engine builds it in C++)
+    "mdf_gcn_embed_agg_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mdf_gcn_embed_lm_agg_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
+                                         c_void_p]),
+    "mdf_agg_prepare_dev": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mdf_cmap_ws_view": (c_int, [c_void_p, c_size_t, c_int64, c_int32, POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p)]),
+    "mdf_dense_to_csr_masks_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                                           c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdf_gcn_pool_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "mdf_head_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
     "mdf_gcn_head_dev": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -619,3 +619,38 @@ def test_forward_pass_from_several_threads(mf, cc):
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_aggregation_kernel_is_chosen_per_protein(mf):
+    """Which kernel aggregates a protein -- the matrix-pipe product on the contact BITS (binary map, at most 512 residues) or the CSR gather
+    (longer proteins, maps with other values) -- depends on that protein alone, so the batched dense-map path, the per-call API and,
+    for maps made from coordinates, the fused path agree bit for bit whatever else is in the batch.  Cases: a symmetric 6 A map, the
+    reference's own test recipe (np.random.randint(0, 2, (L, L)): binary, NOT symmetric, weight_convert notebook cell 1), a float map
+    with entries other than 0 / 1 (gather), a binary map with an odd DIAGONAL (the kernels force the diagonal to 1: still binary), a
+    600-residue protein (gather), all in one batch; each vs the oracle and batch == per call."""
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    w, pred = mf
+    rng = np.random.default_rng(31)
+    seqs, maps = [], []
+    for kind, L in (("sym", 100), ("randint", 300), ("float", 96), ("diag", 77), ("long", 600), ("sym", 512), ("randint", 17)):
+        seqs.append(synthetic.random_sequence(rng, L))
+        if kind == "randint":
+            cm = rng.integers(0, 2, size=(L, L)).astype(np.int32)
+        else:
+            cm = orc.calculate_contact_map(synthetic.random_walk_coords(rng, L), 6.0).astype(np.int32)
+        if kind == "float":
+            cm = cm.astype(np.float32) * rng.choice(np.array([0.5, 1.0, 2.0], dtype=np.float32), size=(L, L))
+        if kind == "diag":
+            cm = cm.copy()
+            cm[np.arange(L), np.arange(L)] = 7
+        maps.append(cm)
+    eng = HotPathEngine({"mf": pred}, device=0, max_rows=4096)
+    out = eng.forward_dense(eng.upload(PackedProteins.pack(seqs, max_rows=4096)), [m.astype(np.float32) for m in maps])["mf"].cpu().numpy()
+    out_i32 = eng.forward_dense(eng.upload(PackedProteins.pack(seqs[:2] + seqs[3:], max_rows=4096)), maps[:2] + maps[3:])["mf"].cpu().numpy()
+    for i, (s, cm) in enumerate(zip(seqs, maps)):
+        y = pred.forward_pass(s, cm)
+        assert np.max(np.abs(y - gcn_oracle.gcn_forward(w, s, cm))) < TOL, i
+        assert np.array_equal(out[i], pred.forward_pass(s, cm.astype(np.float32))), i      # batch == per call, bitwise (float32 maps)
+        if i != 2:
+            assert np.array_equal(out_i32[i - (i > 2)], y), i                             # ... and for int32 maps
+    assert np.array_equal(out[0], out_i32[0])                                              # the dtype of a binary map changes nothing
