@@ -452,9 +452,11 @@ def rooflines(ctx, eng, pk, kernels, lm):
         per_layer = {k: {"avg_us": kernels[k]["avg_us"], "timed_launches": kernels[k]["launches"],
                          "frac": round(bytes_row * rows_launch / (kernels[k]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
                      for k in ("ax2", "ax3") if kernels.get(k, {}).get("launches") and not lm}
-        roof_ax = {"kernel": "k_aggregate<512> (A.X, CSR gather, one wave per residue row)", "bound": "hbm", "achieved": round(gbs, 1),
+        roof_ax = {"kernel": "k_aggregate_mfma (A.X as an exact block-sparse product on the bf16 matrix pipe: contact bits x the fp32 rows split into "
+                             "three bf16 terms, fp32 accumulate; proteins outside its length classes: k_aggregate, CSR gather)",
+                   "bound": "hbm", "achieved": round(gbs, 1),
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                   "traffic": (traffic.get("k_aggregate<512>") or {}).get("bytes"), "traffic_source": src,
+                   "traffic": (traffic.get("k_aggregate") or {}).get("bytes"), "traffic_source": src,
                    "per_launch": {"rows": R, "bytes": bytes_row * R, "nnz_per_row": round(nnz_per_row, 2), "avg_us": a["avg_us"],
                                   "timed_launches": a["launches"]},
                    "per_layer": per_layer}

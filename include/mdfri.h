@@ -289,20 +289,25 @@ int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int
  *     out[i] = d_i * sum_j A'[i][j] * (d_j * H[j])
  * is an exact block-sparse product on the bf16 matrix pipe: A' is 0/1, d_j * H[j] is split into three bf16 terms whose sum is the fp32
  * value, products 1 * term are exact and the accumulation is fp32 -- the same fp32 sum as the CSR gather's, in another order, with
- * every H element crossing L1 once instead of once per neighbour.  It serves proteins of at most MDF_AGG_MAX_LEN residues; longer
- * ones and non-binary maps keep the CSR gather kernel.  Which kernel aggregates a protein depends on that protein alone (its length,
+ * every H element crossing L1 once instead of once per neighbour.  It serves proteins of MDF_AGG_MIN_LEN .. MDF_AGG_MAX_LEN residues
+ * (below, a workgroup per protein and channel slab is mostly overhead and the gather's working set is cache-sized anyway; above, the
+ * accumulators of a protein's row blocks no longer fit a workgroup); the others, and non-binary maps, keep the CSR gather kernel.  Which kernel aggregates a protein depends on that protein alone (its length,
  * its map), never on the batch around it: batch == per call stays bitwise.
- * mdf_agg_desc says, for the R rows of one mdf_gcn_embed*_agg_dev call, which proteins go where. */
-#define MDF_AGG_MAX_LEN 512
+ * mdf_agg_desc says, for the R rows of one mdf_gcn_embed*_agg_dev call, which proteins go where.  The stack takes TWO of them (an array):
+ * [0] for the aggregation in front of layer 2 (and a language-model head's layer 1), whose operand was just written and is cache-resident,
+ * [1] for layer 3 and up, whose operand is not -- the matrix-pipe form gains more there, so more lengths are worth it (mdf_agg_class,
+ * measured: profiles/r04_ax_mfma_by_length.txt).  masks / dinv / blk / row_off / Lq are the same in both. */
+#define MDF_AGG_MIN_LEN 112
+#define MDF_AGG_MAX_LEN 1024
 typedef struct mdf_agg_desc {
     const uint64_t *masks;      /* (R, W) device: bit j of word (r0+i, j/64) = A'[i][j] (diagonal set); rows >= Lq of a protein all zero */
     int32_t W;
     const float *dinv;          /* (R) device: 1 / (1e-6 + sqrt(degree)), from mdf_agg_prepare_dev */
-    const uint32_t *blk;        /* (B, 16) device: bit c of entry (p, b): rows [32b, 32b+32) of protein p have a contact in columns [16c, 16c+16) */
+    const uint64_t *blk;        /* (B, 32) device: bit c of entry (p, b): rows [32b, 32b+32) of protein p have a contact in columns [16c, 16c+16) */
     const int32_t *row_off;     /* (B+1) device */
     const int32_t *Lq;          /* (B) device */
-    const int32_t *plist;       /* (n_mf) device: indices (into row_off / Lq / blk) of the proteins the matrix-pipe kernel aggregates */
-    int32_t n_mf;
+    const int32_t *plist;       /* device: indices (into row_off / Lq / blk) of the proteins the matrix-pipe kernel aggregates, by length class: */
+    int32_t n_mf[3];            /* first n_mf[0] of at most 256 residues, then n_mf[1] of at most 512, then n_mf[2] of at most 1 024 */
     const int32_t *gate;        /* device, may be NULL: per protein (indexed like Lq), 0 = this protein's map is NOT binary: the matrix-pipe
                                  * kernel skips it and the CSR gather launch below takes it (per-call path: known on the device only) */
     const int32_t *csr_seg;     /* HOST: n_seg pairs (first row, row count) left to the CSR gather kernel */
@@ -313,10 +318,14 @@ typedef struct mdf_agg_desc {
                                  * memset behind the launches (when the last protein is a long one the gather over its rows covers them) */
 } mdf_agg_desc;
 
-/* dinv (R) and blk (B, 16) from the contact bits and the per-row degrees (counts: int32 (R), the number of set bits of a row) that
+/* Length class of a protein for the aggregation of kind `resident` (1: the descriptor [0] above, 0: [1]): 0 / 1 / 2 = one / two / four
+ * 32-row blocks per wave of the matrix-pipe kernel (at most 256 / 512 / 1 024 residues), -1 = the CSR gather. */
+int mdf_agg_class(int32_t L, int resident);
+
+/* dinv (R) and blk (B, 32) from the contact bits and the per-row degrees (counts: int32 (R), the number of set bits of a row) that
  * the contact stage leaves in its workspace (mdf_cmap_ws_view).  Proteins longer than MDF_AGG_MAX_LEN get no blk entry. */
 int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts, const int32_t *row_off, const int32_t *Lq, int32_t B,
-                        int64_t R, float *dinv, uint32_t *blk, void *stream);
+                        int64_t R, float *dinv, uint64_t *blk, void *stream);
 /* Pointers into a contact-stage workspace (laid out for R rows, max_len) after mdf_cmap_csr_dev / mdf_dense_to_csr_masks_dev ran on it. */
 int mdf_cmap_ws_view(void *workspace, size_t workspace_bytes, int64_t R, int32_t max_len, const uint64_t **masks, int32_t *W,
                      const int32_t **counts);

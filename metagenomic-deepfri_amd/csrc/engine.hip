@@ -25,11 +25,15 @@ struct PlanChunk {
     int32_t segment;
     int64_t group_base;
     int32_t max_len;   // longest query of the chunk: sizes the contact-bit words of ITS rows
-    // which aggregation kernel takes which protein of the chunk (mdfri.h mdf_agg_desc): by length alone -- the maps of the fused path are binary
-    int64_t plist_pos;          // position of the chunk's list of matrix-pipe proteins (chunk-local indices) in mdf_plan::agg_plist
-    int32_t n_mf;               // proteins of at most MDF_AGG_MAX_LEN residues
+    // which aggregation kernel takes which protein of the chunk (mdfri.h mdf_agg_desc): by length alone -- the maps of the fused path are
+    // binary --, once for the launches whose operand is cache-resident ([0]: layer 2) and once for the others ([1]: layer 3 and up)
+    struct AggLists {
+        int64_t plist_pos;          // position of the list of matrix-pipe proteins (chunk-local indices, class after class) in mdf_plan::agg_plist
+        int32_t n_mf[3];            // proteins per length class (mdf_agg_class)
+        bool last_listed;           // the chunk's last protein is on the list (its workgroups zero the rows behind it)
+        std::vector<int32_t> csr_seg;   // (first row, row count) pairs of the rows of the other proteins: the CSR gather
+    } agg[2];
     int64_t tail_row0;          // first row behind the last protein's padded rows
-    std::vector<int32_t> csr_seg;   // (first row, row count) pairs of the rows of longer proteins: the CSR gather
 };
 struct PlanSegment {
     int32_t p0, p1;
@@ -87,6 +91,8 @@ static void plan_release(void *p, hipStream_t st)
 
 static std::atomic<uint64_t> g_plan_serial{1};
 
+
+
 static void close_segment(mdf_plan *pl, const std::vector<int> &ids, int64_t groups)
 {
     const PlanChunk &first = pl->chunks[ids.front()], &last = pl->chunks[ids.back()];
@@ -140,18 +146,26 @@ extern "C" int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, i
         ch.rows = R;
         {   // aggregation kernels by protein length
             const int32_t *ro = pl->chunk_row_off.data() + ch.row_off_pos;
-            ch.plist_pos = (int64_t)pl->agg_plist.size();
-            for (int32_t p = p0; p < p1; ++p) {
-                if (Lq[p] <= MDF_AGG_MAX_LEN) {
-                    pl->agg_plist.push_back(p - p0);
-                } else if (!ch.csr_seg.empty() && ch.csr_seg[ch.csr_seg.size() - 2] + ch.csr_seg.back() == ro[p - p0]) {
-                    ch.csr_seg.back() += ro[p - p0 + 1] - ro[p - p0];          // adjacent to the previous long protein: one launch
-                } else {
-                    ch.csr_seg.push_back(ro[p - p0]);
-                    ch.csr_seg.push_back(ro[p - p0 + 1] - ro[p - p0]);
+            for (int kind = 0; kind < 2; ++kind) {
+                PlanChunk::AggLists &al = ch.agg[kind];
+                al.plist_pos = (int64_t)pl->agg_plist.size();
+                for (int cls = 0; cls < 3; ++cls) {
+                    al.n_mf[cls] = 0;
+                    for (int32_t p = p0; p < p1; ++p)
+                        if (mdf_agg_class(Lq[p], kind == 0) == cls) pl->agg_plist.push_back(p - p0), ++al.n_mf[cls];
                 }
+                for (int32_t p = p0; p < p1; ++p) {
+                    if (mdf_agg_class(Lq[p], kind == 0) >= 0) continue;
+                    std::vector<int32_t> &seg = al.csr_seg;
+                    if (!seg.empty() && seg[seg.size() - 2] + seg.back() == ro[p - p0]) {
+                        seg.back() += ro[p - p0 + 1] - ro[p - p0];          // adjacent to the previous gather protein: one launch
+                    } else {
+                        seg.push_back(ro[p - p0]);
+                        seg.push_back(ro[p - p0 + 1] - ro[p - p0]);
+                    }
+                }
+                al.last_listed = mdf_agg_class(Lq[p1 - 1], kind == 0) >= 0;
             }
-            ch.n_mf = (int32_t)((int64_t)pl->agg_plist.size() - ch.plist_pos);
             const int32_t last = p1 - 1 - p0;
             ch.tail_row0 = (int64_t)ro[last] + ((int64_t)Lq[p1 - 1] + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
         }
@@ -568,7 +582,7 @@ static int ensure(mdf_engine *e, int64_t rows, int32_t B, int32_t max_len, int64
             if (int rc = c.lsum.grow((size_t)rows * 32 * 4, gen)) return rc;
             if (int rc = c.cws.grow(mdf_cmap_workspace_bytes(1 << 20, rows, max_len), gen)) return rc;
             if (int rc = c.dinv.grow((size_t)rows * 4, gen)) return rc;
-            if (int rc = c.blk.grow((size_t)(rows / GROUP_ROWS + 1) * 16 * 4, gen)) return rc;   // at most rows / 16 proteins in a chunk
+            if (int rc = c.blk.grow((size_t)(rows / GROUP_ROWS + 1) * 32 * 8, gen)) return rc;   // (B, 32) x 64 bits; at most rows / 16 proteins in a chunk
         }
         if (int rc = e->gws.grow(gws, gen)) return rc;
         e->rows_alloc = rows;
@@ -609,10 +623,12 @@ static int encode_chunk(mdf_engine *, const mdf_plan *pl, const mdf_batch_dev *b
 // Which aggregation kernel takes which protein of a chunk when that is not a function of the lengths alone (dense maps: a map that is
 // not binary keeps the CSR gather): replaces the plan's lists for one chunk.
 struct AggOverride {
-    const int32_t *d_plist = nullptr;
-    int32_t n_mf = 0;
-    bool last_listed = false;   // the chunk's last protein is on the list
-    std::vector<int32_t> csr_seg;
+    struct Lists {
+        const int32_t *d_plist = nullptr;
+        int32_t n_mf[3] = {0, 0, 0};
+        bool last_listed = false;   // the chunk's last protein is on the list
+        std::vector<int32_t> csr_seg;
+    } k[2];   // [0]: layer 2, [1]: layer 3 and up
 };
 
 // `bits`: the contact set's workspace holds this chunk's contact bits and degrees (the fused contact stage ran on it with (ch.rows,
@@ -623,26 +639,38 @@ static int gcn_chunk(mdf_engine *e, mdf_engine::ContactSet &c, const mdf_plan *p
     if (!have_lsum && e->want_lsum)
         if (int rc = mdf_letter_sums_dev(seq_ptr, c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), ch.rows, c.lsum.as<float>(), st))
             return rc;
-    mdf_agg_desc agg;
-    memset(&agg, 0, sizeof(agg));
+    mdf_agg_desc agg[2];   // [0]: layer 2 (operand cache-resident), [1]: layer 3 and up
+    memset(agg, 0, sizeof(agg));
     const mdf_agg_desc *aggp = nullptr;
-    if (bits && (ov ? ov->n_mf : ch.n_mf) > 0) {
+    int n_listed = 0;
+    for (int kind = 0; kind < 2; ++kind)
+        for (int c3 = 0; c3 < 3; ++c3) n_listed += ov ? ov->k[kind].n_mf[c3] : ch.agg[kind].n_mf[c3];
+    if (bits && n_listed > 0) {
         const uint64_t *masks = nullptr;
         const int32_t *counts = nullptr;
         int32_t W = 0;
         if (int rc = mdf_cmap_ws_view(c.cws.p, c.cws.bytes, ch.rows, ch.max_len, &masks, &W, &counts)) return rc;
         const int32_t *d_ro = pl->d_chunk_row_off + ch.row_off_pos, *d_lq = b->Lq + ch.p0;
-        if (int rc = mdf_agg_prepare_dev(masks, W, counts, d_ro, d_lq, ch.p1 - ch.p0, ch.rows, c.dinv.as<float>(), c.blk.as<uint32_t>(), st)) return rc;
-        agg.masks = masks, agg.W = W, agg.dinv = c.dinv.as<float>(), agg.blk = c.blk.as<uint32_t>();
-        agg.row_off = d_ro, agg.Lq = d_lq, agg.plist = pl->d_agg_plist + ch.plist_pos, agg.n_mf = ch.n_mf;
-        agg.csr_seg = ch.csr_seg.data(), agg.n_seg = (int32_t)(ch.csr_seg.size() / 2), agg.tail_row0 = ch.tail_row0;
-        if (ov) agg.plist = ov->d_plist, agg.n_mf = ov->n_mf, agg.csr_seg = ov->csr_seg.data(), agg.n_seg = (int32_t)(ov->csr_seg.size() / 2);
-        // the rows behind the last protein: its workgroups zero them when it is on the matrix-pipe list; otherwise the gather segment of that
-        // (long or non-binary) protein runs to the end of the rows and writes zeros there (empty CSR rows)
-        const int32_t last = ch.p1 - ch.p0 - 1;
-        const bool last_listed = ov ? ov->last_listed : pl->Lq[(size_t)ch.p1 - 1] <= MDF_AGG_MAX_LEN;
-        agg.tail_p = last_listed ? last : 0x7fffffff;
-        aggp = &agg;
+        if (int rc = mdf_agg_prepare_dev(masks, W, counts, d_ro, d_lq, ch.p1 - ch.p0, ch.rows, c.dinv.as<float>(), c.blk.as<uint64_t>(), st)) return rc;
+        for (int kind = 0; kind < 2; ++kind) {
+            mdf_agg_desc &a = agg[kind];
+            a.masks = masks, a.W = W, a.dinv = c.dinv.as<float>(), a.blk = c.blk.as<uint64_t>(), a.row_off = d_ro, a.Lq = d_lq;
+            a.tail_row0 = ch.tail_row0;
+            bool last_listed;
+            if (ov) {
+                const AggOverride::Lists &l = ov->k[kind];
+                a.plist = l.d_plist, a.csr_seg = l.csr_seg.data(), a.n_seg = (int32_t)(l.csr_seg.size() / 2), last_listed = l.last_listed;
+                for (int c3 = 0; c3 < 3; ++c3) a.n_mf[c3] = l.n_mf[c3];
+            } else {
+                const PlanChunk::AggLists &l = ch.agg[kind];
+                a.plist = pl->d_agg_plist + l.plist_pos, a.csr_seg = l.csr_seg.data(), a.n_seg = (int32_t)(l.csr_seg.size() / 2), last_listed = l.last_listed;
+                for (int c3 = 0; c3 < 3; ++c3) a.n_mf[c3] = l.n_mf[c3];
+            }
+            // the rows behind the last protein: its workgroups zero them when it is on the matrix-pipe list; otherwise the gather segment of
+            // that protein runs to the end of the rows and writes zeros there (empty CSR rows)
+            a.tail_p = last_listed ? ch.p1 - ch.p0 - 1 : 0x7fffffff;
+        }
+        aggp = agg;
     }
     for (size_t k = 0; k < e->models.size(); ++k) {
         mdf_model *m = e->models[k];
@@ -979,8 +1007,8 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         // pack the chunk's maps + their element offsets into pinned memory: [offsets (Bc x int64) | maps]
         size_t elems = 0;
         for (int32_t p = ch.p0; p < ch.p1; ++p) elems += (size_t)pl->Lq[(size_t)p] * (size_t)pl->Lq[(size_t)p];
-        // pinned block: [offsets (Bc x int64) | maps | list of the proteins the matrix-pipe aggregation takes (<= Bc x int32)]
-        const size_t o_maps = align_up((size_t)Bc * 8, 256), o_plist = align_up(o_maps + elems * 4, 256), total = o_plist + (size_t)Bc * 4;
+        // pinned block: [offsets (Bc x int64) | maps | the two lists of the proteins the matrix-pipe aggregation takes (<= 2 Bc x int32)]
+        const size_t o_maps = align_up((size_t)Bc * 8, 256), o_plist = align_up(o_maps + elems * 4, 256), total = o_plist + (size_t)Bc * 8;   // (two lists: layer 2 / layer 3 and up)
         const int s = parity;
         parity ^= 1;
         if (used[s]) MDF_HIP(hipEventSynchronize(e->map_ev[s]));   // the kernels that read this slot two chunks ago are done
@@ -1046,20 +1074,29 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         {
             int32_t *plist = reinterpret_cast<int32_t *>(e->map_pin[s] + o_plist);
             const int32_t *ro = pl->chunk_row_off.data() + ch.row_off_pos;
-            aov.n_mf = 0;
-            aov.csr_seg.clear();
-            for (int32_t q = 0; q < Bc; ++q) {
-                if (pl->Lq[(size_t)(ch.p0 + q)] <= MDF_AGG_MAX_LEN && !other[(size_t)q]) {
-                    plist[aov.n_mf++] = q;
-                } else if (!aov.csr_seg.empty() && aov.csr_seg[aov.csr_seg.size() - 2] + aov.csr_seg.back() == ro[q]) {
-                    aov.csr_seg.back() += ro[q + 1] - ro[q];
-                } else {
-                    aov.csr_seg.push_back(ro[q]);
-                    aov.csr_seg.push_back(ro[q + 1] - ro[q]);
+            int32_t n_listed = 0;
+            for (int kind = 0; kind < 2; ++kind) {
+                AggOverride::Lists &l = aov.k[kind];
+                auto cls_of = [&](int32_t q) { return other[(size_t)q] ? -1 : mdf_agg_class(pl->Lq[(size_t)(ch.p0 + q)], kind == 0); };
+                l.d_plist = reinterpret_cast<const int32_t *>(e->map_dev[s].as<char>() + o_plist) + n_listed;
+                l.csr_seg.clear();
+                for (int cls = 0; cls < 3; ++cls) {
+                    l.n_mf[cls] = 0;
+                    for (int32_t q = 0; q < Bc; ++q)
+                        if (cls_of(q) == cls) plist[n_listed++] = q, ++l.n_mf[cls];
                 }
+                for (int32_t q = 0; q < Bc; ++q) {
+                    if (cls_of(q) >= 0) continue;
+                    std::vector<int32_t> &seg = l.csr_seg;
+                    if (!seg.empty() && seg[seg.size() - 2] + seg.back() == ro[q]) {
+                        seg.back() += ro[q + 1] - ro[q];
+                    } else {
+                        seg.push_back(ro[q]);
+                        seg.push_back(ro[q + 1] - ro[q]);
+                    }
+                }
+                l.last_listed = cls_of(Bc - 1) >= 0;
             }
-            aov.last_listed = aov.n_mf > 0 && plist[aov.n_mf - 1] == Bc - 1;
-            aov.d_plist = reinterpret_cast<const int32_t *>(e->map_dev[s].as<char>() + o_plist);
         }
         char *d = e->map_dev[s].as<char>();
         // the device slot is free (map_ev[s] was waited for above): the upload overlaps whatever the compute stream is still doing

@@ -826,7 +826,7 @@ __device__ __forceinline__ int agg_xt_off(int term, int ch, int slot) { return (
 // ROWBLOCKS: 32-row blocks of a protein per wave, dealt round robin (block b of wave w = rows [32 (8 b + w), +32)): L <= 256 ROWBLOCKS
 template <int ROWBLOCKS>
 __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const unsigned long long *__restrict__ masks,
-                                                                   int W, const float *__restrict__ dinv, const uint32_t *__restrict__ blk,
+                                                                   int W, const float *__restrict__ dinv, const unsigned long long *__restrict__ blk,
                                                                    const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq,
                                                                    const int32_t *__restrict__ plist, const int32_t *__restrict__ gate,
                                                                    float *__restrict__ out, int tail_p, int tail_row0, int R)
@@ -867,16 +867,8 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
                 x[k] = h * dd[k];
             }
         }
-        unsigned long long mw0[ROWBLOCKS], mw1[ROWBLOCKS], mw2[ROWBLOCKS], mw3[ROWBLOCKS];
-#pragma unroll
-        for (int b = 0; b < ROWBLOCKS; ++b) {
-            const int i = (b * 8 + wid) * 32 + frow;
-            const unsigned long long *mrow = masks + (size_t)(r0 + i) * W + (j0 >> 6);
-            mw0[b] = i < L ? mrow[0] : 0ull;
-            mw1[b] = (i < L && j0 + 64 < L) ? mrow[1] : 0ull;
-            mw2[b] = (i < L && j0 + 128 < L) ? mrow[2] : 0ull;
-            mw3[b] = (i < L && j0 + 192 < L) ? mrow[3] : 0ull;
-        }
+        // (the contact bits of this chunk's 256 columns are fetched per row block inside the matrix phase: all row blocks' words at once
+        // would be 8 registers per block -- the other workgroups of the CU cover the latency)
         __syncthreads();   // the previous chunk's fragments have been read (first chunk: the table is complete)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {   // this lane's 2 channels: 8 consecutive rows each = one 16-byte slot per term
@@ -900,13 +892,18 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
         for (int b = 0; b < ROWBLOCKS; ++b) {
             const int rb = b * 8 + wid;
             if (rb * 32 >= L) break;   // (wave-uniform)
-            unsigned nz = (blk[(size_t)p * 16 + rb] >> (j0 >> 4)) & 0xffffu;
+            unsigned nz = (unsigned)(blk[(size_t)p * 32 + rb] >> (j0 >> 4)) & 0xffffu;
+            if (!nz) continue;
+            const int i = rb * 32 + frow;
+            const unsigned long long *mrow = masks + (size_t)(r0 + i) * W + (j0 >> 6);
+            const unsigned long long mw0 = i < L ? mrow[0] : 0ull, mw1 = (i < L && j0 + 64 < L) ? mrow[1] : 0ull,
+                                     mw2 = (i < L && j0 + 128 < L) ? mrow[2] : 0ull, mw3 = (i < L && j0 + 192 < L) ? mrow[3] : 0ull;
             while (nz) {
                 const int cb = __builtin_ctz(nz);
                 nz &= nz - 1;
                 // the word holding column block cb, selected without an index (an indexed select of registers goes through scratch)
                 const unsigned long long s1 = 0ull - (unsigned long long)((cb >> 2) & 1), s2 = 0ull - (unsigned long long)((cb >> 3) & 1);
-                const unsigned long long m01 = mw0[b] ^ ((mw0[b] ^ mw1[b]) & s1), m23 = mw2[b] ^ ((mw2[b] ^ mw3[b]) & s1);
+                const unsigned long long m01 = mw0 ^ ((mw0 ^ mw1) & s1), m23 = mw2 ^ ((mw2 ^ mw3) & s1);
                 const unsigned long long word = m01 ^ ((m01 ^ m23) & s2);
                 const unsigned byte = (unsigned)(word >> ((cb & 3) * 16 + 8 * half)) & 0xffu;
                 const bf16x8 af = *reinterpret_cast<const bf16x8 *>(lut + byte * 8);
@@ -958,17 +955,17 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
 }
 
 // dinv[row] = 1 / (1e-6 + sqrt(degree)) for every row, and blk[p][b] = which 16-column blocks hold a contact of rows [32 b, 32 b + 32)
-// of protein p (proteins of at most MDF_AGG_MAX_LEN residues).  One wave per (protein, row block); grid.y = 16.
+// of protein p (proteins of at most MDF_AGG_MAX_LEN residues).  One wave per (protein, row block); grid.y = 32.
 __global__ __launch_bounds__(64) void k_agg_prepare(const unsigned long long *__restrict__ masks, int W, const int32_t *__restrict__ counts,
                                                     const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq, float *__restrict__ dinv,
-                                                    uint32_t *__restrict__ blk)
+                                                    unsigned long long *__restrict__ blk)
 {
     const int p = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int r0 = row_off[p], L = Lq[p], rows_end = row_off[p + 1] - r0;   // rows up to the next protein: padding included
-    // degrees -> factors, 64 rows per (p, b): the 16 blocks of a protein cover 1 024 rows, longer proteins loop
-    for (int i = b * 64 + lane; i < rows_end; i += 16 * 64) dinv[r0 + i] = i < L ? 1.0f / (1e-6f + sqrtf((float)counts[r0 + i])) : 0.0f;
-    if (L > MDF_AGG_MAX_LEN) return;
-    unsigned bits = 0;
+    // degrees -> factors, 64 rows per (p, b): the 32 blocks of a protein cover 2 048 rows, longer proteins loop
+    for (int i = b * 64 + lane; i < rows_end; i += 32 * 64) dinv[r0 + i] = i < L ? 1.0f / (1e-6f + sqrtf((float)counts[r0 + i])) : 0.0f;
+    if (L > MDF_AGG_MAX_LEN || L < MDF_AGG_MIN_LEN) return;
+    unsigned long long bits = 0;
     const int i = b * 32 + (lane & 31);
     if (i < L && lane < 32) {
         const unsigned long long *mrow = masks + (size_t)(r0 + i) * W;
@@ -976,11 +973,11 @@ __global__ __launch_bounds__(64) void k_agg_prepare(const unsigned long long *__
             const unsigned long long m = mrow[w];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-                if ((m >> (16 * q)) & 0xffffull) bits |= 1u << (w * 4 + q);
+                if ((m >> (16 * q)) & 0xffffull) bits |= 1ull << (w * 4 + q);
         }
     }
     for (int d = 32; d > 0; d >>= 1) bits |= __shfl_xor(bits, d, 64);
-    if (lane == 0) blk[(size_t)p * 16 + b] = bits;
+    if (lane == 0) blk[(size_t)p * 32 + b] = bits;
 }
 
 // ---- layer 1 (folded embedding): H1[i, :] = elu(S[i, :26] . T1), S = Ahat . onehot, T1 = relu(W_aa) . W_gc1 (26 x C).  A contraction
@@ -1432,10 +1429,21 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
     }
     // per protein: the matrix-pipe kernel for the listed ones (binary map, at most MDF_AGG_MAX_LEN residues), the gather for the row
     // segments left over; rows behind the last protein are zeroed (the H.W GEMM reads every row)
-    if (agg->n_mf > 0) {
-        hipLaunchKernelGGL(k_aggregate_mfma<2>, dim3((unsigned)agg->n_mf * (unsigned)(Cin / AGG_SL)), dim3(AGG_THREADS), 0, st, Hin, Cin,
-                           reinterpret_cast<const unsigned long long *>(agg->masks), agg->W, agg->dinv, agg->blk, agg->row_off, agg->Lq, agg->plist,
-                           agg->gate, AH, agg->tail_p, (int)agg->tail_row0, Ri);
+    if (tk == TK_AX3) ++agg;   // the descriptor of the launches whose operand is not cache-resident (layer 3 and up)
+    {   // one launch per length class (1, 2 or 4 row blocks per wave: the accumulators a workgroup carries)
+        const unsigned slabs = (unsigned)(Cin / AGG_SL);
+        const int32_t *pl = agg->plist;
+#define MDF_AGG(RB, n_)                                                                                                                      \
+    if ((n_) > 0)                                                                                                                            \
+        hipLaunchKernelGGL(k_aggregate_mfma<RB>, dim3((unsigned)(n_) * slabs), dim3(AGG_THREADS), 0, st, Hin, Cin,                            \
+                           reinterpret_cast<const unsigned long long *>(agg->masks), agg->W, agg->dinv,                                      \
+                           reinterpret_cast<const unsigned long long *>(agg->blk), agg->row_off, agg->Lq, pl, agg->gate, AH, agg->tail_p,   \
+                           (int)agg->tail_row0, Ri);                                                                                         \
+    pl += (n_);
+        MDF_AGG(1, agg->n_mf[0])
+        MDF_AGG(2, agg->n_mf[1])
+        MDF_AGG(4, agg->n_mf[2])
+#undef MDF_AGG
     }
     for (int k = 0; k < agg->n_seg; ++k) {
         const int row0 = agg->csr_seg[2 * k], cnt = agg->csr_seg[2 * k + 1];
@@ -2015,12 +2023,21 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
     return mdf_gcn_embed_agg_dev(m, letter_sums, rowptr, colidx, val, R, nullptr, partial, workspace, workspace_bytes, stream);
 }
 
+// Where the matrix-pipe form beats the gather (profiles/r04_ax_mfma_by_length.txt): proteins that fill their 256-row chunks (L just below a
+// multiple of 256), and more widely where the operand is not cache-resident.  A function of (length, kind of launch) alone.
+int mdf_agg_class(int32_t L, int resident)
+{
+    if (L < MDF_AGG_MIN_LEN || L > MDF_AGG_MAX_LEN) return -1;
+    if (resident) return (L >= 176 && L <= 256) ? 0 : (L >= 400 && L <= 512) ? 1 : (L >= 704 && L <= 800) ? 2 : -1;
+    return L <= 256 ? 0 : (L >= 288 && L <= 512) ? 1 : L >= 544 ? 2 : -1;
+}
+
 int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts, const int32_t *row_off, const int32_t *Lq, int32_t B,
-                        int64_t R, float *dinv, uint32_t *blk, void *stream)
+                        int64_t R, float *dinv, uint64_t *blk, void *stream)
 {
     MDF_REQUIRE(masks && counts && row_off && Lq && dinv && blk && B > 0 && W > 0 && R > 0, "agg_prepare_dev: bad argument");
-    hipLaunchKernelGGL(k_agg_prepare, dim3((unsigned)B, 16), dim3(64), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const unsigned long long *>(masks), W, counts, row_off, Lq, dinv, blk);
+    hipLaunchKernelGGL(k_agg_prepare, dim3((unsigned)B, 32), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned long long *>(masks), W, counts, row_off, Lq, dinv, reinterpret_cast<unsigned long long *>(blk));
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -2103,7 +2120,7 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     MDF_REQUIRE(m->lm_dim == 0 || m->lm, "gcn_forward_host: the model has a language-model branch but no mdf_lm is attached (mdf_model_attach_lm)");
     // a protein of at most MDF_AGG_MAX_LEN residues takes the matrix-pipe aggregation when its map turns out binary (decided on the
     // device: the flag gates the two aggregation kernels, no extra synchronisation) -- the same choice the batched paths make for it
-    const bool agg_ok = L <= MDF_AGG_MAX_LEN;
+    const bool agg_ok = L >= MDF_AGG_MIN_LEN && L <= MDF_AGG_MAX_LEN;
     const size_t cws = mdf_cmap_workspace_bytes(1, R, agg_ok ? (int32_t)L : 0), gws = gcn_ws_bytes(m, R), hws = mdf_head_workspace_bytes(m, 1);
     const size_t lws = m->lm_dim ? lm_ws_bytes(m->lm, 1, L) : 0;
     // layout of the session scratch
@@ -2113,7 +2130,7 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
                  o_rp = take((size_t)(R + 1) * 4), o_ci = take((size_t)nnz_cap * 4), o_va = take((size_t)nnz_cap * 4),
                  o_cws = take(cws), o_gws = take(gws), o_hws = take(hws), o_pool = take((size_t)m->feat * 4),
                  o_sc = take((size_t)m->T * 4), o_S = take((size_t)R * 32 * 4), o_part = take((size_t)(R / GROUP_ROWS) * m->feat * 4),
-                 o_lws = take(lws), o_lmh = take(m->lm_dim ? (size_t)R * m->lm_dim * 4 : 0), o_dinv = take((size_t)R * 4), o_blk = take(16 * 4),
+                 o_lws = take(lws), o_lmh = take(m->lm_dim ? (size_t)R * m->lm_dim * 4 : 0), o_dinv = take((size_t)R * 4), o_blk = take(32 * 8),
                  o_flag = take(256);   // [binary flag | plist = {0}]
     if (m->host_ws_bytes < o) {
         (void)hipFree(m->host_ws);
@@ -2147,8 +2164,9 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
     float *d_va = reinterpret_cast<float *>(b + o_va), *d_pool = reinterpret_cast<float *>(b + o_pool),
           *d_sc = reinterpret_cast<float *>(b + o_sc);
     if (int rc = mdf_seq_encode_dev(b + o_seq, dd->seq_off, dd->Lq, dd->row_off, 1, R, d_idx, dd->bad, nullptr)) return rc;
-    mdf_agg_desc agg;
-    memset(&agg, 0, sizeof(agg));
+    mdf_agg_desc agg2[2];   // [0]: layer 2, [1]: layer 3 and up
+    memset(agg2, 0, sizeof(agg2));
+    mdf_agg_desc &agg = agg2[0];
     const int32_t seg_all[2] = {0, (int32_t)R};
     if (agg_ok) {
         int32_t *d_flag = reinterpret_cast<int32_t *>(b + o_flag);
@@ -2161,18 +2179,24 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
         int32_t W = 0;
         if (int rc = mdf_cmap_ws_view(b + o_cws, cws, R, (int32_t)L, &d_masks, &W, &d_counts)) return rc;
         if (int rc = mdf_agg_prepare_dev(d_masks, W, d_counts, dd->row_off, dd->Lq, 1, R, reinterpret_cast<float *>(b + o_dinv),
-                                         reinterpret_cast<uint32_t *>(b + o_blk), nullptr))
+                                         reinterpret_cast<uint64_t *>(b + o_blk), nullptr))
             return rc;
-        agg.masks = d_masks, agg.W = W, agg.dinv = reinterpret_cast<const float *>(b + o_dinv), agg.blk = reinterpret_cast<const uint32_t *>(b + o_blk);
-        agg.row_off = dd->row_off, agg.Lq = dd->Lq, agg.plist = d_flag + 1, agg.n_mf = 1, agg.gate = d_flag;
+        agg.masks = d_masks, agg.W = W, agg.dinv = reinterpret_cast<const float *>(b + o_dinv), agg.blk = reinterpret_cast<const uint64_t *>(b + o_blk);
+        agg.row_off = dd->row_off, agg.Lq = dd->Lq, agg.plist = d_flag + 1, agg.gate = d_flag;
         agg.csr_seg = seg_all, agg.n_seg = 1, agg.csr_gated = 1;     // the gather runs (over all rows) only if the map is not binary
         // the rows behind the protein's padded length: zeroed by a memset (harmless after a gather, which covers every row: they are padding)
         agg.tail_row0 = (L + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
         agg.tail_p = -1;
+        agg2[1] = agg2[0];
+        for (int kind = 0; kind < 2; ++kind) {
+            const int cls = mdf_agg_class((int32_t)L, kind == 0);
+            if (cls >= 0) agg2[kind].n_mf[cls] = 1;
+            else agg2[kind].csr_gated = 0, agg2[kind].gate = nullptr;   // this launch kind leaves the protein to the gather whatever its map holds
+        }
     } else if (int rc = mdf_dense_to_csr_dev(b + o_cm, cmap_dtype, dd->cmap_off, dd->Lq, dd->row_off, 1, R, d_rp, d_ci, d_va, nnz_cap,
                                              dd->status, b + o_cws, cws, nullptr))
         return rc;
-    const mdf_agg_desc *aggp = agg_ok ? &agg : nullptr;
+    const mdf_agg_desc *aggp = agg_ok ? agg2 : nullptr;
     float *d_S = reinterpret_cast<float *>(b + o_S), *d_part = reinterpret_cast<float *>(b + o_part);
     if (m->lm_dim) {
         float *d_lmh = reinterpret_cast<float *>(b + o_lmh);
