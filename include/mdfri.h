@@ -312,6 +312,9 @@ typedef struct mdf_agg_desc {
                                  * kernel skips it and the CSR gather launch below takes it (per-call path: known on the device only) */
     const int32_t *csr_seg;     /* HOST: n_seg pairs (first row, row count) left to the CSR gather kernel */
     int32_t n_seg;
+    const uint32_t *skip_groups;/* device, may be NULL: bit g (word g / 32) set = the MDF_GROUP_ROWS rows of group g belong to a listed protein.  When the
+                                 * rows left to the gather fall into many segments (an UNSORTED batch: one launch per segment would be launch-bound)
+                                 * the gather runs ONCE over all rows and skips the flagged groups */
     int32_t csr_gated;          /* 1: the CSR launches run only where gate[protein 0] == 0 (single-protein calls) */
     int64_t tail_row0;          /* rows [tail_row0, R) belong to no protein: the aggregate is zeroed there ... */
     int32_t tail_p;             /* ... by the workgroups of this listed protein (the last one of the rows, when it is on the list), or, < 0, by a

@@ -29,6 +29,7 @@ struct PlanChunk {
     // binary --, once for the launches whose operand is cache-resident ([0]: layer 2) and once for the others ([1]: layer 3 and up)
     struct AggLists {
         int64_t plist_pos;          // position of the list of matrix-pipe proteins (chunk-local indices, class after class) in mdf_plan::agg_plist
+        int64_t skip_pos;           // position (in int32 words of agg_plist) of the chunk's bitmap of 16-row groups owned by listed proteins
         int32_t n_mf[3];            // proteins per length class (mdf_agg_class)
         bool last_listed;           // the chunk's last protein is on the list (its workgroups zero the rows behind it)
         std::vector<int32_t> csr_seg;   // (first row, row count) pairs of the rows of the other proteins: the CSR gather
@@ -165,6 +166,13 @@ extern "C" int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, i
                     }
                 }
                 al.last_listed = mdf_agg_class(Lq[p1 - 1], kind == 0) >= 0;
+                // bitmap of the 16-row groups of the listed proteins (a gather over all rows skips them: unsorted batches, mdf_agg_desc.skip_groups)
+                al.skip_pos = (int64_t)pl->agg_plist.size();
+                pl->agg_plist.resize(pl->agg_plist.size() + (size_t)((R / GROUP_ROWS + 31) / 32), 0);
+                uint32_t *bits = reinterpret_cast<uint32_t *>(pl->agg_plist.data() + al.skip_pos);
+                for (int32_t p = p0; p < p1; ++p)
+                    if (mdf_agg_class(Lq[p], kind == 0) >= 0)
+                        for (int32_t g = ro[p - p0] / GROUP_ROWS; g < (ro[p - p0] + Lq[p] + GROUP_ROWS - 1) / GROUP_ROWS; ++g) bits[g >> 5] |= 1u << (g & 31);
             }
             const int32_t last = p1 - 1 - p0;
             ch.tail_row0 = (int64_t)ro[last] + ((int64_t)Lq[p1 - 1] + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
@@ -625,6 +633,7 @@ static int encode_chunk(mdf_engine *, const mdf_plan *pl, const mdf_batch_dev *b
 struct AggOverride {
     struct Lists {
         const int32_t *d_plist = nullptr;
+        const uint32_t *d_skip = nullptr;   // bitmap of the 16-row groups of the listed proteins
         int32_t n_mf[3] = {0, 0, 0};
         bool last_listed = false;   // the chunk's last protein is on the list
         std::vector<int32_t> csr_seg;
@@ -660,10 +669,12 @@ static int gcn_chunk(mdf_engine *e, mdf_engine::ContactSet &c, const mdf_plan *p
             if (ov) {
                 const AggOverride::Lists &l = ov->k[kind];
                 a.plist = l.d_plist, a.csr_seg = l.csr_seg.data(), a.n_seg = (int32_t)(l.csr_seg.size() / 2), last_listed = l.last_listed;
+                a.skip_groups = l.d_skip;
                 for (int c3 = 0; c3 < 3; ++c3) a.n_mf[c3] = l.n_mf[c3];
             } else {
                 const PlanChunk::AggLists &l = ch.agg[kind];
                 a.plist = pl->d_agg_plist + l.plist_pos, a.csr_seg = l.csr_seg.data(), a.n_seg = (int32_t)(l.csr_seg.size() / 2), last_listed = l.last_listed;
+                a.skip_groups = reinterpret_cast<const uint32_t *>(pl->d_agg_plist + l.skip_pos);
                 for (int c3 = 0; c3 < 3; ++c3) a.n_mf[c3] = l.n_mf[c3];
             }
             // the rows behind the last protein: its workgroups zero them when it is on the matrix-pipe list; otherwise the gather segment of
@@ -1008,7 +1019,8 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         size_t elems = 0;
         for (int32_t p = ch.p0; p < ch.p1; ++p) elems += (size_t)pl->Lq[(size_t)p] * (size_t)pl->Lq[(size_t)p];
         // pinned block: [offsets (Bc x int64) | maps | the two lists of the proteins the matrix-pipe aggregation takes (<= 2 Bc x int32)]
-        const size_t o_maps = align_up((size_t)Bc * 8, 256), o_plist = align_up(o_maps + elems * 4, 256), total = o_plist + (size_t)Bc * 8;   // (two lists: layer 2 / layer 3 and up)
+        const size_t o_maps = align_up((size_t)Bc * 8, 256), o_plist = align_up(o_maps + elems * 4, 256), skip_words = (size_t)((ch.rows / GROUP_ROWS + 31) / 32),
+                     o_skip = align_up(o_plist + (size_t)Bc * 8, 256), total = o_skip + 2 * skip_words * 4;   // (two lists + two group bitmaps: layer 2 / layer 3 and up)
         const int s = parity;
         parity ^= 1;
         if (used[s]) MDF_HIP(hipEventSynchronize(e->map_ev[s]));   // the kernels that read this slot two chunks ago are done
@@ -1096,6 +1108,12 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
                     }
                 }
                 l.last_listed = cls_of(Bc - 1) >= 0;
+                uint32_t *bits = reinterpret_cast<uint32_t *>(e->map_pin[s] + o_skip) + (size_t)kind * skip_words;
+                memset(bits, 0, skip_words * 4);
+                for (int32_t q = 0; q < Bc; ++q)
+                    if (cls_of(q) >= 0)
+                        for (int32_t g = ro[q] / GROUP_ROWS; g < (ro[q] + pl->Lq[(size_t)(ch.p0 + q)] + GROUP_ROWS - 1) / GROUP_ROWS; ++g) bits[g >> 5] |= 1u << (g & 31);
+                l.d_skip = reinterpret_cast<const uint32_t *>(e->map_dev[s].as<char>() + o_skip) + (size_t)kind * skip_words;
             }
         }
         char *d = e->map_dev[s].as<char>();

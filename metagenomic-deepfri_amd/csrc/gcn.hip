@@ -723,7 +723,7 @@ template <int C>
 __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, const int32_t *__restrict__ rowptr,
                                                    const int32_t *__restrict__ colidx, const float *__restrict__ val,
                                                    float *__restrict__ out, int row0, int R, int sb_log, int nt_store,
-                                                   const int32_t *__restrict__ skip_if)
+                                                   const int32_t *__restrict__ skip_if, const uint32_t *__restrict__ skip_groups)
 {
     constexpr int NV = C / 256;
     if (skip_if && *skip_if != 0) return;   // single-protein calls: the matrix-pipe kernel has this protein (its map is binary)
@@ -735,6 +735,7 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, 
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int row = row0 + (sb << sb_log) + (q % per_sb) * 4 + wid;   // rows [row0, R) of this launch
     if (row >= R) return;
+    if (skip_groups && ((skip_groups[row >> 9] >> ((row >> 4) & 31)) & 1u)) return;   // a row of a protein the matrix-pipe kernel aggregates
     const int lane = threadIdx.x & 63;
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
     float4 acc[NV];
@@ -1415,10 +1416,10 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
     static const int sb_log = getenv("MDFRI_AX_SB_LOG") ? atoi(getenv("MDFRI_AX_SB_LOG")) : 9;
     static const int nt_env = getenv("MDFRI_AX_NT") ? atoi(getenv("MDFRI_AX_NT")) : -1;
     const int nt_store = nt_env >= 0 ? nt_env : ((size_t)Ri * Cin * 8 > (size_t)200 << 20);
-    auto gather = [&](int row0, int row_end, const int32_t *skip_if) {   // the CSR gather over rows [row0, row_end)
+    auto gather = [&](int row0, int row_end, const int32_t *skip_if, const uint32_t *skip_groups = nullptr) {   // the CSR gather over rows [row0, row_end)
         const int n_sb = (row_end - row0 + (1 << sb_log) - 1) >> sb_log;
         const int blocks = 8 * (1 << (sb_log - 2)) * ((n_sb + 7) / 8);
-#define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, row0, row_end, sb_log, nt_store, skip_if)
+#define MDF_AX(CC) hipLaunchKernelGGL(k_aggregate<CC>, dim3(blocks), dim3(256), 0, st, Hin, rowptr, colidx, val, AH, row0, row_end, sb_log, nt_store, skip_if, skip_groups)
         if (Cin == 256) MDF_AX(256); else if (Cin == 512) MDF_AX(512); else MDF_AX(1024);
 #undef MDF_AX
     };
@@ -1445,9 +1446,13 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
         MDF_AGG(4, agg->n_mf[2])
 #undef MDF_AGG
     }
-    for (int k = 0; k < agg->n_seg; ++k) {
-        const int row0 = agg->csr_seg[2 * k], cnt = agg->csr_seg[2 * k + 1];
-        if (cnt > 0) gather(row0, row0 + cnt, agg->csr_gated ? agg->gate : nullptr);
+    if (agg->n_seg > 4 && agg->skip_groups) {
+        gather(0, Ri, nullptr, agg->skip_groups);   // many segments (an unsorted batch): one launch over all rows that skips the listed proteins' groups
+    } else {
+        for (int k = 0; k < agg->n_seg; ++k) {
+            const int row0 = agg->csr_seg[2 * k], cnt = agg->csr_seg[2 * k + 1];
+            if (cnt > 0) gather(row0, row0 + cnt, agg->csr_gated ? agg->gate : nullptr);
+        }
     }
     // (tail_p < 0: nobody's workgroups zero the rows behind the last protein -- a gated single-protein call -- : done here)
     if (agg->tail_p < 0 && agg->tail_row0 < Ri) MDF_HIP(hipMemsetAsync(AH + (size_t)agg->tail_row0 * Cin, 0, (size_t)(Ri - agg->tail_row0) * Cin * 4, st));

@@ -248,3 +248,28 @@ def test_sequence_models_on_proteins_sharing_a_32_row_block():
     for i, s in enumerate(seqs):
         assert np.max(np.abs(out[i] - cnn_oracle.cnn_forward(w, s))) < TOL, (i, len(s))
         assert np.array_equal(out[i], pred.forward_pass(s)), (i, len(s))
+
+
+def test_unsorted_batch_takes_the_skip_bitmap_gather(heads):
+    """An UNSORTED batch interleaves proteins of the matrix-pipe length classes with others: the rows left to the CSR gather fall into many
+    segments, and the gather then runs once over all rows, skipping the 16-row groups of the listed proteins (mdf_agg_desc.skip_groups)
+    instead of one launch per segment.  Same results as per call, bit for bit, and as the same proteins sorted by length."""
+    from mDeepFRI.batch import HotPathEngine
+    ws, preds = heads
+    rng = np.random.default_rng(12)
+    lengths = [int(x) for x in rng.choice([40, 90, 130, 200, 256, 300, 420, 512, 530, 700, 1030], size=44)]
+    prots = [synthetic.synthetic_proteins(seed=800 + k, count=1, length=L, indel_rate=0.04)[0] for k, L in enumerate(lengths)]
+    eng = HotPathEngine(preds, device=0, max_rows=65536)
+    pk = _pack(prots, max_rows=65536)
+    assert len(pk.chunks) == 1                      # one chunk: every class and many gather segments side by side
+    out = eng.run_alignments(pk)
+    order = np.argsort(lengths, kind="stable")
+    out_sorted = eng.run_alignments(_pack([prots[i] for i in order], max_rows=65536))
+    for m in eng.modes:
+        assert np.array_equal(out[m][order], out_sorted[m]), m
+    for i in (0, 5, 17, 30, 43):
+        p = prots[i]
+        cm = orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2)
+        for m in eng.modes:
+            assert np.array_equal(out[m][i], preds[m].forward_pass(p["seq"], cm)), (m, i, lengths[i])
+            assert np.max(np.abs(out[m][i] - gcn_oracle.gcn_forward(ws[m], p["seq"], cm))) < TOL, (m, i)
