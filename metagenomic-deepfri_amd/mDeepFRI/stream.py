@@ -124,7 +124,7 @@ class AlignmentStream:
 @dataclass
 class QueryBatchResult:
     """One slice of the input after QueryStream: `batch` = the AlignedBatch of the queries that had candidates (`aligned`: their positions
-    inside the slice), `kept` = positions inside `batch` whose hit had a structure and `gcn` the filter's arrays for exactly those
+    inside the slice, in the batch's order -- shortest query first unless the stream was made with sort_by_length=False), `kept` = positions inside `batch` whose hit had a structure and `gcn` the filter's arrays for exactly those
     ({mode: (offsets, term_idx, scores)}); `sequence_only` = positions inside the slice without a structure (no candidate, or a hit
     without a trace) and `cnn` the filter's arrays of the sequence-only heads for those (empty without a sequence engine)."""
     first: int
@@ -160,14 +160,19 @@ class QueryStream:
     the CNN heads for the sequence-only queries (optional).  keep_scores: also hand out the full score matrices (`gcn_scores` /
     `cnn_scores`: {mode: float32 (rows, T)}, what `output.write_prediction_matrix` takes) -- 11 KB per protein and three heads more over
     PCIe, on the side stream.  batch_chunks > 0: cut the batches by residue rows instead of by count -- as many queries as fill that many
-    chunks of `max_rows` padded rows (a batch of N queries ends in a mostly empty chunk that still costs whole GEMM rounds)."""
+    chunks of `max_rows` padded rows (a batch of N queries ends in a mostly empty chunk that still costs whole GEMM rounds).
+    sort_by_length (default): the queries of one batch go through the path shortest first, as the reference's work list does
+    (pipeline.py:529-533 sorts it by length) -- proteins of like length then share chunks, which is what the per-length choice of the
+    aggregation kernel is built for (4 000-query batches, three heads, same box: 77.5 k proteins/s sorted against 71.5 k in arrival
+    order; profiles/r04_stream_order.txt).  The results do not depend on it (every protein's scores are the same bits in any batch);
+    `aligned[k]` is the position inside the slice of batch entry k."""
 
     def __init__(self, engine: HotPathEngine, structures, batch_size: int = 4000, max_rows: int = 65536, scoring_matrix="VTML80",
                  gap_open: int = 10, gap_extend: int = 1, threshold: float = 0.1, capacity_per_protein: int = 64, sequence_engine=None,
-                 keep_scores: bool = False, batch_chunks: int = 0):
+                 keep_scores: bool = False, batch_chunks: int = 0, sort_by_length: bool = True):
         import torch
         from .alignment import AlignerWorkspace
-        self.batch_chunks = int(batch_chunks)
+        self.batch_chunks, self.sort_by_length = int(batch_chunks), bool(sort_by_length)
         self.engine, self.structures, self.sequence_engine = engine, structures, sequence_engine
         self.batch_size, self.max_rows = int(batch_size), int(max_rows)
         self.scoring_matrix, self.gap_open, self.gap_extend = scoring_matrix, int(gap_open), int(gap_extend)
@@ -206,8 +211,10 @@ class QueryStream:
                     if t < nb:
                         a, b = starts[t], ends[t]
                         pos = [i for i in range(a, b) if len(target_sequences[i]) > 0]
+                        if self.sort_by_length:      # batch entry k is query pos[k]: `aligned` hands the order out
+                            pos.sort(key=lambda i: len(query_sequences[i]))
                         slices[t] = (a, b, pos)
-                        if len(pos) == b - a:
+                        if len(pos) == b - a and not self.sort_by_length:
                             args = (query_ids[a:b], query_sequences[a:b], target_sequences[a:b])
                         else:
                             args = ([query_ids[i] for i in pos], [query_sequences[i] for i in pos], [target_sequences[i] for i in pos])

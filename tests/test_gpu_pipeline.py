@@ -204,7 +204,8 @@ def test_query_stream_with_a_language_model_head():
     stream = QueryStream(eng, db_xyz, batch_size=30, max_rows=4096, scoring_matrix=sm, keep_scores=True)
     n = 0
     for r in stream.run(qids, qseqs, cands):
-        one = align_queries_arrays(qids[r.first:r.first + r.count], qseqs[r.first:r.first + r.count], cands[r.first:r.first + r.count], scoring_matrix=sm)
+        sel = [r.first + i for i in r.aligned]      # the batch's own order (shortest query first)
+        one = align_queries_arrays([qids[i] for i in sel], [qseqs[i] for i in sel], [cands[i] for i in sel], scoring_matrix=sm)
         pk, kept = PackedProteins.from_aligned_batch(one, [db_xyz[k] for k in one.target_keys], max_rows=4096)
         assert kept == r.kept
         ref = eng.run_alignments(pk)
@@ -261,9 +262,11 @@ def test_query_stream_batches_cut_by_rows_give_the_same_results():
             firsts.append((r.first, r.count))
             off, ti, sc = r.gcn["a"]
             for k, i in enumerate(r.kept):
-                out[r.first + i] = (ti[off[k]:off[k + 1]].tobytes(), sc[off[k]:off[k + 1]].tobytes())
+                out[r.first + r.aligned[i]] = (ti[off[k]:off[k + 1]].tobytes(), sc[off[k]:off[k + 1]].tobytes())
         return out, firsts
     by_count, f1 = per_query(QueryStream(eng, db_xyz, batch_size=40, max_rows=4096, scoring_matrix=sm))
+    arrival, f0 = per_query(QueryStream(eng, db_xyz, batch_size=40, max_rows=4096, scoring_matrix=sm, sort_by_length=False))
+    assert arrival == by_count and f0 == f1      # shortest-first inside a batch (the default) or arrival order: the same bits per query
     by_rows, f2 = per_query(QueryStream(eng, db_xyz, batch_size=40, max_rows=4096, scoring_matrix=sm, batch_chunks=2))
     assert by_count == by_rows and len(by_rows) == 150
     assert f1 != f2 and sum(c for _, c in f2) == 150 and all(a + c == b for (a, c), (b, _) in zip(f2, f2[1:]))

@@ -89,7 +89,8 @@ def stream_main(n_batches=int(os.environ.get("NB", 6)), batch=int(os.environ.get
     weights = {m: synthetic.glorot_gcn_weights(seed=i, n_terms=synthetic.GO_TERMS[m], sparse_scores=True) for i, m in enumerate(MODES)}
     eng = HotPathEngine({m: Predictor(f"syn-{m}", weights=weights[m]) for m in MODES}, max_rows=65536)
     terms = {m: [f"GO:{k:07d}" for k in range(synthetic.GO_TERMS[m])] for m in MODES}
-    qs = QueryStream(eng, db_xyz, batch_size=batch, scoring_matrix=sm, threshold=THRESHOLD, batch_chunks=int(os.environ.get("BATCH_CHUNKS", 0)))
+    qs = QueryStream(eng, db_xyz, batch_size=batch, scoring_matrix=sm, threshold=THRESHOLD, batch_chunks=int(os.environ.get("BATCH_CHUNKS", 0)),
+                     sort_by_length=os.environ.get("SORT", "1") != "0")
     for rep in range(2):             # first pass warms allocations up
         t0 = time.perf_counter()
         n_lines = n_bytes = 0

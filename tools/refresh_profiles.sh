@@ -5,6 +5,7 @@
 set -u
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 O=gpurun_out/refresh
+rm -rf "$O"      # a scratch directory of an earlier call must not leak its traces into the summaries
 mkdir -p "$O"
 T="timeout 600"
 $T python3 bench.py > "$O/r_bench_line.json" 2> "$O/bench.err"                                                   # -> profiles/rNN_bench_line.json

@@ -27,7 +27,7 @@ def main():
             for m in pe.MODES:
                 off, ti, sc = r.gcn[m]
                 for k, i in enumerate(r.kept):
-                    per_query[(r.first + i, m)] = (ti[off[k]:off[k + 1]].tobytes(), sc[off[k]:off[k + 1]].tobytes())
+                    per_query[(r.first + r.aligned[i], m)] = (ti[off[k]:off[k + 1]].tobytes(), sc[off[k]:off[k + 1]].tobytes())
         for key in sorted(per_query):
             h.update(per_query[key][0]); h.update(per_query[key][1])
         digests.append(h.hexdigest())
