@@ -20,13 +20,13 @@ timed region:
   --workload cnn       the sequence-only CNN models (extra measurement)
 
 Objects on the line (tier contract):
-  roofline      dominant kernel (H.W fp32-MFMA GEMM): algorithmic flops per launch / mean launch duration measured with HIP events
+  roofline      dominant kernel (the H.W GEMM; BF16x6 on the bf16 matrix pipe, see csrc/gcn.hip): algorithmic fp32 flops per launch / mean launch duration measured with HIP events
                 on the launch stream inside the timed region (mdf_timing_* hooks of the library)
   roofline_ax   the same for the A.X aggregation kernel against the HBM roofline (the north_star's named kernel)
   cpu_baseline  the oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample: one thread
                 (the configuration the reference ships) and a pool of single-thread worker processes (the reference's own
                 parallelism, pipeline.py:476-481); real onnxruntime-CPU on the exported synthetic weights when ORT is importable
-  by_length / mixed / helix / gcn_only / end_to_end / query_stream   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix,
+  by_length / mixed / helix / f32_pipe / gcn_only / end_to_end / query_stream   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix,
   protein-like helix-bundle traces (fewer contacts per residue than a random walk), the GCN alone on given contact maps, the
                 PCIe-inclusive host-lists-in / host-arrays-out rate, and the stages either side of the path as one stream
                 (sequences + candidate sets in -> aligner -> path -> filter -> results.tsv text out) -- never `value`
@@ -48,6 +48,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
+MFMA_BF16_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s, no sparsity)
+BF16X6_PRODUCTS = 6        # bf16 term products per fp32 product in k_gemm_bf16x6 (csrc/gcn.hip)
 MODES = ("mf", "bp", "cc")
 STRONG = {"configs3": (100000, 46), "configs4": (500000, 47)}   # workload -> (proteins, seed = 42 + 1-based config number)
 
@@ -435,14 +437,28 @@ def rooflines(ctx, eng, pk, kernels, lm):
         # with --lm the class also holds the unfolded layer-1 launch (K = 1024): mean over the three layers
         flops_launch = 2.0 * rows_launch * C * ((1024 + C + C) / 3.0 if lm else C)
         tf = flops_launch / (g["avg_us"] * 1e-6) / 1e12
+        # the roofline of the pipe the kernel runs on (mdf_hw_pipe): BF16x6 executes six bf16 term products per fp32 product, so the
+        # bf16 matrix peak / 6 bounds the ALGORITHMIC (fp32) flop rate of the method; the fp32 instruction's own peak is kept beside it
+        pipe = ctx.lib.mdf_hw_pipe().decode()
+        peak = MFMA_BF16_PEAK_TF / BF16X6_PRODUCTS if pipe == "bf16x6" else MFMA_F32_PEAK_TF
         per_layer = {k: {"avg_us": kernels[k]["avg_us"], "timed_launches": kernels[k]["launches"],
-                         "frac": round(2.0 * rows_launch * C * C / (kernels[k]["avg_us"] * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, 4)}
+                         "frac": round(2.0 * rows_launch * C * C / (kernels[k]["avg_us"] * 1e-6) / 1e12 / peak, 4)}
                      for k in ("gemm2", "gemm3") if kernels.get(k, {}).get("launches") and not lm}
-        roof = {"kernel": "k_gemm_f32 (H.W, 256x256x32 tiles, v_mfma_f32_32x32x2_f32, LDS-DMA staging, ELU+pool epilogue)",
-                "bound": "mfma", "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TF, 4),
+        if pipe == "bf16x6":
+            name = ("k_gemm_bf16x6 (H.W as BF16x6: fp32 operands split in registers into three bf16 terms, six term products per fp32 product on "
+                    "v_mfma_f32_32x32x16_bf16, fp32 accumulate; 256x256x32 tiles, LDS-DMA staging, ELU+pool epilogue)")
+        else:
+            name = "k_gemm_f32 (H.W, 256x256x32 tiles, v_mfma_f32_32x32x2_f32, LDS-DMA staging, ELU+pool epilogue)"
+        roof = {"kernel": name, "pipe": pipe,
+                "bound": "mfma", "achieved": round(tf, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tf / peak, 4),
                 "traffic": traffic.get("gemm_mean_bytes"), "traffic_source": src,
                 "per_launch": {"rows": R, "flops": 2.0 * R * C * C, "avg_us": g["avg_us"], "timed_launches": g["launches"]},
                 "per_layer": per_layer}
+        if pipe == "bf16x6":
+            roof["peak_note"] = (f"bf16 dense MFMA peak {MFMA_BF16_PEAK_TF:.0f} TFLOP/s / {BF16X6_PRODUCTS} term products per fp32 product; `achieved` counts the "
+                                 "algorithmic fp32 flops (2.R.K.N), the matrix pipe executes six times that")
+            roof["executed_bf16_tflops"] = round(tf * BF16X6_PRODUCTS, 1)
+            roof["vs_f32_instruction_peak"] = round(tf / MFMA_F32_PEAK_TF, 4)
     if a.get("launches"):
         # read Z (rows x 512 f32) once + write (rows x 512 f32) once per layer; CSR adjacency (4 B colidx
         # + 4 B val per entry + 4 B rowptr per row) added and stated
@@ -784,6 +800,23 @@ def main():
                                                   "launch times): the GCN kernels alone on maps already in HBM"}
                 return res
 
+            def f32_pipe_leg():
+                # the same headline step with the H.W products on the fp32 matrix instruction (MDFRI_HW_PIPE=f32, read at library load: a child
+                # process started before anything else of this one runs on the device again): the comparison the BF16x6 claim rests on
+                torch.cuda.synchronize()
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+                env["MDFRI_HW_PIPE"] = "f32"
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-extras", "--cpu-seconds", "0",
+                                    "--proteins", str(n_local), "--length", str(args.length), "--chunk-rows", str(args.chunk_rows)],
+                                   env=env, capture_output=True, text=True, timeout=900)
+                sub = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                return {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"], "pipe": sub["roofline"]["pipe"],
+                        "roofline_frac": sub["roofline"]["frac"], "gemm_avg_us": sub["roofline"]["per_launch"]["avg_us"],
+                        "max_abs_err_vs_oracle": sub["verify"]["max_abs_err_vs_oracle"],
+                        "note": "the same run with H.W on v_mfma_f32_32x32x2_f32 (k_gemm_f32; MDFRI_HW_PIPE=f32): its rate, its fraction of the fp32 "
+                                "instruction's peak, and its error against the float64 oracle beside the default path's `verify`; never `value`"}
+
+            leg("f32_pipe", f32_pipe_leg)
             leg("gcn_only", gcn_only_leg)
             if args.end_to_end > 0:
                 leg("end_to_end", end_to_end_leg)

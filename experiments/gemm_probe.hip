@@ -104,7 +104,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&dA, hA.size() * 4));
     CK(hipMalloc(&dB, hB.size() * 4));
     CK(hipMalloc(&dC, (size_t)M * N * 4));
-    CK(hipMalloc(&dP, (size_t)(M / 32) * N * 4));
+    CK(hipMalloc(&dP, (size_t)(M / 16) * N * 4));   // one partial per 16-row pooling group
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice));
     const double flops = 2.0 * M * N * K;

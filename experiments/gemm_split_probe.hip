@@ -28,8 +28,8 @@ struct Raw {
     float4 u, v;
 };
 
-// one pair of a fragment: 2 fp32 -> one dword of each plane (truncation splits: every remainder is exact, the last one has at most 8
-// significant bits).  9 VALU instructions: 2 and + 1 packed subtract, twice, and 3 byte permutes.
+// one pair of a fragment: 2 fp32 -> one dword of each plane: hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid, round to nearest -- every
+// remainder is exact, |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|.  9 VALU instructions: 3 packed conversions, 2 packed subtracts, 4 shifts/ands.
 #ifndef SPLIT_ABL
 #define SPLIT_ABL 0
 #endif
@@ -41,14 +41,15 @@ __device__ __forceinline__ void pairstep(const Raw &r, const int i, Planes &o)
     }
     const float x0 = i == 0 ? r.u.x : i == 1 ? r.u.z : i == 2 ? r.v.x : r.v.z;
     const float x1 = i == 0 ? r.u.y : i == 1 ? r.u.w : i == 2 ? r.v.y : r.v.w;
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
     const v2f xx = {x0, x1};
-    const v2f hi = {__uint_as_float(__float_as_uint(x0) & 0xffff0000u), __uint_as_float(__float_as_uint(x1) & 0xffff0000u)};
-    const v2f r1 = xx - hi;
-    const v2f mi = {__uint_as_float(__float_as_uint(r1.x) & 0xffff0000u), __uint_as_float(__float_as_uint(r1.y) & 0xffff0000u)};
-    const v2f r2 = r1 - mi;
-    o.h[i] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
-    o.m[i] = __builtin_amdgcn_perm(__float_as_uint(r1.y), __float_as_uint(r1.x), 0x07060302u);
-    o.l[i] = __builtin_amdgcn_perm(__float_as_uint(r2.y), __float_as_uint(r2.x), 0x07060302u);
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(xx, v2bf));            // round to nearest even: v_cvt_pk_bf16_f32
+    const v2f r1 = xx - (v2f){__uint_as_float(hp << 16), __uint_as_float(hp & 0xffff0000u)};         // exact
+    const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, v2bf));
+    const v2f r2 = r1 - (v2f){__uint_as_float(mp << 16), __uint_as_float(mp & 0xffff0000u)};         // exact, at most 8 significant bits left
+    o.h[i] = hp;
+    o.m[i] = mp;
+    o.l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, v2bf));
 }
 __device__ __forceinline__ void split8(const Raw &r, Planes &o)
 {
@@ -156,8 +157,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_split(const float *__r
 #define STEP(tm_, PAc, PB0, PB1, X0, X1, X2, X3, X4, X5, X6, X7, X8, X9, X10, X11, X12, X13, X14, X15, X16, X17)                   \
     {                                                                                                                              \
         const Planes &a_ = PAc, &b0_ = PB0, &b1_ = PB1;                                                                            \
-        MF(tm_, l, l, 0) X0 SB MF(tm_, l, l, 1) X1 SB MF(tm_, l, m, 0) X2 SB MF(tm_, l, m, 1) X3 SB                                \
-        MF(tm_, m, l, 0) X4 SB MF(tm_, m, l, 1) X5 SB MF(tm_, l, h, 0) X6 SB MF(tm_, l, h, 1) X7 SB                                \
+        if (NPROD >= 9) { MF(tm_, l, l, 0) } X0 SB if (NPROD >= 9) { MF(tm_, l, l, 1) } X1 SB                                      \
+        if (NPROD >= 8) { MF(tm_, l, m, 0) } X2 SB if (NPROD >= 8) { MF(tm_, l, m, 1) } X3 SB                                      \
+        if (NPROD >= 7) { MF(tm_, m, l, 0) } X4 SB if (NPROD >= 7) { MF(tm_, m, l, 1) } X5 SB MF(tm_, l, h, 0) X6 SB MF(tm_, l, h, 1) X7 SB \
         MF(tm_, m, m, 0) X8 SB MF(tm_, m, m, 1) X9 SB MF(tm_, h, l, 0) X10 SB MF(tm_, h, l, 1) X11 SB                              \
         MF(tm_, m, h, 0) X12 SB MF(tm_, m, h, 1) X13 SB MF(tm_, h, m, 0) X14 SB MF(tm_, h, m, 1) X15 SB                            \
         MF(tm_, h, h, 0) X16 SB MF(tm_, h, h, 1) X17 SB                                                                            \

@@ -226,6 +226,11 @@ int mdf_cnn_forward_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, c
 #define MDF_GROUP_ROWS 16
 int mdf_group_rows(void);   /* = MDF_GROUP_ROWS, for callers that do not compile against this header */
 
+/* Which matrix pipe the graph-convolution products H.W run on in this process: "bf16x6" (default: every fp32 operand split into three
+ * bf16 terms, six term products per fp32 product accumulated in fp32 -- k_gemm_bf16x6, csrc/gcn.hip; error against float64 below the
+ * fp32 instruction's) or "f32" (v_mfma_f32_32x32x2_f32; environment MDFRI_HW_PIPE=f32, read once).  fp32 in, fp32 out either way. */
+const char *mdf_hw_pipe(void);
+
 /* Host helper: row_off[0..B] from Lq[0..B-1] as specified above.  Returns R (total rows) or a negative code. */
 int64_t mdf_layout_rows(const int32_t *Lq, int32_t B, int32_t *row_off);
 

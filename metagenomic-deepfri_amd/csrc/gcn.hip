@@ -54,6 +54,8 @@ struct mdf_model {
 namespace mdf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));   // operand of v_mfma_f32_32x32x16_bf16: lane l holds row l&31, k = 8 (l>>5) .. + 7
 
 constexpr int BM = 256, BN = 256, BK = 32;   // GEMM tile (see k_gemm_f32)
 constexpr int GEMM_THREADS = 512;
@@ -532,6 +534,205 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
 }
 
 
+// ---- H.W on the bf16 matrix pipe: BF16x6 ------------------------------------------------------------------------------------------
+// The fp32 matrix instruction runs at 1/16 of the bf16 one (157 vs 2 500 TFLOP/s), so an fp32 product is cheaper as SIX bf16 products:
+// every operand is split on the fly into three bf16 terms, hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid (round to nearest; both
+// remainders are exact and lo fits bf16, so hi + mid + lo == x bit for bit, |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|), and
+//     a.b  ~  ah.bh + (ah.bm + am.bh) + (am.bm + ah.bl + al.bh),
+// each term product exact in fp32, accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  The three products left
+// out (am.bl, al.bm, al.bl) are together below 2^-26 |a.b| -- a quarter of the rounding of ONE fp32 multiplication -- so the result
+// carries the accumulation rounding of an fp32 GEMM and nothing else: measured against float64 on 65 536 x 512 x 512 the error is
+// rms 2.49e-7 / max 2.4e-6, the same to four digits as with all nine products, and below the fp32 pipe's own 2.95e-7 / 3.4e-6
+// (profiles/r04_gemm_bf16x6_probe.txt).  Vector and matrix instructions of a SIMD do not overlap on this part, and at full bf16 rate
+// the chip throttles to ~1.5 GHz: the in-register split (9 VALU instructions per operand pair) and the six products together land at
+// the same 160 us per 65 536 x 512 x 512 as a version fed pre-split operands with the matrix pipe saturated -- the power floor.
+struct SplitPlanes {
+    u32x4 h, m, l;   // 8 bf16 each
+};
+struct SplitRaw {
+    float4 u, v;     // the 8 fp32 of one fragment
+};
+// operands 2 i, 2 i + 1 of a fragment -> dword i of each plane: 3 packed conversions (v_cvt_pk_bf16_f32), 2 packed subtractions, 4 shifts / ands
+__device__ __forceinline__ void split_pair(const SplitRaw &r, const int i, SplitPlanes &o)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    const float x0 = i == 0 ? r.u.x : i == 1 ? r.u.z : i == 2 ? r.v.x : r.v.z;
+    const float x1 = i == 0 ? r.u.y : i == 1 ? r.u.w : i == 2 ? r.v.y : r.v.w;
+    const v2f xx = {x0, x1};
+    const unsigned hp = __builtin_bit_cast(unsigned, __builtin_convertvector(xx, v2bf));
+    const v2f r1 = xx - (v2f){__uint_as_float(hp << 16), __uint_as_float(hp & 0xffff0000u)};
+    const unsigned mp = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, v2bf));
+    const v2f r2 = r1 - (v2f){__uint_as_float(mp << 16), __uint_as_float(mp & 0xffff0000u)};
+    o.h[i] = hp;
+    o.m[i] = mp;
+    o.l[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, v2bf));
+}
+__device__ __forceinline__ void split_fragment(const SplitRaw &r, SplitPlanes &o)
+{
+    split_pair(r, 0, o);
+    split_pair(r, 1, o);
+    split_pair(r, 2, o);
+    split_pair(r, 3, o);
+}
+// the six term products of one 32 x 32 x 16 block, in THE order every BF16x6 kernel uses (results are bit-identical across them)
+#define MDF_X6_SEQ(acc_, a_, b_)                                                                                                  \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a_).l), __builtin_bit_cast(bf16x8, (b_).h), acc_, 0, 0, 0); \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a_).m), __builtin_bit_cast(bf16x8, (b_).m), acc_, 0, 0, 0); \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a_).h), __builtin_bit_cast(bf16x8, (b_).l), acc_, 0, 0, 0); \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a_).m), __builtin_bit_cast(bf16x8, (b_).h), acc_, 0, 0, 0); \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a_).h), __builtin_bit_cast(bf16x8, (b_).m), acc_, 0, 0, 0); \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a_).h), __builtin_bit_cast(bf16x8, (b_).h), acc_, 0, 0, 0);
+
+// k_gemm_bf16x6: C[M,N] = epilogue(A[M,K] . Bt[N,K]^T), fp32 in and out.  Geometry, staging, LDS image, tile order and epilogues are
+// k_gemm_f32's (256 x 256 x 32 positions, 8 waves x (4 x 2) tiles of 32 x 32, LDS-DMA into two 64 KiB buffers, XOR-swizzled rows, one
+// barrier per position, one flat (tile, position) pipeline); a position is two halves of 16 k.  Lane l of a fragment holds row l & 31
+// and the 8 consecutive k of its half, (l >> 5): two ds_read_b128, then the split.  A step = one A tile against both B tiles (12 matrix
+// instructions) with the next step's fragment reads and splits, and in the first half the next position's DMA, riding behind them.
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
+                                                                 int N, int K, float *__restrict__ C, int ldc, float *__restrict__ pool_partial,
+                                                                 int ldp, int total_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A 256x32 | B 256x32], unpadded rows (as k_gemm_f32)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wid >> 2, wn = wid & 3;
+    const int NT = N / BN, nk = K / BK, stride = gridDim.x;
+    TileCursor cc;
+    cc.kt = 0;
+    int n_mine = 0;
+    {
+        int first = -1, mt, nt;
+        for (int t = blockIdx.x; t < total_tiles; t += stride) {
+            tile_of_block<false>(t, NT, mt, nt);
+            if (mt * BM < M) {
+                if (first < 0) { first = t; cc.t = t; cc.mt = mt; cc.nt = nt; }
+                ++n_mine;
+            }
+        }
+        if (first < 0) return;
+    }
+    int rem = n_mine * nk;
+    TileCursor pc = cc;
+    const int drow = lane >> 3, dslot = lane & 7;
+    int dcol[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dcol[i] = (dslot ^ ((4 * i + (lane >> 4)) & 7)) * 4;
+    const int frow = lane & 31, fswz = (frow >> 1) & 7, hl = lane >> 5;
+    const int fbaseA = (wm * 128 + frow) * 32, fbaseB = (wn * 64 + frow) * 32;
+    int fk[2];   // float offset of the lane's first 16-byte slot in half 0 / 1 (the second slot is this ^ 4)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) fk[kk] = ((4 * kk + 2 * hl) ^ fswz) << 2;
+
+    const float *baseA, *baseB;
+    unsigned oa0, oa1, oa2, oa3;
+    const unsigned ob0 = (unsigned)((drow + 0) * ldb + dcol[0]) * 4u, ob1 = (unsigned)((drow + 8) * ldb + dcol[1]) * 4u,
+                   ob2 = (unsigned)((drow + 16) * ldb + dcol[2]) * 4u, ob3 = (unsigned)((drow + 24) * ldb + dcol[3]) * 4u;
+#define MDF_DMA_SETUP(cur_)                                                                 \
+    {                                                                                       \
+        baseA = A + (size_t)(cur_).kt * BK;                                                 \
+        baseB = Bt + (size_t)((cur_).nt * BN + wid * 32) * ldb + (size_t)(cur_).kt * BK;    \
+        const int rA_ = (cur_).mt * BM + wid * 32 + drow;                                   \
+        oa0 = (unsigned)(min(rA_, M - 1) * lda + dcol[0]) * 4u;                             \
+        oa1 = (unsigned)(min(rA_ + 8, M - 1) * lda + dcol[1]) * 4u;                         \
+        oa2 = (unsigned)(min(rA_ + 16, M - 1) * lda + dcol[2]) * 4u;                        \
+        oa3 = (unsigned)(min(rA_ + 24, M - 1) * lda + dcol[3]) * 4u;                        \
+    }
+#define MDF_DMA_A(i) glds16s(baseA, oa##i, ldsA + (unsigned)((wid * 4 + (i)) * 1024));
+#define MDF_DMA_B(i) glds16s(baseB, ob##i, ldsB + (unsigned)((wid * 4 + (i)) * 1024));
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    const unsigned lds_base = lds_addr_of(smem);
+
+#define MDF_RD(raw_, base_, tile_, kk_)                                                               \
+    {                                                                                                 \
+        (raw_).u = *reinterpret_cast<const float4 *>((base_) + (tile_) * 1024 + fk[kk_]);             \
+        (raw_).v = *reinterpret_cast<const float4 *>((base_) + (tile_) * 1024 + (fk[kk_] ^ 4));       \
+    }
+    SplitPlanes PA[2], PB[2][2];
+    SplitRaw ra, rb, rc;
+    {   // prologue: position 0 -> buffer 0; source addresses of position 1; the first fragments
+        MDF_DMA_SETUP(pc)
+        const unsigned ldsA = lds_base, ldsB = lds_base + BM * BK * 4;
+        MDF_DMA_A(0) MDF_DMA_B(0) MDF_DMA_A(1) MDF_DMA_B(1) MDF_DMA_A(2) MDF_DMA_B(2) MDF_DMA_A(3) MDF_DMA_B(3)
+        cursor_advance<false>(pc, nk, NT, M, total_tiles, stride);
+        MDF_DMA_SETUP(pc)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        MDF_RD(rb, smem + BM * BK + fbaseB, 0, 0)
+        split_fragment(rb, PB[0][0]);
+        MDF_RD(rc, smem + BM * BK + fbaseB, 1, 0)
+        split_fragment(rc, PB[0][1]);
+        MDF_RD(ra, smem + fbaseA, 0, 0)
+        split_fragment(ra, PA[0]);
+    }
+
+#define MDF_SB __builtin_amdgcn_sched_barrier(0);
+#define MDF_BF(x_) __builtin_bit_cast(bf16x8, x_)
+#define MDF_MF(tm_, pa_, pb_, t_) acc[tm_][t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MDF_BF(a_.pa_), MDF_BF(b##t_##_.pb_), acc[tm_][t_], 0, 0, 0);
+    // P rides in front of the step, X0..X11 behind its matrix instructions (the product order per tile is MDF_X6_SEQ's)
+#define MDF_STEP(tm_, PAc, PB0, PB1, P, X0, X1, X2, X3, X4, X5, X6, X7, X8, X9, X10, X11)                                           \
+    {                                                                                                                              \
+        const SplitPlanes &a_ = PAc, &b0_ = PB0, &b1_ = PB1;                                                                       \
+        P MDF_SB                                                                                                                   \
+        MDF_MF(tm_, l, h, 0) X0 MDF_SB MDF_MF(tm_, l, h, 1) X1 MDF_SB MDF_MF(tm_, m, m, 0) X2 MDF_SB MDF_MF(tm_, m, m, 1) X3 MDF_SB \
+        MDF_MF(tm_, h, l, 0) X4 MDF_SB MDF_MF(tm_, h, l, 1) X5 MDF_SB MDF_MF(tm_, m, h, 0) X6 MDF_SB MDF_MF(tm_, m, h, 1) X7 MDF_SB \
+        MDF_MF(tm_, h, m, 0) X8 MDF_SB MDF_MF(tm_, h, m, 1) X9 MDF_SB MDF_MF(tm_, h, h, 0) X10 MDF_SB MDF_MF(tm_, h, h, 1) X11 MDF_SB \
+    }
+#define MDF_PS(raw_, i_, P_) split_pair(raw_, i_, P_);
+    int cur = 0;
+    while (true) {
+        const float *Ab = smem + cur * ((BM + BN) * BK) + fbaseA;
+        const float *Bb = smem + cur * ((BM + BN) * BK) + BM * BK + fbaseB;
+        const float *An = smem + (cur ^ 1) * ((BM + BN) * BK) + fbaseA;
+        const float *Bn = smem + (cur ^ 1) * ((BM + BN) * BK) + BM * BK + fbaseB;
+        const unsigned ldsA = lds_base + (cur ^ 1) * ((BM + BN) * BK * 4), ldsB = ldsA + BM * BK * 4;
+        // half 0: the whole DMA of the next position; the B fragments of half 1
+        MDF_STEP(0, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 1, 0), MDF_DMA_A(0), MDF_DMA_B(0), MDF_DMA_A(1), MDF_DMA_B(1), MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
+        MDF_STEP(1, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 2, 0), MDF_DMA_A(2), MDF_DMA_B(2), MDF_DMA_A(3), MDF_DMA_B(3), MDF_PS(ra, 0, PA[0]), , MDF_PS(ra, 1, PA[0]), , MDF_PS(ra, 2, PA[0]), , MDF_PS(ra, 3, PA[0]), )
+        MDF_STEP(2, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 3, 0) MDF_RD(rb, Bb, 0, 1), , , , , MDF_PS(ra, 0, PA[1]), MDF_PS(rb, 0, PB[1][0]), MDF_PS(ra, 1, PA[1]), MDF_PS(rb, 1, PB[1][0]), MDF_PS(ra, 2, PA[1]), MDF_PS(rb, 2, PB[1][0]), MDF_PS(ra, 3, PA[1]), MDF_PS(rb, 3, PB[1][0]))
+        MDF_STEP(3, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 0, 1) MDF_RD(rb, Bb, 1, 1), , , , , MDF_PS(ra, 0, PA[0]), MDF_PS(rb, 0, PB[1][1]), MDF_PS(ra, 1, PA[0]), MDF_PS(rb, 1, PB[1][1]), MDF_PS(ra, 2, PA[0]), MDF_PS(rb, 2, PB[1][1]), MDF_PS(ra, 3, PA[0]), MDF_PS(rb, 3, PB[1][1]))
+        // half 1: the source addresses of the position after next, then the barrier and the next position's first fragments
+        MDF_STEP(0, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 1, 1), , , , , MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
+        cursor_advance<false>(pc, nk, NT, M, total_tiles, stride);
+        MDF_DMA_SETUP(pc)
+        MDF_STEP(1, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 2, 1), , , , , MDF_PS(ra, 0, PA[0]), , MDF_PS(ra, 1, PA[0]), , MDF_PS(ra, 2, PA[0]), , MDF_PS(ra, 3, PA[0]), )
+        MDF_STEP(2, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 3, 1), , , , , MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next position has landed ...
+        __syncthreads();                                     // ... and everybody's; nobody reads this position's buffer any more
+        MDF_STEP(3, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, An, 0, 0) MDF_RD(rb, Bn, 0, 0) MDF_RD(rc, Bn, 1, 0), , , MDF_PS(ra, 0, PA[0]), MDF_PS(rb, 0, PB[0][0]), MDF_PS(rc, 0, PB[0][1]) MDF_PS(ra, 1, PA[0]), MDF_PS(rb, 1, PB[0][0]), MDF_PS(rc, 1, PB[0][1]) MDF_PS(ra, 2, PA[0]), MDF_PS(rb, 2, PB[0][0]), MDF_PS(rc, 2, PB[0][1]) MDF_PS(ra, 3, PA[0]), MDF_PS(rb, 3, PB[0][0]), MDF_PS(rc, 3, PB[0][1]), )
+        if (cc.kt == nk - 1) {
+            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, nullptr, pool_partial, ldp, nullptr, N, GemmAux());
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+        }
+        --rem;
+        if (rem == 0) break;
+        cursor_advance<false>(cc, nk, NT, M, total_tiles, stride);
+        cur ^= 1;
+    }
+#undef MDF_STEP
+#undef MDF_PS
+#undef MDF_MF
+#undef MDF_BF
+#undef MDF_SB
+#undef MDF_RD
+#undef MDF_DMA_A
+#undef MDF_DMA_B
+#undef MDF_DMA_SETUP
+}
+
+
 // ---- k_gemm_f32_small: the same product for SMALL problems (per-call forward_pass: one protein; a handful of pooled
 // vectors in the GO head).  k_gemm_f32 needs >= 256 output tiles of 256 x 256 to fill the chip and one tile costs
 // K/32 x 6.8 us whatever M is -- a single L=512 protein keeps 4 CUs busy for 110 us per layer and the 1 x 1536 x 1024 head
@@ -660,6 +861,94 @@ __global__ __launch_bounds__(256) void k_gemm_f32_small(const float *__restrict_
             }
         }
     }
+}
+
+// k_gemm_bf16x6_small: k_gemm_f32_small's geometry (one wave per 32 x 32 output tile, operands straight from global memory / L2 through a
+// ring of four register buffers) with k_gemm_bf16x6's arithmetic -- the same fragments (8 consecutive k per lane and half), the same
+// split, the same six products per block of 16 k in the same order: BIT-IDENTICAL to k_gemm_bf16x6, so a protein scores the same
+// through the per-call API and inside a 10 000-protein batch.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_bf16x6_small(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
+                                                           int N, int K, float *__restrict__ C, int ldc, float *__restrict__ pool_partial,
+                                                           int ldp)
+{
+    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL, "graph-convolution layers only");
+    const int lane = threadIdx.x & 63;
+    const int NT = N >> 5, MT = (M + 31) >> 5;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= MT * NT) return;
+    const int mt = t / NT, nt = t - mt * NT;
+    const int frow = lane & 31, khalf = lane >> 5;
+    const float *pa = A + (size_t)min(mt * 32 + frow, M - 1) * lda + khalf * 8;
+    const float *pb = Bt + (size_t)(nt * 32 + frow) * ldb + khalf * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int nblk = K >> 5;   // blocks of 32 k = two matrix-instruction steps of 16 (host-checked: K % 32 == 0)
+    // (the ring and its asm fences: see k_gemm_f32_small)
+#define MDF_LOAD_BLK(BA, BB, blk_)                                                                    \
+    {                                                                                                 \
+        const int kb_ = min((blk_), nblk - 1) * 32;   /* past the end: re-read the last block (harmless) */ \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                 \
+        {                                                                                             \
+            BA[u] = *reinterpret_cast<const float4 *>(pa + kb_ + (u >> 1) * 16 + (u & 1) * 4);        \
+            BB[u] = *reinterpret_cast<const float4 *>(pb + kb_ + (u >> 1) * 16 + (u & 1) * 4);        \
+        }                                                                                             \
+        asm volatile("" ::: "memory");                                                                \
+    }
+#define MDF_MFMA_BLK(BA, BB)                                                                          \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                  \
+    {                                                                                                 \
+        SplitRaw ra_, rb_;                                                                            \
+        SplitPlanes pa_, pb_;                                                                         \
+        ra_.u = BA[2 * s2], ra_.v = BA[2 * s2 + 1], rb_.u = BB[2 * s2], rb_.v = BB[2 * s2 + 1];       \
+        split_fragment(ra_, pa_);                                                                     \
+        split_fragment(rb_, pb_);                                                                     \
+        MDF_X6_SEQ(acc, pa_, pb_)                                                                     \
+    }
+    float4 a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
+    if ((nblk & 3) == 0) {   // K a multiple of 128: four unconditional phases per round
+        MDF_LOAD_BLK(a0, b0, 0)
+        MDF_LOAD_BLK(a1, b1, 1)
+        MDF_LOAD_BLK(a2, b2, 2)
+        MDF_LOAD_BLK(a3, b3, 3)
+        for (int blk = 0; blk < nblk; blk += 4) {
+            MDF_MFMA_BLK(a0, b0)
+            MDF_LOAD_BLK(a0, b0, blk + 4)
+            MDF_MFMA_BLK(a1, b1)
+            MDF_LOAD_BLK(a1, b1, blk + 5)
+            MDF_MFMA_BLK(a2, b2)
+            MDF_LOAD_BLK(a2, b2, blk + 6)
+            MDF_MFMA_BLK(a3, b3)
+            MDF_LOAD_BLK(a3, b3, blk + 7)
+        }
+    } else {                 // short K: one block ahead
+        MDF_LOAD_BLK(a0, b0, 0)
+        for (int blk = 0; blk < nblk; ++blk) {
+            MDF_LOAD_BLK(a1, b1, blk + 1)
+            MDF_MFMA_BLK(a0, b0)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0[u] = a1[u];
+                b0[u] = b1[u];
+            }
+        }
+    }
+#undef MDF_LOAD_BLK
+#undef MDF_MFMA_BLK
+    // epilogue: gemm_epilogue<EPI> on one 32 x 32 tile (as k_gemm_f32_small)
+    const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+    const int rbase = mt * 32, col = nt * 32 + lcol;
+    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+        const float v = elu1(acc[r]);
+        if (r < 8) s0 += v; else s1 += v;
+        if (EPI == EPI_ELU_POOL_STORE) C[(size_t)row * ldc + col] = v;
+    }
+    const float mine = lane < 32 ? s0 : s1, send = lane < 32 ? s1 : s0;
+    pool_partial[(size_t)((rbase >> 4) + (lane >> 5)) * ldp + col] = mine + __shfl_xor(send, 32, 64);
 }
 
 // ---- the GO head for a handful of pooled vectors (M <= 8: one protein through the per-call API, a tiny batch) ----------------
@@ -802,7 +1091,6 @@ __global__ __launch_bounds__(256) void k_aggregate(const float *__restrict__ H, 
 // through a precomputed bitmap (k_agg_prepare): ~6.5 of 32 column blocks per row block are populated at 6 A.
 // A wave64 VALU instruction costs four cycles: the matrix phase keeps to ~11 of them per populated block (contact byte -> A fragment
 // through a 256-entry LDS table, fragment addresses as one xor); a per-lane "is this block populated" test was 10x that.
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int AGG_SL = 32;        // channels of a workgroup's slab (one 32 x 32 MFMA tile wide)
 constexpr int AGG_CHR = 256;      // rows of the protein in LDS at a time (8 waves x 32 rows)
 constexpr int AGG_OPITCH = 40;    // floats per row of a wave's output staging tile (the two lane halves hit disjoint banks)
@@ -1313,8 +1601,20 @@ static int set_gemm_attr_once()
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_LSTM_TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_LSTM_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_ELU_POOL_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_ELU_POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return MDF_OK;
+}
+
+// which matrix pipe the graph-convolution products use (see k_gemm_bf16x6); read once per process
+static bool hw_pipe_bf16x6()
+{
+    static const bool on = []() {
+        const char *e = getenv("MDFRI_HW_PIPE");
+        return !(e && (strcmp(e, "f32") == 0 || strcmp(e, "fp32") == 0));
+    }();
+    return on;
 }
 
 // persistent grid: one 512-thread workgroup per CU (LDS: 128 KiB), a multiple of 8 so that block b stays on XCD b%8
@@ -1354,6 +1654,24 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     }
     const int MT = (M + BM - 1) / BM, NT = N / BN;
     const bool plain = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
+    if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL) {
+        // the graph-convolution products run BF16x6 on the bf16 matrix pipe (k_gemm_bf16x6: fp32 in, fp32 out, error below the fp32
+        // pipe's); MDFRI_HW_PIPE=f32 keeps them on v_mfma_f32_32x32x2_f32 (developer knob, read once: A/B runs and the bench's comparison leg)
+        if (hw_pipe_bf16x6()) {
+            static const int small_env = getenv("MDFRI_GEMM_SMALL") ? atoi(getenv("MDFRI_GEMM_SMALL")) : -1;
+            const bool small = small_env >= 0 ? small_env != 0 : MT * NT * 8 < 3 * gemm_resident_blocks();
+            if (small) {
+                const int tiles = ((M + 31) / 32) * (N / 32);
+                hipLaunchKernelGGL(k_gemm_bf16x6_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, pool_partial, ldp);
+            } else {
+                const int total = 8 * NT * ((MT + 7) / 8);
+                hipLaunchKernelGGL(k_gemm_bf16x6<EPI>, dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb,
+                                   M, N, K, C, ldc, pool_partial, ldp, total);
+            }
+            MDF_HIP(hipGetLastError());
+            return MDF_OK;
+        }
+    }
     if constexpr (EPI != EPI_LSTM_TAB && EPI != EPI_LSTM_BIAS) {
         // small problems (fewer 256 x 256 tiles than 3/8 of the CUs -- measured crossover with the four-block prefetch ring: 8 192
         // rows x 512 columns = 64 tiles 0.91 vs 1.17 ms per 3-head forward, 16 384 rows = 128 tiles 1.49 vs 1.28 ms): one wave per 32 x 32
@@ -1539,6 +1857,8 @@ static size_t lm_ws_bytes(const mdf_lm *lm, int64_t B, int64_t Lmax)
 using namespace mdf;
 
 extern "C" {
+
+const char *mdf_hw_pipe(void) { return hw_pipe_bf16x6() ? "bf16x6" : "f32"; }
 
 int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
 {

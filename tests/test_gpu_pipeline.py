@@ -120,13 +120,14 @@ def test_query_stream_equals_the_stage_by_stage_chain():
         assert first == seen and r.count == min(50, 230 - first)
         sl = range(first, first + r.count)
         seen += r.count
-        assert r.aligned == [i - first for i in sl if cands[i]]
+        assert sorted(r.aligned) == [i - first for i in sl if cands[i]]                  # every query with candidates, shortest first inside the batch
+        assert all(len(qseqs[first + a]) <= len(qseqs[first + c]) for a, c in zip(r.aligned, r.aligned[1:]))
         one = align_queries_arrays([qids[first + i] for i in r.aligned], [qseqs[first + i] for i in r.aligned], [cands[first + i] for i in r.aligned], scoring_matrix=sm)
         assert b.target_keys == one.target_keys and np.array_equal(b.ops, one.ops) and np.array_equal(b.aln_off, one.aln_off)
         coords = [xyz.get(k) for k in one.target_keys]
         assert kept == [i for i, c in enumerate(coords) if c is not None]
         structured = {r.aligned[k] for k in kept}
-        assert r.sequence_only == [i for i in range(r.count) if i not in structured]
+        assert r.sequence_only == [i for i in range(r.count) if i not in structured]          # (positions inside the slice, ascending)
         n_seq_only += len(r.sequence_only)
         if not kept:
             assert res == {} and first == 200
