@@ -63,14 +63,14 @@ def layers(d):
             if name.startswith("k_aggregate"):
                 # the launch in front of a layer-2 aggregation is the layer-1 kernel (k_layer1; the K = 32 GEMM <4, ..> up to round 3), in
                 # front of a layer-3 aggregation an H.W GEMM
-                layer = "layer 2" if prev.startswith("k_layer1") or "<4," in prev else ("layer 3" if prev.startswith("k_gemm_f32") else "other")
+                layer = "layer 2" if prev.startswith("k_layer1") or "<4," in prev else ("layer 3" if prev.startswith(("k_gemm_f32", "k_gemm_bf16x6")) else "other")
                 groups[("k_aggregate (A.X)", layer, name)].append((grid, dur))
-            elif name.startswith("k_gemm_f32<") and not name.startswith("k_gemm_f32_small"):
-                epi = name.split("<", 1)[1]
+            elif name.startswith(("k_gemm_f32<", "k_gemm_bf16x6<")):      # (not the _small forms: per-call API)
+                kern, epi = name.split("<", 1)
                 if epi.startswith("(Epilogue)0") or epi.startswith("0"):
-                    groups[("k_gemm_f32 (H.W)", "layer 2 (stores H2)", name)].append((grid, dur))
+                    groups[(f"{kern} (H.W)", "layer 2 (stores H2)", name)].append((grid, dur))
                 elif epi.startswith("(Epilogue)1") or epi.startswith("1"):
-                    groups[("k_gemm_f32 (H.W)", "layer 3 (pool only)", name)].append((grid, dur))
+                    groups[(f"{kern} (H.W)", "layer 3 (pool only)", name)].append((grid, dur))
             prev = name
         print(f"# per-layer split from {os.path.relpath(f, d)} (full-size launches = the modal launch grid of each group)")
         print(f"{'kernel':22s} {'layer':22s} {'launches':>8s} {'avg_us':>9s} {'min_us':>9s} {'max_us':>9s}")

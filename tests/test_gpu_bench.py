@@ -52,13 +52,14 @@ def test_bare_python_launches_two_ranks_strong_filtered(workload, count):
     assert all(v > 0 for v in line["gathered_survivors"].values())
 
 
-@pytest.mark.parametrize("workload,count,floor", [("configs3", 100_000, 40_000), ("configs4", 500_000, 72_000)])
+@pytest.mark.parametrize("workload,count,floor", [("configs3", 100_000, 52_000), ("configs4", 500_000, 95_000)])
 def test_strong_workloads_at_full_size_one_gpu(workload, count, floor):
     """BASELINE.json configs[3] (100 000 mixed-length proteins) and configs[4] (500 000, proteome length histogram) at their STATED
     size on one GPU: contact-map alignment + three GO heads + GPU filter + the filtered gather plan (degenerate at N = 1), one
     timed step.  Heads at the operating point of trained ones (sparse_scores): the survivors are a few per cent of the terms,
-    so the gathered payload is what the workload advertises -- far below the dense one.  The floors are 0.8 x the rates
-    committed in round 3 (profiles/r03_bench_configs{3,4}_n1.json: 50.0 k and 91.4 k proteins/s): a 20 % regression fails."""
+    so the gathered payload is what the workload advertises -- far below the dense one.  The floors are 0.84 x the rates
+    committed in round 4 (profiles/r04_bench_configs{3,4}_n1.json: 62.4 k and 112.9 k proteins/s; the power-limited BF16x6 GEMM varies
+    a few per cent from box to box)."""
     line = _run("--workload", workload, "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", "--verify", "6", timeout=1500)
     assert line["n_gpus"] == 1 and line["scaling"] == "strong" and line["config"]["proteins_total"] == count
     assert line["metric"] == f"proteins/sec (GCN+cmap), {workload}"

@@ -41,7 +41,9 @@ def main():
     # the A.X launches of the headline workload (L = 512) all run the matrix-pipe kernel k_aggregate_mfma<2>; a build or workload that still
     # runs the CSR gather there is picked up under the same key
     agg_name = next((k for k in fetch if k.startswith("k_aggregate_mfma<2>")), None) or next(k for k in fetch if k.startswith("k_aggregate<512>"))
-    for name, prefix in (("k_aggregate", agg_name), ("k_gemm_f32<0>", "k_gemm_f32<(Epilogue)0"), ("k_gemm_f32<1>", "k_gemm_f32<(Epilogue)1")):
+    # the H.W launches: k_gemm_bf16x6<EPI> (default) or k_gemm_f32<EPI> (MDFRI_HW_PIPE=f32); EPI 0 stores the layer output, 1 only pools
+    gemm = "k_gemm_bf16x6" if any(k.startswith("k_gemm_bf16x6<") for k in fetch) else "k_gemm_f32"
+    for name, prefix in (("k_aggregate", agg_name), (f"{gemm}<0>", f"{gemm}<(Epilogue)0"), (f"{gemm}<1>", f"{gemm}<(Epilogue)1")):
         try:
             f, w = pick(fetch, prefix), pick(write, prefix)
         except AssertionError:
@@ -49,7 +51,8 @@ def main():
             f, w = pick(fetch, alt), pick(write, alt)
         out[name] = {"fetch_kb": round(f, 1), "write_kb": round(w, 1), "bytes": int((2 * f + w) * 1024)}
     out["k_aggregate"]["kernel"] = agg_name
-    out["gemm_mean_bytes"] = (out["k_gemm_f32<0>"]["bytes"] + out["k_gemm_f32<1>"]["bytes"]) // 2
+    out["gemm_kernel"] = gemm
+    out["gemm_mean_bytes"] = (out[f"{gemm}<0>"]["bytes"] + out[f"{gemm}<1>"]["bytes"]) // 2
     print(json.dumps(out, indent=2))
 
 
