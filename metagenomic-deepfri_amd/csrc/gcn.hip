@@ -591,9 +591,12 @@ __device__ __forceinline__ void split_fragment(const SplitRaw &r, SplitPlanes &o
 // instructions) with the next step's fragment reads and splits, and in the first half the next position's DMA, riding behind them.
 template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
-                                                                 int N, int K, float *__restrict__ C, int ldc, float *__restrict__ pool_partial,
-                                                                 int ldp, int total_tiles)
+                                                                 int N, int K, float *__restrict__ C, int ldc, const float *__restrict__ bias,
+                                                                 float *__restrict__ pool_partial, int ldp, int total_tiles, GemmAux aux)
 {
+    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS || EPI == EPI_EMBED,
+                  "graph-convolution layers, LSTM time steps, LM embedding");
+    constexpr bool PLAIN = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A 256x32 | B 256x32], unpadded rows (as k_gemm_f32)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
     {
         int first = -1, mt, nt;
         for (int t = blockIdx.x; t < total_tiles; t += stride) {
-            tile_of_block<false>(t, NT, mt, nt);
+            tile_of_block<PLAIN>(t, NT, mt, nt);
             if (mt * BM < M) {
                 if (first < 0) { first = t; cc.t = t; cc.mt = mt; cc.nt = nt; }
                 ++n_mine;
@@ -631,7 +634,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
                    ob2 = (unsigned)((drow + 16) * ldb + dcol[2]) * 4u, ob3 = (unsigned)((drow + 24) * ldb + dcol[3]) * 4u;
 #define MDF_DMA_SETUP(cur_)                                                                 \
     {                                                                                       \
-        baseA = A + (size_t)(cur_).kt * BK;                                                 \
+        baseA = (EPI == EPI_LSTM_BIAS && (cur_).kt >= aux.ksplit) ? aux.A2 + (size_t)((cur_).kt - aux.ksplit) * BK \
+                                                                   : A + (size_t)(cur_).kt * BK;    \
         baseB = Bt + (size_t)((cur_).nt * BN + wid * 32) * ldb + (size_t)(cur_).kt * BK;    \
         const int rA_ = (cur_).mt * BM + wid * 32 + drow;                                   \
         oa0 = (unsigned)(min(rA_, M - 1) * lda + dcol[0]) * 4u;                             \
@@ -661,7 +665,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
         MDF_DMA_SETUP(pc)
         const unsigned ldsA = lds_base, ldsB = lds_base + BM * BK * 4;
         MDF_DMA_A(0) MDF_DMA_B(0) MDF_DMA_A(1) MDF_DMA_B(1) MDF_DMA_A(2) MDF_DMA_B(2) MDF_DMA_A(3) MDF_DMA_B(3)
-        cursor_advance<false>(pc, nk, NT, M, total_tiles, stride);
+        cursor_advance<PLAIN>(pc, nk, NT, M, total_tiles, stride);
         MDF_DMA_SETUP(pc)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
         MDF_STEP(3, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 0, 1) MDF_RD(rb, Bb, 1, 1), , , , , MDF_PS(ra, 0, PA[0]), MDF_PS(rb, 0, PB[1][1]), MDF_PS(ra, 1, PA[0]), MDF_PS(rb, 1, PB[1][1]), MDF_PS(ra, 2, PA[0]), MDF_PS(rb, 2, PB[1][1]), MDF_PS(ra, 3, PA[0]), MDF_PS(rb, 3, PB[1][1]))
         // half 1: the source addresses of the position after next, then the barrier and the next position's first fragments
         MDF_STEP(0, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 1, 1), , , , , MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
-        cursor_advance<false>(pc, nk, NT, M, total_tiles, stride);
+        cursor_advance<PLAIN>(pc, nk, NT, M, total_tiles, stride);
         MDF_DMA_SETUP(pc)
         MDF_STEP(1, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 2, 1), , , , , MDF_PS(ra, 0, PA[0]), , MDF_PS(ra, 1, PA[0]), , MDF_PS(ra, 2, PA[0]), , MDF_PS(ra, 3, PA[0]), )
         MDF_STEP(2, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 3, 1), , , , , MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
         __syncthreads();                                     // ... and everybody's; nobody reads this position's buffer any more
         MDF_STEP(3, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, An, 0, 0) MDF_RD(rb, Bn, 0, 0) MDF_RD(rc, Bn, 1, 0), , , MDF_PS(ra, 0, PA[0]), MDF_PS(rb, 0, PB[0][0]), MDF_PS(rc, 0, PB[0][1]) MDF_PS(ra, 1, PA[0]), MDF_PS(rb, 1, PB[0][0]), MDF_PS(rc, 1, PB[0][1]) MDF_PS(ra, 2, PA[0]), MDF_PS(rb, 2, PB[0][0]), MDF_PS(rc, 2, PB[0][1]) MDF_PS(ra, 3, PA[0]), MDF_PS(rb, 3, PB[0][0]), MDF_PS(rc, 3, PB[0][1]), )
         if (cc.kt == nk - 1) {
-            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, nullptr, pool_partial, ldp, nullptr, N, GemmAux());
+            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, ldp, nullptr, N, aux);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -718,7 +722,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
         }
         --rem;
         if (rem == 0) break;
-        cursor_advance<false>(cc, nk, NT, M, total_tiles, stride);
+        cursor_advance<PLAIN>(cc, nk, NT, M, total_tiles, stride);
         cur ^= 1;
     }
 #undef MDF_STEP
@@ -870,9 +874,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32_small(const float *__restrict_
 template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_bf16x6_small(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
                                                            int N, int K, float *__restrict__ C, int ldc, float *__restrict__ pool_partial,
-                                                           int ldp)
+                                                           int ldp, GemmAux aux)
 {
-    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL, "graph-convolution layers only");
+    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_EMBED, "graph-convolution layers and the LM embedding");
     const int lane = threadIdx.x & 63;
     const int NT = N >> 5, MT = (M + 31) >> 5;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -939,6 +943,17 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x6_small(const float *__restri
     // epilogue: gemm_epilogue<EPI> on one 32 x 32 tile (as k_gemm_f32_small)
     const int lcol = lane & 31, lrow = 4 * (lane >> 5);
     const int rbase = mt * 32, col = nt * 32 + lcol;
+    if (EPI == EPI_EMBED) {
+        int lt[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lt[r] = min((int)aux.letters[min(rbase + (r & 3) + 8 * (r >> 2) + lrow, M - 1)], 31) * N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+            if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[r] + aux.table[lt[r] + col], aux.floor);
+        }
+        return;
+    }
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1603,6 +1618,9 @@ static int set_gemm_attr_once()
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f32<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_ELU_POOL_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_ELU_POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_LSTM_TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_LSTM_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return MDF_OK;
 }
@@ -1654,19 +1672,24 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     }
     const int MT = (M + BM - 1) / BM, NT = N / BN;
     const bool plain = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
-    if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL) {
-        // the graph-convolution products run BF16x6 on the bf16 matrix pipe (k_gemm_bf16x6: fp32 in, fp32 out, error below the fp32
-        // pipe's); MDFRI_HW_PIPE=f32 keeps them on v_mfma_f32_32x32x2_f32 (developer knob, read once: A/B runs and the bench's comparison leg)
+    if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS || EPI == EPI_EMBED) {
+        // the graph-convolution products (and, on the language-model branch, the LSTM time steps of large groups and the embedding) run BF16x6 on the
+        // bf16 matrix pipe (k_gemm_bf16x6: fp32 in, fp32 out, error below the fp32 pipe's); MDFRI_HW_PIPE=f32 keeps them on
+        // v_mfma_f32_32x32x2_f32 (developer knob, read once: A/B runs and the bench's comparison leg)
         if (hw_pipe_bf16x6()) {
-            static const int small_env = getenv("MDFRI_GEMM_SMALL") ? atoi(getenv("MDFRI_GEMM_SMALL")) : -1;
-            const bool small = small_env >= 0 ? small_env != 0 : MT * NT * 8 < 3 * gemm_resident_blocks();
-            if (small) {
-                const int tiles = ((M + 31) / 32) * (N / 32);
-                hipLaunchKernelGGL(k_gemm_bf16x6_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, pool_partial, ldp);
-            } else {
-                const int total = 8 * NT * ((MT + 7) / 8);
+            bool small = false;
+            if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_EMBED) {
+                static const int small_env = getenv("MDFRI_GEMM_SMALL") ? atoi(getenv("MDFRI_GEMM_SMALL")) : -1;
+                small = small_env >= 0 ? small_env != 0 : MT * NT * 8 < 3 * gemm_resident_blocks();
+                if (small) {
+                    const int tiles = ((M + 31) / 32) * (N / 32);
+                    hipLaunchKernelGGL(k_gemm_bf16x6_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, pool_partial, ldp, aux);
+                }
+            }
+            if (!small) {
+                const int total = plain ? MT * NT : 8 * NT * ((MT + 7) / 8);
                 hipLaunchKernelGGL(k_gemm_bf16x6<EPI>, dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb,
-                                   M, N, K, C, ldc, pool_partial, ldp, total);
+                                   M, N, K, C, ldc, bias, pool_partial, ldp, total, aux);
             }
             MDF_HIP(hipGetLastError());
             return MDF_OK;
