@@ -661,6 +661,10 @@ def main():
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "dtype_note": ("inputs, outputs and every accumulation are fp32; with roofline.pipe = bf16x6 each fp32 product of the GraphConv H.W GEMMs is "
+                           "formed from six bf16 term products of exactly split operands (error against float64 below the fp32 matrix instruction's: "
+                           "profiles/r04_gemm_bf16x6_probe.txt, tests/test_gpu_gcn.py::test_bf16x6_products_are_at_least_as_accurate_as_the_fp32_instruction); "
+                           "`f32_pipe` is the same run on the fp32 instruction") if ctx.lib.mdf_hw_pipe().decode() == "bf16x6" else None,
             "data": "synthetic",
             "config": {"workload": what, "proteins_total": n_job, "proteins_rank0": n_local, "mean_length_rank0": round(mean_len, 1),
                        "length": args.length if args.workload == "configs2" else None, "go_heads": list(MODES), "language_model": bool(args.lm),
