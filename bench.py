@@ -490,12 +490,12 @@ def verify(seqs, coords, q_alns, t_alns, weights, out, n, lm, index=None):
         for m in MODES:
             if lm:
                 import lm_oracle
-                ref = lm_oracle.gcn_lm_forward(weights[m], seqs[i], cm)
+                ref = lm_oracle.gcn_lm_forward(weights[m], seqs[i], cm, dtype=np.float64)
             else:
-                ref = gcn_oracle.gcn_forward(weights[m], seqs[i], cm)
+                ref = gcn_oracle.gcn_forward(weights[m], seqs[i], cm, dtype=np.float64)
             got = out[m][i if index is None else index[i]]
-            worst = max(worst, float(np.max(np.abs(got.cpu().numpy() - ref))))
-    return {"proteins": int(n), "heads": list(MODES), "max_abs_err_vs_oracle": worst, "tolerance": 1e-4}
+            worst = max(worst, float(np.max(np.abs(got.cpu().numpy().astype(np.float64) - ref))))
+    return {"proteins": int(n), "heads": list(MODES), "max_abs_err_vs_oracle": worst, "tolerance": 1e-4, "oracle_dtype": "float64"}
 
 
 def mini_run(ctx, eng, cols, chunk_rows, steps=2, warmup=1, lm=False):
