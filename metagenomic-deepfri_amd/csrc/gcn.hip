@@ -540,7 +540,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
 // remainders are exact and lo fits bf16, so hi + mid + lo == x bit for bit, |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|), and
 //     a.b  ~  ah.bh + (ah.bm + am.bh) + (am.bm + ah.bl + al.bh),
 // each term product exact in fp32, accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  The three products left
-// out (am.bl, al.bm, al.bl) are together below 2^-26 |a.b| -- a quarter of the rounding of ONE fp32 multiplication -- so the result
+// out (am.bl, al.bm, al.bl) are together at most 2^-23 |a.b|, in the mean 2^-28 and without sign bias (tests/test_bf16x6_split_cpu.py) --
+// the size of the rounding of ONE fp32 multiplication or below, against hundreds of accumulation roundings per dot product -- so the result
 // carries the accumulation rounding of an fp32 GEMM and nothing else: measured against float64 on 65 536 x 512 x 512 the error is
 // rms 2.49e-7 / max 2.4e-6, the same to four digits as with all nine products, and below the fp32 pipe's own 2.95e-7 / 3.4e-6
 // (profiles/r04_gemm_bf16x6_probe.txt).  Vector and matrix instructions of a SIMD do not overlap on this part, and at full bf16 rate
