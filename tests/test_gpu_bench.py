@@ -74,18 +74,19 @@ def test_strong_workloads_at_full_size_one_gpu(workload, count, floor):
 
 def test_default_line_regression_net():
     """The headline configuration (configs[2]: 10 000 x L=512, three heads) for three timed steps: rate, both rooflines and the
-    bookkeeping that makes them checkable.  Floors: 68 k proteins/s (committed: 77 k), the H.W GEMM (BF16x6 on the bf16 matrix pipe)
-    >= 1.10 x the fp32 instruction's peak and >= 0.42 of its own roofline, bf16 peak / 6 (committed 1.24 and 0.47; the chip holds
-    ~1.5-1.9 GHz under this load), A.X >= 0.40 of the HBM peak pooled over BOTH layers (north_star's target), the sampled kernel
+    bookkeeping that makes them checkable.  Floors: 64 k proteins/s (committed: 74-79 k from box to box; 61.5-61.9 k on the fp32
+    instruction), the H.W GEMM (BF16x6 on the bf16 matrix pipe) >= 1.02 x the fp32 instruction's peak and >= 0.38 of its own roofline,
+    bf16 peak / 6 (committed 1.18-1.27 and 0.445-0.479: the kernel is power-limited, the chip holds 1.5-1.9 GHz under this load and boxes
+    differ), A.X >= 0.40 of the HBM peak pooled over BOTH layers (north_star's target; committed 0.50-0.53), the sampled kernel
     classes x their launches per step within 3 % of the step, and `traffic` either stamped for this very library or null with the
     reason -- never a stale constant."""
     from mDeepFRI import _hip
     line = _run("--steps", "3", "--warmup", "1", "--no-extras", "--cpu-seconds", "0")
     assert line["metric"] == "proteins/sec (GCN+cmap) at L=512" and line["config"]["proteins_total"] == 10000
-    assert line["value"] >= 68_000, line["value"]
+    assert line["value"] >= 64_000, line["value"]
     r, ax = line["roofline"], line["roofline_ax"]
     assert r["pipe"] == "bf16x6" == _hip.lib().mdf_hw_pipe().decode() and r["bound"] == "mfma", r
-    assert 0.42 <= r["frac"] < 1.0 and abs(r["peak"] - 2500.0 / 6) < 0.1 and r["vs_f32_instruction_peak"] >= 1.10, r
+    assert 0.38 <= r["frac"] < 1.0 and abs(r["peak"] - 2500.0 / 6) < 0.1 and r["vs_f32_instruction_peak"] >= 1.02, r
     assert 0.40 <= ax["frac"] < 1.0 and ax["bound"] == "hbm", ax
     for obj, names in ((r, ("gemm2", "gemm3")), (ax, ("ax2", "ax3"))):
         assert set(obj["per_layer"]) == set(names) and all(v["timed_launches"] >= 20 for v in obj["per_layer"].values()), obj["per_layer"]
