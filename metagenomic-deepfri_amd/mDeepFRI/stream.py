@@ -28,14 +28,18 @@ def _fields(item):
 
 
 class AlignmentStream:
-    """engine: a HotPathEngine; batch_size: proteins per device batch (10 000 L=512 proteins keep an MI355X busy for ~0.18 s
-    with three GO heads); max_rows: residue rows per fused chunk inside a batch."""
+    """engine: a HotPathEngine; batch_size: proteins per device batch (10 000 L=512 proteins keep an MI355X busy for ~0.13 s
+    with three GO heads); max_rows: residue rows per fused chunk inside a batch.  sort_by_length (default): a batch goes through the
+    path shortest protein first (proteins of like length share chunks: ~10 % on the GCN stage of mixed-length batches, DESIGN.md
+    section 5 row 14) and its score rows are put back in input order on the device before they travel -- results and their order do
+    not depend on it."""
 
-    def __init__(self, engine: HotPathEngine, batch_size: int = 10000, max_rows: int = 65536, prefetch: int = 2):
+    def __init__(self, engine: HotPathEngine, batch_size: int = 10000, max_rows: int = 65536, prefetch: int = 2, sort_by_length: bool = True):
         self.engine = engine
         self.batch_size = int(batch_size)
         self.max_rows = int(max_rows)
         self.prefetch = int(prefetch)
+        self.sort_by_length = bool(sort_by_length)
 
     def _producer(self, items, q):
         try:
@@ -53,8 +57,15 @@ class AlignmentStream:
             q.put(e)
 
     def _pack(self, rows):
-        return PackedProteins.pack([r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows], [r[3] for r in rows],
-                                   max_rows=self.max_rows)
+        """-> (packed, order, rows): order[k] = position inside the batch of the k-th packed protein (None: input order)."""
+        order = None
+        if self.sort_by_length:
+            order = sorted(range(len(rows)), key=lambda i: len(rows[i][0]))      # stable: equal lengths keep their input order
+            if order == list(range(len(rows))):
+                order = None
+        use = rows if order is None else [rows[i] for i in order]
+        pk = PackedProteins.pack([r[0] for r in use], [r[1] for r in use], [r[2] for r in use], [r[3] for r in use], max_rows=self.max_rows)
+        return pk, order, rows
 
     def run(self, items):
         """Generator over (first_index, {mode: np.ndarray (n, T) float32}) in input order.  Raises what the device flags
@@ -73,11 +84,14 @@ class AlignmentStream:
             if isinstance(got, BaseException):
                 raise got
             if got is not None:
-                first, pk = got
+                first, (pk, order, rows) = got
                 with torch.cuda.device(eng.device):
                     main = torch.cuda.current_stream(eng.device)
                     db = eng.upload(pk)        # in the compute stream: 75 MB per 10 000 proteins next to the GEMMs on another stream cost more than they hide
                     out = eng.forward_alignments(db)
+                    if order is not None:      # back to input order before the rows travel (a device-side gather: ~30 us per 100 MB)
+                        inv = torch.from_numpy(np.argsort(np.asarray(order, dtype=np.int64))).to(eng.device, non_blocking=True)
+                        out = {m: t.index_select(0, inv) for m, t in out.items()}
                     done = torch.cuda.Event()
                     done.record(main)
                     host = {m: torch.empty(t.shape, dtype=t.dtype, pin_memory=True) for m, t in out.items()}
@@ -93,7 +107,7 @@ class AlignmentStream:
                         flags[1].copy_(db.status, non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(side)
-                nxt = (first, db, host, ev, pk, flags)
+                nxt = (first, db, host, ev, pk, flags, order, rows)
             else:
                 nxt = None
             if pending is not None:
@@ -104,12 +118,24 @@ class AlignmentStream:
         th.join()
 
     def _finish(self, pending):
-        first, db, host, ev, pk, flags = pending
+        first, db, host, ev, pk, flags, order, rows = pending
         ev.synchronize()
         try:
             self.engine.raise_flags(pk, flags[0].numpy(), flags[1].numpy())
         except _hip.CapacityError:   # rare: a denser batch than the CSR capacity planned for; redo it synchronously
-            return first, self.engine.run_alignments(pk)
+            res = self.engine.run_alignments(pk)
+            if order is not None:
+                inv = np.argsort(np.asarray(order, dtype=np.int64))
+                res = {m: a[inv] for m, a in res.items()}
+            return first, res
+        except ValueError:
+            if order is None:
+                raise
+            # an invalid residue (or an over-long query): the reference reports the FIRST one in input order -- let the batch in input
+            # order say which (error path only)
+            self.engine.run_alignments(PackedProteins.pack([r[0] for r in rows], [r[1] for r in rows], [r[2] for r in rows], [r[3] for r in rows],
+                                                           max_rows=self.max_rows))
+            raise
         return first, {m: t.numpy() for m, t in host.items()}
 
     def run_all(self, items) -> dict:

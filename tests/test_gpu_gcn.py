@@ -571,6 +571,8 @@ def test_alignment_stream_matches_one_batch(mf, cc):
     ref = eng.run_alignments(pk)
     for m in got:
         assert np.array_equal(np.concatenate(got[m]), ref[m])
+    arrival = AlignmentStream(eng, batch_size=10, max_rows=2048, sort_by_length=False).run_all(items)      # batches packed in arrival order:
+    assert all(np.array_equal(arrival[m], ref[m]) for m in got)                                              # (the default sorts each by length) the same bits
     bad = list(items)
     bad[37] = ("ACDJ", bad[37][1][:4], "ACDJ", "ACDJ")
     with pytest.raises(ValueError, match="Invalid character in sequence: J"):
