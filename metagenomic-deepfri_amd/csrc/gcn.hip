@@ -1129,12 +1129,22 @@ __device__ __forceinline__ void agg_split3(float x, unsigned short &hi, unsigned
 __device__ __forceinline__ int agg_xt_off(int term, int ch, int slot) { return ((term * AGG_SL + ch) * (AGG_CHR / 8) + (slot ^ (ch & 15))) * 8; }
 
 // ROWBLOCKS: 32-row blocks of a protein per wave, dealt round robin (block b of wave w = rows [32 (8 b + w), +32)): L <= 256 ROWBLOCKS
-template <int ROWBLOCKS>
+// L1 (layer 2 of a model whose layer 1 is the folded embedding, maps made from coordinates): the rows of H1 = elu(S . T1) are not read but MADE
+// here, per 32-row tile and channel slab, on the fp32 matrix instruction -- v_mfma_f32_32x32x2_f32 fed the letters (2 i, 2 i + 1) is, per
+// output, the FMA chain of k_layer1 in the same order, so H1, its pooling partial sums (handed from lane half to lane half in row order)
+// and with them everything downstream are bit-identical to the k_layer1 + k_aggregate_mfma<.., false> pair -- and never touch HBM.
+struct AggLayer1 {
+    const float *S = nullptr;     // (R, 32) letter sums of the contact stage
+    const float *T1 = nullptr;    // (32, C) folded embedding table
+    float *pool_partial = nullptr;
+    int ldp = 0;
+};
+template <int ROWBLOCKS, bool L1 = false>
 __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const unsigned long long *__restrict__ masks,
                                                                    int W, const float *__restrict__ dinv, const unsigned long long *__restrict__ blk,
                                                                    const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq,
                                                                    const int32_t *__restrict__ plist, const int32_t *__restrict__ gate,
-                                                                   float *__restrict__ out, int tail_p, int tail_row0, int R)
+                                                                   float *__restrict__ out, int tail_p, int tail_row0, int R, AggLayer1 l1)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xt[3 * AGG_SL * AGG_CHR];   // 48 KiB; re-used as 8 x 5 KiB output staging at the end
     __shared__ __attribute__((aligned(16))) unsigned short lut[256 * 8];                // contact byte -> its 8 bf16 (0.0 / 1.0): one ds_read_b128
@@ -1154,10 +1164,17 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
     const float *Hs = H + (size_t)r0 * C + slab * AGG_SL;
+    const int Lpad = (L + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+    float t1[13];   // L1: this lane's B operands, T1[2 i + half][slab column frow]
+    if (L1) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) t1[i] = l1.T1[(size_t)(2 * i + half) * C + slab * AGG_SL + frow];
+    }
     for (int j0 = 0; j0 < L; j0 += AGG_CHR) {
         // ---- requests of this chunk: the rows to stage (scaled by d_j), and the contact bits of its 256 columns for the wave's row blocks
         v2f x[8];
-        {
+        f32x16 h1;
+        if (!L1) {
             const int jb = j0 + oct * 8;
             v4f d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
             if (jb < L) {   // (a protein's rows are padded to a multiple of 16: dinv is readable up to jb + 7)
@@ -1171,23 +1188,90 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
                 const v2f h = j < L ? *reinterpret_cast<const v2f *>(Hs + (size_t)j * C + cp * 2) : (v2f){0, 0};
                 x[k] = h * dd[k];
             }
+        } else {
+            // the wave's 32-row tile of the chunk: H1 = elu(S . T1) for the slab's 32 channels, 13 matrix instructions of two letters each
+            const int jt = j0 + wid * 32;            // first row of the tile (wave-uniform)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
+            if (jt < Lpad) {
+                const int j = jt + frow;
+                v4f sr[7];
+#pragma unroll
+                for (int q = 0; q < 7; ++q) sr[q] = j < L ? *reinterpret_cast<const v4f *>(l1.S + (size_t)(r0 + j) * 32 + q * 4) : (v4f){0, 0, 0, 0};
+#pragma unroll
+                for (int i = 0; i < 13; ++i) {
+                    const float lo = sr[(2 * i) >> 2][(2 * i) & 3], hi = sr[(2 * i + 1) >> 2][(2 * i + 1) & 3];
+                    h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? hi : lo, t1[i], h1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h1[r] = elu1(h1[r]);
+                // pooling partial sums of the tile's two 16-row groups, rows added in ascending order as k_layer1 does: rows 4 ph .. 4 ph + 3 of a
+                // group live in lane half (ph & 1), registers 4 (ph >> 1) .. + 3 (group 0) / 8 + ... (group 1); the running sums change halves
+                float sA = 0.0f, sB = 0.0f;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    float tA = sA, tB = sB;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        tA += h1[4 * (ph >> 1) + q];
+                        tB += h1[8 + 4 * (ph >> 1) + q];
+                    }
+                    const bool mine = half == (ph & 1);
+                    sA = mine ? tA : sA;
+                    sB = mine ? tB : sB;
+                    const float oA = __shfl_xor(sA, 32, 64), oB = __shfl_xor(sB, 32, 64);
+                    sA = mine ? sA : oA;
+                    sB = mine ? sB : oB;
+                }
+                if (half) {   // (the last rows of a group live in the upper half: it holds the finished sums)
+                    float *pp = l1.pool_partial + (size_t)((r0 + jt) >> 4) * l1.ldp + slab * AGG_SL + frow;
+                    pp[0] = sA;
+                    if (jt + GROUP_ROWS < Lpad) pp[l1.ldp] = sB;
+                }
+            }
         }
         // (the contact bits of this chunk's 256 columns are fetched per row block inside the matrix phase: all row blocks' words at once
         // would be 8 registers per block -- the other workgroups of the CU cover the latency)
         __syncthreads();   // the previous chunk's fragments have been read (first chunk: the table is complete)
+        if (!L1) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {   // this lane's 2 channels: 8 consecutive rows each = one 16-byte slot per term
-            bf16x8 th, tm, tl;
+            for (int c = 0; c < 2; ++c) {   // this lane's 2 channels: 8 consecutive rows each = one 16-byte slot per term
+                bf16x8 th, tm, tl;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                unsigned short a, b, cc;
-                agg_split3(x[k][c], a, b, cc);
-                th[k] = (short)a, tm[k] = (short)b, tl[k] = (short)cc;
+                for (int k = 0; k < 8; ++k) {
+                    unsigned short a, b, cc;
+                    float xs = x[k][c];
+                    asm("" : "+v"(xs));   // (the d_j product is a rounded fp32 value HERE: never contracted into the split's subtraction -- both forms of the kernel stage the same bits)
+                    agg_split3(xs, a, b, cc);
+                    th[k] = (short)a, tm[k] = (short)b, tl[k] = (short)cc;
+                }
+                const int ch = cp * 2 + c;
+                *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(0, ch, oct)) = th;
+                *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(1, ch, oct)) = tm;
+                *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(2, ch, oct)) = tl;
             }
-            const int ch = cp * 2 + c;
-            *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(0, ch, oct)) = th;
-            *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(1, ch, oct)) = tm;
-            *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(2, ch, oct)) = tl;
+        } else {
+            // this lane's channel (frow), rows 8 g + 4 half .. + 3 of the wave's tile: half a 16-byte slot per term and g
+            typedef short bf16x4 __attribute__((ext_vector_type(4)));
+            const int jt = j0 + wid * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int j = jt + 8 * g + 4 * half;
+                v4f d = {0, 0, 0, 0};
+                if (j < Lpad) d = *reinterpret_cast<const v4f *>(dinv + r0 + j);
+                bf16x4 th, tm, tl;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned short a, b, cc;
+                    float xs = h1[4 * g + q] * d[q];
+                    asm("" : "+v"(xs));   // (rounded here, as in the other form)
+                    agg_split3(xs, a, b, cc);
+                    th[q] = (short)a, tm[q] = (short)b, tl[q] = (short)cc;
+                }
+                *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(0, frow, wid * 4 + g) + 4 * half) = th;
+                *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(1, frow, wid * 4 + g) + 4 * half) = tm;
+                *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(2, frow, wid * 4 + g) + 4 * half) = tl;
+            }
         }
         __syncthreads();
         // ---- every wave: its row blocks x the populated column blocks (16 rows of X each) of this chunk
@@ -1229,7 +1313,6 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
     __syncthreads();   // every wave is done with the last chunk's fragments
     float *ot = reinterpret_cast<float *>(xt) + wid * (32 * AGG_OPITCH);
     float *Os = out + (size_t)r0 * C + slab * AGG_SL;
-    const int Lpad = (L + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
     const int orow = lane >> 3, oq = lane & 7;
 #pragma unroll
     for (int b = 0; b < ROWBLOCKS; ++b) {
@@ -1256,6 +1339,9 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
         float *Ot = out + (size_t)slab * AGG_SL;
         for (int e = threadIdx.x; e < (R - tail_row0) * (AGG_SL / 4); e += AGG_THREADS)
             *reinterpret_cast<v4f *>(Ot + (size_t)(tail_row0 + e / (AGG_SL / 4)) * C + (e % (AGG_SL / 4)) * 4) = (v4f){0, 0, 0, 0};
+        if (L1)   // ... and their layer-1 pooling sums, which k_layer1 would have written (zeros): the last protein's pooling range may run to the chunk's end
+            for (int e = threadIdx.x; e < ((R - tail_row0) / GROUP_ROWS) * AGG_SL; e += AGG_THREADS)
+                l1.pool_partial[(size_t)(tail_row0 / GROUP_ROWS + e / AGG_SL) * l1.ldp + slab * AGG_SL + (e % AGG_SL)] = 0.0f;
     }
 }
 
@@ -1294,7 +1380,8 @@ __global__ __launch_bounds__(64) void k_agg_prepare(const unsigned long long *__
 // registers.  fp32 FMA chain in ascending letter order, the same for a protein alone and inside a batch.
 template <bool STORE>
 __global__ __launch_bounds__(256) void k_layer1(const float *__restrict__ S, const float *__restrict__ T1, int C, int R,
-                                                float *__restrict__ H, float *__restrict__ pool_partial, int ldp, int gpw)
+                                                float *__restrict__ H, float *__restrict__ pool_partial, int ldp, int gpw, int g_first,
+                                                const uint32_t *__restrict__ skip_groups)
 {
     extern __shared__ __attribute__((aligned(16))) float s_rows[];   // [sets * gpw * GROUP_ROWS][32]
     typedef float v4f __attribute__((ext_vector_type(4)));
@@ -1302,8 +1389,8 @@ __global__ __launch_bounds__(256) void k_layer1(const float *__restrict__ S, con
     const int slabs = C >> 8;                       // 256-column slabs of a row: 1, 2 or 4
     const int sets = 4 / slabs;                     // group sets of the workgroup (4 waves = sets x slabs)
     const int set = wi / slabs, cs = wi - set * slabs;
-    const int n_groups = R / GROUP_ROWS;
-    const int g_blk = blockIdx.x * sets * gpw;      // first group of the workgroup
+    const int n_groups = R / GROUP_ROWS;            // (R: the row behind the last one of this launch; groups [g_first, n_groups))
+    const int g_blk = g_first + blockIdx.x * sets * gpw;      // first group of the workgroup
     const int rows_blk = min(sets * gpw, n_groups - g_blk) * GROUP_ROWS;
     {   // stage the letter sums of the workgroup's rows: contiguous in S
         const v4f *src = reinterpret_cast<const v4f *>(S + (size_t)g_blk * GROUP_ROWS * 32);
@@ -1318,6 +1405,7 @@ __global__ __launch_bounds__(256) void k_layer1(const float *__restrict__ S, con
     for (int k = 0; k < gpw; ++k) {
         const int g = g_blk + set * gpw + k;
         if (g >= n_groups) break;
+        if (skip_groups && ((skip_groups[g >> 5] >> (g & 31)) & 1u)) continue;   // a protein whose layer 1 is made inside its aggregation kernel
         const float *sg = s_rows + (size_t)(set * gpw + k) * GROUP_ROWS * 32;
         v4f pool = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
@@ -1748,7 +1836,7 @@ static size_t gcn_ws_bytes(const mdf_model *m, int64_t R)
 
 // Ahat . H over `Cin` channels (k_aggregate)
 static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, const int32_t *colidx, const float *val, float *AH,
-                            int Ri, hipStream_t st, TimedKernel tk = TK_AX, const mdf_agg_desc *agg = nullptr)
+                            int Ri, hipStream_t st, TimedKernel tk = TK_AX, const mdf_agg_desc *agg = nullptr, const AggLayer1 *l1 = nullptr)
 {
     ScopedTiming tm(tk, st);
     static const int mfma_env = getenv("MDFRI_AX_MFMA") ? atoi(getenv("MDFRI_AX_MFMA")) : 1;   // developer knob: 0 = the CSR gather for every row
@@ -1776,17 +1864,20 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
     {   // one launch per length class (1, 2 or 4 row blocks per wave: the accumulators a workgroup carries)
         const unsigned slabs = (unsigned)(Cin / AGG_SL);
         const int32_t *pl = agg->plist;
-#define MDF_AGG(RB, n_)                                                                                                                      \
-    if ((n_) > 0)                                                                                                                            \
-        hipLaunchKernelGGL(k_aggregate_mfma<RB>, dim3((unsigned)(n_) * slabs), dim3(AGG_THREADS), 0, st, Hin, Cin,                            \
-                           reinterpret_cast<const unsigned long long *>(agg->masks), agg->W, agg->dinv,                                      \
-                           reinterpret_cast<const unsigned long long *>(agg->blk), agg->row_off, agg->Lq, pl, agg->gate, AH, agg->tail_p,   \
-                           (int)agg->tail_row0, Ri);                                                                                         \
+#define MDF_AGG_ARGS(n_) dim3((unsigned)(n_) * slabs), dim3(AGG_THREADS), 0, st, Hin, Cin, reinterpret_cast<const unsigned long long *>(agg->masks), \
+                         agg->W, agg->dinv, reinterpret_cast<const unsigned long long *>(agg->blk), agg->row_off, agg->Lq, pl, agg->gate, AH,              \
+                         agg->tail_p, (int)agg->tail_row0, Ri
+#define MDF_AGG(RB, n_)                                                                                  \
+    if ((n_) > 0) {                                                                                      \
+        if (l1) hipLaunchKernelGGL((k_aggregate_mfma<RB, true>), MDF_AGG_ARGS(n_), *l1);                 \
+        else hipLaunchKernelGGL((k_aggregate_mfma<RB, false>), MDF_AGG_ARGS(n_), AggLayer1());           \
+    }                                                                                                    \
     pl += (n_);
         MDF_AGG(1, agg->n_mf[0])
         MDF_AGG(2, agg->n_mf[1])
         MDF_AGG(4, agg->n_mf[2])
 #undef MDF_AGG
+#undef MDF_AGG_ARGS
     }
     if (agg->n_seg > 4 && agg->skip_groups) {
         gather(0, Ri, nullptr, agg->skip_groups);   // many segments (an unsorted batch): one launch over all rows that skips the listed proteins' groups
@@ -1804,7 +1895,8 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
 
 // GraphConv layers 2..n_gc on top of H1 (in Hin): H_k = elu((Ahat . H_{k-1}) . W_k), pooled partial sums at `partial + off`
 static int gcn_upper_layers(mdf_model *m, float *Hin, float *Hout, float *AH, const int32_t *rowptr, const int32_t *colidx,
-                            const float *val, int Ri, float *partial, hipStream_t st, const mdf_agg_desc *agg = nullptr)
+                            const float *val, int Ri, float *partial, hipStream_t st, const mdf_agg_desc *agg = nullptr,
+                            const AggLayer1 *l1 = nullptr)
 {
     const int feat = m->feat;
     int off = m->gc[0];
@@ -1814,7 +1906,7 @@ static int gcn_upper_layers(mdf_model *m, float *Hin, float *Hout, float *AH, co
         // touched) instead of the AH slab: measured -2 % on both A.X launches of a head (profiles/r04_cache_policy_probes.txt, "mid_dead")
         // (only for a launch whose GEMM stores nothing -- the last layer --, or the GEMM would write the slab it reads)
         if (k >= 2 && k == m->n_gc - 1) AH = Hout;
-        if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st, k >= 2 ? TK_AX3 : TK_AX, agg)) return rc;
+        if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st, k >= 2 ? TK_AX3 : TK_AX, agg, k == 1 ? l1 : nullptr)) return rc;
         {
             ScopedTiming tm(k >= 2 ? TK_GEMM3 : TK_GEMM, st);
             const bool last = k == m->n_gc - 1;
@@ -2406,24 +2498,45 @@ int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t 
     float *Ha = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax);
     const int Ri = (int)R, feat = m->feat;
     MDF_REQUIRE(m->lm_dim == 0, "gcn_embed_dev: this model has a language-model branch; use mdf_gcn_embed_lm_dev");
-    // layer 1 (folded embedding): H1 = elu(S . T1) on the MFMA GEMM (K = 32), S = Ahat . onehot from mdf_letter_sums_dev
+    // layer 1 (folded embedding): H1 = elu(S . T1), S = Ahat . onehot from the contact stage.  Proteins whose layer-2 aggregation runs on
+    // the matrix pipe get their H1 rows made inside that kernel (k_aggregate_mfma<.., true>: bit-identical, H1 never written); k_layer1 covers
+    // the rows of the others.  (Maps that may be non-binary -- a gate is set -- keep the two-kernel form: the gather needs H1 in memory.)
+    static const int fuse_env = getenv("MDFRI_L1_FUSE") ? atoi(getenv("MDFRI_L1_FUSE")) : 1;      // developer knobs
+    static const int mfma_env = getenv("MDFRI_AX_MFMA") ? atoi(getenv("MDFRI_AX_MFMA")) : 1;
+    const bool fuse = fuse_env && mfma_env && agg && !agg->gate && m->n_gc >= 2 && agg->n_mf[0] + agg->n_mf[1] + agg->n_mf[2] > 0 &&
+                      (agg->n_seg <= 4 || agg->skip_groups);
+    AggLayer1 l1;
+    l1.S = letter_sums, l1.T1 = m->T1, l1.pool_partial = partial, l1.ldp = feat;
     {
         ScopedTiming tm(TK_GEMM1, st);
         const int C0 = m->gc[0];
         // groups per wave: the wave's slice of T1 (26 KiB per 256-column slab) is fetched once per wave -- with one group per wave a launch
         // reads more table bytes from L2 than it writes output rows
         static const int gpw_env = getenv("MDFRI_L1_GPW") ? atoi(getenv("MDFRI_L1_GPW")) : 0;   // developer knob
-        const int n_groups = Ri / GROUP_ROWS, slabs = C0 / 256, sets = 4 / slabs;
-        const int gpw = std::min(8, gpw_env > 0 ? gpw_env : (n_groups >= 2048 ? 2 : 1));
-        const int blocks = (n_groups + sets * gpw - 1) / (sets * gpw);
-        const size_t lds = (size_t)sets * gpw * GROUP_ROWS * 32 * 4;
-        if (m->n_gc == 1)
-            hipLaunchKernelGGL(k_layer1<false>, dim3((unsigned)blocks), dim3(256), lds, st, letter_sums, m->T1, C0, Ri, (float *)nullptr, partial, feat, gpw);
-        else
-            hipLaunchKernelGGL(k_layer1<true>, dim3((unsigned)blocks), dim3(256), lds, st, letter_sums, m->T1, C0, Ri, Ha, partial, feat, gpw);
+        const int slabs = C0 / 256, sets = 4 / slabs;
+        auto layer1 = [&](int row0, int row_end, const uint32_t *skip) {      // rows [row0, row_end), both multiples of GROUP_ROWS
+            const int n_groups = (row_end - row0) / GROUP_ROWS;
+            const int gpw = std::min(8, gpw_env > 0 ? gpw_env : (n_groups >= 2048 ? 2 : 1));
+            const int blocks = (n_groups + sets * gpw - 1) / (sets * gpw);
+            const size_t lds = (size_t)sets * gpw * GROUP_ROWS * 32 * 4;
+            if (m->n_gc == 1)
+                hipLaunchKernelGGL(k_layer1<false>, dim3((unsigned)blocks), dim3(256), lds, st, letter_sums, m->T1, C0, row_end, (float *)nullptr, partial, feat,
+                                   gpw, row0 / GROUP_ROWS, skip);
+            else
+                hipLaunchKernelGGL(k_layer1<true>, dim3((unsigned)blocks), dim3(256), lds, st, letter_sums, m->T1, C0, row_end, Ha, partial, feat, gpw,
+                                   row0 / GROUP_ROWS, skip);
+        };
+        if (!fuse) {
+            layer1(0, Ri, nullptr);
+        } else if (agg->n_seg > 4) {
+            layer1(0, Ri, agg->skip_groups);
+        } else {
+            for (int k = 0; k < agg->n_seg; ++k)
+                if (agg->csr_seg[2 * k + 1] > 0) layer1(agg->csr_seg[2 * k], agg->csr_seg[2 * k] + agg->csr_seg[2 * k + 1], nullptr);
+        }
         MDF_HIP(hipGetLastError());
     }
-    if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg)) return rc;
+    if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg, fuse ? &l1 : nullptr)) return rc;
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }

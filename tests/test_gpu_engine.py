@@ -1,6 +1,7 @@
 """The batch engine behind the C ABI (include/mdfri.h `mdf_engine_*`, csrc/engine.hip) on the GPU: the single-call host entry,
 the hipGraph replay of short batches, and the validation codes -- against the oracle chain and against the launch-by-launch form
 (bitwise)."""
+import os
 import ctypes
 
 import numpy as np
@@ -273,3 +274,42 @@ def test_unsorted_batch_takes_the_skip_bitmap_gather(heads):
         for m in eng.modes:
             assert np.array_equal(out[m][i], preds[m].forward_pass(p["seq"], cm)), (m, i, lengths[i])
             assert np.max(np.abs(out[m][i] - gcn_oracle.gcn_forward(ws[m], p["seq"], cm))) < TOL, (m, i)
+
+
+def _layer1_form_script() -> str:
+    from conftest import ROOT
+    return (
+        "import sys, os, hashlib; ROOT = %r\n"
+        "for d in ('metagenomic-deepfri_amd', ''): sys.path.insert(0, os.path.join(ROOT, d))\n"
+        "import numpy as np\n"
+        "from mdfri_testkit import synthetic\n"
+        "from mDeepFRI.batch import HotPathEngine, PackedProteins\n"
+        "from mDeepFRI.predict import Predictor\n"
+        "pred = Predictor('syn', weights=synthetic.glorot_gcn_weights(seed=0, n_terms=64))\n"
+        "eng = HotPathEngine({'a': pred}, device=0, max_rows=1024)\n"
+        "def run(seed, count, length):\n"
+        "    prots = synthetic.synthetic_proteins(seed=seed, count=count, length=length, indel_rate=0.1)\n"
+        "    pk = PackedProteins.pack([p['seq'] for p in prots], [p['coords'] for p in prots], [p['q_aln'] for p in prots], [p['t_aln'] for p in prots], max_rows=1024)\n"
+        "    return eng.run_alignments(pk)['a']\n"
+        "run(7, 40, (300, 500))\n"                                   # leaves every workspace of the engine full of another batch's numbers
+        "h = hashlib.sha256()\n"
+        "for seed in (40, 102, 85):\n"                               # mixed chunks; proteins of the matrix-pipe classes end chunks (their pooling range runs to the chunk's end)
+        "    h.update(run(seed, 18, (20, 330)).tobytes())\n"
+        "h.update(run(11, 24, (176, 256)).tobytes())\n"              # chunks of matrix-pipe proteins only: no layer-1 launch at all
+        "print('SHA', h.hexdigest())\n" % ROOT)
+
+
+def test_layer1_made_inside_the_aggregation_kernel_is_bit_identical():
+    """Layer 1 of the proteins whose layer-2 aggregation runs on the matrix pipe is made inside that kernel (k_aggregate_mfma<.., true>:
+    H1 = elu(S . T1) per 32-row tile on v_mfma_f32_32x32x2_f32, pooling sums handed from lane half to lane half in row order, the chunk's
+    trailing groups zeroed by the last protein's workgroups); MDFRI_L1_FUSE=0 keeps the k_layer1 + aggregation pair.  Both forms, each in a
+    process of its own, on engines whose workspaces were used by another batch before: the same bits."""
+    import subprocess
+    import sys
+    sha = {}
+    for fuse in ("1", "0"):
+        env = dict(os.environ, MDFRI_L1_FUSE=fuse)
+        out = subprocess.run([sys.executable, "-c", _layer1_form_script()], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sha[fuse] = out.stdout.split("SHA", 1)[1].strip()
+    assert sha["1"] == sha["0"], sha
