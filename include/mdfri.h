@@ -231,6 +231,11 @@ int mdf_group_rows(void);   /* = MDF_GROUP_ROWS, for callers that do not compile
  * fp32 instruction's) or "f32" (v_mfma_f32_32x32x2_f32; environment MDFRI_HW_PIPE=f32, read once).  fp32 in, fp32 out either way. */
 const char *mdf_hw_pipe(void);
 
+/* How layer 1 (H1 = elu(S . T1), the folded embedding) is computed on the fused engine path: "fused" (default: inside the layer-2
+ * aggregation kernel for the proteins of the matrix-pipe classes, H1 never written; k_layer1 for the rows of the others) or "kernel"
+ * (k_layer1 for every row; environment MDFRI_L1_FUSE=0 or MDFRI_AX_MFMA=0, read once).  Bit-identical results either way. */
+const char *mdf_layer1_form(void);
+
 /* Host helper: row_off[0..B] from Lq[0..B-1] as specified above.  Returns R (total rows) or a negative code. */
 int64_t mdf_layout_rows(const int32_t *Lq, int32_t B, int32_t *row_off);
 

@@ -1714,6 +1714,16 @@ static int set_gemm_attr_once()
     return MDF_OK;
 }
 
+// whether layer 1 is made inside the layer-2 aggregation kernel where that kernel is the matrix-pipe one (see k_aggregate_mfma<.., true>); read once
+static bool layer1_fused()
+{
+    static const bool on = []() {
+        const char *f = getenv("MDFRI_L1_FUSE"), *a = getenv("MDFRI_AX_MFMA");
+        return !(f && atoi(f) == 0) && !(a && atoi(a) == 0);
+    }();
+    return on;
+}
+
 // which matrix pipe the graph-convolution products use (see k_gemm_bf16x6); read once per process
 static bool hw_pipe_bf16x6()
 {
@@ -1975,6 +1985,8 @@ using namespace mdf;
 extern "C" {
 
 const char *mdf_hw_pipe(void) { return hw_pipe_bf16x6() ? "bf16x6" : "f32"; }
+
+const char *mdf_layer1_form(void) { return layer1_fused() ? "fused" : "kernel"; }
 
 int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
 {
@@ -2501,9 +2513,7 @@ int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t 
     // layer 1 (folded embedding): H1 = elu(S . T1), S = Ahat . onehot from the contact stage.  Proteins whose layer-2 aggregation runs on
     // the matrix pipe get their H1 rows made inside that kernel (k_aggregate_mfma<.., true>: bit-identical, H1 never written); k_layer1 covers
     // the rows of the others.  (Maps that may be non-binary -- a gate is set -- keep the two-kernel form: the gather needs H1 in memory.)
-    static const int fuse_env = getenv("MDFRI_L1_FUSE") ? atoi(getenv("MDFRI_L1_FUSE")) : 1;      // developer knobs
-    static const int mfma_env = getenv("MDFRI_AX_MFMA") ? atoi(getenv("MDFRI_AX_MFMA")) : 1;
-    const bool fuse = fuse_env && mfma_env && agg && !agg->gate && m->n_gc >= 2 && agg->n_mf[0] + agg->n_mf[1] + agg->n_mf[2] > 0 &&
+    const bool fuse = layer1_fused() && agg && !agg->gate && m->n_gc >= 2 && agg->n_mf[0] + agg->n_mf[1] + agg->n_mf[2] > 0 &&
                       (agg->n_seg <= 4 || agg->skip_groups);
     AggLayer1 l1;
     l1.S = letter_sums, l1.T1 = m->T1, l1.pool_partial = partial, l1.ldp = feat;

@@ -118,6 +118,7 @@ SIGNATURES = {
     "mdf_layout_rows": (c_int64, [c_void_p, c_int32, c_void_p]),
     "mdf_group_rows": (c_int, []),
     "mdf_hw_pipe": (c_char_p, []),
+    "mdf_layer1_form": (c_char_p, []),
     "mdf_seq_encode_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
     "mdf_cmap_workspace_bytes": (c_size_t, [c_int32, c_int64, c_int32]),
     "mdf_cmap_csr_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32,

@@ -63,7 +63,10 @@ def layers(d):
             if name.startswith("k_aggregate"):
                 # the launch in front of a layer-2 aggregation is the layer-1 kernel (k_layer1; the K = 32 GEMM <4, ..> up to round 3), in
                 # front of a layer-3 aggregation an H.W GEMM
-                layer = "layer 2" if prev.startswith("k_layer1") or "<4," in prev else ("layer 3" if prev.startswith(("k_gemm_f32", "k_gemm_bf16x6")) else "other")
+                if name.startswith("k_aggregate_mfma") and ("true" in name.split("<", 1)[1] or "(bool)1" in name):
+                    layer = "layer 2 (+ layer 1)"      # k_aggregate_mfma<.., true>: layer 1 is made inside this launch
+                else:
+                    layer = "layer 2" if prev.startswith("k_layer1") or "<4," in prev else ("layer 3" if prev.startswith(("k_gemm_f32", "k_gemm_bf16x6")) else "other")
                 groups[("k_aggregate (A.X)", layer, name)].append((grid, dur))
             elif name.startswith(("k_gemm_f32<", "k_gemm_bf16x6<")):      # (not the _small forms: per-call API)
                 kern, epi = name.split("<", 1)
