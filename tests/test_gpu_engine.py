@@ -296,6 +296,14 @@ def _layer1_form_script() -> str:
         "for seed in (40, 102, 85):\n"                               # mixed chunks; proteins of the matrix-pipe classes end chunks (their pooling range runs to the chunk's end)
         "    h.update(run(seed, 18, (20, 330)).tobytes())\n"
         "h.update(run(11, 24, (176, 256)).tobytes())\n"              # chunks of matrix-pipe proteins only: no layer-1 launch at all
+        "rng = np.random.default_rng(123)\n"                         # lengths on the edges of the length classes, in arrival order and sorted
+        "edges = [176, 177, 255, 256, 257, 399, 400, 401, 511, 512, 513, 703, 704, 800, 801, 112, 111]\n"
+        "for it in range(16):\n"
+        "    lens = [int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(20, 900)) for _ in range(int(rng.integers(3, 20)))]\n"
+        "    lens = sorted(lens) if it %% 4 == 0 else lens\n"
+        "    prots = [synthetic.synthetic_proteins(seed=1000 * it + k, count=1, length=L, indel_rate=0.05)[0] for k, L in enumerate(lens)]\n"
+        "    pk = PackedProteins.pack([p['seq'] for p in prots], [p['coords'] for p in prots], [p['q_aln'] for p in prots], [p['t_aln'] for p in prots], max_rows=1024)\n"
+        "    h.update(eng.run_alignments(pk)['a'].tobytes())\n"
         "print('SHA', h.hexdigest())\n" % ROOT)
 
 
