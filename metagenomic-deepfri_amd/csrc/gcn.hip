@@ -537,7 +537,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
 // ---- H.W on the bf16 matrix pipe: BF16x6 ------------------------------------------------------------------------------------------
 // The fp32 matrix instruction runs at 1/16 of the bf16 one (157 vs 2 500 TFLOP/s), so an fp32 product is cheaper as SIX bf16 products:
 // every operand is split on the fly into three bf16 terms, hi = bf16(x), mid = bf16(x - hi), lo = x - hi - mid (round to nearest; both
-// remainders are exact and lo fits bf16, so hi + mid + lo == x bit for bit, |mid| <= 2^-9 |x|, |lo| <= 2^-18 |x|), and
+// remainders are exact and lo fits bf16, so hi + mid + lo == x bit for bit, |mid| <= 2^-8 |x|, |lo| <= 2^-16 |x|; typically a factor 2 and 4 below), and
 //     a.b  ~  ah.bh + (ah.bm + am.bh) + (am.bm + ah.bl + al.bh),
 // each term product exact in fp32, accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  The three products left
 // out (am.bl, al.bm, al.bl) are together at most 2^-23 |a.b|, in the mean 2^-28 and without sign bias (tests/test_bf16x6_split_cpu.py) --
