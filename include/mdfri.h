@@ -228,7 +228,12 @@ int mdf_group_rows(void);   /* = MDF_GROUP_ROWS, for callers that do not compile
 
 /* Which matrix pipe the graph-convolution products H.W run on in this process: "bf16x6" (default: every fp32 operand split into three
  * bf16 terms, six term products per fp32 product accumulated in fp32 -- k_gemm_bf16x6, csrc/gcn.hip; error against float64 below the
- * fp32 instruction's) or "f32" (v_mfma_f32_32x32x2_f32; environment MDFRI_HW_PIPE=f32, read once).  fp32 in, fp32 out either way. */
+ * fp32 instruction's) or "f32" (v_mfma_f32_32x32x2_f32; environment MDFRI_HW_PIPE=f32).  fp32 in, fp32 out either way.
+ * The variable is read ONCE, by the first product of the process: set it before the first call into the library (setting it later is
+ * silently ignored; mdf_hw_pipe() tells which pipe is in use).  Non-finite and near-overflow inputs: the bf16x6 split rounds
+ * hi = bf16(x) to nearest, so |x| > 0x1.fe fp127 (the top 2^-9 of the fp32 range) rounds hi to inf and x - hi to NaN, and an inf operand
+ * gives inf - inf = NaN, where the fp32 instruction would return a finite product / inf.  Activations and weights of the GraphConv and
+ * LSTM layers are many orders of magnitude below that range; a caller that feeds such values selects MDFRI_HW_PIPE=f32. */
 const char *mdf_hw_pipe(void);
 
 /* How layer 1 (H1 = elu(S . T1), the folded embedding) is computed on the fused engine path: "fused" (default: inside the layer-2

@@ -1007,7 +1007,7 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         MDF_HIP(hipStreamCreateWithPriority(&e->map_stream, hipStreamNonBlocking, hi));
     }
     if (int rc = e->flags.grow((size_t)pl->B * 4, &e->generation)) return rc;   // per-protein "binary" flags the dense stage writes on the device (the host lists decide here)
-    int parity = 0;
+    int parity = 0, pending = -1;   // pending: the slot of the chunk whose GraphConv launches have been issued but whose event is not recorded yet
     bool used[2] = {false, false};
     AggOverride aov;
     BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *, bool *have_lsum, bool *bits, const AggOverride **ov) -> int {
@@ -1023,7 +1023,16 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
                      o_skip = align_up(o_plist + (size_t)Bc * 8, 256), total = o_skip + 2 * skip_words * 4;   // (two lists + two group bitmaps: layer 2 / layer 3 and up)
         const int s = parity;
         parity ^= 1;
-        if (used[s]) MDF_HIP(hipEventSynchronize(e->map_ev[s]));   // the kernels that read this slot two chunks ago are done
+        // A slot holds the maps AND the aggregation lists (plist / skip bitmaps) that every GraphConv launch of its chunk reads, for
+        // every head and layer: it may be overwritten only once those launches are done.  run_chunks issues gcn_chunk(ci - 1) between
+        // build(ci - 1) and build(ci), so the event of the previous chunk's slot is recorded HERE, behind its last launch (ADVICE r4:
+        // recorded straight after the CSR conversion it guarded the maps only).
+        if (pending >= 0) {
+            MDF_HIP(hipEventRecord(e->map_ev[pending], st));
+            used[pending] = true;
+            pending = -1;
+        }
+        if (used[s]) MDF_HIP(hipEventSynchronize(e->map_ev[s]));   // every kernel that read this slot two chunks ago is done
         if (e->map_pin_bytes[s] < total) {
             if (e->map_pin[s]) (void)hipHostFree(e->map_pin[s]);
             e->map_pin[s] = nullptr;
@@ -1126,8 +1135,7 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
                                                   e->cs[0].colidx.as<int32_t>(), e->cs[0].val.as<float>(), e->nnz_cap, b->status + 4 * ci,
                                                   e->flags.as<int32_t>(), e->cs[0].cws.p, e->cs[0].cws.bytes, st);
         if (rc) return rc;
-        MDF_HIP(hipEventRecord(e->map_ev[s], st));
-        used[s] = true;
+        pending = s;
         return MDF_OK;
     };
     ++e->eager_runs;

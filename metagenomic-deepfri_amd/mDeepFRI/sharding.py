@@ -122,6 +122,15 @@ class DenseGatherPlan:
             self.dst_rows = flat[self.src_rows]
             self.out = torch.empty((self.total, self.width), dtype=dtype, device=dev)
 
+    @staticmethod
+    def footprint(counts, width: int, itemsize: int = 4):
+        """Sizes of the plan's buffers for shard sizes `counts`, without allocating anything (bench.py --dry-plan, tests): elements
+        of one rank's padded payload (= one collective's count), of the destination's receive block and of its output; rows are
+        indexed with int64 throughout (`index_copy_` / `index_select`), so only the per-collective element count has a limit."""
+        n_max, world, total = max(max(counts), 1), len(counts), int(sum(counts))
+        return {"payload_elems": n_max * width, "recv_elems": world * n_max * width, "out_elems": total * width,
+                "payload_bytes": n_max * width * itemsize, "out_bytes": total * width * itemsize, "row_index_dtype": "int64"}
+
     def run(self, block):
         """block: (n_local, width) scores of this rank.  Returns the (total, width) tensor in input order on `dst`, None
         elsewhere.  Asynchronous on the device for the nccl backend."""
@@ -162,6 +171,11 @@ class FilteredGatherPlan:
         self._pending = None          # (host copy of the all-reduced overflow flag, event) of the previous run
         self.dense = DenseGatherPlan(len(self.local_index), 1, self.local_index, total, self.dev, dtype=torch.int64, dst=dst, group=group,
                                      collectives_for_one_rank=collectives_for_one_rank)
+
+    @staticmethod
+    def max_survivors() -> int:
+        """The returned offsets are int32 (the output stage's format, mDeepFRI.output): the whole job's survivors must stay below 2^31."""
+        return 2 ** 31 - 1
 
     # -- overflow agreement, one step late: all ranks learn it without a synchronisation inside the step ------------------
     def _post_flag(self, overflow: bool):
@@ -263,6 +277,8 @@ def _place_filtered(goff, blocks, dev, sizes):
     survivors of each block as host integers (the caller read them back once), so nothing here waits for the device."""
     import torch
     n = int(sum(sizes))
+    if n > FilteredGatherPlan.max_survivors():
+        raise OverflowError(f"{n} surviving (term, score) pairs do not fit the int32 offsets of the compacted output; gather in several parts")
     out_t = torch.empty(n, dtype=torch.int32, device=dev)
     out_s = torch.empty(n, dtype=torch.float32, device=dev)
     for (rows, c, t, s), z in zip(blocks, sizes):

@@ -168,6 +168,20 @@ class QueryBatchResult:
         return iter((self.first, self.batch, self.kept, self.gcn))
 
 
+_GCN_LUT = np.full(256, 255, dtype=np.uint8)
+_GCN_LUT[np.frombuffer(b"-DGULNTKHYWCPVSOIEFXQABZRM", dtype=np.uint8)] = 0      # the residue alphabet of predict.pyx:26 (case-sensitive)
+
+
+def _first_foreign(seqs, lut):
+    """The first character, in list order, that `lut` (256 bytes, 255 = unknown) does not know; None if there is none."""
+    for s in seqs:
+        raw = np.frombuffer(s.encode("latin-1", "replace"), dtype=np.uint8)
+        bad = lut[raw] == 255
+        if bad.any():
+            return s[int(np.argmax(bad))]
+    return None
+
+
 class QueryStream:
     """The stages either side of the path as ONE stream over arbitrarily many queries: queries + candidate sets -> best hit and
     alignment (GPU aligner, reference alignment.py:223-320) -> C-alpha trace of the hit -> fused contact map + GCN (pipeline.py:476-481,
@@ -216,7 +230,8 @@ class QueryStream:
         from .alignment import align_queries_begin
         query_ids, query_sequences, target_sequences = list(query_ids), list(query_sequences), list(target_sequences)
         if self.batch_chunks > 0 and query_ids:      # slices of ~batch_chunks full chunks: greedy over the padded rows, as the planner fills chunks
-            rows = (np.fromiter(map(len, query_sequences), dtype=np.int64, count=len(query_sequences)) + 15) // 16 * 16   # padded residue rows (MDF_GROUP_ROWS)
+            g = int(self.engine.L.mdf_group_rows())      # MDF_GROUP_ROWS: the planner pads every protein to a multiple of it
+            rows = (np.fromiter(map(len, query_sequences), dtype=np.int64, count=len(query_sequences)) + g - 1) // g * g
             starts, chunk_rows, chunks = [0], 0, 1
             for i, r in enumerate(rows.tolist()):
                 if chunk_rows and chunk_rows + r > self.max_rows:
@@ -246,11 +261,20 @@ class QueryStream:
                             args = ([query_ids[i] for i in pos], [query_sequences[i] for i in pos], [target_sequences[i] for i in pos])
                         aligning[t] = align_queries_begin(*args, self.gap_open, self.gap_extend, self.scoring_matrix, workspace=self.ring[t % 3]) if pos else None
                     if 0 <= t - 1 < nb and aligning[t - 1] is not None:
-                        aligning[t - 1].launch_alignments()
+                        try:
+                            aligning[t - 1].launch_alignments()
+                        except ValueError as e:
+                            self._aligner_error_in_input_order(e, slices[t - 1][2], query_sequences, target_sequences)
+                            raise
                     if 0 <= t - 2 < nb:
                         a, b, pos = slices.pop(t - 2)
                         pend = aligning.pop(t - 2)
-                        running[t - 2] = self._enqueue(a, b, pos, pend.result() if pend is not None else None, query_ids, query_sequences)
+                        try:
+                            batch = pend.result() if pend is not None else None
+                        except ValueError as e:
+                            self._aligner_error_in_input_order(e, pos, query_sequences, target_sequences)
+                            raise
+                        running[t - 2] = self._enqueue(a, b, pos, batch, query_ids, query_sequences)
                     if 0 <= t - 3 < nb:
                         yield self._finish(running.pop(t - 3))
         finally:
@@ -260,6 +284,20 @@ class QueryStream:
             if running:                      # ... and let the enqueued GCN batches finish before their buffers go back to the allocator
                 self.main.synchronize()
                 running.clear()
+
+    def _aligner_error_in_input_order(self, err, pos, query_sequences, target_sequences):
+        """A batch goes through the aligner shortest query first, so the character the library names is the first foreign one in THAT
+        order.  AlignmentStream and the unsorted stream name the first one in input order: say the same here (error path only)."""
+        if not self.sort_by_length or "is not in the scoring matrix alphabet" not in str(err):
+            return
+        from .alignment import _matrix
+        lut = _matrix(self.scoring_matrix)._lut_nocase
+        ordered = sorted(pos)
+        c = _first_foreign([query_sequences[i] for i in ordered], lut)
+        if c is None:      # (the staged list holds the queries first, then the candidates in first-seen order)
+            c = _first_foreign(list(dict.fromkeys(t for i in ordered for t in target_sequences[i].values())), lut)
+        if c is not None:
+            raise ValueError(f"character {c!r} is not in the scoring matrix alphabet") from None
 
     def _launch(self, pk, forward):
         """Upload (side stream), `forward(db)` + filter (main stream), the small results on their way back.  -> the part's state."""
@@ -361,7 +399,17 @@ class QueryStream:
         if ev is not None:
             ev.synchronize()
         if gcn is not None:
-            res.gcn, res.gcn_scores = self._collect(gcn, self.engine.run_alignments)
+            try:
+                res.gcn, res.gcn_scores = self._collect(gcn, self.engine.run_alignments)
+            except ValueError as e:
+                if self.sort_by_length and str(e).startswith("Invalid character in sequence"):
+                    # the packed batch is in sorted order; name the first invalid residue of the slice in INPUT order, as AlignmentStream does
+                    seqs = gcn[1].seqs
+                    by_input = sorted(range(len(seqs)), key=lambda k: res.aligned[res.kept[k]])
+                    c = _first_foreign([seqs[k] for k in by_input], _GCN_LUT)
+                    if c is not None:
+                        raise ValueError(f"Invalid character in sequence: {c}") from None
+                raise
         if cnn is not None:
             res.cnn, res.cnn_scores = self._collect(cnn, None)
         return res

@@ -192,6 +192,30 @@ def test_dense_regrow_reaches_both_contact_sets_of_the_pipelined_stage(heads):
             assert np.array_equal(out[m].cpu().numpy(), ref[m]), m
 
 
+def test_dense_slots_outlive_the_graphconv_launches_that_read_them():
+    """ADVICE r4 (engine.hip, forward_dense): the double-buffered upload slot of a chunk holds its maps AND the aggregation lists (plist,
+    skip bitmaps) that every GraphConv launch of the chunk reads, for every head and layer; the slot may be refilled only behind the
+    chunk's LAST launch.  Many short chunks x three heads (so the device runs far behind the host packing the next maps), lengths of the
+    matrix-pipe classes mixed with gather lengths (so both lists are in use), repeated: dense == fused, bit for bit, every time."""
+    from mDeepFRI.batch import HotPathEngine
+    from mDeepFRI.predict import Predictor
+    ws = {m: synthetic.glorot_gcn_weights(seed=k, n_terms=synthetic.GO_TERMS[m]) for k, m in enumerate(("mf", "bp", "cc"))}
+    preds = {m: Predictor(f"synthetic-{m}", weights=w) for m, w in ws.items()}
+    rng = np.random.default_rng(77)
+    lengths = [int(x) for x in rng.choice([60, 130, 180, 200, 256, 300, 420], size=60)]
+    prots = [synthetic.synthetic_proteins(seed=900 + k, count=1, length=L, indel_rate=0.03)[0] for k, L in enumerate(lengths)]
+    pk = _pack(prots, max_rows=1024)
+    assert len(pk.chunks) >= 12
+    eng = HotPathEngine(preds, device=0, max_rows=1024)
+    ref = eng.run_alignments(pk)
+    maps = [orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2) for p in prots]
+    db = eng.upload(_pack_seq_only(prots, max_rows=1024))
+    for it in range(4):
+        dense = eng.forward_dense(db, maps)
+        for m in eng.modes:
+            assert np.array_equal(dense[m].cpu().numpy(), ref[m]), (it, m)
+
+
 def _pack_seq_only(prots, **kw):
     from mDeepFRI.batch import PackedProteins
     return PackedProteins.pack([p["seq"] for p in prots], **kw)

@@ -183,6 +183,33 @@ def test_query_stream_errors_leave_it_usable():
     assert [r.first for r in stream.run(qids[:40], qseqs[:40], cands[:40])] == [0, 20]
 
 
+def test_query_stream_names_the_first_foreign_letter_in_input_order():
+    """QueryStream sorts a batch by length, so the library meets the SHORTEST offending query first; the stream still names the
+    first one in input order, like AlignmentStream and like the stream made with sort_by_length=False."""
+    from mdfri_testkit import synthetic
+    from mDeepFRI.alignment import ScoringMatrix
+    from mDeepFRI.batch import HotPathEngine
+    from mDeepFRI.predict import Predictor
+    from mDeepFRI.stream import QueryStream
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pipeline_example
+    qids, qseqs, cands, db_xyz = pipeline_example.make_inputs(40, 20, seed=9, k=2)
+    eng = HotPathEngine({"a": Predictor("syn", weights=synthetic.glorot_gcn_weights(seed=0, n_terms=50, sparse_scores=True))}, max_rows=8192)
+    bad = list(qseqs)
+    by_len = sorted(range(40), key=lambda i: len(bad[i]))
+    late_short, early_long = max(by_len[:10]), min(by_len[-10:])        # a short query late in the input, a long one early
+    if late_short < early_long:
+        late_short, early_long = early_long, late_short
+        assert len(bad[late_short]) != len(bad[early_long])
+    bad[early_long] = bad[early_long][:3] + "U" + bad[early_long][4:]
+    bad[late_short] = bad[late_short][:3] + "O" + bad[late_short][4:]
+    first = "U" if early_long < late_short else "O"
+    for sort in (True, False):
+        stream = QueryStream(eng, db_xyz, batch_size=40, max_rows=8192, scoring_matrix=ScoringMatrix.simple(), sort_by_length=sort)
+        with pytest.raises(ValueError, match=f"'{first}' is not in the scoring matrix alphabet"):
+            list(stream.run(qids, bad, cands))
+
+
 def test_query_stream_with_a_language_model_head():
     """A head with the LSTM language-model branch next to one without, inside QueryStream: the LSTM grouping of every batch's plan is
     uploaded asynchronously on the stream (plan-owned sources, stream-ordered allocation) while the previous batch is still running --

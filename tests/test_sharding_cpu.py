@@ -167,6 +167,88 @@ def test_gather_filtered_world_size_2_gloo(n):
         assert np.array_equal(scores[off[i]:off[i + 1]], np.asarray(s, dtype=np.float32))
 
 
+def _worker_w8(rank, world, port, n, T, empty_rank, q):
+    """Both gather plans in one group of `world` ranks: ranks that own no protein at all (n < world) and a rank whose filter keeps
+    nothing still take part in every collective with empty payloads."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lengths = [50 + (i * 37) % 400 for i in range(n)]
+        mine = sharding.partition_by_cost(lengths, world)[rank]
+        local = torch.stack([torch.full((T,), float(i)) + torch.arange(T) / 100.0 for i in mine]) if mine else torch.zeros((0, T))
+        dense = sharding.DenseGatherPlan(len(mine), T, mine, n, "cpu", dst=0)
+        # (the plan returns ITS output buffer: rank 0 copies it before the next run)
+        first_dense = dense.run(local)
+        first_dense = first_dense.clone() if rank == 0 else None
+        second_dense = dense.run(local * 2)
+        off, terms, scores = [0], [], []
+        for i in mine:
+            t, s = ([], []) if rank == empty_rank else _csr_of(i, T)
+            terms += t
+            scores += s
+            off.append(len(terms))
+        plan = sharding.FilteredGatherPlan(mine, n, "cpu", dst=0)
+        args = (torch.tensor(off, dtype=torch.int32), torch.tensor(terms, dtype=torch.int32), torch.tensor(scores, dtype=torch.float32))
+        first = plan.run(*args)
+        again = plan.run(*args, sizes_may_change=False)
+        plan.check()
+        if rank == 0:
+            assert torch.equal(second_dense, first_dense * 2) and all(torch.equal(a, b) for a, b in zip(first, again))
+            q.put((first_dense.numpy(), [x.numpy() for x in first]))
+        else:
+            assert second_dense is None and first is None and again is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,empty_rank", [(5, -1), (8, 0), (50, 3), (50, 0)])
+def test_both_gather_plans_world_size_8_gloo(n, empty_rank):
+    """SURVEY 8e at the node's real rank count: 8 gloo ranks, (a) fewer proteins than ranks -- three ranks own nothing --, (b) a rank
+    (also the destination itself) whose filter keeps nothing.  Dense rows and the compacted (offsets, terms, scores) arrive in input order."""
+    world, T = 8, 11
+    lengths = [50 + (i * 37) % 400 for i in range(n)]
+    shards = sharding.partition_by_cost(lengths, world)
+    if n < world:
+        assert sum(1 for s in shards if not s) == world - n
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_w8, args=(r, world, port, n, T, empty_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    dense, (off, terms, scores) = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    exp = np.stack([np.full(T, float(i)) + np.arange(T) / 100.0 for i in range(n)]).astype(np.float32)
+    assert np.array_equal(dense, exp)
+    emptied = set(shards[empty_rank]) if empty_rank >= 0 else set()
+    assert off.shape == (n + 1,) and off[0] == 0
+    for i in range(n):
+        t, s = ([], []) if i in emptied else _csr_of(i, T)
+        assert list(terms[off[i]:off[i + 1]]) == t, i
+        assert np.array_equal(scores[off[i]:off[i + 1]], np.asarray(s, dtype=np.float32))
+
+
+def test_gather_plans_of_configs4_fit_their_index_types():
+    """BASELINE configs[4] (500 000 proteins, proteome length histogram, MF + BP + CC = 2 752 score columns) on 8 ranks, plan construction
+    only (no payload is allocated): imbalance of the deal below 1 %, the dense gather's element counts (per-rank payload, the destination's
+    receive block and output: 5.5 GB) stay below 2^31 elements per collective and are indexed with int64 rows, and the compacted gather's
+    int32 offsets hold the survivors of the whole job at the bench's keep rate with a wide margin."""
+    from mdfri_testkit import synthetic
+    lengths = synthetic.histogram_lengths(47, 500_000)
+    world, width = 8, sum(synthetic.GO_TERMS[m] for m in ("mf", "bp", "cc"))
+    plan = sharding.plan_summary(lengths, world)
+    assert plan["imbalance"] < 0.01 and sum(plan["proteins"]) == 500_000
+    fp = sharding.DenseGatherPlan.footprint(plan["proteins"], width)
+    assert fp["payload_elems"] < 2 ** 31 and fp["recv_elems"] < 2 ** 31 and fp["out_elems"] < 2 ** 31
+    assert 5.4e9 < fp["out_bytes"] < 5.6e9 and fp["row_index_dtype"] == "int64"
+    # the compacted form: results.tsv keeps a few dozen terms per protein; even 1 000 per protein would fit the int32 offsets
+    assert sharding.FilteredGatherPlan.max_survivors() >= 500_000 * 1000
+    # chunk row offsets inside the engine are int32 per CHUNK (<= max_rows rows), never per job
+    assert max(plan["padded_rows"]) > 2 ** 24 and max(plan["chunks"]) * 65536 >= max(plan["padded_rows"])
+
+
 def test_gather_filtered_single_process():
     off = torch.tensor([0, 2, 2, 3], dtype=torch.int32)
     t = torch.tensor([5, 1, 9], dtype=torch.int32)
