@@ -193,7 +193,11 @@ static int issue_row(const char *name, float *dOut, unsigned long long *dS)
 // ---- part 2: the GEMM forms -------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fsub_rn(float a, float b)
 {
-#ifdef PROBE_PLAIN_SUB   // with -fno-slp-vectorize: hipcc keeps the subtractions scalar by itself and needs no s_nop behind them
+#if defined(PROBE_BARRIER_SUB)
+    float r = a - b;
+    asm("" : "+v"(r));
+    return r;
+#elif defined(PROBE_PLAIN_SUB)   // with -fno-slp-vectorize: hipcc keeps the subtractions scalar by itself and needs no s_nop behind them
     return a - b;
 #else
     float r;
@@ -203,9 +207,15 @@ __device__ __forceinline__ float fsub_rn(float a, float b)
 }
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
 {
+#ifdef PROBE_ASM_CVT   // the conversion as asm instead: no <2 x float> in the IR, so the SLP vectorizer has no seed to pack the subtractions from
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a, b}, v2bf));
+#endif
 }
 // split_pair with scalar subtractions (11 instructions)
 __device__ __forceinline__ void split_pair_s(const SplitRaw &r, const int i, SplitPlanes &o)

@@ -357,6 +357,15 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
 /* ... with the aggregation kernels chosen per protein as `agg` says (NULL: the CSR gather for every row, = mdf_gcn_embed_dev) */
 int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
                           int64_t R, const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, void *stream);
+/* ... one STAGE at a time, for a caller that issues the two kinds of stage on different streams (the engine's split form: the
+ * aggregations, bound by HBM, beside the H.W products, bound by the matrix pipe and the board's power limit; events of the caller order
+ * them).  Stage 0 = layer 1 + the aggregation of layer 2; stage 2 j - 1 = the H.W product of upper layer j; stage 2 j = the aggregation of
+ * upper layer j + 1; mdf_gcn_num_stages = 2 (n_gc - 1), or 1 for a one-layer model.  All stages of one stack take the same arguments and the
+ * same workspace; run in order they are mdf_gcn_embed_agg_dev, bit for bit.  gemm_blocks > 0: the stream of this stage owns that many CUs
+ * (hipExtStreamCreateWithCUMask): the persistent H.W grid is sized for them; 0 = the whole device. */
+int mdf_gcn_num_stages(const mdf_model *m);
+int mdf_gcn_stage_dev(mdf_model *m, int stage, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
+                      const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, int gemm_blocks, void *stream);
 
 /* The same stage for a model with a language-model branch (lm_dim > 0): X0 = relu(lm_h.W_lm + b_lm + W_aa[seq_idx]) on the
  * MFMA GEMM (table row added in the epilogue), then every GraphConv layer as A.X + H.W (layer 1 over `embed` channels).

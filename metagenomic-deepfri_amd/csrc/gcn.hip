@@ -576,6 +576,51 @@ __device__ __forceinline__ void split_fragment(const SplitRaw &r, SplitPlanes &o
     split_pair(r, 2, o);
     split_pair(r, 3, o);
 }
+// The same split for TWO operand pairs (four consecutive k) in lock step, cut into four stages of 6 / 6 / 4 / 6 vector instructions in which no
+// instruction depends on its predecessor: the form k_gemm_bf16x6 issues, one stage behind each matrix instruction (round 5).  What the
+// probe (experiments/gemm_overlap_probe.hip, profiles/r05_gemm_overlap_probe.txt) measured on this part: a v_cvt_pk_bf16_f32 takes two
+// issue slots (8 cycles) like every packed instruction, v_pk_add_f32 costs 12 cycles and an s_nop, and one wave hides about five plain vector
+// instructions behind a matrix instruction -- so the subtractions are scalar (inline asm: hipcc otherwise re-packs them), the two pairs'
+// chains are interleaved, and no slot carries more than one stage except in the three steps that also split B fragments.
+struct SplitQuad {
+    float x0, x1, x2, x3, t0, t1, t2, t3;
+    unsigned ha, hb, ma, mb;
+};
+__device__ __forceinline__ float fsub_scalar(float a, float b)
+{
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // exact here (a remainder); as asm it is neither contracted nor packed
+    return r;
+}
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
+{
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef __bf16 v2bf __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector((v2f){a, b}, v2bf));
+}
+template <int J>   // J = 4 * (which float4 of the fragment: dwords 2 q, 2 q + 1 of each plane) + stage
+__device__ __forceinline__ void split_stage(SplitQuad &q, const SplitRaw &r, SplitPlanes &o)
+{
+    constexpr int quad = J >> 2, st = J & 3;
+    if constexpr (st == 0) {
+        const float4 s = quad ? r.v : r.u;
+        q.x0 = s.x, q.x1 = s.y, q.x2 = s.z, q.x3 = s.w;
+        q.ha = cvt_pk_bf16(q.x0, q.x1), q.hb = cvt_pk_bf16(q.x2, q.x3);
+        q.t0 = __uint_as_float(q.ha << 16), q.t2 = __uint_as_float(q.hb << 16);
+        q.t1 = __uint_as_float(q.ha & 0xffff0000u), q.t3 = __uint_as_float(q.hb & 0xffff0000u);
+    } else if constexpr (st == 1) {
+        q.x0 = fsub_scalar(q.x0, q.t0), q.x2 = fsub_scalar(q.x2, q.t2), q.x1 = fsub_scalar(q.x1, q.t1), q.x3 = fsub_scalar(q.x3, q.t3);
+        q.ma = cvt_pk_bf16(q.x0, q.x1), q.mb = cvt_pk_bf16(q.x2, q.x3);
+    } else if constexpr (st == 2) {
+        q.t0 = __uint_as_float(q.ma << 16), q.t2 = __uint_as_float(q.mb << 16);
+        q.t1 = __uint_as_float(q.ma & 0xffff0000u), q.t3 = __uint_as_float(q.mb & 0xffff0000u);
+    } else {
+        q.x0 = fsub_scalar(q.x0, q.t0), q.x2 = fsub_scalar(q.x2, q.t2), q.x1 = fsub_scalar(q.x1, q.t1), q.x3 = fsub_scalar(q.x3, q.t3);
+        o.h[2 * quad] = q.ha, o.h[2 * quad + 1] = q.hb;
+        o.m[2 * quad] = q.ma, o.m[2 * quad + 1] = q.mb;
+        o.l[2 * quad] = cvt_pk_bf16(q.x0, q.x1), o.l[2 * quad + 1] = cvt_pk_bf16(q.x2, q.x3);
+    }
+}
 // the six term products of one 32 x 32 x 16 block, in THE order every BF16x6 kernel uses (results are bit-identical across them)
 #define MDF_X6_SEQ(acc_, a_, b_)                                                                                                  \
     acc_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a_).l), __builtin_bit_cast(bf16x8, (b_).h), acc_, 0, 0, 0); \
@@ -589,8 +634,11 @@ __device__ __forceinline__ void split_fragment(const SplitRaw &r, SplitPlanes &o
 // k_gemm_f32's (256 x 256 x 32 positions, 8 waves x (4 x 2) tiles of 32 x 32, LDS-DMA into two 64 KiB buffers, XOR-swizzled rows, one
 // barrier per position, one flat (tile, position) pipeline); a position is two halves of 16 k.  Lane l of a fragment holds row l & 31
 // and the 8 consecutive k of its half, (l >> 5): two ds_read_b128, then the split.  A step = one A tile against both B tiles (12 matrix
-// instructions) with the next step's fragment reads and splits, and in the first half the next position's DMA, riding behind them.
-template <int EPI>
+// instructions = 12 slots) with the next step's fragment reads and splits, and in the first half the next position's DMA, riding behind
+// them: ONE split stage (4-6 vector instructions, split_stage) per slot; the three steps that also split B fragments carry two stages in
+// some slots.  SCHED 0 is the round-4 schedule (matrix instructions in pairs, one 11-deep chain with a packed subtraction behind each
+// pair), kept for the A/B knob MDFRI_X6_SCHED=0; both are bit-identical.
+template <int EPI, int SCHED = 1>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
                                                                  int N, int K, float *__restrict__ C, int ldc, const float *__restrict__ bias,
                                                                  float *__restrict__ pool_partial, int ldp, int total_tiles, GemmAux aux)
@@ -691,6 +739,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
         MDF_MF(tm_, h, m, 0) X8 MDF_SB MDF_MF(tm_, h, m, 1) X9 MDF_SB MDF_MF(tm_, h, h, 0) X10 MDF_SB MDF_MF(tm_, h, h, 1) X11 MDF_SB \
     }
 #define MDF_PS(raw_, i_, P_) split_pair(raw_, i_, P_);
+#define MDF_Q(j_, raw_, P_) split_stage<j_>(qs, raw_, P_);
+    SplitQuad qs;
     int cur = 0;
     while (true) {
         const float *Ab = smem + cur * ((BM + BN) * BK) + fbaseA;
@@ -698,20 +748,37 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
         const float *An = smem + (cur ^ 1) * ((BM + BN) * BK) + fbaseA;
         const float *Bn = smem + (cur ^ 1) * ((BM + BN) * BK) + BM * BK + fbaseB;
         const unsigned ldsA = lds_base + (cur ^ 1) * ((BM + BN) * BK * 4), ldsB = ldsA + BM * BK * 4;
-        // half 0: the whole DMA of the next position; the B fragments of half 1
-        MDF_STEP(0, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 1, 0), MDF_DMA_A(0), MDF_DMA_B(0), MDF_DMA_A(1), MDF_DMA_B(1), MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
-        MDF_STEP(1, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 2, 0), MDF_DMA_A(2), MDF_DMA_B(2), MDF_DMA_A(3), MDF_DMA_B(3), MDF_PS(ra, 0, PA[0]), , MDF_PS(ra, 1, PA[0]), , MDF_PS(ra, 2, PA[0]), , MDF_PS(ra, 3, PA[0]), )
-        MDF_STEP(2, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 3, 0) MDF_RD(rb, Bb, 0, 1), , , , , MDF_PS(ra, 0, PA[1]), MDF_PS(rb, 0, PB[1][0]), MDF_PS(ra, 1, PA[1]), MDF_PS(rb, 1, PB[1][0]), MDF_PS(ra, 2, PA[1]), MDF_PS(rb, 2, PB[1][0]), MDF_PS(ra, 3, PA[1]), MDF_PS(rb, 3, PB[1][0]))
-        MDF_STEP(3, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 0, 1) MDF_RD(rb, Bb, 1, 1), , , , , MDF_PS(ra, 0, PA[0]), MDF_PS(rb, 0, PB[1][1]), MDF_PS(ra, 1, PA[0]), MDF_PS(rb, 1, PB[1][1]), MDF_PS(ra, 2, PA[0]), MDF_PS(rb, 2, PB[1][1]), MDF_PS(ra, 3, PA[0]), MDF_PS(rb, 3, PB[1][1]))
-        // half 1: the source addresses of the position after next, then the barrier and the next position's first fragments
-        MDF_STEP(0, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 1, 1), , , , , MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
-        cursor_advance<PLAIN>(pc, nk, NT, M, total_tiles, stride);
-        MDF_DMA_SETUP(pc)
-        MDF_STEP(1, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 2, 1), , , , , MDF_PS(ra, 0, PA[0]), , MDF_PS(ra, 1, PA[0]), , MDF_PS(ra, 2, PA[0]), , MDF_PS(ra, 3, PA[0]), )
-        MDF_STEP(2, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 3, 1), , , , , MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next position has landed ...
-        __syncthreads();                                     // ... and everybody's; nobody reads this position's buffer any more
-        MDF_STEP(3, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, An, 0, 0) MDF_RD(rb, Bn, 0, 0) MDF_RD(rc, Bn, 1, 0), , , MDF_PS(ra, 0, PA[0]), MDF_PS(rb, 0, PB[0][0]), MDF_PS(rc, 0, PB[0][1]) MDF_PS(ra, 1, PA[0]), MDF_PS(rb, 1, PB[0][0]), MDF_PS(rc, 1, PB[0][1]) MDF_PS(ra, 2, PA[0]), MDF_PS(rb, 2, PB[0][0]), MDF_PS(rc, 2, PB[0][1]) MDF_PS(ra, 3, PA[0]), MDF_PS(rb, 3, PB[0][0]), MDF_PS(rc, 3, PB[0][1]), )
+        if constexpr (SCHED == 0) {
+            // half 0: the whole DMA of the next position; the B fragments of half 1
+            MDF_STEP(0, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 1, 0), MDF_DMA_A(0), MDF_DMA_B(0), MDF_DMA_A(1), MDF_DMA_B(1), MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
+            MDF_STEP(1, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 2, 0), MDF_DMA_A(2), MDF_DMA_B(2), MDF_DMA_A(3), MDF_DMA_B(3), MDF_PS(ra, 0, PA[0]), , MDF_PS(ra, 1, PA[0]), , MDF_PS(ra, 2, PA[0]), , MDF_PS(ra, 3, PA[0]), )
+            MDF_STEP(2, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 3, 0) MDF_RD(rb, Bb, 0, 1), , , , , MDF_PS(ra, 0, PA[1]), MDF_PS(rb, 0, PB[1][0]), MDF_PS(ra, 1, PA[1]), MDF_PS(rb, 1, PB[1][0]), MDF_PS(ra, 2, PA[1]), MDF_PS(rb, 2, PB[1][0]), MDF_PS(ra, 3, PA[1]), MDF_PS(rb, 3, PB[1][0]))
+            MDF_STEP(3, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 0, 1) MDF_RD(rb, Bb, 1, 1), , , , , MDF_PS(ra, 0, PA[0]), MDF_PS(rb, 0, PB[1][1]), MDF_PS(ra, 1, PA[0]), MDF_PS(rb, 1, PB[1][1]), MDF_PS(ra, 2, PA[0]), MDF_PS(rb, 2, PB[1][1]), MDF_PS(ra, 3, PA[0]), MDF_PS(rb, 3, PB[1][1]))
+            // half 1: the source addresses of the position after next, then the barrier and the next position's first fragments
+            MDF_STEP(0, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 1, 1), , , , , MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
+            cursor_advance<PLAIN>(pc, nk, NT, M, total_tiles, stride);
+            MDF_DMA_SETUP(pc)
+            MDF_STEP(1, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 2, 1), , , , , MDF_PS(ra, 0, PA[0]), , MDF_PS(ra, 1, PA[0]), , MDF_PS(ra, 2, PA[0]), , MDF_PS(ra, 3, PA[0]), )
+            MDF_STEP(2, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 3, 1), , , , , MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next position has landed ...
+            __syncthreads();                                     // ... and everybody's; nobody reads this position's buffer any more
+            MDF_STEP(3, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, An, 0, 0) MDF_RD(rb, Bn, 0, 0) MDF_RD(rc, Bn, 1, 0), , , MDF_PS(ra, 0, PA[0]), MDF_PS(rb, 0, PB[0][0]), MDF_PS(rc, 0, PB[0][1]) MDF_PS(ra, 1, PA[0]), MDF_PS(rb, 1, PB[0][0]), MDF_PS(rc, 1, PB[0][1]) MDF_PS(ra, 2, PA[0]), MDF_PS(rb, 2, PB[0][0]), MDF_PS(rc, 2, PB[0][1]) MDF_PS(ra, 3, PA[0]), MDF_PS(rb, 3, PB[0][0]), MDF_PS(rc, 3, PB[0][1]), )
+        } else {
+            // half 0: the whole DMA of the next position; the B fragments of half 1
+            MDF_STEP(0, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 1, 0), MDF_DMA_A(0), MDF_DMA_B(0), MDF_DMA_A(1), MDF_DMA_B(1), MDF_Q(0, ra, PA[1]), MDF_Q(1, ra, PA[1]), MDF_Q(2, ra, PA[1]), MDF_Q(3, ra, PA[1]), MDF_Q(4, ra, PA[1]), MDF_Q(5, ra, PA[1]), MDF_Q(6, ra, PA[1]), MDF_Q(7, ra, PA[1]))
+            MDF_STEP(1, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 2, 0), MDF_DMA_A(2), MDF_DMA_B(2), MDF_DMA_A(3), MDF_DMA_B(3), MDF_Q(0, ra, PA[0]), MDF_Q(1, ra, PA[0]), MDF_Q(2, ra, PA[0]), MDF_Q(3, ra, PA[0]), MDF_Q(4, ra, PA[0]), MDF_Q(5, ra, PA[0]), MDF_Q(6, ra, PA[0]), MDF_Q(7, ra, PA[0]))
+            MDF_STEP(2, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 3, 0) MDF_RD(rb, Bb, 0, 1), , MDF_Q(0, ra, PA[1]) MDF_Q(1, ra, PA[1]), MDF_Q(2, ra, PA[1]), MDF_Q(3, ra, PA[1]) MDF_Q(4, ra, PA[1]), MDF_Q(5, ra, PA[1]), MDF_Q(6, ra, PA[1]) MDF_Q(7, ra, PA[1]), MDF_Q(0, rb, PB[1][0]), MDF_Q(1, rb, PB[1][0]) MDF_Q(2, rb, PB[1][0]), MDF_Q(3, rb, PB[1][0]), MDF_Q(4, rb, PB[1][0]) MDF_Q(5, rb, PB[1][0]), MDF_Q(6, rb, PB[1][0]), MDF_Q(7, rb, PB[1][0]))
+            MDF_STEP(3, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 0, 1) MDF_RD(rb, Bb, 1, 1), , MDF_Q(0, ra, PA[0]) MDF_Q(1, ra, PA[0]), MDF_Q(2, ra, PA[0]), MDF_Q(3, ra, PA[0]) MDF_Q(4, ra, PA[0]), MDF_Q(5, ra, PA[0]), MDF_Q(6, ra, PA[0]) MDF_Q(7, ra, PA[0]), MDF_Q(0, rb, PB[1][1]), MDF_Q(1, rb, PB[1][1]) MDF_Q(2, rb, PB[1][1]), MDF_Q(3, rb, PB[1][1]), MDF_Q(4, rb, PB[1][1]) MDF_Q(5, rb, PB[1][1]), MDF_Q(6, rb, PB[1][1]), MDF_Q(7, rb, PB[1][1]))
+            // half 1: the source addresses of the position after next, then the barrier and the next position's first fragments
+            MDF_STEP(0, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 1, 1), , , MDF_Q(0, ra, PA[1]), MDF_Q(1, ra, PA[1]), MDF_Q(2, ra, PA[1]), MDF_Q(3, ra, PA[1]), MDF_Q(4, ra, PA[1]), MDF_Q(5, ra, PA[1]), MDF_Q(6, ra, PA[1]), MDF_Q(7, ra, PA[1]), , )
+            cursor_advance<PLAIN>(pc, nk, NT, M, total_tiles, stride);
+            MDF_DMA_SETUP(pc)
+            MDF_STEP(1, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 2, 1), , , MDF_Q(0, ra, PA[0]), MDF_Q(1, ra, PA[0]), MDF_Q(2, ra, PA[0]), MDF_Q(3, ra, PA[0]), MDF_Q(4, ra, PA[0]), MDF_Q(5, ra, PA[0]), MDF_Q(6, ra, PA[0]), MDF_Q(7, ra, PA[0]), , )
+            MDF_STEP(2, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 3, 1), , , MDF_Q(0, ra, PA[1]), MDF_Q(1, ra, PA[1]), MDF_Q(2, ra, PA[1]), MDF_Q(3, ra, PA[1]), MDF_Q(4, ra, PA[1]), MDF_Q(5, ra, PA[1]), MDF_Q(6, ra, PA[1]), MDF_Q(7, ra, PA[1]), , )
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next position has landed ...
+            __syncthreads();                                     // ... and everybody's; nobody reads this position's buffer any more
+            MDF_STEP(3, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, An, 0, 0) MDF_RD(rb, Bn, 0, 0) MDF_RD(rc, Bn, 1, 0), MDF_Q(0, ra, PA[0]) MDF_Q(1, ra, PA[0]), MDF_Q(2, ra, PA[0]) MDF_Q(3, ra, PA[0]), MDF_Q(4, ra, PA[0]) MDF_Q(5, ra, PA[0]), MDF_Q(6, ra, PA[0]) MDF_Q(7, ra, PA[0]), MDF_Q(0, rb, PB[0][0]) MDF_Q(1, rb, PB[0][0]), MDF_Q(2, rb, PB[0][0]) MDF_Q(3, rb, PB[0][0]), MDF_Q(4, rb, PB[0][0]) MDF_Q(5, rb, PB[0][0]), MDF_Q(6, rb, PB[0][0]) MDF_Q(7, rb, PB[0][0]), MDF_Q(0, rc, PB[0][1]) MDF_Q(1, rc, PB[0][1]), MDF_Q(2, rc, PB[0][1]) MDF_Q(3, rc, PB[0][1]), MDF_Q(4, rc, PB[0][1]) MDF_Q(5, rc, PB[0][1]), MDF_Q(6, rc, PB[0][1]) MDF_Q(7, rc, PB[0][1]))
+        }
         if (cc.kt == nk - 1) {
             gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, ldp, nullptr, N, aux);
 #pragma unroll
@@ -728,6 +795,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
     }
 #undef MDF_STEP
 #undef MDF_PS
+#undef MDF_Q
 #undef MDF_MF
 #undef MDF_BF
 #undef MDF_SB
@@ -1710,6 +1778,8 @@ static int set_gemm_attr_once()
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_LSTM_TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_LSTM_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_ELU_POOL_STORE, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_ELU_POOL, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return MDF_OK;
 }
@@ -1734,9 +1804,14 @@ static bool hw_pipe_bf16x6()
     return on;
 }
 
+// A caller that has given the launch stream only part of the chip (the engine's split form: H.W on some CUs, the aggregation on the
+// others) says how many workgroups are resident there; 0 = the whole device.  Set around the launches of one stage, on the issuing thread.
+static thread_local int tl_gemm_blocks = 0;
+
 // persistent grid: one 512-thread workgroup per CU (LDS: 128 KiB), a multiple of 8 so that block b stays on XCD b%8
 static int gemm_resident_blocks()
 {
+    if (tl_gemm_blocks > 0) return tl_gemm_blocks;
     static std::atomic<int> per_dev[MDF_MAX_DEVICES];   // zero-initialised; keyed by device ordinal (CU counts may differ)
     const int dev = current_device();
     int n = per_dev[dev].load(std::memory_order_relaxed);
@@ -1787,8 +1862,17 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
             }
             if (!small) {
                 const int total = plain ? MT * NT : 8 * NT * ((MT + 7) / 8);
-                hipLaunchKernelGGL(k_gemm_bf16x6<EPI>, dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt, ldb,
-                                   M, N, K, C, ldc, bias, pool_partial, ldp, total, aux);
+                bool old_sched = false;
+                if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL) {   // developer A/B knob (read once): the round-4 issue schedule, bit-identical
+                    static const bool sched0 = getenv("MDFRI_X6_SCHED") && atoi(getenv("MDFRI_X6_SCHED")) == 0;
+                    old_sched = sched0;
+                    if (sched0)
+                        hipLaunchKernelGGL((k_gemm_bf16x6<EPI, 0>), dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda,
+                                           Bt, ldb, M, N, K, C, ldc, bias, pool_partial, ldp, total, aux);
+                }
+                if (!old_sched)
+                    hipLaunchKernelGGL((k_gemm_bf16x6<EPI, 1>), dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt,
+                                       ldb, M, N, K, C, ldc, bias, pool_partial, ldp, total, aux);
             }
             MDF_HIP(hipGetLastError());
             return MDF_OK;
@@ -1903,33 +1987,41 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
     return MDF_OK;
 }
 
-// GraphConv layers 2..n_gc on top of H1 (in Hin): H_k = elu((Ahat . H_{k-1}) . W_k), pooled partial sums at `partial + off`
-static int gcn_upper_layers(mdf_model *m, float *Hin, float *Hout, float *AH, const int32_t *rowptr, const int32_t *colidx,
+// GraphConv layers 2..n_gc on top of H1: H_k = elu((Ahat . H_{k-1}) . W_k), pooled partial sums at `partial + off`.  Layer k (1-based
+// among the upper layers) reads H_{k-1} from Ha (k odd) or Hb (k even) and leaves its output in the other; one call does the aggregation,
+// the H.W product, or both of ONE layer -- the engine's split form issues the two halves on different streams (gcn_stage below).
+static int gcn_upper_layer(mdf_model *m, int k, bool do_agg, bool do_gemm, float *Ha, float *Hb, float *AH, const int32_t *rowptr, const int32_t *colidx,
+                           const float *val, int Ri, float *partial, hipStream_t st, const mdf_agg_desc *agg = nullptr, const AggLayer1 *l1 = nullptr)
+{
+    const int feat = m->feat;
+    int off = 0;
+    for (int j = 0; j < k; ++j) off += m->gc[j];
+    float *Hin = (k & 1) ? Ha : Hb, *Hout = (k & 1) ? Hb : Ha;
+    const int Cin = m->gc[k - 1], Cout = m->gc[k];
+    // from layer 3 on the aggregate goes into the slab that holds H_{k-2} (dead by now, and the last one the previous A.X launch
+    // touched) instead of the AH slab: measured -2 % on both A.X launches of a head (profiles/r04_cache_policy_probes.txt, "mid_dead")
+    // (only for a launch whose GEMM stores nothing -- the last layer --, or the GEMM would write the slab it reads)
+    if (k >= 2 && k == m->n_gc - 1) AH = Hout;
+    if (do_agg)
+        if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st, k >= 2 ? TK_AX3 : TK_AX, agg, k == 1 ? l1 : nullptr)) return rc;
+    if (do_gemm) {
+        ScopedTiming tm(k >= 2 ? TK_GEMM3 : TK_GEMM, st);
+        const bool last = k == m->n_gc - 1;
+        int rc;
+        if (last)
+            rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
+        else
+            rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
+        if (rc) return rc;
+    }
+    return MDF_OK;
+}
+static int gcn_upper_layers(mdf_model *m, float *Ha, float *Hb, float *AH, const int32_t *rowptr, const int32_t *colidx,
                             const float *val, int Ri, float *partial, hipStream_t st, const mdf_agg_desc *agg = nullptr,
                             const AggLayer1 *l1 = nullptr)
 {
-    const int feat = m->feat;
-    int off = m->gc[0];
-    for (int k = 1; k < m->n_gc; ++k) {
-        const int Cin = m->gc[k - 1], Cout = m->gc[k];
-        // from layer 3 on the aggregate goes into the slab that holds H_{k-2} (dead by now, and the last one the previous A.X launch
-        // touched) instead of the AH slab: measured -2 % on both A.X launches of a head (profiles/r04_cache_policy_probes.txt, "mid_dead")
-        // (only for a launch whose GEMM stores nothing -- the last layer --, or the GEMM would write the slab it reads)
-        if (k >= 2 && k == m->n_gc - 1) AH = Hout;
-        if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st, k >= 2 ? TK_AX3 : TK_AX, agg, k == 1 ? l1 : nullptr)) return rc;
-        {
-            ScopedTiming tm(k >= 2 ? TK_GEMM3 : TK_GEMM, st);
-            const bool last = k == m->n_gc - 1;
-            int rc;
-            if (last)
-                rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
-            else
-                rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
-            if (rc) return rc;
-        }
-        off += Cout;
-        std::swap(Hin, Hout);
-    }
+    for (int k = 1; k < m->n_gc; ++k)
+        if (int rc = gcn_upper_layer(m, k, true, true, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg, l1)) return rc;
     return MDF_OK;
 }
 
@@ -2495,18 +2587,21 @@ int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts,
     return MDF_OK;
 }
 
-int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
-                          int64_t R, const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, void *stream)
+// One STAGE of the stack of a model without a language model: stage 0 = layer 1 (k_layer1 for the rows that need H1 in memory) and the
+// aggregation of layer 2; stage 2 j - 1 = the H.W product of upper layer j; stage 2 j = the aggregation of upper layer j + 1.  Even stages
+// are bound by HBM, odd ones by the matrix pipe.  stage < 0: all of them, in order (what mdf_gcn_embed_agg_dev does on one stream).
+static int gcn_stage(mdf_model *m, int stage, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
+                     const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, hipStream_t st)
 {
     MDF_REQUIRE(m && letter_sums && rowptr && colidx && val && partial && workspace, "gcn_embed_dev: NULL argument");
     MDF_REQUIRE(R > 0 && R % 128 == 0 && R < 0x7fffffff, "gcn_embed_dev: bad row count %lld", (long long)R);
     if (workspace_bytes < gcn_ws_bytes(m, R))
         return fail(MDF_ECAPACITY, "gcn_embed_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, gcn_ws_bytes(m, R));
-    hipStream_t st = static_cast<hipStream_t>(stream);
+    MDF_REQUIRE(stage < mdf_gcn_num_stages(m), "gcn_stage: stage %d of %d", stage, mdf_gcn_num_stages(m));
     Carver cv(workspace, workspace_bytes);
     int cmax = 0;
     for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
-    // slab order H1 | AH | H2 (layer 3 aggregates into the H1 slab, see gcn_upper_layers)
+    // slab order H1 | AH | H2 (layer 3 aggregates into the H1 slab, see gcn_upper_layer)
     float *Ha = cv.take<float>((size_t)R * cmax), *AH = cv.take<float>((size_t)R * cmax), *Hb = cv.take<float>((size_t)R * cmax);
     const int Ri = (int)R, feat = m->feat;
     MDF_REQUIRE(m->lm_dim == 0, "gcn_embed_dev: this model has a language-model branch; use mdf_gcn_embed_lm_dev");
@@ -2517,7 +2612,7 @@ int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t 
                       (agg->n_seg <= 4 || agg->skip_groups);
     AggLayer1 l1;
     l1.S = letter_sums, l1.T1 = m->T1, l1.pool_partial = partial, l1.ldp = feat;
-    {
+    if (stage <= 0) {
         ScopedTiming tm(TK_GEMM1, st);
         const int C0 = m->gc[0];
         // groups per wave: the wave's slice of T1 (26 KiB per 256-column slab) is fetched once per wave -- with one group per wave a launch
@@ -2546,9 +2641,36 @@ int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t 
         }
         MDF_HIP(hipGetLastError());
     }
-    if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg, fuse ? &l1 : nullptr)) return rc;
+    const AggLayer1 *l1p = fuse ? &l1 : nullptr;
+    if (stage < 0) {
+        if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg, l1p)) return rc;
+    } else if (m->n_gc >= 2) {
+        const bool gemm = stage & 1;
+        const int k = gemm ? (stage + 1) / 2 : stage / 2 + 1;
+        if (int rc = gcn_upper_layer(m, k, !gemm, gemm, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg, l1p)) return rc;
+    }
     MDF_HIP(hipGetLastError());
     return MDF_OK;
+}
+
+int mdf_gcn_num_stages(const mdf_model *m) { return !m ? 0 : m->n_gc >= 2 ? 2 * (m->n_gc - 1) : 1; }
+
+int mdf_gcn_stage_dev(mdf_model *m, int stage, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
+                      const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, int gemm_blocks, void *stream)
+{
+    MDF_REQUIRE(stage >= 0, "gcn_stage_dev: stage %d", stage);
+    struct Blocks {   // the launches of this stage see a chip of `gemm_blocks` CUs (0: all of them)
+        int keep;
+        explicit Blocks(int n) : keep(tl_gemm_blocks) { tl_gemm_blocks = n > 0 ? std::max(8, n / 8 * 8) : 0; }
+        ~Blocks() { tl_gemm_blocks = keep; }
+    } scope(gemm_blocks);
+    return gcn_stage(m, stage, letter_sums, rowptr, colidx, val, R, agg, partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
+                          int64_t R, const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return gcn_stage(m, -1, letter_sums, rowptr, colidx, val, R, agg, partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int mdf_gcn_pool_dev(mdf_model *m, const float *partial, const int32_t *grp_off, int32_t B, float *pooled, void *stream)
