@@ -272,6 +272,14 @@ int mdf_cmap_csr_dev(const float *coords, const int32_t *coord_off, const char *
                      double threshold, int generated_contacts, int32_t *rowptr, int32_t *colidx, float *val,
                      int64_t nnz_cap, int32_t *status, const uint8_t *seq_idx, float *letter_sums, void *workspace,
                      size_t workspace_bytes, void *stream);
+/* ... with the two offset arrays as (begin, end) PAIRS when off_stride == 2: protein p's residues are [coord_off[2 p], coord_off[2 p + 1]),
+ * its alignment bytes [aln_off[2 p], aln_off[2 p + 1]) -- proteins visited in another order than the packed arrays store them (a plan that
+ * orders a batch by length, mdf_plan_create).  off_stride == 1 is mdf_cmap_csr_dev. */
+int mdf_cmap_csr_pairs_dev(const float *coords, const int32_t *coord_off, const char *q_aln, const char *t_aln,
+                           const int32_t *aln_off, int32_t off_stride, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R, int32_t max_len,
+                           double threshold, int generated_contacts, int32_t *rowptr, int32_t *colidx, float *val,
+                           int64_t nnz_cap, int32_t *status, const uint8_t *seq_idx, float *letter_sums, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* Same stage, reference output format: out[p] = (Lq[p],Lq[p]) int32 at element offset out_off[p] (int64, device).
  * The batched build_align_contact_map; bit-exact with the reference per protein. */
@@ -404,7 +412,17 @@ int mdf_gcn_head_dev(mdf_model *m, const float *pooled, int32_t B, float *scores
  * (at most max_segment_groups groups of MDF_GROUP_ROWS rows).  An immutable plan may be shared by any number of batches of the same
  * lengths. */
 typedef struct mdf_plan mdf_plan;
+/* mdf_plan_create VISITS the proteins shortest first (stable: equal lengths keep their input order), as the reference's work list does
+ * (pipeline.py:529-533 sorts it by length): proteins of like length share chunks, which is what the per-length choice of the aggregation
+ * kernel is built for (an unsorted mixed-length batch costs ~10 % of the GCN stage).  The order is internal: batches (mdf_batch_dev), dense
+ * maps, scores, validation reports and every other per-protein array of the API stay in the CALLER's order; the chunk / segment tables below
+ * and mdf_plan_order() speak of plan positions.  Results do not depend on it (a protein's scores are the same bits in any batch).
+ * mdf_plan_create_ex with MDF_PLAN_KEEP_ORDER visits them in input order (a caller that has sorted already, tests). */
+#define MDF_PLAN_KEEP_ORDER 1u
 int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, int32_t max_segment_groups, mdf_plan **out);
+int mdf_plan_create_ex(const int32_t *Lq, int32_t B, int32_t max_rows, int32_t max_segment_groups, uint32_t flags, mdf_plan **out);
+/* plan position -> index in the caller's batch (B entries, owned by the plan); NULL (count 0) when the plan keeps the input order */
+const int32_t *mdf_plan_order(const mdf_plan *plan, int64_t *count);
 void mdf_plan_free(mdf_plan *plan);
 int32_t mdf_plan_num_proteins(const mdf_plan *plan);
 int32_t mdf_plan_num_chunks(const mdf_plan *plan);

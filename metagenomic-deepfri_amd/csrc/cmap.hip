@@ -164,13 +164,15 @@ __global__ __launch_bounds__(1024) void k_scan_i32_to_i64(const int32_t *__restr
 //   q2t[row_off[p]+q] = target index aligned to query residue q, or -1 when q is an insertion (target gap);
 //   t2q (optional, per-call API)  = the reference's target_to_query_map;  nm_out = its length.
 // ------------------------------------------------------------------------------------------------------------------
+// (os: stride of the offset arrays -- 1: classic offsets, protein p spans [off[p], off[p + 1]); 2: (begin, end) pairs, [off[2 p], off[2 p + 1]):
+// the form the engine builds when its plan visits the proteins in another order than the batch stores them)
 __global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_aln, const char *__restrict__ t_aln,
                                                     const int32_t *__restrict__ aln_off, const int32_t *__restrict__ row_off,
                                                     int32_t *__restrict__ q2t, int32_t *__restrict__ t2q,
-                                                    int32_t *__restrict__ nm_out, int32_t *__restrict__ lq_out)
+                                                    int32_t *__restrict__ nm_out, int32_t *__restrict__ lq_out, int os)
 {
     const int p = blockIdx.x;
-    const int a0 = aln_off[p], La = aln_off[p + 1] - a0;
+    const int a0 = aln_off[p * os], La = aln_off[p * os + 1] - a0;
     const char *q = q_aln + a0, *t = t_aln + a0;
     const int tid = threadIdx.x;
     const int seg = (La + 255) / 256;
@@ -261,7 +263,7 @@ __device__ __forceinline__ void cmap_rows_body(const float *__restrict__ coords,
                                                const int32_t *__restrict__ q2t, float thr2, int gen, int32_t *__restrict__ counts,
                                                int32_t *__restrict__ group_sum, unsigned long long *__restrict__ masks, int W,
                                                int32_t *__restrict__ dense_out, const int64_t *__restrict__ dense_off, int p_lo, int p_hi,
-                                               float4 *s_col_all, int *s_cnt)
+                                               float4 *s_col_all, int *s_cnt, int os)
 {
     const int g = blockIdx.x;
     const int row0 = g * 32;
@@ -282,8 +284,9 @@ __device__ __forceinline__ void cmap_rows_body(const float *__restrict__ coords,
             s_cnt[wid * 8 + lane] = 0;
         }
     }
-    const int Lt = coord_off[p + 1] - coord_off[p];
-    const float *xyz = coords + (int64_t)coord_off[p] * 3;
+    const int c0 = coord_off[p * os];
+    const int Lt = coord_off[p * os + 1] - c0;
+    const float *xyz = coords + (int64_t)c0 * 3;
     const int32_t *q2t_p = q2t + r0;
 
     // per-row uniforms
@@ -422,16 +425,16 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
                                                    int32_t *__restrict__ counts,        // COUNT: out (R)
                                                    int32_t *__restrict__ group_sum,     // COUNT: out (R/32)
                                                    unsigned long long *__restrict__ masks, int W,   // COUNT: out (R, W) contact bits
-                                                   int32_t *__restrict__ dense_out, const int64_t *__restrict__ dense_off)
+                                                   int32_t *__restrict__ dense_out, const int64_t *__restrict__ dense_off, int os)
 {
     __shared__ float4 s_col_all[CMAP_COL_TILE];   // x, y, z, bits of the mapped target index (-2 padding, -1 gap, -3 no coordinates)
     __shared__ int s_cnt[32];
     const int row0 = blockIdx.x * 32;
     const int p_lo = find_protein(row_off, B, row0), p_hi = next_group_protein(row_off, B, p_lo, row0);
     if (p_lo == p_hi)
-        cmap_rows_body<MODE, true>(coords, coord_off, Lq_arr, row_off, q2t, thr2, gen, counts, group_sum, masks, W, dense_out, dense_off, p_lo, p_hi, s_col_all, s_cnt);
+        cmap_rows_body<MODE, true>(coords, coord_off, Lq_arr, row_off, q2t, thr2, gen, counts, group_sum, masks, W, dense_out, dense_off, p_lo, p_hi, s_col_all, s_cnt, os);
     else
-        cmap_rows_body<MODE, false>(coords, coord_off, Lq_arr, row_off, q2t, thr2, gen, counts, group_sum, masks, W, dense_out, dense_off, p_lo, p_hi, s_col_all, s_cnt);
+        cmap_rows_body<MODE, false>(coords, coord_off, Lq_arr, row_off, q2t, thr2, gen, counts, group_sum, masks, W, dense_out, dense_off, p_lo, p_hi, s_col_all, s_cnt, os);
 }
 
 // Exclusive scan of the per-group nnz (int32) with one block of up to 1024 threads (launched with 256: four waves of 36 VGPRs
@@ -985,7 +988,7 @@ int mdf_align_contact_map(const char *q_aln, const char *t_aln, int64_t La, cons
     int32_t *d_q2t = reinterpret_cast<int32_t *>(b + o_q2t), *d_t2q = reinterpret_cast<int32_t *>(b + o_t2q);
     int32_t *d_out = reinterpret_cast<int32_t *>(b + o_out);
     hipLaunchKernelGGL(k_align_scan, dim3(1), dim3(256), 0, 0, b + o_q, b + o_t, d_meta, d_meta + 2, d_q2t, d_t2q,
-                       d_meta + 4, d_meta + 5);
+                       d_meta + 4, d_meta + 5, 1);
     const int64_t elems = Lq * Lq;
     hipLaunchKernelGGL(k_align_init, dim3((unsigned)std::min<int64_t>((elems + 255) / 256, 8192)), dim3(256), 0, 0, d_q2t,
                        (int)Lq, generated_contacts, d_out);
@@ -1005,7 +1008,18 @@ int mdf_cmap_csr_dev(const float *coords, const int32_t *coord_off, const char *
                      int64_t nnz_cap, int32_t *status, const uint8_t *seq_idx, float *letter_sums, void *workspace,
                      size_t workspace_bytes, void *stream)
 {
+    return mdf_cmap_csr_pairs_dev(coords, coord_off, q_aln, t_aln, aln_off, 1, Lq, row_off, B, R, max_len, threshold, generated_contacts, rowptr, colidx, val,
+                                  nnz_cap, status, seq_idx, letter_sums, workspace, workspace_bytes, stream);
+}
+
+int mdf_cmap_csr_pairs_dev(const float *coords, const int32_t *coord_off, const char *q_aln, const char *t_aln,
+                           const int32_t *aln_off, int32_t off_stride, const int32_t *Lq, const int32_t *row_off, int32_t B, int64_t R, int32_t max_len,
+                           double threshold, int generated_contacts, int32_t *rowptr, int32_t *colidx, float *val,
+                           int64_t nnz_cap, int32_t *status, const uint8_t *seq_idx, float *letter_sums, void *workspace,
+                           size_t workspace_bytes, void *stream)
+{
     if (int rc = check_layout(B, R)) return rc;
+    MDF_REQUIRE(off_stride == 1 || off_stride == 2, "cmap_csr_dev: off_stride must be 1 (offsets) or 2 (begin / end pairs)");
     MDF_REQUIRE(coords && coord_off && q_aln && t_aln && aln_off && Lq && row_off && rowptr && colidx && val && status && workspace,
                 "cmap_csr_dev: NULL argument");
     MDF_REQUIRE(nnz_cap > 0 && nnz_cap < 0x7fffffff, "cmap_csr_dev: nnz_cap out of range");
@@ -1019,10 +1033,10 @@ int mdf_cmap_csr_dev(const float *coords, const int32_t *coord_off, const char *
     const float t2 = thr2_f32(threshold);
     ScopedTiming tm(TK_CMAP, st);
     hipLaunchKernelGGL(k_align_scan, dim3(B), dim3(256), 0, st, q_aln, t_aln, aln_off, row_off, w.q2t, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (int32_t *)nullptr);
+                       (int32_t *)nullptr, (int32_t *)nullptr, (int)off_stride);
     // ONE pass over the coordinates: row counts + the contact bits themselves ...
     hipLaunchKernelGGL(k_cmap_rows<CM_COUNT>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t, t2,
-                       generated_contacts, w.counts, w.group_sum, w.masks, W, (int32_t *)nullptr, (const int64_t *)nullptr);
+                       generated_contacts, w.counts, w.group_sum, w.masks, W, (int32_t *)nullptr, (const int64_t *)nullptr, (int)off_stride);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
     // ... then the CSR (and the layer-1 letter sums) from the bits
     const int cols_cap = std::min((max_len + 63) / 64 * 64, CMAP_FILL_COLS);
@@ -1047,10 +1061,10 @@ int mdf_cmap_dense_dev(const float *coords, const int32_t *coord_off, const char
     const int G = (int)(R / 32);
     ScopedTiming tm(TK_CMAP, st);
     hipLaunchKernelGGL(k_align_scan, dim3(B), dim3(256), 0, st, q_aln, t_aln, aln_off, row_off, w.q2t, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (int32_t *)nullptr);
+                       (int32_t *)nullptr, (int32_t *)nullptr, 1);
     hipLaunchKernelGGL(k_cmap_rows<CM_DENSE>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t,
                        thr2_f32(threshold), generated_contacts, (int32_t *)nullptr, (int32_t *)nullptr, (unsigned long long *)nullptr, 0, out,
-                       out_off);
+                       out_off, 1);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }

@@ -53,13 +53,14 @@ struct mdf_plan {
     uint64_t serial = 0;
     int32_t B = 0, max_rows = 0, max_segment_groups = 0, max_len = 0;
     int64_t max_chunk_rows = 0, max_groups = 0;
-    std::vector<int32_t> Lq, chunk_row_off, grp_off, agg_plist;
+    std::vector<int32_t> Lq, chunk_row_off, grp_off, agg_plist;   // Lq: lengths in PLAN order
+    std::vector<int32_t> order;   // plan position -> index in the caller's batch; empty = the plan keeps the input order
     std::vector<PlanChunk> chunks;
     std::vector<PlanSegment> segments;
     // device mirror (created by the first engine call that uses the plan; one device per plan)
     mutable std::mutex mu;
     mutable int device = -1;
-    mutable int32_t *d_chunk_row_off = nullptr, *d_grp_off = nullptr, *d_agg_plist = nullptr;
+    mutable int32_t *d_chunk_row_off = nullptr, *d_grp_off = nullptr, *d_agg_plist = nullptr, *d_order = nullptr;
     // LSTM grouping, keyed by the engine parameters it depends on
     mutable int64_t lm_key[3] = {-1, -1, -1};
     mutable std::vector<LmGroup> lm_groups;
@@ -111,17 +112,38 @@ static void close_segment(mdf_plan *pl, const std::vector<int> &ids, int64_t gro
 
 extern "C" int mdf_plan_create(const int32_t *Lq, int32_t B, int32_t max_rows, int32_t max_segment_groups, mdf_plan **out)
 {
-    MDF_REQUIRE(Lq && out, "plan_create: NULL argument");
+    return mdf_plan_create_ex(Lq, B, max_rows, max_segment_groups, 0u, out);
+}
+
+extern "C" const int32_t *mdf_plan_order(const mdf_plan *pl, int64_t *count)
+{
+    if (count) *count = pl ? (int64_t)pl->order.size() : 0;
+    return pl && !pl->order.empty() ? pl->order.data() : nullptr;
+}
+
+extern "C" int mdf_plan_create_ex(const int32_t *Lq_in, int32_t B, int32_t max_rows, int32_t max_segment_groups, uint32_t flags, mdf_plan **out)
+{
+    MDF_REQUIRE(Lq_in && out, "plan_create: NULL argument");
     MDF_REQUIRE(B > 0, "plan_create: empty batch");
     if (max_rows <= 0) max_rows = 65536;
     if (max_segment_groups <= 0) max_segment_groups = 1 << 20;
-    for (int32_t p = 0; p < B; ++p) MDF_REQUIRE(Lq[p] > 0, "plan_create: empty sequence in batch (protein %d)", p);
+    for (int32_t p = 0; p < B; ++p) MDF_REQUIRE(Lq_in[p] > 0, "plan_create: empty sequence in batch (protein %d)", p);
     auto *pl = new mdf_plan();
     pl->serial = g_plan_serial.fetch_add(1);
     pl->B = B;
     pl->max_rows = max_rows;
     pl->max_segment_groups = max_segment_groups;
-    pl->Lq.assign(Lq, Lq + B);
+    pl->Lq.assign(Lq_in, Lq_in + B);
+    // visit the proteins shortest first (the reference sorts its work list by length, pipeline.py:529-533): proteins of like length share
+    // chunks, and every chunk then holds few aggregation classes.  Stable, so equal lengths keep their input order; a batch that arrives
+    // sorted keeps the identity (no order array, nothing permuted anywhere).
+    if (!(flags & MDF_PLAN_KEEP_ORDER) && !std::is_sorted(Lq_in, Lq_in + B)) {
+        pl->order.resize((size_t)B);
+        for (int32_t p = 0; p < B; ++p) pl->order[(size_t)p] = p;
+        std::stable_sort(pl->order.begin(), pl->order.end(), [&](int32_t a, int32_t b2) { return Lq_in[a] < Lq_in[b2]; });
+        for (int32_t p = 0; p < B; ++p) pl->Lq[(size_t)p] = Lq_in[pl->order[(size_t)p]];
+    }
+    const int32_t *Lq = pl->Lq.data();
     int32_t p0 = 0;
     while (p0 < B) {
         int32_t p1 = p0, ml = 0;
@@ -276,20 +298,22 @@ static int plan_mirror(const mdf_plan *pl, int device, hipStream_t st)
         pl->d_lm_rows = nullptr;
         pl->lm_key[0] = -1;
     }
-    const size_t n1 = pl->chunk_row_off.size(), n2 = pl->grp_off.size(), n3 = pl->agg_plist.size();
+    const size_t n1 = pl->chunk_row_off.size(), n2 = pl->grp_off.size(), n3 = pl->agg_plist.size(), n4 = pl->order.size();
     int32_t *d = nullptr;
-    MDF_HIP(plan_alloc(reinterpret_cast<void **>(&d), (n1 + n2 + n3) * 4 + 256, st));
+    MDF_HIP(plan_alloc(reinterpret_cast<void **>(&d), (n1 + n2 + n3 + n4) * 4 + 256, st));
     // the sources are the plan's own vectors (pageable: the runtime stages them before it returns); the copies sit in the stream in
     // front of the kernels that read the mirror
     if (hipMemcpyAsync(d, pl->chunk_row_off.data(), n1 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
         hipMemcpyAsync(d + n1, pl->grp_off.data(), n2 * 4, hipMemcpyHostToDevice, st) != hipSuccess ||
-        (n3 && hipMemcpyAsync(d + n1 + n2, pl->agg_plist.data(), n3 * 4, hipMemcpyHostToDevice, st) != hipSuccess)) {
+        (n3 && hipMemcpyAsync(d + n1 + n2, pl->agg_plist.data(), n3 * 4, hipMemcpyHostToDevice, st) != hipSuccess) ||
+        (n4 && hipMemcpyAsync(d + n1 + n2 + n3, pl->order.data(), n4 * 4, hipMemcpyHostToDevice, st) != hipSuccess)) {
         plan_release(d, st);
         return fail(MDF_ENODEVICE, "plan: upload of the descriptor arrays failed");
     }
     pl->d_chunk_row_off = d;
     pl->d_grp_off = d + n1;
     pl->d_agg_plist = d + n1 + n2;
+    pl->d_order = n4 ? d + n1 + n2 + n3 : nullptr;
     pl->device = device;
     return MDF_OK;
 }
@@ -403,6 +427,61 @@ struct DevBuf {
     T *as() const { return static_cast<T *>(p); }
 };
 
+// ---- plans that visit the proteins in another order than the batch stores them (mdf_plan_create: shortest first) ---------------------------
+// The batch stays as the caller packed it; the engine derives descriptor arrays in PLAN order from it -- starts of the sequences, lengths,
+// and (begin, end) pairs into the packed coordinates / alignments, which the contact stage reads with an offset stride of 2
+// (mdf_cmap_csr_pairs_dev) -- and puts the pooled feature rows back into the caller's order in front of the GO heads, so scores, logits and
+// every report are in input order.
+__global__ void k_plan_order_desc(const int32_t *__restrict__ order, int B, const int32_t *__restrict__ seq_off, const int32_t *__restrict__ Lq,
+                                  const int32_t *__restrict__ coord_off, const int32_t *__restrict__ aln_off, int32_t *__restrict__ seq_start,
+                                  int32_t *__restrict__ Lq_o, int32_t *__restrict__ coord_pair, int32_t *__restrict__ aln_pair)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= B) return;
+    const int src = order[p];
+    seq_start[p] = seq_off[src];
+    Lq_o[p] = Lq[src];
+    if (coord_off) coord_pair[2 * p] = coord_off[src], coord_pair[2 * p + 1] = coord_off[src + 1];
+    if (aln_off) aln_pair[2 * p] = aln_off[src], aln_pair[2 * p + 1] = aln_off[src + 1];
+}
+// dst[order[p]] = src[p], rows of `width` floats (float4 lanes)
+__global__ __launch_bounds__(256) void k_rows_to_input_order(const float *__restrict__ src, float *__restrict__ dst, const int32_t *__restrict__ order, int width4)
+{
+    const float4 *s = reinterpret_cast<const float4 *>(src) + (size_t)blockIdx.x * width4;
+    float4 *d = reinterpret_cast<float4 *>(dst) + (size_t)order[blockIdx.x] * width4;
+    for (int c = threadIdx.x; c < width4; c += 256) d[c] = s[c];
+}
+static inline int plan_stride(const mdf_plan *pl) { return pl->order.empty() ? 1 : 2; }
+// *view = the batch as the plan visits it (the caller's own descriptor when the plan keeps the input order)
+static int batch_in_plan_order(DevBuf &perm, uint64_t *generation, const mdf_plan *pl, const mdf_batch_dev *b, hipStream_t st, mdf_batch_dev *view)
+{
+    *view = *b;
+    if (pl->order.empty()) return MDF_OK;
+    const size_t B = (size_t)pl->B;
+    if (int rc = perm.grow(B * 6 * 4, generation)) return rc;
+    int32_t *d = perm.as<int32_t>();
+    hipLaunchKernelGGL(k_plan_order_desc, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, st, pl->d_order, (int)B, b->seq_off, b->Lq, b->coord_off, b->aln_off, d,
+                       d + B, d + 2 * B, d + 4 * B);
+    MDF_HIP(hipGetLastError());
+    view->seq_off = d;
+    view->Lq = d + B;
+    if (b->coord_off) view->coord_off = d + 2 * B;
+    if (b->aln_off) view->aln_off = d + 4 * B;
+    return MDF_OK;
+}
+// pooled feature rows (plan order) -> the caller's order, into `scratch`; *out = where the GO head reads them
+static int rows_to_input_order(const mdf_plan *pl, const DevBuf &rows, DevBuf &scratch, uint64_t *generation, size_t width, hipStream_t st, const float **out)
+{
+    *out = rows.as<float>();
+    if (pl->order.empty()) return MDF_OK;
+    MDF_REQUIRE(width % 4 == 0, "engine: feature rows of %zu floats", width);
+    if (int rc = scratch.grow((size_t)pl->B * width * 4, generation)) return rc;
+    hipLaunchKernelGGL(k_rows_to_input_order, dim3((unsigned)pl->B), dim3(256), 0, st, rows.as<float>(), scratch.as<float>(), pl->d_order, (int)(width / 4));
+    MDF_HIP(hipGetLastError());
+    *out = scratch.as<float>();
+    return MDF_OK;
+}
+
 struct GraphEntry {
     std::vector<uint64_t> key;
     int seen = 0;            // calls with this key so far
@@ -441,6 +520,7 @@ struct mdf_engine {
     hipStream_t sg = nullptr, sx = nullptr;
     hipEvent_t ev_stage[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}}, ev_join[2] = {nullptr, nullptr};
     DevBuf gws2;                      // the second stack's slabs
+    DevBuf perm, pool_scratch;        // plans that order the batch: descriptors in plan order; the pooled rows on their way back to input order
     int last_set = 0;
     DevBuf gws, hws, seq_all, lm_ws, host_in, host_scores, map_dev[2], flags;
     std::vector<DevBuf> partial, pooled, lm_h;
@@ -585,6 +665,8 @@ extern "C" void mdf_engine_free(mdf_engine *e)
         if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
     }
     e->gws2.release();
+    e->perm.release();
+    e->pool_scratch.release();
     if (e->map_stream) (void)hipStreamDestroy(e->map_stream);
     for (DevBuf *b : {&e->gws, &e->hws, &e->seq_all, &e->lm_ws, &e->host_in, &e->host_scores, &e->map_dev[0], &e->map_dev[1], &e->flags}) b->release();
     for (auto &b : e->partial) b.release();
@@ -819,12 +901,18 @@ static int run_chunks(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b,
     return MDF_OK;
 }
 
-static int run_heads(mdf_engine *e, int32_t B, float *const *scores, float *const *logits, hipStream_t st)
+static int run_heads(mdf_engine *e, const mdf_plan *pl, float *const *scores, float *const *logits, hipStream_t st)
 {
+    // the scratch of an ordered plan is sized once, for the widest head (growing it between two heads would free what the first still reads)
+    size_t wmax = 0;
+    for (mdf_model *m : e->models) wmax = std::max(wmax, (size_t)mdf_model_feature_dim(m));
+    if (!pl->order.empty())
+        if (int rc = e->pool_scratch.grow((size_t)pl->B * wmax * 4, &e->generation)) return rc;
     for (size_t k = 0; k < e->models.size(); ++k) {
         MDF_REQUIRE(scores[k], "engine: scores[%zu] is NULL", k);
-        if (int rc = mdf_gcn_head_dev(e->models[k], e->pooled[k].as<float>(), B, scores[k], logits ? logits[k] : nullptr, e->hws.p, e->hws.bytes, st))
-            return rc;
+        const float *pooled = nullptr;   // rows in the CALLER's order: scores, logits and everything behind them need no further mapping
+        if (int rc = rows_to_input_order(pl, e->pooled[k], e->pool_scratch, &e->generation, (size_t)mdf_model_feature_dim(e->models[k]), st, &pooled)) return rc;
+        if (int rc = mdf_gcn_head_dev(e->models[k], pooled, pl->B, scores[k], logits ? logits[k] : nullptr, e->hws.p, e->hws.bytes, st)) return rc;
     }
     return MDF_OK;
 }
@@ -835,7 +923,8 @@ static int contact_chunk(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev 
 {
     const PlanChunk &ch = pl->chunks[(size_t)ci];
     if (int rc = encode_chunk(e, pl, b, ci, c.seq_idx.as<uint8_t>(), st)) return rc;
-    return mdf_cmap_csr_dev(b->coords, b->coord_off + ch.p0, b->q_aln, b->t_aln, b->aln_off + ch.p0, b->Lq + ch.p0, pl->d_chunk_row_off + ch.row_off_pos,
+    const int os = plan_stride(pl);
+    return mdf_cmap_csr_pairs_dev(b->coords, b->coord_off + os * ch.p0, b->q_aln, b->t_aln, b->aln_off + os * ch.p0, os, b->Lq + ch.p0, pl->d_chunk_row_off + ch.row_off_pos,
                             ch.p1 - ch.p0, ch.rows, ch.max_len, e->cfg.threshold, e->cfg.generated_contacts, c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(),
                             c.val.as<float>(), e->nnz_cap, b->status + 4 * ci, e->want_lsum ? c.seq_idx.as<uint8_t>() : nullptr,
                             e->want_lsum ? c.lsum.as<float>() : nullptr, c.cws.p, c.cws.bytes, st);
@@ -924,7 +1013,7 @@ static int forward_alignments_split(mdf_engine *e, const mdf_plan *pl, const mdf
     }
     e->last_rows = pl->chunks[(size_t)nC - 1].rows;
     e->last_set = (nC - 1) & 1;
-    if (int rc = run_heads(e, pl->B, scores, logits, sg)) return rc;
+    if (int rc = run_heads(e, pl, scores, logits, sg)) return rc;
     // join: the caller's stream continues behind both (scores from sg, validation flags from sx)
     if (int rc = sx_into_sg()) return rc;
     MDF_HIP(hipEventRecord(e->ev_join[1], sg));
@@ -932,9 +1021,12 @@ static int forward_alignments_split(mdf_engine *e, const mdf_plan *pl, const mdf
     return MDF_OK;
 }
 
-static int forward_alignments_eager(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, float *const *scores, float *const *logits,
+static int forward_alignments_eager(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b_in, float *const *scores, float *const *logits,
                                     hipStream_t st, bool capturing = false)
 {
+    mdf_batch_dev view;   // the batch in the plan's order (the caller's own descriptor when the plan keeps the input order)
+    if (int rc = batch_in_plan_order(e->perm, &e->generation, pl, b_in, st, &view)) return rc;
+    const mdf_batch_dev *b = &view;
     if (e->split_cus && !capturing && e->lms.empty()) return forward_alignments_split(e, pl, b, scores, logits, st);
     if (!e->pipeline_contact) {
         BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *seq_ptr, bool *have_lsum, bool *bits, const AggOverride **) -> int {
@@ -942,13 +1034,14 @@ static int forward_alignments_eager(mdf_engine *e, const mdf_plan *pl, const mdf
             *have_lsum = e->want_lsum;
             *bits = true;
             mdf_engine::ContactSet &c = e->cs[0];
-            return mdf_cmap_csr_dev(b->coords, b->coord_off + ch.p0, b->q_aln, b->t_aln, b->aln_off + ch.p0, b->Lq + ch.p0,
+            const int os = plan_stride(pl);
+            return mdf_cmap_csr_pairs_dev(b->coords, b->coord_off + os * ch.p0, b->q_aln, b->t_aln, b->aln_off + os * ch.p0, os, b->Lq + ch.p0,
                                     pl->d_chunk_row_off + ch.row_off_pos, ch.p1 - ch.p0, ch.rows, ch.max_len, e->cfg.threshold, e->cfg.generated_contacts,
                                     c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), e->nnz_cap, b->status + 4 * ci,
                                     e->want_lsum ? seq_ptr : nullptr, e->want_lsum ? c.lsum.as<float>() : nullptr, c.cws.p, c.cws.bytes, st);
         };
         if (int rc = run_chunks(e, pl, b, build, st)) return rc;
-        return run_heads(e, pl->B, scores, logits, st);
+        return run_heads(e, pl, scores, logits, st);
     }
     // Pipelined form (no language model): the contact stage of chunk c+1 runs on a second, low-priority stream while the GraphConv
     // stacks of chunk c hold the matrix pipe.  Its kernels are small and compute/latency-bound (27-60 VGPRs, next to nothing in
@@ -979,7 +1072,7 @@ static int forward_alignments_eager(mdf_engine *e, const mdf_plan *pl, const mdf
             if (int rc = pool_segment(e, pl, pl->segments[(size_t)ch.segment], st)) return rc;
         MDF_HIP(hipEventRecord(cur.free, st));
     }
-    return run_heads(e, pl->B, scores, logits, st);
+    return run_heads(e, pl, scores, logits, st);
 }
 
 // ---- hipGraph replay of short launch sequences ------------------------------------------------------------------------
@@ -1151,6 +1244,10 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         MDF_HIP(hipStreamCreateWithPriority(&e->map_stream, hipStreamNonBlocking, hi));
     }
     if (int rc = e->flags.grow((size_t)pl->B * 4, &e->generation)) return rc;   // per-protein "binary" flags the dense stage writes on the device (the host lists decide here)
+    mdf_batch_dev view;   // the batch in the plan's order; the host maps are looked up through the same order
+    if (int rc = batch_in_plan_order(e->perm, &e->generation, pl, b, st, &view)) return rc;
+    b = &view;
+    auto map_of = [&](int32_t p) { return cmaps_host[pl->order.empty() ? (size_t)p : (size_t)pl->order[(size_t)p]]; };
     int parity = 0, pending = -1;   // pending: the slot of the chunk whose GraphConv launches have been issued but whose event is not recorded yet
     bool used[2] = {false, false};
     AggOverride aov;
@@ -1202,7 +1299,7 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
             for (int32_t p = ch.p0 + k; p < ch.p1; p += nt) {
                 const size_t Lp = (size_t)pl->Lq[(size_t)p], n = Lp * Lp;
                 char *to = dst + (size_t)offs[p - ch.p0] * 4;
-                memcpy(to, cmaps_host[p], n * 4);
+                memcpy(to, map_of(p), n * 4);
                 const uint32_t *w = reinterpret_cast<const uint32_t *>(to);
                 uint32_t odd = 0;
                 if (cmap_dtype == MDF_DT_I32) {
@@ -1284,7 +1381,7 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
     };
     ++e->eager_runs;
     if (int rc = run_chunks(e, pl, b, build, st)) return rc;
-    if (int rc = run_heads(e, pl->B, scores, logits, st)) return rc;
+    if (int rc = run_heads(e, pl, scores, logits, st)) return rc;
     MDF_HIP(hipStreamSynchronize(st));
     return MDF_OK;
 }
@@ -1303,7 +1400,28 @@ static int check_locked(const mdf_engine *e, const mdf_plan *pl, const mdf_batch
     // reference's serial loop would have hit first (predict.pyx:36-46)
     for (size_t ci = 0; ci < nC; ++ci) {
         if (bad[ci] != -1) {
-            const int64_t p = pl->chunks[ci].p0 + (bad[ci] >> 32), pos = bad[ci] & 0xffffffffLL;
+            int64_t p = pl->chunks[ci].p0 + (bad[ci] >> 32), pos = bad[ci] & 0xffffffffLL;
+            if (!pl->order.empty()) {
+                // the plan visits the proteins shortest first, so the flags name the first invalid residue in THAT order; the report is the first one
+                // in the caller's order: look for it in the sequences themselves (error path only: one copy of the packed sequences back)
+                const size_t B = (size_t)pl->B;
+                std::vector<int32_t> soff(B + 1), lq(B);
+                MDF_HIP(hipMemcpyAsync(soff.data(), b->seq_off, (B + 1) * 4, hipMemcpyDeviceToHost, st));
+                MDF_HIP(hipMemcpyAsync(lq.data(), b->Lq, B * 4, hipMemcpyDeviceToHost, st));
+                MDF_HIP(hipStreamSynchronize(st));
+                std::vector<char> sq((size_t)std::max(soff[B], 1));
+                MDF_HIP(hipMemcpyAsync(sq.data(), b->seqs, (size_t)soff[B], hipMemcpyDeviceToHost, st));
+                MDF_HIP(hipStreamSynchronize(st));
+                bool ok[256] = {false};
+                for (const char *a = "-DGULNTKHYWCPVSOIEFXQABZRM"; *a; ++a) ok[(unsigned char)*a] = true;   // the residue alphabet of predict.pyx:26
+                p = pl->order[(size_t)p];
+                for (size_t q = 0, found = 0; q < B && !found; ++q)
+                    for (int32_t i = 0; i < lq[q]; ++i)
+                        if (!ok[(unsigned char)sq[(size_t)soff[q] + (size_t)i]]) {
+                            p = (int64_t)q, pos = i, found = 1;
+                            break;
+                        }
+            }
             if (info) info[0] = p, info[1] = pos;
             return fail(MDF_EBADCHAR, "Invalid character in sequence: protein %lld, position %lld", (long long)p, (long long)pos);
         }
@@ -1341,7 +1459,7 @@ extern "C" int mdf_engine_check(mdf_engine *e, const mdf_plan *pl, const mdf_bat
 struct mdf_seq_engine {
     int device = 0;
     std::vector<mdf_cnn *> models;
-    DevBuf seq_idx, ws;
+    DevBuf seq_idx, ws, perm, pool_scratch;
     std::vector<DevBuf> pooled;
     std::mutex mu;
 };
@@ -1371,6 +1489,8 @@ extern "C" void mdf_seq_engine_free(mdf_seq_engine *e)
     (void)hipDeviceSynchronize();
     e->seq_idx.release();
     e->ws.release();
+    e->perm.release();
+    e->pool_scratch.release();
     for (auto &b : e->pooled) b.release();
     delete e;
 }
@@ -1385,6 +1505,9 @@ extern "C" int mdf_seq_engine_forward(mdf_seq_engine *e, const mdf_plan *pl, con
     MDF_HIP(g.err);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (int rc = plan_mirror(pl, e->device, st)) return rc;
+    mdf_batch_dev view;   // the batch in the plan's order
+    if (int rc = batch_in_plan_order(e->perm, nullptr, pl, b, st, &view)) return rc;
+    b = &view;
     const int64_t rows = pl->max_chunk_rows;
     if (int rc = e->seq_idx.grow((size_t)rows, nullptr)) return rc;
     if (int rc = e->ws.grow((size_t)(rows / GROUP_ROWS + 2) * 4 + 512, nullptr)) return rc;
@@ -1403,9 +1526,15 @@ extern "C" int mdf_seq_engine_forward(mdf_seq_engine *e, const mdf_plan *pl, con
                                           e->pooled[k].as<float>() + (size_t)ch.p0 * (size_t)cpad[k], e->ws.p, e->ws.bytes, st))
                 return rc;
     }
+    size_t wmax = 0;
+    for (int c : cpad) wmax = std::max(wmax, (size_t)c);
+    if (!pl->order.empty())
+        if (int rc = e->pool_scratch.grow((size_t)pl->B * wmax * 4, nullptr)) return rc;
     for (size_t k = 0; k < e->models.size(); ++k) {
         MDF_REQUIRE(scores[k], "seq_engine_forward: scores[%zu] is NULL", k);
-        if (int rc = mdf_cnn_head_dev(e->models[k], e->pooled[k].as<float>(), pl->B, scores[k], st)) return rc;
+        const float *pooled = nullptr;   // the pooled rows in the caller's order
+        if (int rc = rows_to_input_order(pl, e->pooled[k], e->pool_scratch, nullptr, (size_t)cpad[k], st, &pooled)) return rc;
+        if (int rc = mdf_cnn_head_dev(e->models[k], pooled, pl->B, scores[k], st)) return rc;
     }
     return MDF_OK;
 }
@@ -1433,8 +1562,18 @@ extern "C" int mdf_engine_lm_features_host(mdf_engine *e, const mdf_plan *pl, co
     mdf_lm *lm = e->lms[(size_t)which];
     const size_t H = (size_t)mdf_lm_hidden(lm);
     std::vector<float> host;
+    mdf_batch_dev view;   // the batch in the plan's order
+    if (int rc = batch_in_plan_order(e->perm, &e->generation, pl, b, st, &view)) return rc;
+    b = &view;
+    // the output is packed in the CALLER's order: position of plan entry p = offset of input protein order[p]
     std::vector<size_t> out_pos((size_t)pl->B + 1, 0);
-    for (int32_t p = 0; p < pl->B; ++p) out_pos[(size_t)p + 1] = out_pos[(size_t)p] + (size_t)pl->Lq[(size_t)p] * H;
+    {
+        std::vector<size_t> len_in((size_t)pl->B);
+        for (int32_t p = 0; p < pl->B; ++p) len_in[pl->order.empty() ? (size_t)p : (size_t)pl->order[(size_t)p]] = (size_t)pl->Lq[(size_t)p];
+        std::vector<size_t> start_in((size_t)pl->B + 1, 0);
+        for (int32_t q = 0; q < pl->B; ++q) start_in[(size_t)q + 1] = start_in[(size_t)q] + len_in[(size_t)q] * H;
+        for (int32_t p = 0; p < pl->B; ++p) out_pos[(size_t)p] = start_in[pl->order.empty() ? (size_t)p : (size_t)pl->order[(size_t)p]];
+    }
     for (const LmGroup &grp : pl->lm_groups) {
         const int64_t rows = grp.bases.back();
         if (int rc = e->seq_all.grow((size_t)rows, &e->generation)) return rc;

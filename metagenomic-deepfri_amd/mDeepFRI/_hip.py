@@ -8,12 +8,13 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint8, c_uint32, c_void_p
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MDFRI_HIP_LIB", os.path.join(os.path.dirname(_PKG_DIR), "lib", "libmdfri_hip.so"))
 
 MDF_OK, MDF_EINVAL, MDF_ENODEVICE, MDF_ENOMEM, MDF_EBADCHAR, MDF_ECAPACITY, MDF_EIO = 0, -1, -2, -3, -4, -5, -6
+MDF_PLAN_KEEP_ORDER = 1      # mdf_plan_create_ex flag: visit the proteins as given, not shortest first
 DT_I32, DT_F32, DT_I64, DT_F64, DT_U8 = 0, 1, 2, 3, 4
 
 
@@ -124,6 +125,9 @@ SIGNATURES = {
     "mdf_cmap_csr_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32,
                                  c_double, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                  c_void_p]),
+    "mdf_cmap_csr_pairs_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int64, c_int32,
+                                       c_double, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                       c_void_p]),
     "mdf_cmap_dense_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64,
                                    c_double, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdf_dense_to_csr_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p,
@@ -146,6 +150,8 @@ SIGNATURES = {
     "mdf_head_workspace_bytes": (c_size_t, [c_void_p, c_int32]),
     "mdf_gcn_head_dev": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "mdf_plan_create": (c_int, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
+    "mdf_plan_create_ex": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_uint32, POINTER(c_void_p)]),
+    "mdf_plan_order": (POINTER(c_int32), [c_void_p, _i64p]),
     "mdf_plan_free": (None, [c_void_p]),
     "mdf_plan_num_proteins": (c_int32, [c_void_p]),
     "mdf_plan_num_chunks": (c_int32, [c_void_p]),

@@ -74,14 +74,19 @@ class PackedProteins:
     chunk_row_off: np.ndarray | None = None
     segments: list = field(default_factory=list)
     grp_off: np.ndarray | None = None
+    order: np.ndarray | None = None    # plan position -> index in this batch (mdf_plan_order); None = the plan keeps the input order
 
     @property
     def B(self) -> int:
         return len(self.seqs)
 
     @classmethod
-    def pack(cls, seqs, coords=None, q_alns=None, t_alns=None, max_rows: int = 32768, max_segment_groups: int = 1 << 20):
-        """Host-side packing, vectorised: one join + one encode per column (a non-ASCII letter fails there, as `str.encode("ascii")`
+    def pack(cls, seqs, coords=None, q_alns=None, t_alns=None, max_rows: int = 32768, max_segment_groups: int = 1 << 20, keep_order: bool = False):
+        """keep_order=False (default): the library's plan VISITS the proteins shortest first (the reference sorts its work list by length,
+        pipeline.py:529-533; ~10 % on the GCN stage of a mixed-length batch that arrives unsorted); the packed arrays, the scores and every
+        report stay in the order given here -- only `chunks` / `segments` / `order` speak of plan positions.  keep_order=True: visited as given.
+
+        Host-side packing, vectorised: one join + one encode per column (a non-ASCII letter fails there, as `str.encode("ascii")`
         per sequence did), lengths by `map(len, ...)`, the "gapped query spells its sequence" check by one reduceat over the packed
         bytes -- no per-protein Python work besides `len` (the producer thread of mDeepFRI.stream packs batches while the GPU
         computes: at 22 us per protein the old loop, not the GPU, bounded the host-to-host rate)."""
@@ -117,7 +122,7 @@ class PackedProteins:
             if not np.array_equal(nongap, Lq):
                 i = int(np.argmax(nongap != Lq))
                 raise ValueError(f"protein {i}: gapped query does not spell a sequence of length {int(Lq[i])}")
-        pk._plan(max_rows, max_segment_groups)
+        pk._plan(max_rows, max_segment_groups, keep_order)
         return pk
 
     @classmethod
@@ -173,15 +178,19 @@ class PackedProteins:
         pk._plan(max_rows, max_segment_groups)
         return pk, keep
 
-    def _plan(self, max_rows: int, max_segment_groups: int = 1 << 20):
+    def _plan(self, max_rows: int, max_segment_groups: int = 1 << 20, keep_order: bool = False):
         """Chunks and pooling segments from the library's planner (mdf_plan_create, csrc/engine.hip): the Python objects below
         are a read-only view of its tables; the handle itself is what the engine entry points take."""
         import weakref
         L = _hip.lib()
         lq = np.ascontiguousarray(self.Lq, dtype=np.int32)
         h = ctypes.c_void_p()
-        _hip.check(L.mdf_plan_create(_hip.ptr(lq), len(lq), int(max_rows), int(max_segment_groups), ctypes.byref(h)))
+        _hip.check(L.mdf_plan_create_ex(_hip.ptr(lq), len(lq), int(max_rows), int(max_segment_groups), _hip.MDF_PLAN_KEEP_ORDER if keep_order else 0,
+                                        ctypes.byref(h)))
         self.plan = h
+        n_order = _hip.c_int64(0)
+        optr = L.mdf_plan_order(h, n_order)
+        self.order = np.ctypeslib.as_array(optr, shape=(n_order.value,)).copy() if n_order.value else None
         weakref.finalize(self, L.mdf_plan_free, h)
         nc, ns = L.mdf_plan_num_chunks(h), L.mdf_plan_num_segments(h)
         ct, stab = np.empty((nc, 6), dtype=np.int64), np.empty((ns, 4), dtype=np.int64)
@@ -236,13 +245,25 @@ class DeviceBatch:
         return self.packed.B
 
 
+_RESIDUES = np.zeros(256, dtype=bool)
+_RESIDUES[np.frombuffer(b"-DGULNTKHYWCPVSOIEFXQABZRM", dtype=np.uint8)] = True      # the alphabet of predict.pyx:26
+
+
 def first_invalid_residue(packed: PackedProteins, bad) -> None:
-    """Raise the reference's ValueError for the lowest (protein, position) flagged by mdf_seq_encode_dev, if any."""
-    for ci, ch in enumerate(packed.chunks):
-        key = int(bad[ci])
-        if key != -1:
-            p, pos = ch.p0 + (key >> 32), key & 0xffffffff
-            raise ValueError(f"Invalid character in sequence: {packed.seqs[p][pos]}")
+    """Raise the reference's ValueError for the first invalid residue of the batch IN THE ORDER IT WAS PACKED, if mdf_seq_encode_dev flagged
+    any (the flags are per chunk of the plan, which may visit the proteins shortest first: the sequences themselves say which one comes
+    first -- error path only)."""
+    if not (np.asarray(bad) != -1).any():
+        return
+    ok = _RESIDUES[packed.seq_bytes]
+    if ok.all():      # (flags without an invalid byte: cannot happen; keep the flag's own answer)
+        for ci, ch in enumerate(packed.chunks):
+            key = int(bad[ci])
+            if key != -1:
+                p = ch.p0 + (key >> 32)
+                p = int(packed.order[p]) if packed.order is not None else p
+                raise ValueError(f"Invalid character in sequence: {packed.seqs[p][key & 0xffffffff]}")
+    raise ValueError(f"Invalid character in sequence: {chr(int(packed.seq_bytes[int(np.argmin(ok))]))}")
 
 
 class HotPathEngine:
@@ -494,7 +515,7 @@ def build_align_contact_maps(alignments, threshold: float = 6, generated_contact
     live = [live[k] for k in nonempty]
     seqs = [seqs[k] for k in nonempty]
     pk = PackedProteins.pack(seqs, [alignments[i].coords for i in live], [alignments[i].gapped_sequence for i in live],
-                             [alignments[i].gapped_target for i in live], max_rows=max_rows)
+                             [alignments[i].gapped_target for i in live], max_rows=max_rows, keep_order=True)   # (the launches below index the batch by plan position)
     # Per chunk: one launch builds the dense maps on the device; they cross PCIe into one of two pinned buffers on a second,
     # high-priority stream while the next chunk is being built, and a few host threads cut the buffer into the freshly allocated
     # (Lq, Lq) arrays the reference hands out (1 MiB each at L = 512: the copies, not the kernels, are the cost of this format).

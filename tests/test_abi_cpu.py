@@ -125,10 +125,12 @@ def test_packing_and_chunk_plan():
     assert pk.B == 20 and pk.seq_off[-1] == sum(len(p["seq"]) for p in prots)
     assert pk.coord_off[-1] == sum(p["coords"].shape[0] for p in prots)
     covered = []
+    plan_lq = pk.Lq if pk.order is None else pk.Lq[pk.order]       # the plan visits the proteins shortest first: its tables speak of plan positions
+    assert np.all(np.diff(plan_lq) >= 0)
     for ch in pk.chunks:
         ro = pk.chunk_row_off[ch.row_off_pos:ch.row_off_pos + (ch.p1 - ch.p0) + 1]
         assert ro[0] == 0 and ro[-1] == ch.rows and ch.rows % 128 == 0 and np.all(ro[:-1] % 16 == 0)
-        assert np.all(np.diff(ro)[:-1] >= pk.Lq[ch.p0:ch.p1 - 1])
+        assert np.all(np.diff(ro)[:-1] >= plan_lq[ch.p0:ch.p1 - 1])
         assert ch.rows <= 1024 + 128 or ch.p1 - ch.p0 == 1
         covered += list(range(ch.p0, ch.p1))
     assert covered == list(range(20))
@@ -138,7 +140,7 @@ def test_packing_and_chunk_plan():
     for sg in pk2.segments:
         off = pk2.grp_off[sg.grp_off_pos:sg.grp_off_pos + (sg.p1 - sg.p0) + 1]
         assert off[0] == 0 and off[-1] == sg.groups and np.all(np.diff(off) > 0) and sg.groups <= 64
-        assert np.all(np.diff(off)[:-1] * 16 >= pk2.Lq[sg.p0:sg.p1 - 1])
+        assert np.all(np.diff(off)[:-1] * 16 >= (pk2.Lq if pk2.order is None else pk2.Lq[pk2.order])[sg.p0:sg.p1 - 1])
     assert sum(c.rows // 16 for c in pk2.chunks) == sum(s.groups for s in pk2.segments)
     with pytest.raises(ValueError, match="does not spell"):
         PackedProteins.pack(["ACD"], [prots[0]["coords"]], ["AC-"], ["ACD"])

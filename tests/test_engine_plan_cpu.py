@@ -45,14 +45,23 @@ def _reference_plan(Lq, max_rows, max_segment_groups):
     return chunks, segments, np.concatenate(row_off), np.concatenate(grp_off)
 
 
+@pytest.mark.parametrize("keep_order", [True, False])
 @pytest.mark.parametrize("seed", range(6))
-def test_planner_matches_the_layout_rules(seed):
+def test_planner_matches_the_layout_rules(seed, keep_order):
+    """keep_order: the proteins are visited as given; default: shortest first, stably (mdf_plan_order = the stable argsort of the lengths; the
+    packed arrays themselves stay in the caller's order), and the tables are those of the sorted lengths."""
     rng = np.random.default_rng(seed)
     n = int(rng.integers(1, 400))
     Lq = rng.integers(1, int(rng.choice([40, 300, 1100])), size=n)
     max_rows = int(rng.choice([128, 1024, 4096, 65536]))
     max_groups = int(rng.choice([8, 64, 1 << 20]))
-    pk = PackedProteins.pack(["A" * int(l) for l in Lq], max_rows=max_rows, max_segment_groups=max_groups)
+    pk = PackedProteins.pack(["A" * int(l) for l in Lq], max_rows=max_rows, max_segment_groups=max_groups, keep_order=keep_order)
+    assert np.array_equal(pk.Lq, Lq)                                   # the batch is packed as given either way
+    if keep_order or np.all(np.diff(Lq) >= 0):
+        assert pk.order is None
+    else:
+        assert np.array_equal(pk.order, np.argsort(Lq, kind="stable"))
+        Lq = Lq[pk.order]
     chunks, segments, row_off, grp_off = _reference_plan(Lq, max_rows, max_groups)
     assert [[c.p0, c.p1, c.rows, c.row_off_pos, c.segment, c.group_base] for c in pk.chunks] == chunks
     assert [[s.p0, s.p1, s.groups, s.grp_off_pos] for s in pk.segments] == segments

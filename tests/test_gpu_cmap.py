@@ -272,7 +272,7 @@ def test_other_thresholds_against_the_compiled_reference_goldens():
             assert np.array_equal(cm, out), n
         # the CSR of the fused path: every row's column set == the reference map's row
         pk = PackedProteins.pack([q.replace("-", "") for _, _, q, _, _ in cases], [c for _, c, _, _, _ in cases], [q for _, _, q, _, _ in cases],
-                                 [t for _, _, _, t, _ in cases], max_rows=65536)
+                                 [t for _, _, _, t, _ in cases], max_rows=65536, keep_order=True)   # (the stage is driven by hand below: plan position = batch position)
         assert len(pk.chunks) == 1
         db, R = DeviceBatch(pk, dev), pk.chunks[0].rows
         max_len, cap = int(pk.Lq.max()), R * 128

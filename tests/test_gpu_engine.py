@@ -232,7 +232,7 @@ def test_proteins_sharing_a_32_row_block_and_an_mfma_tile(heads):
     ws, preds = heads
     lengths = [5, 9, 16, 17, 3, 40, 1, 64, 31, 1, 15, 33, 2, 300, 16, 7]
     prots = [synthetic.synthetic_proteins(seed=700 + k, count=1, length=L, indel_rate=0.1 if L > 8 else 0.0)[0] for k, L in enumerate(lengths)]
-    pk = _pack(prots, max_rows=65536)
+    pk = _pack(prots, max_rows=65536, keep_order=True)                         # (visited as listed: the straddling is the point)
     ro = pk.chunk_row_off[:len(prots) + 1]
     assert np.all(ro[:-1] % 16 == 0) and np.any(ro[:-1] % 32 == 16)           # some proteins do start in the middle of a block
     eng = HotPathEngine(preds, device=0, max_rows=65536)
@@ -253,10 +253,14 @@ def test_proteins_sharing_a_32_row_block_and_an_mfma_tile(heads):
     for (_, got), want in zip(build_align_contact_maps(alns, device=0, max_rows=65536), maps):
         assert got.dtype == np.int32 and np.array_equal(got, want)
     # the dense-map path (k_dense_rows) on the same maps == the fused path, bitwise
-    db = eng.upload(_pack_seq_only(prots, max_rows=65536))
+    db = eng.upload(_pack_seq_only(prots, max_rows=65536, keep_order=True))
     dense = eng.forward_dense(db, maps)
     for m in eng.modes:
         assert np.array_equal(dense[m].cpu().numpy(), out[m]), m
+    # ... and with the plan visiting them shortest first (the default): the same bits, fused and dense
+    assert all(np.array_equal(eng.run_alignments(_pack(prots, max_rows=65536))[m], out[m]) for m in eng.modes)
+    dense = eng.forward_dense(eng.upload(_pack_seq_only(prots, max_rows=65536)), maps)
+    assert all(np.array_equal(dense[m].cpu().numpy(), out[m]) for m in eng.modes)
 
 
 def test_sequence_models_on_proteins_sharing_a_32_row_block():
@@ -285,9 +289,11 @@ def test_unsorted_batch_takes_the_skip_bitmap_gather(heads):
     lengths = [int(x) for x in rng.choice([40, 90, 130, 200, 256, 300, 420, 512, 530, 700, 1030], size=44)]
     prots = [synthetic.synthetic_proteins(seed=800 + k, count=1, length=L, indel_rate=0.04)[0] for k, L in enumerate(lengths)]
     eng = HotPathEngine(preds, device=0, max_rows=65536)
-    pk = _pack(prots, max_rows=65536)
+    pk = _pack(prots, max_rows=65536, keep_order=True)   # visited in arrival order (the default plan would sort them)
     assert len(pk.chunks) == 1                      # one chunk: every class and many gather segments side by side
     out = eng.run_alignments(pk)
+    by_plan = eng.run_alignments(_pack(prots, max_rows=65536))     # the default: the plan sorts, the rows come back in arrival order
+    assert all(np.array_equal(by_plan[m], out[m]) for m in eng.modes)
     order = np.argsort(lengths, kind="stable")
     out_sorted = eng.run_alignments(_pack([prots[i] for i in order], max_rows=65536))
     for m in eng.modes:
@@ -298,6 +304,51 @@ def test_unsorted_batch_takes_the_skip_bitmap_gather(heads):
         for m in eng.modes:
             assert np.array_equal(out[m][i], preds[m].forward_pass(p["seq"], cm)), (m, i, lengths[i])
             assert np.max(np.abs(out[m][i] - gcn_oracle.gcn_forward(ws[m], p["seq"], cm))) < TOL, (m, i)
+
+
+def test_every_batch_entry_sorts_inside_and_answers_in_input_order(heads):
+    """the planner visits a batch shortest first (pipeline.py:529-533 is the sort being matched), so a caller that hands the
+    engine a shuffled mixed-length batch gets the sorted-batch launch sequence -- and scores, logits, dense maps, language... every per-protein
+    array in ITS order.  A shuffled batch through HotPathEngine.run_alignments, the single-call C entry, the dense-map path and the sequence
+    engine: bit-identical to the same proteins visited as listed, and to the per-call API; the first invalid residue is the first one of the
+    input, whatever the plan's order."""
+    from mDeepFRI.batch import HotPathEngine, SequenceEngine
+    from mDeepFRI.predict import Predictor
+    ws, preds = heads
+    rng = np.random.default_rng(31)
+    lengths = [int(x) for x in rng.integers(20, 700, size=70)]
+    prots = [synthetic.synthetic_proteins(seed=1200 + k, count=1, length=L, indel_rate=0.04)[0] for k, L in enumerate(lengths)]
+    eng = HotPathEngine(preds, device=0, max_rows=4096)
+    pk = _pack(prots, max_rows=4096)
+    assert pk.order is not None and np.array_equal(pk.order, np.argsort(lengths, kind="stable")) and len(pk.chunks) >= 4
+    ref = eng.run_alignments(_pack(prots, max_rows=4096, keep_order=True))
+    out = eng.run_alignments(pk)
+    rc, outs, info = _run_host(eng.L, eng.handle, prots, [preds[m].n_terms for m in eng.modes])
+    assert rc == 0, _hip.last_error()
+    maps = [orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2) for p in prots]
+    dense = eng.forward_dense(eng.upload(_pack_seq_only(prots, max_rows=4096)), maps)
+    for m, host in zip(eng.modes, outs):
+        assert np.array_equal(out[m], ref[m]) and np.array_equal(host, ref[m]) and np.array_equal(dense[m].cpu().numpy(), ref[m]), m
+    for i in (0, 13, 69):
+        assert np.array_equal(out["mf"][i], preds["mf"].forward_pass(prots[i]["seq"], maps[i])), i
+    # the sequence engine (CNN heads) takes the same plans
+    wc = synthetic.glorot_cnn_weights(seed=4, n_terms=21)
+    pc = Predictor("synthetic-cnn", weights=wc)
+    seqs = [p["seq"] for p in prots]
+    sq = SequenceEngine({"c": pc}, device=0, max_rows=4096).run(seqs)["c"]
+    for i in (0, 13, 41, 69):
+        assert np.array_equal(sq[i], pc.forward_pass(seqs[i])), i
+    # first invalid residue: protein 9 (long) comes before protein 40 (short) in the input, after it in the plan
+    bad = [dict(p) for p in prots]
+    long_i, short_i = int(np.argmax(lengths[:30])), 30 + int(np.argmin(lengths[30:]))
+    for i, pos, c in ((long_i, 7, "J"), (short_i, 3, "*")):
+        s_ = bad[i]["seq"]
+        bad[i]["seq"] = s_[:pos] + c + s_[pos + 1:]
+        bad[i]["q_aln"] = bad[i]["t_aln"] = bad[i]["seq"]
+    rc, _, info = _run_host(eng.L, eng.handle, bad, [preds[m].n_terms for m in eng.modes])
+    assert rc == _hip.MDF_EBADCHAR and info[:2] == [long_i, 7]
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        eng.run_alignments(_pack(bad, max_rows=4096))
 
 
 def _layer1_form_script() -> str:
