@@ -345,6 +345,53 @@ class Ctx:
     pass
 
 
+class BoardSampler:
+    """Board power and shader clock of one GPU while the timed region runs, read by a thread of its own with `rocm-smi` (a process per
+    sample, every ~0.4 s: nothing touches the measured stream).  The H.W GEMM sits on the board's power limit (profiles/r05_gemm_overlap_probe.txt),
+    so the rate moves with the box: the line carries what THIS box held.  Missing tool / unparsable output: the fields are null."""
+
+    def __init__(self, device_index: int = 0):
+        import shutil
+        import threading
+        self.cmd = [shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi", "-d", str(device_index), "--showpower", "--showclocks", "--showmaxpower"]
+        self.power, self.sclk, self.cap = [], [], None
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                txt = subprocess.run(self.cmd, capture_output=True, text=True, timeout=5).stdout
+                m = re.search(r"(?:Current Socket|Average) Graphics Package Power \(W\):\s*([0-9.]+)", txt)
+                if m:
+                    self.power.append(float(m.group(1)))
+                m = re.search(r"sclk clock level:.*?\((\d+)Mhz\)", txt)
+                if m:
+                    self.sclk.append(int(m.group(1)))
+                m = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", txt)
+                if m:
+                    self.cap = float(m.group(1))
+            except Exception:
+                return
+            self._stop.wait(0.4)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._thread.join(timeout=10)
+
+    def summary(self):
+        def stat(v, nd):
+            return {"mean": round(sum(v) / len(v), nd), "min": round(min(v), nd), "max": round(max(v), nd), "samples": len(v)} if v else None
+        return {"board_power_w": stat(self.power, 1), "shader_clock_mhz": stat(self.sclk, 0), "power_cap_w": self.cap,
+                "how": "rocm-smi --showpower --showclocks sampled every ~0.4 s by a separate thread while warmup + timed steps run"}
+
+
 def timed_run(ctx, eng, db, steps, warmup, after=None, timing_period=7):
     """W warmup steps, then exactly K timed steps bracketed by barrier + synchronize; returns (seconds (max over ranks), last out,
     per-rank split).  The split comes from three events per step on the launch stream: forward issued -> forward done (`compute`)
@@ -641,7 +688,8 @@ def main():
         rank_info = {"world_size": 1, "backend": None, "devices": [me]}
 
     timing_period = 0 if args.no_kernel_timing else args.timing_period
-    elapsed, out, split = timed_run(ctx, eng, db, args.steps, args.warmup, after=after, timing_period=timing_period)
+    with BoardSampler(ctx.dev.index or 0) as board:
+        elapsed, out, split = timed_run(ctx, eng, db, args.steps, args.warmup, after=after, timing_period=timing_period)
 
     if strong:
         for m in MODES:
@@ -684,6 +732,7 @@ def main():
                        "parallelism": (f"shard{ctx.world}+gather" if ctx.world > 1 else "single"), "backend": args.backend if ctx.world > 1 else None},
             "roofline": roof,
             "roofline_ax": roof_ax,
+            "board": board.summary(),
             "kernels": kernels,
         }
         if kernels and not args.lm:

@@ -1207,9 +1207,7 @@ struct AggLayer1 {
     float *pool_partial = nullptr;
     int ldp = 0;
 };
-// PF (rows of the NEXT chunk requested before the matrix phase of the current one; only without L1 and at <= 2 row blocks per wave): a developer
-// A/B switch, MDFRI_AX_PF.
-template <int ROWBLOCKS, bool L1 = false, bool PF = false>
+template <int ROWBLOCKS, bool L1 = false>
 __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const unsigned long long *__restrict__ masks,
                                                                    int W, const float *__restrict__ dinv, const unsigned long long *__restrict__ blk,
                                                                    const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq,
@@ -1218,7 +1216,6 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
 {
     __shared__ __attribute__((aligned(16))) unsigned short xt[3 * AGG_SL * AGG_CHR];   // 48 KiB; re-used as 8 x 5 KiB output staging at the end
     __shared__ __attribute__((aligned(16))) unsigned short lut[256 * 8];                // contact byte -> its 8 bf16 (0.0 / 1.0): one ds_read_b128
-    __shared__ __attribute__((aligned(16))) float dsh[L1 ? AGG_CHR : 4];                  // L1: d_j of the chunk's rows
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int slabs = C / AGG_SL;
@@ -1241,56 +1238,25 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
 #pragma unroll
         for (int i = 0; i < 13; ++i) t1[i] = l1.T1[(size_t)(2 * i + half) * C + slab * AGG_SL + frow];
     }
-    // which 16-column blocks of the wave's row blocks hold a contact (all 64 column blocks of a row block in one word): once per kernel
-    unsigned long long bw[ROWBLOCKS];
-#pragma unroll
-    for (int b = 0; b < ROWBLOCKS; ++b) bw[b] = (b * 8 + wid) * 32 < L ? blk[(size_t)p * 32 + b * 8 + wid] : 0ull;
-    // The contact words of a chunk's 256 columns for the wave's row blocks are requested at the TOP of the chunk, together with the rows to
-    // stage (round 5: fetched inside the matrix phase, behind the block bitmap they depend on, they were two serial memory latencies per row
-    // block and chunk -- 60 % of a wave's life was spent parked, profiles/r05_ax_pmc.txt).  Four row blocks per wave would be 32 registers of
-    // them on the 128-register limit: there they stay where they were.
-    constexpr bool MW_AHEAD = ROWBLOCKS <= 2;
-    v2f rh[8];       // the requested rows (8 consecutive rows x 2 channels per lane) and their d_j, as they come from memory
-    v4f rd0, rd1;
     for (int j0 = 0; j0 < L; j0 += AGG_CHR) {
         // ---- requests of this chunk: the rows to stage (scaled by d_j), and the contact bits of its 256 columns for the wave's row blocks
         v2f x[8];
         f32x16 h1;
-        unsigned long long mwa[MW_AHEAD ? ROWBLOCKS : 1][4];
-        float dreg = 0.0f;   // L1: d_j of row j0 + thread of the chunk, handed to the lanes that split that row through LDS (one request per row, at the top)
-#define MDF_AGG_REQUEST_ROWS(j0r_)                                                                                               \
-        {                                                                                                                      \
-            const int jb = (j0r_) + oct * 8;                                                                                   \
-            rd0 = rd1 = (v4f){0, 0, 0, 0};                                                                                     \
-            if (jb < L) {   /* (a protein's rows are padded to a multiple of 16: dinv is readable up to jb + 7) */             \
-                rd0 = *reinterpret_cast<const v4f *>(dinv + r0 + jb);                                                          \
-                rd1 = *reinterpret_cast<const v4f *>(dinv + r0 + jb + 4);                                                      \
-            }                                                                                                                  \
-            _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                                    \
-                const int j = jb + k;                                                                                          \
-                rh[k] = j < L ? *reinterpret_cast<const v2f *>(Hs + (size_t)j * C + cp * 2) : (v2f){0, 0};                     \
-            }                                                                                                                  \
-        }
-#define MDF_AGG_REQUEST_WORDS                                                                                                   \
-        if (MW_AHEAD) {                                                                                                        \
-            _Pragma("unroll") for (int b = 0; b < ROWBLOCKS; ++b) {                                                            \
-                const int i = (b * 8 + wid) * 32 + frow;                                                                       \
-                const bool any = ((unsigned)(bw[b] >> (j0 >> 4)) & 0xffffu) != 0 && i < L;   /* (the block test is wave-uniform) */ \
-                const unsigned long long *mrow = masks + (size_t)(r0 + (i < L ? i : 0)) * W + (j0 >> 6);                       \
-                mwa[b][0] = any ? mrow[0] : 0ull;                                                                              \
-                mwa[b][1] = (any && j0 + 64 < L) ? mrow[1] : 0ull;                                                             \
-                mwa[b][2] = (any && j0 + 128 < L) ? mrow[2] : 0ull;                                                            \
-                mwa[b][3] = (any && j0 + 192 < L) ? mrow[3] : 0ull;                                                            \
-            }                                                                                                                  \
-        }
         if (!L1) {
-            MDF_AGG_REQUEST_WORDS
-            if (!PF || j0 == 0) { MDF_AGG_REQUEST_ROWS(j0) }
-            const float dd[8] = {rd0.x, rd0.y, rd0.z, rd0.w, rd1.x, rd1.y, rd1.z, rd1.w};
+            const int jb = j0 + oct * 8;
+            v4f d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
+            if (jb < L) {   // (a protein's rows are padded to a multiple of 16: dinv is readable up to jb + 7)
+                d0 = *reinterpret_cast<const v4f *>(dinv + r0 + jb);
+                d1 = *reinterpret_cast<const v4f *>(dinv + r0 + jb + 4);
+            }
+            const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x[k] = rh[k] * dd[k];
+            for (int k = 0; k < 8; ++k) {
+                const int j = jb + k;
+                const v2f h = j < L ? *reinterpret_cast<const v2f *>(Hs + (size_t)j * C + cp * 2) : (v2f){0, 0};
+                x[k] = h * dd[k];
+            }
         } else {
-            if (threadIdx.x < AGG_CHR) dreg = j0 + (int)threadIdx.x < Lpad ? dinv[r0 + j0 + threadIdx.x] : 0.0f;
             // the wave's 32-row tile of the chunk: H1 = elu(S . T1) for the slab's 32 channels, 13 matrix instructions of two letters each
             const int jt = j0 + wid * 32;            // first row of the tile (wave-uniform)
 #pragma unroll
@@ -1334,7 +1300,6 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
         }
         // (the contact bits of this chunk's 256 columns are fetched per row block inside the matrix phase: all row blocks' words at once
         // would be 8 registers per block -- the other workgroups of the CU cover the latency)
-        if (L1 && threadIdx.x < AGG_CHR) dsh[threadIdx.x] = dreg;   // (read by the previous chunk's split, which lies before that chunk's second barrier)
         __syncthreads();   // the previous chunk's fragments have been read (first chunk: the table is complete)
         if (!L1) {
 #pragma unroll
@@ -1353,14 +1318,15 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
                 *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(1, ch, oct)) = tm;
                 *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(2, ch, oct)) = tl;
             }
-            if (PF && j0 + AGG_CHR < L) { MDF_AGG_REQUEST_ROWS(j0 + AGG_CHR) }   // in flight under this chunk's matrix phase
         } else {
             // this lane's channel (frow), rows 8 g + 4 half .. + 3 of the wave's tile: half a 16-byte slot per term and g
             typedef short bf16x4 __attribute__((ext_vector_type(4)));
             const int jt = j0 + wid * 32;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const v4f d = *reinterpret_cast<const v4f *>(dsh + wid * 32 + 8 * g + 4 * half);
+                const int j = jt + 8 * g + 4 * half;
+                v4f d = {0, 0, 0, 0};
+                if (j < Lpad) d = *reinterpret_cast<const v4f *>(dinv + r0 + j);
                 bf16x4 th, tm, tl;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1374,7 +1340,6 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
                 *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(1, frow, wid * 4 + g) + 4 * half) = tm;
                 *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(2, frow, wid * 4 + g) + 4 * half) = tl;
             }
-            MDF_AGG_REQUEST_WORDS      // (here the tile's registers are free again; the requests are in flight while the wave waits at the barrier)
         }
         __syncthreads();
         // ---- every wave: its row blocks x the populated column blocks (16 rows of X each) of this chunk
@@ -1384,17 +1349,12 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
         for (int b = 0; b < ROWBLOCKS; ++b) {
             const int rb = b * 8 + wid;
             if (rb * 32 >= L) break;   // (wave-uniform)
-            unsigned nz = (unsigned)(bw[b] >> (j0 >> 4)) & 0xffffu;
+            unsigned nz = (unsigned)(blk[(size_t)p * 32 + rb] >> (j0 >> 4)) & 0xffffu;
             if (!nz) continue;
-            unsigned long long mw0, mw1, mw2, mw3;
-            if (MW_AHEAD) {
-                mw0 = mwa[b][0], mw1 = mwa[b][1], mw2 = mwa[b][2], mw3 = mwa[b][3];
-            } else {
-                const int i = rb * 32 + frow;
-                const unsigned long long *mrow = masks + (size_t)(r0 + i) * W + (j0 >> 6);
-                mw0 = i < L ? mrow[0] : 0ull, mw1 = (i < L && j0 + 64 < L) ? mrow[1] : 0ull;
-                mw2 = (i < L && j0 + 128 < L) ? mrow[2] : 0ull, mw3 = (i < L && j0 + 192 < L) ? mrow[3] : 0ull;
-            }
+            const int i = rb * 32 + frow;
+            const unsigned long long *mrow = masks + (size_t)(r0 + i) * W + (j0 >> 6);
+            const unsigned long long mw0 = i < L ? mrow[0] : 0ull, mw1 = (i < L && j0 + 64 < L) ? mrow[1] : 0ull,
+                                     mw2 = (i < L && j0 + 128 < L) ? mrow[2] : 0ull, mw3 = (i < L && j0 + 192 < L) ? mrow[3] : 0ull;
             while (nz) {
                 const int cb = __builtin_ctz(nz);
                 nz &= nz - 1;
@@ -1452,9 +1412,6 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
                 l1.pool_partial[(size_t)(tail_row0 / GROUP_ROWS + e / AGG_SL) * l1.ldp + slab * AGG_SL + (e % AGG_SL)] = 0.0f;
     }
 }
-
-#undef MDF_AGG_REQUEST_WORDS
-#undef MDF_AGG_REQUEST_ROWS
 
 // dinv[row] = 1 / (1e-6 + sqrt(degree)) for every row, and blk[p][b] = which 16-column blocks hold a contact of rows [32 b, 32 b + 32)
 // of protein p (proteins of at most MDF_AGG_MAX_LEN residues).  One wave per (protein, row block); grid.y = 32.
@@ -2001,14 +1958,12 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
     {   // one launch per length class (1, 2 or 4 row blocks per wave: the accumulators a workgroup carries)
         const unsigned slabs = (unsigned)(Cin / AGG_SL);
         const int32_t *pl = agg->plist;
-        static const int pf_env = getenv("MDFRI_AX_PF") ? atoi(getenv("MDFRI_AX_PF")) : 0;   // developer A/B knob
 #define MDF_AGG_ARGS(n_) dim3((unsigned)(n_) * slabs), dim3(AGG_THREADS), 0, st, Hin, Cin, reinterpret_cast<const unsigned long long *>(agg->masks), \
                          agg->W, agg->dinv, reinterpret_cast<const unsigned long long *>(agg->blk), agg->row_off, agg->Lq, pl, agg->gate, AH,              \
                          agg->tail_p, (int)agg->tail_row0, Ri
 #define MDF_AGG(RB, n_)                                                                                  \
     if ((n_) > 0) {                                                                                      \
         if (l1) hipLaunchKernelGGL((k_aggregate_mfma<RB, true>), MDF_AGG_ARGS(n_), *l1);                 \
-        else if (pf_env && RB <= 2) hipLaunchKernelGGL((k_aggregate_mfma<(RB <= 2 ? RB : 1), false, true>), MDF_AGG_ARGS(n_), AggLayer1()); \
         else hipLaunchKernelGGL((k_aggregate_mfma<RB, false>), MDF_AGG_ARGS(n_), AggLayer1());           \
     }                                                                                                    \
     pl += (n_);

@@ -396,3 +396,38 @@ def test_layer1_made_inside_the_aggregation_kernel_is_bit_identical():
         assert out.returncode == 0, out.stderr[-2000:]
         sha[fuse] = out.stdout.split("SHA", 1)[1].strip()
     assert sha["1"] == sha["0"], sha
+
+
+def test_split_form_on_cu_masked_streams_is_bit_identical():
+    """MDFRI_SPLIT_CUS=192 (developer knob, read at engine creation): the H.W products on 192 CUs, contact stage + layer 1 + aggregations on the
+    other 64, two stacks in flight on two sets of slabs, stage by stage through mdf_gcn_stage_dev with events in between
+    (csrc/engine.hip forward_alignments_split).  Same kernels, same operands: the same bits as the one-stream form -- over mixed chunks, chunk
+    counts odd and even, one and three heads (pairs of stacks straddle chunks), dirty workspaces, repeated calls."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = (
+        "import sys, os, hashlib; ROOT = %r\n"
+        "for d in ('metagenomic-deepfri_amd', ''): sys.path.insert(0, os.path.join(ROOT, d))\n"
+        "import numpy as np\n"
+        "from mdfri_testkit import synthetic\n"
+        "from mDeepFRI.batch import HotPathEngine, PackedProteins\n"
+        "from mDeepFRI.predict import Predictor\n"
+        "preds = {m: Predictor('syn-' + m, weights=synthetic.glorot_gcn_weights(seed=k, n_terms=40 + k)) for k, m in enumerate('abc')}\n"
+        "h = hashlib.sha256()\n"
+        "for heads in (('a',), ('a', 'b', 'c')):\n"
+        "    eng = HotPathEngine({m: preds[m] for m in heads}, device=0, max_rows=2048, graph_max_chunks=-1)\n"
+        "    for seed, count in ((3, 23), (4, 40), (5, 9)):\n"
+        "        prots = synthetic.synthetic_proteins(seed=seed, count=count, length=(20, 560), indel_rate=0.05)\n"
+        "        pk = PackedProteins.pack([p['seq'] for p in prots], [p['coords'] for p in prots], [p['q_aln'] for p in prots], [p['t_aln'] for p in prots], max_rows=2048)\n"
+        "        for _ in range(2):\n"
+        "            out = eng.run_alignments(pk)\n"
+        "            for m in heads: h.update(out[m].tobytes())\n"
+        "print('SHA', h.hexdigest())\n" % ROOT)
+    sha = {}
+    for cus in ("0", "192"):
+        env = dict(os.environ, MDFRI_SPLIT_CUS=cus)
+        out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sha[cus] = out.stdout.split("SHA", 1)[1].strip()
+    assert sha["192"] == sha["0"], sha
