@@ -78,6 +78,7 @@ def parse(argv=None):
     ap.add_argument("--lm", action="store_true",
                     help="give every GO head the language-model branch of the released models (shared 2x512 LSTM + per-head "
                          "LM embedding; SURVEY.md section 8f row 1).  Not the BASELINE.json configuration: an extra measurement.")
+    ap.add_argument("--no-board", action="store_true", help="do not sample board power / shader clock with rocm-smi while the steps run")
     ap.add_argument("--no-extras", action="store_true", help="N = 1 default run: skip the by_length / mixed / end_to_end mini-runs")
     ap.add_argument("--end-to-end", type=int, default=2, metavar="N", help="batches of the end_to_end mini-run (0 = skip)")
     ap.add_argument("--query-stream", type=int, default=6, metavar="N", help="batches of 4 000 queries of the query_stream mini-run (0 = skip)")
@@ -347,12 +348,13 @@ class Ctx:
 
 class BoardSampler:
     """Board power and shader clock of one GPU while the timed region runs, read by a thread of its own with `rocm-smi` (a process per
-    sample, every ~0.4 s: nothing touches the measured stream).  The H.W GEMM sits on the board's power limit (profiles/r05_gemm_overlap_probe.txt),
+    sample, back to back, ~0.3 s each: nothing touches the measured stream).  The H.W GEMM sits on the board's power limit (profiles/r05_gemm_overlap_probe.txt),
     so the rate moves with the box: the line carries what THIS box held.  Missing tool / unparsable output: the fields are null."""
 
-    def __init__(self, device_index: int = 0):
+    def __init__(self, device_index: int = 0, off: bool = False):
         import shutil
         import threading
+        self.off, self.started = off, False
         self.cmd = [shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi", "-d", str(device_index), "--showpower", "--showclocks", "--showmaxpower"]
         self.power, self.sclk, self.cap = [], [], None
         self._stop = threading.Event()
@@ -375,21 +377,25 @@ class BoardSampler:
                     self.cap = float(m.group(1))
             except Exception:
                 return
-            self._stop.wait(0.4)
+            self._stop.wait(0.05)      # (a call takes ~0.25 s of its own)
 
     def __enter__(self):
-        self._thread.start()
+        # not under a profiler: its preloaded library has initialised the GPU before Python starts, and the box refuses the exec of a child there
+        if not self.off and not any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY")):
+            self._thread.start()
+            self.started = True
         return self
 
     def __exit__(self, *exc):
         self._stop.set()
-        self._thread.join(timeout=10)
+        if self.started:
+            self._thread.join(timeout=10)
 
     def summary(self):
         def stat(v, nd):
             return {"mean": round(sum(v) / len(v), nd), "min": round(min(v), nd), "max": round(max(v), nd), "samples": len(v)} if v else None
         return {"board_power_w": stat(self.power, 1), "shader_clock_mhz": stat(self.sclk, 0), "power_cap_w": self.cap,
-                "how": "rocm-smi --showpower --showclocks sampled every ~0.4 s by a separate thread while warmup + timed steps run"}
+                "how": "rocm-smi --showpower --showclocks called back to back (~0.3 s each) by a separate thread while warmup + timed steps run"}
 
 
 def timed_run(ctx, eng, db, steps, warmup, after=None, timing_period=7):
@@ -688,7 +694,7 @@ def main():
         rank_info = {"world_size": 1, "backend": None, "devices": [me]}
 
     timing_period = 0 if args.no_kernel_timing else args.timing_period
-    with BoardSampler(ctx.dev.index or 0) as board:
+    with BoardSampler(ctx.dev.index or 0, off=args.no_board) as board:
         elapsed, out, split = timed_run(ctx, eng, db, args.steps, args.warmup, after=after, timing_period=timing_period)
 
     if strong:

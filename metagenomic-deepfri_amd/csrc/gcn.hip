@@ -2573,8 +2573,10 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
 int mdf_agg_class(int32_t L, int resident)
 {
     if (L < MDF_AGG_MIN_LEN || L > MDF_AGG_MAX_LEN) return -1;
-    if (resident) return (L >= 176 && L <= 256) ? 0 : (L >= 400 && L <= 512) ? 1 : (L >= 704 && L <= 800) ? 2 : -1;
-    return L <= 256 ? 0 : (L >= 288 && L <= 512) ? 1 : L >= 544 ? 2 : -1;
+    // round 5 (profiles/r05_ax_by_length.txt): with layer 1 made inside the layer-2 launch, the four-row-block form of that launch (704-800
+    // residues) takes 155 us against the gather's 71 + 36 for k_layer1 -- its class is gone; and above ~830 residues the gather wins layer 3 too
+    if (resident) return (L >= 176 && L <= 256) ? 0 : (L >= 400 && L <= 512) ? 1 : -1;
+    return L <= 256 ? 0 : (L >= 288 && L <= 512) ? 1 : (L >= 544 && L <= 832) ? 2 : -1;
 }
 
 int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts, const int32_t *row_off, const int32_t *Lq, int32_t B,

@@ -372,7 +372,7 @@ def _layer1_form_script() -> str:
         "    h.update(run(seed, 18, (20, 330)).tobytes())\n"
         "h.update(run(11, 24, (176, 256)).tobytes())\n"              # chunks of matrix-pipe proteins only: no layer-1 launch at all
         "rng = np.random.default_rng(123)\n"                         # lengths on the edges of the length classes, in arrival order and sorted
-        "edges = [176, 177, 255, 256, 257, 399, 400, 401, 511, 512, 513, 703, 704, 800, 801, 112, 111]\n"
+        "edges = [176, 177, 255, 256, 257, 287, 288, 399, 400, 401, 511, 512, 513, 543, 544, 703, 704, 800, 801, 832, 833, 112, 111]\n"
         "for it in range(16):\n"
         "    lens = [int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(20, 900)) for _ in range(int(rng.integers(3, 20)))]\n"
         "    lens = sorted(lens) if it %% 4 == 0 else lens\n"

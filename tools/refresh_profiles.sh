@@ -8,10 +8,10 @@ O=gpurun_out/refresh
 rm -rf "$O"      # a scratch directory of an earlier call must not leak its traces into the summaries
 mkdir -p "$O"
 T="timeout 600"
-$T rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 bench.py --steps 5 --cpu-seconds 0 --no-extras --no-kernel-timing > "$O/prof_bench.log" 2>&1
+$T rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_bench" -- python3 bench.py --steps 5 --cpu-seconds 0 --no-extras --no-kernel-timing --no-board > "$O/prof_bench.log" 2>&1
 { python3 tools/rocprof_summary.py "$O/prof_bench"; python3 profiles/summarize_rocprof.py layers "$O/prof_bench"; } > "$O/r_kernel_stats.txt"   # -> profiles/rNN_kernel_stats.txt
-$T rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$O/pmc1" -- python3 bench.py --steps 1 --warmup 0 --proteins 2048 --cpu-seconds 0 --verify 0 --no-kernel-timing --no-extras > "$O/pmc1.log" 2>&1
-$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc2" -- python3 bench.py --steps 1 --warmup 0 --proteins 2048 --cpu-seconds 0 --verify 0 --no-kernel-timing --no-extras > "$O/pmc2.log" 2>&1
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$O/pmc1" -- python3 bench.py --steps 1 --warmup 0 --proteins 2048 --cpu-seconds 0 --verify 0 --no-kernel-timing --no-extras --no-board > "$O/pmc1.log" 2>&1
+$T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc2" -- python3 bench.py --steps 1 --warmup 0 --proteins 2048 --cpu-seconds 0 --verify 0 --no-kernel-timing --no-extras --no-board > "$O/pmc2.log" 2>&1
 { python3 tools/pmc_summary.py "$O/pmc1"; python3 tools/pmc_summary.py "$O/pmc2"; } > "$O/r_pmc.txt"             # -> profiles/rNN_pmc.txt
 python3 tools/make_traffic_json.py "$O/pmc1" "$O/pmc2" "${ROUND:-0}" > "$O/traffic.json"                          # -> profiles/traffic.json (stamped with mdf_version())
 cp "$O/traffic.json" profiles/traffic.json     # (the box's copy of the repository: the bench line below then carries `traffic` of this very build)
