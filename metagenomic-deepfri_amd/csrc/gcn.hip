@@ -1233,6 +1233,15 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
     const float *Hs = H + (size_t)r0 * C + slab * AGG_SL;
     const int Lpad = (L + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+    // Round 5: the kernel is bound by instruction issue (74 % of every SIMD's issue slots, profiles/r05_ax_pmc.txt), so its memory accesses go
+    // through buffer descriptors sized to the protein: rows at or beyond L read as zeros and stores beyond the padded rows are dropped by the
+    // range check -- no predicate, no branch, no 64-bit address arithmetic per access.  (raw buffers, byte offsets; 0x00020000 = gfx9 DWORD3;
+    // only the vector offset + the instruction's immediate are range-checked, so everything that decides "inside or outside" is in the vector offset)
+    const unsigned rowB = (unsigned)C * 4u;   // bytes per residue row
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Hs), 0, (int)((unsigned)L * rowB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long *>(masks + (size_t)r0 * W), 0, L * W * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L1 ? l1.S + (size_t)r0 * 32 : Hs), 0, L1 ? L * 128 : 0, 0x00020000);   // L1: the letter sums
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dinv + r0), 0, Lpad * 4, 0x00020000);   // (0.0 for rows in [L, Lpad): k_agg_prepare)
     float t1[13];   // L1: this lane's B operands, T1[2 i + half][slab column frow]
     if (L1) {
 #pragma unroll
@@ -1244,16 +1253,15 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
         f32x16 h1;
         if (!L1) {
             const int jb = j0 + oct * 8;
-            v4f d0 = {0, 0, 0, 0}, d1 = {0, 0, 0, 0};
-            if (jb < L) {   // (a protein's rows are padded to a multiple of 16: dinv is readable up to jb + 7)
-                d0 = *reinterpret_cast<const v4f *>(dinv + r0 + jb);
-                d1 = *reinterpret_cast<const v4f *>(dinv + r0 + jb + 4);
-            }
+            // (a protein's rows are padded to a multiple of 16: d_j is readable up to jb + 7, zero in [L, Lpad), out of range beyond)
+            const v4f d0 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsD, jb * 4, 0, 0));
+            const v4f d1 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsD, jb * 4, 16, 0));
             const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            const int vo = jb * (int)rowB + cp * 8;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                const int j = jb + k;
-                const v2f h = j < L ? *reinterpret_cast<const v2f *>(Hs + (size_t)j * C + cp * 2) : (v2f){0, 0};
+                // row jb + k; zeros from row L on.  (The row offset goes into the VECTOR offset: the scalar offset of a buffer access is not range-checked)
+                const v2f h = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsH, vo + k * (int)rowB, 0, 0));
                 x[k] = h * dd[k];
             }
         } else {
@@ -1265,7 +1273,7 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
                 const int j = jt + frow;
                 v4f sr[7];
 #pragma unroll
-                for (int q = 0; q < 7; ++q) sr[q] = j < L ? *reinterpret_cast<const v4f *>(l1.S + (size_t)(r0 + j) * 32 + q * 4) : (v4f){0, 0, 0, 0};
+                for (int q = 0; q < 7; ++q) sr[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsS, j * 128, q * 16, 0));   // zeros from row L on
 #pragma unroll
                 for (int i = 0; i < 13; ++i) {
                     const float lo = sr[(2 * i) >> 2][(2 * i) & 3], hi = sr[(2 * i + 1) >> 2][(2 * i + 1) & 3];
@@ -1325,8 +1333,7 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int j = jt + 8 * g + 4 * half;
-                v4f d = {0, 0, 0, 0};
-                if (j < Lpad) d = *reinterpret_cast<const v4f *>(dinv + r0 + j);
+                const v4f d = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsD, j * 4, 0, 0));   // (out of range from Lpad on: zeros)
                 bf16x4 th, tm, tl;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1349,30 +1356,38 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
         for (int b = 0; b < ROWBLOCKS; ++b) {
             const int rb = b * 8 + wid;
             if (rb * 32 >= L) break;   // (wave-uniform)
-            unsigned nz = (unsigned)(blk[(size_t)p * 32 + rb] >> (j0 >> 4)) & 0xffffu;
+            const unsigned nz = (unsigned)(blk[(size_t)p * 32 + rb] >> (j0 >> 4)) & 0xffffu;
             if (!nz) continue;
             const int i = rb * 32 + frow;
-            const unsigned long long *mrow = masks + (size_t)(r0 + i) * W + (j0 >> 6);
-            const unsigned long long mw0 = i < L ? mrow[0] : 0ull, mw1 = (i < L && j0 + 64 < L) ? mrow[1] : 0ull,
-                                     mw2 = (i < L && j0 + 128 < L) ? mrow[2] : 0ull, mw3 = (i < L && j0 + 192 < L) ? mrow[3] : 0ull;
-            while (nz) {
-                const int cb = __builtin_ctz(nz);
-                nz &= nz - 1;
-                // the word holding column block cb, selected without an index (an indexed select of registers goes through scratch)
-                const unsigned long long s1 = 0ull - (unsigned long long)((cb >> 2) & 1), s2 = 0ull - (unsigned long long)((cb >> 3) & 1);
-                const unsigned long long m01 = mw0 ^ ((mw0 ^ mw1) & s1), m23 = mw2 ^ ((mw2 ^ mw3) & s1);
-                const unsigned long long word = m01 ^ ((m01 ^ m23) & s2);
-                const unsigned byte = (unsigned)(word >> ((cb & 3) * 16 + 8 * half)) & 0xffu;
-                const bf16x8 af = *reinterpret_cast<const bf16x8 *>(lut + byte * 8);
-                const char *fp = reinterpret_cast<const char *>(xt) + fbase + (((cb * 2 + half) ^ fx) << 4);
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(fp);
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(fp + AGG_SL * (AGG_CHR / 8) * 16);
-                const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(fp + 2 * AGG_SL * (AGG_CHR / 8) * 16);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the fragment reads first ...
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2, acc[b], 0, 0, 0);   // smallest addends first
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[b], 0, 0, 0);
-                acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[b], 0, 0, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the three matrix instructions
+            // the contact words of row i for this chunk's 256 columns (rows from L on: out of the descriptor's range = zeros; words that lie beyond
+            // the protein's columns are not read: the conditions are wave-uniform)
+            const int mo = (i * W + (j0 >> 6)) * 8;
+            typedef unsigned u2m __attribute__((ext_vector_type(2)));
+            unsigned long long mw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                mw[k] = (k == 0 || j0 + 64 * k < L) ? __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rsM, mo, 8 * k, 0)) : 0ull;
+            // word by word (unrolled: the word is a register known at compile time -- round 4 selected it per block with 64-bit masks, ~20 scalar
+            // and vector instructions per populated block), column blocks in ascending order as before: the same sums in the same order
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                unsigned nzw = (nz >> (4 * w)) & 0xfu;   // (wave-uniform)
+                while (nzw) {
+                    const int q = __builtin_ctz(nzw);
+                    nzw &= nzw - 1;
+                    const int cb = 4 * w + q;
+                    const unsigned byte = (unsigned)(mw[w] >> (q * 16 + 8 * half)) & 0xffu;
+                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(lut + byte * 8);
+                    const char *fp = reinterpret_cast<const char *>(xt) + fbase + (((cb * 2 + half) ^ fx) << 4);
+                    const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(fp);
+                    const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(fp + AGG_SL * (AGG_CHR / 8) * 16);
+                    const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(fp + 2 * AGG_SL * (AGG_CHR / 8) * 16);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the fragment reads first ...
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2, acc[b], 0, 0, 0);   // smallest addends first
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[b], 0, 0, 0);
+                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[b], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the three matrix instructions
+                }
             }
         }
     }
@@ -1381,6 +1396,7 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
     __syncthreads();   // every wave is done with the last chunk's fragments
     float *ot = reinterpret_cast<float *>(xt) + wid * (32 * AGG_OPITCH);
     float *Os = out + (size_t)r0 * C + slab * AGG_SL;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(Os, 0, (int)((unsigned)Lpad * rowB), 0x00020000);
     const int orow = lane >> 3, oq = lane & 7;
 #pragma unroll
     for (int b = 0; b < ROWBLOCKS; ++b) {
@@ -1393,10 +1409,11 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = ib + k * 8 + orow;
-            if (i < Lpad) {
-                const v4f v = *reinterpret_cast<const v4f *>(ot + (k * 8 + orow) * AGG_OPITCH + oq * 4) * (i < L ? dinv[r0 + i] : 0.0f);
-                __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(Os + (size_t)i * C + oq * 4));
-            }
+            // d_i is 0.0 in [L, Lpad) and reads as zero beyond; the store is dropped from row Lpad on (range check of the descriptor)
+            const float di = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, i * 4, 0, 0));
+            const v4f v = *reinterpret_cast<const v4f *>(ot + (k * 8 + orow) * AGG_OPITCH + oq * 4) * di;
+            typedef unsigned u4s __attribute__((ext_vector_type(4)));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, v), rsO, i * (int)rowB + oq * 16, 0, 2);   // (2 = non-temporal)
         }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -2574,9 +2591,11 @@ int mdf_agg_class(int32_t L, int resident)
 {
     if (L < MDF_AGG_MIN_LEN || L > MDF_AGG_MAX_LEN) return -1;
     // round 5 (profiles/r05_ax_by_length.txt): with layer 1 made inside the layer-2 launch, the four-row-block form of that launch (704-800
-    // residues) takes 155 us against the gather's 71 + 36 for k_layer1 -- its class is gone; and above ~830 residues the gather wins layer 3 too
+    // residues) takes 155 us against the gather's 71 + 36 for k_layer1 -- its class is gone; layer 3 stays on the matrix pipe up to
+    // MDF_AGG_MAX_LEN (after the kernel's instruction diet it wins at every length again: 73-80 us against the gather's 83-85 at 864-1 024)
     if (resident) return (L >= 176 && L <= 256) ? 0 : (L >= 400 && L <= 512) ? 1 : -1;
-    return L <= 256 ? 0 : (L >= 288 && L <= 512) ? 1 : (L >= 544 && L <= 832) ? 2 : -1;
+    static const int l3_max = getenv("MDFRI_AX_L3_MAX") ? atoi(getenv("MDFRI_AX_L3_MAX")) : MDF_AGG_MAX_LEN;   // developer knob (length sweeps)
+    return L <= 256 ? 0 : (L >= 288 && L <= 512) ? 1 : (L >= 544 && L <= l3_max) ? 2 : -1;
 }
 
 int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts, const int32_t *row_off, const int32_t *Lq, int32_t B,
