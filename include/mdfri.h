@@ -342,11 +342,23 @@ typedef struct mdf_agg_desc {
     int64_t tail_row0;          /* rows [tail_row0, R) belong to no protein: the aggregate is zeroed there ... */
     int32_t tail_p;             /* ... by the workgroups of this listed protein (the last one of the rows, when it is on the list), or, < 0, by a
                                  * memset behind the launches (when the last protein is a long one the gather over its rows covers them) */
+    /* descriptor [0] of the fused engine path only (round 5; zero elsewhere): which of the listed proteins get their LAYER-1 rows made inside
+     * the layer-2 launch (mdf_agg_l1_fused) and which run the plain kernel on H1 rows that k_layer1 wrote.  plist then holds the n_mf[]
+     * proteins of the first kind, class after class, FOLLOWED by n_plain[] of the second; csr_seg / skip_groups above describe the rows of
+     * neither (the gather's), l1_seg / l1_skip the rows of everything but the first kind (k_layer1's) */
+    int32_t n_plain[3];
+    const int32_t *l1_seg;      /* HOST: n_l1_seg pairs (first row, row count) */
+    int32_t n_l1_seg;
+    const uint32_t *l1_skip;    /* device, may be NULL: group bitmap of the proteins of the first kind */
 } mdf_agg_desc;
 
 /* Length class of a protein for the aggregation of kind `resident` (1: the descriptor [0] above, 0: [1]): 0 / 1 / 2 = one / two / four
- * 32-row blocks per wave of the matrix-pipe kernel (at most 256 / 512 / 1 024 residues), -1 = the CSR gather. */
+ * 32-row blocks per wave of the matrix-pipe kernel (at most 256 / 512 / 1 024 residues), -1 = the CSR gather.  Since round 5 the two kinds
+ * list the same lengths (after the kernel's instruction diet the matrix-pipe form wins in front of layer 2 wherever it wins in front of
+ * layer 3); what differs in front of layer 2 is whether layer 1 is made inside the launch: mdf_agg_l1_fused(L) != 0 (fused engine path
+ * only; the per-call and dense-map paths run k_layer1 + the plain kernel, bit-identical). */
 int mdf_agg_class(int32_t L, int resident);
+int mdf_agg_l1_fused(int32_t L);
 
 /* dinv (R) and blk (B, 32) from the contact bits and the per-row degrees (counts: int32 (R), the number of set bits of a row) that
  * the contact stage leaves in its workspace (mdf_cmap_ws_view).  Proteins longer than MDF_AGG_MAX_LEN get no blk entry. */

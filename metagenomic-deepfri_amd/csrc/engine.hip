@@ -30,9 +30,12 @@ struct PlanChunk {
     struct AggLists {
         int64_t plist_pos;          // position of the list of matrix-pipe proteins (chunk-local indices, class after class) in mdf_plan::agg_plist
         int64_t skip_pos;           // position (in int32 words of agg_plist) of the chunk's bitmap of 16-row groups owned by listed proteins
-        int32_t n_mf[3];            // proteins per length class (mdf_agg_class)
+        int32_t n_mf[3];            // proteins per length class (mdf_agg_class); [0]: those whose layer 1 is made inside the layer-2 launch (mdf_agg_l1_fused)
+        int32_t n_plain[3];         // [0] only: the listed proteins that run the plain kernel on H1 rows written by k_layer1; they follow the others in the list
         bool last_listed;           // the chunk's last protein is on the list (its workgroups zero the rows behind it)
         std::vector<int32_t> csr_seg;   // (first row, row count) pairs of the rows of the other proteins: the CSR gather
+        std::vector<int32_t> l1_seg;    // [0] only: the rows k_layer1 makes (everything but the proteins counted in n_mf)
+        int64_t l1_skip_pos;        // [0] only: bitmap of the 16-row groups of the proteins counted in n_mf
     } agg[2];
     int64_t tail_row0;          // first row behind the last protein's padded rows
 };
@@ -94,6 +97,41 @@ static void plan_release(void *p, hipStream_t st)
 static std::atomic<uint64_t> g_plan_serial{1};
 
 
+
+// Which aggregation kernel takes which protein of a chunk, for one of the two descriptors (kind 0: in front of layer 2, kind 1: layer 3 and
+// up): the list of matrix-pipe proteins (chunk-local indices, class after class; kind 0: those whose layer 1 is made inside the launch first,
+// then the plain ones), the row segments / group bitmaps of what is left to the CSR gather and -- kind 0 -- to k_layer1.
+struct AggListsHost {
+    std::vector<int32_t> plist, csr_seg, l1_seg;
+    std::vector<uint32_t> skip, l1_skip;
+    int32_t n_mf[3] = {0, 0, 0}, n_plain[3] = {0, 0, 0};
+    bool last_listed = false;
+};
+template <class ClassOf, class LenOf>
+static void build_agg_lists(int kind, int32_t n, const int32_t *ro, int64_t R, ClassOf cls_of, LenOf len_of, AggListsHost &o)
+{
+    auto fused = [&](int32_t q) { return kind == 0 && cls_of(q) >= 0 && mdf_agg_l1_fused(len_of(q)) != 0; };
+    o = AggListsHost();
+    for (int pass = 0; pass < 2; ++pass)          // pass 0: layer 1 inside the launch (kind 0) / everything (kind 1); pass 1: the plain ones of kind 0
+        for (int cls = 0; cls < 3; ++cls)
+            for (int32_t q = 0; q < n; ++q)
+                if (cls_of(q) == cls && (kind == 0 ? fused(q) == (pass == 0) : pass == 0)) o.plist.push_back(q), ++(pass == 0 ? o.n_mf : o.n_plain)[cls];
+    const size_t words = (size_t)((R / GROUP_ROWS + 31) / 32);
+    o.skip.assign(words, 0u);
+    o.l1_skip.assign(kind == 0 ? words : 0, 0u);
+    auto add_seg = [&](std::vector<int32_t> &seg, int32_t q) {
+        if (!seg.empty() && seg[seg.size() - 2] + seg.back() == ro[q]) seg.back() += ro[q + 1] - ro[q];   // adjacent to the previous one: one launch
+        else seg.push_back(ro[q]), seg.push_back(ro[q + 1] - ro[q]);
+    };
+    auto mark = [&](std::vector<uint32_t> &bits, int32_t q) {
+        for (int32_t g = ro[q] / GROUP_ROWS; g < (ro[q] + len_of(q) + GROUP_ROWS - 1) / GROUP_ROWS; ++g) bits[(size_t)(g >> 5)] |= 1u << (g & 31);
+    };
+    for (int32_t q = 0; q < n; ++q) {
+        if (cls_of(q) >= 0) mark(o.skip, q); else add_seg(o.csr_seg, q);
+        if (kind == 0) { if (fused(q)) mark(o.l1_skip, q); else add_seg(o.l1_seg, q); }
+    }
+    o.last_listed = cls_of(n - 1) >= 0;
+}
 
 static void close_segment(mdf_plan *pl, const std::vector<int> &ids, int64_t groups)
 {
@@ -171,30 +209,19 @@ extern "C" int mdf_plan_create_ex(const int32_t *Lq_in, int32_t B, int32_t max_r
             const int32_t *ro = pl->chunk_row_off.data() + ch.row_off_pos;
             for (int kind = 0; kind < 2; ++kind) {
                 PlanChunk::AggLists &al = ch.agg[kind];
+                AggListsHost h;
+                build_agg_lists(kind, p1 - p0, ro, R, [&](int32_t q) { return mdf_agg_class(Lq[p0 + q], kind == 0); }, [&](int32_t q) { return Lq[p0 + q]; }, h);
                 al.plist_pos = (int64_t)pl->agg_plist.size();
-                for (int cls = 0; cls < 3; ++cls) {
-                    al.n_mf[cls] = 0;
-                    for (int32_t p = p0; p < p1; ++p)
-                        if (mdf_agg_class(Lq[p], kind == 0) == cls) pl->agg_plist.push_back(p - p0), ++al.n_mf[cls];
-                }
-                for (int32_t p = p0; p < p1; ++p) {
-                    if (mdf_agg_class(Lq[p], kind == 0) >= 0) continue;
-                    std::vector<int32_t> &seg = al.csr_seg;
-                    if (!seg.empty() && seg[seg.size() - 2] + seg.back() == ro[p - p0]) {
-                        seg.back() += ro[p - p0 + 1] - ro[p - p0];          // adjacent to the previous gather protein: one launch
-                    } else {
-                        seg.push_back(ro[p - p0]);
-                        seg.push_back(ro[p - p0 + 1] - ro[p - p0]);
-                    }
-                }
-                al.last_listed = mdf_agg_class(Lq[p1 - 1], kind == 0) >= 0;
-                // bitmap of the 16-row groups of the listed proteins (a gather over all rows skips them: unsorted batches, mdf_agg_desc.skip_groups)
+                pl->agg_plist.insert(pl->agg_plist.end(), h.plist.begin(), h.plist.end());
+                for (int c3 = 0; c3 < 3; ++c3) al.n_mf[c3] = h.n_mf[c3], al.n_plain[c3] = h.n_plain[c3];
+                al.csr_seg = h.csr_seg;
+                al.l1_seg = h.l1_seg;
+                al.last_listed = h.last_listed;
+                // bitmaps of the 16-row groups of the listed proteins (a gather / k_layer1 over all rows skips them: unsorted batches)
                 al.skip_pos = (int64_t)pl->agg_plist.size();
-                pl->agg_plist.resize(pl->agg_plist.size() + (size_t)((R / GROUP_ROWS + 31) / 32), 0);
-                uint32_t *bits = reinterpret_cast<uint32_t *>(pl->agg_plist.data() + al.skip_pos);
-                for (int32_t p = p0; p < p1; ++p)
-                    if (mdf_agg_class(Lq[p], kind == 0) >= 0)
-                        for (int32_t g = ro[p - p0] / GROUP_ROWS; g < (ro[p - p0] + Lq[p] + GROUP_ROWS - 1) / GROUP_ROWS; ++g) bits[g >> 5] |= 1u << (g & 31);
+                pl->agg_plist.insert(pl->agg_plist.end(), reinterpret_cast<const int32_t *>(h.skip.data()), reinterpret_cast<const int32_t *>(h.skip.data()) + h.skip.size());
+                al.l1_skip_pos = (int64_t)pl->agg_plist.size();
+                pl->agg_plist.insert(pl->agg_plist.end(), reinterpret_cast<const int32_t *>(h.l1_skip.data()), reinterpret_cast<const int32_t *>(h.l1_skip.data()) + h.l1_skip.size());
             }
             const int32_t last = p1 - 1 - p0;
             ch.tail_row0 = (int64_t)ro[last] + ((int64_t)Lq[p1 - 1] + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
@@ -755,13 +782,15 @@ static int encode_chunk(mdf_engine *, const mdf_plan *pl, const mdf_batch_dev *b
 // per-group partial sums land in the head's segment array
 // Which aggregation kernel takes which protein of a chunk when that is not a function of the lengths alone (dense maps: a map that is
 // not binary keeps the CSR gather): replaces the plan's lists for one chunk.
+static const int32_t kNoSeg = 0;   // a non-NULL l1_seg of zero segments: "this descriptor names its layer-1 rows, and there are none"
+
 struct AggOverride {
     struct Lists {
         const int32_t *d_plist = nullptr;
-        const uint32_t *d_skip = nullptr;   // bitmap of the 16-row groups of the listed proteins
-        int32_t n_mf[3] = {0, 0, 0};
+        const uint32_t *d_skip = nullptr, *d_l1_skip = nullptr;   // bitmaps of the 16-row groups of the listed proteins / of those counted in n_mf ([0])
+        int32_t n_mf[3] = {0, 0, 0}, n_plain[3] = {0, 0, 0};
         bool last_listed = false;   // the chunk's last protein is on the list
-        std::vector<int32_t> csr_seg;
+        std::vector<int32_t> csr_seg, l1_seg;
     } k[2];   // [0]: layer 2, [1]: layer 3 and up
 };
 
@@ -774,7 +803,7 @@ static int chunk_agg_desc(mdf_engine *e, mdf_engine::ContactSet &c, const mdf_pl
     *aggp = nullptr;
     int n_listed = 0;
     for (int kind = 0; kind < 2; ++kind)
-        for (int c3 = 0; c3 < 3; ++c3) n_listed += ov ? ov->k[kind].n_mf[c3] : ch.agg[kind].n_mf[c3];
+        for (int c3 = 0; c3 < 3; ++c3) n_listed += ov ? ov->k[kind].n_mf[c3] + ov->k[kind].n_plain[c3] : ch.agg[kind].n_mf[c3] + ch.agg[kind].n_plain[c3];
     if (!(bits && n_listed > 0)) return MDF_OK;
     const uint64_t *masks = nullptr;
     const int32_t *counts = nullptr;
@@ -791,12 +820,15 @@ static int chunk_agg_desc(mdf_engine *e, mdf_engine::ContactSet &c, const mdf_pl
             const AggOverride::Lists &l = ov->k[kind];
             a.plist = l.d_plist, a.csr_seg = l.csr_seg.data(), a.n_seg = (int32_t)(l.csr_seg.size() / 2), last_listed = l.last_listed;
             a.skip_groups = l.d_skip;
-            for (int c3 = 0; c3 < 3; ++c3) a.n_mf[c3] = l.n_mf[c3];
+            for (int c3 = 0; c3 < 3; ++c3) a.n_mf[c3] = l.n_mf[c3], a.n_plain[c3] = l.n_plain[c3];
+            if (kind == 0) a.l1_seg = l.l1_seg.empty() ? &kNoSeg : l.l1_seg.data(), a.n_l1_seg = (int32_t)(l.l1_seg.size() / 2), a.l1_skip = l.d_l1_skip;
         } else {
             const PlanChunk::AggLists &l = ch.agg[kind];
             a.plist = pl->d_agg_plist + l.plist_pos, a.csr_seg = l.csr_seg.data(), a.n_seg = (int32_t)(l.csr_seg.size() / 2), last_listed = l.last_listed;
             a.skip_groups = reinterpret_cast<const uint32_t *>(pl->d_agg_plist + l.skip_pos);
-            for (int c3 = 0; c3 < 3; ++c3) a.n_mf[c3] = l.n_mf[c3];
+            for (int c3 = 0; c3 < 3; ++c3) a.n_mf[c3] = l.n_mf[c3], a.n_plain[c3] = l.n_plain[c3];
+            if (kind == 0)
+                a.l1_seg = l.l1_seg.empty() ? &kNoSeg : l.l1_seg.data(), a.n_l1_seg = (int32_t)(l.l1_seg.size() / 2), a.l1_skip = reinterpret_cast<const uint32_t *>(pl->d_agg_plist + l.l1_skip_pos);
         }
         // the rows behind the last protein: its workgroups zero them when it is on the matrix-pipe list; otherwise the gather segment of
         // that protein runs to the end of the rows and writes zeros there (empty CSR rows)
@@ -1261,7 +1293,7 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         for (int32_t p = ch.p0; p < ch.p1; ++p) elems += (size_t)pl->Lq[(size_t)p] * (size_t)pl->Lq[(size_t)p];
         // pinned block: [offsets (Bc x int64) | maps | the two lists of the proteins the matrix-pipe aggregation takes (<= 2 Bc x int32)]
         const size_t o_maps = align_up((size_t)Bc * 8, 256), o_plist = align_up(o_maps + elems * 4, 256), skip_words = (size_t)((ch.rows / GROUP_ROWS + 31) / 32),
-                     o_skip = align_up(o_plist + (size_t)Bc * 8, 256), total = o_skip + 2 * skip_words * 4;   // (two lists + two group bitmaps: layer 2 / layer 3 and up)
+                     o_skip = align_up(o_plist + (size_t)Bc * 8, 256), total = o_skip + 3 * skip_words * 4;   // (two lists + three group bitmaps, see below)
         const int s = parity;
         parity ^= 1;
         // A slot holds the maps AND the aggregation lists (plist / skip bitmaps) that every GraphConv launch of its chunk reads, for
@@ -1339,31 +1371,24 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
             int32_t n_listed = 0;
             for (int kind = 0; kind < 2; ++kind) {
                 AggOverride::Lists &l = aov.k[kind];
-                auto cls_of = [&](int32_t q) { return other[(size_t)q] ? -1 : mdf_agg_class(pl->Lq[(size_t)(ch.p0 + q)], kind == 0); };
+                AggListsHost h;
+                build_agg_lists(kind, Bc, ro, ch.rows, [&](int32_t q) { return other[(size_t)q] ? -1 : mdf_agg_class(pl->Lq[(size_t)(ch.p0 + q)], kind == 0); },
+                                [&](int32_t q) { return pl->Lq[(size_t)(ch.p0 + q)]; }, h);
                 l.d_plist = reinterpret_cast<const int32_t *>(e->map_dev[s].as<char>() + o_plist) + n_listed;
-                l.csr_seg.clear();
-                for (int cls = 0; cls < 3; ++cls) {
-                    l.n_mf[cls] = 0;
-                    for (int32_t q = 0; q < Bc; ++q)
-                        if (cls_of(q) == cls) plist[n_listed++] = q, ++l.n_mf[cls];
-                }
-                for (int32_t q = 0; q < Bc; ++q) {
-                    if (cls_of(q) >= 0) continue;
-                    std::vector<int32_t> &seg = l.csr_seg;
-                    if (!seg.empty() && seg[seg.size() - 2] + seg.back() == ro[q]) {
-                        seg.back() += ro[q + 1] - ro[q];
-                    } else {
-                        seg.push_back(ro[q]);
-                        seg.push_back(ro[q + 1] - ro[q]);
-                    }
-                }
-                l.last_listed = cls_of(Bc - 1) >= 0;
-                uint32_t *bits = reinterpret_cast<uint32_t *>(e->map_pin[s] + o_skip) + (size_t)kind * skip_words;
-                memset(bits, 0, skip_words * 4);
-                for (int32_t q = 0; q < Bc; ++q)
-                    if (cls_of(q) >= 0)
-                        for (int32_t g = ro[q] / GROUP_ROWS; g < (ro[q] + pl->Lq[(size_t)(ch.p0 + q)] + GROUP_ROWS - 1) / GROUP_ROWS; ++g) bits[g >> 5] |= 1u << (g & 31);
+                memcpy(plist + n_listed, h.plist.data(), h.plist.size() * 4);
+                n_listed += (int32_t)h.plist.size();
+                for (int c3 = 0; c3 < 3; ++c3) l.n_mf[c3] = h.n_mf[c3], l.n_plain[c3] = h.n_plain[c3];
+                l.csr_seg = h.csr_seg;
+                l.l1_seg = h.l1_seg;
+                l.last_listed = h.last_listed;
+                // three group bitmaps in the slot: [0] layer-2 listed, [1] layer-3 listed, [2] layer-2 proteins whose layer 1 is made inside the launch
+                uint32_t *bits = reinterpret_cast<uint32_t *>(e->map_pin[s] + o_skip);
+                memcpy(bits + (size_t)kind * skip_words, h.skip.data(), skip_words * 4);
                 l.d_skip = reinterpret_cast<const uint32_t *>(e->map_dev[s].as<char>() + o_skip) + (size_t)kind * skip_words;
+                if (kind == 0) {
+                    memcpy(bits + 2 * skip_words, h.l1_skip.data(), skip_words * 4);
+                    l.d_l1_skip = reinterpret_cast<const uint32_t *>(e->map_dev[s].as<char>() + o_skip) + 2 * skip_words;
+                }
             }
         }
         char *d = e->map_dev[s].as<char>();

@@ -1362,7 +1362,6 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
             // the contact words of row i for this chunk's 256 columns (rows from L on: out of the descriptor's range = zeros; words that lie beyond
             // the protein's columns are not read: the conditions are wave-uniform)
             const int mo = (i * W + (j0 >> 6)) * 8;
-            typedef unsigned u2m __attribute__((ext_vector_type(2)));
             unsigned long long mw[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -1987,6 +1986,11 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
         MDF_AGG(1, agg->n_mf[0])
         MDF_AGG(2, agg->n_mf[1])
         MDF_AGG(4, agg->n_mf[2])
+        // descriptor [0] of the fused engine path: the listed proteins whose layer 1 is NOT made in the launch follow -- plain kernel on H1 rows
+        l1 = nullptr;
+        MDF_AGG(1, agg->n_plain[0])
+        MDF_AGG(2, agg->n_plain[1])
+        MDF_AGG(4, agg->n_plain[2])
 #undef MDF_AGG
 #undef MDF_AGG_ARGS
     }
@@ -2589,14 +2593,16 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
 // multiple of 256), and more widely where the operand is not cache-resident.  A function of (length, kind of launch) alone.
 int mdf_agg_class(int32_t L, int resident)
 {
+    (void)resident;   // (round 5: the same lengths in front of layer 2 and of layer 3 -- profiles/r05_ax_by_length.txt)
     if (L < MDF_AGG_MIN_LEN || L > MDF_AGG_MAX_LEN) return -1;
-    // round 5 (profiles/r05_ax_by_length.txt): with layer 1 made inside the layer-2 launch, the four-row-block form of that launch (704-800
-    // residues) takes 155 us against the gather's 71 + 36 for k_layer1 -- its class is gone; layer 3 stays on the matrix pipe up to
-    // MDF_AGG_MAX_LEN (after the kernel's instruction diet it wins at every length again: 73-80 us against the gather's 83-85 at 864-1 024)
-    if (resident) return (L >= 176 && L <= 256) ? 0 : (L >= 400 && L <= 512) ? 1 : -1;
     static const int l3_max = getenv("MDFRI_AX_L3_MAX") ? atoi(getenv("MDFRI_AX_L3_MAX")) : MDF_AGG_MAX_LEN;   // developer knob (length sweeps)
     return L <= 256 ? 0 : (L >= 288 && L <= 512) ? 1 : (L >= 544 && L <= l3_max) ? 2 : -1;
 }
+
+// Lengths whose layer-1 rows are made INSIDE the layer-2 aggregation launch on the fused engine path (k_aggregate_mfma<.., true>): where that
+// launch beats k_layer1 + the plain kernel -- proteins that fill their 256-row chunks at one or two row blocks per wave.  With four row blocks
+// the fused form sits on the register limit (155 us against 71 + 36 at 800 residues), and below 176 / between 257 and 399 the plain pair wins.
+int mdf_agg_l1_fused(int32_t L) { return (L >= 176 && L <= 256) || (L >= 400 && L <= 512); }
 
 int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts, const int32_t *row_off, const int32_t *Lq, int32_t B,
                         int64_t R, float *dinv, uint64_t *blk, void *stream)
@@ -2629,8 +2635,14 @@ static int gcn_stage(mdf_model *m, int stage, const float *letter_sums, const in
     // layer 1 (folded embedding): H1 = elu(S . T1), S = Ahat . onehot from the contact stage.  Proteins whose layer-2 aggregation runs on
     // the matrix pipe get their H1 rows made inside that kernel (k_aggregate_mfma<.., true>: bit-identical, H1 never written); k_layer1 covers
     // the rows of the others.  (Maps that may be non-binary -- a gate is set -- keep the two-kernel form: the gather needs H1 in memory.)
+    // (a descriptor that names its layer-1 rows -- the fused engine path's -- lists in n_mf[] exactly the proteins to fuse; one that does not
+    // fuses every listed protein, as before)
+    const bool split_lists = agg && agg->l1_seg;
     const bool fuse = layer1_fused() && agg && !agg->gate && m->n_gc >= 2 && agg->n_mf[0] + agg->n_mf[1] + agg->n_mf[2] > 0 &&
-                      (agg->n_seg <= 4 || agg->skip_groups);
+                      (split_lists ? (agg->n_l1_seg <= 4 || agg->l1_skip) : (agg->n_seg <= 4 || agg->skip_groups));
+    const int32_t *l1_seg = split_lists ? agg->l1_seg : agg ? agg->csr_seg : nullptr;
+    const int n_l1_seg = split_lists ? agg->n_l1_seg : agg ? agg->n_seg : 0;
+    const uint32_t *l1_skip = split_lists ? agg->l1_skip : agg ? agg->skip_groups : nullptr;
     AggLayer1 l1;
     l1.S = letter_sums, l1.T1 = m->T1, l1.pool_partial = partial, l1.ldp = feat;
     if (stage <= 0) {
@@ -2654,11 +2666,11 @@ static int gcn_stage(mdf_model *m, int stage, const float *letter_sums, const in
         };
         if (!fuse) {
             layer1(0, Ri, nullptr);
-        } else if (agg->n_seg > 4) {
-            layer1(0, Ri, agg->skip_groups);
+        } else if (n_l1_seg > 4) {
+            layer1(0, Ri, l1_skip);
         } else {
-            for (int k = 0; k < agg->n_seg; ++k)
-                if (agg->csr_seg[2 * k + 1] > 0) layer1(agg->csr_seg[2 * k], agg->csr_seg[2 * k] + agg->csr_seg[2 * k + 1], nullptr);
+            for (int k = 0; k < n_l1_seg; ++k)
+                if (l1_seg[2 * k + 1] > 0) layer1(l1_seg[2 * k], l1_seg[2 * k] + l1_seg[2 * k + 1], nullptr);
         }
         MDF_HIP(hipGetLastError());
     }

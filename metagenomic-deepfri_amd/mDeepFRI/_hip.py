@@ -142,6 +142,7 @@ SIGNATURES = {
     "mdf_gcn_embed_lm_agg_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
                                          c_void_p]),
     "mdf_agg_class": (c_int, [c_int32, c_int]),
+    "mdf_agg_l1_fused": (c_int, [c_int32]),
     "mdf_agg_prepare_dev": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
     "mdf_cmap_ws_view": (c_int, [c_void_p, c_size_t, c_int64, c_int32, POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p)]),
     "mdf_dense_to_csr_masks_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
