@@ -331,6 +331,18 @@ def test_every_batch_entry_sorts_inside_and_answers_in_input_order(heads):
         assert np.array_equal(out[m], ref[m]) and np.array_equal(host, ref[m]) and np.array_equal(dense[m].cpu().numpy(), ref[m]), m
     for i in (0, 13, 69):
         assert np.array_equal(out["mf"][i], preds["mf"].forward_pass(prots[i]["seq"], maps[i])), i
+    # ... and under hipGraph replay (the descriptor kernel of an ordered plan is part of the captured sequence): a short shuffled batch, six calls
+    few = [prots[i] for i in (5, 60, 17, 33, 2, 48, 29)]
+    geng = HotPathEngine(preds, device=0, max_rows=65536)
+    gdb = geng.upload(_pack(few, max_rows=65536))
+    assert gdb.packed.order is not None
+    gout = geng.outputs_for(gdb)
+    want = {m: ref[m][[5, 60, 17, 33, 2, 48, 29]] for m in eng.modes}
+    for k in range(6):
+        got = geng.forward_alignments(gdb, out=gout)
+        geng.check(gdb)
+        assert all(np.array_equal(got[m].cpu().numpy(), want[m]) for m in geng.modes), k
+    assert geng.graph_stats()[0] >= 3
     # the sequence engine (CNN heads) takes the same plans
     wc = synthetic.glorot_cnn_weights(seed=4, n_terms=21)
     pc = Predictor("synthetic-cnn", weights=wc)
