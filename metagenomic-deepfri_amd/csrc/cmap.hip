@@ -169,9 +169,16 @@ __global__ __launch_bounds__(1024) void k_scan_i32_to_i64(const int32_t *__restr
 __global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_aln, const char *__restrict__ t_aln,
                                                     const int32_t *__restrict__ aln_off, const int32_t *__restrict__ row_off,
                                                     int32_t *__restrict__ q2t, int32_t *__restrict__ t2q,
-                                                    int32_t *__restrict__ nm_out, int32_t *__restrict__ lq_out, int os)
+                                                    int32_t *__restrict__ nm_out, int32_t *__restrict__ lq_out, int os,
+                                                    int32_t *__restrict__ owner = nullptr, int B = 0, int R = 0)
 {
     const int p = blockIdx.x;
+    if (owner) {
+        // owner[g] = protein of the 16-row group g (the largest p with row_off[p] <= 16 g: the groups behind the last protein are its own):
+        // one load in the kernels below instead of a binary search over row_off in every block's prologue
+        const int g0 = row_off[p] / GROUP_ROWS, g1 = (p + 1 < B ? row_off[p + 1] : R) / GROUP_ROWS;
+        for (int g = g0 + (int)threadIdx.x; g < g1; g += (int)blockDim.x) owner[g] = p;
+    }
     const int a0 = aln_off[p * os], La = aln_off[p * os + 1] - a0;
     const char *q = q_aln + a0, *t = t_aln + a0;
     const int tid = threadIdx.x;
@@ -425,12 +432,12 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
                                                    int32_t *__restrict__ counts,        // COUNT: out (R)
                                                    int32_t *__restrict__ group_sum,     // COUNT: out (R/32)
                                                    unsigned long long *__restrict__ masks, int W,   // COUNT: out (R, W) contact bits
-                                                   int32_t *__restrict__ dense_out, const int64_t *__restrict__ dense_off, int os)
+                                                   int32_t *__restrict__ dense_out, const int64_t *__restrict__ dense_off, int os,
+                                                   const int32_t *__restrict__ owner)   // protein of every 16-row group (k_align_scan)
 {
     __shared__ float4 s_col_all[CMAP_COL_TILE];   // x, y, z, bits of the mapped target index (-2 padding, -1 gap, -3 no coordinates)
     __shared__ int s_cnt[32];
-    const int row0 = blockIdx.x * 32;
-    const int p_lo = find_protein(row_off, B, row0), p_hi = next_group_protein(row_off, B, p_lo, row0);
+    const int p_lo = owner[2 * blockIdx.x], p_hi = owner[2 * blockIdx.x + 1];
     if (p_lo == p_hi)
         cmap_rows_body<MODE, true>(coords, coord_off, Lq_arr, row_off, q2t, thr2, gen, counts, group_sum, masks, W, dense_out, dense_off, p_lo, p_hi, s_col_all, s_cnt, os);
     else
@@ -586,6 +593,130 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
             letter_sums[(size_t)(wrow0 + k) * 32 + a] = (a < 26) ? s_bins[wid * 8 + k][a] : 0.0f;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same fill with EIGHT LANES PER ROW that all walk the row (round 5; the form above serves proteins whose staging would not fit the
+// LDS and the A/B knob MDFRI_CMAP_FILL=words): block = 32 rows = 4 waves of 8 rows x 8 lanes; lane k of a row owns the letters a with
+// a mod 8 == k and every eighth CSR entry.  In the word-per-lane form the lanes that hold the words of one row take turns (the letter sums
+// are accumulated in ascending column order), one lane in eight works at a time and a wave runs sum over words of (the fullest word among
+// its 8 rows) serial steps (~45 at 6 A).  Here the eight lanes of a row run the SAME loop over the row's entries in order -- the order is
+// a property of each lane's own program, nothing is handed from lane to lane -- and a wave runs max over its 8 rows of the row's entries
+// (~20) steps, eight waves per SIMD.  (One lane per ROW, 64 rows per wave, was tried first: one wave per SIMD, the kernel's run time was the
+// latency of the wave that held the densest row -- 67 steps of ~1 100 cycles; experiments/cmap_stage_probe.hip.)
+//   * the block's 32 x W contact words are contiguous in memory: staged once, coalesced, into LDS (row pitch W + 1 words: the eight rows
+//     of a wave read eight different banks), so the walk is ONE loop over the row's entries whatever word they sit in;
+//   * degree factor and letter of a COLUMN come as one 8-byte LDS entry, staged for the block's whole column range [first column of the
+//     first row's protein, last column of the last row's protein): column indices of the CSR are global rows, so the range is contiguous;
+//   * letter sums: bins in LDS (row pitch 33 floats), each (row, letter) updated by its one owner lane with ds_add_f32, which the LDS
+//     executes in program order per lane: the summation order of the CSR, hence of k_letter_sums -- bit-identical to the form above.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int FILL_ROWS = 32, FILL_THREADS = 256;
+#ifdef MDF_FILL_STAMPS
+__device__ unsigned long long *g_fill_stamps = nullptr;   // experiments/cmap_stage_probe.hip: [block][12] = realtime (100 MHz) x 5, shader clock x 5, loop trips (wave 0), entries (wave 0)
+#define MDF_FILL_STAMP(i_) if (g_fill_stamps && threadIdx.x == 0) { g_fill_stamps[12ull * blockIdx.x + (i_)] = wall_clock64(); g_fill_stamps[12ull * blockIdx.x + 5 + (i_)] = clock64(); }
+#else
+#define MDF_FILL_STAMP(i_)
+#endif
+static inline int fill_rows_cols_cap(int32_t max_len) { return 2 * ((max_len + 63) / 64 * 64) + FILL_ROWS; }
+static inline size_t fill_rows_lds(int32_t max_len, int W, bool ls)
+{
+    return (size_t)fill_rows_cols_cap(max_len) * 8 + (size_t)FILL_ROWS * (W + 1) * 8 + (ls ? FILL_ROWS * 33 * 4 : 0);
+}
+
+template <bool CSR, bool LS>
+__global__ __launch_bounds__(FILL_THREADS) void k_cmap_fill_rows(const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off,
+                                                                const int32_t *__restrict__ counts, const int32_t *__restrict__ group_base,
+                                                                const unsigned long long *__restrict__ masks, int W, int32_t *__restrict__ rowptr,
+                                                                int32_t *__restrict__ colidx, float *__restrict__ val, int nnz_cap,
+                                                                const uint8_t *__restrict__ seq_idx, float *__restrict__ letter_sums,
+                                                                int32_t *__restrict__ status, int cols_cap, const int32_t *__restrict__ owner)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_fill[];
+    float2 *const s_col = reinterpret_cast<float2 *>(s_fill);                                                  // (degree factor, 4 x letter) per column
+    unsigned long long *const s_words = reinterpret_cast<unsigned long long *>(s_fill + (size_t)cols_cap * 8);   // [32][W + 1]
+    float *const s_bins = reinterpret_cast<float *>(s_fill + (size_t)cols_cap * 8 + (size_t)FILL_ROWS * (W + 1) * 8);   // [32][33]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int g = blockIdx.x, row0 = g * FILL_ROWS;
+    MDF_FILL_STAMP(0)
+    // the block's two 16-row groups may belong to two proteins (owner: per group, k_align_scan)
+    const int p_lo = owner[2 * g], p_hi = owner[2 * g + 1];
+    const int rloc = wid * 8 + (lane >> 3), k = lane & 7;   // this lane's row of the block, its letter class
+    const int row = row0 + rloc;
+    const int p = rloc < GROUP_ROWS ? p_lo : p_hi;
+    const int r0 = row_off[p], Lq = Lq_arr[p];
+    const int c_lo = row_off[p_lo];
+    const int n_stage = min(row_off[p_hi] + Lq_arr[p_hi] - c_lo, cols_cap);
+    {   // the block's contact words: 32 rows x W words, contiguous
+        const unsigned long long *src = masks + (size_t)row0 * W;
+        for (int i = tid; i < FILL_ROWS * W; i += FILL_THREADS) s_words[(i / W) * (W + 1) + i % W] = src[i];
+    }
+    for (int c = tid; c < n_stage; c += FILL_THREADS)
+        s_col[c] = make_float2(1.0f / (1e-6f + sqrtf((float)counts[c_lo + c])), __int_as_float(LS ? min((int)seq_idx[c_lo + c], 31) * 4 : 0));
+    if (LS)
+        for (int e = tid; e < FILL_ROWS * 33; e += FILL_THREADS) s_bins[e] = 0.0f;
+    // row starts: the group's base (k_scan_groups) + an exclusive prefix of the block's 32 counts (every wave computes it for itself)
+    const int c32 = counts[row0 + (lane & 31)];
+    int inc = c32;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const int t = __shfl_up(inc, d, 32);
+        if ((lane & 31) >= d) inc += t;
+    }
+    const int pos = group_base[g] + __shfl(inc - c32, rloc, 64);
+    const int cnt = __shfl(c32, rloc, 64);
+    if (k == 0) rowptr[row] = min(pos, nnz_cap);  // clamped: an overflowing batch stays in bounds (and is flagged)
+    int Wp = (Lq + 63) >> 6;
+    if (Wp > W) {   // the caller's max_len is smaller than this protein: stay inside the bit rows and say so (status[2])
+        if (k == 0) status[2] = Lq;
+        Wp = W;
+    }
+    if (row - r0 >= Lq) Wp = 0;   // padding rows between proteins and behind the last one
+    MDF_FILL_STAMP(1)
+    __syncthreads();
+    MDF_FILL_STAMP(2)
+    const float di = 1.0f / (1e-6f + sqrtf((float)cnt));
+    const float2 *const my_col = s_col + (r0 - c_lo);   // column j of this lane's protein
+    const unsigned long long *const my_words = s_words + rloc * (W + 1);
+    char *const my_bins = reinterpret_cast<char *>(s_bins + rloc * 33);
+    int w = 0, t = 0;   // t: entries of the row so far
+    unsigned long long m = 0;
+    while (w < Wp && (m = my_words[w]) == 0) ++w;
+    while (w < Wp) {
+        const int j = (w << 6) + __builtin_ctzll(m);
+        m &= m - 1;
+        const float2 e = my_col[j];
+        const float v = (di * 1.0f) * e.x;
+        if (CSR && (t & 7) == k && pos + t < nnz_cap) {
+            colidx[pos + t] = r0 + j;
+            val[pos + t] = v;
+        }
+        ++t;
+        if (LS) {
+            const int a4 = __float_as_int(e.y);
+            if (((a4 >> 2) & 7) == k) atomicAdd(reinterpret_cast<float *>(my_bins + a4), v);
+        }
+        if (m == 0) {
+            do ++w;
+            while (w < Wp && (m = my_words[w]) == 0);
+        }
+    }
+    MDF_FILL_STAMP(3)
+#ifdef MDF_FILL_STAMPS
+    if (g_fill_stamps && wid == 0) {
+        int mx = t, sm = k == 0 ? t : 0;
+        for (int d = 1; d < 64; d <<= 1) { mx = max(mx, __shfl_xor(mx, d, 64)); sm += __shfl_xor(sm, d, 64); }
+        if (lane == 0) { g_fill_stamps[12ull * blockIdx.x + 10] = mx; g_fill_stamps[12ull * blockIdx.x + 11] = sm; }
+    }
+#endif
+    __syncthreads();
+    if (LS) {
+        for (int e = tid; e < FILL_ROWS * 32; e += FILL_THREADS) {
+            const int r = e >> 5, a = e & 31;
+            letter_sums[(size_t)(row0 + r) * 32 + a] = (a < 26) ? s_bins[r * 33 + a] : 0.0f;
+        }
+    }
+    MDF_FILL_STAMP(4)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -775,7 +906,7 @@ __global__ void k_seq_encode(const char *__restrict__ seqs, const int32_t *__res
 static inline float thr2_f32(double threshold) { return (float)(threshold * threshold); }
 
 struct CmapWs {
-    int32_t *q2t, *counts, *group_sum, *group_base;
+    int32_t *q2t, *counts, *group_sum, *group_base, *owner;   // owner: protein of every 16-row group (k_align_scan)
     float *rowsum;
     unsigned long long *masks;   // (R, W) contact bits, W = ceil(max_len / 64); only the CSR-from-coordinates path uses them
 };
@@ -784,7 +915,7 @@ static size_t cmap_ws_bytes(int32_t B, int64_t R, int32_t max_len)
 {
     (void)B;
     const size_t G = (size_t)(R / 32 + 1);
-    return 256 * 7 + (size_t)R * 4 * 3 + G * 4 * 2 + (max_len > 0 ? (size_t)R * mask_words(max_len) * 8 : 0) + 4096;
+    return 256 * 8 + (size_t)R * 4 * 3 + G * 4 * 2 + (size_t)(R / GROUP_ROWS + 1) * 4 + (max_len > 0 ? (size_t)R * mask_words(max_len) * 8 : 0) + 4096;
 }
 static bool carve_cmap_ws(void *ws, size_t bytes, int64_t R, int32_t max_len, CmapWs &o)
 {
@@ -795,6 +926,7 @@ static bool carve_cmap_ws(void *ws, size_t bytes, int64_t R, int32_t max_len, Cm
     o.rowsum = c.take<float>(R);
     o.group_sum = c.take<int32_t>(G);
     o.group_base = c.take<int32_t>(G);
+    o.owner = c.take<int32_t>((size_t)(R / GROUP_ROWS + 1));
     o.masks = max_len > 0 ? c.take<unsigned long long>((size_t)R * mask_words(max_len)) : nullptr;
     return c.ok();
 }
@@ -1033,15 +1165,37 @@ int mdf_cmap_csr_pairs_dev(const float *coords, const int32_t *coord_off, const 
     const float t2 = thr2_f32(threshold);
     ScopedTiming tm(TK_CMAP, st);
     hipLaunchKernelGGL(k_align_scan, dim3(B), dim3(256), 0, st, q_aln, t_aln, aln_off, row_off, w.q2t, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (int32_t *)nullptr, (int)off_stride);
+                       (int32_t *)nullptr, (int32_t *)nullptr, (int)off_stride, w.owner, (int)B, (int)R);
     // ONE pass over the coordinates: row counts + the contact bits themselves ...
     hipLaunchKernelGGL(k_cmap_rows<CM_COUNT>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t, t2,
-                       generated_contacts, w.counts, w.group_sum, w.masks, W, (int32_t *)nullptr, (const int64_t *)nullptr, (int)off_stride);
+                       generated_contacts, w.counts, w.group_sum, w.masks, W, (int32_t *)nullptr, (const int64_t *)nullptr, (int)off_stride,
+                       (const int32_t *)w.owner);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
     // ... then the CSR (and the layer-1 letter sums) from the bits
-    const int cols_cap = std::min((max_len + 63) / 64 * 64, CMAP_FILL_COLS);
-    hipLaunchKernelGGL(k_cmap_fill, dim3(G), dim3(256), (size_t)cols_cap * 5, st, Lq, row_off, B, (const int32_t *)w.counts, (const int32_t *)w.group_base,
-                       (const unsigned long long *)w.masks, W, rowptr, colidx, val, nnz_cap, seq_idx, letter_sums, status, cols_cap);
+    static const bool fill_words = [] { const char *e = getenv("MDFRI_CMAP_FILL"); return e && !strcmp(e, "words"); }();   // developer A/B knob
+    if (fill_words || fill_rows_lds(max_len, W, letter_sums != nullptr) > 64 * 1024) {   // (proteins beyond ~3 000 residues: the word-per-lane form)
+        const int cols_cap = std::min((max_len + 63) / 64 * 64, CMAP_FILL_COLS);
+        hipLaunchKernelGGL(k_cmap_fill, dim3(G), dim3(256), (size_t)cols_cap * 5, st, Lq, row_off, B, (const int32_t *)w.counts, (const int32_t *)w.group_base,
+                           (const unsigned long long *)w.masks, W, rowptr, colidx, val, nnz_cap, seq_idx, letter_sums, status, cols_cap);
+    } else {
+        const int cols_cap = fill_rows_cols_cap(max_len);
+        const size_t lds = fill_rows_lds(max_len, W, letter_sums != nullptr);
+#ifdef MDF_FILL_STAMPS
+        if (getenv("MDFRI_FILL_NOCSR")) {   // timing experiment of the probe: the loop without its CSR stores
+            hipLaunchKernelGGL((k_cmap_fill_rows<false, true>), dim3((unsigned)(R / FILL_ROWS)), dim3(FILL_THREADS), lds, st, Lq, row_off, (const int32_t *)w.counts,
+                               (const int32_t *)w.group_base, (const unsigned long long *)w.masks, W, rowptr, colidx, val, (int)nnz_cap, seq_idx, letter_sums, status,
+                               cols_cap, (const int32_t *)w.owner);
+        } else
+#endif
+        if (letter_sums)
+            hipLaunchKernelGGL((k_cmap_fill_rows<true, true>), dim3((unsigned)(R / FILL_ROWS)), dim3(FILL_THREADS), lds, st, Lq, row_off, (const int32_t *)w.counts,
+                               (const int32_t *)w.group_base, (const unsigned long long *)w.masks, W, rowptr, colidx, val, (int)nnz_cap, seq_idx, letter_sums, status,
+                               cols_cap, (const int32_t *)w.owner);
+        else
+            hipLaunchKernelGGL((k_cmap_fill_rows<true, false>), dim3((unsigned)(R / FILL_ROWS)), dim3(FILL_THREADS), lds, st, Lq, row_off, (const int32_t *)w.counts,
+                               (const int32_t *)w.group_base, (const unsigned long long *)w.masks, W, rowptr, colidx, val, (int)nnz_cap, seq_idx, letter_sums, status,
+                               cols_cap, (const int32_t *)w.owner);
+    }
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -1061,10 +1215,10 @@ int mdf_cmap_dense_dev(const float *coords, const int32_t *coord_off, const char
     const int G = (int)(R / 32);
     ScopedTiming tm(TK_CMAP, st);
     hipLaunchKernelGGL(k_align_scan, dim3(B), dim3(256), 0, st, q_aln, t_aln, aln_off, row_off, w.q2t, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (int32_t *)nullptr, 1);
+                       (int32_t *)nullptr, (int32_t *)nullptr, 1, w.owner, (int)B, (int)R);
     hipLaunchKernelGGL(k_cmap_rows<CM_DENSE>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t,
                        thr2_f32(threshold), generated_contacts, (int32_t *)nullptr, (int32_t *)nullptr, (unsigned long long *)nullptr, 0, out,
-                       out_off, 1);
+                       out_off, 1, (const int32_t *)w.owner);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
