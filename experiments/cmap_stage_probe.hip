@@ -71,6 +71,11 @@ int main(int argc, char **argv)
     CK(hipMalloc(&d_stamps, (size_t)blocks * 12 * 8));
     CK(hipMemset(d_stamps, 0, (size_t)blocks * 12 * 8));
     CK(hipMemcpyToSymbol(HIP_SYMBOL(g_fill_stamps), &d_stamps, sizeof(d_stamps)));
+    const int rblocks = (int)(R / 32);
+    unsigned long long *d_rstamps;
+    CK(hipMalloc(&d_rstamps, (size_t)rblocks * 8 * 8));
+    CK(hipMemset(d_rstamps, 0, (size_t)rblocks * 8 * 8));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_rows_stamps), &d_rstamps, sizeof(d_rstamps)));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto run = [&]() {
@@ -108,5 +113,21 @@ int main(int argc, char **argv)
     int tmax = 0;
     for (int b = 0; b < blocks; ++b) { trips += st[12ull * b + 10]; ent += st[12ull * b + 11]; tmax = std::max(tmax, (int)st[12ull * b + 10]); start += (double)(st[12ull * b] - first) * 10.0; }
     printf("  loop trips per wave: mean %.1f max %d; entries per wave %.0f; mean block start %.0f ns after the first\n", trips / blocks, tmax, ent / blocks, start / blocks);
+    {
+        std::vector<unsigned long long> rs((size_t)rblocks * 8);
+        CK(hipMemcpy(rs.data(), d_rstamps, rs.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long f = ~0ull, l = 0;
+        for (int b = 0; b < rblocks; ++b) { f = std::min(f, rs[8ull * b]); l = std::max(l, rs[8ull * b + 5]); }
+        printf("k_cmap_rows<COUNT>: first block start .. last block end %.2f us (L <= 1 024: one column tile)\n", (l - f) * 0.01);
+        const char *rn[5] = {"prologue (rows)", "column staging", "barrier", "distance loop", "counts out"};
+        for (int ph = 0; ph < 5; ++ph) {
+            double ns = 0, mx = 0;
+            for (int b = 0; b < rblocks; ++b) { const double d = (double)(rs[8ull * b + ph + 1] - rs[8ull * b + ph]) * 10.0; ns += d; mx = std::max(mx, d); }
+            printf("  %-20s mean %8.0f ns  max %8.0f ns\n", rn[ph], ns / rblocks, mx);
+        }
+        double start = 0;
+        for (int b = 0; b < rblocks; ++b) start += (double)(rs[8ull * b] - f) * 10.0;
+        printf("  mean block start %.0f ns after the first\n", start / rblocks);
+    }
     return 0;
 }

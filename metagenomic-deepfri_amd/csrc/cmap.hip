@@ -170,7 +170,9 @@ __global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_a
                                                     const int32_t *__restrict__ aln_off, const int32_t *__restrict__ row_off,
                                                     int32_t *__restrict__ q2t, int32_t *__restrict__ t2q,
                                                     int32_t *__restrict__ nm_out, int32_t *__restrict__ lq_out, int os,
-                                                    int32_t *__restrict__ owner = nullptr, int B = 0, int R = 0)
+                                                    int32_t *__restrict__ owner = nullptr, int B = 0, int R = 0,
+                                                    float4 *__restrict__ qx = nullptr, const float *__restrict__ coords = nullptr,
+                                                    const int32_t *__restrict__ coord_off = nullptr)
 {
     const int p = blockIdx.x;
     if (owner) {
@@ -209,6 +211,16 @@ __global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_a
     int qi = (int)(ex >> 32), ti = (int)(ex & 0xffffffffu);
     int32_t *q2t_p = q2t + row_off[p];
     int32_t *t2q_p = t2q ? t2q + a0 : nullptr;
+    // qx (optional): what k_cmap_bits needs of a query row in one 16-byte load -- the coordinates of the target residue it is aligned to and
+    // the bits of that index (-1: aligned to a gap, -3: to a residue without coordinates; both with zero coordinates)
+    float4 *qx_p = qx ? qx + row_off[p] : nullptr;
+    const float *xyz = nullptr;
+    int Lt = 0;
+    if (qx) {
+        const int c0 = coord_off[p * os];
+        Lt = coord_off[p * os + 1] - c0;
+        xyz = coords + (int64_t)c0 * 3;
+    }
     for (int c = c_begin; c < c_end; ++c) {
         const bool qgap = q[c] == GAP, tgap = t[c] == GAP;
         if (qgap) {
@@ -216,10 +228,13 @@ __global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_a
             ++ti;
         } else if (tgap) {
             q2t_p[qi] = -1;
+            if (qx_p) qx_p[qi] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
             ++qi;
         } else {
             if (t2q_p) t2q_p[ti] = qi;
             q2t_p[qi] = ti;
+            if (qx_p) qx_p[qi] = ti < Lt ? make_float4(xyz[ti * 3 + 0], xyz[ti * 3 + 1], xyz[ti * 3 + 2], __int_as_float(ti))
+                                         : make_float4(0.f, 0.f, 0.f, __int_as_float(-3));
             ++qi;
             ++ti;
         }
@@ -241,6 +256,12 @@ __global__ __launch_bounds__(256) void k_align_scan(const char *__restrict__ q_a
 // The contact term is symmetric for coords-derived pairs (argwhere yields (i,j) and (j,i)), so the one-directional
 // write of pyx:115 reproduces exactly this.
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef MDF_FILL_STAMPS
+__device__ unsigned long long *g_rows_stamps = nullptr;   // experiments/cmap_stage_probe.hip: [block][8] realtime stamps of k_cmap_rows (thread 0)
+#define MDF_ROWS_STAMP(i_) if (g_rows_stamps && threadIdx.x == 0) g_rows_stamps[8ull * g + (i_)] = wall_clock64();
+#else
+#define MDF_ROWS_STAMP(i_)
+#endif
 constexpr int CMAP_FILL_COLS = 4096;  // columns of a protein whose degree factor and letter k_cmap_fill keeps in LDS (20 KiB)
 constexpr int CMAP_COL_TILE = 1024;   // columns of a protein staged in LDS at a time (16 KiB)
 enum CmapMode { CM_COUNT = 0, CM_DENSE = 2 };   // COUNT also stores every row's contact bits (64 columns per word) for k_cmap_fill
@@ -274,6 +295,7 @@ __device__ __forceinline__ void cmap_rows_body(const float *__restrict__ coords,
 {
     const int g = blockIdx.x;
     const int row0 = g * 32;
+    MDF_ROWS_STAMP(0)
     // (wid stays a plain per-lane value on purpose: told that it is wave-uniform, the compiler moves the 8 rows' coordinates, target
     // indices and counters into scalar registers, runs out of them and spills through v_writelane / v_readlane: +22 % on the kernel)
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -319,6 +341,7 @@ __device__ __forceinline__ void cmap_rows_body(const float *__restrict__ coords,
     }
     int32_t *dense_p = nullptr;
     if (MODE == CM_DENSE) dense_p = dense_out + dense_off[p];
+    MDF_ROWS_STAMP(1)
 
     // The columns' target coordinates go through LDS, a tile of CMAP_COL_TILE columns at a time, loaded once by the whole workgroup:
     // fetched per 64-column chunk by every wave (an index load and three dependent coordinate loads each time) the kernel spent its
@@ -343,7 +366,9 @@ __device__ __forceinline__ void cmap_rows_body(const float *__restrict__ coords,
             }
             s_col[c - jt] = v;
         }
+        MDF_ROWS_STAMP(2)
         __syncthreads();
+        MDF_ROWS_STAMP(3)
         if (i_first >= Lq) continue;   // (wave-uniform; the barriers above are reached by every wave)
         for (int j0 = jt; j0 < jt_end; j0 += 64) {
             const int j = j0 + lane;
@@ -404,6 +429,7 @@ __device__ __forceinline__ void cmap_rows_body(const float *__restrict__ coords,
                 masks[(int64_t)(row0 + wid * 8 + lane) * W + (j0 >> 6)] = my_mask;
         }
     }
+    MDF_ROWS_STAMP(4)
     if (i_first < Lq) {
         if (MODE == CM_COUNT && lane == 0) {
 #pragma unroll
@@ -423,6 +449,7 @@ __device__ __forceinline__ void cmap_rows_body(const float *__restrict__ coords,
             group_sum[g] = s;
         }
     }
+    MDF_ROWS_STAMP(5)
 }
 
 template <int MODE>
@@ -442,6 +469,175 @@ __global__ __launch_bounds__(256) void k_cmap_rows(const float *__restrict__ coo
         cmap_rows_body<MODE, true>(coords, coord_off, Lq_arr, row_off, q2t, thr2, gen, counts, group_sum, masks, W, dense_out, dense_off, p_lo, p_hi, s_col_all, s_cnt, os);
     else
         cmap_rows_body<MODE, false>(coords, coord_off, Lq_arr, row_off, q2t, thr2, gen, counts, group_sum, masks, W, dense_out, dense_off, p_lo, p_hi, s_col_all, s_cnt, os);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_cmap_bits: k_cmap_rows<COUNT> rebuilt for the batched path (round 5) -- the same bits, counts and group sums, the same block
+// geometry (32 rows = two 16-row groups that may belong to two proteins; lane = column of the current 64-column chunk), eight waves of 4 rows.
+// What changed, from time stamps inside the old kernel (experiments/cmap_stage_probe.hip: 15 us per block, two rounds of blocks at
+// 88 VGPRs, 32 us per 65 536-row chunk):
+//   * rows and columns arrive as ONE 16-byte load each from `qx` (k_align_scan gathers the aligned target coordinates per query row):
+//     the prologue and the column staging lose a dependent memory round trip each (index -> coordinates), and the index arithmetic;
+//   * away from the diagonal two rows go through the distance arithmetic together on the packed fp32 instructions (v_pk_add_f32 /
+//     v_pk_mul_f32: the same IEEE operations in the same order, no fused multiply-add -- this file is compiled with -ffp-contract=off);
+//     a row without coordinates carries NaN, which fails every comparison, instead of a test per row;
+//   * the near-diagonal chunks (|i - j| <= gen logic, at most two chunks per row) keep the old per-row code.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float cm_v2f __attribute__((ext_vector_type(2)));
+
+constexpr int BITS_THREADS = 512, BITS_WAVES = BITS_THREADS / 64, RW = 32 / BITS_WAVES;   // 8 waves x 4 rows: 12 coordinate registers per wave instead of 24 (8 waves per SIMD)
+template <bool SAME>
+__device__ __forceinline__ void cmap_bits_body(const float4 *__restrict__ qx, const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off,
+                                               float thr2, int gen, int32_t *__restrict__ counts, int32_t *__restrict__ group_sum,
+                                               unsigned long long *__restrict__ masks, int W, int p_lo, int p_hi, float4 *s_col_all, int *s_cnt, const int g)
+{
+    const int row0 = g * 32;
+    MDF_ROWS_STAMP(0)
+    // (wid stays a plain per-lane value on purpose, see cmap_rows_body)
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int half = wid / (BITS_WAVES / 2);
+    const int p = (SAME || !half) ? p_lo : p_hi;
+    const int r0 = row_off[p];
+    const int Lq = Lq_arr[p];
+    const int Lq_blk = SAME ? Lq : max(Lq_arr[p_lo], Lq_arr[p_hi]);   // block-uniform trip count of the staging loop
+    const int i_first = row0 - r0 + wid * RW;  // first local row of this wave
+    const float4 *qx_p = qx + r0;
+
+    if (i_first >= Lq) {
+        // padding rows: zero neighbours
+        if (lane < RW) {
+            counts[row0 + wid * RW + lane] = 0;
+            s_cnt[wid * RW + lane] = 0;
+        }
+    }
+    constexpr int tile = SAME ? CMAP_COL_TILE : CMAP_COL_TILE / 2;
+    constexpr int st_n = SAME ? BITS_THREADS : BITS_THREADS / 2;
+    const int st_tid = SAME ? (int)threadIdx.x : (int)(threadIdx.x & (st_n - 1));
+    // this wave's rows, in pairs for the packed arithmetic; NaN coordinates for a row that can have no distance contact (padding, aligned
+    // to a gap or to a residue without coordinates): every comparison with it is false
+    int ti[RW];
+    cm_v2f X[RW / 2], Y[RW / 2], Z[RW / 2];
+    int cnt[RW];
+    {
+        float4 rv[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) rv[r] = qx_p[min(i_first + r, max(Lq - 1, 0))];
+        const float nan = __int_as_float(0x7fc00000);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int t = i_first + r < Lq ? __float_as_int(rv[r].w) : -2;   // -2: row is padding
+            ti[r] = t;
+            const bool has = t >= 0;
+            X[r >> 1][r & 1] = has ? rv[r].x : nan;
+            Y[r >> 1][r & 1] = has ? rv[r].y : nan;
+            Z[r >> 1][r & 1] = has ? rv[r].z : nan;
+            cnt[r] = 0;
+        }
+    }
+    MDF_ROWS_STAMP(1)
+    float4 *const s_col = SAME ? s_col_all : s_col_all + half * (CMAP_COL_TILE / 2);
+    for (int jt = 0; jt < Lq_blk; jt += tile) {
+        const int jt_end = min(jt + tile, Lq);
+        __syncthreads();   // the previous tile has been consumed
+        // (issuing the first tile's loads in front of the rows' -- one memory round trip instead of two -- costs 8 registers and with them the
+        // eighth wave per SIMD: not done)
+        for (int c = jt + st_tid; c < jt_end; c += st_n) s_col[c - jt] = qx_p[c];
+        MDF_ROWS_STAMP(2)
+        __syncthreads();
+        MDF_ROWS_STAMP(3)
+        if (i_first >= Lq) continue;   // (wave-uniform; the barriers above are reached by every wave)
+        for (int j0 = jt; j0 < jt_end; j0 += 64) {
+            const int j = j0 + lane;
+            int tj = -2;
+            float xj = 0.f, yj = 0.f, zj = 0.f;
+            unsigned long long my_mask = 0;   // lane r keeps row r's word of this 64-column chunk
+            if (j < Lq) {
+                const float4 v = s_col[j - jt];
+                tj = __float_as_int(v.w);
+                xj = v.x;
+                yj = v.y;
+                zj = v.z;
+            }
+            const unsigned long long col_ok = __ballot(tj >= 0);   // columns of this chunk with coordinates (false beyond Lq)
+#pragma unroll
+            for (int q = 0; q < RW / 2; ++q) {
+                const int ia = i_first + 2 * q;
+                if (ia >= Lq) continue;  // wave-uniform (the pair's second row is tested where it matters: NaN coordinates, guarded store)
+                if (ia + 1 + gen < j0 || ia - gen > j0 + 63) {
+                    // both rows of the pair are a chunk away from the diagonal (wave-uniform test): only the distance term can set a bit;
+                    // the same three differences and the same unfused sum of squares as the per-row code, two rows per instruction
+                    const cm_v2f dx = X[q] - xj, dy = Y[q] - yj, dz = Z[q] - zj;
+                    cm_v2f d = dx * dx;
+                    d = d + dy * dy;
+                    d = d + dz * dz;
+                    const unsigned long long ma = __ballot(d.x < thr2) & col_ok, mb = __ballot(d.y < thr2) & col_ok;
+                    cnt[2 * q] += __popcll(ma);
+                    cnt[2 * q + 1] += __popcll(mb);
+                    if (lane == 2 * q) my_mask = ma;
+                    if (lane == 2 * q + 1) my_mask = mb;
+                    continue;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = 2 * q + h, i = ia + h;
+                    if (i >= Lq) continue;  // wave-uniform
+                    bool bit = false;
+                    if (j < Lq) {
+                        const int dist = i > j ? i - j : j - i;
+                        bit = (dist == 0) || (dist <= gen && (ti[r] == -1 || tj == -1));
+                        if (!bit && ti[r] >= 0 && tj >= 0) {
+                            const float dx = X[q][h] - xj, dy = Y[q][h] - yj, dz = Z[q][h] - zj;
+                            float d = dx * dx;
+                            d = d + dy * dy;
+                            d = d + dz * dz;
+                            // ti == tj only on the diagonal (the map is injective), handled above
+                            bit = d < thr2;
+                        }
+                    }
+                    const unsigned long long mask = __ballot(bit);
+                    cnt[r] += __popcll(mask);
+                    if (lane == r) my_mask = mask;
+                }
+            }
+            if (lane < RW && i_first + lane < Lq && (j0 >> 6) < W)   // (a protein longer than max_len is flagged by the fill kernel)
+                masks[(int64_t)(row0 + wid * RW + lane) * W + (j0 >> 6)] = my_mask;
+        }
+    }
+    MDF_ROWS_STAMP(4)
+    if (i_first < Lq) {
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int i = i_first + r;
+                const int c = i < Lq ? cnt[r] : 0;
+                counts[row0 + wid * RW + r] = c;
+                s_cnt[wid * RW + r] = c;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {   // (thread 0 adding the 32 counts one LDS read after the other was ~1 us of every block's 7)
+        int sum = lane < 32 ? s_cnt[lane] : 0;
+#pragma unroll
+        for (int d = 16; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+        if (lane == 0) group_sum[g] = sum;
+    }
+    MDF_ROWS_STAMP(5)
+}
+
+__global__ __launch_bounds__(BITS_THREADS) void k_cmap_bits(const float4 *__restrict__ qx, const int32_t *__restrict__ Lq_arr, const int32_t *__restrict__ row_off,
+                                                            float thr2, int gen, int32_t *__restrict__ counts, int32_t *__restrict__ group_sum,
+                                                            unsigned long long *__restrict__ masks, int W, const int32_t *__restrict__ owner)
+{
+    __shared__ float4 s_col_all[CMAP_COL_TILE];   // x, y, z, bits of the mapped target index (-1 gap, -3 no coordinates)
+    __shared__ int s_cnt[32];
+    // (one workgroup per 32-row block.  A resident grid -- 4 workgroups per CU, each walking its blocks -- was tried: 22.5 -> 29 us)
+    const int g = blockIdx.x;
+    const int p_lo = owner[2 * g], p_hi = owner[2 * g + 1];
+    if (p_lo == p_hi)
+        cmap_bits_body<true>(qx, Lq_arr, row_off, thr2, gen, counts, group_sum, masks, W, p_lo, p_hi, s_col_all, s_cnt, g);
+    else
+        cmap_bits_body<false>(qx, Lq_arr, row_off, thr2, gen, counts, group_sum, masks, W, p_lo, p_hi, s_col_all, s_cnt, g);
 }
 
 // Exclusive scan of the per-group nnz (int32) with one block of up to 1024 threads (launched with 256: four waves of 36 VGPRs
@@ -905,8 +1101,10 @@ __global__ void k_seq_encode(const char *__restrict__ seqs, const int32_t *__res
 // ------------------------------------------------------------------------------------------------------------------
 static inline float thr2_f32(double threshold) { return (float)(threshold * threshold); }
 
+
 struct CmapWs {
     int32_t *q2t, *counts, *group_sum, *group_base, *owner;   // owner: protein of every 16-row group (k_align_scan)
+    float4 *qx;                  // (R) aligned target coordinates + index bits per query row (k_align_scan -> k_cmap_bits); CSR path only
     float *rowsum;
     unsigned long long *masks;   // (R, W) contact bits, W = ceil(max_len / 64); only the CSR-from-coordinates path uses them
 };
@@ -915,7 +1113,7 @@ static size_t cmap_ws_bytes(int32_t B, int64_t R, int32_t max_len)
 {
     (void)B;
     const size_t G = (size_t)(R / 32 + 1);
-    return 256 * 8 + (size_t)R * 4 * 3 + G * 4 * 2 + (size_t)(R / GROUP_ROWS + 1) * 4 + (max_len > 0 ? (size_t)R * mask_words(max_len) * 8 : 0) + 4096;
+    return 256 * 8 + (size_t)R * 4 * 3 + G * 4 * 2 + (size_t)(R / GROUP_ROWS + 1) * 4 + (max_len > 0 ? (size_t)R * mask_words(max_len) * 8 + (size_t)R * 16 + 256 : 0) + 4096;
 }
 static bool carve_cmap_ws(void *ws, size_t bytes, int64_t R, int32_t max_len, CmapWs &o)
 {
@@ -928,6 +1126,7 @@ static bool carve_cmap_ws(void *ws, size_t bytes, int64_t R, int32_t max_len, Cm
     o.group_base = c.take<int32_t>(G);
     o.owner = c.take<int32_t>((size_t)(R / GROUP_ROWS + 1));
     o.masks = max_len > 0 ? c.take<unsigned long long>((size_t)R * mask_words(max_len)) : nullptr;
+    o.qx = max_len > 0 ? c.take<float4>((size_t)R) : nullptr;
     return c.ok();
 }
 
@@ -1164,12 +1363,17 @@ int mdf_cmap_csr_pairs_dev(const float *coords, const int32_t *coord_off, const 
     const int G = (int)(R / 32), W = mask_words(max_len);
     const float t2 = thr2_f32(threshold);
     ScopedTiming tm(TK_CMAP, st);
+    static const bool rows_old = [] { const char *e = getenv("MDFRI_CMAP_ROWS"); return e && !strcmp(e, "old"); }();   // developer A/B knob: k_cmap_rows<COUNT>
     hipLaunchKernelGGL(k_align_scan, dim3(B), dim3(256), 0, st, q_aln, t_aln, aln_off, row_off, w.q2t, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (int32_t *)nullptr, (int)off_stride, w.owner, (int)B, (int)R);
+                       (int32_t *)nullptr, (int32_t *)nullptr, (int)off_stride, w.owner, (int)B, (int)R, rows_old ? (float4 *)nullptr : w.qx, coords, coord_off);
     // ONE pass over the coordinates: row counts + the contact bits themselves ...
-    hipLaunchKernelGGL(k_cmap_rows<CM_COUNT>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t, t2,
-                       generated_contacts, w.counts, w.group_sum, w.masks, W, (int32_t *)nullptr, (const int64_t *)nullptr, (int)off_stride,
-                       (const int32_t *)w.owner);
+    if (rows_old)
+        hipLaunchKernelGGL(k_cmap_rows<CM_COUNT>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t, t2,
+                           generated_contacts, w.counts, w.group_sum, w.masks, W, (int32_t *)nullptr, (const int64_t *)nullptr, (int)off_stride,
+                           (const int32_t *)w.owner);
+    else
+        hipLaunchKernelGGL(k_cmap_bits, dim3(G), dim3(BITS_THREADS), 0, st, (const float4 *)w.qx, Lq, row_off, t2, generated_contacts, w.counts, w.group_sum, w.masks, W,
+                           (const int32_t *)w.owner);
     hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
     // ... then the CSR (and the layer-1 letter sums) from the bits
     static const bool fill_words = [] { const char *e = getenv("MDFRI_CMAP_FILL"); return e && !strcmp(e, "words"); }();   // developer A/B knob

@@ -216,6 +216,28 @@ def test_dense_slots_outlive_the_graphconv_launches_that_read_them():
             assert np.array_equal(dense[m].cpu().numpy(), ref[m]), (it, m)
 
 
+def test_contact_fill_forms_by_length(heads):
+    """The CSR / letter-sum kernel of the contact stage has two forms: eight lanes per row with the block's columns and contact words
+    staged in LDS (k_cmap_fill_rows), and -- where that staging would not fit 64 KiB, queries beyond ~3 000 residues -- a word per lane
+    with the first 4 096 columns staged (k_cmap_fill).  A batch whose longest query is 3 300 residues takes the second for every protein
+    of its chunks, short ones included; the same proteins in a batch of their own take the first.  Fused == dense-map path (k_dense_rows +
+    k_letter_sums: another kernel pair, the same CSR order) bit for bit, and the short proteins score the same in both batches."""
+    from mDeepFRI.batch import HotPathEngine
+    ws, preds = heads
+    lengths = [3300, 70, 200, 33, 512]
+    prots = [synthetic.synthetic_proteins(seed=1500 + k, count=1, length=L, indel_rate=0.02)[0] for k, L in enumerate(lengths)]
+    eng = HotPathEngine(preds, device=0, max_rows=4096)
+    pk = _pack(prots, max_rows=4096)
+    ref = eng.run_alignments(pk)
+    maps = [orc.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2) for p in prots]
+    dense = eng.forward_dense(eng.upload(_pack_seq_only(prots, max_rows=4096)), maps)
+    short = eng.run_alignments(_pack(prots[1:], max_rows=4096))
+    for m in eng.modes:
+        assert np.isfinite(ref[m]).all()
+        assert np.array_equal(dense[m].cpu().numpy(), ref[m]), m
+        assert np.array_equal(short[m], ref[m][1:]), m
+
+
 def _pack_seq_only(prots, **kw):
     from mDeepFRI.batch import PackedProteins
     return PackedProteins.pack([p["seq"] for p in prots], **kw)
