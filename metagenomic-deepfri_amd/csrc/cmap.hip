@@ -814,6 +814,11 @@ __device__ unsigned long long *g_fill_stamps = nullptr;   // experiments/cmap_st
 #else
 #define MDF_FILL_STAMP(i_)
 #endif
+static bool fill_words_form()
+{
+    static const bool v = [] { const char *e = getenv("MDFRI_CMAP_FILL"); return e && !strcmp(e, "words"); }();   // developer A/B knob: k_cmap_fill + k_scan_groups
+    return v;
+}
 static inline int fill_rows_cols_cap(int32_t max_len) { return 2 * ((max_len + 63) / 64 * 64) + FILL_ROWS; }
 static inline size_t fill_rows_lds(int32_t max_len, int W, bool ls)
 {
@@ -826,8 +831,10 @@ __global__ __launch_bounds__(FILL_THREADS) void k_cmap_fill_rows(const int32_t *
                                                                 const unsigned long long *__restrict__ masks, int W, int32_t *__restrict__ rowptr,
                                                                 int32_t *__restrict__ colidx, float *__restrict__ val, int nnz_cap,
                                                                 const uint8_t *__restrict__ seq_idx, float *__restrict__ letter_sums,
-                                                                int32_t *__restrict__ status, int cols_cap, const int32_t *__restrict__ owner)
+                                                                int32_t *__restrict__ status, int cols_cap, const int32_t *__restrict__ owner,
+                                                                const int32_t *__restrict__ group_sum, int G_scan, int32_t *__restrict__ rowptr_end)
 {
+    __shared__ long long s_part[FILL_THREADS / 64];
     extern __shared__ __attribute__((aligned(16))) unsigned char s_fill[];
     float2 *const s_col = reinterpret_cast<float2 *>(s_fill);                                                  // (degree factor, 4 x letter) per column
     unsigned long long *const s_words = reinterpret_cast<unsigned long long *>(s_fill + (size_t)cols_cap * 8);   // [32][W + 1]
@@ -851,7 +858,16 @@ __global__ __launch_bounds__(FILL_THREADS) void k_cmap_fill_rows(const int32_t *
         s_col[c] = make_float2(1.0f / (1e-6f + sqrtf((float)counts[c_lo + c])), __int_as_float(LS ? min((int)seq_idx[c_lo + c], 31) * 4 : 0));
     if (LS)
         for (int e = tid; e < FILL_ROWS * 33; e += FILL_THREADS) s_bins[e] = 0.0f;
-    // row starts: the group's base (k_scan_groups) + an exclusive prefix of the block's 32 counts (every wave computes it for itself)
+    // row starts: the group's base + an exclusive prefix of the block's 32 counts (every wave computes it for itself).  The base: from
+    // k_scan_groups, or (G_scan > 0: chunks of up to 4 096 groups) summed here from the group sums below this block's -- sixteen coalesced
+    // loads per thread at most, in flight with the staging loads, instead of a launch of its own between k_cmap_bits and this kernel
+    long long part = 0;
+    if (G_scan > 0) {
+        for (int i = tid; i < g; i += FILL_THREADS) part += group_sum[i];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+        if (lane == 0) s_part[wid] = part;
+    }
     const int c32 = counts[row0 + (lane & 31)];
     int inc = c32;
 #pragma unroll
@@ -859,9 +875,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_cmap_fill_rows(const int32_t *
         const int t = __shfl_up(inc, d, 32);
         if ((lane & 31) >= d) inc += t;
     }
-    const int pos = group_base[g] + __shfl(inc - c32, rloc, 64);
     const int cnt = __shfl(c32, rloc, 64);
-    if (k == 0) rowptr[row] = min(pos, nnz_cap);  // clamped: an overflowing batch stays in bounds (and is flagged)
     int Wp = (Lq + 63) >> 6;
     if (Wp > W) {   // the caller's max_len is smaller than this protein: stay inside the bit rows and say so (status[2])
         if (k == 0) status[2] = Lq;
@@ -871,6 +885,23 @@ __global__ __launch_bounds__(FILL_THREADS) void k_cmap_fill_rows(const int32_t *
     MDF_FILL_STAMP(1)
     __syncthreads();
     MDF_FILL_STAMP(2)
+    long long base = 0;
+    if (G_scan > 0) {
+#pragma unroll
+        for (int u = 0; u < FILL_THREADS / 64; ++u) base += s_part[u];
+        if (g == G_scan - 1 && tid == 0) {   // the last block knows the total: rowptr[R] and the overflow status (what k_scan_groups writes)
+            const long long total = base + group_sum[g];
+            *rowptr_end = (int32_t)(total < nnz_cap ? total : nnz_cap);
+            if (total > nnz_cap || total >= 0x7fffffffLL) {
+                status[0] = 1;
+                status[1] = (int32_t)(total < 0x7fffffffLL ? total : 0x7fffffffLL);
+            }
+        }
+    } else {
+        base = group_base[g];
+    }
+    const int pos = (int)(base < 0x7fffffffLL ? base : 0x7fffffffLL) + __shfl(inc - c32, rloc, 64);
+    if (k == 0) rowptr[row] = min(pos, nnz_cap);  // clamped: an overflowing batch stays in bounds (and is flagged)
     const float di = 1.0f / (1e-6f + sqrtf((float)cnt));
     const float2 *const my_col = s_col + (r0 - c_lo);   // column j of this lane's protein
     const unsigned long long *const my_words = s_words + rloc * (W + 1);
@@ -1374,10 +1405,12 @@ int mdf_cmap_csr_pairs_dev(const float *coords, const int32_t *coord_off, const 
     else
         hipLaunchKernelGGL(k_cmap_bits, dim3(G), dim3(BITS_THREADS), 0, st, (const float4 *)w.qx, Lq, row_off, t2, generated_contacts, w.counts, w.group_sum, w.masks, W,
                            (const int32_t *)w.owner);
-    hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
-    // ... then the CSR (and the layer-1 letter sums) from the bits
-    static const bool fill_words = [] { const char *e = getenv("MDFRI_CMAP_FILL"); return e && !strcmp(e, "words"); }();   // developer A/B knob
-    if (fill_words || fill_rows_lds(max_len, W, letter_sums != nullptr) > 64 * 1024) {   // (proteins beyond ~3 000 residues: the word-per-lane form)
+    // ... then the CSR (and the layer-1 letter sums) from the bits; the exclusive scan of the groups' entry counts is a launch of its own only
+    // where the fill kernel does not sum them itself (see k_cmap_fill_rows)
+    const bool rows_form = !fill_words_form() && fill_rows_lds(max_len, W, letter_sums != nullptr) <= 64 * 1024;   // (else: proteins beyond ~3 000 residues, the word-per-lane form)
+    const int G_scan = rows_form && G <= 4096 ? G : 0;
+    if (!G_scan) hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
+    if (!rows_form) {
         const int cols_cap = std::min((max_len + 63) / 64 * 64, CMAP_FILL_COLS);
         hipLaunchKernelGGL(k_cmap_fill, dim3(G), dim3(256), (size_t)cols_cap * 5, st, Lq, row_off, B, (const int32_t *)w.counts, (const int32_t *)w.group_base,
                            (const unsigned long long *)w.masks, W, rowptr, colidx, val, nnz_cap, seq_idx, letter_sums, status, cols_cap);
@@ -1388,17 +1421,17 @@ int mdf_cmap_csr_pairs_dev(const float *coords, const int32_t *coord_off, const 
         if (getenv("MDFRI_FILL_NOCSR")) {   // timing experiment of the probe: the loop without its CSR stores
             hipLaunchKernelGGL((k_cmap_fill_rows<false, true>), dim3((unsigned)(R / FILL_ROWS)), dim3(FILL_THREADS), lds, st, Lq, row_off, (const int32_t *)w.counts,
                                (const int32_t *)w.group_base, (const unsigned long long *)w.masks, W, rowptr, colidx, val, (int)nnz_cap, seq_idx, letter_sums, status,
-                               cols_cap, (const int32_t *)w.owner);
+                               cols_cap, (const int32_t *)w.owner, (const int32_t *)w.group_sum, G_scan, rowptr + R);
         } else
 #endif
         if (letter_sums)
             hipLaunchKernelGGL((k_cmap_fill_rows<true, true>), dim3((unsigned)(R / FILL_ROWS)), dim3(FILL_THREADS), lds, st, Lq, row_off, (const int32_t *)w.counts,
                                (const int32_t *)w.group_base, (const unsigned long long *)w.masks, W, rowptr, colidx, val, (int)nnz_cap, seq_idx, letter_sums, status,
-                               cols_cap, (const int32_t *)w.owner);
+                               cols_cap, (const int32_t *)w.owner, (const int32_t *)w.group_sum, G_scan, rowptr + R);
         else
             hipLaunchKernelGGL((k_cmap_fill_rows<true, false>), dim3((unsigned)(R / FILL_ROWS)), dim3(FILL_THREADS), lds, st, Lq, row_off, (const int32_t *)w.counts,
                                (const int32_t *)w.group_base, (const unsigned long long *)w.masks, W, rowptr, colidx, val, (int)nnz_cap, seq_idx, letter_sums, status,
-                               cols_cap, (const int32_t *)w.owner);
+                               cols_cap, (const int32_t *)w.owner, (const int32_t *)w.group_sum, G_scan, rowptr + R);
     }
     MDF_HIP(hipGetLastError());
     return MDF_OK;
