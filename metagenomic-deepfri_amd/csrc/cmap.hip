@@ -906,26 +906,64 @@ __global__ __launch_bounds__(FILL_THREADS) void k_cmap_fill_rows(const int32_t *
     const float2 *const my_col = s_col + (r0 - c_lo);   // column j of this lane's protein
     const unsigned long long *const my_words = s_words + rloc * (W + 1);
     char *const my_bins = reinterpret_cast<char *>(s_bins + rloc * 33);
-    int w = 0, t = 0;   // t: entries of the row so far
-    unsigned long long m = 0;
-    while (w < Wp && (m = my_words[w]) == 0) ++w;
-    while (w < Wp) {
-        const int j = (w << 6) + __builtin_ctzll(m);
+    // which of the row's words hold an entry: lane k looks at words k, k + 8, ..., the row's eight lanes OR their findings
+    unsigned long long rest = 0;
+    for (int ww = k; ww < Wp; ww += 8)
+        if (my_words[ww]) rest |= 1ull << ww;
+    rest |= __shfl_xor(rest, 1, 64);
+    rest |= __shfl_xor(rest, 2, 64);
+    rest |= __shfl_xor(rest, 4, 64);
+    int t = 0;   // entries of the row so far
+    if (rest) {
+        // Software pipeline (the densest row's wave is alone on its SIMD at the end and a step is a chain of dependent LDS round trips: ~1 100
+        // cycles as a plain loop): the word after the current one is already in a register, and the NEXT entry's column data is requested before
+        // this entry's stores and sums are issued.
+        int w = __builtin_ctzll(rest);
+        rest &= rest - 1;
+        unsigned long long m = my_words[w], mn = 0;
+        int wn = -1;
+        if (rest) {
+            wn = __builtin_ctzll(rest);
+            rest &= rest - 1;
+            mn = my_words[wn];
+        }
+        int j = (w << 6) + __builtin_ctzll(m);
         m &= m - 1;
-        const float2 e = my_col[j];
-        const float v = (di * 1.0f) * e.x;
-        if (CSR && (t & 7) == k && pos + t < nnz_cap) {
-            colidx[pos + t] = r0 + j;
-            val[pos + t] = v;
-        }
-        ++t;
-        if (LS) {
-            const int a4 = __float_as_int(e.y);
-            if (((a4 >> 2) & 7) == k) atomicAdd(reinterpret_cast<float *>(my_bins + a4), v);
-        }
-        if (m == 0) {
-            do ++w;
-            while (w < Wp && (m = my_words[w]) == 0);
+        float2 e = my_col[j];
+        for (;;) {
+            bool more = true;
+            int jn = j;
+            if (m) {
+                jn = (w << 6) + __builtin_ctzll(m);
+                m &= m - 1;
+            } else if (wn >= 0) {
+                w = wn;
+                m = mn;
+                wn = -1;
+                if (rest) {
+                    wn = __builtin_ctzll(rest);
+                    rest &= rest - 1;
+                    mn = my_words[wn];
+                }
+                jn = (w << 6) + __builtin_ctzll(m);
+                m &= m - 1;
+            } else {
+                more = false;
+            }
+            const float2 en = my_col[jn];
+            const float v = (di * 1.0f) * e.x;
+            if (CSR && (t & 7) == k && pos + t < nnz_cap) {
+                colidx[pos + t] = r0 + j;
+                val[pos + t] = v;
+            }
+            ++t;
+            if (LS) {
+                const int a4 = __float_as_int(e.y);
+                if (((a4 >> 2) & 7) == k) atomicAdd(reinterpret_cast<float *>(my_bins + a4), v);
+            }
+            if (!more) break;
+            e = en;
+            j = jn;
         }
     }
     MDF_FILL_STAMP(3)
