@@ -321,3 +321,51 @@ def test_csr_stage_flags_a_query_longer_than_max_len():
                                       max_len, 6.0, 2, _p(rowptr), _p(colidx), _p(val), R * 40, _p(status), None, None, _p(ws), ws.numel(), st))
         torch.cuda.synchronize()
         assert int(status[2].item()) == expect and int(status[0].item()) == 0
+
+
+def test_contact_stage_kernel_generations_agree_bit_for_bit():
+    """The batched contact stage has two generations of kernels: k_cmap_bits + k_cmap_fill_rows (round 5: gathered coordinates, packed fp32 on
+    row pairs; eight lanes per row, the group scan inside) and k_cmap_rows<COUNT> + k_scan_groups + k_cmap_fill (rounds 1-4; still the path of
+    queries beyond ~3 000 residues and of the knobs MDFRI_CMAP_ROWS=old / MDFRI_CMAP_FILL=words, which are read once per process).  The raw
+    outputs of mdf_cmap_csr_dev -- rowptr, colidx, val, the layer-1 letter sums, status -- over batches with indels, proteins sharing 32-row
+    blocks, several thresholds and generated-contact widths, an overflowing capacity: the same bytes from both, each in a process of its own."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = (
+        "import sys, os, hashlib, ctypes; ROOT = %r\n"
+        "for d in ('metagenomic-deepfri_amd', ''): sys.path.insert(0, os.path.join(ROOT, d))\n"
+        "import numpy as np, torch\n"
+        "from mdfri_testkit import synthetic\n"
+        "from mDeepFRI import _hip\n"
+        "from mDeepFRI.batch import DeviceBatch, PackedProteins, _p\n"
+        "L = _hip.lib(); dev = torch.device('cuda:0'); h = hashlib.sha256()\n"
+        "rng = np.random.default_rng(5)\n"
+        "for it, (thr, gen, lens) in enumerate(((6.0, 2, [40, 7, 300, 16, 17, 1, 513, 64, 31]), (8.0, 0, [200, 200, 90]), (4.5, 5, [33, 700, 15, 15, 260]),\n"
+        "                                      (6.0, 2, [int(x) for x in rng.integers(1, 400, size=40)]))):\n"
+        "    prots = [synthetic.synthetic_proteins(seed=50 * it + k, count=1, length=n, indel_rate=0.08 if n > 8 else 0.0)[0] for k, n in enumerate(lens)]\n"
+        "    pk = PackedProteins.pack([p['seq'] for p in prots], [p['coords'] for p in prots], [p['q_aln'] for p in prots], [p['t_aln'] for p in prots], max_rows=65536, keep_order=True)\n"
+        "    assert len(pk.chunks) == 1\n"
+        "    db, R = DeviceBatch(pk, dev), pk.chunks[0].rows\n"
+        "    max_len = int(pk.Lq.max())\n"
+        "    seq_idx = torch.from_numpy(rng.integers(0, 26, size=R).astype(np.uint8)).to(dev)\n"
+        "    for cap in (R * 64, 100):\n"                              # the second capacity overflows: clamped row pointers, status[0..1]
+        "        ws = torch.zeros(L.mdf_cmap_workspace_bytes(pk.B, R, max_len), dtype=torch.uint8, device=dev)\n"
+        "        rowptr = torch.zeros(R + 1, dtype=torch.int32, device=dev); colidx = torch.zeros(cap, dtype=torch.int32, device=dev)\n"
+        "        val = torch.zeros(cap, dtype=torch.float32, device=dev); lsum = torch.zeros(R * 32, dtype=torch.float32, device=dev)\n"
+        "        status = torch.zeros(4, dtype=torch.int32, device=dev)\n"
+        "        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)\n"
+        "        _hip.check(L.mdf_cmap_csr_dev(_p(db.coords), _p(db.coord_off), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off), _p(db.Lq), _p(db.chunk_row_off), pk.B, R,\n"
+        "                                      max_len, thr, gen, _p(rowptr), _p(colidx), _p(val), cap, _p(status), _p(seq_idx), _p(lsum), _p(ws), ws.numel(), st))\n"
+        "        torch.cuda.synchronize()\n"
+        "        n = min(int(rowptr[R].item()), cap)\n"
+        "        for a in (rowptr, colidx[:n], val[:n], lsum, status): h.update(a.cpu().numpy().tobytes())\n"
+        "        if cap > 100: assert status.tolist() == [0, 0, 0, 0], status.tolist()\n"
+        "        else: assert status[0].item() == 1\n"
+        "print('SHA', h.hexdigest())\n" % ROOT)
+    sha_of = {}
+    for name, env in (("round 5", {}), ("rounds 1-4", {"MDFRI_CMAP_ROWS": "old", "MDFRI_CMAP_FILL": "words"})):
+        out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sha_of[name] = out.stdout.split("SHA", 1)[1].strip()
+    assert sha_of["round 5"] == sha_of["rounds 1-4"], sha_of
