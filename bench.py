@@ -63,7 +63,8 @@ def parse(argv=None):
                     help="proteins per GPU per step for the weak workloads (default 10000 = configs[2]); TOTAL proteins for configs3/configs4 "
                          "(default 100000 / 500000)")
     ap.add_argument("--length", type=int, default=512)
-    ap.add_argument("--chunk-rows", type=int, default=65536, help="residue rows per fused chunk (multiples of 32768 = full rounds of 256x256 GEMM tiles on 256 CUs)")
+    ap.add_argument("--chunk-rows", type=int, default=262144,
+                    help="residue rows per fused chunk (multiples of 32768 = full rounds of 256x256 GEMM tiles on 256 CUs); default = the library's MDF_DEFAULT_CHUNK_ROWS")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="single-thread worker processes of the all-core leg (0 = min(cores, 32))")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket kernels with HIP events")
@@ -848,8 +849,9 @@ def main():
                     a = AlignmentResult(query_name=f"p{k}", query_sequence=seqs[k], target_name=f"t{k}", target_sequence=seqs[k], alignment="M" * len(seqs[k]))
                     a.gapped_sequence, a.gapped_target, a.coords = q_alns[k], t_alns[k], coords[k]
                     alns.append(a)
-                maps = [cm for _, cm in batch.build_align_contact_maps(alns, device=local_rank, max_rows=args.chunk_rows)]
-                pk_d = batch.PackedProteins.pack(seqs[:n], max_rows=args.chunk_rows)
+                dense_rows = min(args.chunk_rows, 65536)   # (1 MiB of map per protein at L = 512: chunks of 128 proteins keep the double-buffered upload busy)
+                maps = [cm for _, cm in batch.build_align_contact_maps(alns, device=local_rank, max_rows=dense_rows)]
+                pk_d = batch.PackedProteins.pack(seqs[:n], max_rows=dense_rows)
                 db_d = eng.upload(pk_d)
                 eng.forward_dense(db_d, maps)
                 torch.cuda.synchronize()

@@ -450,10 +450,17 @@ int mdf_plan_segments(const mdf_plan *plan, int64_t *out);
 const int32_t *mdf_plan_chunk_row_off(const mdf_plan *plan, int64_t *count);
 const int32_t *mdf_plan_grp_off(const mdf_plan *plan, int64_t *count);
 
+/* Residue rows per fused chunk where the caller does not say (mdf_plan_create*, mdf_engine_config.max_rows = 0; the Python layer asks
+ * mdf_default_chunk_rows()).  Rounds 1-5 ran 65 536; measured with the round-5 kernels (tools/chunk_sweep.sh, experiments/r05_chunk_rows_ab.sh):
+ * 262 144 rows per launch take 1-3 % off a step on every workload of the bench (eight 256 x 256 tiles per GEMM workgroup instead of two,
+ * a quarter of the launches), 1.6 GB of slabs per engine at 512 channels.  A chunk never exceeds the batch: small batches are unaffected. */
+#define MDF_DEFAULT_CHUNK_ROWS 262144
+int32_t mdf_default_chunk_rows(void);
+
 /* --- engine --- */
 typedef struct mdf_engine mdf_engine;
 typedef struct {
-    int32_t max_rows;            /* residue rows per fused chunk; 0 = 65536 (multiples of 32768 are whole rounds of GEMM tiles) */
+    int32_t max_rows;            /* residue rows per fused chunk; 0 = MDF_DEFAULT_CHUNK_ROWS (multiples of 32768 are whole rounds of GEMM tiles) */
     int32_t nnz_per_row;         /* initial CSR capacity per residue row; 0 = 40 (6 A maps hold ~13, 10 A maps ~40) */
     double threshold;            /* contact threshold in Angstrom (cli.py:360-371 default 6.0) */
     int32_t generated_contacts;  /* contact_map_utils.pyx:44 generated_contacts (default 2) */

@@ -859,8 +859,8 @@ __global__ __launch_bounds__(FILL_THREADS) void k_cmap_fill_rows(const int32_t *
     if (LS)
         for (int e = tid; e < FILL_ROWS * 33; e += FILL_THREADS) s_bins[e] = 0.0f;
     // row starts: the group's base + an exclusive prefix of the block's 32 counts (every wave computes it for itself).  The base: from
-    // k_scan_groups, or (G_scan > 0: chunks of up to 4 096 groups) summed here from the group sums below this block's -- sixteen coalesced
-    // loads per thread at most, in flight with the staging loads, instead of a launch of its own between k_cmap_bits and this kernel
+    // k_scan_groups, or (G_scan > 0: chunks of up to 16 384 groups = 524 288 rows) summed here from the group sums below this block's -- 64 coalesced
+    // loads per thread at most (L2-resident: the array is 64 KiB), in flight with the staging loads, instead of a launch of its own between k_cmap_bits and this kernel
     long long part = 0;
     if (G_scan > 0) {
         for (int i = tid; i < g; i += FILL_THREADS) part += group_sum[i];
@@ -1446,7 +1446,8 @@ int mdf_cmap_csr_pairs_dev(const float *coords, const int32_t *coord_off, const 
     // ... then the CSR (and the layer-1 letter sums) from the bits; the exclusive scan of the groups' entry counts is a launch of its own only
     // where the fill kernel does not sum them itself (see k_cmap_fill_rows)
     const bool rows_form = !fill_words_form() && fill_rows_lds(max_len, W, letter_sums != nullptr) <= 64 * 1024;   // (else: proteins beyond ~3 000 residues, the word-per-lane form)
-    const int G_scan = rows_form && G <= 4096 ? G : 0;
+    static const int scan_max = getenv("MDFRI_FILL_SCAN_MAX") ? atoi(getenv("MDFRI_FILL_SCAN_MAX")) : 16384;   // developer knob (groups)
+    const int G_scan = rows_form && G <= scan_max ? G : 0;
     if (!G_scan) hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
     if (!rows_form) {
         const int cols_cap = std::min((max_len + 63) / 64 * 64, CMAP_FILL_COLS);

@@ -159,11 +159,13 @@ extern "C" const int32_t *mdf_plan_order(const mdf_plan *pl, int64_t *count)
     return pl && !pl->order.empty() ? pl->order.data() : nullptr;
 }
 
+extern "C" int32_t mdf_default_chunk_rows(void) { return MDF_DEFAULT_CHUNK_ROWS; }
+
 extern "C" int mdf_plan_create_ex(const int32_t *Lq_in, int32_t B, int32_t max_rows, int32_t max_segment_groups, uint32_t flags, mdf_plan **out)
 {
     MDF_REQUIRE(Lq_in && out, "plan_create: NULL argument");
     MDF_REQUIRE(B > 0, "plan_create: empty batch");
-    if (max_rows <= 0) max_rows = 65536;
+    if (max_rows <= 0) max_rows = MDF_DEFAULT_CHUNK_ROWS;
     if (max_segment_groups <= 0) max_segment_groups = 1 << 20;
     for (int32_t p = 0; p < B; ++p) MDF_REQUIRE(Lq_in[p] > 0, "plan_create: empty sequence in batch (protein %d)", p);
     auto *pl = new mdf_plan();
@@ -577,7 +579,7 @@ extern "C" int mdf_engine_create(mdf_model *const *models, int32_t n_models, int
     e->device = device;
     if (cfg) e->cfg = *cfg;
     mdf_engine_config &c = e->cfg;
-    if (c.max_rows <= 0) c.max_rows = 65536;
+    if (c.max_rows <= 0) c.max_rows = MDF_DEFAULT_CHUNK_ROWS;
     if (c.nnz_per_row <= 0) c.nnz_per_row = 40;
     if (!cfg) c.threshold = 6.0, c.generated_contacts = 2;
     if (c.max_segment_groups <= 0) c.max_segment_groups = 1 << 20;

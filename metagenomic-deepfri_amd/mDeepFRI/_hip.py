@@ -153,6 +153,7 @@ SIGNATURES = {
     "mdf_plan_create": (c_int, [c_void_p, c_int32, c_int32, c_int32, POINTER(c_void_p)]),
     "mdf_plan_create_ex": (c_int, [c_void_p, c_int32, c_int32, c_int32, c_uint32, POINTER(c_void_p)]),
     "mdf_plan_order": (POINTER(c_int32), [c_void_p, _i64p]),
+    "mdf_default_chunk_rows": (c_int32, []),
     "mdf_plan_free": (None, [c_void_p]),
     "mdf_plan_num_proteins": (c_int32, [c_void_p]),
     "mdf_plan_num_chunks": (c_int32, [c_void_p]),
@@ -254,6 +255,11 @@ def lib() -> ctypes.CDLL:
 
 def last_error() -> str:
     return lib().mdf_last_error().decode("utf-8", "replace")
+
+
+def default_chunk_rows() -> int:
+    """Residue rows per fused chunk where the caller does not say (include/mdfri.h MDF_DEFAULT_CHUNK_ROWS)."""
+    return int(lib().mdf_default_chunk_rows())
 
 
 def check(rc: int) -> None:

@@ -81,7 +81,7 @@ class PackedProteins:
         return len(self.seqs)
 
     @classmethod
-    def pack(cls, seqs, coords=None, q_alns=None, t_alns=None, max_rows: int = 32768, max_segment_groups: int = 1 << 20, keep_order: bool = False):
+    def pack(cls, seqs, coords=None, q_alns=None, t_alns=None, max_rows: int = None, max_segment_groups: int = 1 << 20, keep_order: bool = False):
         """keep_order=False (default): the library's plan VISITS the proteins shortest first (the reference sorts its work list by length,
         pipeline.py:529-533; ~10 % on the GCN stage of a mixed-length batch that arrives unsorted); the packed arrays, the scores and every
         report stay in the order given here -- only `chunks` / `segments` / `order` speak of plan positions.  keep_order=True: visited as given.
@@ -126,7 +126,7 @@ class PackedProteins:
         return pk
 
     @classmethod
-    def from_alignments(cls, alignments, max_rows: int = 32768, max_segment_groups: int = 1 << 20):
+    def from_alignments(cls, alignments, max_rows: int = None, max_segment_groups: int = 1 << 20):
         """Pack objects carrying the AlignmentResult attributes the reference's path reads (query_sequence, coords,
         gapped_sequence, gapped_target; reference alignment.py:106-150).  Entries without coordinates are skipped, as
         pipeline.py:485 filters them; returns (packed, kept_indices)."""
@@ -137,7 +137,7 @@ class PackedProteins:
         return pk, keep
 
     @classmethod
-    def from_aligned_batch(cls, batch, coords, max_rows: int = 32768, max_segment_groups: int = 1 << 20):
+    def from_aligned_batch(cls, batch, coords, max_rows: int = None, max_segment_groups: int = 1 << 20):
         """Pack the struct-of-arrays output of mDeepFRI.alignment.align_queries_arrays (the GPU aligner) together with the
         targets' C-alpha coordinates -- no AlignmentResult objects, no per-protein string handling: the gapped strings are
         taken as the flat byte arrays the aligner produced.  coords: one float32 (Lt, 3) array per query (its best target's
@@ -181,6 +181,7 @@ class PackedProteins:
     def _plan(self, max_rows: int, max_segment_groups: int = 1 << 20, keep_order: bool = False):
         """Chunks and pooling segments from the library's planner (mdf_plan_create, csrc/engine.hip): the Python objects below
         are a read-only view of its tables; the handle itself is what the engine entry points take."""
+        max_rows = int(max_rows) if max_rows else _hip.default_chunk_rows()   # (None / 0: the library's default, MDF_DEFAULT_CHUNK_ROWS)
         import weakref
         L = _hip.lib()
         lq = np.ascontiguousarray(self.Lq, dtype=np.int32)
@@ -274,7 +275,7 @@ class HotPathEngine:
     launch sequence, the language-model grouping, the GO heads and the hipGraph replay of short batches all run in C++; this
     class owns the torch tensors (inputs, flags, outputs) and turns return codes into the exceptions of the per-call API."""
 
-    def __init__(self, predictors: dict, device: int = 0, max_rows: int = 32768, nnz_per_row: int = 40,
+    def __init__(self, predictors: dict, device: int = 0, max_rows: int = None, nnz_per_row: int = 40,
                  threshold: float = 6.0, generated_contacts: int = 2, lm_batch: int = 8192, lm_workspace_gib: float = 48.0,
                  graph_max_chunks: int = 0, pipeline_contact: int = 0):
         import weakref
@@ -285,7 +286,7 @@ class HotPathEngine:
         self.predictors = dict(predictors)
         self.modes = list(self.predictors)
         self.device = torch.device(f"cuda:{device}")
-        self.max_rows = int(max_rows)
+        self.max_rows = int(max_rows) if max_rows else _hip.default_chunk_rows()
         self.nnz_per_row = int(nnz_per_row)
         self.threshold = float(threshold)
         self.generated_contacts = int(generated_contacts)

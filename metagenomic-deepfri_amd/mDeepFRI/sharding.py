@@ -41,9 +41,13 @@ def partition_by_cost(lengths, world_size: int):
     return shards
 
 
-def plan_summary(lengths, world_size: int, max_rows: int = 65536):
+def plan_summary(lengths, world_size: int, max_rows: int = None):
     """What `bench.py --dry-plan` prints and tests/test_sharding_cpu.py asserts on: per rank the proteins, padded residue rows
     (the cost model) and chunks of `max_rows`, plus the predicted imbalance max/mean - 1 of the padded rows.  CPU only."""
+    if not max_rows:
+        from . import _hip
+        max_rows = _hip.default_chunk_rows()
+    max_rows = int(max_rows)
     lengths = np.asarray(lengths, dtype=np.int64)
     pad = (lengths + GROUP_ROWS - 1) // GROUP_ROWS * GROUP_ROWS
     shards = partition_by_cost(lengths, world_size)
@@ -291,7 +295,7 @@ def _place_filtered(goff, blocks, dev, sizes):
     return goff.to(torch.int32), out_t, out_s
 
 
-def predict_sharded(engine, seqs, coords, q_alns, t_alns, modes=None, dst: int = 0, group=None, max_rows: int = 65536):
+def predict_sharded(engine, seqs, coords, q_alns, t_alns, modes=None, dst: int = 0, group=None, max_rows: int = None):
     """Whole multi-GPU path for one workload known to every rank: deal proteins to ranks by cost, run the fused hot path
     on this rank's shard with `engine` (a mDeepFRI.batch.HotPathEngine bound to this rank's GPU), gather once.
     Returns {mode: (N, T) torch tensor in input order} on `dst`, None on the other ranks.  With an uninitialised
@@ -326,7 +330,7 @@ def predict_sharded(engine, seqs, coords, q_alns, t_alns, modes=None, dst: int =
 
 
 def predict_sharded_filtered(engine, seqs, coords, q_alns, t_alns, threshold: float = 0.1, modes=None, dst: int = 0, group=None,
-                             max_rows: int = 65536):
+                             max_rows: int = None):
     """predict_sharded with the output stage in front of the gather: every rank filters its own scores on the GPU
     (`score >= threshold`, descending, reference pipeline.py:696-705) and only the survivors travel.
     Returns {mode: (offsets, term_idx, kept)} in input order on `dst`, None elsewhere."""

@@ -34,10 +34,10 @@ class AlignmentStream:
     section 5 row 14) and its score rows are put back in input order on the device before they travel -- results and their order do
     not depend on it."""
 
-    def __init__(self, engine: HotPathEngine, batch_size: int = 10000, max_rows: int = 65536, prefetch: int = 2, sort_by_length: bool = True):
+    def __init__(self, engine: HotPathEngine, batch_size: int = 10000, max_rows: int = None, prefetch: int = 2, sort_by_length: bool = True):
         self.engine = engine
         self.batch_size = int(batch_size)
-        self.max_rows = int(max_rows)
+        self.max_rows = int(max_rows) if max_rows else int(engine.max_rows)   # (default: the engine's chunk size)
         self.prefetch = int(prefetch)
         self.sort_by_length = bool(sort_by_length)
 
@@ -207,14 +207,14 @@ class QueryStream:
     order; profiles/r04_stream_order.txt).  The results do not depend on it (every protein's scores are the same bits in any batch);
     `aligned[k]` is the position inside the slice of batch entry k."""
 
-    def __init__(self, engine: HotPathEngine, structures, batch_size: int = 4000, max_rows: int = 65536, scoring_matrix="VTML80",
+    def __init__(self, engine: HotPathEngine, structures, batch_size: int = 4000, max_rows: int = None, scoring_matrix="VTML80",
                  gap_open: int = 10, gap_extend: int = 1, threshold: float = 0.1, capacity_per_protein: int = 64, sequence_engine=None,
                  keep_scores: bool = False, batch_chunks: int = 0, sort_by_length: bool = True):
         import torch
         from .alignment import AlignerWorkspace
         self.batch_chunks, self.sort_by_length = int(batch_chunks), bool(sort_by_length)
         self.engine, self.structures, self.sequence_engine = engine, structures, sequence_engine
-        self.batch_size, self.max_rows = int(batch_size), int(max_rows)
+        self.batch_size, self.max_rows = int(batch_size), int(max_rows) if max_rows else int(engine.max_rows)
         self.scoring_matrix, self.gap_open, self.gap_extend = scoring_matrix, int(gap_open), int(gap_extend)
         self.threshold, self.capacity_per_protein, self.keep_scores = float(threshold), int(capacity_per_protein), bool(keep_scores)
         self.main, self.side = torch.cuda.Stream(engine.device), torch.cuda.Stream(engine.device, priority=-1)

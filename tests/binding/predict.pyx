@@ -242,7 +242,7 @@ cdef class Predictor(object):
 
 
 def predict_batch(list predictors, list seqs, list coords, list q_alns, list t_alns, double threshold = 6.0, int generated_contacts = 2,
-                  int max_rows = 65536):
+                  int max_rows = 262144):   # (= MDF_DEFAULT_CHUNK_ROWS, include/mdfri.h)
     """The batched counterpart of the reference's two loops -- Pool.map(build_align_contact_map) (pipeline.py:476-481) followed by
     _run_prediction_loop (pipeline.py:292-319) -- as ONE call into the library (mdf_engine_run_alignments_host): C-alpha
     coordinates + gapped alignments + sequences of B proteins in, one (B, T) float32 array per GCN Predictor out.  The arrays

@@ -306,3 +306,23 @@ def test_get_residues_coordinates_selects_calpha_of_one_chain():
     assert get_residues_coordinates(s, "B", {"MSE": "MET"})[0] == "MLLSAMG"
     with pytest.raises(ValueError, match="Chain C not found in structure."):
         get_residues_coordinates(s, "C")
+
+
+def test_default_chunk_rows_is_one_number_everywhere():
+    """include/mdfri.h MDF_DEFAULT_CHUNK_ROWS: the planner and the engine fall back to it, the Python layer asks the library, and bench.py's
+    --chunk-rows default and the compiled binding's keyword default state it as a literal -- all the same number, a multiple of 32 768
+    (whole rounds of 256 x 256 GEMM tiles on 256 CUs)."""
+    import re
+    from conftest import ROOT
+    from mDeepFRI import _hip
+    n = _hip.default_chunk_rows()
+    hdr = open(os.path.join(ROOT, "include", "mdfri.h")).read()
+    assert int(re.search(r"#define MDF_DEFAULT_CHUNK_ROWS (\d+)", hdr).group(1)) == n and n % 32768 == 0
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert int(re.search(r'"--chunk-rows", type=int, default=(\d+)', bench).group(1)) == n
+    pyx = open(os.path.join(ROOT, "tests", "binding", "predict.pyx")).read()
+    assert int(re.search(r"int max_rows = (\d+)\)", pyx).group(1)) == n
+    lq = np.full(3000, 512, dtype=np.int32)
+    from mDeepFRI.batch import PackedProteins
+    pk = PackedProteins.pack(["A" * 512] * 3000)
+    assert max(c.rows for c in pk.chunks) == n and len(pk.chunks) == -(-3000 * 512 // n)

@@ -79,7 +79,7 @@ def test_default_line_regression_net():
     bf16 peak / 6 (committed 0.46-0.49: the kernel sits on the board's power limit -- profiles/r05_gemm_overlap_probe.txt -- and boxes
     differ); A.X proper -- the layer-3 launches; with layer 1 made inside the layer-2 launch that one is NOT part of this figure -- >= 0.40
     of the HBM peak (north_star's target; committed 0.50-0.52); the layer-2 launch that also makes layer 1 has a ceiling of its own,
-    105 us per 65 536 rows (committed 88-90); the sampled kernel classes x their launches per step within 5 % of the step; `traffic`
+    105 us per 65 536 rows (committed 74-82); the sampled kernel classes x their launches per step within 5 % of the step; `traffic`
     either stamped for this very library or null with the reason -- never a stale constant; and the board's power / shader clock while
     the steps ran, when rocm-smi is there."""
     from mDeepFRI import _hip
@@ -95,7 +95,8 @@ def test_default_line_regression_net():
         layers = obj["per_layer"]
         if obj is ax and ax.get("layer1_form") == "fused":      # the layer-2 launch also makes layer 1: the A.X roofline is over the layer-3 launches
             assert _hip.lib().mdf_layer1_form() == b"fused" and layers["ax2"]["makes_layer1"] is True
-            assert layers["ax2"]["avg_us"] <= 105.0, layers["ax2"]          # the fused launch's own guard (k_aggregate_mfma<2, true>)
+            per_64k = layers["ax2"]["avg_us"] * 65536.0 / ax["per_launch"]["rows"]   # (a launch covers a chunk: MDF_DEFAULT_CHUNK_ROWS rows by default)
+            assert per_64k <= 105.0, (layers["ax2"], ax["per_launch"]["rows"])   # the fused launch's own guard (k_aggregate_mfma<2, true>)
             layers = {"ax3": layers["ax3"]}
         pooled = sum(v["avg_us"] * v["timed_launches"] for v in layers.values()) / sum(v["timed_launches"] for v in layers.values())
         assert abs(pooled - obj["per_launch"]["avg_us"]) < 0.02 * pooled          # `achieved` is the mean over every (pure) launch of the kernel

@@ -246,7 +246,8 @@ def test_gather_plans_of_configs4_fit_their_index_types():
     # the compacted form: results.tsv keeps a few dozen terms per protein; even 1 000 per protein would fit the int32 offsets
     assert sharding.FilteredGatherPlan.max_survivors() >= 500_000 * 1000
     # chunk row offsets inside the engine are int32 per CHUNK (<= max_rows rows), never per job
-    assert max(plan["padded_rows"]) > 2 ** 24 and max(plan["chunks"]) * 65536 >= max(plan["padded_rows"])
+    from mDeepFRI import _hip
+    assert max(plan["padded_rows"]) > 2 ** 24 and max(plan["chunks"]) * _hip.default_chunk_rows() >= max(plan["padded_rows"])
 
 
 def test_gather_filtered_single_process():

@@ -1,5 +1,5 @@
 """profiles/traffic.json from two rocprofv3 counter passes of the bench command (tools/refresh_profiles.sh: pmc1 = FETCH_SIZE ..., pmc2 =
-WRITE_SIZE; `--proteins 2048` = 16 full chunks of 65 536 rows), stamped with the library's mdf_version() -- a hash of the GraphConv
+WRITE_SIZE; `--proteins 2048` = 1 048 576 rows = whole chunks of bench.py's default size, MDF_DEFAULT_CHUNK_ROWS), stamped with the library's mdf_version() -- a hash of the GraphConv
 kernels' source.  bench.py reports these bytes as `roofline*.traffic` only while the stamp matches the library it runs.
     python3 tools/make_traffic_json.py gpurun_out/refresh/pmc1 gpurun_out/refresh/pmc2 ROUND > profiles/traffic.json"""
 import csv
@@ -33,11 +33,12 @@ def pick(m, prefix):
 def main():
     from mDeepFRI import _hip
     fetch, write = means(sys.argv[1], "FETCH_SIZE"), means(sys.argv[2], "WRITE_SIZE")
-    out = {"_comment": "HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; 65536 residue rows per launch, configs[2] "
+    rows = _hip.default_chunk_rows()   # (the passes run bench.py with its default --chunk-rows, which is this number)
+    out = {"_comment": f"HBM traffic per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; {rows} residue rows per launch, configs[2] "
                        "inputs). bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 rocprofv3 tallies "
                        "128-B read requests at 64 B); WRITE_SIZE reproduces the algorithmic store bytes (131072 KB for a 128 MiB slab) and is used as is. "
                        "`library` is mdf_version() of the build the passes ran on: bench.py drops `traffic` for any other build.",
-           "round": int(sys.argv[3]), "library": _hip.lib().mdf_version().decode(), "rows_per_launch": 65536}
+           "round": int(sys.argv[3]), "library": _hip.lib().mdf_version().decode(), "rows_per_launch": rows}
     # the A.X launches of the headline workload (L = 512) all run the matrix-pipe kernel k_aggregate_mfma<2>; a build or workload that still
     # runs the CSR gather there is picked up under the same key
     # (k_aggregate_mfma<2, false> is the A.X kernel proper; <2, true> also makes layer 1 and is listed beside it)
