@@ -1206,6 +1206,7 @@ struct AggLayer1 {
     const float *T1 = nullptr;    // (32, C) folded embedding table
     float *pool_partial = nullptr;
     int ldp = 0;
+    int reverse = 0;              // walk the protein list from its end (see launch_aggregate)
 };
 template <int ROWBLOCKS, bool L1 = false>
 __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const unsigned long long *__restrict__ masks,
@@ -1219,7 +1220,8 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef float v4f __attribute__((ext_vector_type(4)));
     const int slabs = C / AGG_SL;
-    const int p = plist[blockIdx.x / slabs], slab = blockIdx.x % slabs;
+    const int pi = blockIdx.x / slabs, slab = blockIdx.x % slabs;
+    const int p = plist[l1.reverse ? (int)(gridDim.x / slabs) - 1 - pi : pi];
     if (gate && gate[p] == 0) return;                            // not a binary map: the CSR gather launch takes this protein
     const int r0 = row_off[p], L = Lq[p];
     for (int e = threadIdx.x; e < 256 * 8; e += AGG_THREADS) lut[e] = ((e >> 3) >> (e & 7)) & 1 ? 0x3f80 : 0;
@@ -1977,10 +1979,17 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
 #define MDF_AGG_ARGS(n_) dim3((unsigned)(n_) * slabs), dim3(AGG_THREADS), 0, st, Hin, Cin, reinterpret_cast<const unsigned long long *>(agg->masks), \
                          agg->W, agg->dinv, reinterpret_cast<const unsigned long long *>(agg->blk), agg->row_off, agg->Lq, pl, agg->gate, AH,              \
                          agg->tail_p, (int)agg->tail_row0, Ri
+        // Chunks beyond ~100 000 rows: a 512-channel slab no longer fits the 256 MiB Infinity Cache, and a kernel that reads its operand in
+        // the order the previous kernel wrote it finds nothing of it there.  The aggregation walks its proteins from the END of the list
+        // (MDFRI_AX_REVERSE=0: from the start): the rows the H.W product wrote last are read first, and the rows it writes last -- the
+        // chunk's first -- are the ones the next product starts with.  Same workgroups, same arithmetic: bit-identical.
+        static const int reverse = getenv("MDFRI_AX_REVERSE") ? atoi(getenv("MDFRI_AX_REVERSE")) : 1;
+        AggLayer1 l1v = l1 ? *l1 : AggLayer1(), plainv;
+        l1v.reverse = plainv.reverse = reverse;
 #define MDF_AGG(RB, n_)                                                                                  \
     if ((n_) > 0) {                                                                                      \
-        if (l1) hipLaunchKernelGGL((k_aggregate_mfma<RB, true>), MDF_AGG_ARGS(n_), *l1);                 \
-        else hipLaunchKernelGGL((k_aggregate_mfma<RB, false>), MDF_AGG_ARGS(n_), AggLayer1());           \
+        if (l1) hipLaunchKernelGGL((k_aggregate_mfma<RB, true>), MDF_AGG_ARGS(n_), l1v);                 \
+        else hipLaunchKernelGGL((k_aggregate_mfma<RB, false>), MDF_AGG_ARGS(n_), plainv);                \
     }                                                                                                    \
     pl += (n_);
         MDF_AGG(1, agg->n_mf[0])
