@@ -432,6 +432,21 @@ def test_layer1_made_inside_the_aggregation_kernel_is_bit_identical():
     assert sha["1"] == sha["0"], sha
 
 
+def test_aggregation_order_knob_is_bit_identical():
+    """k_aggregate_mfma takes its proteins from the END of the chunk's list by default (the rows the H.W product wrote last are read first:
+    they are the ones a 512-MiB slab still has in the Infinity Cache); MDFRI_AX_REVERSE=0 walks the list from the start.  Which workgroup
+    takes which protein changes nothing of what is computed -- including the chunk's trailing rows, zeroed by the LAST protein's workgroups,
+    which now start first: the same bits, each order in a process of its own, over the batches of the layer-1 form test."""
+    import subprocess
+    import sys
+    sha = {}
+    for rev in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", _layer1_form_script()], env=dict(os.environ, MDFRI_AX_REVERSE=rev), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        sha[rev] = out.stdout.split("SHA", 1)[1].strip()
+    assert sha["1"] == sha["0"], sha
+
+
 def test_split_form_on_cu_masked_streams_is_bit_identical():
     """MDFRI_SPLIT_CUS=192 (developer knob, read at engine creation): the H.W products on 192 CUs, contact stage + layer 1 + aggregations on the
     other 64, two stacks in flight on two sets of slabs, stage by stage through mdf_gcn_stage_dev with events in between
