@@ -952,7 +952,7 @@ __global__ __launch_bounds__(FILL_THREADS) void k_cmap_fill_rows(const int32_t *
             }
             const float2 en = my_col[jn];
             const float v = (di * 1.0f) * e.x;
-            if (CSR && (t & 7) == k && (unsigned)(pos + t) < (unsigned)nnz_cap) {   // (unsigned: a position past 2^31 -- an overflow the status word reports -- is not a small negative index)
+            if (CSR && (t & 7) == k && (unsigned)pos + (unsigned)t < (unsigned)nnz_cap) {   // (unsigned: a position past 2^31 -- an overflow the status word reports -- is not a small negative index)
                 colidx[pos + t] = r0 + j;
                 val[pos + t] = v;
             }
