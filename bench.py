@@ -45,6 +45,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)   # mdfri_testkit: synthetic workloads + weights (not part of the product package)
 
 import numpy as np  # noqa: E402
+from mDeepFRI._hip import DEFAULT_CHUNK_ROWS  # noqa: E402   (a constant of the module: importing it loads neither the library nor the HIP runtime)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
@@ -63,7 +64,7 @@ def parse(argv=None):
                     help="proteins per GPU per step for the weak workloads (default 10000 = configs[2]); TOTAL proteins for configs3/configs4 "
                          "(default 100000 / 500000)")
     ap.add_argument("--length", type=int, default=512)
-    ap.add_argument("--chunk-rows", type=int, default=262144,
+    ap.add_argument("--chunk-rows", type=int, default=DEFAULT_CHUNK_ROWS,
                     help="residue rows per fused chunk (multiples of 32768 = full rounds of 256x256 GEMM tiles on 256 CUs); default = the library's MDF_DEFAULT_CHUNK_ROWS")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, help="single-thread worker processes of the all-core leg (0 = min(cores, 32))")
@@ -849,7 +850,7 @@ def main():
                     a = AlignmentResult(query_name=f"p{k}", query_sequence=seqs[k], target_name=f"t{k}", target_sequence=seqs[k], alignment="M" * len(seqs[k]))
                     a.gapped_sequence, a.gapped_target, a.coords = q_alns[k], t_alns[k], coords[k]
                     alns.append(a)
-                dense_rows = min(args.chunk_rows, 65536)   # (1 MiB of map per protein at L = 512: chunks of 128 proteins keep the double-buffered upload busy)
+                dense_rows = min(args.chunk_rows, batch.DENSE_CHUNK_ROWS)   # (1 MiB of map per protein at L = 512: chunks of 128 proteins keep the double-buffered upload busy)
                 maps = [cm for _, cm in batch.build_align_contact_maps(alns, device=local_rank, max_rows=dense_rows)]
                 pk_d = batch.PackedProteins.pack(seqs[:n], max_rows=dense_rows)
                 db_d = eng.upload(pk_d)

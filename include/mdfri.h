@@ -262,7 +262,7 @@ int mdf_seq_encode_dev(const char *seqs, const int32_t *seq_off, const int32_t *
  * status: device int32[4], zero-initialised by the caller: [0] != 0 -> CSR overflow (needed nnz in [1]); [2] != 0 -> a query
  * longer than max_len was met (its length in [2]): the result of that protein is invalid.
  * seq_idx / letter_sums (both or neither): with the residue indices of mdf_seq_encode_dev given, the layer-1 operand of
- * mdf_gcn_embed_dev (see mdf_letter_sums_dev) is written in the same pass as the CSR -- (R, 32) f32.
+ * mdf_gcn_embed_dev (see mdf_letter_sums_dev) is written in the same pass as the CSR -- R x 32 f32 in the order of MDF_LSUM_INDEX.
  * The coordinates are read ONCE: a first kernel counts every row's contacts and stores the contact bits, the CSR is filled
  * from the bits.  workspace: mdf_cmap_workspace_bytes(B, R, max_len) bytes of device scratch (max_len = 0: the size the
  * dense-format and dense-to-CSR entry points below need). */
@@ -301,9 +301,17 @@ int mdf_dense_to_csr_masks_dev(const void *cmaps, int cmap_dtype, const int64_t 
                                int32_t B, int64_t R, int32_t max_len, int32_t *rowptr, int32_t *colidx, float *val, int64_t nnz_cap,
                                int32_t *status, int32_t *binary, void *workspace, size_t workspace_bytes, void *stream);
 
-/* Layer-1 operand, shared by every GO head: letter_sums[i][a] = sum of val over the CSR entries of row i whose column
- * residue is letter a  (= (Ahat . onehot)[i][a]); (R, 32) f32, columns 26..31 zero.  With the embedding folded at model
- * load (relu(onehot W_aa) W_gc1 is a 26-row table), GraphConv layer 1 is elu(letter_sums . table). */
+/* Layer-1 operand, shared by every GO head: S[i][a] = sum of val over the CSR entries of row i whose column
+ * residue is letter a  (= (Ahat . onehot)[i][a]); R x 32 f32, letters 26..31 zero.  With the embedding folded at model
+ * load (relu(onehot W_aa) W_gc1 is a 26-row table), GraphConv layer 1 is elu(S . table).
+ * Storage order (round 6): `letter_sums` is an operand between two stages of this library, and it is stored the way its hottest reader
+ * -- the aggregation kernel that makes layer 1 from it on the fp32 matrix instruction -- takes it: per 16-row group (MDF_GROUP_ROWS) 512
+ * floats, element (row, letter a) at MDF_LSUM_INDEX(row, a): the 16 bytes a lane of that kernel loads are the four letters it feeds to four
+ * consecutive matrix instructions, a wave's load instruction covers 2 x 512 contiguous bytes (8 cache lines instead of 32: the row-major
+ * form cost 160 of 500 us per launch in L1 line look-ups, profiles/r06_ax_timeline.txt).  Every producer (mdf_cmap_csr_dev,
+ * mdf_letter_sums_dev) and consumer (mdf_gcn_embed_*_dev, mdf_gcn_stage_dev) of this library uses the macro. */
+#define MDF_LSUM_INDEX(row, a) \
+    ((size_t)((row) >> 4) * 512 + (size_t)((((a) >> 3) * 128) + ((((a) & 1) * 16 + ((row) & 15)) * 4) + (((a) >> 1) & 3)))
 int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
                         float *letter_sums, void *stream);
 
@@ -323,8 +331,17 @@ int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int
 #define MDF_AGG_MIN_LEN 112
 #define MDF_AGG_MAX_LEN 1024
 typedef struct mdf_agg_desc {
-    const uint64_t *masks;      /* (R, W) device: bit j of word (r0+i, j/64) = A'[i][j] (diagonal set); rows >= Lq of a protein all zero */
+    const uint64_t *masks;      /* (R, W) device: bit j of word (r0+i, j/64) = A'[i][j] (diagonal set); rows >= Lq of a protein all zero.
+                                 * What mdf_agg_prepare_dev read; the aggregation kernels read `tiles` below */
     int32_t W;
+    const uint8_t *tiles;       /* device, from mdf_agg_prepare_dev: the same bits in the order the matrix-pipe kernel takes them (round 6).
+                                 * Protein p (first row r0, nch = ceil(Lq / 256) column chunks) owns the bytes from r0 * tile_row_bytes on;
+                                 * 16-row group g of the protein x column chunk c is a 512-byte tile at ((g * nch + c) * 512), byte
+                                 * ((i % 16) * 2 + h) * 16 + cb of it = the bits of row 16 g + i % 16, columns 256 c + 16 cb + 8 h .. + 7:
+                                 * a lane of the kernel (row, lane half h) gets the A-operand bytes of all 16 column blocks of a chunk in ONE
+                                 * 16-byte load, and a wave's load covers 2 x 512 contiguous bytes (8 cache lines; the word form: 4 loads
+                                 * of 16-32 lines each -- four fifths of the kernel's L1 line look-ups) */
+    int32_t tile_row_bytes;     /* 32 * ceil(min(max_len, MDF_AGG_MAX_LEN) / 256): mdf_agg_tile_row_bytes(max_len) */
     const float *dinv;          /* (R) device: 1 / (1e-6 + sqrt(degree)), from mdf_agg_prepare_dev */
     const uint64_t *blk;        /* (B, 32) device: bit c of entry (p, b): rows [32b, 32b+32) of protein p have a contact in columns [16c, 16c+16) */
     const int32_t *row_off;     /* (B+1) device */
@@ -361,9 +378,12 @@ int mdf_agg_class(int32_t L, int resident);
 int mdf_agg_l1_fused(int32_t L);
 
 /* dinv (R) and blk (B, 32) from the contact bits and the per-row degrees (counts: int32 (R), the number of set bits of a row) that
- * the contact stage leaves in its workspace (mdf_cmap_ws_view).  Proteins longer than MDF_AGG_MAX_LEN get no blk entry. */
+ * the contact stage leaves in its workspace (mdf_cmap_ws_view), and the contact bits once more as the byte tiles the matrix-pipe kernel
+ * loads (mdf_agg_desc.tiles).  Proteins longer than MDF_AGG_MAX_LEN (or shorter than MDF_AGG_MIN_LEN) get no blk entry and no tiles. */
 int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts, const int32_t *row_off, const int32_t *Lq, int32_t B,
-                        int64_t R, float *dinv, uint64_t *blk, void *stream);
+                        int64_t R, float *dinv, uint64_t *blk, uint8_t *tiles, int32_t tile_row_bytes, void *stream);
+/* ... `tiles`: R * mdf_agg_tile_row_bytes(max_len) bytes (max_len: the longest protein of the R rows), see mdf_agg_desc.tiles. */
+int32_t mdf_agg_tile_row_bytes(int32_t max_len);
 /* Pointers into a contact-stage workspace (laid out for R rows, max_len) after mdf_cmap_csr_dev / mdf_dense_to_csr_masks_dev ran on it. */
 int mdf_cmap_ws_view(void *workspace, size_t workspace_bytes, int64_t R, int32_t max_len, const uint64_t **masks, int32_t *W,
                      const int32_t **counts);
@@ -503,7 +523,12 @@ typedef struct {
 int mdf_engine_forward_alignments(mdf_engine *e, const mdf_plan *plan, const mdf_batch_dev *batch, float *const *scores,
                                   float *const *logits, void *stream);
 /* The reference-format path: one dense (Lq,Lq) contact map per protein (what build_align_contact_map returns) in HOST
- * memory, all of cmap_dtype (MDF_DT_I32 or MDF_DT_F32), uploaded chunk by chunk.  Synchronises `stream` before returning. */
+ * memory, all of cmap_dtype (MDF_DT_I32 or MDF_DT_F32), uploaded chunk by chunk.  Synchronises `stream` before returning.
+ * Footprint: the engine keeps TWO pinned host slots and TWO device slots of (sum of Lq^2 over a chunk's proteins) x 4 B each, about
+ * chunk rows x Lq x 4 B: plan this path with MDF_DENSE_CHUNK_ROWS rows per chunk (128 MiB per slot at Lq = 512, 1 GiB at Lq = 4 096),
+ * not with MDF_DEFAULT_CHUNK_ROWS (four times that, and the first chunk's host copy overlaps nothing); the Python layer
+ * (HotPathEngine.forward_dense) re-plans a batch that was planned with larger chunks. */
+#define MDF_DENSE_CHUNK_ROWS 65536
 int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *plan, const mdf_batch_dev *batch, const void *const *cmaps_host,
                              int cmap_dtype, float *const *scores, float *const *logits, void *stream);
 /* Synchronise `stream` and report what the asynchronous stages flagged, in the order the per-call API would raise it:

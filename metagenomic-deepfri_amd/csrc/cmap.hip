@@ -784,9 +784,9 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
     }
     wave_sync_lds();
     if (letter_sums) {
-        for (int e = lane; e < 8 * 32; e += 64) {
-            const int k = e >> 5, a = e & 31;
-            letter_sums[(size_t)(wrow0 + k) * 32 + a] = (a < 26) ? s_bins[wid * 8 + k][a] : 0.0f;
+        for (int e = lane; e < 8 * 32; e += 64) {   // (storage order MDF_LSUM_INDEX: the wave's 8 rows x 4 letters are 128 contiguous bytes)
+            const int q = e >> 6, hf = (e >> 5) & 1, k = (e >> 2) & 7, c = e & 3, a = 8 * q + 2 * c + hf;
+            letter_sums[MDF_LSUM_INDEX((size_t)(wrow0 + k), a)] = (a < 26) ? s_bins[wid * 8 + k][a] : 0.0f;
         }
     }
 }
@@ -976,9 +976,11 @@ __global__ __launch_bounds__(FILL_THREADS) void k_cmap_fill_rows(const int32_t *
 #endif
     __syncthreads();
     if (LS) {
+        // storage order MDF_LSUM_INDEX: the block's 32 rows are two 16-row groups of 512 floats, written as they lie in memory
+        static_assert(FILL_ROWS % 16 == 0, "a block of the fill kernel covers whole 16-row groups");
         for (int e = tid; e < FILL_ROWS * 32; e += FILL_THREADS) {
-            const int r = e >> 5, a = e & 31;
-            letter_sums[(size_t)(row0 + r) * 32 + a] = (a < 26) ? s_bins[r * 33 + a] : 0.0f;
+            const int g = e >> 9, q = (e >> 7) & 3, hf = (e >> 6) & 1, r = (e >> 2) & 15, c = e & 3, a = 8 * q + 2 * c + hf;
+            letter_sums[(size_t)(row0 >> 4) * 512 + e] = (a < 26) ? s_bins[(g * 16 + r) * 33 + a] : 0.0f;
         }
     }
     MDF_FILL_STAMP(4)

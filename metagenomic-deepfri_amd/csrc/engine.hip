@@ -537,7 +537,7 @@ struct mdf_engine {
     // the contact stage's outputs exist twice: while the GraphConv stacks of chunk c read one set, the contact stage of chunk
     // c+1 fills the other on a second stream (pipelined fused path); everything else uses set 0
     struct ContactSet {
-        DevBuf rowptr, colidx, val, seq_idx, lsum, cws, dinv, blk;   // dinv / blk: operands of the matrix-pipe aggregation (mdf_agg_prepare_dev)
+        DevBuf rowptr, colidx, val, seq_idx, lsum, cws, dinv, blk, tiles;   // dinv / blk / tiles: operands of the matrix-pipe aggregation (mdf_agg_prepare_dev)
         hipEvent_t ready = nullptr, free = nullptr;
     } cs[2];
     hipStream_t aux = nullptr;        // low-priority stream of the pipelined contact stage
@@ -680,7 +680,7 @@ extern "C" void mdf_engine_free(mdf_engine *e)
     drop_graphs(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (auto &c : e->cs) {
-        for (DevBuf *b : {&c.rowptr, &c.colidx, &c.val, &c.seq_idx, &c.lsum, &c.cws, &c.dinv, &c.blk}) b->release();
+        for (DevBuf *b : {&c.rowptr, &c.colidx, &c.val, &c.seq_idx, &c.lsum, &c.cws, &c.dinv, &c.blk, &c.tiles}) b->release();
         if (c.ready) (void)hipEventDestroy(c.ready);
         if (c.free) (void)hipEventDestroy(c.free);
     }
@@ -743,6 +743,7 @@ static int ensure(mdf_engine *e, int64_t rows, int32_t B, int32_t max_len, int64
             if (int rc = c.cws.grow(mdf_cmap_workspace_bytes(1 << 20, rows, max_len), gen)) return rc;
             if (int rc = c.dinv.grow((size_t)rows * 4, gen)) return rc;
             if (int rc = c.blk.grow((size_t)(rows / GROUP_ROWS + 1) * 32 * 8, gen)) return rc;   // (B, 32) x 64 bits; at most rows / 16 proteins in a chunk
+            if (int rc = c.tiles.grow((size_t)rows * mdf_agg_tile_row_bytes(max_len), gen)) return rc;   // the contact bits as the kernel's byte tiles
         }
         if (int rc = e->gws.grow(gws, gen)) return rc;
         if (e->split_cus)
@@ -812,9 +813,11 @@ static int chunk_agg_desc(mdf_engine *e, mdf_engine::ContactSet &c, const mdf_pl
     int32_t W = 0;
     if (int rc = mdf_cmap_ws_view(c.cws.p, c.cws.bytes, ch.rows, ch.max_len, &masks, &W, &counts)) return rc;
     const int32_t *d_ro = pl->d_chunk_row_off + ch.row_off_pos, *d_lq = b->Lq + ch.p0;
-    if (int rc = mdf_agg_prepare_dev(masks, W, counts, d_ro, d_lq, ch.p1 - ch.p0, ch.rows, c.dinv.as<float>(), c.blk.as<uint64_t>(), st)) return rc;
+    const int32_t Wt = mdf_agg_tile_row_bytes(ch.max_len);
+    if (int rc = mdf_agg_prepare_dev(masks, W, counts, d_ro, d_lq, ch.p1 - ch.p0, ch.rows, c.dinv.as<float>(), c.blk.as<uint64_t>(), c.tiles.as<uint8_t>(), Wt, st)) return rc;
     for (int kind = 0; kind < 2; ++kind) {
         mdf_agg_desc &a = agg[kind];
+        a.tiles = c.tiles.as<uint8_t>(), a.tile_row_bytes = Wt;
         a.masks = masks, a.W = W, a.dinv = c.dinv.as<float>(), a.blk = c.blk.as<uint64_t>(), a.row_off = d_ro, a.Lq = d_lq;
         a.tail_row0 = ch.tail_row0;
         bool last_listed;

@@ -1201,124 +1201,212 @@ __device__ __forceinline__ int agg_xt_off(int term, int ch, int slot) { return (
 // here, per 32-row tile and channel slab, on the fp32 matrix instruction -- v_mfma_f32_32x32x2_f32 fed the letters (2 i, 2 i + 1) is, per
 // output, the FMA chain of k_layer1 in the same order, so H1, its pooling partial sums (handed from lane half to lane half in row order)
 // and with them everything downstream are bit-identical to the k_layer1 + k_aggregate_mfma<.., false> pair -- and never touch HBM.
+static_assert(GROUP_ROWS == 16, "MDF_LSUM_INDEX (mdfri.h) lays the letter sums out per 16-row group");
 struct AggLayer1 {
-    const float *S = nullptr;     // (R, 32) letter sums of the contact stage
+    const float *S = nullptr;     // R x 32 letter sums of the contact stage, stored in the order of MDF_LSUM_INDEX (mdfri.h)
     const float *T1 = nullptr;    // (32, C) folded embedding table
     float *pool_partial = nullptr;
     int ldp = 0;
     int reverse = 0;              // walk the protein list from its end (see launch_aggregate)
 };
+#ifdef MDF_AX_PROBE   // developer build (tools/ax_timeline.py): wall-clock stamps (100 MHz) of every wave at the phase boundaries below
+__device__ unsigned long long *g_ax_probe = nullptr;   // [workgroup][8 waves][32]
+#define MDF_AX_STAMP(k_) if (g_ax_probe && lane == 0 && (k_) < 32) g_ax_probe[((size_t)blockIdx.x * 8 + wid) * 32 + (k_)] = wall_clock64();
+#else
+#define MDF_AX_STAMP(k_)
+#endif
+// Round 6 -- what the time stamps inside the kernel showed (tools/ax_timeline.py, profiles/r06_ax_timeline.txt), and what follows from it:
+//  * the kernel is bound by what ONE CU gets through, and that is resident workgroups / life of a workgroup: the plain form runs THREE
+//    workgroups per CU (<= 84 registers, <= 53 KiB of LDS) and loses 8-17 % as soon as it has two -- whatever the two do faster;
+//  * a load instruction costs the CU's L1 one look-up per 128-byte line it touches: the letter sums of a tile, read row-major (32 lines per
+//    instruction, 7 instructions), were 160 of 500 us of the layer-2 launch -- they are now stored in the order the matrix instruction
+//    takes them (MDF_LSUM_INDEX, mdfri.h: 8 lines per instruction, 4 instructions);
+//  * up to nine SERIAL memory round trips per 256-row chunk stood in front of ~3 000 cycles of work per wave (the letter sums in four
+//    instalments interleaved with the fp32 matrix chain, d_j behind the first barrier, per row block the populated-block word and then
+//    the contact words behind it).
+// The two forms therefore differ in what they keep in flight:
+//   L1 form (two workgroups per CU either way: 16 more registers of layer-1 tile)
+//     once per workgroup   d_j of the protein's rows -> LDS (`dl`; the split and the epilogue read it there), the slab's slice of T1 -> LDS,
+//                          the wave's populated-block words (scalar registers);
+//     one chunk ahead      the next tile's letter sums (right behind the chain that consumed the previous ones), the contact words of the
+//                          wave's row blocks (behind the matrix phase that consumed the previous ones).  Requested on EVERY path, beyond the
+//                          protein too (out of the descriptor's range: zeros, no memory access): the compiler's wait counters assume the worst
+//                          order of requests over all paths into a wait, and one skipped request makes everything older look youngest.
+//   plain form (three workgroups per CU: nothing may live in registers across a phase)
+//     the populated-block words once per workgroup; the chunk's rows and their d_j at the top of the chunk; the contact words of row block 0
+//     in front of the second barrier, those of row block b + 1 in front of row block b's matrix instructions.
+// `sched_barrier`s keep the compiler from sinking the requests back to their first use.  Same operands, same order of every sum:
+// bit-identical to the round-5 kernel (tools/ax_ab.py prints a digest of the scores for two builds of the library).
 template <int ROWBLOCKS, bool L1 = false>
-__global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const unsigned long long *__restrict__ masks,
-                                                                   int W, const float *__restrict__ dinv, const unsigned long long *__restrict__ blk,
+__global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const uint8_t *__restrict__ tiles,
+                                                                   int Wt, const float *__restrict__ dinv, const unsigned long long *__restrict__ blk,
                                                                    const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq,
                                                                    const int32_t *__restrict__ plist, const int32_t *__restrict__ gate,
                                                                    float *__restrict__ out, int tail_p, int tail_row0, int R, AggLayer1 l1)
 {
     __shared__ __attribute__((aligned(16))) unsigned short xt[3 * AGG_SL * AGG_CHR];   // 48 KiB; re-used as 8 x 5 KiB output staging at the end
     __shared__ __attribute__((aligned(16))) unsigned short lut[256 * 8];                // contact byte -> its 8 bf16 (0.0 / 1.0): one ds_read_b128
+    __shared__ __attribute__((aligned(16))) float dl[L1 ? ROWBLOCKS * AGG_CHR : 4];     // L1: d_j of the protein's rows, 0.0 from row L on
+    __shared__ __attribute__((aligned(16))) float t1l[L1 ? 4 * 64 * 4 : 4];             // L1: the slab's slice of T1 as the waves' B operands: [i / 4][lane][i % 4] = T1[2 i + (lane >> 5)][slab column lane & 31]
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    constexpr bool MW_AHEAD = L1;   // contact bytes one chunk ahead (4 registers per row block)
+    constexpr int NDL = L1 ? (ROWBLOCKS * AGG_CHR + AGG_THREADS - 1) / AGG_THREADS : 1;
     const int slabs = C / AGG_SL;
     const int pi = blockIdx.x / slabs, slab = blockIdx.x % slabs;
     const int p = plist[l1.reverse ? (int)(gridDim.x / slabs) - 1 - pi : pi];
     if (gate && gate[p] == 0) return;                            // not a binary map: the CSR gather launch takes this protein
     const int r0 = row_off[p], L = Lq[p];
-    for (int e = threadIdx.x; e < 256 * 8; e += AGG_THREADS) lut[e] = ((e >> 3) >> (e & 7)) & 1 ? 0x3f80 : 0;
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int frow = lane & 31, half = lane >> 5;
     const int oct = threadIdx.x >> 4, cp = threadIdx.x & 15;     // staging role: rows 8 oct .. 8 oct + 7 of the chunk, channels 2 cp, 2 cp + 1
+    const float *Hs = H + (size_t)r0 * C + slab * AGG_SL;
+    const int Lpad = (L + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
+    // Every memory access goes through a buffer descriptor sized to the protein: rows at or beyond L read as zeros and stores beyond the
+    // padded rows are dropped by the range check -- no predicate, no branch, no 64-bit address arithmetic per access.  (raw buffers, byte
+    // offsets; 0x00020000 = gfx9 DWORD3; only the vector offset + the instruction's immediate are range-checked, so everything that decides
+    // "inside or outside" is in the vector offset)
+    const unsigned rowB = (unsigned)C * 4u;   // bytes per residue row
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Hs), 0, (int)((unsigned)L * rowB), 0x00020000);
+    // the protein's contact bits as byte tiles (mdfri.h mdf_agg_desc.tiles): 16-row group g x column chunk c at (g * nch + c) * 512
+    const int nch = (L + AGG_CHR - 1) / AGG_CHR;
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(tiles + (size_t)r0 * Wt), 0, (Lpad >> 4) * nch * 512, 0x00020000);
+    // L1: the letter sums of the protein's 16-row groups, 2 KiB each in the order of MDF_LSUM_INDEX (rows [L, Lpad) hold zeros: they have no contacts)
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L1 ? l1.S + (size_t)r0 * 32 : Hs), 0, L1 ? Lpad * 128 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dinv + r0), 0, Lpad * 4, 0x00020000);   // (0.0 for rows in [L, Lpad): k_agg_prepare)
+    // L1: the pooling partial sums of the protein's groups (base at its first group and this slab; 1 GiB: any offset inside a protein fits)
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(L1 ? l1.pool_partial + (size_t)(r0 >> 4) * l1.ldp + slab * AGG_SL : const_cast<float *>(Hs), 0, L1 ? 1 << 30 : 0, 0x00020000);
+    constexpr int OUTSIDE = 0x7ffffff0;       // a vector offset no descriptor of this kernel covers: the load returns zeros, the store is dropped
+    MDF_AX_STAMP(0)
+
+    // ---- requests of the whole workgroup life (and, L1, of chunk 0), oldest first: a wait for an early one leaves the later ones in flight
+    float dreg[NDL];
+    if (L1) {
+#pragma unroll
+        for (int e = 0; e < NDL; ++e) dreg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, (int)(threadIdx.x + e * AGG_THREADS) * 4, 0, 0));
+    }
+    unsigned long long bw[ROWBLOCKS];   // which 16-column blocks of the wave's row blocks hold a contact (wave-uniform: scalar registers)
+#pragma unroll
+    for (int b = 0; b < ROWBLOCKS; ++b) bw[b] = (b * 8 + wid) * 32 < L ? blk[(size_t)p * 32 + b * 8 + wid] : 0ull;
+    float t1r[2];   // L1: the two entries of `t1l` this thread fetches (13 registers per lane for the kernel's life were one too many at 128)
+    v4f sv[4];      // L1: this lane's A operands of the current tile: sv[q][c] = S[row frow of the tile][2 (4 q + c) + half]
+    u32x4v mwa[MW_AHEAD ? ROWBLOCKS : 1];   // L1: contact bytes of the current chunk's 16 column blocks for the wave's row blocks
+    auto request_sums = [&](int j0r) {   // a load instruction of the wave covers 2 x 512 contiguous bytes; groups from Lpad on: out of range, zeros
+        const int row = j0r + wid * 32 + frow;
+        const int vo = (row >> 4) * 2048 + (half * 16 + (row & 15)) * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sv[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsS, vo, q * 512, 0));
+    };
+    // the contact bytes of this lane's row of row block b (of the wave) for the 16 column blocks of the chunk at j0r: ONE 16-byte load, byte cb =
+    // the lane half's 8 columns of column block cb.  Groups from Lpad on: out of the descriptor's range = zeros; a (row block, chunk) without a
+    // populated block -- most of them far from the diagonal --, or a chunk behind the protein: an offset outside the descriptor instead of a
+    // branch (no memory access, one path for the wait counters)
+    auto request_bytes = [&](int b, int j0r) -> u32x4v {
+        const bool any = j0r < L && ((unsigned)(bw[b] >> (j0r >> 4)) & 0xffffu) != 0;   // (wave-uniform)
+        const int vo = (((b * 8 + wid) * 2 + (frow >> 4)) * nch + (j0r >> 8)) * 512 + ((frow & 15) * 2 + half) * 16;
+        return __builtin_bit_cast(u32x4v, __builtin_amdgcn_raw_buffer_load_b128(rsM, any ? vo : OUTSIDE, 0, 0));
+    };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sv[q] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
+    if (L1) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int en = threadIdx.x + e * AGG_THREADS, i = (en >> 8) * 4 + (en & 3), ln = (en >> 2) & 63;   // (letters 26 .. 31: zero rows of T1)
+            t1r[e] = l1.T1[(size_t)(2 * i + (ln >> 5)) * C + slab * AGG_SL + (ln & 31)];
+        }
+        request_sums(0);
+#pragma unroll
+        for (int b = 0; b < (MW_AHEAD ? ROWBLOCKS : 0); ++b) mwa[b] = request_bytes(b, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int e = threadIdx.x; e < 256 * 8; e += AGG_THREADS) lut[e] = ((e >> 3) >> (e & 7)) & 1 ? 0x3f80 : 0;
+    if (L1) {
+#pragma unroll
+        for (int e = 0; e < NDL; ++e)
+            if ((int)(threadIdx.x + e * AGG_THREADS) < ROWBLOCKS * AGG_CHR) dl[threadIdx.x + e * AGG_THREADS] = dreg[e];
+        t1l[threadIdx.x] = t1r[0], t1l[threadIdx.x + AGG_THREADS] = t1r[1];
+        __syncthreads();   // (the first chunk's tiles are made in front of the loop's first barrier)
+    }
     f32x16 acc[ROWBLOCKS];
 #pragma unroll
     for (int b = 0; b < ROWBLOCKS; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
-    const float *Hs = H + (size_t)r0 * C + slab * AGG_SL;
-    const int Lpad = (L + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS;
-    // Round 5: the kernel is bound by instruction issue (74 % of every SIMD's issue slots, profiles/r05_ax_pmc.txt), so its memory accesses go
-    // through buffer descriptors sized to the protein: rows at or beyond L read as zeros and stores beyond the padded rows are dropped by the
-    // range check -- no predicate, no branch, no 64-bit address arithmetic per access.  (raw buffers, byte offsets; 0x00020000 = gfx9 DWORD3;
-    // only the vector offset + the instruction's immediate are range-checked, so everything that decides "inside or outside" is in the vector offset)
-    const unsigned rowB = (unsigned)C * 4u;   // bytes per residue row
-    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Hs), 0, (int)((unsigned)L * rowB), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long *>(masks + (size_t)r0 * W), 0, L * W * 8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L1 ? l1.S + (size_t)r0 * 32 : Hs), 0, L1 ? L * 128 : 0, 0x00020000);   // L1: the letter sums
-    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dinv + r0), 0, Lpad * 4, 0x00020000);   // (0.0 for rows in [L, Lpad): k_agg_prepare)
-    float t1[13];   // L1: this lane's B operands, T1[2 i + half][slab column frow]
-    if (L1) {
-#pragma unroll
-        for (int i = 0; i < 13; ++i) t1[i] = l1.T1[(size_t)(2 * i + half) * C + slab * AGG_SL + frow];
-    }
+
     for (int j0 = 0; j0 < L; j0 += AGG_CHR) {
-        // ---- requests of this chunk: the rows to stage (scaled by d_j), and the contact bits of its 256 columns for the wave's row blocks
-        v2f x[8];
+        const int jt = j0 + wid * 32;            // L1: first row of the wave's 32-row tile of the chunk (wave-uniform)
+        MDF_AX_STAMP(1 + (j0 >> 8) * 6)
+        v2f x[8];       // plain: rows 8 oct .. + 7 of the chunk, channels 2 cp, 2 cp + 1, as they come from memory
+        v4f pd0, pd1;   // plain: their d_j
         f32x16 h1;
         if (!L1) {
+            // (a protein's rows are padded to a multiple of 16: d_j is readable up to jb + 7, zero in [L, Lpad), out of range beyond; rows from L
+            // on read as zeros.  The row offset goes into the VECTOR offset: the scalar offset of a buffer access is not range-checked)
             const int jb = j0 + oct * 8;
-            // (a protein's rows are padded to a multiple of 16: d_j is readable up to jb + 7, zero in [L, Lpad), out of range beyond)
-            const v4f d0 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsD, jb * 4, 0, 0));
-            const v4f d1 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsD, jb * 4, 16, 0));
-            const float dd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+            pd0 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsD, jb * 4, 0, 0));
+            pd1 = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsD, jb * 4, 16, 0));
             const int vo = jb * (int)rowB + cp * 8;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                // row jb + k; zeros from row L on.  (The row offset goes into the VECTOR offset: the scalar offset of a buffer access is not range-checked)
-                const v2f h = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsH, vo + k * (int)rowB, 0, 0));
-                x[k] = h * dd[k];
-            }
+            for (int k = 0; k < 8; ++k) x[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsH, vo + k * (int)rowB, 0, 0));
         } else {
-            // the wave's 32-row tile of the chunk: H1 = elu(S . T1) for the slab's 32 channels, 13 matrix instructions of two letters each
-            const int jt = j0 + wid * 32;            // first row of the tile (wave-uniform)
+            // the wave's tile: H1 = elu(S . T1) for the slab's 32 channels, 13 matrix instructions of two letters each
 #pragma unroll
             for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
             if (jt < Lpad) {
-                const int j = jt + frow;
-                v4f sr[7];
 #pragma unroll
-                for (int q = 0; q < 7; ++q) sr[q] = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsS, j * 128, q * 16, 0));   // zeros from row L on
+                for (int i4 = 0; i4 < 4; ++i4) {
+                    const v4f t = *reinterpret_cast<const v4f *>(t1l + i4 * 256 + lane * 4);
 #pragma unroll
-                for (int i = 0; i < 13; ++i) {
-                    const float lo = sr[(2 * i) >> 2][(2 * i) & 3], hi = sr[(2 * i + 1) >> 2][(2 * i + 1) & 3];
-                    h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? hi : lo, t1[i], h1, 0, 0, 0);
+                    for (int c = 0; c < 4; ++c)
+#ifdef AX_ABL_CHAIN   // (probe build only: 1 of the 13 matrix instructions)
+                        if (i4 * 4 + c < 1) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i4][c] + sv[3][0], t[c], h1, 0, 0, 0);
+#else
+                        if (i4 * 4 + c < 13) h1 = __builtin_amdgcn_mfma_f32_32x32x2f32(sv[i4][c], t[c], h1, 0, 0, 0);
+#endif
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h1[r] = elu1(h1[r]);
                 // pooling partial sums of the tile's two 16-row groups, rows added in ascending order as k_layer1 does: rows 4 ph .. 4 ph + 3 of a
                 // group live in lane half (ph & 1), registers 4 (ph >> 1) .. + 3 (group 0) / 8 + ... (group 1); the running sums change halves
+                // three times (v_permlane32_swap_b32 of a value with itself: first result = the lower half's value in every lane, second = the upper's)
                 float sA = 0.0f, sB = 0.0f;
 #pragma unroll
                 for (int ph = 0; ph < 4; ++ph) {
-                    float tA = sA, tB = sB;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        tA += h1[4 * (ph >> 1) + q];
-                        tB += h1[8 + 4 * (ph >> 1) + q];
+                        sA += h1[4 * (ph >> 1) + q];
+                        sB += h1[8 + 4 * (ph >> 1) + q];
                     }
-                    const bool mine = half == (ph & 1);
-                    sA = mine ? tA : sA;
-                    sB = mine ? tB : sB;
-                    const float oA = __shfl_xor(sA, 32, 64), oB = __shfl_xor(sB, 32, 64);
-                    sA = mine ? sA : oA;
-                    sB = mine ? sB : oB;
+                    if (ph < 3) {
+                        const unsigned ua = __float_as_uint(sA), ub = __float_as_uint(sB);
+                        sA = __uint_as_float(__builtin_amdgcn_permlane32_swap(ua, ua, false, false)[ph & 1]);
+                        sB = __uint_as_float(__builtin_amdgcn_permlane32_swap(ub, ub, false, false)[ph & 1]);
+                    }
                 }
-                if (half) {   // (the last rows of a group live in the upper half: it holds the finished sums)
-                    float *pp = l1.pool_partial + (size_t)((r0 + jt) >> 4) * l1.ldp + slab * AGG_SL + frow;
-                    pp[0] = sA;
-                    if (jt + GROUP_ROWS < Lpad) pp[l1.ldp] = sB;
-                }
+                // (the last rows of a group live in the upper half: it holds the finished sums; the lower half's stores, and the second group's
+                // when the protein ends in the tile's first, go to an offset outside the descriptor: dropped -- no branch, one path for the wait counters)
+                const int po = (jt >> 4) * l1.ldp * 4 + frow * 4;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sA), rsP, half ? po : OUTSIDE, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sB), rsP, half && jt + GROUP_ROWS < Lpad ? po + l1.ldp * 4 : OUTSIDE, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            request_sums(j0 + AGG_CHR);   // the next chunk's tile: in flight under everything below
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // (the contact bits of this chunk's 256 columns are fetched per row block inside the matrix phase: all row blocks' words at once
-        // would be 8 registers per block -- the other workgroups of the CU cover the latency)
-        __syncthreads();   // the previous chunk's fragments have been read (first chunk: the table is complete)
+        MDF_AX_STAMP(2 + (j0 >> 8) * 6)
+        __syncthreads();   // the previous chunk's fragments have been read (first chunk: the tables are complete)
+        MDF_AX_STAMP(3 + (j0 >> 8) * 6)
+        u32x4v mwp[ROWBLOCKS];   // plain: contact bytes of the wave's row blocks for this chunk
         if (!L1) {
+            const float dd[8] = {pd0.x, pd0.y, pd0.z, pd0.w, pd1.x, pd1.y, pd1.z, pd1.w};
 #pragma unroll
             for (int c = 0; c < 2; ++c) {   // this lane's 2 channels: 8 consecutive rows each = one 16-byte slot per term
                 bf16x8 th, tm, tl;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     unsigned short a, b, cc;
-                    float xs = x[k][c];
+                    float xs = x[k][c] * dd[k];
                     asm("" : "+v"(xs));   // (the d_j product is a rounded fp32 value HERE: never contracted into the split's subtraction -- both forms of the kernel stage the same bits)
                     agg_split3(xs, a, b, cc);
                     th[k] = (short)a, tm[k] = (short)b, tl[k] = (short)cc;
@@ -1328,14 +1416,16 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
                 *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(1, ch, oct)) = tm;
                 *reinterpret_cast<bf16x8 *>(xt + agg_xt_off(2, ch, oct)) = tl;
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < ROWBLOCKS; ++b) mwp[b] = request_bytes(b, j0);   // (the rows' registers are free again: in flight across the barrier)
+            __builtin_amdgcn_sched_barrier(0);
         } else {
             // this lane's channel (frow), rows 8 g + 4 half .. + 3 of the wave's tile: half a 16-byte slot per term and g
             typedef short bf16x4 __attribute__((ext_vector_type(4)));
-            const int jt = j0 + wid * 32;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int j = jt + 8 * g + 4 * half;
-                const v4f d = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(rsD, j * 4, 0, 0));   // (out of range from Lpad on: zeros)
+                const v4f d = *reinterpret_cast<const v4f *>(dl + jt + 8 * g + 4 * half);
                 bf16x4 th, tm, tl;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -1350,51 +1440,58 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
                 *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(2, frow, wid * 4 + g) + 4 * half) = tl;
             }
         }
+        MDF_AX_STAMP(4 + (j0 >> 8) * 6)
         __syncthreads();
+        MDF_AX_STAMP(5 + (j0 >> 8) * 6)
         // ---- every wave: its row blocks x the populated column blocks (16 rows of X each) of this chunk
         const int fbase = (frow * (AGG_CHR / 8)) * 16;   // byte offset of this lane's channel line (term 0) ...
         const int fx = frow & 15;                          // ... whose 16-byte slots are XOR-swizzled by this
 #pragma unroll
         for (int b = 0; b < ROWBLOCKS; ++b) {
-            const int rb = b * 8 + wid;
-            if (rb * 32 >= L) break;   // (wave-uniform)
-            const unsigned nz = (unsigned)(blk[(size_t)p * 32 + rb] >> (j0 >> 4)) & 0xffffu;
-            if (!nz) continue;
-            const int i = rb * 32 + frow;
-            // the contact words of row i for this chunk's 256 columns (rows from L on: out of the descriptor's range = zeros; words that lie beyond
-            // the protein's columns are not read: the conditions are wave-uniform)
-            const int mo = (i * W + (j0 >> 6)) * 8;
-            unsigned long long mw[4];
+#ifdef AX_ABL_MATRIX   // (probe build only: one populated block per row block and chunk)
+            const unsigned nz = (unsigned)(bw[b] >> (j0 >> 4)) & 0xffffu & 1u;
+#else
+            const unsigned nz = (unsigned)(bw[b] >> (j0 >> 4)) & 0xffffu;
+#endif
+            if (nz) {   // (wave-uniform; a row block beyond the protein has no populated block)
+                const u32x4v mw = MW_AHEAD ? mwa[MW_AHEAD ? b : 0] : mwp[b];
+                // four column blocks at a time (unrolled: their bytes lie in a register known at compile time), column blocks in ascending order:
+                // the same sums in the same order
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                mw[k] = (k == 0 || j0 + 64 * k < L) ? __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(rsM, mo, 8 * k, 0)) : 0ull;
-            // word by word (unrolled: the word is a register known at compile time -- round 4 selected it per block with 64-bit masks, ~20 scalar
-            // and vector instructions per populated block), column blocks in ascending order as before: the same sums in the same order
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                unsigned nzw = (nz >> (4 * w)) & 0xfu;   // (wave-uniform)
-                while (nzw) {
-                    const int q = __builtin_ctz(nzw);
-                    nzw &= nzw - 1;
-                    const int cb = 4 * w + q;
-                    const unsigned byte = (unsigned)(mw[w] >> (q * 16 + 8 * half)) & 0xffu;
-                    const bf16x8 af = *reinterpret_cast<const bf16x8 *>(lut + byte * 8);
-                    const char *fp = reinterpret_cast<const char *>(xt) + fbase + (((cb * 2 + half) ^ fx) << 4);
-                    const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(fp);
-                    const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(fp + AGG_SL * (AGG_CHR / 8) * 16);
-                    const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(fp + 2 * AGG_SL * (AGG_CHR / 8) * 16);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the fragment reads first ...
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2, acc[b], 0, 0, 0);   // smallest addends first
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[b], 0, 0, 0);
-                    acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[b], 0, 0, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the three matrix instructions
+                for (int w = 0; w < 4; ++w) {
+                    unsigned nzw = (nz >> (4 * w)) & 0xfu;   // (wave-uniform)
+                    while (nzw) {
+                        const int q = __builtin_ctz(nzw);
+                        nzw &= nzw - 1;
+                        const int cb = 4 * w + q;
+                        const unsigned byte = (mw[w] >> (8 * q)) & 0xffu;
+                        const bf16x8 af = *reinterpret_cast<const bf16x8 *>(lut + byte * 8);
+                        const char *fp = reinterpret_cast<const char *>(xt) + fbase + (((cb * 2 + half) ^ fx) << 4);
+                        const bf16x8 b0 = *reinterpret_cast<const bf16x8 *>(fp);
+                        const bf16x8 b1 = *reinterpret_cast<const bf16x8 *>(fp + AGG_SL * (AGG_CHR / 8) * 16);
+                        const bf16x8 b2 = *reinterpret_cast<const bf16x8 *>(fp + 2 * AGG_SL * (AGG_CHR / 8) * 16);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);   // the fragment reads first ...
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2, acc[b], 0, 0, 0);   // smallest addends first
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc[b], 0, 0, 0);
+                        acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc[b], 0, 0, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // ... then the three matrix instructions
+                    }
                 }
             }
+        }
+        MDF_AX_STAMP(6 + (j0 >> 8) * 6)
+        if (MW_AHEAD) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < (MW_AHEAD ? ROWBLOCKS : 0); ++b) mwa[b] = request_bytes(b, j0 + AGG_CHR);   // in flight under the next chunk's staging
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // ---- out[i, slab] = d_i * acc through a wave-private LDS tile: a 32 x 32 result leaves as 16-byte stores, 8 rows x 128 B per
     // instruction.  Rows [L, padded L) are written too (zeros): the H.W GEMM reads every row up to the next protein.
+    MDF_AX_STAMP(29)
     __syncthreads();   // every wave is done with the last chunk's fragments
+    MDF_AX_STAMP(30)
     float *ot = reinterpret_cast<float *>(xt) + wid * (32 * AGG_OPITCH);
     float *Os = out + (size_t)r0 * C + slab * AGG_SL;
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(Os, 0, (int)((unsigned)Lpad * rowB), 0x00020000);
@@ -1411,7 +1508,7 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
         for (int k = 0; k < 4; ++k) {
             const int i = ib + k * 8 + orow;
             // d_i is 0.0 in [L, Lpad) and reads as zero beyond; the store is dropped from row Lpad on (range check of the descriptor)
-            const float di = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, i * 4, 0, 0));
+            const float di = L1 ? dl[i] : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsD, i * 4, 0, 0));
             const v4f v = *reinterpret_cast<const v4f *>(ot + (k * 8 + orow) * AGG_OPITCH + oq * 4) * di;
             typedef unsigned u4s __attribute__((ext_vector_type(4)));
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4s, v), rsO, i * (int)rowB + oq * 16, 0, 2);   // (2 = non-temporal)
@@ -1419,6 +1516,7 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
+    MDF_AX_STAMP(31)
     // the rows behind the last protein of the launch (the chunk's rows are rounded up to 128) belong to nobody: zeroed by that protein's
     // workgroups -- when the last protein is a long one, the gather over its rows covers them
     if (p == tail_p) {
@@ -1433,9 +1531,10 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
 
 // dinv[row] = 1 / (1e-6 + sqrt(degree)) for every row, and blk[p][b] = which 16-column blocks hold a contact of rows [32 b, 32 b + 32)
 // of protein p (proteins of at most MDF_AGG_MAX_LEN residues).  One wave per (protein, row block); grid.y = 32.
+// Round 6: ... and the protein's contact bits once more, as the byte tiles k_aggregate_mfma loads (mdfri.h mdf_agg_desc.tiles).
 __global__ __launch_bounds__(64) void k_agg_prepare(const unsigned long long *__restrict__ masks, int W, const int32_t *__restrict__ counts,
                                                     const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq, float *__restrict__ dinv,
-                                                    unsigned long long *__restrict__ blk)
+                                                    unsigned long long *__restrict__ blk, uint8_t *__restrict__ tiles, int Wt)
 {
     const int p = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
     const int r0 = row_off[p], L = Lq[p], rows_end = row_off[p + 1] - r0;   // rows up to the next protein: padding included
@@ -1444,13 +1543,26 @@ __global__ __launch_bounds__(64) void k_agg_prepare(const unsigned long long *__
     if (L > MDF_AGG_MAX_LEN || L < MDF_AGG_MIN_LEN) return;
     unsigned long long bits = 0;
     const int i = b * 32 + (lane & 31);
-    if (i < L && lane < 32) {
+    const int Lpad = (L + GROUP_ROWS - 1) / GROUP_ROWS * GROUP_ROWS, nch = (L + AGG_CHR - 1) / AGG_CHR;
+    if (i < Lpad && lane < 32) {   // (rows [L, Lpad): padding, all zero; rows from Lpad on are the next protein's)
         const unsigned long long *mrow = masks + (size_t)(r0 + i) * W;
-        for (int w = 0; w * 64 < L; ++w) {
-            const unsigned long long m = mrow[w];
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        uint8_t *trow = tiles + (size_t)r0 * Wt + (size_t)((i >> 4) * nch) * 512 + (i & 15) * 32;
+        for (int c = 0; c < nch; ++c) {
+            u4 ev, od;   // the even / odd bytes of the row's 32 bytes of this chunk: columns 16 cb .. + 7 / 16 cb + 8 .. + 15, cb = 0 .. 15
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if ((m >> (16 * q)) & 0xffffull) bits |= 1ull << (w * 4 + q);
+            for (int k = 0; k < 4; ++k) {
+                const int w = c * 4 + k;
+                const unsigned long long m = (i < L && w * 64 < L) ? mrow[w] : 0ull;   // (words beyond the protein's columns are not defined)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((m >> (16 * q)) & 0xffffull) bits |= 1ull << (w * 4 + q);
+                const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+                ev[k] = __builtin_amdgcn_perm(hi, lo, 0x06040200u);
+                od[k] = __builtin_amdgcn_perm(hi, lo, 0x07050301u);
+            }
+            *reinterpret_cast<u4 *>(trow + (size_t)c * 512) = ev;
+            *reinterpret_cast<u4 *>(trow + (size_t)c * 512 + 16) = od;
         }
     }
     for (int d = 32; d > 0; d >>= 1) bits |= __shfl_xor(bits, d, 64);
@@ -1497,13 +1609,15 @@ __global__ __launch_bounds__(256) void k_layer1(const float *__restrict__ S, con
 #pragma unroll 4
         for (int r = 0; r < GROUP_ROWS; ++r) {
             const int row = g * GROUP_ROWS + r;
-            v4f s4[7];                              // the row's 26 (+2) letter sums: LDS broadcasts
+            v4f s4[4][2];                           // the row's 26 (+6) letter sums: LDS broadcasts; letter a = s4[a >> 3][a & 1][(a >> 1) & 3] (MDF_LSUM_INDEX)
 #pragma unroll
-            for (int q = 0; q < 7; ++q) s4[q] = *reinterpret_cast<const v4f *>(sg + r * 32 + q * 4);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) s4[q][hf] = *reinterpret_cast<const v4f *>(sg + q * 128 + (hf * 16 + r) * 4);
             v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int a = 0; a < 26; ++a) {
-                const float sa = s4[a >> 2][a & 3];
+                const float sa = s4[a >> 3][a & 1][(a >> 1) & 3];
                 acc = __builtin_elementwise_fma((v4f){sa, sa, sa, sa}, t[a], acc);
             }
             const v4f v = {elu1(acc.x), elu1(acc.y), elu1(acc.z), elu1(acc.w)};
@@ -1541,7 +1655,7 @@ __global__ __launch_bounds__(256) void k_letter_sums(const uint8_t *__restrict__
             c += (lane == ak) ? vk : 0.0f;
         }
     }
-    if (lane < 32) S[(size_t)row * 32 + lane] = (lane < 26) ? c : 0.0f;
+    if (lane < 32) S[MDF_LSUM_INDEX((size_t)row, lane)] = (lane < 26) ? c : 0.0f;   // (storage order of the letter sums: mdfri.h)
 }
 
 // pooled[p, c] = sum over the groups (GROUP_ROWS rows each) [grp_off[p], grp_off[p+1]) of partial[g, c]   (c over all GraphConv layers);
@@ -1976,8 +2090,8 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
     {   // one launch per length class (1, 2 or 4 row blocks per wave: the accumulators a workgroup carries)
         const unsigned slabs = (unsigned)(Cin / AGG_SL);
         const int32_t *pl = agg->plist;
-#define MDF_AGG_ARGS(n_) dim3((unsigned)(n_) * slabs), dim3(AGG_THREADS), 0, st, Hin, Cin, reinterpret_cast<const unsigned long long *>(agg->masks), \
-                         agg->W, agg->dinv, reinterpret_cast<const unsigned long long *>(agg->blk), agg->row_off, agg->Lq, pl, agg->gate, AH,              \
+#define MDF_AGG_ARGS(n_) dim3((unsigned)(n_) * slabs), dim3(AGG_THREADS), 0, st, Hin, Cin, agg->tiles,                                               \
+                         agg->tile_row_bytes, agg->dinv, reinterpret_cast<const unsigned long long *>(agg->blk), agg->row_off, agg->Lq, pl, agg->gate, AH,              \
                          agg->tail_p, (int)agg->tail_row0, Ri
         // Chunks beyond ~100 000 rows: a 512-channel slab no longer fits the 256 MiB Infinity Cache, and a kernel that reads its operand in
         // the order the previous kernel wrote it finds nothing of it there.  The aggregation walks its proteins from the END of the list
@@ -1986,9 +2100,13 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
         static const int reverse = getenv("MDFRI_AX_REVERSE") ? atoi(getenv("MDFRI_AX_REVERSE")) : 1;
         AggLayer1 l1v = l1 ? *l1 : AggLayer1(), plainv;
         l1v.reverse = plainv.reverse = reverse;
+        // (layer 1 is made inside the launch for proteins of at most 512 residues only -- mdf_agg_l1_fused; gcn_stage does not fuse a
+        // descriptor that lists longer ones -- so the form with four row blocks per wave exists without it only)
+        MDF_REQUIRE(agg->tiles && agg->tile_row_bytes >= 32, "launch_aggregate: the descriptor carries no contact-byte tiles (mdf_agg_prepare_dev)");
+        MDF_REQUIRE(!(l1 && agg->n_mf[2] > 0), "launch_aggregate: layer 1 inside the aggregation launch for a protein of more than 512 residues");
 #define MDF_AGG(RB, n_)                                                                                  \
     if ((n_) > 0) {                                                                                      \
-        if (l1) hipLaunchKernelGGL((k_aggregate_mfma<RB, true>), MDF_AGG_ARGS(n_), l1v);                 \
+        if (l1) hipLaunchKernelGGL((k_aggregate_mfma<(RB <= 2 ? RB : 2), true>), MDF_AGG_ARGS(n_), l1v); \
         else hipLaunchKernelGGL((k_aggregate_mfma<RB, false>), MDF_AGG_ARGS(n_), plainv);                \
     }                                                                                                    \
     pl += (n_);
@@ -2105,6 +2223,15 @@ static size_t lm_ws_bytes(const mdf_lm *lm, int64_t B, int64_t Lmax)
 using namespace mdf;
 
 extern "C" {
+
+#ifdef MDF_AX_PROBE
+int mdf_debug_ax_probe(void *buf)
+{
+    unsigned long long *p = (unsigned long long *)buf;
+    MDF_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_ax_probe), &p, sizeof(p)));
+    return MDF_OK;
+}
+#endif
 
 const char *mdf_hw_pipe(void) { return hw_pipe_bf16x6() ? "bf16x6" : "f32"; }
 
@@ -2613,12 +2740,17 @@ int mdf_agg_class(int32_t L, int resident)
 // the fused form sits on the register limit (155 us against 71 + 36 at 800 residues), and below 176 / between 257 and 399 the plain pair wins.
 int mdf_agg_l1_fused(int32_t L) { return (L >= 176 && L <= 256) || (L >= 400 && L <= 512); }
 
+int32_t mdf_agg_tile_row_bytes(int32_t max_len) { return 32 * ((std::min(std::max(max_len, 1), MDF_AGG_MAX_LEN) + AGG_CHR - 1) / AGG_CHR); }
+
 int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts, const int32_t *row_off, const int32_t *Lq, int32_t B,
-                        int64_t R, float *dinv, uint64_t *blk, void *stream)
+                        int64_t R, float *dinv, uint64_t *blk, uint8_t *tiles, int32_t tile_row_bytes, void *stream)
 {
-    MDF_REQUIRE(masks && counts && row_off && Lq && dinv && blk && B > 0 && W > 0 && R > 0, "agg_prepare_dev: bad argument");
+    MDF_REQUIRE(masks && counts && row_off && Lq && dinv && blk && tiles && B > 0 && W > 0 && R > 0, "agg_prepare_dev: bad argument");
+    MDF_REQUIRE(tile_row_bytes >= 32 && tile_row_bytes % 32 == 0 && tile_row_bytes <= 32 * (MDF_AGG_MAX_LEN / AGG_CHR) && (int64_t)R * tile_row_bytes < 0x7fffffffLL,
+                "agg_prepare_dev: tile_row_bytes %d (mdf_agg_tile_row_bytes) for %lld rows", tile_row_bytes, (long long)R);
     hipLaunchKernelGGL(k_agg_prepare, dim3((unsigned)B, 32), dim3(64), 0, static_cast<hipStream_t>(stream),
-                       reinterpret_cast<const unsigned long long *>(masks), W, counts, row_off, Lq, dinv, reinterpret_cast<unsigned long long *>(blk));
+                       reinterpret_cast<const unsigned long long *>(masks), W, counts, row_off, Lq, dinv, reinterpret_cast<unsigned long long *>(blk), tiles,
+                       (int)tile_row_bytes);
     MDF_HIP(hipGetLastError());
     return MDF_OK;
 }
@@ -2647,7 +2779,7 @@ static int gcn_stage(mdf_model *m, int stage, const float *letter_sums, const in
     // (a descriptor that names its layer-1 rows -- the fused engine path's -- lists in n_mf[] exactly the proteins to fuse; one that does not
     // fuses every listed protein, as before)
     const bool split_lists = agg && agg->l1_seg;
-    const bool fuse = layer1_fused() && agg && !agg->gate && m->n_gc >= 2 && agg->n_mf[0] + agg->n_mf[1] + agg->n_mf[2] > 0 &&
+    const bool fuse = layer1_fused() && agg && !agg->gate && m->n_gc >= 2 && agg->n_mf[0] + agg->n_mf[1] > 0 && agg->n_mf[2] == 0 &&
                       (split_lists ? (agg->n_l1_seg <= 4 || agg->l1_skip) : (agg->n_seg <= 4 || agg->skip_groups));
     const int32_t *l1_seg = split_lists ? agg->l1_seg : agg ? agg->csr_seg : nullptr;
     const int n_l1_seg = split_lists ? agg->n_l1_seg : agg ? agg->n_seg : 0;
@@ -2766,7 +2898,7 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
                  o_rp = take((size_t)(R + 1) * 4), o_ci = take((size_t)nnz_cap * 4), o_va = take((size_t)nnz_cap * 4),
                  o_cws = take(cws), o_gws = take(gws), o_hws = take(hws), o_pool = take((size_t)m->feat * 4),
                  o_sc = take((size_t)m->T * 4), o_S = take((size_t)R * 32 * 4), o_part = take((size_t)(R / GROUP_ROWS) * m->feat * 4),
-                 o_lws = take(lws), o_lmh = take(m->lm_dim ? (size_t)R * m->lm_dim * 4 : 0), o_dinv = take((size_t)R * 4), o_blk = take(32 * 8),
+                 o_lws = take(lws), o_lmh = take(m->lm_dim ? (size_t)R * m->lm_dim * 4 : 0), o_dinv = take((size_t)R * 4), o_blk = take(32 * 8), o_tiles = take((size_t)R * mdf_agg_tile_row_bytes((int32_t)L)),
                  o_flag = take(256);   // [binary flag | plist = {0}]
     if (m->host_ws_bytes < o) {
         (void)hipFree(m->host_ws);
@@ -2815,8 +2947,9 @@ int mdf_gcn_forward_host(mdf_model *m, const char *seq, int64_t L, const void *c
         int32_t W = 0;
         if (int rc = mdf_cmap_ws_view(b + o_cws, cws, R, (int32_t)L, &d_masks, &W, &d_counts)) return rc;
         if (int rc = mdf_agg_prepare_dev(d_masks, W, d_counts, dd->row_off, dd->Lq, 1, R, reinterpret_cast<float *>(b + o_dinv),
-                                         reinterpret_cast<uint64_t *>(b + o_blk), nullptr))
+                                         reinterpret_cast<uint64_t *>(b + o_blk), reinterpret_cast<uint8_t *>(b + o_tiles), mdf_agg_tile_row_bytes((int32_t)L), nullptr))
             return rc;
+        agg.tiles = reinterpret_cast<const uint8_t *>(b + o_tiles), agg.tile_row_bytes = mdf_agg_tile_row_bytes((int32_t)L);
         agg.masks = d_masks, agg.W = W, agg.dinv = reinterpret_cast<const float *>(b + o_dinv), agg.blk = reinterpret_cast<const uint64_t *>(b + o_blk);
         agg.row_off = dd->row_off, agg.Lq = dd->Lq, agg.plist = d_flag + 1, agg.gate = d_flag;
         agg.csr_seg = seg_all, agg.n_seg = 1, agg.csr_gated = 1;     // the gather runs (over all rows) only if the map is not binary

@@ -143,7 +143,8 @@ SIGNATURES = {
                                          c_void_p]),
     "mdf_agg_class": (c_int, [c_int32, c_int]),
     "mdf_agg_l1_fused": (c_int, [c_int32]),
-    "mdf_agg_prepare_dev": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p]),
+    "mdf_agg_prepare_dev": (c_int, [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "mdf_agg_tile_row_bytes": (c_int32, [c_int32]),
     "mdf_cmap_ws_view": (c_int, [c_void_p, c_size_t, c_int64, c_int32, POINTER(c_void_p), POINTER(c_int32), POINTER(c_void_p)]),
     "mdf_dense_to_csr_masks_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
                                            c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -257,8 +258,14 @@ def last_error() -> str:
     return lib().mdf_last_error().decode("utf-8", "replace")
 
 
+# include/mdfri.h MDF_DEFAULT_CHUNK_ROWS, stated here too so that host-only callers (sharding.plan_summary, bench.py --dry-plan, the
+# binding's keyword default) need not load the library -- and with it the HIP runtime -- to read a constant; tests/test_abi_cpu.py
+# asserts that header, library, this constant, bench.py and the compiled binding all say the same number.
+DEFAULT_CHUNK_ROWS = 262144
+
+
 def default_chunk_rows() -> int:
-    """Residue rows per fused chunk where the caller does not say (include/mdfri.h MDF_DEFAULT_CHUNK_ROWS)."""
+    """Residue rows per fused chunk where the caller does not say (include/mdfri.h MDF_DEFAULT_CHUNK_ROWS), as the LOADED library states it."""
     return int(lib().mdf_default_chunk_rows())
 
 

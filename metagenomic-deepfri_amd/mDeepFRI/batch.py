@@ -217,6 +217,11 @@ def _p(t, elem_offset: int = 0):
     return ctypes.c_void_p(t.data_ptr() + elem_offset * t.element_size())
 
 
+# Rows per chunk of the dense-map path (HotPathEngine.forward_dense): its upload slots grow with chunk rows x L (see there); 65 536 keeps
+# the double-buffered upload busy (bench.py's `dense` leg) at a quarter of the pinned memory of the fused path's default chunk.
+DENSE_CHUNK_ROWS = 65536
+
+
 class DeviceBatch:
     """PackedProteins uploaded to one GPU (torch tensors own the memory; `desc` is the mdf_batch_dev the engine takes)."""
 
@@ -341,10 +346,18 @@ class HotPathEngine:
 
     def forward_dense(self, db: DeviceBatch, cmaps, want_logits: bool = False):
         """Reference-format path: one dense (L,L) contact map per protein (what build_align_contact_map returns,
-        int32) -> scores.  Maps are uploaded chunk by chunk (inside the library); synchronises before returning."""
+        int32) -> scores.  Maps are uploaded chunk by chunk (inside the library); synchronises before returning.
+
+        The library stages a chunk's maps in two pinned host slots and two device slots of (sum of L^2 over the chunk's proteins) x 4 B
+        each -- about chunk rows x L x 4 B: 128 MiB per slot at 65 536 rows of L = 512, four times that at the fused path's default
+        chunk (MDF_DEFAULT_CHUNK_ROWS) -- and the first chunk's host copy overlaps nothing.  A batch planned with larger chunks
+        is therefore re-planned here with DENSE_CHUNK_ROWS rows per chunk (a second plan + upload of the small per-protein arrays; the
+        scores do not depend on the plan: tests/test_gpu_engine.py); plan with `max_rows <= DENSE_CHUNK_ROWS` to avoid the copy."""
         torch = _torch()
         if len(cmaps) != db.B:
             raise ValueError("one contact map per protein expected")
+        if db.packed.max_chunk_rows > DENSE_CHUNK_ROWS:
+            db = self._dense_view(db)
         flat = []
         for p, A in enumerate(cmaps):
             A = np.asarray(A)
@@ -360,6 +373,16 @@ class HotPathEngine:
             scores, logits, sp, lp = self._outputs(db, want_logits)
             _hip.check(self.L.mdf_engine_forward_dense(self.handle, db.packed.plan, ctypes.byref(db.desc), ptrs, dt, sp, lp, self._stream()))
         return (scores, logits) if want_logits else scores
+
+    def _dense_view(self, db: DeviceBatch) -> DeviceBatch:
+        """`db` re-planned with at most DENSE_CHUNK_ROWS rows per chunk (cached on `db`): same proteins, same order, smaller upload slots."""
+        view = getattr(db, "_dense", None)
+        if view is None:
+            import copy
+            pk = copy.copy(db.packed)
+            pk._plan(DENSE_CHUNK_ROWS)
+            view = db._dense = DeviceBatch(pk, self.device)
+        return view
 
     def lm_features(self, packed: PackedProteins, which: int = 0):
         """Language-model features (LSTM2 output) of every protein of `packed`: list of (L_p, H) float32 arrays.  For

@@ -45,8 +45,7 @@ def plan_summary(lengths, world_size: int, max_rows: int = None):
     """What `bench.py --dry-plan` prints and tests/test_sharding_cpu.py asserts on: per rank the proteins, padded residue rows
     (the cost model) and chunks of `max_rows`, plus the predicted imbalance max/mean - 1 of the padded rows.  CPU only."""
     if not max_rows:
-        from . import _hip
-        max_rows = _hip.default_chunk_rows()
+        from ._hip import DEFAULT_CHUNK_ROWS as max_rows   # (a constant of the module: no library, no HIP runtime is loaded for a plan on paper)
     max_rows = int(max_rows)
     lengths = np.asarray(lengths, dtype=np.int64)
     pad = (lengths + GROUP_ROWS - 1) // GROUP_ROWS * GROUP_ROWS

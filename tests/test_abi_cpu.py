@@ -316,10 +316,13 @@ def test_default_chunk_rows_is_one_number_everywhere():
     from conftest import ROOT
     from mDeepFRI import _hip
     n = _hip.default_chunk_rows()
+    assert _hip.DEFAULT_CHUNK_ROWS == n   # the Python-side constant host-only callers use (sharding.plan_summary: no library load)
+    from mDeepFRI import batch
     hdr = open(os.path.join(ROOT, "include", "mdfri.h")).read()
+    assert int(re.search(r"#define MDF_DENSE_CHUNK_ROWS (\d+)", hdr).group(1)) == batch.DENSE_CHUNK_ROWS <= n   # the dense-map path's own chunk
     assert int(re.search(r"#define MDF_DEFAULT_CHUNK_ROWS (\d+)", hdr).group(1)) == n and n % 32768 == 0
     bench = open(os.path.join(ROOT, "bench.py")).read()
-    assert int(re.search(r'"--chunk-rows", type=int, default=(\d+)', bench).group(1)) == n
+    assert re.search(r'"--chunk-rows", type=int, default=DEFAULT_CHUNK_ROWS,', bench) and "from mDeepFRI._hip import DEFAULT_CHUNK_ROWS" in bench
     pyx = open(os.path.join(ROOT, "tests", "binding", "predict.pyx")).read()
     assert int(re.search(r"int max_rows = (\d+)\)", pyx).group(1)) == n
     lq = np.full(3000, 512, dtype=np.int32)
