@@ -82,7 +82,8 @@ def parse(argv=None):
                          "LM embedding; SURVEY.md section 8f row 1).  Not the BASELINE.json configuration: an extra measurement.")
     ap.add_argument("--no-board", action="store_true", help="do not sample board power / shader clock with rocm-smi while the steps run")
     ap.add_argument("--no-extras", action="store_true", help="N = 1 default run: skip the by_length / mixed / end_to_end mini-runs")
-    ap.add_argument("--end-to-end", type=int, default=2, metavar="N", help="batches of the end_to_end mini-run (0 = skip)")
+    ap.add_argument("--end-to-end", type=int, default=8, metavar="N",
+                    help="batches of the host-to-host mini-runs end_to_end / host_pipeline / binding (0 = skip); their `steady` is the rate once the pipeline is full")
     ap.add_argument("--query-stream", type=int, default=6, metavar="N", help="batches of 4 000 queries of the query_stream mini-run (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--force-device", type=int, default=None, help="testing aid: put every rank on this device ordinal")
@@ -791,21 +792,72 @@ def main():
             leg("helix", lambda: dict(mini_run(ctx, eng, make_helix(42 + 5, n_local, args.length), args.chunk_rows),
                                       note="same shape as the headline run, protein-like C-alpha traces (helix bundles) instead of random walks"))
 
+            def host_batches(n_batches):
+                # two distinct batches of host lists, taken in turn (generating 8 x 10 000 proteins would take longer than the leg itself)
+                two = [make_fixed_length(777 + k, n_local, args.length) for k in range(2)]
+                return [two[k & 1] for k in range(n_batches)]
+
+            def steady(done, t0, per_batch):
+                # done[k]: the wall clock at which batch k's score arrays were in the caller's hands.  `value` = all batches over all of the
+                # time (fill and drain included); `steady` = the rate at which results come out once the pipeline is full (batches 1 .. n - 1
+                # over the time between the first and the last completion); `fill_ms` = the first batch alone
+                n = len(done)
+                out = {"value": round(n * per_batch / (done[-1] - t0), 1), "unit": "proteins/s", "batches": n, "fill_ms": round(1e3 * (done[0] - t0), 1)}
+                if n > 1:
+                    out["steady"] = round((n - 1) * per_batch / (done[-1] - done[0]), 1)
+                    out["steady_ms_per_batch"] = round(1e3 * (done[-1] - done[0]) / (n - 1), 2)
+                return out
+
             def end_to_end_leg():
                 from mDeepFRI.stream import AlignmentStream
                 items = []
-                for k in range(args.end_to_end):
-                    s2, c2, _, _ = make_fixed_length(777 + k, n_local, args.length)
+                for s2, c2, _, _ in host_batches(args.end_to_end):
                     items += [(a, b, a, a) for a, b in zip(s2, c2)]
                 stream = AlignmentStream(eng, batch_size=n_local, max_rows=args.chunk_rows)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                n_out = sum(res[MODES[0]].shape[0] for _, res in stream.run(items))
-                dt = time.perf_counter() - t0
+                done, n_out = [], 0
+                for _, res in stream.run(items):
+                    n_out += res[MODES[0]].shape[0]
+                    done.append(time.perf_counter())
                 assert n_out == len(items)
-                return {"value": round(len(items) / dt, 1), "unit": "proteins/s", "batches": args.end_to_end,
-                        "note": "PCIe-inclusive: host lists in -> host float32 score arrays out (packing thread + upload + compute + "
-                                "download, batches pipelined; mDeepFRI.stream.AlignmentStream); never `value`"}
+                return dict(steady(done, t0, n_local),
+                            note="PCIe-inclusive: host lists in -> host float32 score arrays out (packing thread + upload + compute + "
+                                 "download, batches pipelined; mDeepFRI.stream.AlignmentStream); never `value`")
+
+            def host_pipeline_leg(which):
+                # the same through the library's own two-slot pipeline (mdf_engine_submit_alignments_host / mdf_engine_collect_host): `binding` =
+                # the COMPILED reference-side module (tests/binding/predict.pyx BatchEngine: cdef extern calls, no torch, no ctypes), `ctypes` =
+                # mDeepFRI.batch.HostPipeline.  Every batch's scores are compared bit for bit with the device-resident run's when the lists are the same
+                batches = host_batches(args.end_to_end)
+                if which == "binding":
+                    sys.path.insert(0, os.path.join(ROOT, "tests"))
+                    import tempfile
+                    import binding_loader
+                    from mDeepFRI import weights as wfile
+                    _, bp = binding_loader.load()
+                    with tempfile.TemporaryDirectory() as td:
+                        bpreds = []
+                        for m in MODES:
+                            wfile.save_mdfw(os.path.join(td, m + ".mdfw"), weights[m])
+                            bpreds.append(bp.Predictor(os.path.join(td, m + ".mdfw")))
+                    runner = bp.BatchEngine(bpreds, max_rows=args.chunk_rows)
+                    as_dict = lambda res: dict(zip(MODES, res))  # noqa: E731
+                else:
+                    runner = batch.HostPipeline(eng)
+                    as_dict = lambda res: res  # noqa: E731
+                runner.submit(seqs, coords, q_alns, t_alns)      # the headline run's own lists: the same bits as its device-resident scores? (also sizes the buffers)
+                ref = as_dict(runner.collect())
+                same = all(np.array_equal(ref[m], out[m].cpu().numpy()) for m in MODES)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                done = []
+                for res in runner.run(batches):
+                    done.append(time.perf_counter())
+                return dict(steady(done, t0, n_local), bitwise_equal_to_device_resident=bool(same),
+                            note=("compiled binding (tests/binding/predict.pyx BatchEngine)" if which == "binding" else "mDeepFRI.batch.HostPipeline (ctypes)") +
+                                 ": host lists in -> host float32 arrays out through mdf_engine_submit_alignments_host / mdf_engine_collect_host "
+                                 "(two batches in flight: packing and unpacking under the other batch's kernels); never `value`")
 
             def query_stream_leg():
                 # the stages either side of the path as one stream (SURVEY 8f rows 3 and 4 around the path): host sequences + candidate sets
@@ -894,6 +946,8 @@ def main():
             leg("gcn_only", gcn_only_leg)
             if args.end_to_end > 0:
                 leg("end_to_end", end_to_end_leg)
+                leg("binding", lambda: host_pipeline_leg("binding"))
+                leg("host_pipeline", lambda: host_pipeline_leg("ctypes"))
             if args.query_stream > 0:
                 leg("query_stream", query_stream_leg)
         line["cpu_baseline"] = cpu_leg

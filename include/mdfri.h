@@ -562,6 +562,16 @@ int mdf_seq_engine_check(mdf_seq_engine *e, const mdf_plan *plan, const mdf_batc
 int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords,
                                    const int32_t *Lt, const char *q_aln, const char *t_aln, const int32_t *La,
                                    float *const *scores_host, int64_t info[4]);
+/* The same call as a pipeline of two slots (round 6): submit packs the batch into pinned staging, sends it over on a copy stream and
+ * enqueues plan + fused forward + the download into pinned memory on engine-owned streams -- and returns a ticket; collect waits for
+ * that batch, validates it (one automatic re-run with a larger CSR capacity) and copies the scores out, in the caller's order.  While
+ * batch k computes, the caller packs batch k + 1 and unpacks batch k - 1: host lists -> host arrays at the rate of the device-resident
+ * path.  At most TWO batches are in flight: a third submit fails with MDF_EINVAL until the oldest is collected; every ticket must be
+ * collected (errors included: the slot is free afterwards).  mdf_engine_run_alignments_host == submit + collect: the same bits.  The
+ * input arrays are copied before submit returns. */
+int mdf_engine_submit_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords,
+                                      const int32_t *Lt, const char *q_aln, const char *t_aln, const int32_t *La, int64_t *ticket);
+int mdf_engine_collect_host(mdf_engine *e, int64_t ticket, float *const *scores_host, int64_t info[4]);
 
 /* Output stage next to the path (mDeepFRI/pipeline.py:696-705, 733-740: results.tsv keeps, per protein, the terms with
  * float(score) >= 0.1 sorted by score descending; Python's sort is stable, so equal scores keep term order).

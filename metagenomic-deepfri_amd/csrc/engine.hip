@@ -525,6 +525,22 @@ struct GraphEntry {
 #define MDF_SPLIT_CUS_DEFAULT 0
 #endif
 
+// one slot of the host pipeline (mdf_engine_submit_alignments_host, near the end of this file)
+struct mdf_host_slot {
+    char *pin_in = nullptr, *pin_out = nullptr;
+    size_t pin_in_bytes = 0, pin_out_bytes = 0;
+    DevBuf d_in, d_out;
+    mdf_plan *plan = nullptr;
+    hipEvent_t ev_in = nullptr, ev_comp = nullptr, ev_done = nullptr;
+    int64_t ticket = -1;        // -1: free
+    int32_t B = 0;
+    size_t in_bytes = 0, o_seq = 0, o_soff = 0, o_lq = 0, o_status = 0, o_bad = 0, out_flags = 0, out_bytes = 0;
+    std::vector<size_t> s_off;  // per head: offset of its (B, T) block in d_out / pin_out
+    mdf_batch_dev b{};
+};
+
+static void host_slots_release(mdf_engine *e);
+
 struct mdf_engine {
     int device = 0;
     std::vector<mdf_model *> models;
@@ -551,7 +567,11 @@ struct mdf_engine {
     DevBuf gws2;                      // the second stack's slabs
     DevBuf perm, pool_scratch;        // plans that order the batch: descriptors in plan order; the pooled rows on their way back to input order
     int last_set = 0;
-    DevBuf gws, hws, seq_all, lm_ws, host_in, host_scores, map_dev[2], flags;
+    DevBuf gws, hws, seq_all, lm_ws, map_dev[2], flags;
+    // the two slots of the host pipeline (mdf_engine_submit_alignments_host / mdf_engine_collect_host) and its three streams
+    mdf_host_slot hslot[2];
+    hipStream_t hs_in = nullptr, hs_comp = nullptr, hs_out = nullptr;
+    int64_t next_ticket = 0;
     std::vector<DevBuf> partial, pooled, lm_h;
     int64_t rows_alloc = 0, nnz_cap = 0;
     int32_t len_alloc = 0;
@@ -678,6 +698,7 @@ extern "C" void mdf_engine_free(mdf_engine *e)
     DeviceGuard g(e->device);
     (void)hipDeviceSynchronize();
     drop_graphs(e);
+    host_slots_release(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (auto &c : e->cs) {
         for (DevBuf *b : {&c.rowptr, &c.colidx, &c.val, &c.seq_idx, &c.lsum, &c.cws, &c.dinv, &c.blk, &c.tiles}) b->release();
@@ -697,7 +718,7 @@ extern "C" void mdf_engine_free(mdf_engine *e)
     e->perm.release();
     e->pool_scratch.release();
     if (e->map_stream) (void)hipStreamDestroy(e->map_stream);
-    for (DevBuf *b : {&e->gws, &e->hws, &e->seq_all, &e->lm_ws, &e->host_in, &e->host_scores, &e->map_dev[0], &e->map_dev[1], &e->flags}) b->release();
+    for (DevBuf *b : {&e->gws, &e->hws, &e->seq_all, &e->lm_ws, &e->map_dev[0], &e->map_dev[1], &e->flags}) b->release();
     for (auto &b : e->partial) b.release();
     for (auto &b : e->pooled) b.release();
     for (auto &b : e->lm_h) b.release();
@@ -1631,11 +1652,111 @@ extern "C" int mdf_engine_lm_features_host(mdf_engine *e, const mdf_plan *pl, co
 }
 
 // ---- everything in one call, host buffers -------------------------------------------------------------------------------
-extern "C" int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords, const int32_t *Lt,
-                                              const char *q_aln, const char *t_aln, const int32_t *La, float *const *scores_host, int64_t info[4])
+// Round 6: the call is a pipeline of two slots.  mdf_engine_submit_alignments_host packs a batch into the slot's PINNED staging block,
+// sends it over on a copy stream, enqueues plan + fused forward on the engine's compute stream behind it and the download into pinned
+// memory on a third stream behind that -- and returns; mdf_engine_collect_host waits for the slot's last event, validates the flags
+// that came back with the scores (one automatic re-run with a larger CSR capacity) and hands the scores over.  While batch k computes,
+// the caller packs batch k + 1 and unpacks batch k - 1: host lists -> host arrays at the device-resident rate (bench.py `binding` leg).
+// mdf_engine_run_alignments_host is submit + collect: one code path, the same bits.
+static int pinned_grow(char **p, size_t *have, size_t need)
 {
-    MDF_REQUIRE(e && seqs && Lq && coords && Lt && q_aln && t_aln && La && scores_host, "engine_run_alignments_host: NULL argument");
-    MDF_REQUIRE(B > 0, "engine_run_alignments_host: empty batch");
+    if (*p && *have >= need) return MDF_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr, *have = 0;
+    need = align_up(need + need / 8, 4096);
+    MDF_HIP(hipHostMalloc(reinterpret_cast<void **>(p), need, hipHostMallocDefault));
+    *have = need;
+    return MDF_OK;
+}
+
+static void host_slots_release(mdf_engine *e)
+{
+    for (mdf_host_slot &s : e->hslot) {
+        if (s.pin_in) (void)hipHostFree(s.pin_in);
+        if (s.pin_out) (void)hipHostFree(s.pin_out);
+        s.d_in.release(), s.d_out.release();
+        if (s.plan) mdf_plan_free(s.plan);
+        for (hipEvent_t ev : {s.ev_in, s.ev_comp, s.ev_done})
+            if (ev) (void)hipEventDestroy(ev);
+        s = mdf_host_slot();
+    }
+    for (hipStream_t *st : {&e->hs_in, &e->hs_comp, &e->hs_out}) {
+        if (*st) (void)hipStreamDestroy(*st);
+        *st = nullptr;
+    }
+}
+
+// the flags of a finished batch (host copies) -> the verdict of mdf_engine_check.  seqs / seq_off / Lq: the batch's own sequences (host), for
+// the error path that names the first invalid residue in the CALLER's order
+static int verdict_from_flags(const mdf_engine *e, const mdf_plan *pl, const int64_t *bad, const int32_t *status, const char *seqs, const int32_t *seq_off,
+                              const int32_t *Lq, int64_t *info)
+{
+    const size_t nC = pl->chunks.size();
+    if (info) info[0] = info[1] = info[2] = info[3] = -1;
+    for (size_t ci = 0; ci < nC; ++ci) {
+        if (bad[ci] == -1) continue;
+        int64_t p = pl->chunks[ci].p0 + (bad[ci] >> 32), pos = bad[ci] & 0xffffffffLL;
+        if (!pl->order.empty()) {   // the plan visits the proteins shortest first: the report is the first invalid residue in the caller's order
+            bool ok[256] = {false};
+            for (const char *a = "-DGULNTKHYWCPVSOIEFXQABZRM"; *a; ++a) ok[(unsigned char)*a] = true;   // the residue alphabet of predict.pyx:26
+            p = pl->order[(size_t)p];
+            for (int32_t q = 0, found = 0; q < pl->B && !found; ++q)
+                for (int32_t i = 0; i < Lq[q]; ++i)
+                    if (!ok[(unsigned char)seqs[(size_t)seq_off[q] + (size_t)i]]) {
+                        p = q, pos = i, found = 1;
+                        break;
+                    }
+        }
+        if (info) info[0] = p, info[1] = pos;
+        return fail(MDF_EBADCHAR, "Invalid character in sequence: protein %lld, position %lld", (long long)p, (long long)pos);
+    }
+    int32_t too_long = 0, need = 0;
+    bool overflow = false;
+    for (size_t ci = 0; ci < nC; ++ci) {
+        too_long = std::max(too_long, status[ci * 4 + 2]);
+        if (status[ci * 4]) overflow = true, need = std::max(need, status[ci * 4 + 1]);
+    }
+    if (too_long) {
+        if (info) info[2] = too_long;
+        return fail(MDF_EINVAL, "a query of length %d exceeds the max_len the contact stage was given", too_long);
+    }
+    if (overflow) {
+        if (info) info[3] = need;
+        return fail(MDF_ECAPACITY, "CSR capacity %lld too small (a chunk needs %d); raise nnz_per_row", (long long)(e ? e->nnz_cap : 0), need);
+    }
+    return MDF_OK;
+}
+
+// plan mirror + fused forward of the slot's batch on the compute stream, then scores + flags into the slot's pinned block on the download stream
+static int host_slot_enqueue(mdf_engine *e, mdf_host_slot &s)
+{
+    char *d = s.d_in.as<char>();
+    const size_t nC = s.plan->chunks.size();
+    MDF_HIP(hipStreamWaitEvent(e->hs_comp, s.ev_in, 0));
+    MDF_HIP(hipMemsetAsync(d + s.o_status, 0, nC * 16, e->hs_comp));
+    MDF_HIP(hipMemsetAsync(d + s.o_bad, 0xff, nC * 8, e->hs_comp));
+    // a one-shot plan (fresh serial on every call): issued eagerly, never through the graph cache -- its entry could not be
+    // seen again and would only push the captured graphs of the serving callers out of the LRU
+    if (int rc = ensure(e, s.plan->max_chunk_rows, s.plan->B, s.plan->max_len, s.plan->max_groups)) return rc;
+    ++e->eager_runs;
+    std::vector<float *> d_scores(e->models.size());
+    for (size_t k = 0; k < e->models.size(); ++k) d_scores[k] = reinterpret_cast<float *>(s.d_out.as<char>() + s.s_off[k]);
+    if (int rc = forward_alignments_eager(e, s.plan, &s.b, d_scores.data(), nullptr, e->hs_comp)) return rc;
+    MDF_HIP(hipEventRecord(s.ev_comp, e->hs_comp));
+    MDF_HIP(hipStreamWaitEvent(e->hs_out, s.ev_comp, 0));
+    MDF_HIP(hipMemcpyAsync(s.pin_out, s.d_out.p, s.out_flags, hipMemcpyDeviceToHost, e->hs_out));
+    MDF_HIP(hipMemcpyAsync(s.pin_out + s.out_flags, d + s.o_status, nC * 16, hipMemcpyDeviceToHost, e->hs_out));
+    MDF_HIP(hipMemcpyAsync(s.pin_out + s.out_flags + nC * 16, d + s.o_bad, nC * 8, hipMemcpyDeviceToHost, e->hs_out));
+    MDF_HIP(hipEventRecord(s.ev_done, e->hs_out));
+    return MDF_OK;
+}
+
+extern "C" int mdf_engine_submit_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords, const int32_t *Lt,
+                                                 const char *q_aln, const char *t_aln, const int32_t *La, int64_t *ticket)
+{
+    MDF_REQUIRE(e && seqs && Lq && coords && Lt && q_aln && t_aln && La && ticket, "engine_submit_alignments_host: NULL argument");
+    MDF_REQUIRE(B > 0, "engine_submit_alignments_host: empty batch");
+    *ticket = -1;
     // offsets + the consistency the Python packer checks (a gapped query must spell its sequence)
     std::vector<int32_t> seq_off((size_t)B + 1, 0), coord_off((size_t)B + 1, 0), aln_off((size_t)B + 1, 0);
     int64_t so = 0, co = 0, ao = 0;
@@ -1653,77 +1774,122 @@ extern "C" int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, c
     if (int rc = mdf_plan_create(Lq, B, e->cfg.max_rows, e->cfg.max_segment_groups, &pl)) return rc;
     struct PlanGuard {
         mdf_plan *p;
-        ~PlanGuard() { mdf_plan_free(p); }
+        ~PlanGuard() { if (p) mdf_plan_free(p); }
     } pg{pl};
     const size_t nC = pl->chunks.size();
-    int rc = MDF_OK;
-    {
-        std::unique_lock<std::mutex> lk(e->mu);
-        DeviceGuard g(e->device);
-        MDF_HIP(g.err);
-        hipStream_t st = nullptr;
-        // one device slab for the inputs: [seqs | seq_off | Lq | coords | coord_off | q_aln | t_aln | aln_off | status | bad]
-        size_t o = 0;
-        auto take = [&](size_t bytes) { const size_t r = o; o = align_up(o + std::max<size_t>(bytes, 4), 256); return r; };
-        const size_t o_seq = take((size_t)so), o_soff = take(((size_t)B + 1) * 4), o_lq = take((size_t)B * 4), o_xyz = take((size_t)co * 12),
-                     o_coff = take(((size_t)B + 1) * 4), o_q = take((size_t)ao), o_t = take((size_t)ao), o_aoff = take(((size_t)B + 1) * 4),
-                     o_status = take(nC * 16), o_bad = take(nC * 8);
-        if ((rc = e->host_in.grow(o, &e->generation))) return rc;
-        char *d = e->host_in.as<char>();
-        MDF_HIP(hipMemcpyAsync(d + o_seq, seqs, (size_t)so, hipMemcpyHostToDevice, st));
-        MDF_HIP(hipMemcpyAsync(d + o_soff, seq_off.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice, st));
-        MDF_HIP(hipMemcpyAsync(d + o_lq, Lq, (size_t)B * 4, hipMemcpyHostToDevice, st));
-        if (co) MDF_HIP(hipMemcpyAsync(d + o_xyz, coords, (size_t)co * 12, hipMemcpyHostToDevice, st));
-        MDF_HIP(hipMemcpyAsync(d + o_coff, coord_off.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice, st));
-        if (ao) {
-            MDF_HIP(hipMemcpyAsync(d + o_q, q_aln, (size_t)ao, hipMemcpyHostToDevice, st));
-            MDF_HIP(hipMemcpyAsync(d + o_t, t_aln, (size_t)ao, hipMemcpyHostToDevice, st));
-        }
-        MDF_HIP(hipMemcpyAsync(d + o_aoff, aln_off.data(), ((size_t)B + 1) * 4, hipMemcpyHostToDevice, st));
-        mdf_batch_dev b{};
-        b.B = B;
-        b.seqs = d + o_seq;
-        b.seq_off = reinterpret_cast<const int32_t *>(d + o_soff);
-        b.Lq = reinterpret_cast<const int32_t *>(d + o_lq);
-        b.coords = reinterpret_cast<const float *>(d + o_xyz);
-        b.coord_off = reinterpret_cast<const int32_t *>(d + o_coff);
-        b.q_aln = d + o_q;
-        b.t_aln = d + o_t;
-        b.aln_off = reinterpret_cast<const int32_t *>(d + o_aoff);
-        b.status = reinterpret_cast<int32_t *>(d + o_status);
-        b.bad = reinterpret_cast<int64_t *>(d + o_bad);
-        // device score blocks
-        std::vector<size_t> s_off(e->models.size());
-        size_t s_total = 0;
-        for (size_t k = 0; k < e->models.size(); ++k) {
-            MDF_REQUIRE(scores_host[k], "engine_run_alignments_host: scores_host[%zu] is NULL", k);
-            s_off[k] = s_total;
-            s_total = align_up(s_total + (size_t)B * (size_t)mdf_model_num_terms(e->models[k]) * 4, 256);
-        }
-        if ((rc = e->host_scores.grow(s_total, &e->generation))) return rc;
-        std::vector<float *> d_scores(e->models.size());
-        for (size_t k = 0; k < e->models.size(); ++k) d_scores[k] = reinterpret_cast<float *>(e->host_scores.as<char>() + s_off[k]);
-        int64_t inf[4] = {-1, -1, -1, -1};
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            MDF_HIP(hipMemsetAsync(d + o_status, 0, nC * 16, st));
-            MDF_HIP(hipMemsetAsync(d + o_bad, 0xff, nC * 8, st));
-            // a one-shot plan (fresh serial on every call): issued eagerly, never through the graph cache -- its entry could not be
-            // seen again and would only push the captured graphs of the serving callers out of the LRU
-            if ((rc = plan_mirror(pl, e->device, st))) return rc;
-            if ((rc = ensure(e, pl->max_chunk_rows, pl->B, pl->max_len, pl->max_groups))) return rc;
-            ++e->eager_runs;
-            if ((rc = forward_alignments_eager(e, pl, &b, d_scores.data(), nullptr, st))) return rc;
-            rc = check_locked(e, pl, &b, st, inf);
-            if (rc != MDF_ECAPACITY || attempt == 1) break;
-            // a denser batch than the CSR arrays planned for: raise the capacity once and re-run
-            e->cfg.nnz_per_row = (int32_t)(inf[3] / std::max<int64_t>(pl->max_chunk_rows, 1) + 8);
-            e->rows_alloc = 0;
-        }
-        if (info) memcpy(info, inf, sizeof(inf));
-        if (rc) return rc;
-        for (size_t k = 0; k < e->models.size(); ++k)
-            MDF_HIP(hipMemcpyAsync(scores_host[k], d_scores[k], (size_t)B * (size_t)mdf_model_num_terms(e->models[k]) * 4, hipMemcpyDeviceToHost, st));
-        MDF_HIP(hipStreamSynchronize(st));
+    std::unique_lock<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    MDF_HIP(g.err);
+    mdf_host_slot &s = e->hslot[(size_t)(e->next_ticket % 2)];
+    if (s.ticket >= 0)
+        return fail(MDF_EINVAL, "engine_submit_alignments_host: two batches are in flight; collect ticket %lld first", (long long)s.ticket);
+    if (!e->hs_comp) {
+        int lo = 0, hi = 0;
+        MDF_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        MDF_HIP(hipStreamCreateWithPriority(&e->hs_in, hipStreamNonBlocking, hi));   // the transfers: queues of their own, under the other batch's kernels
+        MDF_HIP(hipStreamCreateWithPriority(&e->hs_out, hipStreamNonBlocking, hi));
+        MDF_HIP(hipStreamCreateWithFlags(&e->hs_comp, hipStreamNonBlocking));
     }
+    for (hipEvent_t *ev : {&s.ev_in, &s.ev_comp, &s.ev_done})
+        if (!*ev) MDF_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    // one block for the inputs, the same layout in pinned and device memory: [seqs | seq_off | Lq | coords | coord_off | q_aln | t_aln | aln_off | status | bad]
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t r = o; o = align_up(o + std::max<size_t>(bytes, 4), 256); return r; };
+    const size_t o_seq = take((size_t)so), o_soff = take(((size_t)B + 1) * 4), o_lq = take((size_t)B * 4), o_xyz = take((size_t)co * 12),
+                 o_coff = take(((size_t)B + 1) * 4), o_q = take((size_t)ao), o_t = take((size_t)ao), o_aoff = take(((size_t)B + 1) * 4);
+    const size_t upload = o;
+    const size_t o_status = take(nC * 16), o_bad = take(nC * 8);
+    if (int rc = pinned_grow(&s.pin_in, &s.pin_in_bytes, upload)) return rc;
+    if (int rc = s.d_in.grow(o, nullptr)) return rc;
+    memcpy(s.pin_in + o_seq, seqs, (size_t)so);
+    memcpy(s.pin_in + o_soff, seq_off.data(), ((size_t)B + 1) * 4);
+    memcpy(s.pin_in + o_lq, Lq, (size_t)B * 4);
+    if (co) memcpy(s.pin_in + o_xyz, coords, (size_t)co * 12);
+    memcpy(s.pin_in + o_coff, coord_off.data(), ((size_t)B + 1) * 4);
+    if (ao) memcpy(s.pin_in + o_q, q_aln, (size_t)ao), memcpy(s.pin_in + o_t, t_aln, (size_t)ao);
+    memcpy(s.pin_in + o_aoff, aln_off.data(), ((size_t)B + 1) * 4);
+    char *d = s.d_in.as<char>();
+    MDF_HIP(hipMemcpyAsync(d, s.pin_in, upload, hipMemcpyHostToDevice, e->hs_in));
+    if (int rc = plan_mirror(pl, e->device, e->hs_in)) return rc;   // (its small tables are pageable: staged on the copy stream, not behind the other batch's kernels)
+    MDF_HIP(hipEventRecord(s.ev_in, e->hs_in));
+    s.b = mdf_batch_dev{};
+    s.b.B = B;
+    s.b.seqs = d + o_seq;
+    s.b.seq_off = reinterpret_cast<const int32_t *>(d + o_soff);
+    s.b.Lq = reinterpret_cast<const int32_t *>(d + o_lq);
+    s.b.coords = reinterpret_cast<const float *>(d + o_xyz);
+    s.b.coord_off = reinterpret_cast<const int32_t *>(d + o_coff);
+    s.b.q_aln = d + o_q;
+    s.b.t_aln = d + o_t;
+    s.b.aln_off = reinterpret_cast<const int32_t *>(d + o_aoff);
+    s.b.status = reinterpret_cast<int32_t *>(d + o_status);
+    s.b.bad = reinterpret_cast<int64_t *>(d + o_bad);
+    s.B = B, s.in_bytes = o, s.o_seq = o_seq, s.o_soff = o_soff, s.o_lq = o_lq, s.o_status = o_status, s.o_bad = o_bad;
+    // score blocks of the heads, then the flags: [scores head 0 | ... | status | bad]
+    s.s_off.assign(e->models.size(), 0);
+    size_t s_total = 0;
+    for (size_t k = 0; k < e->models.size(); ++k) {
+        s.s_off[k] = s_total;
+        s_total = align_up(s_total + (size_t)B * (size_t)mdf_model_num_terms(e->models[k]) * 4, 256);
+    }
+    s.out_flags = s_total, s.out_bytes = s_total + nC * 24;
+    if (int rc = s.d_out.grow(s_total, nullptr)) return rc;
+    if (int rc = pinned_grow(&s.pin_out, &s.pin_out_bytes, s.out_bytes)) return rc;
+    if (s.plan) mdf_plan_free(s.plan);
+    s.plan = pl;
+    pg.p = nullptr;   // the slot owns the plan now
+    if (int rc = host_slot_enqueue(e, s)) return rc;
+    s.ticket = *ticket = e->next_ticket++;
     return MDF_OK;
+}
+
+extern "C" int mdf_engine_collect_host(mdf_engine *e, int64_t ticket, float *const *scores_host, int64_t info[4])
+{
+    MDF_REQUIRE(e && scores_host && ticket >= 0, "engine_collect_host: bad argument");
+    std::unique_lock<std::mutex> lk(e->mu);
+    DeviceGuard g(e->device);
+    MDF_HIP(g.err);
+    mdf_host_slot &s = e->hslot[(size_t)(ticket % 2)];
+    MDF_REQUIRE(s.ticket == ticket, "engine_collect_host: ticket %lld is not in flight", (long long)ticket);
+    for (size_t k = 0; k < e->models.size(); ++k) MDF_REQUIRE(scores_host[k], "engine_collect_host: scores_host[%zu] is NULL", k);
+    struct Release {   // whatever happens below, the slot is free afterwards
+        mdf_host_slot &s;
+        ~Release() { s.ticket = -1; }
+    } rel{s};
+    const size_t nC = s.plan->chunks.size();
+    int64_t inf[4] = {-1, -1, -1, -1};
+    int rc = MDF_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        lk.unlock();   // (the wait does not need the engine: the other slot may be submitted meanwhile)
+        const hipError_t werr = hipEventSynchronize(s.ev_done);
+        lk.lock();
+        MDF_HIP(werr);
+        const int32_t *status = reinterpret_cast<const int32_t *>(s.pin_out + s.out_flags);
+        const int64_t *bad = reinterpret_cast<const int64_t *>(s.pin_out + s.out_flags + nC * 16);
+        rc = verdict_from_flags(e, s.plan, bad, status, s.pin_in + s.o_seq, reinterpret_cast<const int32_t *>(s.pin_in + s.o_soff),
+                                reinterpret_cast<const int32_t *>(s.pin_in + s.o_lq), inf);
+        if (rc != MDF_ECAPACITY || attempt == 1) break;
+        // a denser batch than the CSR arrays planned for: once everything in flight has left the workspaces, raise the capacity and run this
+        // batch again from its device copy (the other slot's results are in its own blocks already)
+        MDF_HIP(hipStreamSynchronize(e->hs_comp));
+        e->cfg.nnz_per_row = (int32_t)(inf[3] / std::max<int64_t>(s.plan->max_chunk_rows, 1) + 8);
+        e->rows_alloc = 0;
+        MDF_HIP(hipEventRecord(s.ev_in, e->hs_in));
+        if ((rc = host_slot_enqueue(e, s))) break;
+    }
+    if (info) memcpy(info, inf, sizeof(inf));
+    if (rc) return rc;
+    for (size_t k = 0; k < e->models.size(); ++k)
+        memcpy(scores_host[k], s.pin_out + s.s_off[k], (size_t)s.B * (size_t)mdf_model_num_terms(e->models[k]) * 4);
+    return MDF_OK;
+}
+
+extern "C" int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords, const int32_t *Lt,
+                                              const char *q_aln, const char *t_aln, const int32_t *La, float *const *scores_host, int64_t info[4])
+{
+    MDF_REQUIRE(e && seqs && Lq && coords && Lt && q_aln && t_aln && La && scores_host, "engine_run_alignments_host: NULL argument");
+    MDF_REQUIRE(B > 0, "engine_run_alignments_host: empty batch");
+    int64_t ticket = -1;
+    if (int rc = mdf_engine_submit_alignments_host(e, seqs, Lq, B, coords, Lt, q_aln, t_aln, La, &ticket)) return rc;
+    return mdf_engine_collect_host(e, ticket, scores_host, info);
 }

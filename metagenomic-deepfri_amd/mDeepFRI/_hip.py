@@ -182,6 +182,8 @@ SIGNATURES = {
     "mdf_seq_engine_check": (c_int, [c_void_p, c_void_p, POINTER(BatchDev), c_void_p, _i64p]),
     "mdf_engine_run_alignments_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                                POINTER(c_void_p), _i64p]),
+    "mdf_engine_submit_alignments_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, _i64p]),
+    "mdf_engine_collect_host": (c_int, [c_void_p, c_int64, POINTER(c_void_p), _i64p]),
     "mdf_filter_workspace_bytes": (c_size_t, [c_int32]),
     "mdf_filter_scores_dev": (c_int, [c_void_p, c_int32, c_int32, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),

@@ -453,6 +453,78 @@ class HotPathEngine:
         return {m: t.cpu().numpy() for m, t in out.items()}
 
 
+class HostBatch:
+    """Host lists of one batch flattened for the library's single-call entries (mdf_engine_run_alignments_host and its pipelined pair): packed
+    bytes / floats + per-protein lengths.  What `predict_batch` of the compiled binding builds, in Python."""
+
+    def __init__(self, seqs, coords, q_alns, t_alns):
+        if not (len(seqs) == len(coords) == len(q_alns) == len(t_alns)) or len(seqs) == 0:
+            raise ValueError("seqs, coords, q_alns and t_alns must be non-empty lists of one length")
+        self.seqs = seqs
+        self.B = len(seqs)
+        self.seq_bytes = "".join(seqs).encode("ascii")
+        self.q_bytes, self.t_bytes = "".join(q_alns).encode("ascii"), "".join(t_alns).encode("ascii")
+        self.Lq = np.fromiter(map(len, seqs), dtype=np.int32, count=self.B)
+        self.La = np.fromiter(map(len, q_alns), dtype=np.int32, count=self.B)
+        if not np.array_equal(self.La, np.fromiter(map(len, t_alns), dtype=np.int32, count=self.B)):
+            raise ValueError("gapped query and target differ in length")
+        cs = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1, 3) for c in coords]
+        self.Lt = np.fromiter((c.shape[0] for c in cs), dtype=np.int32, count=self.B)
+        self.xyz = np.ascontiguousarray(np.concatenate(cs, axis=0)) if int(self.Lt.sum()) else np.zeros((1, 3), np.float32)
+
+
+class HostPipeline:
+    """Host lists in -> host float32 score arrays out through the library's two-slot pipeline (mdf_engine_submit_alignments_host /
+    mdf_engine_collect_host): the batched counterpart of the reference's two loops (pipeline.py:476-481, 292-319) for a caller that has
+    Python lists and wants numpy arrays, at the device-resident rate -- packing of batch k + 1 and unpacking of batch k - 1 run under
+    the kernels of batch k.
+
+        pipe = HostPipeline(engine)
+        for scores in pipe.run(batches):       # batches: iterable of (seqs, coords, q_alns, t_alns); scores: {mode: (B, T) float32}, in order
+            ...
+    """
+
+    def __init__(self, engine: "HotPathEngine"):
+        self.engine = engine
+        self.L = engine.L
+        self._inflight = []   # (ticket, HostBatch, outputs)
+
+    def submit(self, seqs, coords, q_alns, t_alns):
+        hb = seqs if isinstance(seqs, HostBatch) else HostBatch(seqs, coords, q_alns, t_alns)
+        eng = self.engine
+        out = {m: np.empty((hb.B, p.n_terms), dtype=np.float32) for m, p in eng.predictors.items()}
+        ticket = _hip.c_int64(-1)
+        with _torch().cuda.device(eng.device):
+            _hip.check(self.L.mdf_engine_submit_alignments_host(eng.handle, hb.seq_bytes, _hip.ptr(hb.Lq), hb.B, _hip.ptr(hb.xyz), _hip.ptr(hb.Lt),
+                                                                 hb.q_bytes, hb.t_bytes, _hip.ptr(hb.La), ticket))
+        self._inflight.append((ticket.value, hb, out))
+        return ticket.value
+
+    def collect(self):
+        """Scores of the OLDEST batch in flight ({mode: (B, T) float32}); raises what the reference's loop would (ValueError on an invalid residue)."""
+        ticket, hb, out = self._inflight.pop(0)
+        eng = self.engine
+        ptrs = (ctypes.c_void_p * len(eng.modes))(*[out[m].ctypes.data for m in eng.modes])
+        info = (_hip.c_int64 * 4)()
+        with _torch().cuda.device(eng.device):
+            rc = self.L.mdf_engine_collect_host(eng.handle, ticket, ptrs, info)
+        if rc == _hip.MDF_EBADCHAR:
+            raise ValueError(f"Invalid character in sequence: {hb.seqs[info[0]][info[1]]}")
+        _hip.check(rc)
+        return out
+
+    def run(self, batches):
+        for item in batches:
+            if isinstance(item, HostBatch):
+                self.submit(item, None, None, None)
+            else:
+                self.submit(*item)
+            if len(self._inflight) == 2:
+                yield self.collect()
+        while self._inflight:
+            yield self.collect()
+
+
 class SequenceEngine:
     """Sequence-only CNN models for batches of proteins on one GPU: the batched counterpart of the reference's CNN loop
     over the unaligned queries (pipeline.py:600-648, `_run_prediction_loop(predictor=cnn, ...)`).

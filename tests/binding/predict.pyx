@@ -85,6 +85,9 @@ cdef extern from "mdfri.h":
     int mdf_engine_run_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords,
                                        const int32_t *Lt, const char *q_aln, const char *t_aln, const int32_t *La,
                                        float *const *scores_host, int64_t *info) nogil
+    int mdf_engine_submit_alignments_host(mdf_engine *e, const char *seqs, const int32_t *Lq, int32_t B, const float *coords,
+                                          const int32_t *Lt, const char *q_aln, const char *t_aln, const int32_t *La, int64_t *ticket) nogil
+    int mdf_engine_collect_host(mdf_engine *e, int64_t ticket, float *const *scores_host, int64_t *info) nogil
 
 DEF MDF_EBADCHAR = -4
 DEF MDF_DT_F32 = 1
@@ -295,3 +298,103 @@ def predict_batch(list predictors, list seqs, list coords, list q_alns, list t_a
     finally:
         mdf_engine_free(eng)
     return results
+
+
+cdef class BatchEngine:
+    """predict_batch for a caller with MANY batches: one engine for the object's life (predict_batch above makes and frees one per call)
+    and the library's two-slot host pipeline (mdf_engine_submit_alignments_host / mdf_engine_collect_host): `submit` returns as soon as
+    the batch is packed and enqueued, `collect` hands out the score arrays of the oldest batch in flight -- so the Python packing of batch
+    k + 1 and the unpacking of batch k - 1 run under the kernels of batch k.  `run(batches)` is the loop; `predict_batch` is submit + collect.
+
+        eng = BatchEngine([mf, bp, cc])
+        for scores in eng.run(batches):      # batches: iterable of (seqs, coords, q_alns, t_alns); scores: one (B, T) float32 array per Predictor
+            ...
+    """
+    cdef mdf_engine *_eng
+    cdef int _n
+    cdef list _predictors, _inflight
+
+    def __cinit__(self):
+        self._eng = NULL
+        self._n = 0
+
+    def __init__(self, list predictors, double threshold = 6.0, int generated_contacts = 2, int max_rows = 262144):   # (= MDF_DEFAULT_CHUNK_ROWS)
+        cdef mdf_model *models[MAX_HEADS]
+        cdef mdf_engine_config cfg
+        cdef Predictor pr
+        cdef int k, n = len(predictors)
+        if n == 0 or n > MAX_HEADS:
+            raise ValueError(f"1..{MAX_HEADS} predictors expected")
+        for k in range(n):
+            pr = predictors[k]
+            if pr._gcn == NULL:
+                raise ValueError("BatchEngine takes GCN predictors")
+            models[k] = pr._gcn
+        cfg.max_rows, cfg.nnz_per_row, cfg.threshold, cfg.generated_contacts = max_rows, 0, threshold, generated_contacts
+        cfg.max_segment_groups, cfg.lm_batch, cfg.lm_workspace_gib, cfg.graph_max_chunks, cfg.pipeline_contact = 0, 0, 0.0, 0, 0
+        _check(mdf_engine_create(models, n, 0, &cfg, &self._eng))
+        self._n = n
+        self._predictors = list(predictors)   # (the engine borrows their model handles)
+        self._inflight = []
+
+    def __dealloc__(self):
+        if self._eng != NULL:
+            mdf_engine_free(self._eng)
+
+    def submit(self, list seqs, list coords, list q_alns, list t_alns):
+        cdef int B = len(seqs), rc
+        cdef int64_t ticket = -1
+        if not (len(coords) == len(q_alns) == len(t_alns) == B) or B == 0:
+            raise ValueError("seqs, coords, q_alns and t_alns must be non-empty lists of one length")
+        cdef bytes sb = "".join(seqs).encode("ascii"), qb = "".join(q_alns).encode("ascii"), tb = "".join(t_alns).encode("ascii")
+        cdef cnp.ndarray[int32_t, ndim=1, mode="c"] Lq = np.fromiter(map(len, seqs), dtype=np.int32, count=B)
+        cdef cnp.ndarray[int32_t, ndim=1, mode="c"] La = np.fromiter(map(len, q_alns), dtype=np.int32, count=B)
+        if not np.array_equal(La, np.fromiter(map(len, t_alns), dtype=np.int32, count=B)):
+            raise ValueError("gapped query and target differ in length")
+        cs = [np.ascontiguousarray(c, dtype=np.float32).reshape(-1, 3) for c in coords]
+        cdef cnp.ndarray[int32_t, ndim=1, mode="c"] Lt = np.fromiter((c.shape[0] for c in cs), dtype=np.int32, count=B)
+        cdef cnp.ndarray[float, ndim=2, mode="c"] xyz = np.ascontiguousarray(np.concatenate(cs, axis=0)) if int(Lt.sum()) else np.zeros((1, 3), np.float32)
+        cdef const char *sp = sb
+        cdef const char *qp = qb
+        cdef const char *tp = tb
+        cdef const int32_t *lqp = <const int32_t *>Lq.data
+        cdef const int32_t *ltp = <const int32_t *>Lt.data
+        cdef const int32_t *lap = <const int32_t *>La.data
+        cdef const float *xp = <const float *>xyz.data
+        with nogil:
+            rc = mdf_engine_submit_alignments_host(self._eng, sp, lqp, B, xp, ltp, qp, tp, lap, &ticket)
+        _check(rc)
+        self._inflight.append((ticket, B, seqs))
+        return ticket
+
+    def collect(self):
+        """Score arrays of the oldest batch in flight: one (B, T) float32 array per Predictor, rows in the order the lists were given."""
+        cdef float *outs[MAX_HEADS]
+        cdef int64_t info[4]
+        cdef int64_t ticket
+        cdef int k, rc, B
+        if not self._inflight:
+            raise ValueError("no batch in flight")
+        t, B, seqs = self._inflight.pop(0)
+        ticket = t
+        results = [np.empty((B, (<Predictor>self._predictors[k])._T), dtype=np.float32) for k in range(self._n)]
+        for k in range(self._n):
+            outs[k] = <float *>cnp.PyArray_DATA(results[k])
+        with nogil:
+            rc = mdf_engine_collect_host(self._eng, ticket, outs, info)
+        if rc == MDF_EBADCHAR:
+            raise ValueError(f"Invalid character in sequence: {seqs[info[0]][info[1]]}")
+        _check(rc)
+        return results
+
+    def predict_batch(self, list seqs, list coords, list q_alns, list t_alns):
+        self.submit(seqs, coords, q_alns, t_alns)
+        return self.collect()
+
+    def run(self, batches):
+        for item in batches:
+            self.submit(*item)
+            if len(self._inflight) == 2:
+                yield self.collect()
+        while self._inflight:
+            yield self.collect()

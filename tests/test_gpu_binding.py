@@ -124,6 +124,36 @@ def test_predict_batch_10k_l512_through_the_compiled_binding(compiled, tmp_path)
         pr.predict_batch(preds, ["ACD", "AJD"], [coords[0][:3], coords[1][:3]], ["ACD", "AJD"], ["ACD", "AJD"])
 
 
+def test_batch_engine_of_the_compiled_binding_pipelines_batches_bitwise(compiled, tmp_path):
+    """Round 6: `BatchEngine` of the compiled module -- one engine for many batches, mdf_engine_submit_alignments_host /
+    mdf_engine_collect_host behind `run` -- against `predict_batch` (an engine per call, synchronous) on the same lists: the same bits, batch
+    after batch, in order; an invalid residue is raised at its batch's collect with the reference's message."""
+    _, pr = compiled
+    ws = {"mf": synthetic.glorot_gcn_weights(seed=0, n_terms=37), "cc": synthetic.glorot_gcn_weights(seed=2, n_terms=21)}
+    preds = []
+    for m, w in ws.items():
+        weights.save_mdfw(str(tmp_path / f"{m}.mdfw"), w)
+        preds.append(pr.Predictor(str(tmp_path / f"{m}.mdfw")))
+    sets = [synthetic.synthetic_proteins(seed=400 + k, count=n, length=ln, indel_rate=0.04) for k, (n, ln) in enumerate(((30, (20, 400)), (5, 512), (64, (16, 200))))]
+    cols = lambda ps: ([p["seq"] for p in ps], [p["coords"] for p in ps], [p["q_aln"] for p in ps], [p["t_aln"] for p in ps])  # noqa: E731
+    refs = [pr.predict_batch(preds, *cols(ps), max_rows=4096) for ps in sets]
+    be = pr.BatchEngine(preds, max_rows=4096)
+    got = list(be.run([cols(ps) for ps in sets] * 2))
+    assert len(got) == 6
+    for k, g in enumerate(got):
+        assert all(np.array_equal(a, b) for a, b in zip(g, refs[k % 3])), k
+    assert all(np.array_equal(a, b) for a, b in zip(be.predict_batch(*cols(sets[1])), refs[1]))
+    poisoned = [dict(p) for p in sets[0]]
+    k = [i for i, c in enumerate(poisoned[4]["q_aln"]) if c != "-"][1]
+    poisoned[4]["seq"] = poisoned[4]["seq"][:1] + "J" + poisoned[4]["seq"][2:]
+    poisoned[4]["q_aln"] = poisoned[4]["q_aln"][:k] + "J" + poisoned[4]["q_aln"][k + 1:]
+    be.submit(*cols(poisoned))
+    be.submit(*cols(sets[2]))
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        be.collect()
+    assert all(np.array_equal(a, b) for a, b in zip(be.collect(), refs[2]))
+
+
 def test_forked_pool_map_build_align_contact_map():
     """reference pipeline.py:476-481 from a parent that has not touched the GPU (a fresh interpreter: this pytest process has)."""
     env = dict(os.environ)

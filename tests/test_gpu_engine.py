@@ -89,6 +89,57 @@ def test_single_call_host_entry_reports_what_the_loop_would_raise(heads):
     assert all(np.array_equal(o, ref[m]) for m, o in zip(tight.modes, outs))
 
 
+def _poison(p, pos, letter="J"):
+    """protein `p` with residue `pos` of its query replaced by an invalid letter, in the sequence and in the gapped query alike"""
+    q = dict(p)
+    q["seq"] = p["seq"][:pos] + letter + p["seq"][pos + 1:]
+    k = [i for i, c in enumerate(p["q_aln"]) if c != "-"][pos]
+    q["q_aln"] = p["q_aln"][:k] + letter + p["q_aln"][k + 1:]
+    return q
+
+
+def test_host_pipeline_two_batches_in_flight_is_bitwise_the_single_call(heads):
+    """Round 6: mdf_engine_submit_alignments_host / mdf_engine_collect_host (mDeepFRI.batch.HostPipeline) -- pinned staging, a copy stream
+    either side of the compute stream, two batches in flight.  Batches of different sizes and chunk counts through one pipeline, in order:
+    every batch == the synchronous engine on the same lists, bit for bit.  A third submit is refused until the oldest is collected; an
+    invalid residue surfaces at ITS batch's collect (the reference's message, first in input order) and leaves the pipeline usable; a CSR
+    capacity far too small is raised and the batch re-run inside collect while the next batch is already in flight."""
+    from mDeepFRI.batch import HostPipeline, HotPathEngine
+    ws, preds = heads
+    sets = [synthetic.synthetic_proteins(seed=300 + k, count=n, length=ln, indel_rate=0.05) for k, (n, ln) in enumerate(((40, (20, 300)), (7, (100, 700)), (90, (16, 120)), (25, 256)))]
+    cols = lambda ps: ([p["seq"] for p in ps], [p["coords"] for p in ps], [p["q_aln"] for p in ps], [p["t_aln"] for p in ps])  # noqa: E731
+    eng = HotPathEngine(preds, device=0, max_rows=2048)
+    refs = [eng.run_alignments(_pack(ps, max_rows=2048)) for ps in sets]
+    pipe = HostPipeline(eng)
+    got = list(pipe.run([cols(ps) for ps in sets] * 2))
+    assert len(got) == 8
+    for k, g in enumerate(got):
+        assert all(np.array_equal(g[m], refs[k % 4][m]) for m in eng.modes), k
+    # the depth is two
+    pipe.submit(*cols(sets[0]))
+    pipe.submit(*cols(sets[1]))
+    with pytest.raises(ValueError, match="two batches are in flight"):
+        pipe.submit(*cols(sets[2]))
+    same = lambda got, want: all(np.array_equal(got[m], want[m]) for m in eng.modes)  # noqa: E731
+    assert same(pipe.collect(), refs[0])
+    # an invalid residue: reported when its batch is collected, batches around it unharmed
+    bad = [dict(p) for p in sets[2]]
+    for i, pos in ((50, 3), (11, 9)):
+        bad[i] = _poison(bad[i], pos)
+    pipe.submit(*cols(bad))
+    assert same(pipe.collect(), refs[1])
+    pipe.submit(*cols(sets[3]))
+    with pytest.raises(ValueError, match="Invalid character in sequence: J"):
+        pipe.collect()
+    assert same(pipe.collect(), refs[3])
+    # CSR capacity far too small: raised inside collect, with the next batch already enqueued behind
+    tight = HotPathEngine(preds, device=0, max_rows=2048, nnz_per_row=2)
+    tp = HostPipeline(tight)
+    out = list(tp.run([cols(sets[0]), cols(sets[1]), cols(sets[2])]))
+    for k, g in enumerate(out):
+        assert all(np.array_equal(g[m], refs[k][m]) for m in eng.modes), k
+
+
 @pytest.mark.parametrize("B,L", [(8, 512), (3, 77), (64, 200)])
 def test_short_batches_replay_as_one_graph_bitwise(heads, B, L):
     """A batch of at most graph_max_chunks chunks: from the third identical call on the launch sequence is ONE hipGraphLaunch.
