@@ -116,7 +116,7 @@ def launch_ranks(args) -> int:
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, deadline = [], 0.0
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -133,10 +133,16 @@ def launch_ranks(args) -> int:
                     rc = code
                     for q in procs:       # a dead rank would leave the others waiting in a collective
                         q.terminate()
+                    deadline = time.time() + 20.0   # ... and one that sits in a collective may not see SIGTERM: SIGKILL after a grace period
+            if rc != 0 and procs and time.time() > deadline:
+                for q in procs:
+                    q.kill()
             time.sleep(0.05)
     finally:
         for p in procs:
             p.kill()
+        for p in procs:
+            p.wait()
     return rc
 
 
@@ -432,6 +438,10 @@ def timed_run(ctx, eng, db, steps, warmup, after=None, timing_period=7):
     out = None
     for _ in range(warmup):
         out = step()
+    # fault injection for the launcher's test (tests/test_gpu_bench.py): this rank dies between warmup and the timed steps, with kernels of
+    # its own in flight and the other ranks on their way into the barrier below -- the parent must take them all down and report the failure
+    if os.environ.get("MDFRI_BENCH_FAIL_RANK") == str(ctx.rank):
+        os._exit(17)
     fence()
     eng.check(db)  # invalid residues / CSR overflow would surface here
     ctx.lib.mdf_timing_reset()
@@ -667,7 +677,10 @@ def main():
 
         def after(out):   # output stage on every rank, then ONE gather of the survivors per head
             for m in MODES:
-                off, ti, kept = filter_scores(out[m], threshold=0.1, capacity_per_protein=preds[m].n_terms)
+                if n_local:
+                    off, ti, kept = filter_scores(out[m], threshold=0.1, capacity_per_protein=preds[m].n_terms)
+                else:      # a rank that owns nothing sends empty blocks
+                    off, ti, kept = torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.float32, device=dev)
                 gathered[m] = plans[m].run(off, ti, kept, sizes_may_change=False)   # the same workload every step: sizes fixed by the first call
     else:
         n_local = args.proteins or 10000
@@ -684,8 +697,27 @@ def main():
             def after(out):
                 gathered["all"] = plan.run(torch.cat([out[m] for m in MODES], dim=1))
     seqs, coords, q_alns, t_alns = cols
-    pk = batch.PackedProteins.pack(seqs, coords, q_alns, t_alns, max_rows=args.chunk_rows)
-    db = eng.upload(pk)
+    if n_local == 0:
+        # a rank that owns nothing (fewer proteins than ranks): it runs no kernel, and its gather plan sends empty blocks -- what
+        # sharding.predict_sharded_filtered does for such a rank (tests/test_sharding_cpu.py at world size 8)
+        class _NoWork:
+            chunks, Lq = [], np.zeros(0, dtype=np.int32)
+
+        class _Idle:
+            modes = eng.modes
+
+            def forward_alignments(self, db):
+                return {m: torch.zeros((0, preds[m].n_terms), dtype=torch.float32, device=dev) for m in MODES}
+
+            def check(self, db):
+                return None
+
+            def last_chunk_nnz(self):
+                return 0
+        pk, db, eng = _NoWork(), None, _Idle()
+    else:
+        pk = batch.PackedProteins.pack(seqs, coords, q_alns, t_alns, max_rows=args.chunk_rows)
+        db = eng.upload(pk)
 
     # who is in the job: device name per rank and the world size as the backend reports it
     me = f"rank {ctx.rank}: {torch.cuda.get_device_name(dev)} (cuda:{local_rank})"

@@ -34,6 +34,33 @@ def cmap_golden():
 
 
 @pytest.fixture(scope="session")
+def cmap_special_golden():
+    """tests/golden/make_special_golden.py: subnormal / overflowing / signed-zero / NaN / inf coordinates and on-threshold pairs through the
+    compiled reference (D as bit patterns, the map per threshold, the aligned map)."""
+    return np.load(os.path.join(GOLDEN, "cmap_special_golden.npz"))
+
+
+def special_cases(g):
+    """(name, X, D bits, [(threshold, map)], {gen: aligned map}) per coordinate set of cmap_special_golden.npz"""
+    thr = [float(t) for t in g["thresholds"]]
+    for name in [str(x) for x in g["index/sets"]]:
+        X = np.ascontiguousarray(g[name + "/X"])
+        n = X.shape[0]
+        maps = [(t, np.unpackbits(g[f"{name}/cmap_bits/{k}"], axis=1)[:, :n].astype(np.int32)) for k, t in enumerate(thr)]
+        aligned = {gen: np.unpackbits(g[f"{name}/aligned_bits/gen{gen}"], axis=1)[:, :n].astype(np.int32) for gen in (0, 2)}
+        yield name, X, g[name + "/D_bits"], maps, aligned
+
+
+def same_float_bits(got, want_bits):
+    """float32 array == stored bit patterns, cell by cell; where the reference has a NaN only NaN-ness is compared (its sign and payload are
+    platform-specific: x86 SSE produces the negative default NaN, gfx950 the positive one; every later use is `D < thr`, false for any NaN)"""
+    want = np.asarray(want_bits, dtype=np.uint32).view(np.float32)
+    nan = np.isnan(want)
+    return got.dtype == np.float32 and got.shape == want.shape and np.array_equal(np.isnan(got), nan) and \
+        np.array_equal(got.view(np.uint32)[~nan], np.asarray(want_bits, dtype=np.uint32)[~nan])
+
+
+@pytest.fixture(scope="session")
 def gcn_golden():
     return np.load(os.path.join(GOLDEN, "gcn_golden.npz"))
 

@@ -52,6 +52,44 @@ def test_bare_python_launches_two_ranks_strong_filtered(workload, count):
     assert all(v > 0 for v in line["gathered_survivors"].values())
 
 
+def test_bare_python_launches_eight_ranks_weak_on_one_device():
+    """The node's REAL rank count on the one GPU of the test box: the bare-python parent starts eight rank processes, eight
+    engines share cuda:0 (default chunk size: three 512 MiB slabs each), gloo carries the gather -- configs2, weak scaling."""
+    line = _run("--gpus", "8", "--backend", "gloo", "--force-device", "0", "--proteins", "96", "--steps", "1", "--warmup", "1", "--cpu-seconds", "0", timeout=1500)
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["proteins_total"] == 8 * 96
+    assert line["verify"]["max_abs_err_vs_oracle"] < 1e-4
+    r = line["ranks"]
+    assert r["world_size"] == 8 and len(r["devices"]) == 8 and all("cuda:0" in d for d in r["devices"])
+    assert all(len(r["per_rank_ms_per_step"][k]) == 8 for k in ("compute_ms", "gather_ms", "step_ms"))
+
+
+@pytest.mark.parametrize("workload,count", [("configs3", 2400), ("configs4", 3000), ("configs3", 5)])
+def test_bare_python_launches_eight_ranks_strong_filtered(workload, count):
+    """... and the strong workloads: eight FilteredGatherPlans, the per-rank split of the step, the input order restored on rank 0; with 5
+    proteins three ranks of eight own nothing (their engines run no kernel, their gathers send empty blocks)."""
+    line = _run("--gpus", "8", "--backend", "gloo", "--force-device", "0", "--workload", workload, "--proteins", str(count), "--steps", "1",
+                "--warmup", "1", "--cpu-seconds", "0", "--chunk-rows", "16384", timeout=1500)
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["proteins_total"] == count
+    assert line["verify"]["max_abs_err_vs_oracle"] < 1e-4 and line["verify"]["gather_restores_input_order"] is True
+    assert all(len(line["ranks"]["per_rank_ms_per_step"][k]) == 8 for k in ("compute_ms", "gather_ms", "step_ms"))
+    if count >= 8:
+        assert all(v > 0 for v in line["gathered_survivors"].values())
+
+
+def test_a_rank_that_dies_takes_the_job_down():
+    """A rank process that dies between warmup and the timed steps (kernels in flight, the other seven heading into the barrier): the parent
+    terminates the others and exits non-zero -- it never hangs and never re-executes itself (a process that touched the GPU must not exec)."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["MDFRI_BENCH_FAIL_RANK"] = "3"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--backend", "gloo", "--force-device", "0", "--proteins", "64", "--steps", "1", "--warmup", "1",
+                        "--cpu-seconds", "0", "--chunk-rows", "16384"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 17, (r.returncode, r.stderr[-2000:])
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]      # no bench line from a broken job
+    assert time.time() - t0 < 600
+
+
 @pytest.mark.parametrize("workload,count,floor", [("configs3", 100_000, 52_000), ("configs4", 500_000, 95_000)])
 def test_strong_workloads_at_full_size_one_gpu(workload, count, floor):
     """BASELINE.json configs[3] (100 000 mixed-length proteins) and configs[4] (500 000, proteome length histogram) at their STATED

@@ -73,6 +73,47 @@ def test_pairwise_nan_rows_keep_zero_diagonal():
     assert np.all(np.diag(D) == 0)
 
 
+def test_special_values_bit_exact_vs_the_compiled_reference(cmap_special_golden):
+    """subnormal d^2 (points 1e-20 apart), d^2 that overflows to inf, -0.0 / 1e18-scale / NaN / inf coordinates and pairs exactly
+    on the threshold, against fixtures made by the compiled reference (tests/golden/make_special_golden.py): the per-call distance kernel bit
+    for bit (NaN cells: NaN-ness), the thresholded map at six thresholds (one float32 step either side of 6 A, 1e-19 A whose square is
+    subnormal, 3e19 A whose square overflows the float32 the comparison is made in, and 0), the per-call aligned map, and the batched contact
+    stage (k_cmap_bits: packed fp32 on row pairs away from the diagonal, per-row code next to it) through build_align_contact_maps.  The
+    kernels run with float32 denormals on (hipcc's default for gfx950; no flush-to-zero flag in csrc/Makefile): no divergence to document."""
+    from conftest import same_float_bits, special_cases
+    from mDeepFRI.alignment import AlignmentResult
+    from mDeepFRI.batch import build_align_contact_maps
+    from mDeepFRI.bio_utils import build_align_contact_map, calculate_contact_map
+    from mDeepFRI.contact_map_utils import pairwise_sqeuclidean
+    alns = []
+    for name, X, D_bits, maps, aligned in special_cases(cmap_special_golden):
+        assert same_float_bits(pairwise_sqeuclidean(X), D_bits), name
+        for thr, cm in maps:
+            got = calculate_contact_map(X, thr)
+            assert got.dtype == np.int32 and np.array_equal(got, cm), (name, thr, int(got.sum()), int(cm.sum()))
+        seq = "A" * X.shape[0]
+        for gen, want in aligned.items():
+            _, got = build_align_contact_map(Aln(X, seq, seq), 6.0, gen)
+            assert np.array_equal(got, want), (name, gen)
+        a = AlignmentResult(query_name=name, query_sequence=seq, target_name="t", target_sequence=seq, alignment="")
+        a.gapped_sequence, a.gapped_target, a.coords = seq, seq, X
+        alns.append((a, aligned))
+    for gen in (0, 2):      # the batched stage, the two sets side by side in one launch (and once more behind a long protein: another chunk geometry)
+        for extra in ([], [800]):
+            batch = [a for a, _ in alns]
+            for L in extra:
+                rng = np.random.default_rng(L)
+                s2 = synthetic.random_sequence(rng, L)
+                b = AlignmentResult(query_name="pad", query_sequence=s2, target_name="t", target_sequence=s2, alignment="")
+                b.gapped_sequence, b.gapped_target, b.coords = s2, s2, synthetic.random_walk_coords(rng, L)
+                batch = [b] + batch
+            res = build_align_contact_maps(batch, threshold=6.0, generated_contacts=gen, device=0)
+            for (a, aligned), (_, got) in zip(alns, res[len(extra):]):
+                assert got.dtype == np.int32 and np.array_equal(got, aligned[gen]), (a.query_name, gen, extra)
+        # ... and the fused path's contact stage (k_cmap_bits + k_cmap_fill_rows): the CSR holds exactly the reference's contacts
+        _assert_csr_holds_exactly_these_maps([(a.query_name, a.coords, a.gapped_sequence, a.gapped_target, aligned[gen]) for a, aligned in alns], 6.0, gen)
+
+
 def test_align_golden_cases_bit_exact(cmap_golden):
     from mDeepFRI.contact_map_utils import align_contact_map
     for n in [str(x) for x in cmap_golden["index/align"]]:
@@ -239,6 +280,40 @@ def test_batched_build_align_contact_maps_matches_per_call():
             assert np.array_equal(cm, orc.build_align_contact_map(a.coords, a.gapped_sequence, a.gapped_target, 6.0, 2))
 
 
+def _assert_csr_holds_exactly_these_maps(cases, thr, gen):
+    """The CSR the fused GCN path consumes (mdf_cmap_csr_dev: k_align_scan + k_cmap_bits + k_cmap_fill_rows) for `cases` = [(name, coords, q_aln,
+    t_aln, expected aligned map)]: every row's column set == the expected map's row (plus the self loop GraphConv adds)."""
+    import ctypes
+    import torch
+    from mDeepFRI import _hip
+    from mDeepFRI.batch import DeviceBatch, PackedProteins, _p
+    L = _hip.lib()
+    dev = torch.device("cuda:0")
+    pk = PackedProteins.pack([q.replace("-", "") for _, _, q, _, _ in cases], [c for _, c, _, _, _ in cases], [q for _, _, q, _, _ in cases],
+                             [t for _, _, _, t, _ in cases], max_rows=65536, keep_order=True)   # (the stage is driven by hand below: plan position = batch position)
+    assert len(pk.chunks) == 1
+    db, R = DeviceBatch(pk, dev), pk.chunks[0].rows
+    max_len, cap = int(pk.Lq.max()), R * 256
+    ws = torch.empty(L.mdf_cmap_workspace_bytes(pk.B, R, max_len), dtype=torch.uint8, device=dev)
+    rowptr = torch.empty(R + 1, dtype=torch.int32, device=dev)
+    colidx = torch.empty(cap, dtype=torch.int32, device=dev)
+    val = torch.empty(cap, dtype=torch.float32, device=dev)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _hip.check(L.mdf_cmap_csr_dev(_p(db.coords), _p(db.coord_off), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off), _p(db.Lq), _p(db.chunk_row_off), pk.B, R,
+                                  max_len, thr, gen, _p(rowptr), _p(colidx), _p(val), cap, _p(status), None, None, _p(ws), ws.numel(), st))
+    torch.cuda.synchronize()
+    assert status.tolist() == [0, 0, 0, 0]
+    rp, ci = rowptr.cpu().numpy(), colidx.cpu().numpy()
+    ro = pk.chunk_row_off
+    for k, (n, _, _, _, out) in enumerate(cases):
+        r0 = int(ro[k])
+        for i in range(out.shape[0]):
+            cols = ci[rp[r0 + i]:rp[r0 + i + 1]] - r0
+            exp = np.flatnonzero(out[i] | (np.arange(out.shape[0]) == i))          # GraphConv adds the self loop
+            assert np.array_equal(cols, exp), (n, i)
+
+
 def test_other_thresholds_against_the_compiled_reference_goldens():
     """(10 A, 2) -- the operating point of the released `..._ca_10.0_...` models --, (4, 0), (8, 5), (10, 0), (7.5, 1): the per-call
     drop-in functions, the fused per-call build and the batched dense build, bit for bit against outputs of the COMPILED REFERENCE
@@ -270,30 +345,7 @@ def test_other_thresholds_against_the_compiled_reference_goldens():
         res = build_align_contact_maps([Aln(c, q, t) for _, c, q, t, _ in cases], thr, gen, max_rows=1024)
         for (n, _, _, _, out), (_, cm) in zip(cases, res):
             assert np.array_equal(cm, out), n
-        # the CSR of the fused path: every row's column set == the reference map's row
-        pk = PackedProteins.pack([q.replace("-", "") for _, _, q, _, _ in cases], [c for _, c, _, _, _ in cases], [q for _, _, q, _, _ in cases],
-                                 [t for _, _, _, t, _ in cases], max_rows=65536, keep_order=True)   # (the stage is driven by hand below: plan position = batch position)
-        assert len(pk.chunks) == 1
-        db, R = DeviceBatch(pk, dev), pk.chunks[0].rows
-        max_len, cap = int(pk.Lq.max()), R * 128
-        ws = torch.empty(L.mdf_cmap_workspace_bytes(pk.B, R, max_len), dtype=torch.uint8, device=dev)
-        rowptr = torch.empty(R + 1, dtype=torch.int32, device=dev)
-        colidx = torch.empty(cap, dtype=torch.int32, device=dev)
-        val = torch.empty(cap, dtype=torch.float32, device=dev)
-        status = torch.zeros(4, dtype=torch.int32, device=dev)
-        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        _hip.check(L.mdf_cmap_csr_dev(_p(db.coords), _p(db.coord_off), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off), _p(db.Lq), _p(db.chunk_row_off), pk.B, R,
-                                      max_len, thr, gen, _p(rowptr), _p(colidx), _p(val), cap, _p(status), None, None, _p(ws), ws.numel(), st))
-        torch.cuda.synchronize()
-        assert status.tolist() == [0, 0, 0, 0]
-        rp, ci = rowptr.cpu().numpy(), colidx.cpu().numpy()
-        ro = pk.chunk_row_off
-        for k, (n, _, _, _, out) in enumerate(cases):
-            r0 = int(ro[k])
-            for i in range(out.shape[0]):
-                cols = ci[rp[r0 + i]:rp[r0 + i + 1]] - r0
-                exp = np.flatnonzero(out[i] | (np.arange(out.shape[0]) == i))          # GraphConv adds the self loop
-                assert np.array_equal(cols, exp), (n, i)
+        _assert_csr_holds_exactly_these_maps(cases, thr, gen)
 
 
 def test_csr_stage_flags_a_query_longer_than_max_len():

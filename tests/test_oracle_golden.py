@@ -99,6 +99,25 @@ def test_chain_cases_at_other_thresholds_bit_exact():
             assert np.array_equal(np.packbits(out.astype(np.uint8), axis=1), z[n + "/out_bits"]), n
 
 
+def test_special_values_through_the_oracle(cmap_special_golden):
+    """the C restatement against the compiled reference on squared distances that are subnormal, overflow to inf, involve
+    -0.0 / NaN / inf coordinates or sit exactly on the threshold, at thresholds one float32 step either side of 6 A, tiny, huge (its square
+    overflows float32: numpy compares with inf) and zero: D bit for bit, the int32 map per threshold, the aligned map."""
+    from conftest import same_float_bits, special_cases
+    seen = 0
+    for name, X, D_bits, maps, aligned in special_cases(cmap_special_golden):
+        D = orc.pairwise_sqeuclidean(X)
+        assert same_float_bits(D, D_bits), name
+        for thr, cm in maps:
+            assert np.array_equal(orc.calculate_contact_map(X, thr), cm), (name, thr)
+        seq = "A" * X.shape[0]
+        for gen, want in aligned.items():
+            assert np.array_equal(orc.build_align_contact_map(X, seq, seq, 6.0, gen), want), (name, gen)
+        Dw = np.asarray(D_bits, dtype=np.uint32).view(np.float32)
+        seen += int(((Dw > 0) & (Dw < np.finfo(np.float32).tiny)).sum()) + int(np.isinf(Dw).sum()) + int(np.isnan(Dw).sum())
+    assert seen > 2500      # the fixtures do hold subnormal, inf and NaN cells
+
+
 def test_oracle_against_live_reference_when_present():
     """When oracle/_ref (the compiled reference) is available, fuzz the restatement against it directly."""
     import build_ref
