@@ -17,6 +17,20 @@
  *     "dev" entry points take device pointers and a hipStream_t (passed as void*), enqueue work and
  *     return without synchronising: they are the batched counterpart the reference lacks.
  *   - there is NO CPU fallback: without a GPU every compute entry point fails with MDF_ENODEVICE.
+ *
+ * Environment switches (ALL of them; each is read once per process or per object, so set it before the first call; round 6 removed the
+ * other 23 developer knobs of rounds 1-5 with the kernel variants behind them -- experiments/r06_pruned_variants.patch)
+ *   MDFRI_HW_PIPE=f32            the GraphConv / LSTM products on v_mfma_f32_32x32x2_f32 instead of BF16x6 (mdf_hw_pipe() reports the pipe;
+ *                                another arithmetic: tests/test_gpu_gcn.py::test_bf16x6_products_are_at_least_as_accurate_as_the_fp32_instruction)
+ *   MDFRI_L1_FUSE=0              layer 1 by k_layer1 for every row instead of inside the layer-2 aggregation launch (mdf_layer1_form();
+ *                                bit-identical: tests/test_gpu_engine.py::test_layer1_made_inside_the_aggregation_kernel_is_bit_identical)
+ *   MDFRI_AX_MFMA=0              every protein through the CSR gather instead of the per-protein choice with the matrix-pipe aggregation
+ *                                (another summation order, agreement to 1e-5: ...::test_gather_everywhere_knob_agrees_with_the_matrix_pipe_form)
+ *   MDFRI_ENGINE_GRAPH=0         an engine never replays short batches as a hipGraph (bit-identical: ...::test_graph_replay_knob_is_bit_identical)
+ *   MDFRI_LM_PERSISTENT_MAX_B=n  largest group of the one-launch LSTM, 0 = always the per-step GEMM form (bit-identical: tests/test_gpu_lm.py)
+ *   MDFRI_NW_INT16=0             the aligner's 32-bit sweep for every pair instead of the packed 16-bit one where it qualifies (identical
+ *                                alignments: tests/test_gpu_nw.py)
+ *   (Python layer: MDFRI_HIP_LIB, MDFRI_DEVICE, MDFRI_NO_TORCH_HIP_PRELOAD -- mDeepFRI/_hip.py)
  */
 #ifndef MDFRI_H
 #define MDFRI_H
@@ -309,7 +323,7 @@ int mdf_dense_to_csr_masks_dev(const void *cmaps, int cmap_dtype, const int64_t 
  * floats, element (row, letter a) at MDF_LSUM_INDEX(row, a): the 16 bytes a lane of that kernel loads are the four letters it feeds to four
  * consecutive matrix instructions, a wave's load instruction covers 2 x 512 contiguous bytes (8 cache lines instead of 32: the row-major
  * form cost 160 of 500 us per launch in L1 line look-ups, profiles/r06_ax_timeline.txt).  Every producer (mdf_cmap_csr_dev,
- * mdf_letter_sums_dev) and consumer (mdf_gcn_embed_*_dev, mdf_gcn_stage_dev) of this library uses the macro. */
+ * mdf_letter_sums_dev) and consumer (mdf_gcn_embed_*_dev) of this library uses the macro. */
 #define MDF_LSUM_INDEX(row, a) \
     ((size_t)((row) >> 4) * 512 + (size_t)((((a) >> 3) * 128) + ((((a) & 1) * 16 + ((row) & 15)) * 4) + (((a) >> 1) & 3)))
 int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
@@ -397,15 +411,6 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
 /* ... with the aggregation kernels chosen per protein as `agg` says (NULL: the CSR gather for every row, = mdf_gcn_embed_dev) */
 int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
                           int64_t R, const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, void *stream);
-/* ... one STAGE at a time, for a caller that issues the two kinds of stage on different streams (the engine's split form: the
- * aggregations, bound by HBM, beside the H.W products, bound by the matrix pipe and the board's power limit; events of the caller order
- * them).  Stage 0 = layer 1 + the aggregation of layer 2; stage 2 j - 1 = the H.W product of upper layer j; stage 2 j = the aggregation of
- * upper layer j + 1; mdf_gcn_num_stages = 2 (n_gc - 1), or 1 for a one-layer model.  All stages of one stack take the same arguments and the
- * same workspace; run in order they are mdf_gcn_embed_agg_dev, bit for bit.  gemm_blocks > 0: the stream of this stage owns that many CUs
- * (hipExtStreamCreateWithCUMask): the persistent H.W grid is sized for them; 0 = the whole device. */
-int mdf_gcn_num_stages(const mdf_model *m);
-int mdf_gcn_stage_dev(mdf_model *m, int stage, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
-                      const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, int gemm_blocks, void *stream);
 
 /* The same stage for a model with a language-model branch (lm_dim > 0): X0 = relu(lm_h.W_lm + b_lm + W_aa[seq_idx]) on the
  * MFMA GEMM (table row added in the epilogue), then every GraphConv layer as A.X + H.W (layer 1 over `embed` channels).

@@ -814,11 +814,6 @@ __device__ unsigned long long *g_fill_stamps = nullptr;   // experiments/cmap_st
 #else
 #define MDF_FILL_STAMP(i_)
 #endif
-static bool fill_words_form()
-{
-    static const bool v = [] { const char *e = getenv("MDFRI_CMAP_FILL"); return e && !strcmp(e, "words"); }();   // developer A/B knob: k_cmap_fill + k_scan_groups
-    return v;
-}
 static inline int fill_rows_cols_cap(int32_t max_len) { return 2 * ((max_len + 63) / 64 * 64) + FILL_ROWS; }
 static inline size_t fill_rows_lds(int32_t max_len, int W, bool ls)
 {
@@ -1434,21 +1429,16 @@ int mdf_cmap_csr_pairs_dev(const float *coords, const int32_t *coord_off, const 
     const int G = (int)(R / 32), W = mask_words(max_len);
     const float t2 = thr2_f32(threshold);
     ScopedTiming tm(TK_CMAP, st);
-    static const bool rows_old = [] { const char *e = getenv("MDFRI_CMAP_ROWS"); return e && !strcmp(e, "old"); }();   // developer A/B knob: k_cmap_rows<COUNT>
     hipLaunchKernelGGL(k_align_scan, dim3(B), dim3(256), 0, st, q_aln, t_aln, aln_off, row_off, w.q2t, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (int32_t *)nullptr, (int)off_stride, w.owner, (int)B, (int)R, rows_old ? (float4 *)nullptr : w.qx, coords, coord_off);
-    // ONE pass over the coordinates: row counts + the contact bits themselves ...
-    if (rows_old)
-        hipLaunchKernelGGL(k_cmap_rows<CM_COUNT>, dim3(G), dim3(256), 0, st, coords, coord_off, Lq, row_off, B, w.q2t, t2,
-                           generated_contacts, w.counts, w.group_sum, w.masks, W, (int32_t *)nullptr, (const int64_t *)nullptr, (int)off_stride,
-                           (const int32_t *)w.owner);
-    else
-        hipLaunchKernelGGL(k_cmap_bits, dim3(G), dim3(BITS_THREADS), 0, st, (const float4 *)w.qx, Lq, row_off, t2, generated_contacts, w.counts, w.group_sum, w.masks, W,
-                           (const int32_t *)w.owner);
+                       (int32_t *)nullptr, (int32_t *)nullptr, (int)off_stride, w.owner, (int)B, (int)R, w.qx, coords, coord_off);
+    // ONE pass over the coordinates: row counts + the contact bits themselves ...  (the round-1-4 kernel of this step, k_cmap_rows<COUNT>, left the
+    // library in round 6 with its A/B knob: experiments/r06_pruned_variants.patch)
+    hipLaunchKernelGGL(k_cmap_bits, dim3(G), dim3(BITS_THREADS), 0, st, (const float4 *)w.qx, Lq, row_off, t2, generated_contacts, w.counts, w.group_sum, w.masks, W,
+                       (const int32_t *)w.owner);
     // ... then the CSR (and the layer-1 letter sums) from the bits; the exclusive scan of the groups' entry counts is a launch of its own only
     // where the fill kernel does not sum them itself (see k_cmap_fill_rows)
-    const bool rows_form = !fill_words_form() && fill_rows_lds(max_len, W, letter_sums != nullptr) <= 64 * 1024;   // (else: proteins beyond ~3 000 residues, the word-per-lane form)
-    static const int scan_max = getenv("MDFRI_FILL_SCAN_MAX") ? atoi(getenv("MDFRI_FILL_SCAN_MAX")) : 16384;   // developer knob (groups)
+    const bool rows_form = fill_rows_lds(max_len, W, letter_sums != nullptr) <= 64 * 1024;   // (else: proteins beyond ~3 000 residues, the word-per-lane form)
+    constexpr int scan_max = 16384;   // groups the fill kernel sums itself (measured: experiments/r05_fill_scan_max_ab.sh)
     const int G_scan = rows_form && G <= scan_max ? G : 0;
     if (!G_scan) hipLaunchKernelGGL(k_scan_groups, dim3(1), dim3(256), 0, st, w.group_sum, G, w.group_base, rowptr + R, nnz_cap, status);
     if (!rows_form) {
@@ -1458,13 +1448,6 @@ int mdf_cmap_csr_pairs_dev(const float *coords, const int32_t *coord_off, const 
     } else {
         const int cols_cap = fill_rows_cols_cap(max_len);
         const size_t lds = fill_rows_lds(max_len, W, letter_sums != nullptr);
-#ifdef MDF_FILL_STAMPS
-        if (getenv("MDFRI_FILL_NOCSR")) {   // timing experiment of the probe: the loop without its CSR stores
-            hipLaunchKernelGGL((k_cmap_fill_rows<false, true>), dim3((unsigned)(R / FILL_ROWS)), dim3(FILL_THREADS), lds, st, Lq, row_off, (const int32_t *)w.counts,
-                               (const int32_t *)w.group_base, (const unsigned long long *)w.masks, W, rowptr, colidx, val, (int)nnz_cap, seq_idx, letter_sums, status,
-                               cols_cap, (const int32_t *)w.owner, (const int32_t *)w.group_sum, G_scan, rowptr + R);
-        } else
-#endif
         if (letter_sums)
             hipLaunchKernelGGL((k_cmap_fill_rows<true, true>), dim3((unsigned)(R / FILL_ROWS)), dim3(FILL_THREADS), lds, st, Lq, row_off, (const int32_t *)w.counts,
                                (const int32_t *)w.group_base, (const unsigned long long *)w.masks, W, rowptr, colidx, val, (int)nnz_cap, seq_idx, letter_sums, status,

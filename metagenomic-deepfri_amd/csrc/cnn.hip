@@ -286,8 +286,7 @@ int mdf_cnn_pool_dev(mdf_cnn *m, const uint8_t *seq_idx, const int32_t *Lq, cons
     const int n_groups = (int)(R / 32);
     MDF_HIP(hipMemsetAsync(pooled, 0, (size_t)B * m->Cpad * 4, st));   // relu floor; channels C..Cpad stay zero
     ScopedTiming tm(TK_CNN, st);
-    static const bool no_lds = getenv("MDFRI_CNN_NO_LDS") != nullptr;   // developer knob: force the cache form
-    const int n_lds = no_lds ? 0 : m->n_lds_tiles;
+    const int n_lds = m->n_lds_tiles;
     if (n_lds > 0) {
         {
             static PerDeviceOnce once;   // per-device function attribute

@@ -520,11 +520,6 @@ struct GraphEntry {
     uint64_t last_use = 0;
 };
 
-// H.W CUs of the split form when MDFRI_SPLIT_CUS is not set (0 = one-stream form)
-#ifndef MDF_SPLIT_CUS_DEFAULT
-#define MDF_SPLIT_CUS_DEFAULT 0
-#endif
-
 // one slot of the host pipeline (mdf_engine_submit_alignments_host, near the end of this file)
 struct mdf_host_slot {
     char *pin_in = nullptr, *pin_out = nullptr;
@@ -559,12 +554,6 @@ struct mdf_engine {
     hipStream_t aux = nullptr;        // low-priority stream of the pipelined contact stage
     hipEvent_t ev_fork = nullptr;
     bool pipeline_contact = false;
-    // split form (see forward_alignments_split): the H.W products on `split_cus` CUs, everything bound by HBM (contact stage, layer 1,
-    // aggregations) on the others, each on a stream of its own made with hipExtStreamCreateWithCUMask; two stacks in flight
-    int split_cus = 0;                // 0 = off
-    hipStream_t sg = nullptr, sx = nullptr;
-    hipEvent_t ev_stage[2][4] = {{nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}}, ev_join[2] = {nullptr, nullptr};
-    DevBuf gws2;                      // the second stack's slabs
     DevBuf perm, pool_scratch;        // plans that order the batch: descriptors in plan order; the pooled rows on their way back to input order
     int last_set = 0;
     DevBuf gws, hws, seq_all, lm_ws, map_dev[2], flags;
@@ -639,8 +628,7 @@ extern "C" int mdf_engine_create(mdf_model *const *models, int32_t n_models, int
     // groups ahead of the contact stage): +0.8 % on the step, but the aggregation kernel loses 15 % next to the co-resident contact
     // kernels, so the default keeps everything on the caller's stream
     {
-        static const int knob = getenv("MDFRI_CONTACT_PIPELINE") ? atoi(getenv("MDFRI_CONTACT_PIPELINE")) : -1;   // developer knob: 0 / 1 override
-        const bool want = knob >= 0 ? knob != 0 : e->cfg.pipeline_contact > 0;
+        const bool want = e->cfg.pipeline_contact > 0;
         if (want && e->lms.empty()) {
             DeviceGuard g(device);
             int lo = 0, hi = 0;
@@ -652,28 +640,6 @@ extern "C" int mdf_engine_create(mdf_model *const *models, int32_t n_models, int
                      hipEventCreateWithFlags(&c.free, hipEventDisableTiming) == hipSuccess;
             if (!ok) (void)hipGetLastError();
             e->pipeline_contact = ok;
-        }
-    }
-    // Split form: MDFRI_SPLIT_CUS = CUs of the H.W stream (a multiple of 32: whole groups of four per XCD keep the tile order's L2 sharing),
-    // 0 = off.  Engines without a language model only (those issue whole LSTM groups between the stages).
-    {
-        static const int knob = getenv("MDFRI_SPLIT_CUS") ? atoi(getenv("MDFRI_SPLIT_CUS")) : MDF_SPLIT_CUS_DEFAULT;
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-        const int want = knob / 32 * 32;
-        if (want > 0 && want < cus && cus <= 256 && e->lms.empty() && !e->pipeline_contact) {
-            DeviceGuard g(device);
-            uint32_t mg[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            // mask bit i is CU (i / 8) of XCD (i % 8) (experiments/cumask_probe.hip): the first `want` bits are want / 8 CUs of every XCD
-            for (int b = 0; b < cus; ++b) (b < want ? mg : mx)[b >> 5] |= 1u << (b & 31);
-            bool ok = hipExtStreamCreateWithCUMask(&e->sg, 8, mg) == hipSuccess && hipExtStreamCreateWithCUMask(&e->sx, 8, mx) == hipSuccess;
-            if (!e->ev_fork) ok = ok && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
-            for (int i = 0; i < 2 && ok; ++i) {
-                for (int k = 0; k < 4 && ok; ++k) ok = hipEventCreateWithFlags(&e->ev_stage[i][k], hipEventDisableTiming) == hipSuccess;
-                ok = ok && hipEventCreateWithFlags(&e->ev_join[i], hipEventDisableTiming) == hipSuccess;
-            }
-            if (!ok) (void)hipGetLastError();
-            e->split_cus = ok ? want : 0;
         }
     }
     e->partial.resize(e->models.size());
@@ -707,14 +673,6 @@ extern "C" void mdf_engine_free(mdf_engine *e)
     }
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
     if (e->aux) (void)hipStreamDestroy(e->aux);
-    if (e->sg) (void)hipStreamDestroy(e->sg);
-    if (e->sx) (void)hipStreamDestroy(e->sx);
-    for (int i = 0; i < 2; ++i) {
-        for (int k = 0; k < 4; ++k)
-            if (e->ev_stage[i][k]) (void)hipEventDestroy(e->ev_stage[i][k]);
-        if (e->ev_join[i]) (void)hipEventDestroy(e->ev_join[i]);
-    }
-    e->gws2.release();
     e->perm.release();
     e->pool_scratch.release();
     if (e->map_stream) (void)hipStreamDestroy(e->map_stream);
@@ -754,7 +712,7 @@ static int ensure(mdf_engine *e, int64_t rows, int32_t B, int32_t max_len, int64
         MDF_REQUIRE(cap < 0x7fffffffLL, "engine: %lld rows x %d entries per row exceed the int32 CSR; lower max_rows", (long long)rows, e->cfg.nnz_per_row);
         size_t gws = 0;
         for (mdf_model *m : e->models) gws = std::max(gws, mdf_gcn_workspace_bytes(m, rows));
-        for (int k = 0; k < (e->pipeline_contact || e->split_cus ? 2 : 1); ++k) {
+        for (int k = 0; k < (e->pipeline_contact ? 2 : 1); ++k) {
             mdf_engine::ContactSet &c = e->cs[k];
             if (int rc = c.rowptr.grow((size_t)(rows + 1) * 4, gen)) return rc;
             if (int rc = c.colidx.grow((size_t)cap * 4, gen)) return rc;
@@ -767,8 +725,6 @@ static int ensure(mdf_engine *e, int64_t rows, int32_t B, int32_t max_len, int64
             if (int rc = c.tiles.grow((size_t)rows * mdf_agg_tile_row_bytes(max_len), gen)) return rc;   // the contact bits as the kernel's byte tiles
         }
         if (int rc = e->gws.grow(gws, gen)) return rc;
-        if (e->split_cus)
-            if (int rc = e->gws2.grow(gws, gen)) return rc;
         e->rows_alloc = rows;
         e->nnz_cap = cap;
         e->len_alloc = max_len;
@@ -988,104 +944,12 @@ static int contact_chunk(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev 
                             e->want_lsum ? c.lsum.as<float>() : nullptr, c.cws.p, c.cws.bytes, st);
 }
 
-// Split form (round 5).  The H.W products sit on the board's power limit -- on fewer CUs the clock rises and they take little longer
-// (65 536 x 512 x 512: 170 us on 256 CUs, 198 us on 192, experiments/cumask_probe.hip) -- while everything else of a stack is bound by HBM
-// and does not slow them down from other CUs.  So the engine owns two streams made with CU masks: `sg` (split_cus CUs, the same number in
-// every XCD) runs the products, `sx` (the other CUs) the contact stage, layer 1 and the aggregations; two stacks (chunk, head) are in flight
-// on two sets of slabs, issued stage by stage so that a product of one always has an aggregation of the other beside it:
-//     sx:  A2(a)  A2(b)  A3(a)  A3(b)  A2(c)  A2(d) ...
-//     sg:         G2(a)  G2(b)  G3(a)  G3(b)  G2(c) ...
-// Events carry the order inside a stack and the reuse of a set of slabs; the contact outputs alternate between the two contact sets (only
-// `sx` touches them, in order).  Same kernels, same operands: bit-identical to the one-stream form.  Not under graph capture (a captured
-// launch loses its stream's CU mask) and not with a language model.
-static int forward_alignments_split(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, float *const *scores, float *const *logits, hipStream_t st)
-{
-    const int nC = (int)pl->chunks.size(), nM = (int)e->models.size();
-    hipStream_t sx = e->sx, sg = e->sg;
-    MDF_HIP(hipEventRecord(e->ev_fork, st));          // whatever precedes this call on st (uploads, the previous batch) comes first
-    MDF_HIP(hipStreamWaitEvent(sx, e->ev_fork, 0));
-    MDF_HIP(hipStreamWaitEvent(sg, e->ev_fork, 0));
-    mdf_agg_desc agg[2][2];
-    const mdf_agg_desc *aggp[2] = {nullptr, nullptr};
-    int prepared = -1;                                 // chunks up to this one have had their contact stage issued
-    bool slab_used[2] = {false, false};
-    DevBuf *slabs[2] = {&e->gws, &e->gws2};
-    auto sx_into_sg = [&]() -> int {                   // everything issued on sx so far comes before what sg is given next
-        MDF_HIP(hipEventRecord(e->ev_join[0], sx));
-        MDF_HIP(hipStreamWaitEvent(sg, e->ev_join[0], 0));
-        return MDF_OK;
-    };
-    // one stage of stack (chunk ci, head k) on slab set `slot`
-    auto stage = [&](int ci, int k, int slot, int s) -> int {
-        const PlanChunk &ch = pl->chunks[(size_t)ci];
-        mdf_engine::ContactSet &c = e->cs[ci & 1];
-        mdf_model *m = e->models[(size_t)k];
-        hipStream_t on = (s & 1) ? sg : sx;
-        if (s == 0) {
-            for (; prepared < ci; ++prepared) {        // the chunk's contact stage, once, in front of its first stack
-                const int cn = prepared + 1;
-                mdf_engine::ContactSet &cc = e->cs[cn & 1];
-                if (int rc = contact_chunk(e, pl, b, cn, cc, sx)) return rc;
-                if (int rc = chunk_agg_desc(e, cc, pl, b, pl->chunks[(size_t)cn], /*bits=*/true, nullptr, sx, agg[cn & 1], &aggp[cn & 1])) return rc;
-            }
-            if (slab_used[slot]) MDF_HIP(hipStreamWaitEvent(sx, e->ev_stage[slot][3], 0));   // the stack that used these slabs before has run its last stage
-        } else {
-            MDF_HIP(hipStreamWaitEvent(on, e->ev_stage[slot][s - 1], 0));
-        }
-        float *part = e->partial[(size_t)k].as<float>() + (size_t)ch.group_base * (size_t)mdf_model_feature_dim(m);
-        if (int rc = mdf_gcn_stage_dev(m, s, c.lsum.as<float>(), c.rowptr.as<int32_t>(), c.colidx.as<int32_t>(), c.val.as<float>(), ch.rows, aggp[ci & 1], part,
-                                       slabs[slot]->p, slabs[slot]->bytes, (s & 1) ? e->split_cus : 0, on))
-            return rc;
-        const int last = mdf_gcn_num_stages(m) - 1;
-        // (the last stage's event goes into slot 3 whatever its number: "this set of slabs is free again")
-        MDF_HIP(hipEventRecord(e->ev_stage[slot][s == last ? 3 : s], on));
-        if (s == last) slab_used[slot] = true;
-        return MDF_OK;
-    };
-    // stacks in issue order, two at a time; a pair never straddles a pooling segment (the next segment reuses the partial arrays)
-    int ci = 0, k = 0;
-    auto next = [&](int &c2, int &k2) { if (++k2 == nM) k2 = 0, ++c2; };
-    while (ci < nC) {
-        const int a_ci = ci, a_k = k;
-        next(ci, k);
-        const bool seg_end_a = ci > a_ci && (ci == nC || pl->chunks[(size_t)ci].segment != pl->chunks[(size_t)a_ci].segment);
-        int b_ci = -1, b_k = 0;
-        if (!seg_end_a && ci < nC) b_ci = ci, b_k = k, next(ci, k);
-        const int Sa = mdf_gcn_num_stages(e->models[(size_t)a_k]), Sb = b_ci >= 0 ? mdf_gcn_num_stages(e->models[(size_t)b_k]) : 0;
-        MDF_REQUIRE(Sa <= 4 && Sb <= 4, "engine: a GraphConv stack of more than three layers");
-        for (int s2 = 0; s2 < std::max(Sa, Sb); ++s2) {
-            if (s2 < Sa)
-                if (int rc = stage(a_ci, a_k, 0, s2)) return rc;
-            if (s2 < Sb)
-                if (int rc = stage(b_ci, b_k, 1, s2)) return rc;
-        }
-        const int done_ci = b_ci >= 0 ? b_ci : a_ci, done_k = b_ci >= 0 ? b_k : a_k;
-        if (done_k == nM - 1 && (done_ci + 1 == nC || pl->chunks[(size_t)done_ci + 1].segment != pl->chunks[(size_t)done_ci].segment)) {
-            // the segment's last stack has been issued: pool it on sg behind everything (its partial sums come from both streams), and let
-            // the next segment's first launches on sx wait for the pooling (they overwrite the partial arrays)
-            if (int rc = sx_into_sg()) return rc;
-            if (int rc = pool_segment(e, pl, pl->segments[(size_t)pl->chunks[(size_t)done_ci].segment], sg)) return rc;
-            MDF_HIP(hipEventRecord(e->ev_join[1], sg));
-            MDF_HIP(hipStreamWaitEvent(sx, e->ev_join[1], 0));
-        }
-    }
-    e->last_rows = pl->chunks[(size_t)nC - 1].rows;
-    e->last_set = (nC - 1) & 1;
-    if (int rc = run_heads(e, pl, scores, logits, sg)) return rc;
-    // join: the caller's stream continues behind both (scores from sg, validation flags from sx)
-    if (int rc = sx_into_sg()) return rc;
-    MDF_HIP(hipEventRecord(e->ev_join[1], sg));
-    MDF_HIP(hipStreamWaitEvent(st, e->ev_join[1], 0));
-    return MDF_OK;
-}
-
 static int forward_alignments_eager(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b_in, float *const *scores, float *const *logits,
                                     hipStream_t st, bool capturing = false)
 {
     mdf_batch_dev view;   // the batch in the plan's order (the caller's own descriptor when the plan keeps the input order)
     if (int rc = batch_in_plan_order(e->perm, &e->generation, pl, b_in, st, &view)) return rc;
     const mdf_batch_dev *b = &view;
-    if (e->split_cus && !capturing && e->lms.empty()) return forward_alignments_split(e, pl, b, scores, logits, st);
     if (!e->pipeline_contact) {
         BuildCsr build = [&](int ci, const PlanChunk &ch, const uint8_t *seq_ptr, bool *have_lsum, bool *bits, const AggOverride **) -> int {
             // contact stage: coordinates read once; the CSR fill also writes the layer-1 letter sums of the chunk
@@ -1268,16 +1132,8 @@ extern "C" int64_t mdf_engine_last_chunk_nnz(mdf_engine *e, void *stream)
 }
 
 // ---- dense-map path ------------------------------------------------------------------------------------------------
-// host threads that stage dense maps into pinned memory (MDFRI_HOST_COPY_THREADS, default: up to 8)
-static int host_copy_threads()
-{
-    static const int v = [] {
-        const char *e = getenv("MDFRI_HOST_COPY_THREADS");
-        const int n = e ? atoi(e) : (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
-        return std::min(std::max(n, 1), 64);
-    }();
-    return v;
-}
+// host threads that stage dense maps into pinned memory: up to 8
+static int host_copy_threads() { return (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u); }
 
 extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const mdf_batch_dev *b, const void *const *cmaps_host, int cmap_dtype,
                                         float *const *scores, float *const *logits, void *stream)
@@ -1384,7 +1240,7 @@ extern "C" int mdf_engine_forward_dense(mdf_engine *e, const mdf_plan *pl, const
         if (nnz_needed > e->nnz_cap) {   // a denser chunk than the CSR arrays hold: grow them (hipFree waits for the device)
             MDF_REQUIRE(nnz_needed < 0x7fffffffLL, "engine_forward_dense: a chunk needs %lld CSR entries; lower max_rows", (long long)nnz_needed);
             // EVERY live contact set grows with the shared capacity: a later pipelined forward_alignments hands e->nnz_cap to both
-            for (int k = 0; k < (e->pipeline_contact || e->split_cus ? 2 : 1); ++k) {
+            for (int k = 0; k < (e->pipeline_contact ? 2 : 1); ++k) {
                 if (int rc = e->cs[k].colidx.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
                 if (int rc = e->cs[k].val.grow((size_t)nnz_needed * 4, &e->generation)) return rc;
             }

@@ -544,9 +544,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_f32(const float *__res
 // the size of the rounding of ONE fp32 multiplication or below, against hundreds of accumulation roundings per dot product -- so the result
 // carries the accumulation rounding of an fp32 GEMM and nothing else: measured against float64 on 65 536 x 512 x 512 the error is
 // rms 2.49e-7 / max 2.4e-6, the same to four digits as with all nine products, and below the fp32 pipe's own 2.95e-7 / 3.4e-6
-// (profiles/r04_gemm_bf16x6_probe.txt).  Vector and matrix instructions of a SIMD do not overlap on this part, and at full bf16 rate
-// the chip throttles to ~1.5 GHz: the in-register split (9 VALU instructions per operand pair) and the six products together land at
-// the same 160 us per 65 536 x 512 x 512 as a version fed pre-split operands with the matrix pipe saturated -- the power floor.
+// (profiles/r04_gemm_bf16x6_probe.txt).  What bounds it (round 5, measured: profiles/r05_gemm_overlap_probe.txt): a wave hides ~5 plain
+// vector instructions behind a matrix instruction, the in-register split needs 5.5 per matrix instruction (1.5 of them conversions at two
+// issue slots) -- the loop is issue-bound exactly at the matrix rate, so the schedule matters --, and once the schedule is good the BOARD's
+// power limit takes over: four bit-identical forms of the loop all land on 146-150 us in-kernel per 65 536 x 512 x 512 at 1 330-1 361 W
+// while the clock falls 1.87 -> 1.75 GHz; ~1.40 PFLOP/s of executed bf16 work is what 1 400 W buy on real operands.
 struct SplitPlanes {
     u32x4 h, m, l;   // 8 bf16 each
 };
@@ -636,9 +638,9 @@ __device__ __forceinline__ void split_stage(SplitQuad &q, const SplitRaw &r, Spl
 // and the 8 consecutive k of its half, (l >> 5): two ds_read_b128, then the split.  A step = one A tile against both B tiles (12 matrix
 // instructions = 12 slots) with the next step's fragment reads and splits, and in the first half the next position's DMA, riding behind
 // them: ONE split stage (4-6 vector instructions, split_stage) per slot; the three steps that also split B fragments carry two stages in
-// some slots.  SCHED 0 is the round-4 schedule (matrix instructions in pairs, one 11-deep chain with a packed subtraction behind each
-// pair), kept for the A/B knob MDFRI_X6_SCHED=0; both are bit-identical.
-template <int EPI, int SCHED = 1>
+// some slots.  (The round-4 schedule -- matrix instructions in pairs, one 11-deep chain with a packed subtraction behind each pair, 4.4 % slower,
+// bit-identical -- left the library in round 6: experiments/r06_pruned_variants.patch.)
+template <int EPI>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
                                                                  int N, int K, float *__restrict__ C, int ldc, const float *__restrict__ bias,
                                                                  float *__restrict__ pool_partial, int ldp, int total_tiles, GemmAux aux)
@@ -738,7 +740,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
         MDF_MF(tm_, h, l, 0) X4 MDF_SB MDF_MF(tm_, h, l, 1) X5 MDF_SB MDF_MF(tm_, m, h, 0) X6 MDF_SB MDF_MF(tm_, m, h, 1) X7 MDF_SB \
         MDF_MF(tm_, h, m, 0) X8 MDF_SB MDF_MF(tm_, h, m, 1) X9 MDF_SB MDF_MF(tm_, h, h, 0) X10 MDF_SB MDF_MF(tm_, h, h, 1) X11 MDF_SB \
     }
-#define MDF_PS(raw_, i_, P_) split_pair(raw_, i_, P_);
 #define MDF_Q(j_, raw_, P_) split_stage<j_>(qs, raw_, P_);
     SplitQuad qs;
     int cur = 0;
@@ -748,22 +749,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
         const float *An = smem + (cur ^ 1) * ((BM + BN) * BK) + fbaseA;
         const float *Bn = smem + (cur ^ 1) * ((BM + BN) * BK) + BM * BK + fbaseB;
         const unsigned ldsA = lds_base + (cur ^ 1) * ((BM + BN) * BK * 4), ldsB = ldsA + BM * BK * 4;
-        if constexpr (SCHED == 0) {
-            // half 0: the whole DMA of the next position; the B fragments of half 1
-            MDF_STEP(0, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 1, 0), MDF_DMA_A(0), MDF_DMA_B(0), MDF_DMA_A(1), MDF_DMA_B(1), MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
-            MDF_STEP(1, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 2, 0), MDF_DMA_A(2), MDF_DMA_B(2), MDF_DMA_A(3), MDF_DMA_B(3), MDF_PS(ra, 0, PA[0]), , MDF_PS(ra, 1, PA[0]), , MDF_PS(ra, 2, PA[0]), , MDF_PS(ra, 3, PA[0]), )
-            MDF_STEP(2, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 3, 0) MDF_RD(rb, Bb, 0, 1), , , , , MDF_PS(ra, 0, PA[1]), MDF_PS(rb, 0, PB[1][0]), MDF_PS(ra, 1, PA[1]), MDF_PS(rb, 1, PB[1][0]), MDF_PS(ra, 2, PA[1]), MDF_PS(rb, 2, PB[1][0]), MDF_PS(ra, 3, PA[1]), MDF_PS(rb, 3, PB[1][0]))
-            MDF_STEP(3, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 0, 1) MDF_RD(rb, Bb, 1, 1), , , , , MDF_PS(ra, 0, PA[0]), MDF_PS(rb, 0, PB[1][1]), MDF_PS(ra, 1, PA[0]), MDF_PS(rb, 1, PB[1][1]), MDF_PS(ra, 2, PA[0]), MDF_PS(rb, 2, PB[1][1]), MDF_PS(ra, 3, PA[0]), MDF_PS(rb, 3, PB[1][1]))
-            // half 1: the source addresses of the position after next, then the barrier and the next position's first fragments
-            MDF_STEP(0, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 1, 1), , , , , MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
-            cursor_advance<PLAIN>(pc, nk, NT, M, total_tiles, stride);
-            MDF_DMA_SETUP(pc)
-            MDF_STEP(1, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 2, 1), , , , , MDF_PS(ra, 0, PA[0]), , MDF_PS(ra, 1, PA[0]), , MDF_PS(ra, 2, PA[0]), , MDF_PS(ra, 3, PA[0]), )
-            MDF_STEP(2, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 3, 1), , , , , MDF_PS(ra, 0, PA[1]), , MDF_PS(ra, 1, PA[1]), , MDF_PS(ra, 2, PA[1]), , MDF_PS(ra, 3, PA[1]), )
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next position has landed ...
-            __syncthreads();                                     // ... and everybody's; nobody reads this position's buffer any more
-            MDF_STEP(3, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, An, 0, 0) MDF_RD(rb, Bn, 0, 0) MDF_RD(rc, Bn, 1, 0), , , MDF_PS(ra, 0, PA[0]), MDF_PS(rb, 0, PB[0][0]), MDF_PS(rc, 0, PB[0][1]) MDF_PS(ra, 1, PA[0]), MDF_PS(rb, 1, PB[0][0]), MDF_PS(rc, 1, PB[0][1]) MDF_PS(ra, 2, PA[0]), MDF_PS(rb, 2, PB[0][0]), MDF_PS(rc, 2, PB[0][1]) MDF_PS(ra, 3, PA[0]), MDF_PS(rb, 3, PB[0][0]), MDF_PS(rc, 3, PB[0][1]), )
-        } else {
+        {
             // half 0: the whole DMA of the next position; the B fragments of half 1
             MDF_STEP(0, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 1, 0), MDF_DMA_A(0), MDF_DMA_B(0), MDF_DMA_A(1), MDF_DMA_B(1), MDF_Q(0, ra, PA[1]), MDF_Q(1, ra, PA[1]), MDF_Q(2, ra, PA[1]), MDF_Q(3, ra, PA[1]), MDF_Q(4, ra, PA[1]), MDF_Q(5, ra, PA[1]), MDF_Q(6, ra, PA[1]), MDF_Q(7, ra, PA[1]))
             MDF_STEP(1, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 2, 0), MDF_DMA_A(2), MDF_DMA_B(2), MDF_DMA_A(3), MDF_DMA_B(3), MDF_Q(0, ra, PA[0]), MDF_Q(1, ra, PA[0]), MDF_Q(2, ra, PA[0]), MDF_Q(3, ra, PA[0]), MDF_Q(4, ra, PA[0]), MDF_Q(5, ra, PA[0]), MDF_Q(6, ra, PA[0]), MDF_Q(7, ra, PA[0]))
@@ -794,7 +780,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
         cur ^= 1;
     }
 #undef MDF_STEP
-#undef MDF_PS
 #undef MDF_Q
 #undef MDF_MF
 #undef MDF_BF
@@ -1910,18 +1895,27 @@ static int set_gemm_attr_once()
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_LSTM_TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_LSTM_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_ELU_POOL_STORE, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
-    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_ELU_POOL, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return MDF_OK;
 }
 
-// whether layer 1 is made inside the layer-2 aggregation kernel where that kernel is the matrix-pipe one (see k_aggregate_mfma<.., true>); read once
+// MDFRI_AX_MFMA=0 (read once per process): every protein through the CSR gather instead of the per-protein choice with the matrix-pipe
+// aggregation -- the A/B switch between the two aggregation kernels (mdfri.h "Environment switches")
+static bool ax_mfma_on()
+{
+    static const bool on = []() {
+        const char *a = getenv("MDFRI_AX_MFMA");
+        return !(a && atoi(a) == 0);
+    }();
+    return on;
+}
+// whether layer 1 is made inside the layer-2 aggregation kernel where that kernel is the matrix-pipe one (see k_aggregate_mfma<.., true>);
+// MDFRI_L1_FUSE=0 (read once per process): k_layer1 for every row, bit-identical
 static bool layer1_fused()
 {
     static const bool on = []() {
-        const char *f = getenv("MDFRI_L1_FUSE"), *a = getenv("MDFRI_AX_MFMA");
-        return !(f && atoi(f) == 0) && !(a && atoi(a) == 0);
+        const char *f = getenv("MDFRI_L1_FUSE");
+        return !(f && atoi(f) == 0) && ax_mfma_on();
     }();
     return on;
 }
@@ -1936,14 +1930,9 @@ static bool hw_pipe_bf16x6()
     return on;
 }
 
-// A caller that has given the launch stream only part of the chip (the engine's split form: H.W on some CUs, the aggregation on the
-// others) says how many workgroups are resident there; 0 = the whole device.  Set around the launches of one stage, on the issuing thread.
-static thread_local int tl_gemm_blocks = 0;
-
 // persistent grid: one 512-thread workgroup per CU (LDS: 128 KiB), a multiple of 8 so that block b stays on XCD b%8
 static int gemm_resident_blocks()
 {
-    if (tl_gemm_blocks > 0) return tl_gemm_blocks;
     static std::atomic<int> per_dev[MDF_MAX_DEVICES];   // zero-initialised; keyed by device ordinal (CU counts may differ)
     const int dev = current_device();
     int n = per_dev[dev].load(std::memory_order_relaxed);
@@ -1951,7 +1940,6 @@ static int gemm_resident_blocks()
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         n = std::max(8, cus / 8 * 8);
-        if (const char *e = getenv("MDFRI_GEMM_BLOCKS")) n = std::max(8, atoi(e) / 8 * 8);  // developer override
         per_dev[dev].store(n, std::memory_order_relaxed);
     }
     return n;
@@ -1969,7 +1957,7 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     if (int rc = set_gemm_attr_once()) return rc;
     if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_SOFTMAX2) {
         // a handful of pooled vectors through the GO head: one lane per output column, bit-identical FMA chain (k_gemv_f32)
-        static const int gemv_max = getenv("MDFRI_GEMV_MAX_M") ? atoi(getenv("MDFRI_GEMV_MAX_M")) : 8;   // developer knob: 0 = never
+        constexpr int gemv_max = 8;
         if (M <= gemv_max) {
             hipLaunchKernelGGL(k_gemv_f32<EPI>, dim3(N / 64, M), dim3(64), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias, logits, n_real);
             MDF_HIP(hipGetLastError());
@@ -1985,8 +1973,7 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
         if (hw_pipe_bf16x6()) {
             bool small = false;
             if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_EMBED) {
-                static const int small_env = getenv("MDFRI_GEMM_SMALL") ? atoi(getenv("MDFRI_GEMM_SMALL")) : -1;
-                small = small_env >= 0 ? small_env != 0 : MT * NT * 8 < 3 * gemm_resident_blocks();
+                small = MT * NT * 8 < 3 * gemm_resident_blocks();
                 if (small) {
                     const int tiles = ((M + 31) / 32) * (N / 32);
                     hipLaunchKernelGGL(k_gemm_bf16x6_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, pool_partial, ldp, aux);
@@ -1994,17 +1981,8 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
             }
             if (!small) {
                 const int total = plain ? MT * NT : 8 * NT * ((MT + 7) / 8);
-                bool old_sched = false;
-                if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL) {   // developer A/B knob (read once): the round-4 issue schedule, bit-identical
-                    static const bool sched0 = getenv("MDFRI_X6_SCHED") && atoi(getenv("MDFRI_X6_SCHED")) == 0;
-                    old_sched = sched0;
-                    if (sched0)
-                        hipLaunchKernelGGL((k_gemm_bf16x6<EPI, 0>), dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda,
-                                           Bt, ldb, M, N, K, C, ldc, bias, pool_partial, ldp, total, aux);
-                }
-                if (!old_sched)
-                    hipLaunchKernelGGL((k_gemm_bf16x6<EPI, 1>), dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt,
-                                       ldb, M, N, K, C, ldc, bias, pool_partial, ldp, total, aux);
+                hipLaunchKernelGGL((k_gemm_bf16x6<EPI>), dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt,
+                                   ldb, M, N, K, C, ldc, bias, pool_partial, ldp, total, aux);
             }
             MDF_HIP(hipGetLastError());
             return MDF_OK;
@@ -2014,8 +1992,7 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
         // small problems (fewer 256 x 256 tiles than 3/8 of the CUs -- measured crossover with the four-block prefetch ring: 8 192
         // rows x 512 columns = 64 tiles 0.91 vs 1.17 ms per 3-head forward, 16 384 rows = 128 tiles 1.49 vs 1.28 ms): one wave per 32 x 32
         // tile, bit-identical results
-        static const int small_env = getenv("MDFRI_GEMM_SMALL") ? atoi(getenv("MDFRI_GEMM_SMALL")) : -1;   // developer knob: 0 never, 1 always
-        const bool small = small_env >= 0 ? small_env != 0 : MT * NT * 8 < 3 * gemm_resident_blocks();
+        const bool small = MT * NT * 8 < 3 * gemm_resident_blocks();
         if (small) {
             const int tiles = ((M + 31) / 32) * (N / 32);
             hipLaunchKernelGGL(k_gemm_f32_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias, pool_partial, ldp,
@@ -2065,13 +2042,11 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
                             int Ri, hipStream_t st, TimedKernel tk = TK_AX, const mdf_agg_desc *agg = nullptr, const AggLayer1 *l1 = nullptr)
 {
     ScopedTiming tm(tk, st);
-    static const int mfma_env = getenv("MDFRI_AX_MFMA") ? atoi(getenv("MDFRI_AX_MFMA")) : 1;   // developer knob: 0 = the CSR gather for every row
-    if (agg && !mfma_env) agg = nullptr;
-    // developer knobs; defaults: 512-row super-blocks per XCD, and non-temporal output stores once input + output
-    // slabs no longer fit the 256 MiB Infinity Cache together (measured: +12 % at 65536 rows, -2 % at 32768)
-    static const int sb_log = getenv("MDFRI_AX_SB_LOG") ? atoi(getenv("MDFRI_AX_SB_LOG")) : 9;
-    static const int nt_env = getenv("MDFRI_AX_NT") ? atoi(getenv("MDFRI_AX_NT")) : -1;
-    const int nt_store = nt_env >= 0 ? nt_env : ((size_t)Ri * Cin * 8 > (size_t)200 << 20);
+    if (agg && !ax_mfma_on()) agg = nullptr;
+    // the gather: 512-row super-blocks per XCD, and non-temporal output stores once input + output slabs no longer fit the 256 MiB
+    // Infinity Cache together (measured: +12 % at 65536 rows, -2 % at 32768; profiles/r04_cache_policy_probes.txt)
+    constexpr int sb_log = 9;
+    const int nt_store = (size_t)Ri * Cin * 8 > (size_t)200 << 20;
     auto gather = [&](int row0, int row_end, const int32_t *skip_if, const uint32_t *skip_groups = nullptr) {   // the CSR gather over rows [row0, row_end)
         const int n_sb = (row_end - row0 + (1 << sb_log) - 1) >> sb_log;
         const int blocks = 8 * (1 << (sb_log - 2)) * ((n_sb + 7) / 8);
@@ -2095,12 +2070,12 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
                          agg->tail_p, (int)agg->tail_row0, Ri
         // Chunks beyond ~100 000 rows: a 512-channel slab no longer fits the 256 MiB Infinity Cache, and a kernel that reads its operand in
         // the order the previous kernel wrote it finds nothing of it there.  The aggregation walks its proteins from the END of the list
-        // (MDFRI_AX_REVERSE=0: from the start): the rows the H.W product wrote last are read first, and the rows it writes last -- the
+        // (A/B'd in round 5, experiments/r05_ax_reverse_ab.sh): the rows the H.W product wrote last are read first, and the rows it writes last -- the
         // chunk's first -- are the ones the next product starts with.  Same workgroups, same arithmetic: bit-identical.
-        static const int reverse = getenv("MDFRI_AX_REVERSE") ? atoi(getenv("MDFRI_AX_REVERSE")) : 1;
+        constexpr int reverse = 1;
         AggLayer1 l1v = l1 ? *l1 : AggLayer1(), plainv;
         l1v.reverse = plainv.reverse = reverse;
-        // (layer 1 is made inside the launch for proteins of at most 512 residues only -- mdf_agg_l1_fused; gcn_stage does not fuse a
+        // (layer 1 is made inside the launch for proteins of at most 512 residues only -- mdf_agg_l1_fused; gcn_stack does not fuse a
         // descriptor that lists longer ones -- so the form with four row blocks per wave exists without it only)
         MDF_REQUIRE(agg->tiles && agg->tile_row_bytes >= 32, "launch_aggregate: the descriptor carries no contact-byte tiles (mdf_agg_prepare_dev)");
         MDF_REQUIRE(!(l1 && agg->n_mf[2] > 0), "launch_aggregate: layer 1 inside the aggregation launch for a protein of more than 512 residues");
@@ -2136,9 +2111,8 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
 }
 
 // GraphConv layers 2..n_gc on top of H1: H_k = elu((Ahat . H_{k-1}) . W_k), pooled partial sums at `partial + off`.  Layer k (1-based
-// among the upper layers) reads H_{k-1} from Ha (k odd) or Hb (k even) and leaves its output in the other; one call does the aggregation,
-// the H.W product, or both of ONE layer -- the engine's split form issues the two halves on different streams (gcn_stage below).
-static int gcn_upper_layer(mdf_model *m, int k, bool do_agg, bool do_gemm, float *Ha, float *Hb, float *AH, const int32_t *rowptr, const int32_t *colidx,
+// among the upper layers) reads H_{k-1} from Ha (k odd) or Hb (k even) and leaves its output in the other.
+static int gcn_upper_layer(mdf_model *m, int k, float *Ha, float *Hb, float *AH, const int32_t *rowptr, const int32_t *colidx,
                            const float *val, int Ri, float *partial, hipStream_t st, const mdf_agg_desc *agg = nullptr, const AggLayer1 *l1 = nullptr)
 {
     const int feat = m->feat;
@@ -2150,9 +2124,8 @@ static int gcn_upper_layer(mdf_model *m, int k, bool do_agg, bool do_gemm, float
     // touched) instead of the AH slab: measured -2 % on both A.X launches of a head (profiles/r04_cache_policy_probes.txt, "mid_dead")
     // (only for a launch whose GEMM stores nothing -- the last layer --, or the GEMM would write the slab it reads)
     if (k >= 2 && k == m->n_gc - 1) AH = Hout;
-    if (do_agg)
-        if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st, k >= 2 ? TK_AX3 : TK_AX, agg, k == 1 ? l1 : nullptr)) return rc;
-    if (do_gemm) {
+    if (int rc = launch_aggregate(Hin, Cin, rowptr, colidx, val, AH, Ri, st, k >= 2 ? TK_AX3 : TK_AX, agg, k == 1 ? l1 : nullptr)) return rc;
+    {
         ScopedTiming tm(k >= 2 ? TK_GEMM3 : TK_GEMM, st);
         const bool last = k == m->n_gc - 1;
         int rc;
@@ -2169,7 +2142,7 @@ static int gcn_upper_layers(mdf_model *m, float *Ha, float *Hb, float *AH, const
                             const AggLayer1 *l1 = nullptr)
 {
     for (int k = 1; k < m->n_gc; ++k)
-        if (int rc = gcn_upper_layer(m, k, true, true, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg, l1)) return rc;
+        if (int rc = gcn_upper_layer(m, k, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg, l1)) return rc;
     return MDF_OK;
 }
 
@@ -2731,8 +2704,7 @@ int mdf_agg_class(int32_t L, int resident)
 {
     (void)resident;   // (round 5: the same lengths in front of layer 2 and of layer 3 -- profiles/r05_ax_by_length.txt)
     if (L < MDF_AGG_MIN_LEN || L > MDF_AGG_MAX_LEN) return -1;
-    static const int l3_max = getenv("MDFRI_AX_L3_MAX") ? atoi(getenv("MDFRI_AX_L3_MAX")) : MDF_AGG_MAX_LEN;   // developer knob (length sweeps)
-    return L <= 256 ? 0 : (L >= 288 && L <= 512) ? 1 : (L >= 544 && L <= l3_max) ? 2 : -1;
+    return L <= 256 ? 0 : (L >= 288 && L <= 512) ? 1 : (L >= 544 && L <= MDF_AGG_MAX_LEN) ? 2 : -1;
 }
 
 // Lengths whose layer-1 rows are made INSIDE the layer-2 aggregation launch on the fused engine path (k_aggregate_mfma<.., true>): where that
@@ -2755,17 +2727,16 @@ int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts,
     return MDF_OK;
 }
 
-// One STAGE of the stack of a model without a language model: stage 0 = layer 1 (k_layer1 for the rows that need H1 in memory) and the
-// aggregation of layer 2; stage 2 j - 1 = the H.W product of upper layer j; stage 2 j = the aggregation of upper layer j + 1.  Even stages
-// are bound by HBM, odd ones by the matrix pipe.  stage < 0: all of them, in order (what mdf_gcn_embed_agg_dev does on one stream).
-static int gcn_stage(mdf_model *m, int stage, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
+// The GraphConv stack of a model without a language model on one stream: layer 1 (k_layer1 for the rows that need H1 in memory), then per
+// upper layer the aggregation and the H.W product.  (Round 5's stage-by-stage entry, mdf_gcn_stage_dev, served the engine's split form on
+// CU-masked streams -- measured slower, DESIGN.md section 5 -- and left the library with it: experiments/r06_pruned_variants.patch.)
+static int gcn_stack(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
                      const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, hipStream_t st)
 {
     MDF_REQUIRE(m && letter_sums && rowptr && colidx && val && partial && workspace, "gcn_embed_dev: NULL argument");
     MDF_REQUIRE(R > 0 && R % 128 == 0 && R < 0x7fffffff, "gcn_embed_dev: bad row count %lld", (long long)R);
     if (workspace_bytes < gcn_ws_bytes(m, R))
         return fail(MDF_ECAPACITY, "gcn_embed_dev: workspace of %zu bytes is smaller than %zu", workspace_bytes, gcn_ws_bytes(m, R));
-    MDF_REQUIRE(stage < mdf_gcn_num_stages(m), "gcn_stage: stage %d of %d", stage, mdf_gcn_num_stages(m));
     Carver cv(workspace, workspace_bytes);
     int cmax = 0;
     for (int k = 0; k < m->n_gc; ++k) cmax = std::max(cmax, m->gc[k]);
@@ -2786,16 +2757,15 @@ static int gcn_stage(mdf_model *m, int stage, const float *letter_sums, const in
     const uint32_t *l1_skip = split_lists ? agg->l1_skip : agg ? agg->skip_groups : nullptr;
     AggLayer1 l1;
     l1.S = letter_sums, l1.T1 = m->T1, l1.pool_partial = partial, l1.ldp = feat;
-    if (stage <= 0) {
+    {
         ScopedTiming tm(TK_GEMM1, st);
         const int C0 = m->gc[0];
         // groups per wave: the wave's slice of T1 (26 KiB per 256-column slab) is fetched once per wave -- with one group per wave a launch
         // reads more table bytes from L2 than it writes output rows
-        static const int gpw_env = getenv("MDFRI_L1_GPW") ? atoi(getenv("MDFRI_L1_GPW")) : 0;   // developer knob
         const int slabs = C0 / 256, sets = 4 / slabs;
         auto layer1 = [&](int row0, int row_end, const uint32_t *skip) {      // rows [row0, row_end), both multiples of GROUP_ROWS
             const int n_groups = (row_end - row0) / GROUP_ROWS;
-            const int gpw = std::min(8, gpw_env > 0 ? gpw_env : (n_groups >= 2048 ? 2 : 1));
+            const int gpw = n_groups >= 2048 ? 2 : 1;
             const int blocks = (n_groups + sets * gpw - 1) / (sets * gpw);
             const size_t lds = (size_t)sets * gpw * GROUP_ROWS * 32 * 4;
             if (m->n_gc == 1)
@@ -2816,35 +2786,15 @@ static int gcn_stage(mdf_model *m, int stage, const float *letter_sums, const in
         MDF_HIP(hipGetLastError());
     }
     const AggLayer1 *l1p = fuse ? &l1 : nullptr;
-    if (stage < 0) {
-        if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg, l1p)) return rc;
-    } else if (m->n_gc >= 2) {
-        const bool gemm = stage & 1;
-        const int k = gemm ? (stage + 1) / 2 : stage / 2 + 1;
-        if (int rc = gcn_upper_layer(m, k, !gemm, gemm, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg, l1p)) return rc;
-    }
+    if (int rc = gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg, l1p)) return rc;
     MDF_HIP(hipGetLastError());
     return MDF_OK;
-}
-
-int mdf_gcn_num_stages(const mdf_model *m) { return !m ? 0 : m->n_gc >= 2 ? 2 * (m->n_gc - 1) : 1; }
-
-int mdf_gcn_stage_dev(mdf_model *m, int stage, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val, int64_t R,
-                      const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, int gemm_blocks, void *stream)
-{
-    MDF_REQUIRE(stage >= 0, "gcn_stage_dev: stage %d", stage);
-    struct Blocks {   // the launches of this stage see a chip of `gemm_blocks` CUs (0: all of them)
-        int keep;
-        explicit Blocks(int n) : keep(tl_gemm_blocks) { tl_gemm_blocks = n > 0 ? std::max(8, n / 8 * 8) : 0; }
-        ~Blocks() { tl_gemm_blocks = keep; }
-    } scope(gemm_blocks);
-    return gcn_stage(m, stage, letter_sums, rowptr, colidx, val, R, agg, partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int mdf_gcn_embed_agg_dev(mdf_model *m, const float *letter_sums, const int32_t *rowptr, const int32_t *colidx, const float *val,
                           int64_t R, const mdf_agg_desc *agg, float *partial, void *workspace, size_t workspace_bytes, void *stream)
 {
-    return gcn_stage(m, -1, letter_sums, rowptr, colidx, val, R, agg, partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return gcn_stack(m, letter_sums, rowptr, colidx, val, R, agg, partial, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int mdf_gcn_pool_dev(mdf_model *m, const float *partial, const int32_t *grp_off, int32_t B, float *pooled, void *stream)

@@ -723,14 +723,12 @@ static int32_t count_long(const int32_t *seq_len, const int32_t *pair_q, const i
 
 int32_t mdf_nw_count_long(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P)
 {
-    static const int64_t min_cells = getenv("MDFRI_NW_COOP_MIN_CELLS") ? atoll(getenv("MDFRI_NW_COOP_MIN_CELLS")) : NW_COOP_MIN_CELLS;   // developer knob
-    return count_long(seq_len, pair_q, pair_t, P, min_cells);
+    return count_long(seq_len, pair_q, pair_t, P, NW_COOP_MIN_CELLS);
 }
 
 int32_t mdf_nw_count_long_align(const int32_t *seq_len, const int32_t *pair_q, const int32_t *pair_t, int32_t P)
 {
-    static const int64_t min_cells = getenv("MDFRI_NW_COOP_MIN_CELLS_ALIGN") ? atoll(getenv("MDFRI_NW_COOP_MIN_CELLS_ALIGN")) : NW_COOP_MIN_CELLS_ALIGN;
-    return count_long(seq_len, pair_q, pair_t, P, min_cells);
+    return count_long(seq_len, pair_q, pair_t, P, NW_COOP_MIN_CELLS_ALIGN);
 }
 
 // Score mode only needs the corner of the matrix, and NW(q, t; S) = NW(t, q; S^T): for a symmetric substitution matrix a pair may be swept
@@ -740,8 +738,6 @@ int32_t mdf_nw_count_long_align(const int32_t *seq_len, const int32_t *pair_q, c
 int32_t mdf_nw_orient_pairs(const int32_t *seq_len, int32_t *pair_q, int32_t *pair_t, int32_t P, const int32_t *matrix, int32_t A, int gap_open, int gap_extend)
 {
     if (!seq_len || !pair_q || !pair_t || !matrix || P < 0 || A <= 0) return fail(MDF_EINVAL, "nw_orient_pairs: bad arguments");
-    static const bool off = getenv("MDFRI_NW_ORIENT") && atoi(getenv("MDFRI_NW_ORIENT")) == 0;   // developer knob
-    if (off) return 0;
     int smin = INT32_MAX, smax = INT32_MIN;
     for (int32_t r = 0; r < A; ++r)
         for (int32_t c = 0; c < A; ++c) {
@@ -798,8 +794,7 @@ int mdf_nw_score_dev(const uint8_t *codes, const int64_t *seq_off, const int32_t
     // score mode is throughput-bound: four-wave workgroups (a long pair's strips run four deep), every pair to the kernel whose
     // arithmetic width it qualifies for (decided per pair on the device, nw16_eligible)
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const int waves_env = getenv("MDFRI_NW_SCORE_WAVES") ? atoi(getenv("MDFRI_NW_SCORE_WAVES")) : 4;   // developer knob
-    const int waves = std::min(std::max(waves_env, 1), NW_WG_WAVES), a16 = nw_allow16();
+    const int waves = std::min(4, NW_WG_WAVES), a16 = nw_allow16();   // (four waves per score workgroup: tools/nw_sweep.sh, round 3)
     const dim3 grid((unsigned)(n_long + (P - n_long + waves - 1) / waves));
     const int lds_ints = n_long ? NW_LDS_INTS_SCORE : 0;
     const size_t lds = (size_t)lds_ints * sizeof(int);
@@ -996,8 +991,7 @@ int nw_workspace_new(int device, hipStream_t stream, mdf_nw_workspace **out)
     } else {
         int lo = 0, hi = 0;
         e = hipDeviceGetStreamPriorityRange(&lo, &hi);
-        static const char *pr = getenv("MDFRI_NW_STREAM_PRIORITY");   // developer knob: "low" / "normal" (default: highest)
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&w->st, hipStreamNonBlocking, pr && pr[0] == 'l' ? lo : pr && pr[0] == 'n' ? (lo + hi) / 2 : hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&w->st, hipStreamNonBlocking, hi);
         w->own_stream = e == hipSuccess;
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev1, hipEventDisableTiming);
@@ -1040,19 +1034,6 @@ void order_by_cells(const int32_t *seq_len, const int32_t *pq, const int32_t *pt
     if (i0 != order.data()) std::copy(i0, i0 + P, order.data());   // three passes: the result sits in the second buffer
 }
 
-struct StageTimer {   // MDFRI_NW_TIMING=1: host milliseconds per step of the batched entry, on stderr (developer knob)
-    bool on;
-    double last;
-    static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-    StageTimer() : on(getenv("MDFRI_NW_TIMING") != nullptr), last(now()) {}
-    void operator()(const char *what)
-    {
-        if (!on) return;
-        const double t = now();
-        fprintf(stderr, "[nw_best_hits] %-28s %.2f ms\n", what, t - last);
-        last = t;
-    }
-};
 
 // the workspace of a thread that did not bring one: created on first use, per device, kept for the life of the process
 int nw_thread_workspace(mdf_nw_workspace **out)
@@ -1149,7 +1130,6 @@ static int nw_best_hits_begin_steps(mdf_nw_workspace *w, const uint8_t *text, co
     if (int rc = require_device()) return rc;
     DeviceGuard guard(w->device);
     MDF_HIP(guard.err);
-    StageTimer tm;
     w->n_seq = n_seq, w->nq = nq, w->P = P, w->A = A, w->go = gap_open, w->ge = gap_extend, w->tie_rule = tie_rule, w->max_trace = max_trace_bytes;
     w->total = total, w->lut = lut != nullptr, w->want_cs = want_cand_scores != 0;
     w->seq_len.assign(seq_len, seq_len + n_seq);
@@ -1161,7 +1141,6 @@ static int nw_best_hits_begin_steps(mdf_nw_workspace *w, const uint8_t *text, co
     for (int32_t q = 0; q < nq; ++q)
         for (int64_t p = first[q]; p < first[q + 1]; ++p) pq[(size_t)p] = q;
     order_by_cells(seq_len, pq.data(), cand, P, order);
-    tm("order pairs");
     size_t ho = 0;
     auto htake = [&](size_t bytes) { size_t r = ho; ho = align_up(ho + bytes, 256); return r; };
     w->h_text = htake((size_t)total + 16), w->h_soff = htake((size_t)n_seq * 8), w->h_slen = htake((size_t)n_seq * 4), w->h_pq = htake((size_t)P * 4);
@@ -1211,7 +1190,6 @@ static int nw_best_hits_begin_steps(mdf_nw_workspace *w, const uint8_t *text, co
     if (int rc = w->s1.reserve(o)) return rc;
     char *b1 = static_cast<char *>(w->s1.ptr);
     hipStream_t st = w->st;
-    tm("stage phase 1");
     *enqueued = true;
     MDF_HIP(hipMemcpyAsync(b1 + w->d_in, h, w->h_up, hipMemcpyHostToDevice, st));
     auto I = [&](size_t off) { return b1 + w->d_in + off; };
@@ -1230,7 +1208,6 @@ static int nw_best_hits_begin_steps(mdf_nw_workspace *w, const uint8_t *text, co
     if (w->want_cs) MDF_HIP(hipMemcpyAsync(h + w->h_csc, b1 + d_csc, (size_t)P * 4, hipMemcpyDeviceToHost, st));
     MDF_HIP(hipEventRecord(w->ev1, st));
     w->stage = 1;
-    tm("enqueue phase 1");
     return MDF_OK;
 }
 
@@ -1251,10 +1228,8 @@ int mdf_nw_best_hits_align(mdf_nw_workspace *w, int64_t *info)
 
 static int nw_best_hits_align_steps(mdf_nw_workspace *w, int64_t *info)
 {
-    StageTimer tm;
     w->stage = 0;   // any failure below abandons the call
     MDF_HIP(hipEventSynchronize(w->ev1));
-    tm("wait for scores");
     char *h = w->hs.ptr;
     const int32_t nq = w->nq, n_seq = w->n_seq;
     const int32_t *seq_len = w->seq_len.data();
@@ -1325,7 +1300,6 @@ static int nw_best_hits_align_steps(mdf_nw_workspace *w, int64_t *info)
     if (int rc = w->s2.reserve(o2)) return rc;
     char *b1 = static_cast<char *>(w->s1.ptr), *b2 = static_cast<char *>(w->s2.ptr);
     hipStream_t st = w->st;
-    tm("plan winners");
     MDF_HIP(hipMemcpyAsync(b2 + e_in, g, w->g_up, hipMemcpyHostToDevice, st));
     auto I = [&](size_t off) { return b1 + w->d_in + off; };
     auto J = [&](size_t off) { return b2 + e_in + off; };
@@ -1354,7 +1328,6 @@ static int nw_best_hits_align_steps(mdf_nw_workspace *w, int64_t *info)
     }
     MDF_HIP(hipEventRecord(w->ev2, st));
     w->stage = 2;
-    tm("enqueue phase 2");
     return MDF_OK;
 }
 
@@ -1368,10 +1341,8 @@ int mdf_nw_best_hits_finish(mdf_nw_workspace *w, int32_t *best, int32_t *score, 
     MDF_REQUIRE(!cand_scores || w->want_cs, "nw_best_hits_finish: candidate scores were not asked for at begin");
     DeviceGuard guard(w->device);
     MDF_HIP(guard.err);
-    StageTimer tm;
     w->stage = 0;
     MDF_HIP(hipEventSynchronize(w->ev2));
-    tm("wait for alignments");
     const int32_t nq = w->nq;
     const char *h = w->hs.ptr, *g = w->hs2.ptr;
     const int64_t *r_off = reinterpret_cast<const int64_t *>(g + w->g_meta);
@@ -1393,7 +1364,6 @@ int mdf_nw_best_hits_finish(mdf_nw_workspace *w, int32_t *best, int32_t *score, 
     memcpy(ops, g + w->g_ops, (size_t)r_off[nq]);
     memcpy(q_aln, g + w->g_qa, (size_t)r_off[nq]);
     memcpy(t_aln, g + w->g_ta, (size_t)r_off[nq]);
-    tm("hand out");
     return MDF_OK;
 }
 

@@ -137,8 +137,6 @@ SIGNATURES = {
     "mdf_gcn_embed_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     # the matrix-pipe aggregation (mdf_agg_desc is passed by pointer: opaque here, the batch engine builds it in C++)
     "mdf_gcn_embed_agg_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
-    "mdf_gcn_num_stages": (c_int, [c_void_p]),
-    "mdf_gcn_stage_dev": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "mdf_gcn_embed_lm_agg_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
                                          c_void_p]),
     "mdf_agg_class": (c_int, [c_int32, c_int]),

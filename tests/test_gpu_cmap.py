@@ -375,49 +375,56 @@ def test_csr_stage_flags_a_query_longer_than_max_len():
         assert int(status[2].item()) == expect and int(status[0].item()) == 0
 
 
-def test_contact_stage_kernel_generations_agree_bit_for_bit():
-    """The batched contact stage has two generations of kernels: k_cmap_bits + k_cmap_fill_rows (round 5: gathered coordinates, packed fp32 on
-    row pairs; eight lanes per row, the group scan inside) and k_cmap_rows<COUNT> + k_scan_groups + k_cmap_fill (rounds 1-4; still the path of
-    queries beyond ~3 000 residues and of the knobs MDFRI_CMAP_ROWS=old / MDFRI_CMAP_FILL=words, which are read once per process).  The raw
-    outputs of mdf_cmap_csr_dev -- rowptr, colidx, val, the layer-1 letter sums, status -- over batches with indels, proteins sharing 32-row
-    blocks, several thresholds and generated-contact widths, an overflowing capacity: the same bytes from both, each in a process of its own."""
-    import subprocess
-    import sys
-    from conftest import ROOT
-    script = (
-        "import sys, os, hashlib, ctypes; ROOT = %r\n"
-        "for d in ('metagenomic-deepfri_amd', ''): sys.path.insert(0, os.path.join(ROOT, d))\n"
-        "import numpy as np, torch\n"
-        "from mdfri_testkit import synthetic\n"
-        "from mDeepFRI import _hip\n"
-        "from mDeepFRI.batch import DeviceBatch, PackedProteins, _p\n"
-        "L = _hip.lib(); dev = torch.device('cuda:0'); h = hashlib.sha256()\n"
-        "rng = np.random.default_rng(5)\n"
-        "for it, (thr, gen, lens) in enumerate(((6.0, 2, [40, 7, 300, 16, 17, 1, 513, 64, 31]), (8.0, 0, [200, 200, 90]), (4.5, 5, [33, 700, 15, 15, 260]),\n"
-        "                                      (6.0, 2, [int(x) for x in rng.integers(1, 400, size=40)]))):\n"
-        "    prots = [synthetic.synthetic_proteins(seed=50 * it + k, count=1, length=n, indel_rate=0.08 if n > 8 else 0.0)[0] for k, n in enumerate(lens)]\n"
-        "    pk = PackedProteins.pack([p['seq'] for p in prots], [p['coords'] for p in prots], [p['q_aln'] for p in prots], [p['t_aln'] for p in prots], max_rows=65536, keep_order=True)\n"
-        "    assert len(pk.chunks) == 1\n"
-        "    db, R = DeviceBatch(pk, dev), pk.chunks[0].rows\n"
-        "    max_len = int(pk.Lq.max())\n"
-        "    seq_idx = torch.from_numpy(rng.integers(0, 26, size=R).astype(np.uint8)).to(dev)\n"
-        "    for cap in (R * 64, 100):\n"                              # the second capacity overflows: clamped row pointers, status[0..1]
-        "        ws = torch.zeros(L.mdf_cmap_workspace_bytes(pk.B, R, max_len), dtype=torch.uint8, device=dev)\n"
-        "        rowptr = torch.zeros(R + 1, dtype=torch.int32, device=dev); colidx = torch.zeros(cap, dtype=torch.int32, device=dev)\n"
-        "        val = torch.zeros(cap, dtype=torch.float32, device=dev); lsum = torch.zeros(R * 32, dtype=torch.float32, device=dev)\n"
-        "        status = torch.zeros(4, dtype=torch.int32, device=dev)\n"
-        "        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)\n"
-        "        _hip.check(L.mdf_cmap_csr_dev(_p(db.coords), _p(db.coord_off), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off), _p(db.Lq), _p(db.chunk_row_off), pk.B, R,\n"
-        "                                      max_len, thr, gen, _p(rowptr), _p(colidx), _p(val), cap, _p(status), _p(seq_idx), _p(lsum), _p(ws), ws.numel(), st))\n"
-        "        torch.cuda.synchronize()\n"
-        "        n = min(int(rowptr[R].item()), cap)\n"
-        "        for a in (rowptr, colidx[:n], val[:n], lsum, status): h.update(a.cpu().numpy().tobytes())\n"
-        "        if cap > 100: assert status.tolist() == [0, 0, 0, 0], status.tolist()\n"
-        "        else: assert status[0].item() == 1\n"
-        "print('SHA', h.hexdigest())\n" % ROOT)
-    sha_of = {}
-    for name, env in (("round 5", {}), ("rounds 1-4", {"MDFRI_CMAP_ROWS": "old", "MDFRI_CMAP_FILL": "words"})):
-        out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-        assert out.returncode == 0, out.stderr[-2000:]
-        sha_of[name] = out.stdout.split("SHA", 1)[1].strip()
-    assert sha_of["round 5"] == sha_of["rounds 1-4"], sha_of
+def test_contact_fill_forms_agree_bit_for_bit_on_the_raw_outputs():
+    """The CSR / letter-sum step of the batched contact stage has two forms: k_cmap_fill_rows (eight lanes per row, the block's columns staged in
+    LDS, the group scan inside) and, where that staging would not fit 64 KiB -- a batch whose longest query is beyond ~3 000 residues --,
+    k_scan_groups + k_cmap_fill (a word per lane) for every protein of the launch.  The same proteins alone (first form) and in front of a
+    3 300-residue query (second form, wider contact-bit rows): the raw outputs of mdf_cmap_csr_dev for THEIR rows -- row pointers, column
+    indices, values, the layer-1 letter sums -- are the same bytes, over indels, proteins sharing 32-row blocks, several thresholds and
+    generated-contact widths; and a capacity that overflows is flagged with clamped row pointers.  (Until round 6 an environment knob forced the
+    second form, and a third kernel -- k_cmap_rows<COUNT>, rounds 1-4 -- stood behind another: experiments/r06_pruned_variants.patch.)"""
+    import ctypes
+    import torch
+    from mDeepFRI import _hip
+    from mDeepFRI.batch import DeviceBatch, PackedProteins, _p
+    L = _hip.lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    long_one = synthetic.synthetic_proteins(seed=999, count=1, length=3300, indel_rate=0.02)[0]
+
+    def stage(prots, thr, gen, seq_idx_all, cap_per_row=64, cap=None):
+        pk = PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots], [p["t_aln"] for p in prots],
+                                 max_rows=1 << 17, keep_order=True)
+        assert len(pk.chunks) == 1
+        db, R = DeviceBatch(pk, dev), pk.chunks[0].rows
+        max_len = int(pk.Lq.max())
+        cap = cap or R * cap_per_row
+        seq_idx = torch.from_numpy(seq_idx_all[:R].copy()).to(dev)
+        ws = torch.zeros(L.mdf_cmap_workspace_bytes(pk.B, R, max_len), dtype=torch.uint8, device=dev)
+        rowptr = torch.zeros(R + 1, dtype=torch.int32, device=dev)
+        colidx, val = torch.zeros(cap, dtype=torch.int32, device=dev), torch.zeros(cap, dtype=torch.float32, device=dev)
+        lsum, status = torch.zeros(R * 32, dtype=torch.float32, device=dev), torch.zeros(4, dtype=torch.int32, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _hip.check(L.mdf_cmap_csr_dev(_p(db.coords), _p(db.coord_off), _p(db.q_aln), _p(db.t_aln), _p(db.aln_off), _p(db.Lq), _p(db.chunk_row_off), pk.B, R,
+                                      max_len, thr, gen, _p(rowptr), _p(colidx), _p(val), cap, _p(status), _p(seq_idx), _p(lsum), _p(ws), ws.numel(), st))
+        torch.cuda.synchronize()
+        return R, rowptr.cpu().numpy(), colidx.cpu().numpy(), val.cpu().numpy(), lsum.cpu().numpy(), status.cpu().numpy(), pk
+
+    for it, (thr, gen, lens) in enumerate(((6.0, 2, [40, 7, 300, 16, 17, 1, 513, 64, 31]), (8.0, 0, [200, 200, 90]), (4.5, 5, [33, 700, 15, 15, 260]),
+                                           (6.0, 2, [int(x) for x in rng.integers(1, 400, size=40)]))):
+        prots = [synthetic.synthetic_proteins(seed=50 * it + k, count=1, length=n, indel_rate=0.08 if n > 8 else 0.0)[0] for k, n in enumerate(lens)]
+        letters = rng.integers(0, 26, size=1 << 17).astype(np.uint8)
+        R, rp, ci, va, ls, status, pk = stage(prots, thr, gen, letters)
+        assert status.tolist() == [0, 0, 0, 0]
+        R2, rp2, ci2, va2, ls2, status2, pk2 = stage(prots + [long_one], thr, gen, letters)
+        assert status2.tolist() == [0, 0, 0, 0] and R2 > R
+        rows = int(pk2.chunk_row_off[len(prots)])         # the rows of the shared proteins: the long one starts at the next 16-row group
+        assert rows <= R and np.array_equal(pk.chunk_row_off[:len(prots)], pk2.chunk_row_off[:len(prots)])
+        n = int(rp[rows])
+        assert n > 0 and np.array_equal(rp[:rows + 1], rp2[:rows + 1])
+        assert np.array_equal(ci[:n], ci2[:n]) and np.array_equal(va[:n].view(np.uint32), va2[:n].view(np.uint32))
+        assert np.array_equal(ls[:rows * 32].view(np.uint32), ls2[:rows * 32].view(np.uint32))
+        assert np.count_nonzero(ls[:rows * 32]) > rows          # the letter sums are there
+        # a capacity that overflows: flagged, nothing written past the arrays (the row pointers are clamped to the capacity)
+        _, rp3, _, _, _, status3, _ = stage(prots, thr, gen, letters, cap=100)
+        assert status3[0] == 1 and status3[1] >= n, status3.tolist()

@@ -436,8 +436,14 @@ def test_every_batch_entry_sorts_inside_and_answers_in_input_order(heads):
         eng.run_alignments(_pack(bad, max_rows=4096))
 
 
-def _layer1_form_script() -> str:
+def _layer1_form_script(dump: bool = False) -> str:
+    """A script (for a process of its own) that runs batches through one engine and prints `SHA <digest of all scores>`; with `dump` also
+    `DUMP <path of an .npy with the scores of its last fixed batches>`."""
     from conftest import ROOT
+    tail = ("import tempfile\n"
+            "fd, path = tempfile.mkstemp(suffix='.npy'); os.close(fd)\n"
+            "np.save(path, np.concatenate([run(seed, 18, (20, 330)) for seed in (40, 102, 85)] + [run(11, 24, (176, 256)), run(12, 6, (400, 512))], axis=0))\n"
+            "print('DUMP', path)\n") if dump else ""
     return (
         "import sys, os, hashlib; ROOT = %r\n"
         "for d in ('metagenomic-deepfri_amd', ''): sys.path.insert(0, os.path.join(ROOT, d))\n"
@@ -464,7 +470,7 @@ def _layer1_form_script() -> str:
         "    prots = [synthetic.synthetic_proteins(seed=1000 * it + k, count=1, length=L, indel_rate=0.05)[0] for k, L in enumerate(lens)]\n"
         "    pk = PackedProteins.pack([p['seq'] for p in prots], [p['coords'] for p in prots], [p['q_aln'] for p in prots], [p['t_aln'] for p in prots], max_rows=1024)\n"
         "    h.update(eng.run_alignments(pk)['a'].tobytes())\n"
-        "print('SHA', h.hexdigest())\n" % ROOT)
+        "print('SHA', h.hexdigest())\n" % ROOT) + tail
 
 
 def test_layer1_made_inside_the_aggregation_kernel_is_bit_identical():
@@ -483,51 +489,59 @@ def test_layer1_made_inside_the_aggregation_kernel_is_bit_identical():
     assert sha["1"] == sha["0"], sha
 
 
-def test_aggregation_order_knob_is_bit_identical():
-    """k_aggregate_mfma takes its proteins from the END of the chunk's list by default (the rows the H.W product wrote last are read first:
-    they are the ones a 512-MiB slab still has in the Infinity Cache); MDFRI_AX_REVERSE=0 walks the list from the start.  Which workgroup
-    takes which protein changes nothing of what is computed -- including the chunk's trailing rows, zeroed by the LAST protein's workgroups,
-    which now start first: the same bits, each order in a process of its own, over the batches of the layer-1 form test."""
+def test_gather_everywhere_knob_agrees_with_the_matrix_pipe_form():
+    """MDFRI_AX_MFMA=0 (mdfri.h "Environment switches"; read once per process): every protein aggregates through the CSR gather
+    (k_aggregate) instead of the per-protein choice with the matrix-pipe kernel, and layer 1 is k_layer1 for every row.  Another summation
+    order (not bit-identical): both forms within 1e-5 of each other on the batches of the layer-1 form test and within the oracle tolerance
+    (the gather is what every other test of a protein outside the matrix-pipe classes exercises)."""
     import subprocess
     import sys
-    sha = {}
-    for rev in ("1", "0"):
-        out = subprocess.run([sys.executable, "-c", _layer1_form_script()], env=dict(os.environ, MDFRI_AX_REVERSE=rev), capture_output=True, text=True, timeout=900)
+    vals = {}
+    for mfma in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", _layer1_form_script(dump=True)], env=dict(os.environ, MDFRI_AX_MFMA=mfma), capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-2000:]
-        sha[rev] = out.stdout.split("SHA", 1)[1].strip()
-    assert sha["1"] == sha["0"], sha
+        vals[mfma] = np.load(out.stdout.split("DUMP", 1)[1].strip().split()[0])
+        os.unlink(out.stdout.split("DUMP", 1)[1].strip().split()[0])
+    assert vals["1"].shape == vals["0"].shape and vals["1"].size > 1000
+    assert not np.array_equal(vals["1"], vals["0"])        # the knob did switch kernels ...
+    assert float(np.max(np.abs(vals["1"] - vals["0"]))) < 1e-5      # ... and they agree
 
 
-def test_split_form_on_cu_masked_streams_is_bit_identical():
-    """MDFRI_SPLIT_CUS=192 (developer knob, read at engine creation): the H.W products on 192 CUs, contact stage + layer 1 + aggregations on the
-    other 64, two stacks in flight on two sets of slabs, stage by stage through mdf_gcn_stage_dev with events in between
-    (csrc/engine.hip forward_alignments_split).  Same kernels, same operands: the same bits as the one-stream form -- over mixed chunks, chunk
-    counts odd and even, one and three heads (pairs of stacks straddle chunks), dirty workspaces, repeated calls."""
+def test_graph_replay_knob_is_bit_identical():
+    """MDFRI_ENGINE_GRAPH=0 (read at engine creation): short batches are never replayed as one hipGraph; launch by launch gives the same bits
+    (the batches of tests/test_gpu_engine.py::test_short_batches_replay_as_one_graph_bitwise, each form in a process of its own)."""
     import subprocess
     import sys
     from conftest import ROOT
     script = (
         "import sys, os, hashlib; ROOT = %r\n"
         "for d in ('metagenomic-deepfri_amd', ''): sys.path.insert(0, os.path.join(ROOT, d))\n"
-        "import numpy as np\n"
+        "import numpy as np, ctypes\n"
         "from mdfri_testkit import synthetic\n"
+        "from mDeepFRI import _hip\n"
         "from mDeepFRI.batch import HotPathEngine, PackedProteins\n"
         "from mDeepFRI.predict import Predictor\n"
-        "preds = {m: Predictor('syn-' + m, weights=synthetic.glorot_gcn_weights(seed=k, n_terms=40 + k)) for k, m in enumerate('abc')}\n"
+        "preds = {m: Predictor('syn-' + m, weights=synthetic.glorot_gcn_weights(seed=k, n_terms=40 + k)) for k, m in enumerate('ab')}\n"
+        "eng = HotPathEngine(preds, device=0, max_rows=4096)\n"
         "h = hashlib.sha256()\n"
-        "for heads in (('a',), ('a', 'b', 'c')):\n"
-        "    eng = HotPathEngine({m: preds[m] for m in heads}, device=0, max_rows=2048, graph_max_chunks=-1)\n"
-        "    for seed, count in ((3, 23), (4, 40), (5, 9)):\n"
-        "        prots = synthetic.synthetic_proteins(seed=seed, count=count, length=(20, 560), indel_rate=0.05)\n"
-        "        pk = PackedProteins.pack([p['seq'] for p in prots], [p['coords'] for p in prots], [p['q_aln'] for p in prots], [p['t_aln'] for p in prots], max_rows=2048)\n"
-        "        for _ in range(2):\n"
-        "            out = eng.run_alignments(pk)\n"
-        "            for m in heads: h.update(out[m].tobytes())\n"
-        "print('SHA', h.hexdigest())\n" % ROOT)
-    sha = {}
-    for cus in ("0", "192"):
-        env = dict(os.environ, MDFRI_SPLIT_CUS=cus)
-        out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
+        "for seed, count, ln in ((3, 8, 512), (4, 3, 77), (5, 64, 200)):\n"
+        "    prots = synthetic.synthetic_proteins(seed=seed, count=count, length=ln, indel_rate=0.05)\n"
+        "    db = eng.upload(PackedProteins.pack([p['seq'] for p in prots], [p['coords'] for p in prots], [p['q_aln'] for p in prots], [p['t_aln'] for p in prots], max_rows=4096))\n"
+        "    out = eng.outputs_for(db)\n"
+        "    for _ in range(5):\n"
+        "        res = eng.forward_alignments(db, out=out)\n"
+        "    eng.check(db)\n"
+        "    for m in eng.modes: h.update(res[m].cpu().numpy().tobytes())\n"
+        "g, e = _hip.c_int64(0), _hip.c_int64(0)\n"
+        "_hip.check(eng.L.mdf_engine_graph_stats(eng.handle, g, e))\n"
+        "print('SHA', h.hexdigest(), 'GRAPHS', g.value)\n" % ROOT)
+    got = {}
+    for knob in ("1", "0"):
+        out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, MDFRI_ENGINE_GRAPH=knob), capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-2000:]
-        sha[cus] = out.stdout.split("SHA", 1)[1].strip()
-    assert sha["192"] == sha["0"], sha
+        tail = out.stdout.split("SHA", 1)[1].split()
+        got[knob] = (tail[0], int(tail[2]))
+    assert got["1"][0] == got["0"][0], got
+    assert got["1"][1] > 0 and got["0"][1] == 0, got      # replayed with the default, never with the knob
+
+
