@@ -80,6 +80,7 @@ def parse(argv=None):
     ap.add_argument("--lm", action="store_true",
                     help="give every GO head the language-model branch of the released models (shared 2x512 LSTM + per-head "
                          "LM embedding; SURVEY.md section 8f row 1).  Not the BASELINE.json configuration: an extra measurement.")
+    ap.add_argument("--lm-batch", type=int, default=0, help="--lm: proteins per LSTM group (0 = the engine's default, 8192: 10 000 proteins run as two groups of 5 000)")
     ap.add_argument("--no-board", action="store_true", help="do not sample board power / shader clock with rocm-smi while the steps run")
     ap.add_argument("--no-extras", action="store_true", help="N = 1 default run: skip the by_length / mixed / end_to_end mini-runs")
     ap.add_argument("--end-to-end", type=int, default=8, metavar="N",
@@ -588,7 +589,7 @@ def mini_run(ctx, eng, cols, chunk_rows, steps=2, warmup=1, lm=False):
     return {"value": round(n * steps / elapsed, 1), "unit": "proteins/s", "proteins": n, "steps": steps, "ms_per_step": round(1e3 * elapsed / steps, 3),
             "mean_length": round(float(np.mean([len(s) for s in cols[0]])), 1),
             "roofline": {k: roof[k] for k in ("achieved", "unit", "frac")} if roof else None,
-            "roofline_ax": {k: roof_ax[k] for k in ("achieved", "unit", "frac")} if roof_ax else None}
+            "roofline_ax": dict({k: roof_ax[k] for k in ("achieved", "unit", "frac")}, per_layer=roof_ax.get("per_layer")) if roof_ax else None}
 
 
 def dry_plan(args):
@@ -661,7 +662,7 @@ def main():
     weights = make_weights(args.lm, sparse_scores=args.workload in STRONG)
     preds = {m: Predictor(f"synthetic-{m}", weights=weights[m], device=local_rank) for m in MODES}
     T_total = sum(p.n_terms for p in preds.values())
-    eng = batch.HotPathEngine(preds, device=local_rank, max_rows=args.chunk_rows)
+    eng = batch.HotPathEngine(preds, device=local_rank, max_rows=args.chunk_rows, **({"lm_batch": args.lm_batch} if args.lm_batch > 0 else {}))
 
     strong = args.workload in STRONG
     after, local_index = None, None
@@ -776,6 +777,24 @@ def main():
             "board": board.summary(),
             "kernels": kernels,
         }
+        if kernels and args.lm:
+            # the language-model branch's own kernels against the roofline of the pipe they run on: an LSTM time step is one
+            # k_gemm_bf16x6<LSTM_*> launch per layer -- M = proteins of the group, N = 4 H, K = H (layer 1: the letter's table row rides in the
+            # epilogue) or 2 H (layer 2: [x_t | h_{t-1}]) --, the embedding one launch per chunk (M = rows, N = embed, K = H)
+            H, E = int(weights[MODES[0]]["lm_U1"].shape[0]), int(weights[MODES[0]]["W_lm"].shape[1])
+            lm_b = args.lm_batch if args.lm_batch > 0 else 8192
+            n_groups = max(1, -(-n_local // min(lm_b, 65535)))
+            B_grp = n_local / n_groups
+            peak = (MFMA_BF16_PEAK_TF / BF16X6_PRODUCTS) if ctx.lib.mdf_hw_pipe().decode() == "bf16x6" else MFMA_F32_PEAK_TF
+            rows_launch = sum(c.rows for c in pk.chunks) / len(pk.chunks)
+            fl = {"lstm": 2.0 * B_grp * 4 * H * H, "lstm2": 2.0 * B_grp * 4 * H * 2 * H, "embed": 2.0 * rows_launch * E * H}
+            line["lm_kernels"] = {k: {"avg_us": kernels[k]["avg_us"], "timed_launches": kernels[k]["launches"], "flops_per_launch": fl[k],
+                                      "tflops": round(fl[k] / (kernels[k]["avg_us"] * 1e-6) / 1e12, 1),
+                                      "frac": round(fl[k] / (kernels[k]["avg_us"] * 1e-6) / 1e12 / peak, 4)}
+                                  for k in ("lstm", "lstm2", "embed") if kernels.get(k, {}).get("launches")}
+            line["lm_kernels"]["groups"] = {"count": n_groups, "proteins_per_group": round(B_grp, 1), "peak_tflops": round(peak, 1),
+                                            "note": "a time step of the two LSTM layers is two launches on two streams (they run under each other); "
+                                                    "160 tiles of 256 x 256 per launch at 5 000 proteins: 0.625 of one round of 256 CUs"}
         if kernels and not args.lm:
             # the sampled mean of every kernel class x the launches a step really makes: must add up to the step (nothing skipped, no idle stream)
             nC, nH = len(pk.chunks), len(MODES)
@@ -823,6 +842,16 @@ def main():
             leg("mixed", lambda: mini_run(ctx, eng, make_mixed(42 + 4, n_local), args.chunk_rows))
             leg("helix", lambda: dict(mini_run(ctx, eng, make_helix(42 + 5, n_local, args.length), args.chunk_rows),
                                       note="same shape as the headline run, protein-like C-alpha traces (helix bundles) instead of random walks"))
+
+            def thr10_leg():
+                # the operating point of the released model files (`..._ca_10.0_...`, /root/reference/mDeepFRI/__init__.py:73,78): contacts at 10 A,
+                # generated_contacts 2, protein-like traces -- three to four times the entries per row of the 6 A headline: an engine of its own
+                # (threshold is a property of the engine), the same heads, one chunk geometry
+                eng10 = batch.HotPathEngine(preds, device=local_rank, max_rows=args.chunk_rows, threshold=10.0, generated_contacts=2, nnz_per_row=96)
+                res = mini_run(ctx, eng10, make_helix(42 + 7, n_local, args.length), args.chunk_rows)
+                return dict(res, threshold_A=10.0, generated_contacts=2, nnz_per_row=round(float(eng10.last_chunk_nnz()) / float(args.chunk_rows), 2),
+                            note="same shape as the headline run at the released models' 10 A threshold on helix-bundle traces; roofline_ax counts this "
+                                 "density's own bytes per row (2 x 2 KiB + 4 + 8 x entries)")
 
             def host_batches(n_batches):
                 # two distinct batches of host lists, taken in turn (generating 8 x 10 000 proteins would take longer than the leg itself)
@@ -976,6 +1005,7 @@ def main():
 
             leg("f32_pipe", f32_pipe_leg)
             leg("gcn_only", gcn_only_leg)
+            leg("thr10", thr10_leg)
             if args.end_to_end > 0:
                 leg("end_to_end", end_to_end_leg)
                 leg("binding", lambda: host_pipeline_leg("binding"))

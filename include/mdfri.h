@@ -342,7 +342,9 @@ int mdf_letter_sums_dev(const uint8_t *seq_idx, const int32_t *rowptr, const int
  * [0] for the aggregation in front of layer 2 (and a language-model head's layer 1), whose operand was just written and is cache-resident,
  * [1] for layer 3 and up, whose operand is not -- the matrix-pipe form gains more there, so more lengths are worth it (mdf_agg_class,
  * measured: profiles/r04_ax_mfma_by_length.txt).  masks / dinv / blk / row_off / Lq are the same in both. */
-#define MDF_AGG_MIN_LEN 112
+#ifndef MDF_AGG_MIN_LEN   /* (a build for a length sweep may state another: experiments/r06_len_classes.sh) */
+#define MDF_AGG_MIN_LEN 80    /* round 6 (profiles/r06_len_classes.txt): 96 residues +5.7 %, 80 +2 % on the step against the gather; 64 -4 % (rounds 4-5: 112) */
+#endif
 #define MDF_AGG_MAX_LEN 1024
 typedef struct mdf_agg_desc {
     const uint64_t *masks;      /* (R, W) device: bit j of word (r0+i, j/64) = A'[i][j] (diagonal set); rows >= Lq of a protein all zero.

@@ -78,6 +78,8 @@ struct GemmAux {
     const uint8_t *letters = nullptr;  // (M) residue indices 0..25 (anything larger reads the zero rows 26..31)
     float floor = 0.0f;                // EPI_EMBED: X0 = max(acc + table, floor): 0 = relu, -FLT_MAX = no activation
     float *cstate = nullptr;           // EPI_LSTM_*: (M, N/4) cell state, updated in place
+    float *logits = nullptr;           // EPI_BIAS_SOFTMAX2 on the bf16x6 kernels: NULL, or (M, n_real) pre-softmax values
+    int n_real = 0;                    // ... and the real output columns (2 T)
 };
 
 // sigmoid / tanh on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error < 3e-7.
@@ -198,18 +200,23 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n
         for (int tm = 0; tm < 4; ++tm) {
             const int rbase = m0 + wm * 128 + tm * 32;
             if (rbase >= M) continue;
-            int lt[16];
+            // (eight rows at a time: the next tile's operand fragments are live across the epilogue, and 16 + 16 values on top of them and the 128
+            // accumulators spilled seven registers)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) lt[r] = min((int)aux.letters[rbase + (r & 3) + 8 * (r >> 2) + lrow], 31) * N;
+            for (int r0 = 0; r0 < 16; r0 += 8) {
+                int lt[8];
 #pragma unroll
-            for (int tn = 0; tn < 2; ++tn) {
-                const int col = n0 + wn * 64 + tn * 32 + lcol;
-                float tv[16];
+                for (int q = 0; q < 8; ++q) lt[q] = min((int)aux.letters[rbase + ((r0 + q) & 3) + 8 * ((r0 + q) >> 2) + lrow], 31) * N;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tv[r] = aux.table[lt[r] + col];
+                for (int tn = 0; tn < 2; ++tn) {
+                    const int col = n0 + wn * 64 + tn * 32 + lcol;
+                    float tv[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    C[(size_t)(rbase + (r & 3) + 8 * (r >> 2) + lrow) * ldc + col] = fmaxf(acc[tm][tn][r] + tv[r], aux.floor);
+                    for (int q = 0; q < 8; ++q) tv[q] = aux.table[lt[q] + col];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        C[(size_t)(rbase + ((r0 + q) & 3) + 8 * ((r0 + q) >> 2) + lrow) * ldc + col] = fmaxf(acc[tm][tn][r0 + q] + tv[q], aux.floor);
+                }
             }
         }
         return;
@@ -645,8 +652,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
                                                                  int N, int K, float *__restrict__ C, int ldc, const float *__restrict__ bias,
                                                                  float *__restrict__ pool_partial, int ldp, int total_tiles, GemmAux aux)
 {
-    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS || EPI == EPI_EMBED,
-                  "graph-convolution layers, LSTM time steps, LM embedding");
+    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS || EPI == EPI_EMBED ||
+                      EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_SOFTMAX2,
+                  "graph-convolution layers, LSTM time steps, LM embedding, the two dense products of the GO head");
     constexpr bool PLAIN = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A 256x32 | B 256x32], unpadded rows (as k_gemm_f32)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -766,7 +774,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__
             MDF_STEP(3, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, An, 0, 0) MDF_RD(rb, Bn, 0, 0) MDF_RD(rc, Bn, 1, 0), MDF_Q(0, ra, PA[0]) MDF_Q(1, ra, PA[0]), MDF_Q(2, ra, PA[0]) MDF_Q(3, ra, PA[0]), MDF_Q(4, ra, PA[0]) MDF_Q(5, ra, PA[0]), MDF_Q(6, ra, PA[0]) MDF_Q(7, ra, PA[0]), MDF_Q(0, rb, PB[0][0]) MDF_Q(1, rb, PB[0][0]), MDF_Q(2, rb, PB[0][0]) MDF_Q(3, rb, PB[0][0]), MDF_Q(4, rb, PB[0][0]) MDF_Q(5, rb, PB[0][0]), MDF_Q(6, rb, PB[0][0]) MDF_Q(7, rb, PB[0][0]), MDF_Q(0, rc, PB[0][1]) MDF_Q(1, rc, PB[0][1]), MDF_Q(2, rc, PB[0][1]) MDF_Q(3, rc, PB[0][1]), MDF_Q(4, rc, PB[0][1]) MDF_Q(5, rc, PB[0][1]), MDF_Q(6, rc, PB[0][1]) MDF_Q(7, rc, PB[0][1]))
         }
         if (cc.kt == nk - 1) {
-            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, ldp, nullptr, N, aux);
+            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, ldp,
+                               EPI == EPI_BIAS_SOFTMAX2 ? aux.logits : nullptr, EPI == EPI_BIAS_SOFTMAX2 ? aux.n_real : N, aux);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -927,10 +936,11 @@ __global__ __launch_bounds__(256) void k_gemm_f32_small(const float *__restrict_
 // through the per-call API and inside a 10 000-protein batch.
 template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_bf16x6_small(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
-                                                           int N, int K, float *__restrict__ C, int ldc, float *__restrict__ pool_partial,
-                                                           int ldp, GemmAux aux)
+                                                           int N, int K, float *__restrict__ C, int ldc, const float *__restrict__ bias,
+                                                           float *__restrict__ pool_partial, int ldp, GemmAux aux)
 {
-    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_EMBED, "graph-convolution layers and the LM embedding");
+    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_EMBED || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_SOFTMAX2,
+                  "graph-convolution layers, the LM embedding, the two dense products of the GO head");
     const int lane = threadIdx.x & 63;
     const int NT = N >> 5, MT = (M + 31) >> 5;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1005,6 +1015,33 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x6_small(const float *__restri
         for (int r = 0; r < 16; ++r) {
             const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
             if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[r] + aux.table[lt[r] + col], aux.floor);
+        }
+        return;
+    }
+    if (EPI == EPI_BIAS_RELU) {   // (the head epilogues: the arithmetic of gemm_epilogue<EPI> on one tile, as in k_gemm_f32_small)
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+            if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[r] + bv, 0.0f);
+        }
+        return;
+    }
+    if (EPI == EPI_BIAS_SOFTMAX2) {
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+            const float z = acc[r] + bv;
+            const float zo = __shfl_xor(z, 1, 64);
+            if (row < M && col < aux.n_real) {
+                if (aux.logits) aux.logits[(size_t)row * aux.n_real + col] = z;
+                if ((col & 1) == 0) {
+                    const float mx = fmaxf(z, zo);
+                    const float e0 = expf(z - mx), e1 = expf(zo - mx);
+                    C[(size_t)row * ldc + (col >> 1)] = e0 / (e0 + e1);
+                }
+            }
         }
         return;
     }
@@ -1335,7 +1372,10 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
 #pragma unroll
             for (int k = 0; k < 8; ++k) x[k] = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(rsH, vo + k * (int)rowB, 0, 0));
         } else {
-            // the wave's tile: H1 = elu(S . T1) for the slab's 32 channels, 13 matrix instructions of two letters each
+            // the wave's tile: H1 = elu(S . T1) for the slab's 32 channels, 13 matrix instructions of two letters each.  (Round 6 also tried the
+            // chain of the NEXT chunk's tile spread over this chunk's matrix phase, one or two instructions in front of every group of four column
+            // blocks: the tile phase shrank by 1.0 us and the matrix phase grew by 1.3 -- the waves queue for the same matrix pipe either way;
+            // profiles/r06_ax_timeline.txt.)
 #pragma unroll
             for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
             if (jt < Lpad) {
@@ -1438,7 +1478,7 @@ __global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *
 #else
             const unsigned nz = (unsigned)(bw[b] >> (j0 >> 4)) & 0xffffu;
 #endif
-            if (nz) {   // (wave-uniform; a row block beyond the protein has no populated block)
+            {   // (nz is wave-uniform; a row block beyond the protein has no populated block)
                 const u32x4v mw = MW_AHEAD ? mwa[MW_AHEAD ? b : 0] : mwp[b];
                 // four column blocks at a time (unrolled: their bytes lie in a register known at compile time), column blocks in ascending order:
                 // the same sums in the same order
@@ -1895,6 +1935,8 @@ static int set_gemm_attr_once()
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_LSTM_TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_LSTM_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_BIAS_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_BIAS_SOFTMAX2>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return MDF_OK;
 }
@@ -1956,9 +1998,9 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
                 "gemm: operand larger than 4 GiB (M=%d lda=%d N=%d ldb=%d); split the batch", M, lda, N, ldb);
     if (int rc = set_gemm_attr_once()) return rc;
     if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_SOFTMAX2) {
-        // a handful of pooled vectors through the GO head: one lane per output column, bit-identical FMA chain (k_gemv_f32)
+        // fp32 pipe only: a handful of pooled vectors through the GO head, one lane per output column, bit-identical FMA chain (k_gemv_f32)
         constexpr int gemv_max = 8;
-        if (M <= gemv_max) {
+        if (M <= gemv_max && !hw_pipe_bf16x6()) {
             hipLaunchKernelGGL(k_gemv_f32<EPI>, dim3(N / 64, M), dim3(64), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias, logits, n_real);
             MDF_HIP(hipGetLastError());
             return MDF_OK;
@@ -1966,23 +2008,27 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
     }
     const int MT = (M + BM - 1) / BM, NT = N / BN;
     const bool plain = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
-    if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS || EPI == EPI_EMBED) {
+    if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS || EPI == EPI_EMBED ||
+                  EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_SOFTMAX2) {
         // the graph-convolution products (and, on the language-model branch, the LSTM time steps of large groups and the embedding) run BF16x6 on the
         // bf16 matrix pipe (k_gemm_bf16x6: fp32 in, fp32 out, error below the fp32 pipe's); MDFRI_HW_PIPE=f32 keeps them on
-        // v_mfma_f32_32x32x2_f32 (developer knob, read once: A/B runs and the bench's comparison leg)
+        // v_mfma_f32_32x32x2_f32 (read once: A/B runs and the bench's comparison leg).  Round 6: so do the two dense products of the GO head
+        // (40 x 4 tiles of 256 x 256 fill 160 of 256 CUs for one round whatever the pipe: 444 + 375 us per head on the fp32 instruction)
         if (hw_pipe_bf16x6()) {
+            GemmAux ax = aux;
+            if constexpr (EPI == EPI_BIAS_SOFTMAX2) ax.logits = logits, ax.n_real = n_real;
             bool small = false;
-            if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_EMBED) {
+            if constexpr (EPI != EPI_LSTM_TAB && EPI != EPI_LSTM_BIAS) {
                 small = MT * NT * 8 < 3 * gemm_resident_blocks();
                 if (small) {
                     const int tiles = ((M + 31) / 32) * (N / 32);
-                    hipLaunchKernelGGL(k_gemm_bf16x6_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, pool_partial, ldp, aux);
+                    hipLaunchKernelGGL(k_gemm_bf16x6_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, bias, pool_partial, ldp, ax);
                 }
             }
             if (!small) {
                 const int total = plain ? MT * NT : 8 * NT * ((MT + 7) / 8);
                 hipLaunchKernelGGL((k_gemm_bf16x6<EPI>), dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt,
-                                   ldb, M, N, K, C, ldc, bias, pool_partial, ldp, total, aux);
+                                   ldb, M, N, K, C, ldc, bias, pool_partial, ldp, total, ax);
             }
             MDF_HIP(hipGetLastError());
             return MDF_OK;
@@ -2698,19 +2744,31 @@ int mdf_gcn_embed_dev(mdf_model *m, const float *letter_sums, const int32_t *row
     return mdf_gcn_embed_agg_dev(m, letter_sums, rowptr, colidx, val, R, nullptr, partial, workspace, workspace_bytes, stream);
 }
 
-// Where the matrix-pipe form beats the gather (profiles/r04_ax_mfma_by_length.txt): proteins that fill their 256-row chunks (L just below a
-// multiple of 256), and more widely where the operand is not cache-resident.  A function of (length, kind of launch) alone.
+// Where the matrix-pipe form beats the gather: every length from MDF_AGG_MIN_LEN to MDF_AGG_MAX_LEN (rounds 4-5 left gaps just above the
+// multiples of 256, where a protein's last 256-row chunk is mostly empty: profiles/r04_ax_mfma_by_length.txt).  A function of the length alone.
 int mdf_agg_class(int32_t L, int resident)
 {
     (void)resident;   // (round 5: the same lengths in front of layer 2 and of layer 3 -- profiles/r05_ax_by_length.txt)
     if (L < MDF_AGG_MIN_LEN || L > MDF_AGG_MAX_LEN) return -1;
-    return L <= 256 ? 0 : (L >= 288 && L <= 512) ? 1 : (L >= 544 && L <= MDF_AGG_MAX_LEN) ? 2 : -1;
+#ifdef MDF_AGG_CLASS_EXPERIMENT   // (length-class sweeps: a build with another rule, e.g. -D'MDF_AGG_CLASS_EXPERIMENT(L)=(L<=256?0:L<=512?1:2)'; tools/ax_ab.py compares builds)
+    return MDF_AGG_CLASS_EXPERIMENT(L);
+#else
+    // round 6 (experiments/r06_len_classes.sh, profiles/r06_len_classes.txt): with the contact bits as byte tiles the matrix-pipe form wins just above
+    // the multiples of 256 too -- 272 residues: 148.8 k against 129.5 k proteins/s through the gather, 528: 78.1 k against 68.7 k
+    return L <= 256 ? 0 : L <= 512 ? 1 : 2;
+#endif
 }
 
 // Lengths whose layer-1 rows are made INSIDE the layer-2 aggregation launch on the fused engine path (k_aggregate_mfma<.., true>): where that
-// launch beats k_layer1 + the plain kernel -- proteins that fill their 256-row chunks at one or two row blocks per wave.  With four row blocks
-// the fused form sits on the register limit (155 us against 71 + 36 at 800 residues), and below 176 / between 257 and 399 the plain pair wins.
-int mdf_agg_l1_fused(int32_t L) { return (L >= 176 && L <= 256) || (L >= 400 && L <= 512); }
+// launch beats k_layer1 + the plain kernel.  The form exists for one or two row blocks per wave (at most 512 residues; with four it sat on the
+// register limit in round 5: 155 us against 71 + 36 at 800 residues).
+#ifdef MDF_AGG_FUSED_EXPERIMENT
+int mdf_agg_l1_fused(int32_t L) { return MDF_AGG_FUSED_EXPERIMENT(L); }
+#else
+// round 6: with the letter sums stored in the matrix instruction's order the fused launch wins at every length it exists for (one or two row
+// blocks per wave): 128 residues +6.6 %, 288-384 +5 % on the step, the old ranges unchanged (profiles/r06_len_classes.txt)
+int mdf_agg_l1_fused(int32_t L) { return L >= MDF_AGG_MIN_LEN && L <= 512; }
+#endif
 
 int32_t mdf_agg_tile_row_bytes(int32_t max_len) { return 32 * ((std::min(std::max(max_len, 1), MDF_AGG_MAX_LEN) + AGG_CHR - 1) / AGG_CHR); }
 

@@ -36,9 +36,10 @@ def worker():
     shapes = (("L512", 3, 1024, 512, 0.0), ("L256", 4, 2048, 256, 0.0), ("L1024", 5, 512, 1024, 0.0), ("mixed", 6, 1200, (128, 1024), 0.05),
               ("L448", 7, 1024, 448, 0.03), ("L200", 8, 2048, 200, 0.0))
     only = os.environ.get("AX_AB_SHAPES")
+    if only:      # any fixed length: "L384" = one chunk's worth of 384-residue proteins (x 2)
+        known = {sh[0]: sh for sh in shapes}
+        shapes = [known[nm] if nm in known else (nm, 100 + int(nm[1:]), max(2, 2 * 262144 // int(nm[1:])), int(nm[1:]), 0.0) for nm in only.split(",")]
     for name, seed, n, length, indel in shapes:
-        if only and name not in only.split(","):
-            continue
         prots = synthetic.synthetic_proteins(seed, n, length, indel)
         pk = PackedProteins.pack([p["seq"] for p in prots], [p["coords"] for p in prots], [p["q_aln"] for p in prots], [p["t_aln"] for p in prots])
         db = eng.upload(pk)
