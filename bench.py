@@ -80,7 +80,7 @@ def parse(argv=None):
     ap.add_argument("--lm", action="store_true",
                     help="give every GO head the language-model branch of the released models (shared 2x512 LSTM + per-head "
                          "LM embedding; SURVEY.md section 8f row 1).  Not the BASELINE.json configuration: an extra measurement.")
-    ap.add_argument("--lm-batch", type=int, default=0, help="--lm: proteins per LSTM group (0 = the engine's default, 8192: 10 000 proteins run as two groups of 5 000)")
+    ap.add_argument("--lm-batch", type=int, default=0, help="--lm: proteins per LSTM group (0 = the engine's default, 16384: 10 000 proteins run as one group)")
     ap.add_argument("--no-board", action="store_true", help="do not sample board power / shader clock with rocm-smi while the steps run")
     ap.add_argument("--no-extras", action="store_true", help="N = 1 default run: skip the by_length / mixed / end_to_end mini-runs")
     ap.add_argument("--end-to-end", type=int, default=8, metavar="N",
@@ -730,7 +730,7 @@ def main():
         rank_info = {"world_size": 1, "backend": None, "devices": [me]}
 
     timing_period = 0 if args.no_kernel_timing else args.timing_period
-    with BoardSampler(ctx.dev.index or 0, off=args.no_board) as board:
+    with BoardSampler(ctx.dev.index or 0, off=args.no_board or ctx.rank != 0) as board:   # (rank 0 only: one sampler per job)
         elapsed, out, split = timed_run(ctx, eng, db, args.steps, args.warmup, after=after, timing_period=timing_period)
 
     if strong:
@@ -782,7 +782,7 @@ def main():
             # k_gemm_bf16x6<LSTM_*> launch per layer -- M = proteins of the group, N = 4 H, K = H (layer 1: the letter's table row rides in the
             # epilogue) or 2 H (layer 2: [x_t | h_{t-1}]) --, the embedding one launch per chunk (M = rows, N = embed, K = H)
             H, E = int(weights[MODES[0]]["lm_U1"].shape[0]), int(weights[MODES[0]]["W_lm"].shape[1])
-            lm_b = args.lm_batch if args.lm_batch > 0 else 8192
+            lm_b = args.lm_batch if args.lm_batch > 0 else 16384
             n_groups = max(1, -(-n_local // min(lm_b, 65535)))
             B_grp = n_local / n_groups
             peak = (MFMA_BF16_PEAK_TF / BF16X6_PRODUCTS) if ctx.lib.mdf_hw_pipe().decode() == "bf16x6" else MFMA_F32_PEAK_TF
@@ -792,9 +792,13 @@ def main():
                                       "tflops": round(fl[k] / (kernels[k]["avg_us"] * 1e-6) / 1e12, 1),
                                       "frac": round(fl[k] / (kernels[k]["avg_us"] * 1e-6) / 1e12 / peak, 4)}
                                   for k in ("lstm", "lstm2", "embed") if kernels.get(k, {}).get("launches")}
-            line["lm_kernels"]["groups"] = {"count": n_groups, "proteins_per_group": round(B_grp, 1), "peak_tflops": round(peak, 1),
-                                            "note": "a time step of the two LSTM layers is two launches on two streams (they run under each other); "
-                                                    "160 tiles of 256 x 256 per launch at 5 000 proteins: 0.625 of one round of 256 CUs"}
+            both = line["lm_kernels"].get("lstm"), line["lm_kernels"].get("lstm2")
+            if all(both):   # the two layers' launches of a time step run under each other on two streams: their flops over the longer of the two
+                t_step = max(both[0]["avg_us"], both[1]["avg_us"]) * 1e-6
+                line["lm_kernels"]["recurrence"] = {"tflops": round((fl["lstm"] + fl["lstm2"]) / t_step / 1e12, 1),
+                                                    "frac": round((fl["lstm"] + fl["lstm2"]) / t_step / 1e12 / peak, 4),
+                                                    "note": "both layers of one time step together: the rate to hold against the H.W GEMM's (roofline.frac)"}
+            line["lm_kernels"]["groups"] = {"count": n_groups, "proteins_per_group": round(B_grp, 1), "peak_tflops": round(peak, 1)}
         if kernels and not args.lm:
             # the sampled mean of every kernel class x the launches a step really makes: must add up to the step (nothing skipped, no idle stream)
             nC, nH = len(pk.chunks), len(MODES)
@@ -849,7 +853,7 @@ def main():
                 # (threshold is a property of the engine), the same heads, one chunk geometry
                 eng10 = batch.HotPathEngine(preds, device=local_rank, max_rows=args.chunk_rows, threshold=10.0, generated_contacts=2, nnz_per_row=96)
                 res = mini_run(ctx, eng10, make_helix(42 + 7, n_local, args.length), args.chunk_rows)
-                return dict(res, threshold_A=10.0, generated_contacts=2, nnz_per_row=round(float(eng10.last_chunk_nnz()) / float(args.chunk_rows), 2),
+                return dict(res, threshold_A=10.0, generated_contacts=2, nnz_per_row=round(float(eng10.last_chunk_nnz()) / float((n_local * args.length) % args.chunk_rows or args.chunk_rows), 2),
                             note="same shape as the headline run at the released models' 10 A threshold on helix-bundle traces; roofline_ax counts this "
                                  "density's own bytes per row (2 x 2 KiB + 4 + 8 x entries)")
 

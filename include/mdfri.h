@@ -492,7 +492,7 @@ typedef struct {
     double threshold;            /* contact threshold in Angstrom (cli.py:360-371 default 6.0) */
     int32_t generated_contacts;  /* contact_map_utils.pyx:44 generated_contacts (default 2) */
     int32_t max_segment_groups;  /* 0 = 1 << 20 */
-    int32_t lm_batch;            /* proteins per LSTM group for heads with a language model; 0 = 8192 */
+    int32_t lm_batch;            /* proteins per LSTM group for heads with a language model; 0 = 16384 */
     double lm_workspace_gib;     /* LSTM time-major workspace budget; 0 = 48 */
     int32_t graph_max_chunks;    /* batches of at most this many chunks replay their launch sequence as ONE hipGraph from the
                                     third identical call on (same plan, buffers and outputs); 0 = 8, negative = never */

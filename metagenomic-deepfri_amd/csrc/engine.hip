@@ -592,7 +592,7 @@ extern "C" int mdf_engine_create(mdf_model *const *models, int32_t n_models, int
     if (c.nnz_per_row <= 0) c.nnz_per_row = 40;
     if (!cfg) c.threshold = 6.0, c.generated_contacts = 2;
     if (c.max_segment_groups <= 0) c.max_segment_groups = 1 << 20;
-    if (c.lm_batch <= 0) c.lm_batch = 8192;
+    if (c.lm_batch <= 0) c.lm_batch = 16384;   // (round 6: one group of 10 000 proteins against two of 5 000: +1.1 % on the --lm line)
     if (c.lm_workspace_gib <= 0) c.lm_workspace_gib = 48.0;
     if (c.graph_max_chunks == 0) c.graph_max_chunks = 8;
     if (const char *g = getenv("MDFRI_ENGINE_GRAPH")) {   // developer knob: 0 = never replay graphs

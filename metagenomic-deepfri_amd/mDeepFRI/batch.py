@@ -281,7 +281,7 @@ class HotPathEngine:
     class owns the torch tensors (inputs, flags, outputs) and turns return codes into the exceptions of the per-call API."""
 
     def __init__(self, predictors: dict, device: int = 0, max_rows: int = None, nnz_per_row: int = 40,
-                 threshold: float = 6.0, generated_contacts: int = 2, lm_batch: int = 8192, lm_workspace_gib: float = 48.0,
+                 threshold: float = 6.0, generated_contacts: int = 2, lm_batch: int = 0, lm_workspace_gib: float = 48.0,
                  graph_max_chunks: int = 0, pipeline_contact: int = 0):
         import weakref
         torch = _torch()

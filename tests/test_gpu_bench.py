@@ -111,35 +111,35 @@ def test_strong_workloads_at_full_size_one_gpu(workload, count, floor):
 
 
 def test_default_line_regression_net():
-    """The headline configuration (configs[2]: 10 000 x L=512, three heads) for three timed steps: rate, both rooflines and the
-    bookkeeping that makes them checkable.  Floors: 72 k proteins/s (round 5 committed: 84-89 k from box to box; 64-66 k on the fp32
-    instruction), the H.W GEMM (BF16x6 on the bf16 matrix pipe) >= 1.02 x the fp32 instruction's peak and >= 0.40 of its own roofline,
-    bf16 peak / 6 (committed 0.46-0.49: the kernel sits on the board's power limit -- profiles/r05_gemm_overlap_probe.txt -- and boxes
-    differ); A.X proper -- the layer-3 launches; with layer 1 made inside the layer-2 launch that one is NOT part of this figure -- >= 0.40
-    of the HBM peak (north_star's target; committed 0.50-0.52); the layer-2 launch that also makes layer 1 has a ceiling of its own,
-    105 us per 65 536 rows (committed 74-82); the sampled kernel classes x their launches per step within 5 % of the step; `traffic`
-    either stamped for this very library or null with the reason -- never a stale constant; and the board's power / shader clock while
-    the steps ran, when rocm-smi is there."""
+    """The headline configuration (configs[2]: 10 000 x L=512, three heads) for six timed steps: rate, both rooflines and the
+    bookkeeping that makes them checkable.  Floors: 78 k proteins/s (round 6 committed: 90.1-91.5 k from box to box; round 5: 84-89 k; 68 k on
+    the fp32 instruction), the H.W GEMM (BF16x6 on the bf16 matrix pipe) >= 1.02 x the fp32 instruction's peak and >= 0.40 of its own roofline,
+    bf16 peak / 6 (committed 0.49-0.52: the kernel sits on the board's power limit -- profiles/r05_gemm_overlap_probe.txt -- and boxes
+    differ); A.X proper -- the layer-3 launches; with layer 1 made inside the layer-2 launch that one is NOT part of this figure -- >= 0.52
+    of the HBM peak (north_star's target: 0.40; committed 0.64-0.66, 200-209 us per 262 144 rows); the layer-2 launch that also makes layer 1
+    has a ceiling of its own, 80 us per 65 536 rows (committed 59-62; round 5: 76); the sampled kernel classes x their launches per step
+    within 3 % of the step (six steps, every 5th launch timed -- 48 timed launches per GraphConv class); `traffic` either stamped
+    for this very library or null with the reason -- never a stale constant; and the board's power / shader clock while the steps ran, when
+    rocm-smi is there."""
     from mDeepFRI import _hip
-    line = _run("--steps", "3", "--warmup", "1", "--no-extras", "--cpu-seconds", "0")
+    line = _run("--steps", "6", "--warmup", "1", "--no-extras", "--cpu-seconds", "0", "--timing-period", "5")
     assert line["metric"] == "proteins/sec (GCN+cmap) at L=512" and line["config"]["proteins_total"] == 10000
-    assert line["value"] >= 72_000, line["value"]
+    assert line["value"] >= 78_000, line["value"]
     r, ax = line["roofline"], line["roofline_ax"]
     assert r["pipe"] == "bf16x6" == _hip.lib().mdf_hw_pipe().decode() and r["bound"] == "mfma", r
     assert 0.40 <= r["frac"] < 1.0 and abs(r["peak"] - 2500.0 / 6) < 0.1 and r["vs_f32_instruction_peak"] >= 1.02, r
-    assert 0.40 <= ax["frac"] < 1.0 and ax["bound"] == "hbm", ax
+    assert 0.52 <= ax["frac"] < 1.0 and ax["bound"] == "hbm", ax
     for obj, names in ((r, ("gemm2", "gemm3")), (ax, ("ax2", "ax3"))):
-        assert set(obj["per_layer"]) == set(names) and all(v["timed_launches"] >= 20 for v in obj["per_layer"].values()), obj["per_layer"]
+        assert set(obj["per_layer"]) == set(names) and all(v["timed_launches"] >= 40 for v in obj["per_layer"].values()), obj["per_layer"]
         layers = obj["per_layer"]
         if obj is ax and ax.get("layer1_form") == "fused":      # the layer-2 launch also makes layer 1: the A.X roofline is over the layer-3 launches
             assert _hip.lib().mdf_layer1_form() == b"fused" and layers["ax2"]["makes_layer1"] is True
             per_64k = layers["ax2"]["avg_us"] * 65536.0 / ax["per_launch"]["rows"]   # (a launch covers a chunk: MDF_DEFAULT_CHUNK_ROWS rows by default)
-            assert per_64k <= 105.0, (layers["ax2"], ax["per_launch"]["rows"])   # the fused launch's own guard (k_aggregate_mfma<2, true>)
+            assert per_64k <= 80.0, (layers["ax2"], ax["per_launch"]["rows"])   # the fused launch's own guard (k_aggregate_mfma<2, true>)
             layers = {"ax3": layers["ax3"]}
         pooled = sum(v["avg_us"] * v["timed_launches"] for v in layers.values()) / sum(v["timed_launches"] for v in layers.values())
         assert abs(pooled - obj["per_launch"]["avg_us"]) < 0.02 * pooled          # `achieved` is the mean over every (pure) launch of the kernel
-    # (5 %: every 7th launch of a class is timed, and right behind the full-size workloads of this file the clock still moves; typical +1.5 %)
-    assert abs(line["kernel_sum_ms_per_step"] - line["ms_per_step"]) < 0.05 * line["ms_per_step"], (line["kernel_sum_ms_per_step"], line["ms_per_step"])
+    assert abs(line["kernel_sum_ms_per_step"] - line["ms_per_step"]) < 0.03 * line["ms_per_step"], (line["kernel_sum_ms_per_step"], line["ms_per_step"])
     board = line["board"]
     assert set(board) >= {"board_power_w", "shader_clock_mhz", "power_cap_w"}
     if board["board_power_w"] is not None:       # (rocm-smi present and parsable)
