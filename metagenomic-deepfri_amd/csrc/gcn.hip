@@ -1238,8 +1238,11 @@ __device__ unsigned long long *g_ax_probe = nullptr;   // [workgroup][8 waves][3
 #define MDF_AX_STAMP(k_)
 #endif
 // Round 6 -- what the time stamps inside the kernel showed (tools/ax_timeline.py, profiles/r06_ax_timeline.txt), and what follows from it:
-//  * the kernel is bound by what ONE CU gets through, and that is resident workgroups / life of a workgroup: the plain form runs THREE
-//    workgroups per CU (<= 84 registers, <= 53 KiB of LDS) and loses 8-17 % as soon as it has two -- whatever the two do faster;
+//  * the kernel is bound by what ONE CU gets through: resident workgroups / life of a workgroup.  The plain form of one or two row blocks
+//    per wave is held to 80 registers (the launch bound asks for six waves per SIMD; it compiled to 82 -- two over: TWO workgroups per CU
+//    by hipOccupancyMaxActiveBlocksPerMultiprocessor, tools/ax_occupancy.py) and 52 KiB of LDS = THREE workgroups per CU: layer 3 at 320
+//    residues 244 -> 220 us, at 448-512 -3 %.  The fused form (111 registers, 58 KiB: the layer-1 tile on top of the aggregation's state)
+//    stays at two; held to 80 registers without its LDS staging it spills 35 and loses 75 % (experiments/r06_ax_l1_lean.patch);
 //  * a load instruction costs the CU's L1 one look-up per 128-byte line it touches: the letter sums of a tile, read row-major (32 lines per
 //    instruction, 7 instructions), were 160 of 500 us of the layer-2 launch -- they are now stored in the order the matrix instruction
 //    takes them (MDF_LSUM_INDEX, mdfri.h: 8 lines per instruction, 4 instructions);
@@ -1260,7 +1263,7 @@ __device__ unsigned long long *g_ax_probe = nullptr;   // [workgroup][8 waves][3
 // `sched_barrier`s keep the compiler from sinking the requests back to their first use.  Same operands, same order of every sum:
 // bit-identical to the round-5 kernel (tools/ax_ab.py prints a digest of the scores for two builds of the library).
 template <int ROWBLOCKS, bool L1 = false>
-__global__ __launch_bounds__(AGG_THREADS, 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const uint8_t *__restrict__ tiles,
+__global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const uint8_t *__restrict__ tiles,
                                                                    int Wt, const float *__restrict__ dinv, const unsigned long long *__restrict__ blk,
                                                                    const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq,
                                                                    const int32_t *__restrict__ plist, const int32_t *__restrict__ gate,
@@ -2243,6 +2246,21 @@ using namespace mdf;
 
 extern "C" {
 
+#ifdef MDF_AX_OCC   // developer build (tools/ax_occupancy.py): resident workgroups per CU of every instantiation of the aggregation kernel, as the runtime computes them
+int mdf_debug_ax_occupancy(int *out)
+{
+    int k = 0;
+#define MDF_OCC(...)                                                                                                                \
+    {                                                                                                                               \
+        int n = -1;                                                                                                                 \
+        MDF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(&k_aggregate_mfma<__VA_ARGS__>), AGG_THREADS, 0)); \
+        out[k++] = n;                                                                                                               \
+    }
+    MDF_OCC(1, false) MDF_OCC(2, false) MDF_OCC(4, false) MDF_OCC(1, true) MDF_OCC(2, true)
+#undef MDF_OCC
+    return k;
+}
+#endif
 #ifdef MDF_AX_PROBE
 int mdf_debug_ax_probe(void *buf)
 {
