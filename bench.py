@@ -550,11 +550,18 @@ def rooflines(ctx, eng, pk, kernels, lm):
                                   "timed_launches": a["launches"]},
                    "per_layer": per_layer}
         if fused_l1:
+            # which proteins of THIS workload get their layer 1 inside the layer-2 launch: those the matrix pipe takes at one or two row blocks per
+            # wave (mdf_agg_l1_fused: 80 .. 512 residues); the others' layer 1 is k_layer1 (`gemm1` class) in front of the plain form
+            lq = np.asarray(pk.Lq)
+            n_fused = int(sum(int(ctx.lib.mdf_agg_l1_fused(int(x))) != 0 for x in np.unique(lq) for _ in range(1)))
+            fused_frac = float(np.mean([ctx.lib.mdf_agg_l1_fused(int(x)) != 0 for x in lq])) if len(lq) <= 200000 else None
+            roof_ax["layer1_inside_layer2_launch"] = {"distinct_lengths_fused": n_fused, "distinct_lengths": int(len(np.unique(lq))),
+                                                      "proteins_fused_fraction": None if fused_frac is None else round(fused_frac, 4)}
             roof_ax["layer1_form"] = "fused"
             roof_ax["note"] = ("`achieved` is over the layer-3 launches (the A.X kernel proper); the layer-2 launch (`per_layer.ax2`) also makes layer 1 "
                                "(H1 = elu(S.T1), never written) and replaces a k_layer1 launch + an A.X launch -- its `frac` against the A.X bytes is "
                                "kept for comparison only; MDFRI_L1_FUSE=0 runs the two-kernel form")
-            per_layer["ax2"]["makes_layer1"] = True
+            per_layer["ax2"]["makes_layer1"] = bool(n_fused > 0)
     return roof, roof_ax
 
 

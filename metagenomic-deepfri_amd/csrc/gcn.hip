@@ -1230,6 +1230,7 @@ struct AggLayer1 {
     float *pool_partial = nullptr;
     int ldp = 0;
     int reverse = 0;              // walk the protein list from its end (see launch_aggregate)
+    int n_prot = 0;               // proteins of this launch (the grid is padded to groups of eight proteins: XCD-aware order)
 };
 #ifdef MDF_AX_PROBE   // developer build (tools/ax_timeline.py): wall-clock stamps (100 MHz) of every wave at the phase boundaries below
 __device__ unsigned long long *g_ax_probe = nullptr;   // [workgroup][8 waves][32]
@@ -1279,8 +1280,16 @@ __global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void 
     constexpr bool MW_AHEAD = L1;   // contact bytes one chunk ahead (4 registers per row block)
     constexpr int NDL = L1 ? (ROWBLOCKS * AGG_CHR + AGG_THREADS - 1) / AGG_THREADS : 1;
     const int slabs = C / AGG_SL;
-    const int pi = blockIdx.x / slabs, slab = blockIdx.x % slabs;
-    const int p = plist[l1.reverse ? (int)(gridDim.x / slabs) - 1 - pi : pi];
+    // XCD-aware order: block b runs on XCD b % 8 (observed placement), and the `slabs` workgroups of a protein share its contact-byte tiles, its
+    // d_j, its populated-block words and (L1) its letter sums -- so all of them go to ONE XCD: XCD x takes the proteins x, x + 8, ... and walks
+    // their slabs; with consecutive blocks on consecutive slabs (rounds 4-5) every one of the eight L2s fetches every protein's shared operands.
+    // The grid is padded to whole groups of eight proteins.
+    // (measured, profiles/r06_ax_ab.txt #7: the plain form gains 3-5 % -- layer 3 at 512 residues 212.6 -> 202.2 us --, the fused form LOSES 2-3 %:
+    // its 16 slabs then ask one L2 for the same letter-sum lines at the same time; it keeps consecutive blocks on consecutive slabs)
+    const int xq = (int)(blockIdx.x >> 3);
+    const int pi = L1 ? (int)blockIdx.x / slabs : (xq / slabs) * 8 + (int)(blockIdx.x & 7), slab = L1 ? (int)blockIdx.x % slabs : xq % slabs;
+    if (pi >= l1.n_prot) return;
+    const int p = plist[l1.reverse ? l1.n_prot - 1 - pi : pi];
     if (gate && gate[p] == 0) return;                            // not a binary map: the CSR gather launch takes this protein
     const int r0 = row_off[p], L = Lq[p];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -2114,7 +2123,7 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
     {   // one launch per length class (1, 2 or 4 row blocks per wave: the accumulators a workgroup carries)
         const unsigned slabs = (unsigned)(Cin / AGG_SL);
         const int32_t *pl = agg->plist;
-#define MDF_AGG_ARGS(n_) dim3((unsigned)(n_) * slabs), dim3(AGG_THREADS), 0, st, Hin, Cin, agg->tiles,                                               \
+#define MDF_AGG_ARGS(n_) dim3((unsigned)(((n_) + 7) / 8 * 8) * slabs), dim3(AGG_THREADS), 0, st, Hin, Cin, agg->tiles,                                               \
                          agg->tile_row_bytes, agg->dinv, reinterpret_cast<const unsigned long long *>(agg->blk), agg->row_off, agg->Lq, pl, agg->gate, AH,              \
                          agg->tail_p, (int)agg->tail_row0, Ri
         // Chunks beyond ~100 000 rows: a 512-channel slab no longer fits the 256 MiB Infinity Cache, and a kernel that reads its operand in
@@ -2130,6 +2139,7 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
         MDF_REQUIRE(!(l1 && agg->n_mf[2] > 0), "launch_aggregate: layer 1 inside the aggregation launch for a protein of more than 512 residues");
 #define MDF_AGG(RB, n_)                                                                                  \
     if ((n_) > 0) {                                                                                      \
+        l1v.n_prot = plainv.n_prot = (n_);                                                               \
         if (l1) hipLaunchKernelGGL((k_aggregate_mfma<(RB <= 2 ? RB : 2), true>), MDF_AGG_ARGS(n_), l1v); \
         else hipLaunchKernelGGL((k_aggregate_mfma<RB, false>), MDF_AGG_ARGS(n_), plainv);                \
     }                                                                                                    \
@@ -2794,8 +2804,8 @@ int mdf_agg_prepare_dev(const uint64_t *masks, int32_t W, const int32_t *counts,
                         int64_t R, float *dinv, uint64_t *blk, uint8_t *tiles, int32_t tile_row_bytes, void *stream)
 {
     MDF_REQUIRE(masks && counts && row_off && Lq && dinv && blk && tiles && B > 0 && W > 0 && R > 0, "agg_prepare_dev: bad argument");
-    MDF_REQUIRE(tile_row_bytes >= 32 && tile_row_bytes % 32 == 0 && tile_row_bytes <= 32 * (MDF_AGG_MAX_LEN / AGG_CHR) && (int64_t)R * tile_row_bytes < 0x7fffffffLL,
-                "agg_prepare_dev: tile_row_bytes %d (mdf_agg_tile_row_bytes) for %lld rows", tile_row_bytes, (long long)R);
+    MDF_REQUIRE(tile_row_bytes >= 32 && tile_row_bytes % 32 == 0 && tile_row_bytes <= 32 * (MDF_AGG_MAX_LEN / AGG_CHR),
+                "agg_prepare_dev: tile_row_bytes %d is not mdf_agg_tile_row_bytes(max_len)", tile_row_bytes);   // (a protein's tiles are addressed from its own 64-bit base: no limit on R)
     hipLaunchKernelGGL(k_agg_prepare, dim3((unsigned)B, 32), dim3(64), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const unsigned long long *>(masks), W, counts, row_off, Lq, dinv, reinterpret_cast<unsigned long long *>(blk), tiles,
                        (int)tile_row_bytes);

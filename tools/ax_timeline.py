@@ -43,7 +43,7 @@ db = eng.upload(pk)
 for _ in range(2):
     eng.forward_alignments(db)
 torch.cuda.synchronize()
-n_wg = a.proteins * 16
+n_wg = (a.proteins + 7) // 8 * 8 * 16      # (the grid is padded to whole groups of eight proteins: XCD-aware order)
 buf = torch.zeros((n_wg, 8, 32), dtype=torch.int64, device="cuda")
 assert lib.mdf_debug_ax_probe(buf.data_ptr()) == 0
 eng.forward_alignments(db)
