@@ -1201,6 +1201,9 @@ constexpr int AGG_SL = 32;        // channels of a workgroup's slab (one 32 x 32
 constexpr int AGG_CHR = 256;      // rows of the protein in LDS at a time (8 waves x 32 rows)
 constexpr int AGG_OPITCH = 40;    // floats per row of a wave's output staging tile (the two lane halves hit disjoint banks)
 constexpr int AGG_THREADS = 512;
+#ifndef MDF_AX_L1_SPAN   // XCDs the slab workgroups of a protein are spread over in the fused form (the plain form: 1); see k_aggregate_mfma
+#define MDF_AX_L1_SPAN 8
+#endif
 
 // bf16 terms of an fp32 value: hi = x with the low 16 bits cleared, mid = (x - hi) likewise, lo = x - hi - mid (at most 8 significant
 // bits: exact in bf16).  hi + mid + lo == x (barring underflow of the residuals below 2^-126).
@@ -1286,8 +1289,10 @@ __global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void 
     // The grid is padded to whole groups of eight proteins.
     // (measured, profiles/r06_ax_ab.txt #7: the plain form gains 3-5 % -- layer 3 at 512 residues 212.6 -> 202.2 us --, the fused form LOSES 2-3 %:
     // its 16 slabs then ask one L2 for the same letter-sum lines at the same time; it keeps consecutive blocks on consecutive slabs)
-    const int xq = (int)(blockIdx.x >> 3);
-    const int pi = L1 ? (int)blockIdx.x / slabs : (xq / slabs) * 8 + (int)(blockIdx.x & 7), slab = L1 ? (int)blockIdx.x % slabs : xq % slabs;
+    // SPAN = XCDs a protein's slabs are spread over (8: every XCD two slabs of every protein; 1: all sixteen on one); proteins in sets of 8 / SPAN
+    constexpr int SPAN = L1 ? MDF_AX_L1_SPAN : 1;
+    const int bx = (int)(blockIdx.x & 7), bq = (int)(blockIdx.x >> 3), per = slabs / SPAN;
+    const int pi = (bq / per) * (8 / SPAN) + bx / SPAN, slab = (bq % per) * SPAN + bx % SPAN;
     if (pi >= l1.n_prot) return;
     const int p = plist[l1.reverse ? l1.n_prot - 1 - pi : pi];
     if (gate && gate[p] == 0) return;                            // not a binary map: the CSR gather launch takes this protein
