@@ -329,3 +329,24 @@ def test_default_chunk_rows_is_one_number_everywhere():
     from mDeepFRI.batch import PackedProteins
     pk = PackedProteins.pack(["A" * 512] * 3000)
     assert max(c.rows for c in pk.chunks) == n and len(pk.chunks) == -(-3000 * 512 // n)
+
+
+def test_host_batch_packs_lists_and_refuses_inconsistent_ones():
+    """mDeepFRI.batch.HostBatch: the host lists of one batch flattened for mdf_engine_submit_alignments_host (what the compiled binding's
+    BatchEngine.submit builds) -- joined bytes, int32 lengths, one (sum Lt, 3) float32 array; lists of different lengths, a gapped target
+    of another length than the gapped query, an empty batch are refused before anything reaches the library."""
+    from mDeepFRI.batch import HostBatch
+    rng = np.random.default_rng(1)
+    seqs, q, t = ["ACD", "MKVLA"], ["AC-D", "MKVLA"], ["ACGD", "MK-LA"]
+    coords = [rng.standard_normal((4, 3)), rng.standard_normal((4, 3)).astype(np.float64)]
+    hb = HostBatch(seqs, coords, q, t)
+    assert hb.B == 2 and hb.seq_bytes == b"ACDMKVLA" and hb.q_bytes == b"AC-DMKVLA" and hb.t_bytes == b"ACGDMK-LA"
+    assert hb.Lq.tolist() == [3, 5] and hb.La.tolist() == [4, 5] and hb.Lt.tolist() == [4, 4]
+    assert hb.xyz.dtype == np.float32 and hb.xyz.shape == (8, 3) and hb.xyz.flags["C_CONTIGUOUS"]
+    assert np.array_equal(hb.xyz[4:], coords[1].astype(np.float32))
+    with pytest.raises(ValueError, match="one length"):
+        HostBatch(seqs, coords[:1], q, t)
+    with pytest.raises(ValueError, match="differ in length"):
+        HostBatch(seqs, coords, q, ["ACGD", "MKLA"])
+    with pytest.raises(ValueError, match="non-empty"):
+        HostBatch([], [], [], [])

@@ -706,3 +706,84 @@ def test_bf16x6_products_are_at_least_as_accurate_as_the_fp32_instruction():
         assert res[pipe]["pipe"] == pipe and res[pipe]["bitwise"] is True, res[pipe]
         assert res[pipe]["batch_err"] < 2e-6 and res[pipe]["percall_err"] < 2e-6, res[pipe]
     assert res["bf16x6"]["batch_err"] <= 1.25 * res["f32"]["batch_err"] + 1e-7, res
+
+
+def test_agg_prepare_writes_the_contact_bits_as_byte_tiles():
+    """mdf_agg_prepare_dev (round 6): beside d_j and the populated-block words, the contact bits once more in the order the matrix-pipe
+    aggregation loads them (mdfri.h mdf_agg_desc.tiles): 16-row group g x 256-column chunk c of a protein at ((g nch + c) 512), byte
+    ((i mod 16) 2 + h) 16 + cb = the bits of row i, columns 256 c + 16 cb + 8 h .. + 7.  Random symmetric-free bit matrices for proteins of
+    80 .. 1 024 residues (and one too short, one too long: no tiles, no block words), rebuilt in numpy from the same masks."""
+    import ctypes
+    import torch
+    from mDeepFRI import _hip
+    L = _hip.lib()
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(12)
+    lens = [80, 97, 256, 257, 300, 512, 513, 1000, 1024, 64, 1500]
+    Lq = np.array(lens, dtype=np.int32)
+    row_off = np.zeros(len(lens) + 1, dtype=np.int32)
+    R = int(L.mdf_layout_rows(_hip.ptr(Lq), len(lens), _hip.ptr(row_off)))
+    max_len = int(Lq.max())
+    W = (max_len + 63) // 64
+    masks = np.zeros((R, W), dtype=np.uint64)
+    counts = np.zeros(R, dtype=np.int32)
+    dense = []
+    for p, n in enumerate(lens):
+        A = (rng.random((n, n)) < 0.04)
+        A |= np.abs(np.subtract.outer(np.arange(n), np.arange(n))) <= 2
+        dense.append(A)
+        bits = np.zeros((n, W * 64), dtype=bool)
+        bits[:, :n] = A
+        words = np.packbits(bits.reshape(n, W, 64)[:, :, ::-1], axis=2).view(">u8").reshape(n, W).astype(np.uint64)   # bit j of word w = column 64 w + j
+        masks[row_off[p]:row_off[p] + n] = words
+        counts[row_off[p]:row_off[p] + n] = A.sum(axis=1)
+    Wt = int(L.mdf_agg_tile_row_bytes(max_len))
+    assert Wt == 128
+    up = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    d_masks, d_counts, d_ro, d_lq = up(masks.view(np.int64)), up(counts), up(row_off), up(Lq)
+    dinv = torch.full((R,), -1.0, dtype=torch.float32, device=dev)
+    blk = torch.zeros((len(lens), 32), dtype=torch.int64, device=dev)
+    tiles = torch.full((R * Wt,), 0xEE, dtype=torch.uint8, device=dev)
+    p_ = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    _hip.check(L.mdf_agg_prepare_dev(p_(d_masks), W, p_(d_counts), p_(d_ro), p_(d_lq), len(lens), R, p_(dinv), p_(blk), p_(tiles), Wt, None))
+    torch.cuda.synchronize()
+    th, bh, dh = tiles.cpu().numpy(), blk.cpu().numpy().view(np.uint64), dinv.cpu().numpy()
+    for p, n in enumerate(lens):
+        r0, A = int(row_off[p]), dense[p]
+        assert np.array_equal(dh[r0:r0 + n], (1.0 / (np.float32(1e-6) + np.sqrt(A.sum(axis=1).astype(np.float32)))).astype(np.float32)), p
+        if n < 80 or n > 1024:
+            assert np.all(th[r0 * Wt:(r0 + n) * Wt] == 0xEE) and not bh[p].any()       # outside the matrix-pipe lengths: untouched
+            continue
+        npad, nch = (n + 15) // 16 * 16, (n + 255) // 256
+        Ap = np.zeros((npad, nch * 256), dtype=bool)
+        Ap[:n, :n] = A
+        region = th[r0 * Wt:r0 * Wt + (npad // 16) * nch * 512].reshape(npad // 16, nch, 16, 2, 16)     # [group][chunk][row in group][half][column block]
+        want = np.packbits(Ap.reshape(npad // 16, 16, nch, 16, 2, 8)[..., ::-1], axis=5)[..., 0]           # [g][i][c][cb][h] -> byte, bit k = column ... + k
+        assert np.array_equal(region, want.transpose(0, 2, 1, 4, 3)), (p, n)
+        for b in range((n + 31) // 32):      # bit c of blk[p][b]: rows [32 b, 32 b + 32) have a contact in columns [16 c, 16 c + 16)
+            rows = Ap[32 * b:32 * b + 32]
+            exp = sum(1 << c for c in range(nch * 16) if rows[:, 16 * c:16 * c + 16].any())
+            assert int(bh[p, b]) == exp, (p, b)
+
+
+def test_dense_map_path_replans_a_batch_planned_with_the_fused_paths_chunks():
+    """HotPathEngine.forward_dense stages a chunk's maps in pinned + device slots of chunk rows x L x 4 B each; a batch planned with the
+    fused path's default chunk (262 144 rows) is re-planned with DENSE_CHUNK_ROWS (65 536) -- same scores, bit for bit, as the same maps through
+    a batch planned small from the start and as the fused path."""
+    import cmap_oracle
+    from mDeepFRI import batch
+    from mDeepFRI.batch import HotPathEngine, PackedProteins
+    from mDeepFRI.predict import Predictor
+    from mdfri_testkit import synthetic
+    w = synthetic.glorot_gcn_weights(seed=3, n_terms=55)
+    eng = HotPathEngine({"a": Predictor("syn", weights=w)}, device=0)
+    prots = synthetic.synthetic_proteins(seed=77, count=300, length=(200, 330), indel_rate=0.03)      # ~80 000 padded rows: two chunks of 65 536, one of the default
+    maps = [cmap_oracle.build_align_contact_map(p["coords"], p["q_aln"], p["t_aln"], 6.0, 2) for p in prots]
+    seqs = [p["seq"] for p in prots]
+    big = eng.upload(PackedProteins.pack(seqs))
+    assert big.packed.max_chunk_rows > batch.DENSE_CHUNK_ROWS and len(big.packed.chunks) == 1
+    got = eng.forward_dense(big, maps)["a"].cpu().numpy()
+    assert len(big._dense.packed.chunks) == 2 and big._dense.packed.max_chunk_rows <= batch.DENSE_CHUNK_ROWS
+    small = eng.forward_dense(eng.upload(PackedProteins.pack(seqs, max_rows=batch.DENSE_CHUNK_ROWS)), maps)["a"].cpu().numpy()
+    fused = eng.run_alignments(PackedProteins.pack(seqs, [p["coords"] for p in prots], [p["q_aln"] for p in prots], [p["t_aln"] for p in prots]))["a"]
+    assert np.array_equal(got, small) and np.array_equal(got, fused)

@@ -112,6 +112,12 @@ def test_engine_scores_with_language_model_full_size():
         for m, w in heads.items():
             ref = lm_oracle.gcn_lm_forward(w, d["seq"], A) if "W_lm" in w else gcn_oracle.gcn_forward(w, d["seq"], A)
             assert np.abs(out[m][p] - ref).max() < 1e-4, (m, p)
+    # the same batches through the library's two-slot host pipeline (round 6; the LSTM groups run on the pipeline's compute stream): the same bits
+    from mDeepFRI.batch import HostPipeline
+    cols = ([d["seq"] for d in prot], [d["coords"] for d in prot], [d["q_aln"] for d in prot], [d["t_aln"] for d in prot])
+    got = list(HostPipeline(eng).run([cols, tuple(c[::-1] for c in cols), cols]))
+    for m in heads:
+        assert np.array_equal(got[0][m], out[m]) and np.array_equal(got[2][m], out[m]) and np.array_equal(got[1][m], out[m][::-1]), m
 
 
 def test_language_model_head_with_linear_embedding_and_aa_bias():
