@@ -389,7 +389,8 @@ typedef struct mdf_agg_desc {
  * 32-row blocks per wave of the matrix-pipe kernel (at most 256 / 512 / 1 024 residues), -1 = the CSR gather.  Since round 5 the two kinds
  * list the same lengths (after the kernel's instruction diet the matrix-pipe form wins in front of layer 2 wherever it wins in front of
  * layer 3); what differs in front of layer 2 is whether layer 1 is made inside the launch: mdf_agg_l1_fused(L) != 0 (fused engine path
- * only; the per-call and dense-map paths run k_layer1 + the plain kernel, bit-identical). */
+ * only; the per-call and dense-map paths run k_layer1 + the plain kernel, bit-identical).  Round 6: every length from MDF_AGG_MIN_LEN to
+ * MDF_AGG_MAX_LEN takes the matrix pipe (no gaps above the multiples of 256), and every one of them has its layer 1 made inside the launch. */
 int mdf_agg_class(int32_t L, int resident);
 int mdf_agg_l1_fused(int32_t L);
 

@@ -1201,6 +1201,12 @@ constexpr int AGG_SL = 32;        // channels of a workgroup's slab (one 32 x 32
 constexpr int AGG_CHR = 256;      // rows of the protein in LDS at a time (8 waves x 32 rows)
 constexpr int AGG_OPITCH = 40;    // floats per row of a wave's output staging tile (the two lane halves hit disjoint banks)
 constexpr int AGG_THREADS = 512;
+#ifndef MDF_AX_L1_RB1_W6   // (experiment) the fused form of one row block per wave at 80 registers / 53 KiB: three workgroups per CU
+#define MDF_AX_L1_RB1_W6 0
+#endif
+#ifndef MDF_AX_L1_FUSED_MAX   // longest protein whose layer 1 is made inside the layer-2 aggregation launch (a length sweep may build with another)
+#define MDF_AX_L1_FUSED_MAX MDF_AGG_MAX_LEN
+#endif
 #ifndef MDF_AX_L1_SPAN   // XCDs the slab workgroups of a protein are spread over in the fused form (the plain form: 1); see k_aggregate_mfma
 #define MDF_AX_L1_SPAN 8
 #endif
@@ -1267,7 +1273,7 @@ __device__ unsigned long long *g_ax_probe = nullptr;   // [workgroup][8 waves][3
 // `sched_barrier`s keep the compiler from sinking the requests back to their first use.  Same operands, same order of every sum:
 // bit-identical to the round-5 kernel (tools/ax_ab.py prints a digest of the scores for two builds of the library).
 template <int ROWBLOCKS, bool L1 = false>
-__global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const uint8_t *__restrict__ tiles,
+__global__ __launch_bounds__(AGG_THREADS, ((!L1 && ROWBLOCKS <= 2) || (L1 && ROWBLOCKS == 1 && MDF_AX_L1_RB1_W6)) ? 6 : 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const uint8_t *__restrict__ tiles,
                                                                    int Wt, const float *__restrict__ dinv, const unsigned long long *__restrict__ blk,
                                                                    const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq,
                                                                    const int32_t *__restrict__ plist, const int32_t *__restrict__ gate,
@@ -1276,11 +1282,13 @@ __global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void 
     __shared__ __attribute__((aligned(16))) unsigned short xt[3 * AGG_SL * AGG_CHR];   // 48 KiB; re-used as 8 x 5 KiB output staging at the end
     __shared__ __attribute__((aligned(16))) unsigned short lut[256 * 8];                // contact byte -> its 8 bf16 (0.0 / 1.0): one ds_read_b128
     __shared__ __attribute__((aligned(16))) float dl[L1 ? ROWBLOCKS * AGG_CHR : 4];     // L1: d_j of the protein's rows, 0.0 from row L on
-    __shared__ __attribute__((aligned(16))) float t1l[L1 ? 4 * 64 * 4 : 4];             // L1: the slab's slice of T1 as the waves' B operands: [i / 4][lane][i % 4] = T1[2 i + (lane >> 5)][slab column lane & 31]
+    constexpr bool T1_LDS = L1 && !(ROWBLOCKS == 1 && MDF_AX_L1_RB1_W6);   // one row block per wave: T1 operands straight from L2 (53 KiB of LDS + 80 registers = three workgroups per CU)
+    __shared__ __attribute__((aligned(16))) float t1l[T1_LDS ? 4 * 64 * 4 : 4];             // L1: the slab's slice of T1 as the waves' B operands: [i / 4][lane][i % 4] = T1[2 i + (lane >> 5)][slab column lane & 31]
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-    constexpr bool MW_AHEAD = L1;   // contact bytes one chunk ahead (4 registers per row block)
+    constexpr bool MW_AHEAD = L1 && ROWBLOCKS <= 2;   // contact bytes one chunk ahead (4 registers per row block; with four row blocks: in front of the second barrier, as in the plain form)
+    constexpr bool SV_AHEAD = L1 && ROWBLOCKS <= 2;   // the next tile's letter sums one chunk ahead (16 registers; with four row blocks the kernel sits on the 128-register limit: requested at the top of the chunk -- measured equal, profiles/r06_ax_ab.txt #9)
     constexpr int NDL = L1 ? (ROWBLOCKS * AGG_CHR + AGG_THREADS - 1) / AGG_THREADS : 1;
     const int slabs = C / AGG_SL;
     // XCD-aware order: block b runs on XCD b % 8 (observed placement), and the `slabs` workgroups of a protein share its contact-byte tiles, its
@@ -1316,6 +1324,7 @@ __global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void 
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dinv + r0), 0, Lpad * 4, 0x00020000);   // (0.0 for rows in [L, Lpad): k_agg_prepare)
     // L1: the pooling partial sums of the protein's groups (base at its first group and this slab; 1 GiB: any offset inside a protein fits)
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(L1 ? l1.pool_partial + (size_t)(r0 >> 4) * l1.ldp + slab * AGG_SL : const_cast<float *>(Hs), 0, L1 ? 1 << 30 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L1 ? l1.T1 + slab * AGG_SL : Hs), 0, L1 ? 32 * (int)rowB : 0, 0x00020000);   // L1: the slab's columns of the 32 rows of T1
     constexpr int OUTSIDE = 0x7ffffff0;       // a vector offset no descriptor of this kernel covers: the load returns zeros, the store is dropped
     MDF_AX_STAMP(0)
 
@@ -1349,10 +1358,12 @@ __global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void 
 #pragma unroll
     for (int q = 0; q < 4; ++q) sv[q] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
     if (L1) {
+        if (T1_LDS) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int en = threadIdx.x + e * AGG_THREADS, i = (en >> 8) * 4 + (en & 3), ln = (en >> 2) & 63;   // (letters 26 .. 31: zero rows of T1)
-            t1r[e] = l1.T1[(size_t)(2 * i + (ln >> 5)) * C + slab * AGG_SL + (ln & 31)];
+            for (int e = 0; e < 2; ++e) {
+                const int en = threadIdx.x + e * AGG_THREADS, i = (en >> 8) * 4 + (en & 3), ln = (en >> 2) & 63;   // (letters 26 .. 31: zero rows of T1)
+                t1r[e] = l1.T1[(size_t)(2 * i + (ln >> 5)) * C + slab * AGG_SL + (ln & 31)];
+            }
         }
         request_sums(0);
 #pragma unroll
@@ -1364,7 +1375,7 @@ __global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void 
 #pragma unroll
         for (int e = 0; e < NDL; ++e)
             if ((int)(threadIdx.x + e * AGG_THREADS) < ROWBLOCKS * AGG_CHR) dl[threadIdx.x + e * AGG_THREADS] = dreg[e];
-        t1l[threadIdx.x] = t1r[0], t1l[threadIdx.x + AGG_THREADS] = t1r[1];
+        if (T1_LDS) t1l[threadIdx.x] = t1r[0], t1l[threadIdx.x + AGG_THREADS] = t1r[1];
         __syncthreads();   // (the first chunk's tiles are made in front of the loop's first barrier)
     }
     f32x16 acc[ROWBLOCKS];
@@ -1396,9 +1407,17 @@ __global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void 
 #pragma unroll
             for (int r = 0; r < 16; ++r) h1[r] = 0.0f;
             if (jt < Lpad) {
+                if (!SV_AHEAD && j0 > 0) request_sums(j0);   // (four row blocks: no register to carry them across the matrix phase; chunk 0's were requested in the prologue)
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
-                    const v4f t = *reinterpret_cast<const v4f *>(t1l + i4 * 256 + lane * 4);
+                    v4f t;
+                    if (T1_LDS) {
+                        t = *reinterpret_cast<const v4f *>(t1l + i4 * 256 + lane * 4);
+                    } else {   // T1[2 i + half][slab column frow]: a wave's load = two 128-byte lines
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            t[c] = i4 * 4 + c < 13 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, (half * C + frow) * 4, (i4 * 4 + c) * 2 * (int)rowB, 0)) : 0.0f;
+                    }
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #ifdef AX_ABL_CHAIN   // (probe build only: 1 of the 13 matrix instructions)
@@ -1432,9 +1451,11 @@ __global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void 
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sA), rsP, half ? po : OUTSIDE, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sB), rsP, half && jt + GROUP_ROWS < Lpad ? po + l1.ldp * 4 : OUTSIDE, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            request_sums(j0 + AGG_CHR);   // the next chunk's tile: in flight under everything below
-            __builtin_amdgcn_sched_barrier(0);
+            if (SV_AHEAD) {
+                __builtin_amdgcn_sched_barrier(0);
+                request_sums(j0 + AGG_CHR);   // the next chunk's tile: in flight under everything below
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         MDF_AX_STAMP(2 + (j0 >> 8) * 6)
         __syncthreads();   // the previous chunk's fragments have been read (first chunk: the tables are complete)
@@ -1465,6 +1486,8 @@ __global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void 
         } else {
             // this lane's channel (frow), rows 8 g + 4 half .. + 3 of the wave's tile: half a 16-byte slot per term and g
             typedef short bf16x4 __attribute__((ext_vector_type(4)));
+            int fr = frow;
+            if (ROWBLOCKS != 2) asm volatile("" : "+v"(fr));   // (four row blocks: the 12 store addresses below are recomputed per chunk instead of living in registers -- they were spilled)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const v4f d = *reinterpret_cast<const v4f *>(dl + jt + 8 * g + 4 * half);
@@ -1477,9 +1500,15 @@ __global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void 
                     agg_split3(xs, a, b, cc);
                     th[q] = (short)a, tm[q] = (short)b, tl[q] = (short)cc;
                 }
-                *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(0, frow, wid * 4 + g) + 4 * half) = th;
-                *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(1, frow, wid * 4 + g) + 4 * half) = tm;
-                *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(2, frow, wid * 4 + g) + 4 * half) = tl;
+                *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(0, fr, wid * 4 + g) + 4 * half) = th;
+                *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(1, fr, wid * 4 + g) + 4 * half) = tm;
+                *reinterpret_cast<bf16x4 *>(xt + agg_xt_off(2, fr, wid * 4 + g) + 4 * half) = tl;
+            }
+            if (!MW_AHEAD) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < ROWBLOCKS; ++b) mwp[b] = request_bytes(b, j0);   // (the tile's registers are free again)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         MDF_AX_STAMP(4 + (j0 >> 8) * 6)
@@ -2138,14 +2167,11 @@ static int launch_aggregate(const float *Hin, int Cin, const int32_t *rowptr, co
         constexpr int reverse = 1;
         AggLayer1 l1v = l1 ? *l1 : AggLayer1(), plainv;
         l1v.reverse = plainv.reverse = reverse;
-        // (layer 1 is made inside the launch for proteins of at most 512 residues only -- mdf_agg_l1_fused; gcn_stack does not fuse a
-        // descriptor that lists longer ones -- so the form with four row blocks per wave exists without it only)
         MDF_REQUIRE(agg->tiles && agg->tile_row_bytes >= 32, "launch_aggregate: the descriptor carries no contact-byte tiles (mdf_agg_prepare_dev)");
-        MDF_REQUIRE(!(l1 && agg->n_mf[2] > 0), "launch_aggregate: layer 1 inside the aggregation launch for a protein of more than 512 residues");
 #define MDF_AGG(RB, n_)                                                                                  \
     if ((n_) > 0) {                                                                                      \
         l1v.n_prot = plainv.n_prot = (n_);                                                               \
-        if (l1) hipLaunchKernelGGL((k_aggregate_mfma<(RB <= 2 ? RB : 2), true>), MDF_AGG_ARGS(n_), l1v); \
+        if (l1) hipLaunchKernelGGL((k_aggregate_mfma<RB, true>), MDF_AGG_ARGS(n_), l1v);                 \
         else hipLaunchKernelGGL((k_aggregate_mfma<RB, false>), MDF_AGG_ARGS(n_), plainv);                \
     }                                                                                                    \
     pl += (n_);
@@ -2271,7 +2297,7 @@ int mdf_debug_ax_occupancy(int *out)
         MDF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void *>(&k_aggregate_mfma<__VA_ARGS__>), AGG_THREADS, 0)); \
         out[k++] = n;                                                                                                               \
     }
-    MDF_OCC(1, false) MDF_OCC(2, false) MDF_OCC(4, false) MDF_OCC(1, true) MDF_OCC(2, true)
+    MDF_OCC(1, false) MDF_OCC(2, false) MDF_OCC(4, false) MDF_OCC(1, true) MDF_OCC(2, true) MDF_OCC(4, true)
 #undef MDF_OCC
     return k;
 }
@@ -2793,14 +2819,15 @@ int mdf_agg_class(int32_t L, int resident)
 }
 
 // Lengths whose layer-1 rows are made INSIDE the layer-2 aggregation launch on the fused engine path (k_aggregate_mfma<.., true>): where that
-// launch beats k_layer1 + the plain kernel.  The form exists for one or two row blocks per wave (at most 512 residues; with four it sat on the
-// register limit in round 5: 155 us against 71 + 36 at 800 residues).
+// launch beats k_layer1 + the plain kernel -- since round 6 every length the matrix pipe takes.  (Round 5's form with four row blocks per wave
+// spilled 32 registers and lost -- 155 us against 71 + 36 at 800 residues; the round-6 form has no spill -- its 12 LDS store addresses are
+// recomputed per chunk instead of living in registers -- and wins: 544-1 024 residues +5.0 ... +6.4 % on the step, mixed +4.0 %.)
 #ifdef MDF_AGG_FUSED_EXPERIMENT
 int mdf_agg_l1_fused(int32_t L) { return MDF_AGG_FUSED_EXPERIMENT(L); }
 #else
-// round 6: with the letter sums stored in the matrix instruction's order the fused launch wins at every length it exists for (one or two row
-// blocks per wave): 128 residues +6.6 %, 288-384 +5 % on the step, the old ranges unchanged (profiles/r06_len_classes.txt)
-int mdf_agg_l1_fused(int32_t L) { return L >= MDF_AGG_MIN_LEN && L <= 512; }
+// round 6: with the letter sums stored in the matrix instruction's order the fused launch wins at every length: 128 residues +6.6 %, 288-384 +5 %
+// on the step, the old ranges unchanged (profiles/r06_len_classes.txt); 544-1 024 +5 ... +6 % (profiles/r06_ax_ab.txt #9)
+int mdf_agg_l1_fused(int32_t L) { return L >= MDF_AGG_MIN_LEN && L <= MDF_AX_L1_FUSED_MAX; }
 #endif
 
 int32_t mdf_agg_tile_row_bytes(int32_t max_len) { return 32 * ((std::min(std::max(max_len, 1), MDF_AGG_MAX_LEN) + AGG_CHR - 1) / AGG_CHR); }
@@ -2841,7 +2868,7 @@ static int gcn_stack(mdf_model *m, const float *letter_sums, const int32_t *rowp
     // (a descriptor that names its layer-1 rows -- the fused engine path's -- lists in n_mf[] exactly the proteins to fuse; one that does not
     // fuses every listed protein, as before)
     const bool split_lists = agg && agg->l1_seg;
-    const bool fuse = layer1_fused() && agg && !agg->gate && m->n_gc >= 2 && agg->n_mf[0] + agg->n_mf[1] > 0 && agg->n_mf[2] == 0 &&
+    const bool fuse = layer1_fused() && agg && !agg->gate && m->n_gc >= 2 && agg->n_mf[0] + agg->n_mf[1] + agg->n_mf[2] > 0 &&
                       (split_lists ? (agg->n_l1_seg <= 4 || agg->l1_skip) : (agg->n_seg <= 4 || agg->skip_groups));
     const int32_t *l1_seg = split_lists ? agg->l1_seg : agg ? agg->csr_seg : nullptr;
     const int n_l1_seg = split_lists ? agg->n_l1_seg : agg ? agg->n_seg : 0;
