@@ -473,6 +473,21 @@ def _layer1_form_script(dump: bool = False) -> str:
         "print('SHA', h.hexdigest())\n" % ROOT) + tail
 
 
+def _run_child(script: str, env: dict, timeout: int = 300):
+    """One engine script in a process of its own.  A child that exceeds `timeout` is started ONCE more and the event is printed: one run
+    of round 6 on a fresh box sat in its first child for 900 s (the same scripts take 5-8 s; not reproduced in ten further runs of the
+    suite and of this file, `profiles/r06_gpu_tests.txt`); a second expiry fails the test."""
+    import subprocess
+    import sys
+    for attempt in (0, 1):
+        try:
+            return subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=timeout)
+        except subprocess.TimeoutExpired:
+            print("child exceeded %d s (attempt %d)" % (timeout, attempt), file=sys.stderr)
+            if attempt:
+                raise
+
+
 def test_layer1_made_inside_the_aggregation_kernel_is_bit_identical():
     """Layer 1 of the proteins whose layer-2 aggregation runs on the matrix pipe is made inside that kernel (k_aggregate_mfma<.., true>:
     H1 = elu(S . T1) per 32-row tile on v_mfma_f32_32x32x2_f32, pooling sums handed from lane half to lane half in row order, the chunk's
@@ -483,7 +498,7 @@ def test_layer1_made_inside_the_aggregation_kernel_is_bit_identical():
     sha = {}
     for fuse in ("1", "0"):
         env = dict(os.environ, MDFRI_L1_FUSE=fuse)
-        out = subprocess.run([sys.executable, "-c", _layer1_form_script()], env=env, capture_output=True, text=True, timeout=900)
+        out = _run_child(_layer1_form_script(), env)
         assert out.returncode == 0, out.stderr[-2000:]
         sha[fuse] = out.stdout.split("SHA", 1)[1].strip()
     assert sha["1"] == sha["0"], sha
@@ -498,7 +513,7 @@ def test_gather_everywhere_knob_agrees_with_the_matrix_pipe_form():
     import sys
     vals = {}
     for mfma in ("1", "0"):
-        out = subprocess.run([sys.executable, "-c", _layer1_form_script(dump=True)], env=dict(os.environ, MDFRI_AX_MFMA=mfma), capture_output=True, text=True, timeout=900)
+        out = _run_child(_layer1_form_script(dump=True), dict(os.environ, MDFRI_AX_MFMA=mfma))
         assert out.returncode == 0, out.stderr[-2000:]
         vals[mfma] = np.load(out.stdout.split("DUMP", 1)[1].strip().split()[0])
         os.unlink(out.stdout.split("DUMP", 1)[1].strip().split()[0])
@@ -537,7 +552,7 @@ def test_graph_replay_knob_is_bit_identical():
         "print('SHA', h.hexdigest(), 'GRAPHS', g.value)\n" % ROOT)
     got = {}
     for knob in ("1", "0"):
-        out = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, MDFRI_ENGINE_GRAPH=knob), capture_output=True, text=True, timeout=900)
+        out = _run_child(script, dict(os.environ, MDFRI_ENGINE_GRAPH=knob))
         assert out.returncode == 0, out.stderr[-2000:]
         tail = out.stdout.split("SHA", 1)[1].split()
         got[knob] = (tail[0], int(tail[2]))
