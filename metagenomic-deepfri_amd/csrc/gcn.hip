@@ -1201,9 +1201,6 @@ constexpr int AGG_SL = 32;        // channels of a workgroup's slab (one 32 x 32
 constexpr int AGG_CHR = 256;      // rows of the protein in LDS at a time (8 waves x 32 rows)
 constexpr int AGG_OPITCH = 40;    // floats per row of a wave's output staging tile (the two lane halves hit disjoint banks)
 constexpr int AGG_THREADS = 512;
-#ifndef MDF_AX_L1_RB1_W6   // (experiment) the fused form of one row block per wave at 80 registers / 53 KiB: three workgroups per CU
-#define MDF_AX_L1_RB1_W6 0
-#endif
 #ifndef MDF_AX_L1_FUSED_MAX   // longest protein whose layer 1 is made inside the layer-2 aggregation launch (a length sweep may build with another)
 #define MDF_AX_L1_FUSED_MAX MDF_AGG_MAX_LEN
 #endif
@@ -1273,7 +1270,7 @@ __device__ unsigned long long *g_ax_probe = nullptr;   // [workgroup][8 waves][3
 // `sched_barrier`s keep the compiler from sinking the requests back to their first use.  Same operands, same order of every sum:
 // bit-identical to the round-5 kernel (tools/ax_ab.py prints a digest of the scores for two builds of the library).
 template <int ROWBLOCKS, bool L1 = false>
-__global__ __launch_bounds__(AGG_THREADS, ((!L1 && ROWBLOCKS <= 2) || (L1 && ROWBLOCKS == 1 && MDF_AX_L1_RB1_W6)) ? 6 : 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const uint8_t *__restrict__ tiles,
+__global__ __launch_bounds__(AGG_THREADS, (!L1 && ROWBLOCKS <= 2) ? 6 : 4) void k_aggregate_mfma(const float *__restrict__ H, int C, const uint8_t *__restrict__ tiles,
                                                                    int Wt, const float *__restrict__ dinv, const unsigned long long *__restrict__ blk,
                                                                    const int32_t *__restrict__ row_off, const int32_t *__restrict__ Lq,
                                                                    const int32_t *__restrict__ plist, const int32_t *__restrict__ gate,
@@ -1282,8 +1279,7 @@ __global__ __launch_bounds__(AGG_THREADS, ((!L1 && ROWBLOCKS <= 2) || (L1 && ROW
     __shared__ __attribute__((aligned(16))) unsigned short xt[3 * AGG_SL * AGG_CHR];   // 48 KiB; re-used as 8 x 5 KiB output staging at the end
     __shared__ __attribute__((aligned(16))) unsigned short lut[256 * 8];                // contact byte -> its 8 bf16 (0.0 / 1.0): one ds_read_b128
     __shared__ __attribute__((aligned(16))) float dl[L1 ? ROWBLOCKS * AGG_CHR : 4];     // L1: d_j of the protein's rows, 0.0 from row L on
-    constexpr bool T1_LDS = L1 && !(ROWBLOCKS == 1 && MDF_AX_L1_RB1_W6);   // one row block per wave: T1 operands straight from L2 (53 KiB of LDS + 80 registers = three workgroups per CU)
-    __shared__ __attribute__((aligned(16))) float t1l[T1_LDS ? 4 * 64 * 4 : 4];             // L1: the slab's slice of T1 as the waves' B operands: [i / 4][lane][i % 4] = T1[2 i + (lane >> 5)][slab column lane & 31]
+    __shared__ __attribute__((aligned(16))) float t1l[L1 ? 4 * 64 * 4 : 4];             // L1: the slab's slice of T1 as the waves' B operands: [i / 4][lane][i % 4] = T1[2 i + (lane >> 5)][slab column lane & 31]
     typedef float v2f __attribute__((ext_vector_type(2)));
     typedef float v4f __attribute__((ext_vector_type(4)));
     typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
@@ -1324,7 +1320,6 @@ __global__ __launch_bounds__(AGG_THREADS, ((!L1 && ROWBLOCKS <= 2) || (L1 && ROW
     const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dinv + r0), 0, Lpad * 4, 0x00020000);   // (0.0 for rows in [L, Lpad): k_agg_prepare)
     // L1: the pooling partial sums of the protein's groups (base at its first group and this slab; 1 GiB: any offset inside a protein fits)
     const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(L1 ? l1.pool_partial + (size_t)(r0 >> 4) * l1.ldp + slab * AGG_SL : const_cast<float *>(Hs), 0, L1 ? 1 << 30 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(L1 ? l1.T1 + slab * AGG_SL : Hs), 0, L1 ? 32 * (int)rowB : 0, 0x00020000);   // L1: the slab's columns of the 32 rows of T1
     constexpr int OUTSIDE = 0x7ffffff0;       // a vector offset no descriptor of this kernel covers: the load returns zeros, the store is dropped
     MDF_AX_STAMP(0)
 
@@ -1358,12 +1353,10 @@ __global__ __launch_bounds__(AGG_THREADS, ((!L1 && ROWBLOCKS <= 2) || (L1 && ROW
 #pragma unroll
     for (int q = 0; q < 4; ++q) sv[q] = (v4f){0.0f, 0.0f, 0.0f, 0.0f};
     if (L1) {
-        if (T1_LDS) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int en = threadIdx.x + e * AGG_THREADS, i = (en >> 8) * 4 + (en & 3), ln = (en >> 2) & 63;   // (letters 26 .. 31: zero rows of T1)
-                t1r[e] = l1.T1[(size_t)(2 * i + (ln >> 5)) * C + slab * AGG_SL + (ln & 31)];
-            }
+        for (int e = 0; e < 2; ++e) {
+            const int en = threadIdx.x + e * AGG_THREADS, i = (en >> 8) * 4 + (en & 3), ln = (en >> 2) & 63;   // (letters 26 .. 31: zero rows of T1)
+            t1r[e] = l1.T1[(size_t)(2 * i + (ln >> 5)) * C + slab * AGG_SL + (ln & 31)];
         }
         request_sums(0);
 #pragma unroll
@@ -1375,7 +1368,7 @@ __global__ __launch_bounds__(AGG_THREADS, ((!L1 && ROWBLOCKS <= 2) || (L1 && ROW
 #pragma unroll
         for (int e = 0; e < NDL; ++e)
             if ((int)(threadIdx.x + e * AGG_THREADS) < ROWBLOCKS * AGG_CHR) dl[threadIdx.x + e * AGG_THREADS] = dreg[e];
-        if (T1_LDS) t1l[threadIdx.x] = t1r[0], t1l[threadIdx.x + AGG_THREADS] = t1r[1];
+        t1l[threadIdx.x] = t1r[0], t1l[threadIdx.x + AGG_THREADS] = t1r[1];
         __syncthreads();   // (the first chunk's tiles are made in front of the loop's first barrier)
     }
     f32x16 acc[ROWBLOCKS];
@@ -1410,14 +1403,7 @@ __global__ __launch_bounds__(AGG_THREADS, ((!L1 && ROWBLOCKS <= 2) || (L1 && ROW
                 if (!SV_AHEAD && j0 > 0) request_sums(j0);   // (four row blocks: no register to carry them across the matrix phase; chunk 0's were requested in the prologue)
 #pragma unroll
                 for (int i4 = 0; i4 < 4; ++i4) {
-                    v4f t;
-                    if (T1_LDS) {
-                        t = *reinterpret_cast<const v4f *>(t1l + i4 * 256 + lane * 4);
-                    } else {   // T1[2 i + half][slab column frow]: a wave's load = two 128-byte lines
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            t[c] = i4 * 4 + c < 13 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsT, (half * C + frow) * 4, (i4 * 4 + c) * 2 * (int)rowB, 0)) : 0.0f;
-                    }
+                    const v4f t = *reinterpret_cast<const v4f *>(t1l + i4 * 256 + lane * 4);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
 #ifdef AX_ABL_CHAIN   // (probe build only: 1 of the 13 matrix instructions)
@@ -1487,7 +1473,7 @@ __global__ __launch_bounds__(AGG_THREADS, ((!L1 && ROWBLOCKS <= 2) || (L1 && ROW
             // this lane's channel (frow), rows 8 g + 4 half .. + 3 of the wave's tile: half a 16-byte slot per term and g
             typedef short bf16x4 __attribute__((ext_vector_type(4)));
             int fr = frow;
-            if (ROWBLOCKS != 2) asm volatile("" : "+v"(fr));   // (four row blocks: the 12 store addresses below are recomputed per chunk instead of living in registers -- they were spilled)
+            if (ROWBLOCKS != 2) asm volatile("" : "+v"(fr));   // (one and four row blocks: the store addresses below are recomputed per chunk instead of living in registers -- with four they were spilled)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const v4f d = *reinterpret_cast<const v4f *>(dl + jt + 8 * g + 4 * half);
