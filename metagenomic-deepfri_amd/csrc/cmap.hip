@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256) void k_cmap_fill(const int32_t *__restrict__ L
 
 // ------------------------------------------------------------------------------------------------------------------
 // The same fill with EIGHT LANES PER ROW that all walk the row (round 5; the form above serves proteins whose staging would not fit the
-// LDS and the A/B knob MDFRI_CMAP_FILL=words): block = 32 rows = 4 waves of 8 rows x 8 lanes; lane k of a row owns the letters a with
+// LDS): block = 32 rows = 4 waves of 8 rows x 8 lanes; lane k of a row owns the letters a with
 // a mod 8 == k and every eighth CSR entry.  In the word-per-lane form the lanes that hold the words of one row take turns (the letter sums
 // are accumulated in ascending column order), one lane in eight works at a time and a wave runs sum over words of (the fullest word among
 // its 8 rows) serial steps (~45 at 6 A).  Here the eight lanes of a row run the SAME loop over the row's entries in order -- the order is
