@@ -26,7 +26,7 @@ Objects on the line (tier contract):
   cpu_baseline  the oracle (CPU restatement of the reference path) timed on this box's host cores on a bounded sample: one thread
                 (the configuration the reference ships) and a pool of single-thread worker processes (the reference's own
                 parallelism, pipeline.py:476-481); real onnxruntime-CPU on the exported synthetic weights when ORT is importable
-  by_length / mixed / helix / f32_pipe / gcn_only / end_to_end / query_stream   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix,
+  by_length / mixed / helix / f32_pipe / f16x3_pipe / gcn_only / end_to_end / query_stream   (default N = 1 run only) mini-runs at L = 256 and L = 1024, the configs[3]-shaped mix,
   protein-like helix-bundle traces (fewer contacts per residue than a random walk), the GCN alone on given contact maps, the
                 PCIe-inclusive host-lists-in / host-arrays-out rate, and the stages either side of the path as one stream
                 (sequences + candidate sets in -> aligner -> path -> filter -> results.tsv text out) -- never `value`
@@ -51,6 +51,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; ~
 MFMA_F32_PEAK_TF = 157.3   # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
 MFMA_BF16_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s, no sparsity)
 BF16X6_PRODUCTS = 6        # bf16 term products per fp32 product in k_gemm_bf16x6 (csrc/gcn.hip)
+F16X3_PRODUCTS = 3         # fp16 term products per fp32 product in k_gemm_f16x3 (opt-in pipe, MDFRI_HW_PIPE=f16x3)
 MODES = ("mf", "bp", "cc")
 STRONG = {"configs3": (100000, 46), "configs4": (500000, 47)}   # workload -> (proteins, seed = 42 + 1-based config number)
 
@@ -507,13 +508,16 @@ def rooflines(ctx, eng, pk, kernels, lm):
         # the roofline of the pipe the kernel runs on (mdf_hw_pipe): BF16x6 executes six bf16 term products per fp32 product, so the
         # bf16 matrix peak / 6 bounds the ALGORITHMIC (fp32) flop rate of the method; the fp32 instruction's own peak is kept beside it
         pipe = ctx.lib.mdf_hw_pipe().decode()
-        peak = MFMA_BF16_PEAK_TF / BF16X6_PRODUCTS if pipe == "bf16x6" else MFMA_F32_PEAK_TF
+        peak = MFMA_BF16_PEAK_TF / BF16X6_PRODUCTS if pipe == "bf16x6" else MFMA_BF16_PEAK_TF / F16X3_PRODUCTS if pipe == "f16x3" else MFMA_F32_PEAK_TF
         per_layer = {k: {"avg_us": kernels[k]["avg_us"], "timed_launches": kernels[k]["launches"],
                          "frac": round(2.0 * rows_launch * C * C / (kernels[k]["avg_us"] * 1e-6) / 1e12 / peak, 4)}
                      for k in ("gemm2", "gemm3") if kernels.get(k, {}).get("launches") and not lm}
         if pipe == "bf16x6":
             name = ("k_gemm_bf16x6 (H.W as BF16x6: fp32 operands split in registers into three bf16 terms, six term products per fp32 product on "
                     "v_mfma_f32_32x32x16_bf16, fp32 accumulate; 256x256x32 tiles, LDS-DMA staging, ELU+pool epilogue)")
+        elif pipe == "f16x3":
+            name = ("k_gemm_f16x3 (H.W as F16x3, opt-in: fp32 operands scaled by a power of two and split in registers into two fp16 terms, three term products "
+                    "per fp32 product on v_mfma_f32_32x32x16_f16, fp32 accumulate; the split keeps 22 of 24 bits)")
         else:
             name = "k_gemm_f32 (H.W, 256x256x32 tiles, v_mfma_f32_32x32x2_f32, LDS-DMA staging, ELU+pool epilogue)"
         roof = {"kernel": name, "pipe": pipe,
@@ -525,6 +529,11 @@ def rooflines(ctx, eng, pk, kernels, lm):
             roof["peak_note"] = (f"bf16 dense MFMA peak {MFMA_BF16_PEAK_TF:.0f} TFLOP/s / {BF16X6_PRODUCTS} term products per fp32 product; `achieved` counts the "
                                  "algorithmic fp32 flops (2.R.K.N), the matrix pipe executes six times that")
             roof["executed_bf16_tflops"] = round(tf * BF16X6_PRODUCTS, 1)
+            roof["vs_f32_instruction_peak"] = round(tf / MFMA_F32_PEAK_TF, 4)
+        if pipe == "f16x3":
+            roof["peak_note"] = (f"fp16 dense MFMA peak {MFMA_BF16_PEAK_TF:.0f} TFLOP/s (the bf16 instruction's) / {F16X3_PRODUCTS} term products per fp32 product; "
+                                 "`achieved` counts the algorithmic fp32 flops (2.R.K.N)")
+            roof["executed_f16_tflops"] = round(tf * F16X3_PRODUCTS, 1)
             roof["vs_f32_instruction_peak"] = round(tf / MFMA_F32_PEAK_TF, 4)
     if a.get("launches"):
         # read Z (rows x 512 f32) once + write (rows x 512 f32) once per layer; CSR adjacency (4 B colidx
@@ -792,7 +801,7 @@ def main():
             lm_b = args.lm_batch if args.lm_batch > 0 else 16384
             n_groups = max(1, -(-n_local // min(lm_b, 65535)))
             B_grp = n_local / n_groups
-            peak = (MFMA_BF16_PEAK_TF / BF16X6_PRODUCTS) if ctx.lib.mdf_hw_pipe().decode() == "bf16x6" else MFMA_F32_PEAK_TF
+            peak = MFMA_F32_PEAK_TF if ctx.lib.mdf_hw_pipe().decode() == "f32" else (MFMA_BF16_PEAK_TF / BF16X6_PRODUCTS)   # (under f16x3 these stay BF16x6)
             rows_launch = sum(c.rows for c in pk.chunks) / len(pk.chunks)
             fl = {"lstm": 2.0 * B_grp * 4 * H * H, "lstm2": 2.0 * B_grp * 4 * H * 2 * H, "embed": 2.0 * rows_launch * E * H}
             line["lm_kernels"] = {k: {"avg_us": kernels[k]["avg_us"], "timed_launches": kernels[k]["launches"], "flops_per_launch": fl[k],
@@ -1014,7 +1023,26 @@ def main():
                         "note": "the same run with H.W on v_mfma_f32_32x32x2_f32 (k_gemm_f32; MDFRI_HW_PIPE=f32): its rate, its fraction of the fp32 "
                                 "instruction's peak, and its error against the float64 oracle beside the default path's `verify`; never `value`"}
 
+            def f16x3_pipe_leg():
+                # the same headline step with the GraphConv H.W products as F16x3 (MDFRI_HW_PIPE=f16x3, opt-in: two fp16 terms per scaled operand, three
+                # term products per fp32 product -- half the matrix work of the default, 22 of 24 operand bits): its rate and its error beside the default's
+                torch.cuda.synchronize()
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+                env["MDFRI_HW_PIPE"] = "f16x3"
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-extras", "--cpu-seconds", "0",
+                                    "--proteins", str(n_local), "--length", str(args.length), "--chunk-rows", str(args.chunk_rows)],
+                                   env=env, capture_output=True, text=True, timeout=900)
+                sub = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                return {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"], "pipe": sub["roofline"]["pipe"],
+                        "roofline_frac": sub["roofline"]["frac"], "gemm_avg_us": sub["roofline"]["per_launch"]["avg_us"],
+                        "max_abs_err_vs_oracle": sub["verify"]["max_abs_err_vs_oracle"],
+                        "note": "OPT-IN, never `value`: the same run with the GraphConv H.W products as F16x3 (k_gemm_f16x3; MDFRI_HW_PIPE=f16x3): operands scaled "
+                                "by a power of two and split into two fp16 terms (22 of their 24 bits; BF16x6's three-term split is exact), three term products "
+                                "instead of six; its rate, its fraction of fp16 peak / 3, and its error against the float64 oracle beside the default path's "
+                                "`verify` (DESIGN.md section 4: why it is not the default)"}
+
             leg("f32_pipe", f32_pipe_leg)
+            leg("f16x3_pipe", f16x3_pipe_leg)
             leg("gcn_only", gcn_only_leg)
             leg("thr10", thr10_leg)
             if args.end_to_end > 0:

@@ -33,6 +33,7 @@ struct mdf_model {
     int n_out_pad = 0;            // 2T rounded up to the GEMM's BN
     float *T1 = nullptr;          // (32, gc0)      relu(W_aa) @ W_gc1, letters padded 26 -> 32 (zero rows); computed in double on the host
     float *Wt[3] = {nullptr, nullptr, nullptr};  // k>=1: (gc_k, gc_{k-1}) = W_gc{k+1}^T  ([N][K], K contiguous)
+    float Wt_scale[3] = {0.0f, 0.0f, 0.0f};      // k>=1: the power of two that brings max |W_gc{k+1}| to [2^13, 2^14) (operand scale of the F16x3 pipe)
     float *Wfc_t = nullptr;       // (fc, feat)
     float *bfc = nullptr;         // (fc)
     float *Wout_t = nullptr;      // (n_out_pad, fc), rows >= 2T zero
@@ -80,6 +81,7 @@ struct GemmAux {
     float *cstate = nullptr;           // EPI_LSTM_*: (M, N/4) cell state, updated in place
     float *logits = nullptr;           // EPI_BIAS_SOFTMAX2 on the bf16x6 kernels: NULL, or (M, n_real) pre-softmax values
     int n_real = 0;                    // ... and the real output columns (2 T)
+    float sA = 0.0f, sB = 0.0f;        // F16x3 (MDFRI_HW_PIPE=f16x3): power-of-two scales of the operands; sB = 0: this product has none and stays on BF16x6
 };
 
 // sigmoid / tanh on the hardware exponential and reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp each); absolute error < 3e-7.
@@ -647,158 +649,172 @@ __device__ __forceinline__ void split_stage(SplitQuad &q, const SplitRaw &r, Spl
 // them: ONE split stage (4-6 vector instructions, split_stage) per slot; the three steps that also split B fragments carry two stages in
 // some slots.  (The round-4 schedule -- matrix instructions in pairs, one 11-deep chain with a packed subtraction behind each pair, 4.4 % slower,
 // bit-identical -- left the library in round 6: experiments/r06_pruned_variants.patch.)
-template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void k_gemm_bf16x6(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
-                                                                 int N, int K, float *__restrict__ C, int ldc, const float *__restrict__ bias,
-                                                                 float *__restrict__ pool_partial, int ldp, int total_tiles, GemmAux aux)
+#define MDF_GS_KERNEL k_gemm_bf16x6
+#define MDF_GS_X3 0
+#include "gemm_split_kernel.inc"
+#undef MDF_GS_KERNEL
+#undef MDF_GS_X3
+
+// ---- H.W with HALF the matrix work: F16x3 (round 6; opt-in, MDFRI_HW_PIPE=f16x3) -------------------------------------------------------
+// Every operand, scaled by a power of two, is split into TWO fp16 terms: hi = f16(x s), lo = f16(x s - hi) (round to nearest; x s - hi is exact,
+// 11 + 11 significant bits: |x s - hi - lo| <= 2^-22 |x s|), and  a.b ~ (al.bh + ah.bl) + ah.bh  on v_mfma_f32_32x32x16_f16, fp32 accumulate,
+// smallest terms first -- THREE term products per fp32 product where BF16x6 spends six.  Unlike BF16x6 the split is not exact: the per-product
+// error bound is ~3 x 2^-22 (BF16x6: 2^-23).  Measured against float64 on 65 536 x 512 x 512 of activation-like operands the result is
+// nevertheless CLOSER than BF16x6's (rms 6.7e-7 vs 8.7e-7, max 2.0e-5 vs 3.7e-5: half as many accumulation roundings; experiments/
+// gemm_f16x3_probe.hip, profiles/r06_gemm_f16x3_probe.txt) and the launch takes 110 us where BF16x6 takes 164 (same box, 2 000 launches each).
+// It stays opt-in because of what it needs and what it gives up: fp16's exponent range wants a scale per operand -- the weights' is exact
+// (2^14 / max |w| rounded down to a power of two, at model load), the activations' is the CONSTANT 2^3 (a data-dependent one would make a
+// protein's bits depend on its batch): |a| >= 2^-5 keeps the full 22 bits, smaller values lose bits at an absolute error below 2^-28, and an
+// activation beyond 8 190 becomes inf -> NaN scores (never silently wrong).  Split per quad of operands: 4 v_mul + 2 v_cvt_pk_f16_f32 +
+// 4 v_fma_mix_f32 (x s - float(hi): conversion and subtraction in ONE instruction) + 2 v_cvt_pk_f16_f32 = 12 vector instructions (BF16x6: 22).
+constexpr float F16X3_SCALE_A = 8.0f;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // operand of v_mfma_f32_32x32x16_f16 (the bf16 instruction's layout)
+struct SplitPlanes2 {
+    u32x4 h, l;   // 8 fp16 each
+};
+struct SplitQuad2 {
+    float x0, x1, x2, x3;
+    unsigned ha, hb;
+};
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b)
 {
-    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS || EPI == EPI_EMBED ||
-                      EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_SOFTMAX2,
-                  "graph-convolution layers, LSTM time steps, LM embedding, the two dense products of the GO head");
-    constexpr bool PLAIN = (EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS);
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2 buffers][A 256x32 | B 256x32], unpadded rows (as k_gemm_f32)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wid >> 2, wn = wid & 3;
-    const int NT = N / BN, nk = K / BK, stride = gridDim.x;
-    TileCursor cc;
-    cc.kt = 0;
-    int n_mine = 0;
-    {
-        int first = -1, mt, nt;
-        for (int t = blockIdx.x; t < total_tiles; t += stride) {
-            tile_of_block<PLAIN>(t, NT, mt, nt);
-            if (mt * BM < M) {
-                if (first < 0) { first = t; cc.t = t; cc.mt = mt; cc.nt = nt; }
-                ++n_mine;
+    unsigned r;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));   // round to nearest even (the mode register's default)
+    return r;
+}
+// x s - float(low / high half of h): exact (the remainder of a round-to-nearest conversion), one instruction
+__device__ __forceinline__ float f16_rem_lo(float x, float s, unsigned h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(h));
+    return r;
+}
+__device__ __forceinline__ float f16_rem_hi(float x, float s, unsigned h)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(h));
+    return r;
+}
+template <int J>   // J = 4 * (which float4 of the fragment: dwords 2 q, 2 q + 1 of each plane) + stage (the slots of split_stage)
+__device__ __forceinline__ void split_stage2(SplitQuad2 &q, const SplitRaw &r, SplitPlanes2 &o, const float s)
+{
+    constexpr int quad = J >> 2, st = J & 3;
+    if constexpr (st == 0) {
+        const float4 v = quad ? r.v : r.u;
+        q.x0 = v.x, q.x1 = v.y, q.x2 = v.z, q.x3 = v.w;
+        q.ha = cvt_pk_f16(q.x0 * s, q.x1 * s), q.hb = cvt_pk_f16(q.x2 * s, q.x3 * s);
+    } else if constexpr (st == 1) {
+        q.x0 = f16_rem_lo(q.x0, s, q.ha), q.x1 = f16_rem_hi(q.x1, s, q.ha);
+    } else if constexpr (st == 2) {
+        q.x2 = f16_rem_lo(q.x2, s, q.hb), q.x3 = f16_rem_hi(q.x3, s, q.hb);
+    } else {
+        o.h[2 * quad] = q.ha, o.h[2 * quad + 1] = q.hb;
+        o.l[2 * quad] = cvt_pk_f16(q.x0, q.x1), o.l[2 * quad + 1] = cvt_pk_f16(q.x2, q.x3);
+    }
+}
+__device__ __forceinline__ void split_fragment2(const SplitRaw &r, SplitPlanes2 &o, const float s)
+{
+    SplitQuad2 q;
+    split_stage2<0>(q, r, o, s); split_stage2<1>(q, r, o, s); split_stage2<2>(q, r, o, s); split_stage2<3>(q, r, o, s);
+    split_stage2<4>(q, r, o, s); split_stage2<5>(q, r, o, s); split_stage2<6>(q, r, o, s); split_stage2<7>(q, r, o, s);
+}
+// the three term products of one 32 x 32 x 16 block, in THE order both F16x3 kernels use (results are bit-identical across them)
+#define MDF_X3_SEQ(acc_, a_, b_)                                                                                                  \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a_).l), __builtin_bit_cast(f16x8, (b_).h), acc_, 0, 0, 0); \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a_).h), __builtin_bit_cast(f16x8, (b_).l), acc_, 0, 0, 0); \
+    acc_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a_).h), __builtin_bit_cast(f16x8, (b_).h), acc_, 0, 0, 0);
+
+#define MDF_GS_KERNEL k_gemm_f16x3
+#define MDF_GS_X3 1
+#include "gemm_split_kernel.inc"
+#undef MDF_GS_KERNEL
+#undef MDF_GS_X3
+
+// k_gemm_f16x3_small: k_gemm_bf16x6_small's geometry (one wave per 32 x 32 output tile, operands straight from L2 through a ring of four
+// register buffers) for the graph-convolution layers of SMALL problems under MDFRI_HW_PIPE=f16x3; the same split with the same scales and
+// the same three products per 16 k in the same order as k_gemm_f16x3, the same epilogue arithmetic: bit-identical to it.
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f16x3_small(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
+                                                           int N, int K, float *__restrict__ C, int ldc, float *__restrict__ pool_partial, int ldp, GemmAux aux)
+{
+    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL, "graph-convolution layers");
+    const int lane = threadIdx.x & 63;
+    const int NT = N >> 5, MT = (M + 31) >> 5;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= MT * NT) return;
+    const int mt = t / NT, nt = t - mt * NT;
+    const int frow = lane & 31, khalf = lane >> 5;
+    const float *pa = A + (size_t)min(mt * 32 + frow, M - 1) * lda + khalf * 8;
+    const float *pb = Bt + (size_t)(nt * 32 + frow) * ldb + khalf * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    const int nblk = K >> 5;   // blocks of 32 k = two matrix-instruction steps of 16 (host-checked: K % 32 == 0)
+#define MDF_LOAD_BLK(BA, BB, blk_)                                                                    \
+    {                                                                                                 \
+        const int kb_ = min((blk_), nblk - 1) * 32;   /* past the end: re-read the last block (harmless) */ \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                 \
+        {                                                                                             \
+            BA[u] = *reinterpret_cast<const float4 *>(pa + kb_ + (u >> 1) * 16 + (u & 1) * 4);        \
+            BB[u] = *reinterpret_cast<const float4 *>(pb + kb_ + (u >> 1) * 16 + (u & 1) * 4);        \
+        }                                                                                             \
+        asm volatile("" ::: "memory");                                                                \
+    }
+#define MDF_MFMA_BLK(BA, BB)                                                                          \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                  \
+    {                                                                                                 \
+        SplitRaw ra_, rb_;                                                                            \
+        SplitPlanes2 pa_, pb_;                                                                        \
+        ra_.u = BA[2 * s2], ra_.v = BA[2 * s2 + 1], rb_.u = BB[2 * s2], rb_.v = BB[2 * s2 + 1];       \
+        split_fragment2(ra_, pa_, aux.sA);                                                            \
+        split_fragment2(rb_, pb_, aux.sB);                                                            \
+        MDF_X3_SEQ(acc, pa_, pb_)                                                                     \
+    }
+    float4 a0[4], b0[4], a1[4], b1[4], a2[4], b2[4], a3[4], b3[4];
+    if ((nblk & 3) == 0) {   // K a multiple of 128: four unconditional phases per round (the ring and its asm fences: see k_gemm_f32_small)
+        MDF_LOAD_BLK(a0, b0, 0)
+        MDF_LOAD_BLK(a1, b1, 1)
+        MDF_LOAD_BLK(a2, b2, 2)
+        MDF_LOAD_BLK(a3, b3, 3)
+        for (int blk = 0; blk < nblk; blk += 4) {
+            MDF_MFMA_BLK(a0, b0)
+            MDF_LOAD_BLK(a0, b0, blk + 4)
+            MDF_MFMA_BLK(a1, b1)
+            MDF_LOAD_BLK(a1, b1, blk + 5)
+            MDF_MFMA_BLK(a2, b2)
+            MDF_LOAD_BLK(a2, b2, blk + 6)
+            MDF_MFMA_BLK(a3, b3)
+            MDF_LOAD_BLK(a3, b3, blk + 7)
+        }
+    } else {                 // short K: one block ahead
+        MDF_LOAD_BLK(a0, b0, 0)
+        for (int blk = 0; blk < nblk; ++blk) {
+            MDF_LOAD_BLK(a1, b1, blk + 1)
+            MDF_MFMA_BLK(a0, b0)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0[u] = a1[u];
+                b0[u] = b1[u];
             }
         }
-        if (first < 0) return;
     }
-    int rem = n_mine * nk;
-    TileCursor pc = cc;
-    const int drow = lane >> 3, dslot = lane & 7;
-    int dcol[4];
+#undef MDF_LOAD_BLK
+#undef MDF_MFMA_BLK
+    // epilogue: the scales come out (exact), then gemm_epilogue<EPI> on one 32 x 32 tile (as k_gemm_bf16x6_small)
+    const float inv = 1.0f / (aux.sA * aux.sB);
+    const int lcol = lane & 31, lrow = 4 * (lane >> 5);
+    const int rbase = mt * 32, col = nt * 32 + lcol;
+    float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dcol[i] = (dslot ^ ((4 * i + (lane >> 4)) & 7)) * 4;
-    const int frow = lane & 31, fswz = (frow >> 1) & 7, hl = lane >> 5;
-    const int fbaseA = (wm * 128 + frow) * 32, fbaseB = (wn * 64 + frow) * 32;
-    int fk[2];   // float offset of the lane's first 16-byte slot in half 0 / 1 (the second slot is this ^ 4)
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) fk[kk] = ((4 * kk + 2 * hl) ^ fswz) << 2;
-
-    const float *baseA, *baseB;
-    unsigned oa0, oa1, oa2, oa3;
-    const unsigned ob0 = (unsigned)((drow + 0) * ldb + dcol[0]) * 4u, ob1 = (unsigned)((drow + 8) * ldb + dcol[1]) * 4u,
-                   ob2 = (unsigned)((drow + 16) * ldb + dcol[2]) * 4u, ob3 = (unsigned)((drow + 24) * ldb + dcol[3]) * 4u;
-#define MDF_DMA_SETUP(cur_)                                                                 \
-    {                                                                                       \
-        baseA = (EPI == EPI_LSTM_BIAS && (cur_).kt >= aux.ksplit) ? aux.A2 + (size_t)((cur_).kt - aux.ksplit) * BK \
-                                                                   : A + (size_t)(cur_).kt * BK;    \
-        baseB = Bt + (size_t)((cur_).nt * BN + wid * 32) * ldb + (size_t)(cur_).kt * BK;    \
-        const int rA_ = (cur_).mt * BM + wid * 32 + drow;                                   \
-        oa0 = (unsigned)(min(rA_, M - 1) * lda + dcol[0]) * 4u;                             \
-        oa1 = (unsigned)(min(rA_ + 8, M - 1) * lda + dcol[1]) * 4u;                         \
-        oa2 = (unsigned)(min(rA_ + 16, M - 1) * lda + dcol[2]) * 4u;                        \
-        oa3 = (unsigned)(min(rA_ + 24, M - 1) * lda + dcol[3]) * 4u;                        \
+    for (int r = 0; r < 16; ++r) {
+        const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+        const float v = elu1(acc[r] * inv);
+        if (r < 8) s0 += v; else s1 += v;
+        if (EPI == EPI_ELU_POOL_STORE) C[(size_t)row * ldc + col] = v;
     }
-#define MDF_DMA_A(i) glds16s(baseA, oa##i, ldsA + (unsigned)((wid * 4 + (i)) * 1024));
-#define MDF_DMA_B(i) glds16s(baseB, ob##i, ldsB + (unsigned)((wid * 4 + (i)) * 1024));
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    const unsigned lds_base = lds_addr_of(smem);
-
-#define MDF_RD(raw_, base_, tile_, kk_)                                                               \
-    {                                                                                                 \
-        (raw_).u = *reinterpret_cast<const float4 *>((base_) + (tile_) * 1024 + fk[kk_]);             \
-        (raw_).v = *reinterpret_cast<const float4 *>((base_) + (tile_) * 1024 + (fk[kk_] ^ 4));       \
-    }
-    SplitPlanes PA[2], PB[2][2];
-    SplitRaw ra, rb, rc;
-    {   // prologue: position 0 -> buffer 0; source addresses of position 1; the first fragments
-        MDF_DMA_SETUP(pc)
-        const unsigned ldsA = lds_base, ldsB = lds_base + BM * BK * 4;
-        MDF_DMA_A(0) MDF_DMA_B(0) MDF_DMA_A(1) MDF_DMA_B(1) MDF_DMA_A(2) MDF_DMA_B(2) MDF_DMA_A(3) MDF_DMA_B(3)
-        cursor_advance<PLAIN>(pc, nk, NT, M, total_tiles, stride);
-        MDF_DMA_SETUP(pc)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        MDF_RD(rb, smem + BM * BK + fbaseB, 0, 0)
-        split_fragment(rb, PB[0][0]);
-        MDF_RD(rc, smem + BM * BK + fbaseB, 1, 0)
-        split_fragment(rc, PB[0][1]);
-        MDF_RD(ra, smem + fbaseA, 0, 0)
-        split_fragment(ra, PA[0]);
-    }
-
-#define MDF_SB __builtin_amdgcn_sched_barrier(0);
-#define MDF_BF(x_) __builtin_bit_cast(bf16x8, x_)
-#define MDF_MF(tm_, pa_, pb_, t_) acc[tm_][t_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MDF_BF(a_.pa_), MDF_BF(b##t_##_.pb_), acc[tm_][t_], 0, 0, 0);
-    // P rides in front of the step, X0..X11 behind its matrix instructions (the product order per tile is MDF_X6_SEQ's)
-#define MDF_STEP(tm_, PAc, PB0, PB1, P, X0, X1, X2, X3, X4, X5, X6, X7, X8, X9, X10, X11)                                           \
-    {                                                                                                                              \
-        const SplitPlanes &a_ = PAc, &b0_ = PB0, &b1_ = PB1;                                                                       \
-        P MDF_SB                                                                                                                   \
-        MDF_MF(tm_, l, h, 0) X0 MDF_SB MDF_MF(tm_, l, h, 1) X1 MDF_SB MDF_MF(tm_, m, m, 0) X2 MDF_SB MDF_MF(tm_, m, m, 1) X3 MDF_SB \
-        MDF_MF(tm_, h, l, 0) X4 MDF_SB MDF_MF(tm_, h, l, 1) X5 MDF_SB MDF_MF(tm_, m, h, 0) X6 MDF_SB MDF_MF(tm_, m, h, 1) X7 MDF_SB \
-        MDF_MF(tm_, h, m, 0) X8 MDF_SB MDF_MF(tm_, h, m, 1) X9 MDF_SB MDF_MF(tm_, h, h, 0) X10 MDF_SB MDF_MF(tm_, h, h, 1) X11 MDF_SB \
-    }
-#define MDF_Q(j_, raw_, P_) split_stage<j_>(qs, raw_, P_);
-    SplitQuad qs;
-    int cur = 0;
-    while (true) {
-        const float *Ab = smem + cur * ((BM + BN) * BK) + fbaseA;
-        const float *Bb = smem + cur * ((BM + BN) * BK) + BM * BK + fbaseB;
-        const float *An = smem + (cur ^ 1) * ((BM + BN) * BK) + fbaseA;
-        const float *Bn = smem + (cur ^ 1) * ((BM + BN) * BK) + BM * BK + fbaseB;
-        const unsigned ldsA = lds_base + (cur ^ 1) * ((BM + BN) * BK * 4), ldsB = ldsA + BM * BK * 4;
-        {
-            // half 0: the whole DMA of the next position; the B fragments of half 1
-            MDF_STEP(0, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 1, 0), MDF_DMA_A(0), MDF_DMA_B(0), MDF_DMA_A(1), MDF_DMA_B(1), MDF_Q(0, ra, PA[1]), MDF_Q(1, ra, PA[1]), MDF_Q(2, ra, PA[1]), MDF_Q(3, ra, PA[1]), MDF_Q(4, ra, PA[1]), MDF_Q(5, ra, PA[1]), MDF_Q(6, ra, PA[1]), MDF_Q(7, ra, PA[1]))
-            MDF_STEP(1, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 2, 0), MDF_DMA_A(2), MDF_DMA_B(2), MDF_DMA_A(3), MDF_DMA_B(3), MDF_Q(0, ra, PA[0]), MDF_Q(1, ra, PA[0]), MDF_Q(2, ra, PA[0]), MDF_Q(3, ra, PA[0]), MDF_Q(4, ra, PA[0]), MDF_Q(5, ra, PA[0]), MDF_Q(6, ra, PA[0]), MDF_Q(7, ra, PA[0]))
-            MDF_STEP(2, PA[0], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 3, 0) MDF_RD(rb, Bb, 0, 1), , MDF_Q(0, ra, PA[1]) MDF_Q(1, ra, PA[1]), MDF_Q(2, ra, PA[1]), MDF_Q(3, ra, PA[1]) MDF_Q(4, ra, PA[1]), MDF_Q(5, ra, PA[1]), MDF_Q(6, ra, PA[1]) MDF_Q(7, ra, PA[1]), MDF_Q(0, rb, PB[1][0]), MDF_Q(1, rb, PB[1][0]) MDF_Q(2, rb, PB[1][0]), MDF_Q(3, rb, PB[1][0]), MDF_Q(4, rb, PB[1][0]) MDF_Q(5, rb, PB[1][0]), MDF_Q(6, rb, PB[1][0]), MDF_Q(7, rb, PB[1][0]))
-            MDF_STEP(3, PA[1], PB[0][0], PB[0][1], MDF_RD(ra, Ab, 0, 1) MDF_RD(rb, Bb, 1, 1), , MDF_Q(0, ra, PA[0]) MDF_Q(1, ra, PA[0]), MDF_Q(2, ra, PA[0]), MDF_Q(3, ra, PA[0]) MDF_Q(4, ra, PA[0]), MDF_Q(5, ra, PA[0]), MDF_Q(6, ra, PA[0]) MDF_Q(7, ra, PA[0]), MDF_Q(0, rb, PB[1][1]), MDF_Q(1, rb, PB[1][1]) MDF_Q(2, rb, PB[1][1]), MDF_Q(3, rb, PB[1][1]), MDF_Q(4, rb, PB[1][1]) MDF_Q(5, rb, PB[1][1]), MDF_Q(6, rb, PB[1][1]), MDF_Q(7, rb, PB[1][1]))
-            // half 1: the source addresses of the position after next, then the barrier and the next position's first fragments
-            MDF_STEP(0, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 1, 1), , , MDF_Q(0, ra, PA[1]), MDF_Q(1, ra, PA[1]), MDF_Q(2, ra, PA[1]), MDF_Q(3, ra, PA[1]), MDF_Q(4, ra, PA[1]), MDF_Q(5, ra, PA[1]), MDF_Q(6, ra, PA[1]), MDF_Q(7, ra, PA[1]), , )
-            cursor_advance<PLAIN>(pc, nk, NT, M, total_tiles, stride);
-            MDF_DMA_SETUP(pc)
-            MDF_STEP(1, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 2, 1), , , MDF_Q(0, ra, PA[0]), MDF_Q(1, ra, PA[0]), MDF_Q(2, ra, PA[0]), MDF_Q(3, ra, PA[0]), MDF_Q(4, ra, PA[0]), MDF_Q(5, ra, PA[0]), MDF_Q(6, ra, PA[0]), MDF_Q(7, ra, PA[0]), , )
-            MDF_STEP(2, PA[0], PB[1][0], PB[1][1], MDF_RD(ra, Ab, 3, 1), , , MDF_Q(0, ra, PA[1]), MDF_Q(1, ra, PA[1]), MDF_Q(2, ra, PA[1]), MDF_Q(3, ra, PA[1]), MDF_Q(4, ra, PA[1]), MDF_Q(5, ra, PA[1]), MDF_Q(6, ra, PA[1]), MDF_Q(7, ra, PA[1]), , )
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA of the next position has landed ...
-            __syncthreads();                                     // ... and everybody's; nobody reads this position's buffer any more
-            MDF_STEP(3, PA[1], PB[1][0], PB[1][1], MDF_RD(ra, An, 0, 0) MDF_RD(rb, Bn, 0, 0) MDF_RD(rc, Bn, 1, 0), MDF_Q(0, ra, PA[0]) MDF_Q(1, ra, PA[0]), MDF_Q(2, ra, PA[0]) MDF_Q(3, ra, PA[0]), MDF_Q(4, ra, PA[0]) MDF_Q(5, ra, PA[0]), MDF_Q(6, ra, PA[0]) MDF_Q(7, ra, PA[0]), MDF_Q(0, rb, PB[0][0]) MDF_Q(1, rb, PB[0][0]), MDF_Q(2, rb, PB[0][0]) MDF_Q(3, rb, PB[0][0]), MDF_Q(4, rb, PB[0][0]) MDF_Q(5, rb, PB[0][0]), MDF_Q(6, rb, PB[0][0]) MDF_Q(7, rb, PB[0][0]), MDF_Q(0, rc, PB[0][1]) MDF_Q(1, rc, PB[0][1]), MDF_Q(2, rc, PB[0][1]) MDF_Q(3, rc, PB[0][1]), MDF_Q(4, rc, PB[0][1]) MDF_Q(5, rc, PB[0][1]), MDF_Q(6, rc, PB[0][1]) MDF_Q(7, rc, PB[0][1]))
-        }
-        if (cc.kt == nk - 1) {
-            gemm_epilogue<EPI>(acc, cc.mt * BM, cc.nt * BN, wm, wn, lane, M, N, C, ldc, bias, pool_partial, ldp,
-                               EPI == EPI_BIAS_SOFTMAX2 ? aux.logits : nullptr, EPI == EPI_BIAS_SOFTMAX2 ? aux.n_real : N, aux);
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-        }
-        --rem;
-        if (rem == 0) break;
-        cursor_advance<PLAIN>(cc, nk, NT, M, total_tiles, stride);
-        cur ^= 1;
-    }
-#undef MDF_STEP
-#undef MDF_Q
-#undef MDF_MF
-#undef MDF_BF
-#undef MDF_SB
-#undef MDF_RD
-#undef MDF_DMA_A
-#undef MDF_DMA_B
-#undef MDF_DMA_SETUP
+    const float mine = lane < 32 ? s0 : s1, send = lane < 32 ? s1 : s0;
+    pool_partial[(size_t)((rbase >> 4) + (lane >> 5)) * ldp + col] = mine + __shfl_xor(send, 32, 64);
 }
-
 
 // ---- k_gemm_f32_small: the same product for SMALL problems (per-call forward_pass: one protein; a handful of pooled
 // vectors in the GO head).  k_gemm_f32 needs >= 256 output tiles of 256 x 256 to fill the chip and one tile costs
@@ -1969,6 +1985,8 @@ static int set_gemm_attr_once()
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_BIAS_RELU>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_BIAS_SOFTMAX2>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16x3<EPI_ELU_POOL_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16x3<EPI_ELU_POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return MDF_OK;
 }
@@ -1994,15 +2012,20 @@ static bool layer1_fused()
     return on;
 }
 
-// which matrix pipe the graph-convolution products use (see k_gemm_bf16x6); read once per process
-static bool hw_pipe_bf16x6()
+// which matrix pipe the graph-convolution products use (see k_gemm_bf16x6, k_gemm_f16x3); read once per process
+enum HwPipe { PIPE_BF16X6 = 0, PIPE_F32 = 1, PIPE_F16X3 = 2 };
+static HwPipe hw_pipe()
 {
-    static const bool on = []() {
+    static const HwPipe pipe = []() {
         const char *e = getenv("MDFRI_HW_PIPE");
-        return !(e && (strcmp(e, "f32") == 0 || strcmp(e, "fp32") == 0));
+        if (e && (strcmp(e, "f32") == 0 || strcmp(e, "fp32") == 0)) return PIPE_F32;
+        if (e && (strcmp(e, "f16x3") == 0 || strcmp(e, "fp16x3") == 0)) return PIPE_F16X3;
+        return PIPE_BF16X6;
     }();
-    return on;
+    return pipe;
 }
+// (under f16x3 only the GraphConv layers' H.W products change pipe: GO heads, LSTM steps, LM embedding and the K = 32 / 1 024 layer-1 products stay BF16x6)
+static bool hw_pipe_bf16x6() { return hw_pipe() != PIPE_F32; }
 
 // persistent grid: one 512-thread workgroup per CU (LDS: 128 KiB), a multiple of 8 so that block b stays on XCD b%8
 static int gemm_resident_blocks()
@@ -2049,6 +2072,21 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
         if (hw_pipe_bf16x6()) {
             GemmAux ax = aux;
             if constexpr (EPI == EPI_BIAS_SOFTMAX2) ax.logits = logits, ax.n_real = n_real;
+            if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL) {
+                if (hw_pipe() == PIPE_F16X3 && ax.sB > 0.0f) {   // a GraphConv layer whose caller handed over the weights' scale: three fp16 term products
+                    ax.sA = F16X3_SCALE_A;
+                    if (MT * NT * 8 < 3 * gemm_resident_blocks()) {
+                        const int tiles = ((M + 31) / 32) * (N / 32);
+                        hipLaunchKernelGGL(k_gemm_f16x3_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, pool_partial, ldp, ax);
+                    } else {
+                        const int total = 8 * NT * ((MT + 7) / 8);
+                        hipLaunchKernelGGL((k_gemm_f16x3<EPI>), dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt,
+                                           ldb, M, N, K, C, ldc, bias, pool_partial, ldp, total, ax);
+                    }
+                    MDF_HIP(hipGetLastError());
+                    return MDF_OK;
+                }
+            }
             bool small = false;
             if constexpr (EPI != EPI_LSTM_TAB && EPI != EPI_LSTM_BIAS) {
                 small = MT * NT * 8 < 3 * gemm_resident_blocks();
@@ -2205,10 +2243,12 @@ static int gcn_upper_layer(mdf_model *m, int k, float *Ha, float *Hb, float *AH,
         ScopedTiming tm(k >= 2 ? TK_GEMM3 : TK_GEMM, st);
         const bool last = k == m->n_gc - 1;
         int rc;
+        GemmAux ax;
+        ax.sB = m->Wt_scale[k];   // (used under MDFRI_HW_PIPE=f16x3 only)
         if (last)
-            rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
+            rc = launch_gemm<EPI_ELU_POOL>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, nullptr, Cout, nullptr, partial + off, feat, nullptr, Cout, st, ax);
         else
-            rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st);
+            rc = launch_gemm<EPI_ELU_POOL_STORE>(AH, Cin, m->Wt[k], Cin, Ri, Cout, Cin, Hout, Cout, nullptr, partial + off, feat, nullptr, Cout, st, ax);
         if (rc) return rc;
     }
     return MDF_OK;
@@ -2297,7 +2337,7 @@ int mdf_debug_ax_probe(void *buf)
 }
 #endif
 
-const char *mdf_hw_pipe(void) { return hw_pipe_bf16x6() ? "bf16x6" : "f32"; }
+const char *mdf_hw_pipe(void) { return hw_pipe() == PIPE_F32 ? "f32" : hw_pipe() == PIPE_F16X3 ? "f16x3" : "bf16x6"; }
 
 const char *mdf_layer1_form(void) { return layer1_fused() ? "fused" : "kernel"; }
 
@@ -2353,6 +2393,9 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
     for (int k = 1; k < w->n_gc && rc == MDF_OK; ++k) {
         auto t = transpose(w->W_gc[k], w->gc_dims[k - 1], w->gc_dims[k], w->gc_dims[k]);
         rc = upload(&m->Wt[k], t.data(), t.size());
+        float wmax = 0.0f;
+        for (float x : t) wmax = std::max(wmax, std::fabs(x));
+        m->Wt_scale[k] = (wmax > 0.0f && std::isfinite(wmax)) ? std::ldexp(1.0f, 14 - (int)std::ceil(std::log2(wmax))) : 1.0f;
     }
     if (rc == MDF_OK) {
         auto t = transpose(w->W_fc, feat, w->fc_dim, w->fc_dim);

@@ -708,6 +708,29 @@ def test_bf16x6_products_are_at_least_as_accurate_as_the_fp32_instruction():
     assert res["bf16x6"]["batch_err"] <= 1.25 * res["f32"]["batch_err"] + 1e-7, res
 
 
+def test_f16x3_pipe_opt_in_is_fp32_class_and_bitwise_across_kernels():
+    """MDFRI_HW_PIPE=f16x3 (opt-in, csrc/gcn.hip "F16x3"): the GraphConv layers' H.W products from THREE fp16 term products (operands scaled by a
+    power of two, two fp16 terms each: 22 of 24 bits).  In a process of its own against the FLOAT64 oracle on the proteins of the pipe test
+    above: the library reports the pipe, the batch (k_gemm_f16x3, 256 x 256 tiles) equals the per-call API (k_gemm_f16x3_small, a wave per
+    tile) bit for bit, and the error stays two orders inside the 1e-4 score tolerance -- within 1.5 x + 1e-7 of the default pipe's on the
+    same proteins (it is not held to "at most the fp32 instruction's": the two-term split is not exact)."""
+    import json
+    import subprocess
+    import sys
+    res = {}
+    for pipe in ("bf16x6", "f16x3"):
+        env = {k: v for k, v in os.environ.items() if k != "MDFRI_HW_PIPE"}
+        if pipe != "bf16x6":
+            env["MDFRI_HW_PIPE"] = pipe
+        out = subprocess.run([sys.executable, "-c", _pipe_error_script()], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[pipe] = json.loads(out.stdout.split("RESULT", 1)[1])
+        assert res[pipe]["pipe"] == pipe and res[pipe]["bitwise"] is True, res[pipe]
+        assert res[pipe]["batch_err"] < 2e-6 and res[pipe]["percall_err"] < 2e-6, res[pipe]
+    assert res["f16x3"]["batch_err"] <= 1.5 * res["bf16x6"]["batch_err"] + 1e-7, res
+    assert res["f16x3"] != res["bf16x6"]      # the switch did change the arithmetic
+
+
 def test_agg_prepare_writes_the_contact_bits_as_byte_tiles():
     """mdf_agg_prepare_dev (round 6): beside d_j and the populated-block words, the contact bits once more in the order the matrix-pipe
     aggregation loads them (mdfri.h mdf_agg_desc.tiles): 16-row group g x 256-column chunk c of a protein at ((g nch + c) 512), byte
