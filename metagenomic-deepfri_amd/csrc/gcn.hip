@@ -91,6 +91,9 @@ __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn
 // the absolute error is < 2e-7, far inside the 1e-4 score budget; libm expf costs ~40 VALU instructions per element and
 // made the GEMM epilogue (64 elements per lane) ~12 % of the tile time.
 __device__ __forceinline__ float elu1(float x) { return x > 0.0f ? x : __expf(x) - 1.0f; }
+// ReLU that hands a NaN on (v_max_f32 would return the other operand, 0): a non-finite feature must surface as a NaN score, never as a
+// plausible one -- every ReLU epilogue of the GO head uses this one form (the tile, wave-per-tile and per-lane kernels stay bit-identical)
+__device__ __forceinline__ float relu_keep_nan(float z) { return z < 0.0f ? 0.0f : z; }
 
 // XCD-aware tile order: block b runs on XCD b%8 (observed placement; used for L2 affinity only).  The NT column
 // tiles of one 128-row tile are issued back to back on the same XCD so that the A rows are fetched into that
@@ -252,7 +255,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[4][2], int m0, int n
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
-                    if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[tm][tn][r] + bv, 0.0f);
+                    if (row < M) C[(size_t)row * ldc + col] = relu_keep_nan(acc[tm][tn][r] + bv);
                 }
             } else {  // EPI_BIAS_SOFTMAX2: columns (2t, 2t+1) are the two channels of term t; keep channel 0
                 const float bv = bias[col];
@@ -808,7 +811,8 @@ __global__ __launch_bounds__(256) void k_gemm_f16x3_small(const float *__restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
-        const float v = elu1(acc[r] * inv);
+        const float d = acc[r] * inv;
+        const float v = elu1(__builtin_fabsf(d) < __builtin_inff() ? d : __builtin_nanf(""));   // (an operand beyond the fp16 range: NaN, as in k_gemm_f16x3)
         if (r < 8) s0 += v; else s1 += v;
         if (EPI == EPI_ELU_POOL_STORE) C[(size_t)row * ldc + col] = v;
     }
@@ -925,7 +929,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32_small(const float *__restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
-            if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[r] + bv, 0.0f);
+            if (row < M) C[(size_t)row * ldc + col] = relu_keep_nan(acc[r] + bv);
         }
     } else {   // EPI_BIAS_SOFTMAX2
         const float bv = bias[col];
@@ -1039,7 +1043,7 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x6_small(const float *__restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
-            if (row < M) C[(size_t)row * ldc + col] = fmaxf(acc[r] + bv, 0.0f);
+            if (row < M) C[(size_t)row * ldc + col] = relu_keep_nan(acc[r] + bv);
         }
         return;
     }
@@ -1112,7 +1116,7 @@ __global__ __launch_bounds__(64) void k_gemv_f32(const float *__restrict__ A, in
     }
     const float bv = bias[n];
     if (EPI == EPI_BIAS_RELU) {
-        C[(size_t)m * ldc + n] = fmaxf(acc + bv, 0.0f);
+        C[(size_t)m * ldc + n] = relu_keep_nan(acc + bv);
     } else {   // EPI_BIAS_SOFTMAX2: columns (2t, 2t+1) are the two channels of term t; keep channel 0
         const float z = acc + bv;
         const float zo = __shfl_xor(z, 1, 64);

@@ -731,6 +731,42 @@ def test_f16x3_pipe_opt_in_is_fp32_class_and_bitwise_across_kernels():
     assert res["f16x3"] != res["bf16x6"]      # the switch did change the arithmetic
 
 
+def test_f16x3_pipe_turns_an_activation_beyond_its_range_into_nan_scores_not_into_wrong_ones():
+    """The documented limit of the opt-in pipe (include/mdfri.h, mdf_hw_pipe): the activations' scale is the constant 2^3, so an aggregated
+    activation of magnitude >= 8 190 becomes inf in the split and the protein's scores NaN -- loud.  A model whose first GraphConv weights are
+    blown up by 1e6 produces such activations: under MDFRI_HW_PIPE=f16x3 every score of the protein is NaN, on the default pipe the same call
+    returns finite scores (bf16 has fp32's exponent range).  Each pipe in a process of its own."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = (
+        "import sys, os, json; ROOT = %r\n"
+        "for d in ('metagenomic-deepfri_amd', 'oracle', ''): sys.path.insert(0, os.path.join(ROOT, d))\n"
+        "import numpy as np\n"
+        "import cmap_oracle as orc\n"
+        "from mdfri_testkit import synthetic\n"
+        "from mDeepFRI import _hip\n"
+        "from mDeepFRI.predict import Predictor\n"
+        "w = synthetic.glorot_gcn_weights(seed=3, n_terms=64)\n"
+        "w['W_gc1'] = (w['W_gc1'] * np.float32(1e6)).astype(np.float32)\n"
+        "p = synthetic.synthetic_proteins(seed=5, count=1, length=300)[0]\n"
+        "cm = orc.build_align_contact_map(p['coords'], p['q_aln'], p['t_aln'], 6.0, 2)\n"
+        "y = Predictor('big', weights=w).forward_pass(p['seq'], cm)\n"
+        "print('RESULT', json.dumps({'pipe': _hip.lib().mdf_hw_pipe().decode(), 'nan': int(np.isnan(y).sum()), 'finite': int(np.isfinite(y).sum()), 'n': int(y.size)}))\n" % ROOT)
+    res = {}
+    for pipe in ("bf16x6", "f16x3"):
+        env = {k: v for k, v in os.environ.items() if k != "MDFRI_HW_PIPE"}
+        if pipe != "bf16x6":
+            env["MDFRI_HW_PIPE"] = pipe
+        out = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res[pipe] = json.loads(out.stdout.split("RESULT", 1)[1])
+        assert res[pipe]["pipe"] == pipe, res
+    assert res["bf16x6"]["finite"] == res["bf16x6"]["n"], res
+    assert res["f16x3"]["nan"] == res["f16x3"]["n"], res
+
+
 def test_agg_prepare_writes_the_contact_bits_as_byte_tiles():
     """mdf_agg_prepare_dev (round 6): beside d_j and the populated-block words, the contact bits once more in the order the matrix-pipe
     aggregation loads them (mdfri.h mdf_agg_desc.tiles): 16-row group g x 256-column chunk c of a protein at ((g nch + c) 512), byte
