@@ -801,7 +801,8 @@ def main():
             lm_b = args.lm_batch if args.lm_batch > 0 else 16384
             n_groups = max(1, -(-n_local // min(lm_b, 65535)))
             B_grp = n_local / n_groups
-            peak = MFMA_F32_PEAK_TF if ctx.lib.mdf_hw_pipe().decode() == "f32" else (MFMA_BF16_PEAK_TF / BF16X6_PRODUCTS)   # (under f16x3 these stay BF16x6)
+            lm_pipe = ctx.lib.mdf_hw_pipe().decode()
+            peak = MFMA_F32_PEAK_TF if lm_pipe == "f32" else MFMA_BF16_PEAK_TF / (F16X3_PRODUCTS if lm_pipe == "f16x3" else BF16X6_PRODUCTS)
             rows_launch = sum(c.rows for c in pk.chunks) / len(pk.chunks)
             fl = {"lstm": 2.0 * B_grp * 4 * H * H, "lstm2": 2.0 * B_grp * 4 * H * 2 * H, "embed": 2.0 * rows_launch * E * H}
             line["lm_kernels"] = {k: {"avg_us": kernels[k]["avg_us"], "timed_launches": kernels[k]["launches"], "flops_per_launch": fl[k],

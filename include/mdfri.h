@@ -22,8 +22,9 @@
  * other 23 developer knobs of rounds 1-5 with the kernel variants behind them -- experiments/r06_pruned_variants.patch)
  *   MDFRI_HW_PIPE=f32            the GraphConv / LSTM products on v_mfma_f32_32x32x2_f32 instead of BF16x6 (mdf_hw_pipe() reports the pipe;
  *                                another arithmetic: tests/test_gpu_gcn.py::test_bf16x6_products_are_at_least_as_accurate_as_the_fp32_instruction)
- *   MDFRI_HW_PIPE=f16x3          (opt-in, round 6) the GraphConv layers' H.W products from THREE fp16 term products instead of six bf16 ones: half
- *                                the matrix work, operands held to 22 of their 24 bits, activations beyond 8 190 become NaN scores (mdf_hw_pipe();
+ *   MDFRI_HW_PIPE=f16x3          (opt-in, round 6) the GraphConv layers' H.W products, the LSTM time steps and the LM embedding from THREE fp16 term
+ *                                products instead of six bf16 ones: half the matrix work, operands held to 22 of their 24 bits, GraphConv
+ *                                activations beyond 8 190 become NaN scores (mdf_hw_pipe(); tests/test_gpu_lm.py passes under it;
  *                                another arithmetic: tests/test_gpu_gcn.py::test_f16x3_pipe_opt_in_is_fp32_class_and_bitwise_across_kernels)
  *   MDFRI_L1_FUSE=0              layer 1 by k_layer1 for every row instead of inside the layer-2 aggregation launch (mdf_layer1_form();
  *                                bit-identical: tests/test_gpu_engine.py::test_layer1_made_inside_the_aggregation_kernel_is_bit_identical)
@@ -246,10 +247,10 @@ int mdf_group_rows(void);   /* = MDF_GROUP_ROWS, for callers that do not compile
 /* Which matrix pipe the graph-convolution products H.W run on in this process: "bf16x6" (default: every fp32 operand split into three
  * bf16 terms, six term products per fp32 product accumulated in fp32 -- k_gemm_bf16x6, csrc/gcn.hip; error against float64 below the
  * fp32 instruction's), "f32" (v_mfma_f32_32x32x2_f32; environment MDFRI_HW_PIPE=f32) or "f16x3" (opt-in, MDFRI_HW_PIPE=f16x3: the GraphConv
- * layers' products -- and only those -- from three fp16 term products: each operand times a power of two, split into two fp16 terms that hold
+ * layers' products, the LSTM time steps and the LM embedding -- not the GO heads -- from three fp16 term products: each operand times a power of two, split into two fp16 terms that hold
  * 22 of its 24 bits; the weights' scale is taken from their maximum at model load, the activations' is the constant 2^3, so an activation of
- * magnitude >= 8 190 turns into inf and the protein's scores into NaN, and one below 2^-5 is held to an absolute 2^-28 instead of 22 bits;
- * k_gemm_f16x3, csrc/gcn.hip).  fp32 in, fp32 out in every case.
+ * magnitude >= 8 190 turns into inf and the protein's scores into NaN, and one below 2^-5 is held to an absolute 2^-28 instead of 22 bits
+ * (the LSTM's hidden state lies in (-1, 1): scale 2^13, no limit); k_gemm_f16x3, csrc/gcn.hip).  fp32 in, fp32 out in every case.
  * The variable is read ONCE, by the first product of the process: set it before the first call into the library (setting it later is
  * silently ignored; mdf_hw_pipe() tells which pipe is in use).  Non-finite and near-overflow inputs: the bf16x6 split rounds
  * hi = bf16(x) to nearest, so |x| > 0x1.fe fp127 (the top 2^-9 of the fp32 range) rounds hi to inf and x - hi to NaN, and an inf operand

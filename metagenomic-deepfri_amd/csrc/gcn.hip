@@ -27,13 +27,22 @@
 
 #include "common.h"
 
+// F16x3 (MDFRI_HW_PIPE=f16x3): the power of two that brings the largest magnitude of a weight matrix to (2^13, 2^14]
+static inline float f16x3_weight_scale(const float *w, size_t n)
+{
+    float wmax = 0.0f;
+    for (size_t i = 0; i < n; ++i) wmax = std::max(wmax, std::fabs(w[i]));
+    return (wmax > 0.0f && std::isfinite(wmax)) ? std::ldexp(1.0f, 14 - (int)std::ceil(std::log2(wmax))) : 1.0f;
+}
+
 struct mdf_model {
     int device = 0;
     int embed = 0, n_gc = 0, gc[3] = {0, 0, 0}, fc = 0, T = 0, feat = 0;
     int n_out_pad = 0;            // 2T rounded up to the GEMM's BN
     float *T1 = nullptr;          // (32, gc0)      relu(W_aa) @ W_gc1, letters padded 26 -> 32 (zero rows); computed in double on the host
     float *Wt[3] = {nullptr, nullptr, nullptr};  // k>=1: (gc_k, gc_{k-1}) = W_gc{k+1}^T  ([N][K], K contiguous)
-    float Wt_scale[3] = {0.0f, 0.0f, 0.0f};      // k>=1: the power of two that brings max |W_gc{k+1}| to [2^13, 2^14) (operand scale of the F16x3 pipe)
+    float Wt_scale[3] = {0.0f, 0.0f, 0.0f};      // k>=1: the power of two that brings max |W_gc{k+1}| to (2^13, 2^14] (operand scale of the F16x3 pipe)
+    float Wlm_scale = 0.0f, Wgc1_scale = 0.0f;   // the same for W_lm^T and W_gc1^T (language-model branch)
     float *Wfc_t = nullptr;       // (fc, feat)
     float *bfc = nullptr;         // (fc)
     float *Wout_t = nullptr;      // (n_out_pad, fc), rows >= 2T zero
@@ -668,9 +677,11 @@ __device__ __forceinline__ void split_stage(SplitQuad &q, const SplitRaw &r, Spl
 // It stays opt-in because of what it needs and what it gives up: fp16's exponent range wants a scale per operand -- the weights' is exact
 // (2^14 / max |w| rounded down to a power of two, at model load), the activations' is the CONSTANT 2^3 (a data-dependent one would make a
 // protein's bits depend on its batch): |a| >= 2^-5 keeps the full 22 bits, smaller values lose bits at an absolute error below 2^-28, and an
-// activation beyond 8 190 becomes inf -> NaN scores (never silently wrong).  Split per quad of operands: 4 v_mul + 2 v_cvt_pk_f16_f32 +
+// activation beyond 8 190 becomes inf -> NaN scores (never silently wrong).  The language-model branch's products (LSTM time steps, LM embedding)
+// take the LSTM's hidden state as A: |h| < 1, scale 2^13, no limit; under this pipe the one-launch LSTM form is off (it computes BF16x6).  Split per quad of operands: 4 v_mul + 2 v_cvt_pk_f16_f32 +
 // 4 v_fma_mix_f32 (x s - float(hi): conversion and subtraction in ONE instruction) + 2 v_cvt_pk_f16_f32 = 12 vector instructions (BF16x6: 22).
-constexpr float F16X3_SCALE_A = 8.0f;
+constexpr float F16X3_SCALE_A = 8.0f;         // GraphConv activations (unbounded in principle: the documented range limit)
+constexpr float F16X3_SCALE_UNIT = 8192.0f;   // operands known to lie in (-1, 1): the LSTM's hidden state (time steps, LM embedding) -- no limit to document
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // operand of v_mfma_f32_32x32x16_f16 (the bf16 instruction's layout)
 struct SplitPlanes2 {
     u32x4 h, l;   // 8 fp16 each
@@ -740,7 +751,7 @@ template <int EPI>
 __global__ __launch_bounds__(256) void k_gemm_f16x3_small(const float *__restrict__ A, int lda, const float *__restrict__ Bt, int ldb, int M,
                                                            int N, int K, float *__restrict__ C, int ldc, float *__restrict__ pool_partial, int ldp, GemmAux aux)
 {
-    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL, "graph-convolution layers");
+    static_assert(EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_EMBED, "graph-convolution layers, the LM embedding");
     const int lane = threadIdx.x & 63;
     const int NT = N >> 5, MT = (M + 31) >> 5;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -807,6 +818,18 @@ __global__ __launch_bounds__(256) void k_gemm_f16x3_small(const float *__restric
     const float inv = 1.0f / (aux.sA * aux.sB);
     const int lcol = lane & 31, lrow = 4 * (lane >> 5);
     const int rbase = mt * 32, col = nt * 32 + lcol;
+    if (EPI == EPI_EMBED) {   // (as k_gemm_bf16x6_small)
+        int lt[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lt[r] = min((int)aux.letters[min(rbase + (r & 3) + 8 * (r >> 2) + lrow, M - 1)], 31) * N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2) + lrow;
+            const float d = acc[r] * inv;
+            if (row < M) C[(size_t)row * ldc + col] = fmaxf((__builtin_fabsf(d) < __builtin_inff() ? d : __builtin_nanf("")) + aux.table[lt[r] + col], aux.floor);
+        }
+        return;
+    }
     float s0 = 0.0f, s1 = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1991,6 +2014,9 @@ static int set_gemm_attr_once()
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_bf16x6<EPI_BIAS_SOFTMAX2>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16x3<EPI_ELU_POOL_STORE>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16x3<EPI_ELU_POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16x3<EPI_LSTM_TAB>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16x3<EPI_LSTM_BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
+    MDF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gemm_f16x3<EPI_EMBED>), hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES));
     done = true;
     return MDF_OK;
 }
@@ -2028,7 +2054,8 @@ static HwPipe hw_pipe()
     }();
     return pipe;
 }
-// (under f16x3 only the GraphConv layers' H.W products change pipe: GO heads, LSTM steps, LM embedding and the K = 32 / 1 024 layer-1 products stay BF16x6)
+// (under f16x3 the products whose caller hands over the weights' scale change pipe -- the GraphConv layers incl. the unfolded K = 1 024 layer 1, the LSTM time
+// steps and the LM embedding, whose A operand lies in (-1, 1) --; the GO heads, whose input grows with the protein's length, stay BF16x6)
 static bool hw_pipe_bf16x6() { return hw_pipe() != PIPE_F32; }
 
 // persistent grid: one 512-thread workgroup per CU (LDS: 128 KiB), a multiple of 8 so that block b stays on XCD b%8
@@ -2076,14 +2103,16 @@ static int launch_gemm(const float *A, int lda, const float *Bt, int ldb, int M,
         if (hw_pipe_bf16x6()) {
             GemmAux ax = aux;
             if constexpr (EPI == EPI_BIAS_SOFTMAX2) ax.logits = logits, ax.n_real = n_real;
-            if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL) {
-                if (hw_pipe() == PIPE_F16X3 && ax.sB > 0.0f) {   // a GraphConv layer whose caller handed over the weights' scale: three fp16 term products
-                    ax.sA = F16X3_SCALE_A;
-                    if (MT * NT * 8 < 3 * gemm_resident_blocks()) {
-                        const int tiles = ((M + 31) / 32) * (N / 32);
-                        hipLaunchKernelGGL(k_gemm_f16x3_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, pool_partial, ldp, ax);
+            if constexpr (EPI == EPI_ELU_POOL_STORE || EPI == EPI_ELU_POOL || EPI == EPI_LSTM_TAB || EPI == EPI_LSTM_BIAS || EPI == EPI_EMBED) {
+                if (hw_pipe() == PIPE_F16X3 && ax.sB > 0.0f) {   // a product whose caller handed over the weights' scale: three fp16 term products
+                    if (!(ax.sA > 0.0f)) ax.sA = F16X3_SCALE_A;
+                    if (!plain && MT * NT * 8 < 3 * gemm_resident_blocks()) {
+                        if constexpr (EPI != EPI_LSTM_TAB && EPI != EPI_LSTM_BIAS) {
+                            const int tiles = ((M + 31) / 32) * (N / 32);
+                            hipLaunchKernelGGL(k_gemm_f16x3_small<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, A, lda, Bt, ldb, M, N, K, C, ldc, pool_partial, ldp, ax);
+                        }
                     } else {
-                        const int total = 8 * NT * ((MT + 7) / 8);
+                        const int total = plain ? MT * NT : 8 * NT * ((MT + 7) / 8);
                         hipLaunchKernelGGL((k_gemm_f16x3<EPI>), dim3(std::min(total, gemm_resident_blocks())), dim3(GEMM_THREADS), GEMM_LDS_BYTES, st, A, lda, Bt,
                                            ldb, M, N, K, C, ldc, bias, pool_partial, ldp, total, ax);
                     }
@@ -2280,6 +2309,7 @@ struct mdf_lm {
     float *U1t = nullptr;     // (4H, H)   recurrent kernel of LSTM1, transposed, gate columns permuted (lstm_col_of)
     float *tab1 = nullptr;    // (32, 4H)  W1[a] + b1 per letter (rows 26..31 zero), permuted
     float *W2U2t = nullptr;   // (4H, 2H)  [W2 ; U2]^T of LSTM2, permuted
+    float U1_scale = 0.0f, W2U2_scale = 0.0f;   // F16x3: the powers of two that bring their largest magnitudes to (2^13, 2^14]
     float *b2p = nullptr;     // (4H)      b2, permuted
     // LSTM2 runs on its own stream, one step behind LSTM1 (see mdf_lm_forward_dev)
     hipStream_t s2 = nullptr;
@@ -2397,9 +2427,7 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
     for (int k = 1; k < w->n_gc && rc == MDF_OK; ++k) {
         auto t = transpose(w->W_gc[k], w->gc_dims[k - 1], w->gc_dims[k], w->gc_dims[k]);
         rc = upload(&m->Wt[k], t.data(), t.size());
-        float wmax = 0.0f;
-        for (float x : t) wmax = std::max(wmax, std::fabs(x));
-        m->Wt_scale[k] = (wmax > 0.0f && std::isfinite(wmax)) ? std::ldexp(1.0f, 14 - (int)std::ceil(std::log2(wmax))) : 1.0f;
+        m->Wt_scale[k] = f16x3_weight_scale(t.data(), t.size());
     }
     if (rc == MDF_OK) {
         auto t = transpose(w->W_fc, feat, w->fc_dim, w->fc_dim);
@@ -2421,6 +2449,7 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
         m->lm_dim = Hl;
         auto t = transpose(w->W_lm, Hl, E, E);
         rc = upload(&m->Wlm_t, t.data(), t.size());
+        m->Wlm_scale = f16x3_weight_scale(t.data(), t.size());
         if (rc == MDF_OK) {
             std::vector<float> t0((size_t)32 * E, 0.0f);
             for (int a = 0; a < 26; ++a)
@@ -2430,6 +2459,7 @@ int mdf_model_create(const mdf_gcn_weights *w, int device, mdf_model **out)
         if (rc == MDF_OK) {
             auto g = transpose(w->W_gc[0], E, C0, C0);
             rc = upload(&m->Wgc1_t, g.data(), g.size());
+            m->Wgc1_scale = f16x3_weight_scale(g.data(), g.size());
         }
     }
     if (rc != MDF_OK) {
@@ -2492,6 +2522,8 @@ int mdf_lm_create(const mdf_lm_weights *w, int device, mdf_lm **out)
         for (int a = 0; a < 26; ++a) tab[(size_t)a * G + p] = w->W1[(size_t)a * G + kc] + w->b1[kc];
         b2p[p] = w->b2[kc];
     }
+    lm->U1_scale = f16x3_weight_scale(u1t.data(), u1t.size());
+    lm->W2U2_scale = f16x3_weight_scale(w2u2t.data(), w2u2t.size());
     int rc = upload(&lm->U1t, u1t.data(), u1t.size());
     if (rc == MDF_OK) rc = upload(&lm->tab1, tab.data(), tab.size());
     if (rc == MDF_OK) rc = upload(&lm->W2U2t, w2u2t.data(), w2u2t.size());
@@ -2577,7 +2609,8 @@ int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_r
     // small groups: the whole recurrence in one persistent launch (k_lstm_persistent)
     {
         const char *e = getenv("MDFRI_LM_PERSISTENT_MAX_B");   // developer knob: 0 forces the GEMM form
-        const int max_b = e ? std::min(atoi(e), LSTM_P_MAX_B) : LSTM_P_DEFAULT_B;
+        // (under MDFRI_HW_PIPE=f16x3 the time steps run as F16x3 products: the one-launch form, BF16x6 arithmetic, would make a protein's bits depend on its group's size)
+        const int max_b = hw_pipe() == PIPE_F16X3 ? 0 : e ? std::min(atoi(e), LSTM_P_MAX_B) : LSTM_P_DEFAULT_B;
         bool fits = B <= max_b && (H == 64 || H == 128 || H == 256 || H == 512 || H == 1024);
         const void *fn = nullptr;
         if (fits) {
@@ -2644,6 +2677,7 @@ int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_r
             a1.table = lm->tab1;
             a1.letters = let_tm + (size_t)t * B;
             a1.cstate = c1;
+            a1.sA = F16X3_SCALE_UNIT, a1.sB = lm->U1_scale;   // (F16x3 only) |h| < 1
             if (int rc = launch_gemm<EPI_LSTM_TAB>(h1 + t * blk, H, lm->U1t, H, active, 4 * H, H, h1 + (t + 1) * blk, H, nullptr, nullptr,
                                                    0, nullptr, 0, st, a1))
                 return rc;
@@ -2656,6 +2690,7 @@ int mdf_lm_forward_dev(mdf_lm *lm, const uint8_t *seq_idx, const int64_t *prot_r
             a2.A2 = h2 + t * blk;
             a2.ksplit = H / BK;
             a2.cstate = c2;
+            a2.sA = F16X3_SCALE_UNIT, a2.sB = lm->W2U2_scale;
             if (int rc = launch_gemm<EPI_LSTM_BIAS>(h1 + (t + 1) * blk, H, lm->W2U2t, 2 * H, active, 4 * H, 2 * H, h2 + (t + 1) * blk, H,
                                                     lm->b2p, nullptr, 0, nullptr, 0, s2, a2))
                 return rc;
@@ -2698,6 +2733,7 @@ int mdf_gcn_embed_lm_agg_dev(mdf_model *m, const uint8_t *seq_idx, const float *
         a.table = m->T0;
         a.letters = seq_idx;
         a.floor = m->embed_linear ? -3.402823466e38f : 0.0f;
+        a.sA = F16X3_SCALE_UNIT, a.sB = m->Wlm_scale;   // (F16x3 only) the LSTM's hidden state: |h| < 1
         if (int rc = launch_gemm<EPI_EMBED>(lm_h, m->lm_dim, m->Wlm_t, m->lm_dim, Ri, E, m->lm_dim, X0, E, nullptr, nullptr, 0, nullptr, E, st, a))
             return rc;
     }
@@ -2705,10 +2741,12 @@ int mdf_gcn_embed_lm_agg_dev(mdf_model *m, const uint8_t *seq_idx, const float *
     {
         ScopedTiming tm(TK_GEMM, st);
         int rc;
+        GemmAux ax;
+        ax.sB = m->Wgc1_scale;   // (F16x3 only; the activations' constant scale as for the upper layers)
         if (m->n_gc == 1)
-            rc = launch_gemm<EPI_ELU_POOL>(AX, E, m->Wgc1_t, E, Ri, C0, E, nullptr, C0, nullptr, partial, feat, nullptr, C0, st);
+            rc = launch_gemm<EPI_ELU_POOL>(AX, E, m->Wgc1_t, E, Ri, C0, E, nullptr, C0, nullptr, partial, feat, nullptr, C0, st, ax);
         else
-            rc = launch_gemm<EPI_ELU_POOL_STORE>(AX, E, m->Wgc1_t, E, Ri, C0, E, Ha, C0, nullptr, partial, feat, nullptr, C0, st);
+            rc = launch_gemm<EPI_ELU_POOL_STORE>(AX, E, m->Wgc1_t, E, Ri, C0, E, Ha, C0, nullptr, partial, feat, nullptr, C0, st, ax);
         if (rc) return rc;
     }
     return gcn_upper_layers(m, Ha, Hb, AH, rowptr, colidx, val, Ri, partial, st, agg);
