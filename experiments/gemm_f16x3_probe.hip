@@ -93,6 +93,9 @@ int main(int argc, char **argv)
     ship(); if (error("k_gemm_bf16x6 (shipped)")) return 1;
     f16(sA, sB); if (error("F16x3, operands scaled to 2^14")) return 1;
     f16(8.0f, sB); if (error("F16x3, the library's scales (A: 2^3, B: from its maximum)")) return 1;
+    f16(1.0f, sB); if (error("F16x3, A unscaled (2^0), B from its maximum")) return 1;
+    f16(0.25f, sB); if (error("F16x3, A scaled by 2^-2, B from its maximum")) return 1;
+    f16(0.03125f, sB); if (error("F16x3, A scaled by 2^-5, B from its maximum")) return 1;
     f16(1.0f, 1.0f); if (error("F16x3, no scales")) return 1;
     f16(sA / 1024.0f, sB / 1024.0f); if (error("F16x3, scales 2^10 too small (lo terms subnormal)")) return 1;
     // timing: alternate blocks of launches, three rounds (the board settles into its power state within a few hundred launches)
