@@ -43,6 +43,28 @@ def test_bare_python_launches_two_ranks_weak():
     assert line["verify"]["max_abs_err_vs_oracle"] < 1e-4
 
 
+def test_the_drivers_own_launch_line_under_torch_distributed_run():
+    """The contract's N > 1 command, word for word: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the launcher, bench.py
+    must not start ranks of its own, rank 0 alone prints the line.  Two ranks; the test box has one GPU, so both are pinned to it and gloo
+    carries the gather (`--force-device 0 --backend gloo`: RCCL refuses two ranks on one device)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--proteins", "200", "--cpu-seconds", "0", "--no-extras",
+                        "--force-device", "0", "--backend", "gloo"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak" and line["config"]["proteins_total"] == 400
+    assert line["ranks"]["world_size"] == 2 and len(line["ranks"]["per_rank_ms_per_step"]["step_ms"]) == 2
+    assert line["verify"]["max_abs_err_vs_oracle"] < 1e-4
+
+
 @pytest.mark.parametrize("workload,count", [("configs3", 600), ("configs4", 900)])
 def test_bare_python_launches_two_ranks_strong_filtered(workload, count):
     line = _run("--gpus", "2", "--backend", "gloo", "--force-device", "0", "--workload", workload, "--proteins", str(count), "--steps", "1",
