@@ -205,7 +205,7 @@ __device__ __forceinline__ float fsub_rn(float a, float b)
     return r;
 #endif
 }
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b)
+__device__ __forceinline__ unsigned probe_cvt_pk_bf16(float a, float b)
 {
 #ifdef PROBE_ASM_CVT   // the conversion as asm instead: no <2 x float> in the IR, so the SLP vectorizer has no seed to pack the subtractions from
     unsigned r;
@@ -222,13 +222,13 @@ __device__ __forceinline__ void split_pair_s(const SplitRaw &r, const int i, Spl
 {
     const float x0 = i == 0 ? r.u.x : i == 1 ? r.u.z : i == 2 ? r.v.x : r.v.z;
     const float x1 = i == 0 ? r.u.y : i == 1 ? r.u.w : i == 2 ? r.v.y : r.v.w;
-    const unsigned hp = cvt_pk_bf16(x0, x1);
+    const unsigned hp = probe_cvt_pk_bf16(x0, x1);
     const float a0 = fsub_rn(x0, __uint_as_float(hp << 16)), a1 = fsub_rn(x1, __uint_as_float(hp & 0xffff0000u));
-    const unsigned mp = cvt_pk_bf16(a0, a1);
+    const unsigned mp = probe_cvt_pk_bf16(a0, a1);
     const float b0 = fsub_rn(a0, __uint_as_float(mp << 16)), b1 = fsub_rn(a1, __uint_as_float(mp & 0xffff0000u));
     o.h[i] = hp;
     o.m[i] = mp;
-    o.l[i] = cvt_pk_bf16(b0, b1);
+    o.l[i] = probe_cvt_pk_bf16(b0, b1);
 }
 // two operand pairs (4 consecutive k) split in lock step: 22 instructions in four stages of 6 / 6 / 4 / 6, none depending on its predecessor
 struct Quad {
@@ -242,12 +242,12 @@ __device__ __forceinline__ void qstage(Quad &q, const SplitRaw &r, SplitPlanes &
     if constexpr (st == 0) {
         const float4 s = quad ? r.v : r.u;
         q.x0 = s.x, q.x1 = s.y, q.x2 = s.z, q.x3 = s.w;
-        q.ha = cvt_pk_bf16(q.x0, q.x1), q.hb = cvt_pk_bf16(q.x2, q.x3);
+        q.ha = probe_cvt_pk_bf16(q.x0, q.x1), q.hb = probe_cvt_pk_bf16(q.x2, q.x3);
         q.t0 = __uint_as_float(q.ha << 16), q.t2 = __uint_as_float(q.hb << 16);
         q.t1 = __uint_as_float(q.ha & 0xffff0000u), q.t3 = __uint_as_float(q.hb & 0xffff0000u);
     } else if constexpr (st == 1) {
         q.x0 = fsub_rn(q.x0, q.t0), q.x2 = fsub_rn(q.x2, q.t2), q.x1 = fsub_rn(q.x1, q.t1), q.x3 = fsub_rn(q.x3, q.t3);
-        q.ma = cvt_pk_bf16(q.x0, q.x1), q.mb = cvt_pk_bf16(q.x2, q.x3);
+        q.ma = probe_cvt_pk_bf16(q.x0, q.x1), q.mb = probe_cvt_pk_bf16(q.x2, q.x3);
     } else if constexpr (st == 2) {
         q.t0 = __uint_as_float(q.ma << 16), q.t2 = __uint_as_float(q.mb << 16);
         q.t1 = __uint_as_float(q.ma & 0xffff0000u), q.t3 = __uint_as_float(q.mb & 0xffff0000u);
@@ -255,7 +255,7 @@ __device__ __forceinline__ void qstage(Quad &q, const SplitRaw &r, SplitPlanes &
         q.x0 = fsub_rn(q.x0, q.t0), q.x2 = fsub_rn(q.x2, q.t2), q.x1 = fsub_rn(q.x1, q.t1), q.x3 = fsub_rn(q.x3, q.t3);
         o.h[2 * quad] = q.ha, o.h[2 * quad + 1] = q.hb;
         o.m[2 * quad] = q.ma, o.m[2 * quad + 1] = q.mb;
-        o.l[2 * quad] = cvt_pk_bf16(q.x0, q.x1), o.l[2 * quad + 1] = cvt_pk_bf16(q.x2, q.x3);
+        o.l[2 * quad] = probe_cvt_pk_bf16(q.x0, q.x1), o.l[2 * quad + 1] = probe_cvt_pk_bf16(q.x2, q.x3);
     }
 }
 
@@ -479,11 +479,11 @@ __global__ void k_split_planes(const float *__restrict__ X, int rows, int K, uns
     const float *x = X + (size_t)r * K + b * 16;
     unsigned short *o = out + ((size_t)r * (K / 32) + (b >> 1)) * 96 + (b & 1) * 48;
     for (int k = 0; k < 16; k += 2) {
-        const unsigned hp = cvt_pk_bf16(x[k], x[k + 1]);
+        const unsigned hp = probe_cvt_pk_bf16(x[k], x[k + 1]);
         const float a0 = fsub_rn(x[k], __uint_as_float(hp << 16)), a1 = fsub_rn(x[k + 1], __uint_as_float(hp & 0xffff0000u));
-        const unsigned mp = cvt_pk_bf16(a0, a1);
+        const unsigned mp = probe_cvt_pk_bf16(a0, a1);
         const float b0 = fsub_rn(a0, __uint_as_float(mp << 16)), b1 = fsub_rn(a1, __uint_as_float(mp & 0xffff0000u));
-        const unsigned lp = cvt_pk_bf16(b0, b1);
+        const unsigned lp = probe_cvt_pk_bf16(b0, b1);
         o[k] = (unsigned short)hp, o[k + 1] = (unsigned short)(hp >> 16);
         o[16 + k] = (unsigned short)mp, o[16 + k + 1] = (unsigned short)(mp >> 16);
         o[32 + k] = (unsigned short)lp, o[32 + k + 1] = (unsigned short)(lp >> 16);
