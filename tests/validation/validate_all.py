@@ -102,6 +102,17 @@ def main():
     print(f"onnxruntime: {'used' if have_ort else 'not importable here (graph referee = tests/onnx_numpy_runtime.py)'}")
     print(f"aligner (PyOpal / VTML80): rc={opal_rc}: {opal}")
     print(f"goldens: {golden}")
+    # The same files once more under the opt-in pipe (include/mdfri.h: MDFRI_HW_PIPE=f16x3 -- its activation scale is a constant, DESIGN.md section 4:
+    # this run tells whether the released weights stay inside its range).  A child process (the pipe is read once per process), goldens into a
+    # scratch directory, no aligner check; informational: its verdicts are printed, the exit code is the default pipe's.
+    if os.environ.get("MDFRI_HW_PIPE", "") == "" and os.environ.get("MDFRI_VALIDATE_CHILD") is None:
+        env = dict(os.environ, MDFRI_HW_PIPE="f16x3", MDFRI_VALIDATE_CHILD="1")
+        cmd = [sys.executable, os.path.abspath(__file__)] + (["--self-test"] if args.self_test else [args.model_dir]) + \
+              ["--no-opal", "--golden-dir", tempfile.mkdtemp(prefix="mdfri_validate_f16x3_"), "--length", str(length)]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True)
+        table = r.stdout.split("=" * 118)[-1].strip() if "=" * 118 in r.stdout else (r.stdout.strip()[-600:] or r.stderr.strip()[-600:])
+        print("\n--- the same files under MDFRI_HW_PIPE=f16x3 (opt-in pipe; informational, rc=%d) ---" % r.returncode)
+        print(table)
     return max(worst, 1 if opal_rc == 1 else 0)
 
 

@@ -9,6 +9,8 @@
 # pairwise max |delta| against 1e-4, and writes tests/golden/release_<kind>_<mode>.npz -- from then on tests/test_gpu_validation.py
 # pins the GPU suite to the released file.  Then validate_opal.py names the aligner's tie rule (PyOpal + VTML80) or skips cleanly.
 # The last lines are a table: file, kind, which embedding variant the graph turned out to be, verdict; and the detected TIE_RULE.
+# Then the same files once more in a child process under MDFRI_HW_PIPE=f16x3 (the opt-in pipe: does the released model stay inside its activation
+# range?) -- printed, informational, the exit code is the default pipe's.
 # Exit 0 = every file PASSed (and the aligner check passed or was skipped), 1 = a mismatch, 2 = nothing could be decided.
 # Test infrastructure (it uses oracle/ as the checker); nothing here is imported by the product.
 set -u
