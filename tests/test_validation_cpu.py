@@ -85,8 +85,11 @@ def test_validate_all_one_command_self_test(tmp_path):
     (PyOpal absent: skipped cleanly).  Every file PASSes, the table names the embedding variant, goldens are written per (kind, mode)."""
     r = subprocess.run(["bash", os.path.join(KIT, "validate_all.sh"), "--self-test", "--golden-dir", str(tmp_path)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    table = [ln for ln in r.stdout.splitlines() if ln.startswith("selftest-")]
+    main, _, f16x3 = r.stdout.partition("--- the same files under MDFRI_HW_PIPE=f16x3")
+    table = [ln for ln in main.splitlines() if ln.startswith("selftest-")]
     assert len(table) == 8 and all(" PASS " in ln for ln in table), table
+    again = [ln for ln in f16x3.splitlines() if ln.startswith("selftest-")]      # the same files once more in a child under the opt-in pipe (informational)
+    assert len(again) == 8 and all(" PASS " in ln for ln in again), again
     assert sum("embed_relu" in ln for ln in table) == 4 and sum("cnn 4 branches" in ln for ln in table) == 4
     assert "aligner (PyOpal / VTML80): rc=0" in r.stdout
     names = sorted(os.listdir(tmp_path))
