@@ -642,6 +642,7 @@ def main():
         cpu_leg = cpu_baseline(c_seqs[:n_cpu], c_coords[:n_cpu], make_weights(args.lm), args)
         del c_seqs, c_coords
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # (set before the first HIP call: the host driver shares device memory between rank processes by dmabuf only)
     import torch
     import torch.distributed as dist
 
