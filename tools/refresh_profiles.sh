@@ -27,4 +27,10 @@ $T python3 tools/format_rate.py > "$O/r_format_rate.txt" 2>&1                   
 $T python3 tools/small_batch_rate.py > "$O/r_small_batch_rate.json" 2> "$O/small.err"                             # -> profiles/rNN_small_batch_rate.json
 $T python3 bench.py --workload configs3 --cpu-seconds 0 --steps 2 > "$O/r_bench_configs3_n1.json" 2> "$O/c3.err"  # -> profiles/rNN_bench_configs3_n1.json
 timeout 900 python3 bench.py --workload configs4 --cpu-seconds 0 --steps 2 > "$O/r_bench_configs4_n1.json" 2> "$O/c4.err"
+# the headline step once more under the opt-in pipe (kernel trace + one counter pass)                                                  # -> profiles/rNN_f16x3_kernel_stats.txt
+export MDFRI_HW_PIPE=f16x3
+$T rocprofv3 --kernel-trace --stats --output-format csv -d "$O/prof_f16x3" -- python3 bench.py --steps 5 --cpu-seconds 0 --no-extras --no-kernel-timing --no-board > "$O/prof_f16x3.log" 2>&1
+$T rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d "$O/pmc_f16x3" -- python3 bench.py --steps 1 --warmup 0 --proteins 2048 --cpu-seconds 0 --verify 0 --no-kernel-timing --no-extras --no-board > "$O/pmc_f16x3.log" 2>&1
+unset MDFRI_HW_PIPE
+{ python3 tools/rocprof_summary.py "$O/prof_f16x3"; python3 tools/pmc_summary.py "$O/pmc_f16x3"; } > "$O/r_f16x3_kernel_stats.txt"
 ls -la "$O"/r_*
